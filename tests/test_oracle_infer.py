@@ -1,0 +1,96 @@
+"""The CPU oracle against golden vectors produced by the real reference
+(tests/golden/make_golden_infer.py).  CPU only."""
+import numpy as np
+import torch
+
+from conftest import load_npz, sd_from_npz
+from oracle import unet_ref as O
+
+RTOL = 2e-5  # same ATen kernels, but thread count / op order may differ slightly
+
+
+def _close(a, b, tol=RTOL):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(1e-6, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max()) / scale
+    assert err <= tol, err
+
+
+def test_small_net_all_outputs():
+    d = load_npz("infer_small.npz")
+    f_maps, levels, groups = [int(v) for v in d["cfg"]]
+    sd = sd_from_npz(d)
+    x = torch.from_numpy(d["x"])
+    out = O.forward_all(x, sd, f_maps=f_maps, num_levels=levels, num_groups=groups)
+    for i, f in enumerate(out["feat"]):
+        _close(f.numpy(), d["feat%d" % i])
+    keys = [k[4:] for k in d if k.startswith("out/")]
+    assert sorted(keys) == sorted(k for k in out if k != "feat")
+    for k in keys:
+        if k == "label":
+            assert out[k].dtype == torch.int64
+            assert np.array_equal(out[k].numpy(), d["out/label"])
+        else:
+            _close(out[k].numpy(), d["out/" + k])
+
+
+def test_left_hemis_head_set():
+    d = load_npz("infer_hemis.npz")
+    f_maps, levels, groups = [int(v) for v in d["cfg"]]
+    sd = sd_from_npz(d)
+    x = torch.from_numpy(d["x"])
+    out = O.forward_all(x, sd, f_maps=f_maps, num_levels=levels, num_groups=groups, left_hemis_only=True)
+    assert "rp" not in out and out["segmentation"].shape[1] == 18
+    for k in [k[4:] for k in d if k.startswith("out/")]:
+        if k == "label":
+            assert np.array_equal(out[k].numpy(), d["out/label"])
+        else:
+            _close(out[k].numpy(), d["out/" + k])
+
+
+def test_full_width_blocks():
+    d = load_npz("infer_layers.npz")
+    sd = {}
+    for blk, pre in (("enc0", "backbone.encoders.0."), ("enc1", "backbone.encoders.1."), ("dec", "backbone.decoders.0.")):
+        for k, v in d.items():
+            if k.startswith(blk + "/"):
+                sd[pre + k[len(blk) + 1:]] = torch.from_numpy(v)
+    x = torch.from_numpy(d["x"])
+    e0 = O.single_conv(O.single_conv(x, sd, "backbone.encoders.0.basic_module.SingleConv1"), sd,
+                       "backbone.encoders.0.basic_module.SingleConv2")
+    _close(e0.numpy(), d["e0"])
+    p = torch.nn.functional.max_pool3d(e0, 2)
+    e1 = O.single_conv(O.single_conv(p, sd, "backbone.encoders.1.basic_module.SingleConv1"), sd,
+                       "backbone.encoders.1.basic_module.SingleConv2")
+    _close(e1.numpy(), d["e1"])
+    up = torch.nn.functional.interpolate(e1, size=e0.shape[2:], mode="nearest")
+    y = torch.cat((e0, up), 1)
+    y = O.single_conv(O.single_conv(y, sd, "backbone.decoders.0.basic_module.SingleConv1"), sd,
+                      "backbone.decoders.0.basic_module.SingleConv2")
+    _close(y.numpy(), d["y"])
+
+
+def test_tiling_ranges_match_reference():
+    d = load_npz("tiling_ranges.npz")
+    for n in (160, 200, 256):
+        ranges, cnt = O.tiling_ranges((n, n, n), [80] * 3, [160] * 3)
+        assert np.array_equal(np.array(ranges), d["ranges_%d" % n])
+        assert np.array_equal(np.bincount(cnt.astype(np.int64).ravel(), minlength=9), d["cnt_%d_hist" % n])
+        assert np.array_equal(cnt[np.arange(n), np.arange(n), np.arange(n)], d["cnt_%d_diag" % n])
+    assert np.array_equal(np.array(O.axis_intervals(512, 160, 80)), d["ranges_512_x"])
+    # 256 -> (0,160),(160,240),(176,256)
+    assert O.axis_intervals(256, 160, 80) == [(0, 160), (160, 240), (176, 256)]
+
+
+def test_tiled_stitch_toy():
+    d = load_npz("infer_tiled.npz")
+    f_maps, levels, groups, stride, win = [int(v) for v in d["cfg"]]
+    sd = sd_from_npz(d)
+    full = torch.from_numpy(d["full"])
+    out, ranges, cnt = O.tiled_inference(full, sd, [stride] * 3, [win] * 3, f_maps=f_maps, num_levels=levels,
+                                         num_groups=groups)
+    assert np.array_equal(np.array(ranges), d["ranges"])
+    assert np.array_equal(cnt, d["cnt"])
+    for k in [k[9:] for k in d if k.startswith("stitched/")]:
+        _close(out[k].numpy(), d["stitched/" + k], 5e-5)
