@@ -1,0 +1,176 @@
+"""Benchmark of the north-star path: whole-volume multi-task tiled inference on a 256^3 volume.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 256] [--passes 3]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one synthetic 256^3 volume (27 overlapping tiles, win 160 /
+stride 80, all 9 task heads, fused tail, on-device stitching), input resident in HBM.  N>1 shards the
+tiles over ranks (weak scaling: every rank also runs its own volume? no -- see "scaling" below) and
+gathers the masked tile outputs to rank 0 over RCCL.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def make_volume(n, device):
+    """rand inside a centred ellipsoid (semi-axes 100,110,90 scaled), exact 0 outside."""
+    g = torch.Generator().manual_seed(0)
+    s = n / 256.0
+    ax = torch.arange(n, dtype=torch.float32) - (n - 1) / 2.0
+    zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
+    ell = ((zz / (100 * s)) ** 2 + (yy / (110 * s)) ** 2 + (xx / (90 * s)) ** 2) <= 1
+    v = torch.rand((n, n, n), generator=g) * ell
+    return v[None, None].to(device)
+
+
+def conv_flops_tile(dims, fm=(64, 128, 256, 512, 1024, 2048)):
+    """Algorithmic FLOPs (2*MACs) of all 3x3x3 convs + heads for one tile (SURVEY 8d formula)."""
+    d = list(dims)
+    total, sizes = 0.0, []
+    for i, co in enumerate(fm):
+        if i > 0:
+            d = [v // 2 for v in d]
+        ci = 1 if i == 0 else fm[i - 1]
+        c1 = max(co // 2, ci)
+        nv = d[0] * d[1] * d[2]
+        total += 2.0 * 27 * nv * (ci * c1 + c1 * co)
+        sizes.append(list(d))
+    rev = list(reversed(fm))
+    rs = list(reversed(sizes))
+    for i in range(len(rev) - 1):
+        nv = rs[i + 1][0] * rs[i + 1][1] * rs[i + 1][2]
+        total += 2.0 * 27 * nv * ((rev[i] + rev[i + 1]) * rev[i + 1] + rev[i + 1] * rev[i + 1])
+    nv = dims[0] * dims[1] * dims[2]
+    total += 2.0 * nv * 64 * 69
+    return total
+
+
+def cpu_baseline(state_dict, full, n):
+    """The CPU oracle (a port of the reference's PyTorch-CPU path) timed on this host, rank 0 only,
+    on a bounded sample: the first 80^3 tile of the reference tiling (all heads)."""
+    from oracle import unet_ref as O
+    cores = torch.get_num_threads()
+    s = 80 if n >= 160 else max(16, n // 2)
+    tile = full[:, :, n // 2 - s // 2:n // 2 + s // 2, n // 2 - s // 2:n // 2 + s // 2,
+                n // 2 - s // 2:n // 2 + s // 2].cpu().contiguous()
+    sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+    t0 = time.time()
+    with torch.no_grad():
+        O.forward_all(tile, sd, f_maps=64, num_levels=6)
+    dt = time.time() - t0
+    return {"value": tile.numel() / dt, "unit": "voxels/s", "cores": cores, "kind": "port",
+            "sample": "one central %d^3 tile of the volume, all 9 heads, oracle/unet_ref.py (torch-CPU fp32), "
+                      "1 run, %.1f s" % (s, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--passes", type=int, default=3, help="3 = fp32-grade split-f16 MFMA (parity mode), 1 = fast")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    from brainfm_amd import test_utils as TU
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.size
+    torch.manual_seed(1)                                   # default nn init under seed 1
+    ga, ta = TU.default_inference_args(f_maps=64, num_levels=6)
+    sess = TU.InferenceSession(ga, ta, dev, passes=args.passes)
+    full = make_volume(n, dev)
+    stride, win = [80] * 3, [160] * 3
+    ranges = TU.tiling_ranges((n, n, n), stride, win)
+    eng = sess.engine
+
+    def step():
+        if world > 1:
+            return TU.tiled_inference_distributed(full, sess, stride, win)
+        return TU.tiled_inference(full, sess, stride, win)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.prof = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = eng.prof
+    eng.prof = None
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # dominant kernel: conv_mfma.  HIP events were recorded around every launch inside the timed region,
+    # on the stream the kernels run on.
+    k_ms = sum(a.elapsed_time(b) for a, b, _, _ in prof)
+    k_fl = sum(f for _, _, f, _ in prof)
+    k_by = sum(b for _, _, _, b in prof)
+    agg = torch.tensor([k_ms, k_fl, k_by, float(len(prof))], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(agg)
+    k_ms, k_fl, k_by, k_n = [float(v) for v in agg.tolist()]
+    achieved = k_fl / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    peak = 2500.0                                            # dense f16 MFMA, MI355X_MICROARCH.md
+    if rank == 0:
+        tile_vox = sum(TU.tile_cost(r) for r in ranges)
+        flops_step = sum(conv_flops_tile([r[a][1] - r[a][0] for a in range(3)]) for r in ranges)
+        line = {
+            "metric": "voxels/sec whole-volume multi-task inference, 256^3 tiled",
+            "value": n ** 3 * args.steps / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "f16x3-split (fp32-grade)" if args.passes == 3 else "f16", "data": "synthetic",
+            "config": {"workload": "%d^3 volume, reference tiling win160/stride80 -> %d tiles, UNet3D f64 x6 levels, "
+                                   "9 heads (69 ch), fused tail + on-device stitch" % (n, len(ranges)),
+                       "tile_voxels_per_step": tile_vox, "tile_voxels_per_s": tile_vox * args.steps / dt,
+                       "algorithmic_tflop_per_step": flops_step / 1e12,
+                       "end_to_end_tflops": flops_step * args.steps / dt / 1e12, "mfma_passes": args.passes,
+                       "parallelism": "tiles sharded over %d rank(s), gather to rank 0" % world},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma<*,*,%d> (all %d launches of the timed region)"
+                                                    % (args.passes, int(k_n)),
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "kernel_ms_per_step": k_ms / args.steps / max(world, 1), "traffic": None,
+                         "algorithmic_bytes_per_step": k_by / args.steps,
+                         "note": "achieved = algorithmic conv FLOPs / HIP-event time of the launches; the kernel "
+                                 "issues %dx that in f16 MFMA FLOPs" % args.passes},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            sd = {k: v for k, v in sess.model.state_dict().items()}
+            line["cpu_baseline"] = cpu_baseline(sd, full, n)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

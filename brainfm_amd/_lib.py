@@ -1,0 +1,117 @@
+"""ctypes binding of libbrainfm_hip.so (the C ABI in include/brainfm_hip.h).
+
+There is no fallback: if the shared library is missing or a call is rejected,
+this module raises.  Build with ``python -m brainfm_amd.build``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbrainfm_hip.so")
+
+ERR = {0: "BFM_OK", -1: "BFM_E_ARG", -2: "BFM_E_SHAPE", -3: "BFM_E_WORKSPACE", -4: "BFM_E_LAUNCH"}
+
+ROLE_PLAIN, ROLE_CT, ROLE_BIAS_LOG, ROLE_SEG, ROLE_DIST, ROLE_SR, ROLE_PATHOL = range(7)
+(EW_EXP, EW_AFFINE, EW_CLAMP, EW_CLAMP_MIN, EW_GAMMA, EW_SIGMOID, EW_DIV, EW_NONZERO, EW_SUB_DIV) = range(9)
+(EW_ADD, EW_MUL, EW_MUL_EXP, EW_AXPY_CLAMP0, EW_AXPY, EW_DIV2) = range(6)
+
+
+class BfmError(RuntimeError):
+    pass
+
+
+class Upsample(C.Structure):
+    _fields_ = [("d", C.c_int), ("h", C.c_int), ("w", C.c_int),
+                ("mapD", C.c_void_p), ("mapH", C.c_void_p), ("mapW", C.c_void_p),
+                ("repD", C.c_void_p), ("repH", C.c_void_p), ("repW", C.c_void_p)]
+
+
+class TailDesc(C.Structure):
+    _fields_ = [("n_out", C.c_int), ("c_feat", C.c_int),
+                ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("roles", C.c_void_p), ("out_slot", C.c_void_p),
+                ("seg_first", C.c_int), ("n_seg", C.c_int), ("seg_lut", C.c_void_p),
+                ("n_dist", C.c_int), ("dist_first", C.c_int), ("max_dist", C.c_float),
+                ("unit_feat", C.c_int), ("slot_high_res", C.c_int), ("slot_fake_cortical", C.c_int)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_L = C.c_int64
+_Z = C.c_size_t
+_UP = C.POINTER(Upsample)
+
+# name -> (restype, argtypes); every symbol declared in include/brainfm_hip.h
+SIGNATURES = {
+    "bfm_version": (C.c_char_p, []),
+    "bfm_gn_stats_workspace": (_Z, [_I, _I, _I, _I, _I, _UP]),
+    "bfm_gn_stats": (_I, [_P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _I, _F, _P, _P, _P, _P, _Z, _P]),
+    "bfm_pack_conv_weights_direct_bytes": (_Z, [_I, _I]),
+    "bfm_pack_conv_weights_direct": (_I, [_P, _I, _I, _P, _P]),
+    "bfm_pack_conv_weights_mfma_bytes": (_Z, [_I, _I]),
+    "bfm_pack_conv_weights_mfma": (_I, [_P, _I, _I, _F, _P, C.POINTER(_I), _P]),
+    "bfm_conv3x3x3_direct": (_I, [_P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _P, _I, _F, _P, _P]),
+    "bfm_conv3x3x3_mfma_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "bfm_conv3x3x3_mfma_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),
+    "bfm_conv3x3x3_mfma": (_I, [_P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _P, _I, _P, _I, _I, _F, _I,
+                                C.POINTER(_I), _P, _P, _Z, _P]),
+    "bfm_maxpool2": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "bfm_tail_heads": (_I, [_P, _P, _L, C.POINTER(TailDesc), _P, _P, _P, _P, _P, _P]),
+    "bfm_ew_unary": (_I, [_I, _P, _L, _P, _L, _L, _F, _F, _P]),
+    "bfm_ew_binary": (_I, [_I, _P, _L, _P, _L, _P, _L, _L, _F, _P]),
+    "bfm_softmax_cl": (_I, [_P, _L, _I, _P, _L, _L, _P]),
+    "bfm_argmax_lut_cl": (_I, [_P, _L, _I, _P, _P, _L, _P]),
+    "bfm_fake_cortical": (_I, [_P, _L, _I, _P, _L, _P]),
+    "bfm_stitch_accumulate": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "bfm_mask_tile": (_I, [_P, _P, _P, _L, _P, _P]),
+    "bfm_tile_count_add": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "bfm_divide_by_count": (_I, [_P, _P, _L, _P]),
+}
+
+_lib = None
+
+
+def register(sigs):
+    """Let sibling modules (synthesis kernels) add their symbols before load()."""
+    SIGNATURES.update(sigs)
+    if _lib is not None:
+        _bind(_lib, sigs)
+
+
+def _bind(lib, sigs):
+    for name, (res, args) in sigs.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise BfmError("libbrainfm_hip.so does not export %s -- rebuild it" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BfmError("HIP extension missing: %s (run `python -m brainfm_amd.build`); "
+                           "there is no CPU fallback in the product path" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        _bind(lib, SIGNATURES)
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise BfmError("%s failed: %s (%d)" % (what, ERR.get(rc, "?"), rc))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,508 @@
+// 3x3x3 convolution as an implicit GEMM on CDNA4 matrix cores (gfx950).
+//
+//   out[v][co] = LeakyReLU( sum_{tap,ci} (x[v+tap][ci]*scale[ci]+shift[ci]) * w[co][ci][tap] )
+//
+// i.e. the body of SingleConv 'gcl' (Trainer/models/unet3d/buildingblocks.py:31-60)
+// with the GroupNorm affine folded into the operand load, zero padding applied
+// after the affine, and -- for decoder inputs -- the nearest-upsample + concat
+// of Decoder._joining (buildingblocks.py:265-276) folded into the load as a
+// second source pointer (never materialised).
+//
+// GEMM view: M = output voxels (a TDxTHxTW box per workgroup), N = Cout,
+// K = 27 taps x Cin.  Per 16-channel K-chunk the workgroup stages the box's
+// halo ((TD+2)(TH+2)(TW+2) voxels x 16 ch) into LDS once -- affine applied,
+// split into fp16 hi + lo planes -- and re-reads it for all 27 taps
+// (the im2col happens at ds_read time).  Weights are pre-packed in exact MFMA
+// fragment order and stream L2 -> VGPR with one 16-byte load per lane.
+//
+// Numerics: fp32 operands are split x = hi + lo (both fp16 after a power-of-two
+// pre-scale chosen from the GroupNorm bound / max|w| so that nothing can
+// overflow fp16) and the product is hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_32x32x16_f16 with fp32 accumulation: 3 MFMAs at 16x the fp32
+// matrix rate each => 5.3x faster than v_mfma_f32_32x32x2_f32 at ~2^-22
+// relative product error (passes=3).  passes=1 keeps only hi*hi.
+//
+// Wave tile 64x64 (2x2 MFMA blocks), workgroup = WM x WN waves.
+#include "bfm_common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int KC = 16;            // channels per K-chunk
+constexpr int FRAG_U4 = 64;       // one fragment = 64 lanes x uint4
+
+struct ConvParams {
+    const float *A, *B;
+    int CA, CB, D, H, W;
+    UpView up;
+    const float *scale, *shift, *bound;
+    int G;
+    const uint4* wp;
+    int wexp;
+    int Cout;
+    float slope;
+    float* out;
+    int TD, TH, TW, HT, WT;        // box and halo'd box
+    int nTy, nTx, nMt, NT;          // tiles
+    int KCN, kc_per_split, splitk;
+    int nvox_lds, plane_stride;     // LDS geometry (plane_stride in bytes)
+    int tw_shift, thw_shift;        // >=0 when TW / TH*TW are powers of two
+    int64_t split_stride;           // elements between split-K slabs
+};
+
+// lane (= MFMA row) -> position inside the 32-row block such that every
+// ds_read_b128 lane group {0-3,12-15,20-27} / {4-11,16-19,28-31} reads 16
+// consecutive box positions (one w-run when TW == 16): conflict-free.
+__device__ __forceinline__ int row_perm(int l) {
+    if (l < 4) return l;
+    if (l < 12) return l + 12;
+    if (l < 16) return l - 8;
+    if (l < 20) return l + 8;
+    if (l < 28) return l - 12;
+    return l;
+}
+
+__device__ __forceinline__ void box_coords(const ConvParams& p, int q, int& d, int& h, int& w) {
+    if (p.tw_shift >= 0 && p.thw_shift >= 0) {
+        d = q >> p.thw_shift;
+        int rem = q & ((1 << p.thw_shift) - 1);
+        h = rem >> p.tw_shift;
+        w = rem & ((1 << p.tw_shift) - 1);
+    } else {
+        int thw = p.TH * p.TW;
+        d = q / thw;
+        int rem = q - d * thw;
+        h = rem / p.TW;
+        w = rem - h * p.TW;
+    }
+}
+
+template <int WM, int WN, int NPASS>
+__global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(ConvParams p) {
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int NPL = (NPASS == 3) ? 2 : 1;      // planes per k-half (hi[, lo])
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l32 = lane & 31, khalf = lane >> 5;
+
+    // ---- block -> (M tile, N tile): XCD-aware bijective remap so that the 8
+    // round-robin XCDs each own a contiguous run of tiles (neighbouring boxes
+    // share halo lines and all N tiles of a box share its input in one L2).
+    int bid = blockIdx.x;
+    {
+        const int nblk = p.nMt * p.NT;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = bid / p.NT, nt = bid - mt * p.NT;
+    const int split = blockIdx.y;
+    const int tx = mt % p.nTx;
+    const int ty = (mt / p.nTx) % p.nTy;
+    const int tz = mt / (p.nTx * p.nTy);
+    const int z0 = tz * p.TD, y0 = ty * p.TH, x0 = tx * p.TW;
+    const int boxN = p.TD * p.TH * p.TW;
+
+    // ---- operand scale from the GroupNorm bound (power of two, exact)
+    float bmax = 0.f;
+    for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, p.bound[g]);
+    int aexp = 0;
+    if (bmax > 0.f && bmax < INFINITY) {
+        int ex;
+        (void)frexpf(bmax, &ex);       // bmax = m * 2^ex, m in [0.5,1)
+        aexp = 14 - ex;
+        aexp = aexp > 60 ? 60 : (aexp < -60 ? -60 : aexp);
+    }
+    const float a_scale = ldexpf(1.0f, aexp);
+    const float dq = ldexpf(1.0f, -(aexp + p.wexp));
+
+    // ---- per-lane A fragment base offsets (bytes) for the two 32-row blocks
+    int a_off[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        int q = wm * 64 + mb * 32 + row_perm(l32);
+        int d = 0, h = 0, w = 0;
+        if (q < boxN) box_coords(p, q, d, h, w);
+        int vox = (d * p.HT + h) * p.WT + w;
+        a_off[mb] = (khalf * NPL) * p.plane_stride + vox * 16;
+    }
+
+    // ---- staging bookkeeping: element e = tid + it*NTHR -> (halo voxel, channel quad)
+    constexpr int MAX_IT = 12;
+    const int n_el = p.nvox_lds * 4;
+    const int q4 = tid & 3;                              // NTHR % 4 == 0 -> fixed per thread
+    int packed[MAX_IT];                                  // hz | hy<<10 | hx<<20, or -1
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        int e = tid + it * NTHR;
+        packed[it] = -1;
+        if (e < n_el) {
+            int vox = e >> 2;
+            int hz = vox / (p.HT * p.WT);
+            int rem = vox - hz * (p.HT * p.WT);
+            int hy = rem / p.WT;
+            int hx = rem - hy * p.WT;
+            packed[it] = hz | (hy << 10) | (hx << 20);
+        }
+    }
+    const int st_plane = ((q4 >> 1) * NPL) * p.plane_stride + (q4 & 1) * 8;
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+    const int ntw = nt * WN + wn;                        // 64-column tile of this wave
+    const int kc_begin = split * p.kc_per_split;
+    const int kc_end = min(p.KCN, kc_begin + p.kc_per_split);
+
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+        // ================= stage chunk kc =================
+        const int c0 = kc * KC;
+        const bool fromB = c0 >= p.CA;
+        const float* src = fromB ? p.B : p.A;
+        const int cs = fromB ? p.CB : p.CA;              // channel stride of the source
+        const int cof = (fromB ? c0 - p.CA : c0) + q4 * 4;
+        const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + c0 + q4 * 4);
+        const float4 sh4 = *reinterpret_cast<const float4*>(p.shift + c0 + q4 * 4);
+        const float sc[4] = {sc4.x * a_scale, sc4.y * a_scale, sc4.z * a_scale, sc4.w * a_scale};
+        const float sh[4] = {sh4.x * a_scale, sh4.y * a_scale, sh4.z * a_scale, sh4.w * a_scale};
+
+        __syncthreads();                                 // previous chunk's readers are done
+#pragma unroll
+        for (int it0 = 0; it0 < MAX_IT; it0 += 4) {
+            float4 v[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int pk = packed[it0 + u];
+                ok[u] = false;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pk >= 0) {
+                    int gz = z0 + (pk & 1023) - 1, gy = y0 + ((pk >> 10) & 1023) - 1, gx = x0 + (pk >> 20) - 1;
+                    if (gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                        int64_t off;
+                        if (fromB)
+                            off = (((int64_t)p.up.mapD[gz] * p.up.h + p.up.mapH[gy]) * p.up.w + p.up.mapW[gx]) * cs;
+                        else
+                            off = (((int64_t)gz * p.H + gy) * p.W + gx) * cs;
+                        v[u] = *reinterpret_cast<const float4*>(src + off + cof);
+                        ok[u] = true;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = tid + (it0 + u) * NTHR;
+                if (packed[it0 + u] >= 0) {
+                    float y[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    half4 hi, lo;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float t = ok[u] ? fmaf(y[i], sc[i], sh[i]) : 0.f;   // zero padding AFTER the affine
+                        _Float16 hh = (_Float16)t;
+                        hi[i] = hh;
+                        lo[i] = (_Float16)(t - (float)hh);
+                    }
+                    unsigned char* dst = lds + st_plane + (e >> 2) * 16;
+                    *reinterpret_cast<half4*>(dst) = hi;
+                    if constexpr (NPASS == 3) *reinterpret_cast<half4*>(dst + p.plane_stride) = lo;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ================= 27 taps of MFMA on the staged chunk =================
+        const uint4* wb = p.wp + ((size_t)(ntw * p.KCN + kc) * 27) * (4 * FRAG_U4) + lane;
+
+        half8 a0[2][NPL], b0[2][NPL], a1[2][NPL], b1[2][NPL];
+
+        auto load_tap = [&](int tap, half8 (&a)[2][NPL], half8 (&b)[2][NPL]) {
+            const int kd = tap / 9, r9 = tap - kd * 9, kh = r9 / 3, kw = r9 - kh * 3;
+            const int toff = ((kd * p.HT + kh) * p.WT + kw) * 16;
+            const uint4* wt = wb + (size_t)tap * (4 * FRAG_U4);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int hl = 0; hl < NPL; ++hl) {
+                    uint4 raw = wt[(nb * 2 + hl) * FRAG_U4];
+                    b[nb][hl] = *reinterpret_cast<half8*>(&raw);
+                }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int hl = 0; hl < NPL; ++hl)
+                    a[mb][hl] = *reinterpret_cast<const half8*>(lds + a_off[mb] + hl * p.plane_stride + toff);
+        };
+        auto mma_tap = [&](half8 (&a)[2][NPL], half8 (&b)[2][NPL]) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    if constexpr (NPASS == 3) {
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][1], b[nb][0], acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][0], b[nb][1], acc[mb][nb], 0, 0, 0);
+                    }
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][0], b[nb][0], acc[mb][nb], 0, 0, 0);
+                }
+        };
+
+        load_tap(0, a0, b0);
+        for (int tp = 0; tp < 13; ++tp) {               // taps 2tp (buf0) and 2tp+1 (buf1)
+            load_tap(2 * tp + 1, a1, b1);
+            mma_tap(a0, b0);
+            load_tap(2 * tp + 2, a0, b0);
+            mma_tap(a1, b1);
+        }
+        mma_tap(a0, b0);                                // tap 26
+    }
+
+    // ================= epilogue =================
+    const bool final_out = p.splitk == 1;
+    float* obase = p.out + (final_out ? 0 : (int64_t)split * p.split_stride);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rr = (i >> 2) * 8 + khalf * 4 + (i & 3);
+            const int q = wm * 64 + mb * 32 + row_perm(rr);
+            if (q >= boxN) continue;
+            int d, h, w;
+            box_coords(p, q, d, h, w);
+            const int gz = z0 + d, gy = y0 + h, gx = x0 + w;
+            if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
+            float* orow = obase + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + ntw * 64 + l32;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                float r = acc[mb][nb][i] * dq;
+                if (final_out) r = r >= 0.f ? r : r * p.slope;
+                orow[nb * 32] = r;
+            }
+        }
+    }
+}
+
+// sum split-K slabs in slab order, then LeakyReLU
+__global__ void splitk_reduce(const float* __restrict__ ws, int splitk, int64_t n4, int64_t stride4, float slope,
+                              float* __restrict__ out) {
+    const float4* w4 = reinterpret_cast<const float4*>(ws);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 s = w4[i];
+        for (int k = 1; k < splitk; ++k) {
+            float4 t = w4[i + k * stride4];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        s.x = s.x >= 0.f ? s.x : s.x * slope; s.y = s.y >= 0.f ? s.y : s.y * slope;
+        s.z = s.z >= 0.f ? s.z : s.z * slope; s.w = s.w >= 0.f ? s.w : s.w * slope;
+        o4[i] = s;
+    }
+}
+
+// packed[ntile64][kc][tap][nb][hl][lane] (uint4 = 8 halfs): lane l holds
+// B[k = 8*(l>>5)+j][n = l&31] = w[co = ntile*64 + nb*32 + (l&31)][ci = kc*16 + 8*(l>>5) + j][tap] * 2^wexp
+__global__ void pack_mfma(const float* __restrict__ w, int Cin, int Cout, int wexp, uint4* __restrict__ out) {
+    const int KCN = Cin / KC;
+    const int64_t n = (int64_t)(Cout / 64) * KCN * 27 * 2 * 2 * 64;
+    const float s = ldexpf(1.0f, wexp);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int lane = (int)(i & 63);
+        int64_t r = i >> 6;
+        int hl = (int)(r & 1); r >>= 1;
+        int nb = (int)(r & 1); r >>= 1;
+        int tap = (int)(r % 27); r /= 27;
+        int kc = (int)(r % KCN);
+        int ntile = (int)(r / KCN);
+        int co = ntile * 64 + nb * 32 + (lane & 31);
+        int ci0 = kc * KC + (lane >> 5) * 8;
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = w[((int64_t)co * Cin + ci0 + j) * 27 + tap] * s;
+            _Float16 hh = (_Float16)x;
+            v[j] = hl ? (_Float16)(x - (float)hh) : hh;
+        }
+        out[i] = *reinterpret_cast<uint4*>(&v);
+    }
+}
+
+struct HostPlan {
+    int WM, WN, TD, TH, TW, splitk;
+};
+
+constexpr int LDS_LIMIT = 64 * 1024;
+
+int plane_stride_for(int nvox) { return ((nvox * 16 + 63) / 64) * 64 + 32; }
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+int ilog2(int v) { int s = 0; while ((1 << s) < v) ++s; return s; }
+
+HostPlan choose_plan(int Cin, int Cout, int D, int H, int W) {
+    HostPlan hp{};
+    if (Cout % 128 == 0) { hp.WM = 2; hp.WN = 2; } else { hp.WM = 4; hp.WN = 1; }
+    const int rows = hp.WM * 64;
+    double best = 1e300;
+    for (int tw = 1; tw <= std::min(W, 32); ++tw)
+        for (int th = 1; th <= std::min(H, rows / tw); ++th) {
+            int td = std::min(D, rows / (tw * th));
+            if (td < 1) continue;
+            int nvox = (td + 2) * (th + 2) * (tw + 2);
+            if (4 * plane_stride_for(nvox) > LDS_LIMIT) continue;
+            if (nvox * 4 > 12 * 64 * hp.WM * hp.WN) continue;          // MAX_IT staging slots
+            double tiles = (double)bfm_cdiv(D, td) * bfm_cdiv(H, th) * bfm_cdiv(W, tw);
+            double conflict = (tw % 16 == 0) ? 1.0 : 1.25;
+            // MFMA work per tile is fixed (rows x 64*WN x K); staging grows with the halo
+            double cost = tiles * (rows * 27.0 + nvox * 4.0 * conflict);
+            if (cost < best) { best = cost; hp.TD = td; hp.TH = th; hp.TW = tw; }
+        }
+    const int KCN = Cin / KC;
+    int nMt = bfm_cdiv(D, hp.TD) * bfm_cdiv(H, hp.TH) * bfm_cdiv(W, hp.TW);
+    int wgs = nMt * (Cout / (64 * hp.WN));
+    hp.splitk = 1;
+    if (wgs < 256 && KCN >= 8) {
+        int want = bfm_cdiv(512, wgs);
+        int maxs = KCN / 4;
+        int s = std::min(want, maxs);
+        if (s > 1) {
+            int per = bfm_cdiv(KCN, s);
+            hp.splitk = bfm_cdiv(KCN, per);
+        }
+    }
+    return hp;
+}
+
+template <int WM, int WN>
+void launch(const ConvParams& p, int passes, dim3 grid, size_t smem, hipStream_t st) {
+    if (passes == 3) hipLaunchKernelGGL((conv_mfma<WM, WN, 3>), grid, dim3(64 * WM * WN), smem, st, p);
+    else hipLaunchKernelGGL((conv_mfma<WM, WN, 1>), grid, dim3(64 * WM * WN), smem, st, p);
+}
+
+}  // namespace
+
+extern "C" size_t bfm_pack_conv_weights_mfma_bytes(int Cin, int Cout) {
+    if (Cin % KC || Cout % 64) return 0;
+    return (size_t)(Cout / 64) * (Cin / KC) * 27 * 2 * 2 * 64 * 16;
+}
+
+extern "C" int bfm_pack_conv_weights_mfma(const float* w, int Cin, int Cout, float wmax_abs_host, void* wpacked,
+                                          int* wexp_host, bfm_stream_t stream) {
+    if (!w || !wpacked || !wexp_host || Cin <= 0 || Cout <= 0) return BFM_E_ARG;
+    if (Cin % KC || Cout % 64) return BFM_E_SHAPE;
+    int wexp = 0;
+    if (wmax_abs_host > 0.f && wmax_abs_host < INFINITY) {
+        int ex;
+        (void)frexpf(wmax_abs_host, &ex);
+        wexp = 14 - ex;
+        wexp = wexp > 60 ? 60 : (wexp < -60 ? -60 : wexp);
+    }
+    *wexp_host = wexp;
+    int64_t n = (int64_t)(Cout / 64) * (Cin / KC) * 27 * 2 * 2 * 64;
+    int nb = (int)std::min<int64_t>(4096, bfm_cdiv64(n, 256));
+    hipLaunchKernelGGL(pack_mfma, dim3(nb), dim3(256), 0, bfm_s(stream), w, Cin, Cout, wexp,
+                       reinterpret_cast<uint4*>(wpacked));
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_conv3x3x3_mfma_plan(int Cin, int Cout, int D, int H, int W, int* cfg) {
+    if (!cfg || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return BFM_E_ARG;
+    if (Cin % KC || Cout % 64) return BFM_E_SHAPE;
+    HostPlan hp = choose_plan(Cin, Cout, D, H, W);
+    if (hp.TD == 0) return BFM_E_SHAPE;
+    cfg[0] = hp.WM; cfg[1] = hp.WN; cfg[2] = hp.TD; cfg[3] = hp.TH; cfg[4] = hp.TW; cfg[5] = hp.splitk;
+    cfg[6] = 0; cfg[7] = 0;
+    return BFM_OK;
+}
+
+extern "C" size_t bfm_conv3x3x3_mfma_workspace(int Cin, int Cout, int D, int H, int W, int splitk) {
+    (void)Cin;
+    if (splitk <= 1) return 0;
+    return (size_t)splitk * D * H * W * Cout * sizeof(float);
+}
+
+extern "C" int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB, int D, int H, int W,
+                                  const bfm_upsample_t* up, const float* scale, const float* shift,
+                                  const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope,
+                                  int passes, const int* cfg, float* out, void* workspace, size_t workspace_bytes,
+                                  bfm_stream_t stream) {
+    if (!A || CA <= 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || G <= 0 || !wpacked || !out)
+        return BFM_E_ARG;
+    if (CB < 0 || (CB > 0 && (!B || !up || !up->mapD || !up->mapH || !up->mapW || up->d <= 0 || up->h <= 0 ||
+                              up->w <= 0)))
+        return BFM_E_ARG;
+    if (CA % KC || CB % KC || Cout % 64) return BFM_E_SHAPE;
+    if (passes != 1 && passes != 3) return BFM_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(A) & 15) || (CB > 0 && (reinterpret_cast<uintptr_t>(B) & 15)) ||
+        (reinterpret_cast<uintptr_t>(scale) & 15) || (reinterpret_cast<uintptr_t>(shift) & 15) ||
+        (reinterpret_cast<uintptr_t>(wpacked) & 15) || (reinterpret_cast<uintptr_t>(out) & 15))
+        return BFM_E_ARG;
+    const int Cin = CA + CB;
+    HostPlan hp;
+    if (cfg) {
+        hp = HostPlan{cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5]};
+    } else {
+        hp = choose_plan(Cin, Cout, D, H, W);
+    }
+    const bool wg_ok = (hp.WM == 4 && hp.WN == 1) || (hp.WM == 2 && hp.WN == 2);
+    if (!wg_ok || hp.TD < 1 || hp.TH < 1 || hp.TW < 1 || hp.TD * hp.TH * hp.TW > hp.WM * 64) return BFM_E_SHAPE;
+    if (Cout % (64 * hp.WN)) return BFM_E_SHAPE;
+    if (hp.TD + 2 > 1023 || hp.TH + 2 > 1023 || hp.TW + 2 > 1023) return BFM_E_SHAPE;
+
+    ConvParams p{};
+    p.A = A; p.B = B; p.CA = CA; p.CB = CB; p.D = D; p.H = H; p.W = W;
+    p.up = make_upview(up);
+    p.scale = scale; p.shift = shift; p.bound = bound; p.G = G;
+    p.wp = reinterpret_cast<const uint4*>(wpacked);
+    p.wexp = wexp; p.Cout = Cout; p.slope = slope;
+    p.TD = hp.TD; p.TH = hp.TH; p.TW = hp.TW; p.HT = hp.TH + 2; p.WT = hp.TW + 2;
+    const int nTz = bfm_cdiv(D, hp.TD);
+    p.nTy = bfm_cdiv(H, hp.TH); p.nTx = bfm_cdiv(W, hp.TW);
+    p.nMt = nTz * p.nTy * p.nTx;
+    p.NT = Cout / (64 * hp.WN);
+    p.KCN = Cin / KC;
+    p.splitk = hp.splitk < 1 ? 1 : hp.splitk;
+    if (p.splitk > p.KCN) p.splitk = p.KCN;
+    p.kc_per_split = bfm_cdiv(p.KCN, p.splitk);
+    p.splitk = bfm_cdiv(p.KCN, p.kc_per_split);
+    p.nvox_lds = (hp.TD + 2) * p.HT * p.WT;
+    p.plane_stride = plane_stride_for(p.nvox_lds);
+    p.tw_shift = is_pow2(hp.TW) ? ilog2(hp.TW) : -1;
+    p.thw_shift = is_pow2(hp.TH * hp.TW) ? ilog2(hp.TH * hp.TW) : -1;
+    const int npl = passes == 3 ? 2 : 1;
+    const size_t smem = (size_t)2 * npl * p.plane_stride;
+    if (smem > (size_t)LDS_LIMIT) return BFM_E_SHAPE;
+    if (p.nvox_lds * 4 > 12 * 64 * hp.WM * hp.WN) return BFM_E_SHAPE;
+    const int64_t nvox = (int64_t)D * H * W;
+    p.split_stride = nvox * Cout;
+    if (p.splitk > 1) {
+        if (!workspace || workspace_bytes < (size_t)p.splitk * nvox * Cout * sizeof(float)) return BFM_E_WORKSPACE;
+        if (reinterpret_cast<uintptr_t>(workspace) & 15) return BFM_E_ARG;
+        p.out = static_cast<float*>(workspace);
+    } else {
+        p.out = out;
+    }
+    if ((int64_t)p.nMt * p.NT > 0x7fffffff) return BFM_E_SHAPE;
+    dim3 grid((unsigned)(p.nMt * p.NT), (unsigned)p.splitk);
+    hipStream_t st = bfm_s(stream);
+    if (hp.WM == 4) launch<4, 1>(p, passes, grid, smem, st);
+    else launch<2, 2>(p, passes, grid, smem, st);
+    int rc = bfm_launch_status();
+    if (rc != BFM_OK) return rc;
+    if (p.splitk > 1) {
+        int64_t n4 = nvox * Cout / 4;
+        int nb = (int)std::min<int64_t>(2048, bfm_cdiv64(n4, 256));
+        hipLaunchKernelGGL(splitk_reduce, dim3(nb), dim3(256), 0, st, static_cast<const float*>(workspace), p.splitk,
+                           n4, p.split_stride / 4, slope, out);
+        rc = bfm_launch_status();
+    }
+    return rc;
+}

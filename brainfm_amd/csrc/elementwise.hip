@@ -1,0 +1,128 @@
+// Small HBM-bound per-voxel kernels shared by the stand-alone processors /
+// post-processor (joiner.py:69-77,149-157; Trainer/models/__init__.py:272-354)
+// and by the synthesis augmentations (Generator/utils.py:568-638,
+// Generator/datasets.py:306-372).  Strided so that channel slices of a
+// channels-last buffer can be read in place.
+#include "bfm_common.h"
+
+namespace {
+
+inline int grid_for(int64_t n, int tpb = 256, int cap = 4096) {
+    int64_t b = bfm_cdiv64(n, tpb);
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+__global__ void ew_unary(int op, const float* __restrict__ in, int64_t is, float* __restrict__ out, int64_t os,
+                         int64_t n, float a, float b) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float x = in[i * is], r;
+        switch (op) {
+            case BFM_EW_EXP: r = expf(x); break;
+            case BFM_EW_AFFINE: r = x * a + b; break;
+            case BFM_EW_CLAMP: r = fminf(fmaxf(x, a), b); break;
+            case BFM_EW_CLAMP_MIN: r = x < a ? a : x; break;
+            case BFM_EW_GAMMA: r = a * powf(x / a, b); break;
+            case BFM_EW_SIGMOID: r = 1.f / (1.f + expf(-x)); break;
+            case BFM_EW_DIV: r = x / a; break;
+            case BFM_EW_NONZERO: r = x != 0.f ? 1.f : 0.f; break;
+            case BFM_EW_SUB_DIV: r = (x - a) / b; break;
+            default: r = x;
+        }
+        out[i * os] = r;
+    }
+}
+
+__global__ void ew_binary(int op, const float* __restrict__ x, int64_t xs, const float* __restrict__ y, int64_t ys,
+                          float* __restrict__ out, int64_t os, int64_t n, float a) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float p = x[i * xs], q = y[i * ys], r;
+        switch (op) {
+            case BFM_EW_ADD: r = p + q; break;
+            case BFM_EW_MUL: r = p * q; break;
+            case BFM_EW_MUL_EXP: r = p * expf(q); break;
+            case BFM_EW_AXPY_CLAMP0: r = p + a * q; r = r < 0.f ? 0.f : r; break;   // add_noise, utils.py:633-638
+            case BFM_EW_AXPY: r = p + a * q; break;
+            case BFM_EW_DIV2: r = p / q; break;
+            default: r = p;
+        }
+        out[i * os] = r;
+    }
+}
+
+// softmax over the last (channel) axis of a channels-last tensor, one thread per voxel
+__global__ void softmax_cl(const float* __restrict__ x, int64_t xrs, int C, float* __restrict__ y, int64_t yrs,
+                           int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float* r = x + i * xrs;
+        float* o = y + i * yrs;
+        float m = -INFINITY;
+        for (int c = 0; c < C; ++c) m = fmaxf(m, r[c]);
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(r[c] - m);
+        for (int c = 0; c < C; ++c) o[c] = expf(r[c] - m) / s;
+    }
+}
+
+__global__ void argmax_lut_cl(const float* __restrict__ p, int64_t prs, int C, const int32_t* __restrict__ lut,
+                              int64_t* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float* r = p + i * prs;
+        int best = 0;
+        float bv = r[0];
+        for (int c = 1; c < C; ++c) if (r[c] > bv) { bv = r[c]; best = c; }
+        out[i] = lut ? (int64_t)lut[best] : (int64_t)best;
+    }
+}
+
+__device__ __forceinline__ float fake_term(float v, float add, float gain) {
+    return gain * (1.f - (tanhf(2.f * (v + add)) + 1.f) / 2.f);
+}
+
+// fake_cortical, Trainer/models/__init__.py:327-338 (a = 2)
+__global__ void fake_cortical(const float* __restrict__ d, int64_t rs, int nd, float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float* r = d + i * rs;
+        float f = fake_term(r[1], 0.3f, 70.f) + fake_term(r[0], 0.f, 40.f);
+        if (nd == 4) f = f + (fake_term(r[3], 0.3f, 70.f) + fake_term(r[2], 0.f, 40.f));
+        out[i] = f;
+    }
+}
+
+}  // namespace
+
+extern "C" int bfm_ew_unary(int op, const float* in, int64_t in_stride, float* out, int64_t out_stride, int64_t n,
+                            float a, float b, bfm_stream_t stream) {
+    if (!in || !out || n <= 0 || in_stride <= 0 || out_stride <= 0) return BFM_E_ARG;
+    hipLaunchKernelGGL(ew_unary, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), op, in, in_stride, out, out_stride, n,
+                       a, b);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_ew_binary(int op, const float* x, int64_t xs, const float* y, int64_t ys, float* out, int64_t os,
+                             int64_t n, float a, bfm_stream_t stream) {
+    if (!x || !y || !out || n <= 0 || xs <= 0 || ys < 0 || os <= 0) return BFM_E_ARG;
+    hipLaunchKernelGGL(ew_binary, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), op, x, xs, y, ys, out, os, n, a);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_softmax_cl(const float* x, int64_t x_row_stride, int C, float* y, int64_t y_row_stride, int64_t n,
+                              bfm_stream_t stream) {
+    if (!x || !y || n <= 0 || C <= 0 || x_row_stride < C || y_row_stride < C) return BFM_E_ARG;
+    hipLaunchKernelGGL(softmax_cl, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), x, x_row_stride, C, y, y_row_stride,
+                       n);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_argmax_lut_cl(const float* p, int64_t row_stride, int C, const int32_t* lut, int64_t* out,
+                                 int64_t n, bfm_stream_t stream) {
+    if (!p || !out || n <= 0 || C <= 0 || row_stride < C) return BFM_E_ARG;
+    hipLaunchKernelGGL(argmax_lut_cl, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), p, row_stride, C, lut, out, n);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_fake_cortical(const float* dist, int64_t row_stride, int n_dist, float* out, int64_t n,
+                                 bfm_stream_t stream) {
+    if (!dist || !out || n <= 0 || (n_dist != 2 && n_dist != 4) || row_stride < n_dist) return BFM_E_ARG;
+    hipLaunchKernelGGL(fake_cortical, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), dist, row_stride, n_dist, out, n);
+    return bfm_launch_status();
+}

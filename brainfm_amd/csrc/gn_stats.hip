@@ -1,0 +1,328 @@
+// GroupNorm statistics for channels-last-3D fp32 activations (HBM-bound).
+//
+// Replaces nn.GroupNorm's moment pass (Trainer/models/unet3d/buildingblocks.py:48-60)
+// for the SingleConv input, including the decoder's virtual concatenation
+// cat((skip, nearest_up(x))) (buildingblocks.py:265-276): the upsampled half is
+// never materialised -- its moments are the low-res moments weighted by the
+// per-voxel replication count of the nearest-neighbour map.
+//
+// Two launches, both deterministic (no atomics):
+//   gn_partial : per-block, per-channel {sum, sum of squares} in fp64 and
+//                {min, max} in fp32 over a contiguous voxel range;
+//   gn_finalize: one block per group; fixed-order reduction of the partials,
+//                mean / rstd, folded affine scale/shift per channel and the
+//                group's bound on |x*scale+shift| (used by the MFMA conv to
+//                choose its fp16 operand scale).
+#include "bfm_common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+struct RepView {
+    int d, h, w;                       // dims of the tensor being reduced
+    const int32_t *rd, *rh, *rw;       // replication counts (nullptr -> weight 1)
+};
+
+__device__ __forceinline__ double vox_weight(const RepView& r, int64_t v) {
+    if (r.rd == nullptr) return 1.0;
+    int x = (int)(v % r.w);
+    int64_t t = v / r.w;
+    int y = (int)(t % r.h);
+    int z = (int)(t / r.h);
+    return (double)r.rd[z] * (double)r.rh[y] * (double)r.rw[x];
+}
+
+template <int VEC>
+struct Acc {
+    double s[VEC], q[VEC];
+    float mn[VEC], mx[VEC];
+    __device__ void init() {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { s[i] = 0.0; q[i] = 0.0; mn[i] = INFINITY; mx[i] = -INFINITY; }
+    }
+    __device__ void add(const float* x, double wgt) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            double xv = (double)x[i];
+            s[i] += wgt * xv;
+            q[i] += wgt * xv * xv;
+            mn[i] = fminf(mn[i], x[i]);
+            mx[i] = fmaxf(mx[i], x[i]);
+        }
+    }
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float* out) {
+    if constexpr (VEC == 4) {
+        float4 v = *reinterpret_cast<const float4*>(p);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else {
+        out[0] = *p;
+    }
+}
+
+// partial tables: psum/psq [nblocks][C] double, pmin/pmax [nblocks][C] float
+template <int VEC>
+__global__ void __launch_bounds__(TPB) gn_partial(const float* __restrict__ X, int C, int64_t nvox,
+                                                  int64_t vox_per_block, RepView rep, double* __restrict__ psum,
+                                                  double* __restrict__ psq, float* __restrict__ pmin,
+                                                  float* __restrict__ pmax) {
+    extern __shared__ double smem_d[];
+    const int t = threadIdx.x;
+    const int CV = C / VEC;
+    const int64_t v0 = (int64_t)blockIdx.x * vox_per_block;
+    const int64_t v1 = min(nvox, v0 + vox_per_block);
+    const size_t row = (size_t)blockIdx.x * C;
+
+    if (CV > TPB) {
+        // wide tensors: each thread owns a column, walks every voxel of the range
+        for (int cb = 0; cb < CV; cb += TPB) {
+            int col = cb + t;
+            if (col >= CV) continue;
+            Acc<VEC> a; a.init();
+            for (int64_t v = v0; v < v1; ++v) {
+                float x[VEC];
+                load_vec<VEC>(X + v * C + (size_t)col * VEC, x);
+                a.add(x, vox_weight(rep, v));
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+                psum[row + col * VEC + i] = a.s[i];
+                psq[row + col * VEC + i] = a.q[i];
+                pmin[row + col * VEC + i] = a.mn[i];
+                pmax[row + col * VEC + i] = a.mx[i];
+            }
+        }
+        return;
+    }
+
+    const int RP = TPB / CV;              // voxel rows in flight per pass
+    const bool active = t < RP * CV;
+    const int r0 = t / CV, col = t % CV;
+    Acc<VEC> a; a.init();
+    if (active) {
+        for (int64_t v = v0 + r0; v < v1; v += RP) {
+            float x[VEC];
+            load_vec<VEC>(X + v * C + (size_t)col * VEC, x);
+            a.add(x, vox_weight(rep, v));
+        }
+    }
+    // reduce the RP rows in fixed order through LDS
+    double* ls = smem_d;                       // [RP][C]
+    double* lq = ls + (size_t)RP * C;          // [RP][C]
+    float* lmn = reinterpret_cast<float*>(lq + (size_t)RP * C);
+    float* lmx = lmn + (size_t)RP * C;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+            int idx = r0 * C + col * VEC + i;
+            ls[idx] = a.s[i]; lq[idx] = a.q[i]; lmn[idx] = a.mn[i]; lmx[idx] = a.mx[i];
+        }
+    }
+    __syncthreads();
+    // second stage: thread t folds RP/STEP rows, then a serial tail; keep it simple & ordered
+    for (int c = t; c < C; c += TPB) {
+        double s = 0.0, q = 0.0; float mn = INFINITY, mx = -INFINITY;
+        for (int r = 0; r < RP; ++r) {
+            s += ls[r * C + c]; q += lq[r * C + c];
+            mn = fminf(mn, lmn[r * C + c]); mx = fmaxf(mx, lmx[r * C + c]);
+        }
+        psum[row + c] = s; psq[row + c] = q; pmin[row + c] = mn; pmax[row + c] = mx;
+    }
+}
+
+struct PartTab {
+    const double *psum, *psq;
+    const float *pmin, *pmax;
+    int nb, C;
+};
+
+// One block per group.  Dynamic LDS: chan_s[cpg], chan_q[cpg] (double), chan_mn[cpg], chan_mx[cpg] (float),
+// red_s[TPB], red_q[TPB] (double), red_mn[TPB], red_mx[TPB] (float)
+__global__ void __launch_bounds__(TPB) gn_finalize(PartTab ta, PartTab tb, int G, double count_per_channel,
+                                                   float eps, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float* __restrict__ scale,
+                                                   float* __restrict__ shift, float* __restrict__ bound) {
+    extern __shared__ double smem_d[];
+    const int t = threadIdx.x;
+    const int g = blockIdx.x;
+    const int Ctot = ta.C + tb.C;
+    const int cpg = Ctot / G;
+    const int c_first = g * cpg;
+
+    double* chan_s = smem_d;
+    double* chan_q = chan_s + cpg;
+    double* red_s = chan_q + cpg;
+    double* red_q = red_s + TPB;
+    float* chan_mn = reinterpret_cast<float*>(red_q + TPB);
+    float* chan_mx = chan_mn + cpg;
+    float* red_mn = chan_mx + cpg;
+    float* red_mx = red_mn + TPB;
+
+    const int cpgP = cpg < TPB ? cpg : TPB;
+    const int P = TPB / cpgP;
+    const bool active = t < P * cpgP;
+    const int cl = t % cpgP, part = t / cpgP;
+
+    for (int cb = 0; cb < cpg; cb += cpgP) {
+        const int cg = cb + cl;                 // channel within group
+        double s = 0.0, q = 0.0; float mn = INFINITY, mx = -INFINITY;
+        if (active && cg < cpg) {
+            int c = c_first + cg;
+            const PartTab& T = (c < ta.C) ? ta : tb;
+            int cc = (c < ta.C) ? c : c - ta.C;
+            for (int b = part; b < T.nb; b += P) {
+                size_t i = (size_t)b * T.C + cc;
+                s += T.psum[i]; q += T.psq[i];
+                mn = fminf(mn, T.pmin[i]); mx = fmaxf(mx, T.pmax[i]);
+            }
+        }
+        red_s[t] = s; red_q[t] = q; red_mn[t] = mn; red_mx[t] = mx;
+        __syncthreads();
+        if (active && part == 0 && cg < cpg) {
+            for (int p = 1; p < P; ++p) {
+                int i = p * cpgP + cl;
+                s += red_s[i]; q += red_q[i];
+                mn = fminf(mn, red_mn[i]); mx = fmaxf(mx, red_mx[i]);
+            }
+            chan_s[cg] = s; chan_q[cg] = q; chan_mn[cg] = mn; chan_mx[cg] = mx;
+        }
+        __syncthreads();
+    }
+
+    // group moments: fixed-order serial sum (cpg <= a few hundred)
+    __shared__ float sh_mean, sh_rstd;
+    if (t == 0) {
+        double S = 0.0, Q = 0.0;
+        for (int c = 0; c < cpg; ++c) { S += chan_s[c]; Q += chan_q[c]; }
+        double n = count_per_channel * (double)cpg;
+        double mean = S / n;
+        double var = Q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        sh_mean = (float)mean;
+        sh_rstd = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const float mean = sh_mean, rstd = sh_rstd;
+    float bmax = 0.f;
+    for (int cg = t; cg < cpg; cg += TPB) {
+        int c = c_first + cg;
+        float sc = rstd * gamma[c];
+        float sh = -sc * mean + beta[c];
+        scale[c] = sc; shift[c] = sh;
+        float b0 = fabsf(fmaf(chan_mn[cg], sc, sh));
+        float b1 = fabsf(fmaf(chan_mx[cg], sc, sh));
+        bmax = fmaxf(bmax, fmaxf(b0, b1));
+    }
+    red_mx[t] = bmax;
+    __syncthreads();
+    if (t == 0) {
+        float b = 0.f;
+        for (int i = 0; i < TPB; ++i) b = fmaxf(b, red_mx[i]);
+        bound[g] = b;
+    }
+}
+
+struct Plan {
+    int nbA, nbB;
+    int64_t vpbA, vpbB;
+    size_t offA_sum, offA_sq, offA_mn, offA_mx, offB_sum, offB_sq, offB_mn, offB_mx, total;
+};
+
+int blocks_for(int64_t nvox, int C, int64_t* vpb) {
+    // enough blocks to stream from HBM, few enough that finalize stays cheap
+    int64_t target = 16;                       // min voxels per block
+    int64_t nb = bfm_cdiv64(nvox, target);
+    int64_t cap = 2048;
+    if ((int64_t)C * cap > (1 << 20)) cap = ((1 << 20) / C) > 8 ? ((1 << 20) / C) : 8;   // bound partial table size
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    *vpb = bfm_cdiv64(nvox, nb);
+    nb = bfm_cdiv64(nvox, *vpb);
+    return (int)nb;
+}
+
+Plan make_plan(int CA, int CB, int64_t nvoxA, int64_t nvoxB) {
+    Plan p{};
+    p.nbA = blocks_for(nvoxA, CA, &p.vpbA);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    p.offA_sum = take((size_t)p.nbA * CA * 8); p.offA_sq = take((size_t)p.nbA * CA * 8);
+    p.offA_mn = take((size_t)p.nbA * CA * 4); p.offA_mx = take((size_t)p.nbA * CA * 4);
+    if (CB > 0) {
+        p.nbB = blocks_for(nvoxB, CB, &p.vpbB);
+        p.offB_sum = take((size_t)p.nbB * CB * 8); p.offB_sq = take((size_t)p.nbB * CB * 8);
+        p.offB_mn = take((size_t)p.nbB * CB * 4); p.offB_mx = take((size_t)p.nbB * CB * 4);
+    }
+    p.total = off;
+    return p;
+}
+
+void launch_partial(const float* X, int C, int64_t nvox, int nb, int64_t vpb, RepView rep, char* ws, size_t o_sum,
+                    size_t o_sq, size_t o_mn, size_t o_mx, hipStream_t st) {
+    double* ps = reinterpret_cast<double*>(ws + o_sum);
+    double* pq = reinterpret_cast<double*>(ws + o_sq);
+    float* pn = reinterpret_cast<float*>(ws + o_mn);
+    float* px = reinterpret_cast<float*>(ws + o_mx);
+    bool vec4 = (C % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    int CV = vec4 ? C / 4 : C;
+    int RP = CV > TPB ? 0 : TPB / CV;
+    size_t smem = (size_t)RP * C * 24;
+    if (vec4) hipLaunchKernelGGL(gn_partial<4>, dim3(nb), dim3(TPB), smem, st, X, C, nvox, vpb, rep, ps, pq, pn, px);
+    else hipLaunchKernelGGL(gn_partial<1>, dim3(nb), dim3(TPB), smem, st, X, C, nvox, vpb, rep, ps, pq, pn, px);
+}
+
+}  // namespace
+
+extern "C" size_t bfm_gn_stats_workspace(int CA, int CB, int D, int H, int W, const bfm_upsample_t* up) {
+    int64_t nvoxA = (int64_t)D * H * W;
+    int64_t nvoxB = (CB > 0 && up) ? (int64_t)up->d * up->h * up->w : 0;
+    return make_plan(CA, CB, nvoxA, nvoxB).total;
+}
+
+extern "C" int bfm_gn_stats(const float* A, int CA, const float* B, int CB, int D, int H, int W,
+                            const bfm_upsample_t* up, const float* gamma, const float* beta, int G, float eps,
+                            float* scale, float* shift, float* bound, void* workspace, size_t workspace_bytes,
+                            bfm_stream_t stream) {
+    if (!A || CA <= 0 || D <= 0 || H <= 0 || W <= 0 || !gamma || !beta || !scale || !shift || !bound || !workspace)
+        return BFM_E_ARG;
+    if (CB < 0 || (CB > 0 && (!B || !up || up->d <= 0 || up->h <= 0 || up->w <= 0 || !up->repD || !up->repH ||
+                              !up->repW)))
+        return BFM_E_ARG;
+    const int Ctot = CA + CB;
+    if (G <= 0 || Ctot % G != 0) return BFM_E_SHAPE;
+    const int cpg = Ctot / G;
+    // LDS of gn_partial: RP*C*24 bytes must fit 64 KiB
+    auto partial_ok = [](int C) {
+        int CV = (C % 4 == 0) ? C / 4 : C;
+        int RP = CV > TPB ? 0 : TPB / CV;
+        return (size_t)RP * C * 24 <= 64 * 1024;
+    };
+    if (!partial_ok(CA) || (CB > 0 && !partial_ok(CB))) return BFM_E_SHAPE;
+    size_t fin_smem = (size_t)cpg * 24 + (size_t)TPB * 24;
+    if (fin_smem > 64 * 1024) return BFM_E_SHAPE;
+
+    const int64_t nvoxA = (int64_t)D * H * W;
+    const int64_t nvoxB = CB > 0 ? (int64_t)up->d * up->h * up->w : 0;
+    Plan p = make_plan(CA, CB, nvoxA, nvoxB);
+    if (workspace_bytes < p.total) return BFM_E_WORKSPACE;
+    char* ws = static_cast<char*>(workspace);
+    hipStream_t st = bfm_s(stream);
+
+    RepView none{D, H, W, nullptr, nullptr, nullptr};
+    launch_partial(A, CA, nvoxA, p.nbA, p.vpbA, none, ws, p.offA_sum, p.offA_sq, p.offA_mn, p.offA_mx, st);
+    PartTab ta{reinterpret_cast<double*>(ws + p.offA_sum), reinterpret_cast<double*>(ws + p.offA_sq),
+               reinterpret_cast<float*>(ws + p.offA_mn), reinterpret_cast<float*>(ws + p.offA_mx), p.nbA, CA};
+    PartTab tb{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if (CB > 0) {
+        RepView rep{up->d, up->h, up->w, up->repD, up->repH, up->repW};
+        launch_partial(B, CB, nvoxB, p.nbB, p.vpbB, rep, ws, p.offB_sum, p.offB_sq, p.offB_mn, p.offB_mx, st);
+        tb = PartTab{reinterpret_cast<double*>(ws + p.offB_sum), reinterpret_cast<double*>(ws + p.offB_sq),
+                     reinterpret_cast<float*>(ws + p.offB_mn), reinterpret_cast<float*>(ws + p.offB_mx), p.nbB, CB};
+    }
+    hipLaunchKernelGGL(gn_finalize, dim3(G), dim3(TPB), fin_smem, st, ta, tb, G, (double)nvoxA, eps, gamma, beta,
+                       scale, shift, bound);
+    return bfm_launch_status();
+}

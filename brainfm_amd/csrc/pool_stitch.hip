@@ -1,0 +1,143 @@
+// HBM-bound helpers of the inference path: MaxPool3d(2) and tile stitching.
+#include "bfm_common.h"
+
+namespace {
+
+// nn.MaxPool3d(kernel_size=2): window 2, stride 2, floor, no padding
+// (Trainer/models/unet3d/buildingblocks.py:185-186).  Channels-last, float4 per lane.
+template <int VEC>
+__global__ void maxpool2_kernel(const float* __restrict__ in, int C, int D, int H, int W, int d, int h, int w,
+                                float* __restrict__ out) {
+    const int CV = C / VEC;
+    const int64_t n = (int64_t)d * h * w * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int cv = (int)(i % CV);
+        int64_t v = i / CV;
+        int x = (int)(v % w);
+        int64_t t = v / w;
+        int y = (int)(t % h);
+        int z = (int)(t / h);
+        float m[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) m[k] = -INFINITY;
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const float* p = in + ((((int64_t)(2 * z + dz)) * H + (2 * y + dy)) * W + (2 * x + dx)) * C +
+                                     (int64_t)cv * VEC;
+                    if constexpr (VEC == 4) {
+                        float4 q = *reinterpret_cast<const float4*>(p);
+                        // torch's max propagates NaN; fmaxf does not -- keep NaN visible
+                        m[0] = (q.x != q.x) ? q.x : fmaxf(m[0], q.x);
+                        m[1] = (q.y != q.y) ? q.y : fmaxf(m[1], q.y);
+                        m[2] = (q.z != q.z) ? q.z : fmaxf(m[2], q.z);
+                        m[3] = (q.w != q.w) ? q.w : fmaxf(m[3], q.w);
+                    } else {
+                        float q = *p;
+                        m[0] = (q != q) ? q : fmaxf(m[0], q);
+                    }
+                }
+        float* o = out + v * C + (int64_t)cv * VEC;
+        if constexpr (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(m[0], m[1], m[2], m[3]);
+        else *o = m[0];
+    }
+}
+
+// scripts/demo_test.py:88-89,113-118: full[range] += tile * (tile_input != 0)
+__global__ void stitch_kernel(const float* __restrict__ tile, const int64_t* __restrict__ tile_label,
+                              const float* __restrict__ tin, int td, int th, int tw, float* __restrict__ full, int H,
+                              int W, int z0, int y0, int x0) {
+    const int64_t n = (int64_t)td * th * tw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int x = (int)(i % tw);
+        int64_t t = i / tw;
+        int y = (int)(t % th);
+        int z = (int)(t / th);
+        float m = (tin == nullptr || tin[i] != 0.f) ? 1.f : 0.f;
+        // labels: (int64 * float mask) -> float, saved, re-read as int, summed into a float volume
+        float v = tile_label ? (float)(int)((float)tile_label[i] * m) : tile[i] * m;
+        full[((int64_t)(z0 + z) * H + (y0 + y)) * W + (x0 + x)] += v;
+    }
+}
+
+// tile output * (tile_input != 0), flattened (what a rank ships to rank 0)
+__global__ void mask_kernel(const float* __restrict__ tile, const int64_t* __restrict__ tile_label,
+                            const float* __restrict__ tin, int64_t n, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float m = tin[i] != 0.f ? 1.f : 0.f;
+        out[i] = tile_label ? (float)(int)((float)tile_label[i] * m) : tile[i] * m;
+    }
+}
+
+__global__ void count_add_kernel(float* __restrict__ cnt, int H, int W, int z0, int z1, int y0, int y1, int x0,
+                                 int x1) {
+    const int tw = x1 - x0, th = y1 - y0, td = z1 - z0;
+    const int64_t n = (int64_t)td * th * tw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int x = (int)(i % tw);
+        int64_t t = i / tw;
+        int y = (int)(t % th);
+        int z = (int)(t / th);
+        cnt[((int64_t)(z0 + z) * H + (y0 + y)) * W + (x0 + x)] += 1.f;
+    }
+}
+
+__global__ void divide_kernel(float* __restrict__ full, const float* __restrict__ cnt, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        full[i] = full[i] / cnt[i];
+}
+
+inline int grid_for(int64_t n, int tpb = 256, int cap = 4096) {
+    int64_t b = bfm_cdiv64(n, tpb);
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" int bfm_maxpool2(const float* in, int C, int D, int H, int W, float* out, bfm_stream_t stream) {
+    if (!in || !out || C <= 0 || D < 2 || H < 2 || W < 2) return BFM_E_ARG;
+    int d = D / 2, h = H / 2, w = W / 2;
+    bool v4 = (C % 4 == 0) && !((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15);
+    int64_t n = (int64_t)d * h * w * (v4 ? C / 4 : C);
+    if (v4) hipLaunchKernelGGL(maxpool2_kernel<4>, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), in, C, D, H, W, d, h, w, out);
+    else hipLaunchKernelGGL(maxpool2_kernel<1>, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), in, C, D, H, W, d, h, w, out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_stitch_accumulate(const float* tile, const int64_t* tile_label, const float* tile_input, int td,
+                                     int th, int tw, float* full, int D, int H, int W, int z0, int y0, int x0,
+                                     bfm_stream_t stream) {
+    if ((!tile && !tile_label) || !full || td <= 0 || th <= 0 || tw <= 0) return BFM_E_ARG;
+    if (z0 < 0 || y0 < 0 || x0 < 0 || z0 + td > D || y0 + th > H || x0 + tw > W) return BFM_E_SHAPE;
+    int64_t n = (int64_t)td * th * tw;
+    hipLaunchKernelGGL(stitch_kernel, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), tile, tile_label, tile_input, td,
+                       th, tw, full, H, W, z0, y0, x0);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_mask_tile(const float* tile, const int64_t* tile_label, const float* tile_input, int64_t n,
+                             float* out, bfm_stream_t stream) {
+    if ((!tile && !tile_label) || !tile_input || !out || n <= 0) return BFM_E_ARG;
+    hipLaunchKernelGGL(mask_kernel, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), tile, tile_label, tile_input, n, out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_tile_count_add(float* cnt, int D, int H, int W, int z0, int z1, int y0, int y1, int x0, int x1,
+                                  bfm_stream_t stream) {
+    if (!cnt) return BFM_E_ARG;
+    if (z0 < 0 || y0 < 0 || x0 < 0 || z1 > D || y1 > H || x1 > W || z1 <= z0 || y1 <= y0 || x1 <= x0)
+        return BFM_E_SHAPE;
+    int64_t n = (int64_t)(z1 - z0) * (y1 - y0) * (x1 - x0);
+    hipLaunchKernelGGL(count_add_kernel, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), cnt, H, W, z0, z1, y0, y1, x0,
+                       x1);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_divide_by_count(float* full, const float* cnt, int64_t n, bfm_stream_t stream) {
+    if (!full || !cnt || n <= 0) return BFM_E_ARG;
+    hipLaunchKernelGGL(divide_kernel, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), full, cnt, n);
+    return bfm_launch_status();
+}

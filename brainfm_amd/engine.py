@@ -1,0 +1,376 @@
+"""Device driver for the BrainFM inference path on MI355X.
+
+Owns the packed weights and drives the HIP kernels of libbrainfm_hip.so for
+``AbstractUNet.get_feature`` (Trainer/models/unet3d/model.py:195-209) and the
+fused tail (head.py:52-59, joiner.py:69-77,149-157,
+Trainer/models/__init__.py:272-354).  torch is used for device memory and
+streams only -- every arithmetic step is a kernel from brainfm_amd/csrc.
+
+Activations live in HBM as fp32 channels-last-3D (D,H,W,C) buffers; the
+tensors handed back to callers are NCDHW *views* of those buffers
+(torch.channels_last_3d strides), so shapes and values match the reference.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+LABELS_LEFT = [0, 1, 2, 3, 4, 7, 8, 9, 10, 14, 15, 17, 31, 34, 36, 38, 40, 42]
+LABELS_FULL = [0, 11, 12, 13, 16, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 46,
+               1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 14, 15, 17, 47, 49, 51, 53, 55,
+               18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 48, 50, 52, 54, 56]
+
+
+def features_per_level(f_maps, num_levels):
+    """number_of_features_per_level, Trainer/models/unet3d/utils.py:109-110."""
+    return [f_maps * 2 ** k for k in range(num_levels)]
+
+
+def nearest_index_map(n_in, n_out):
+    """F.interpolate(mode='nearest') source index per destination index:
+    min(floor(dst * float32(in/out)), in-1) -- ATen's nearest_neighbor_compute_source_index."""
+    scale = np.float32(n_in) / np.float32(n_out)
+    idx = np.floor(np.arange(n_out, dtype=np.float32) * scale).astype(np.int64)
+    return np.minimum(idx, n_in - 1).astype(np.int32)
+
+
+class _Layer:
+    __slots__ = ("name", "cin", "cout", "groups", "gamma", "beta", "kind", "wpacked", "wexp", "w_raw")
+
+
+class UNetEngine:
+    """Weights + kernels for UNet3D('gcl') inference.
+
+    state_dict uses the reference's key names
+    (``backbone.encoders.{i}.basic_module.SingleConv{j}.{groupnorm.weight,groupnorm.bias,conv.weight}``,
+    ``head.final_conv_{task}.{weight,bias}``); a ``backbone.``-less or ``module.``-prefixed dict is accepted
+    the way utils/checkpoint.py:558-571 suffix-matches names.
+    """
+
+    def __init__(self, state_dict, in_channels=1, f_maps=64, num_levels=6, num_groups=8, unit_feat=True,
+                 device="cuda", passes=3, eps=1e-5, slope=0.01):
+        self.lib = L.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.BfmError("UNetEngine needs a HIP device; the product path has no CPU fallback")
+        self.fm = features_per_level(f_maps, num_levels) if isinstance(f_maps, int) else list(f_maps)
+        self.in_channels = in_channels
+        self.num_groups = num_groups
+        self.unit_feat = bool(unit_feat)
+        self.passes = int(passes)
+        self.eps = float(eps)
+        self.slope = float(slope)
+        self._up_cache = {}
+        self._ws = None
+        self._plan_cache = {}
+        self.force_direct = False
+        self.prof = None            # bench.py: list collecting (start_event, end_event, flops, bytes) per MFMA conv launch
+        sd = self._normalise_keys(state_dict)
+        self.enc = []
+        for i, co in enumerate(self.fm):
+            ci = in_channels if i == 0 else self.fm[i - 1]
+            c1 = max(co // 2, ci)                       # DoubleConv encoder rule, buildingblocks.py:131-137
+            self.enc.append([self._make_layer(sd, "backbone.encoders.%d.basic_module.SingleConv1" % i, ci, c1),
+                             self._make_layer(sd, "backbone.encoders.%d.basic_module.SingleConv2" % i, c1, co)])
+        rev = list(reversed(self.fm))
+        self.dec = []
+        for i in range(len(rev) - 1):
+            ci, co = rev[i] + rev[i + 1], rev[i + 1]    # decoder rule, buildingblocks.py:139-141,313-319
+            self.dec.append([self._make_layer(sd, "backbone.decoders.%d.basic_module.SingleConv1" % i, ci, co),
+                             self._make_layer(sd, "backbone.decoders.%d.basic_module.SingleConv2" % i, co, co)])
+        self.sd = sd
+
+    # ------------------------------------------------------------------ weights
+    @staticmethod
+    def _normalise_keys(state_dict):
+        out = {}
+        for k, v in state_dict.items():
+            for marker in ("backbone.", "head."):
+                j = k.find(marker)
+                if j >= 0:
+                    out[k[j:]] = v
+                    break
+            else:
+                out[k] = v
+        return out
+
+    def _dev(self, t, dtype=torch.float32):
+        return torch.as_tensor(t).to(device=self.device, dtype=dtype).contiguous()
+
+    def _make_layer(self, sd, name, cin, cout):
+        ly = _Layer()
+        ly.name, ly.cin, ly.cout = name, cin, cout
+        ly.groups = self.num_groups if cin >= self.num_groups else 1      # buildingblocks.py:56-57
+        ly.gamma = self._dev(sd[name + ".groupnorm.weight"])
+        ly.beta = self._dev(sd[name + ".groupnorm.bias"])
+        w = self._dev(sd[name + ".conv.weight"])
+        if tuple(w.shape) != (cout, cin, 3, 3, 3):
+            raise L.BfmError("%s.conv.weight has shape %s, expected %s" % (name, tuple(w.shape), (cout, cin, 3, 3, 3)))
+        ly.w_raw = w
+        ly.kind = None
+        ly.wpacked = None
+        ly.wexp = 0
+        return ly
+
+    def _mfma_ok(self, ly, ca, cb):
+        return (not self.force_direct) and ca % 16 == 0 and cb % 16 == 0 and ly.cout % 64 == 0
+
+    def _pack(self, ly, mfma):
+        kind = "mfma" if mfma else "direct"
+        if ly.kind == kind:
+            return
+        st = L.stream_ptr()
+        if mfma:
+            nbytes = self.lib.bfm_pack_conv_weights_mfma_bytes(ly.cin, ly.cout)
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            wexp = C.c_int(0)
+            wmax = float(ly.w_raw.abs().max().item())
+            L.check(self.lib.bfm_pack_conv_weights_mfma(L.ptr(ly.w_raw), ly.cin, ly.cout, wmax, L.ptr(buf),
+                                                        C.byref(wexp), st), "pack_mfma " + ly.name)
+            ly.wexp = wexp.value
+        else:
+            buf = torch.empty(27 * ly.cin * ly.cout, dtype=torch.float32, device=self.device)
+            L.check(self.lib.bfm_pack_conv_weights_direct(L.ptr(ly.w_raw), ly.cin, ly.cout, L.ptr(buf), st),
+                    "pack_direct " + ly.name)
+        ly.wpacked = buf
+        ly.kind = kind
+
+    # ------------------------------------------------------------------ helpers
+    def _upsample_desc(self, lo, hi):
+        key = (tuple(lo), tuple(hi))
+        if key not in self._up_cache:
+            maps = [nearest_index_map(lo[a], hi[a]) for a in range(3)]
+            reps = [np.bincount(maps[a], minlength=lo[a]).astype(np.int32) for a in range(3)]
+            dev = [torch.from_numpy(m).to(self.device) for m in maps + reps]
+            up = L.Upsample(lo[0], lo[1], lo[2], *[t.data_ptr() for t in dev])
+            self._up_cache[key] = (up, dev)
+        return self._up_cache[key][0]
+
+    def _workspace(self, nbytes):
+        nbytes = max(int(nbytes), 256)
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _plan(self, cin, cout, dims):
+        key = (cin, cout, tuple(dims))
+        if key not in self._plan_cache:
+            cfg = (C.c_int * 8)()
+            L.check(self.lib.bfm_conv3x3x3_mfma_plan(cin, cout, dims[0], dims[1], dims[2], cfg), "mfma_plan")
+            self._plan_cache[key] = cfg
+        return self._plan_cache[key]
+
+    # ------------------------------------------------------------------ one SingleConv
+    def single_conv(self, ly, A, dims, B=None, lo_dims=None):
+        """GroupNorm -> Conv3d(3,p=1) -> LeakyReLU on cat((A, nearest_up(B))).
+        A: (D,H,W,CA) fp32, B: (d,h,w,CB) fp32 or None.  Returns (D,H,W,Cout)."""
+        D, H, W = dims
+        ca = A.shape[-1]
+        cb = 0 if B is None else B.shape[-1]
+        assert ca + cb == ly.cin, (ly.name, ca, cb, ly.cin)
+        st = L.stream_ptr()
+        up = self._upsample_desc(lo_dims, dims) if B is not None else None
+        upp = C.byref(up) if up is not None else None
+        scale = torch.empty(ly.cin, dtype=torch.float32, device=self.device)
+        shift = torch.empty(ly.cin, dtype=torch.float32, device=self.device)
+        bound = torch.empty(ly.groups, dtype=torch.float32, device=self.device)
+        wsb = self.lib.bfm_gn_stats_workspace(ca, cb, D, H, W, upp)
+        mfma = self._mfma_ok(ly, ca, cb)
+        cfg = None
+        wsc = 0
+        if mfma:
+            cfg = self._plan(ly.cin, ly.cout, dims)
+            wsc = self.lib.bfm_conv3x3x3_mfma_workspace(ly.cin, ly.cout, D, H, W, cfg[5])
+        ws = self._workspace(max(wsb, wsc))
+        L.check(self.lib.bfm_gn_stats(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(ly.gamma), L.ptr(ly.beta),
+                                      ly.groups, self.eps, L.ptr(scale), L.ptr(shift), L.ptr(bound), L.ptr(ws),
+                                      ws.numel(), st), "gn_stats " + ly.name)
+        self._pack(ly, mfma)
+        out = torch.empty((D, H, W, ly.cout), dtype=torch.float32, device=self.device)
+        if mfma:
+            ev = None
+            if self.prof is not None:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            L.check(self.lib.bfm_conv3x3x3_mfma(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(scale), L.ptr(shift),
+                                                L.ptr(bound), ly.groups, L.ptr(ly.wpacked), ly.wexp, ly.cout,
+                                                self.slope, self.passes, cfg, L.ptr(out), L.ptr(ws), ws.numel(), st),
+                    "conv_mfma " + ly.name)
+            if ev is not None:
+                ev[1].record()
+                nv = D * H * W
+                lo = 0 if B is None else lo_dims[0] * lo_dims[1] * lo_dims[2]
+                self.prof.append((ev[0], ev[1], 2.0 * 27 * ly.cin * ly.cout * nv,
+                                  4.0 * (nv * ca + lo * cb + nv * ly.cout + 27 * ly.cin * ly.cout)))
+        else:
+            L.check(self.lib.bfm_conv3x3x3_direct(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(scale),
+                                                  L.ptr(shift), L.ptr(ly.wpacked), ly.cout, self.slope, L.ptr(out),
+                                                  st), "conv_direct " + ly.name)
+        return out
+
+    def maxpool(self, X, dims):
+        D, H, W = dims
+        c = X.shape[-1]
+        out = torch.empty((D // 2, H // 2, W // 2, c), dtype=torch.float32, device=self.device)
+        L.check(self.lib.bfm_maxpool2(L.ptr(X), c, D, H, W, L.ptr(out), L.stream_ptr()), "maxpool2")
+        return out, (D // 2, H // 2, W // 2)
+
+    # ------------------------------------------------------------------ backbone
+    def backbone_cl(self, x_cl, dims):
+        """x_cl: (D,H,W,Cin).  Returns the decoder feature maps as channels-last buffers,
+        deepest first, the last one NOT yet L2-normalised (the tail kernel does that)."""
+        skips = []
+        x, d = x_cl, tuple(dims)
+        for i, (l1, l2) in enumerate(self.enc):
+            if i > 0:
+                if min(d) < 2:
+                    raise L.BfmError("volume %s too small for %d pooling levels" % (dims, len(self.enc) - 1))
+                x, d = self.maxpool(x, d)
+            x = self.single_conv(l1, x, d)
+            x = self.single_conv(l2, x, d)
+            skips.insert(0, (x, d))
+        skips = skips[1:]
+        feats = [(x, d)]
+        for (l1, l2), (skip, sd_) in zip(self.dec, skips):
+            y = self.single_conv(l1, skip, sd_, B=x, lo_dims=d)
+            x = self.single_conv(l2, y, sd_)
+            d = sd_
+            feats.append((x, d))
+        return feats
+
+    @staticmethod
+    def as_ncdhw(buf):
+        """(D,H,W,C) buffer -> (1,C,D,H,W) view (channels_last_3d strides)."""
+        return buf.permute(3, 0, 1, 2).unsqueeze(0)
+
+    def to_cl(self, x):
+        """(1,C,D,H,W) tensor of any layout -> (D,H,W,C) contiguous fp32 device buffer."""
+        if x.dim() != 5 or x.shape[0] != 1:
+            raise L.BfmError("expected a (1,C,D,H,W) tensor, got %s" % (tuple(x.shape),))
+        x = x.to(device=self.device, dtype=torch.float32)
+        return x[0].permute(1, 2, 3, 0).contiguous()
+
+    # ------------------------------------------------------------------ tail
+    def make_tail(self, out_channels, left_hemis_only=False, max_surf_distance=3.0, uncertainty=False):
+        return Tail(self, out_channels, left_hemis_only, max_surf_distance)
+
+
+class Tail:
+    """Head weights + role table for bfm_tail_heads (data-driven head set)."""
+
+    def __init__(self, eng, out_channels, left_hemis_only, max_surf_distance):
+        self.eng = eng
+        dev = eng.device
+        sd = eng.sd
+        self.out_channels = OrderedDict(out_channels)
+        c_feat = eng.fm[0]
+        rows_w, rows_b, roles, names = [], [], [], []
+        self.row_of = {}
+        for task, n in self.out_channels.items():
+            if n <= 0:
+                raise L.BfmError("head '%s' (age-style pooled head) is outside the inference path" % task)
+            w = torch.as_tensor(sd["head.final_conv_%s.weight" % task]).reshape(n, c_feat)
+            b = torch.as_tensor(sd["head.final_conv_%s.bias" % task]).reshape(n)
+            self.row_of[task] = (len(roles), n)
+            rows_w.append(w)
+            rows_b.append(b)
+            for j in range(n):
+                if task == "CT":
+                    r = L.ROLE_CT if j == 0 else L.ROLE_PLAIN
+                elif task == "bias_field_log":
+                    r = L.ROLE_BIAS_LOG if j == 0 else L.ROLE_PLAIN
+                elif task == "segmentation":
+                    r = L.ROLE_SEG
+                elif task == "distance":
+                    r = L.ROLE_DIST
+                elif task == "high_res_residual":
+                    r = L.ROLE_SR if j == 0 else L.ROLE_PLAIN
+                elif task == "pathology":
+                    r = L.ROLE_PATHOL
+                else:
+                    r = L.ROLE_PLAIN
+                roles.append(r)
+                names.append((task, j))
+        self.n_out = len(roles)
+        self.c_feat = c_feat
+        self.head_w = torch.cat(rows_w, 0).to(device=dev, dtype=torch.float32).contiguous()
+        self.head_b = torch.cat(rows_b, 0).to(device=dev, dtype=torch.float32).contiguous()
+        self.roles = torch.tensor(roles, dtype=torch.int32, device=dev)
+        # output maps in post-processor order (Trainer/models/__init__.py:307-352)
+        self.map_names = []
+        slot_of_row = [-1] * self.n_out
+
+        def add(name, row=None):
+            self.map_names.append(name)
+            if row is not None:
+                slot_of_row[row] = len(self.map_names) - 1
+            return len(self.map_names) - 1
+
+        self.slot_high_res = -1
+        self.slot_fake = -1
+        for task, (r0, n) in self.row_of.items():
+            if task in ("T1", "T2", "FLAIR", "CT", "pathology"):
+                add(task, r0)
+                for j in range(1, n):
+                    add("%s_sigma" % task, r0 + j)
+            elif task == "bias_field_log":
+                add("bias_field", r0)
+            elif task == "high_res_residual":
+                add("high_res_residual", r0)
+            elif task == "distance":
+                for j, nm in enumerate(["lp", "lw", "rp", "rw"][:n]):
+                    add(nm, r0 + j)
+            elif task == "registration":
+                for j, nm in enumerate(["regx", "regy", "regz"][:n]):
+                    add(nm, r0 + j)
+            elif task == "segmentation":
+                pass
+            else:
+                for j in range(n):
+                    add(task if n == 1 else "%s_%d" % (task, j), r0 + j)
+        if "high_res_residual" in self.row_of:
+            self.slot_high_res = add("high_res")
+        if "distance" in self.row_of:
+            self.slot_fake = add("fake_cortical")
+        self.out_slot = torch.tensor(slot_of_row, dtype=torch.int32, device=dev)
+        self.lut_list = LABELS_LEFT if left_hemis_only else LABELS_FULL
+        seg = self.row_of.get("segmentation", (0, 0))
+        if seg[1] and seg[1] != len(self.lut_list):
+            raise L.BfmError("segmentation head has %d channels but the label list has %d" % (seg[1], len(self.lut_list)))
+        self.seg_lut = torch.tensor(self.lut_list, dtype=torch.int32, device=dev)
+        dist = self.row_of.get("distance", (0, 0))
+        self.desc = L.TailDesc(self.n_out, c_feat, self.head_w.data_ptr(), self.head_b.data_ptr(),
+                               self.roles.data_ptr(), self.out_slot.data_ptr(), seg[0], seg[1],
+                               self.seg_lut.data_ptr(), dist[1], dist[0], float(max_surf_distance),
+                               1 if eng.unit_feat else 0, self.slot_high_res, self.slot_fake)
+
+    def run(self, feat_cl, dims, input_cl=None, want_feat=True, want_seg=True):
+        """Fused tail.  feat_cl: (D,H,W,c_feat) raw last decoder output.
+        Returns (maps: {name: (D,H,W) fp32}, feat_norm (D,H,W,C)|None, seg (D,H,W,n_seg)|None, label (D,H,W) int64|None)."""
+        eng = self.eng
+        D, H, W = dims
+        nvox = D * H * W
+        dev = eng.device
+        maps_buf = torch.empty((len(self.map_names), D, H, W), dtype=torch.float32, device=dev)
+        ptrs = torch.tensor([maps_buf[i].data_ptr() for i in range(len(self.map_names))], dtype=torch.int64, device=dev)
+        nseg = self.desc.n_seg
+        feat_norm = torch.empty_like(feat_cl) if want_feat else None
+        seg = torch.empty((D, H, W, nseg), dtype=torch.float32, device=dev) if (want_seg and nseg) else None
+        label = torch.empty((D, H, W), dtype=torch.int64, device=dev) if nseg else None
+        L.check(eng.lib.bfm_tail_heads(L.ptr(feat_cl), L.ptr(input_cl), nvox, C.byref(self.desc), L.ptr(feat_norm),
+                                       L.ptr(ptrs), L.ptr(seg), L.ptr(label), None, L.stream_ptr()), "tail_heads")
+        maps = OrderedDict((n, maps_buf[i]) for i, n in enumerate(self.map_names))
+        return maps, feat_norm, seg, label
+
+    def run_raw(self, feat_cl, dims, want_feat=True):
+        """TaskHead.forward only: raw logits (D,H,W,n_out) [+ normalised features]."""
+        eng = self.eng
+        D, H, W = dims
+        raw = torch.empty((D, H, W, self.n_out), dtype=torch.float32, device=eng.device)
+        feat_norm = torch.empty_like(feat_cl) if (want_feat and eng.unit_feat) else None
+        L.check(eng.lib.bfm_tail_heads(L.ptr(feat_cl), None, D * H * W, C.byref(self.desc), L.ptr(feat_norm), None,
+                                       None, None, L.ptr(raw), L.stream_ptr()), "tail_heads(raw)")
+        return raw, feat_norm

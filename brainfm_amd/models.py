@@ -1,0 +1,557 @@
+"""Host-side mirror of ``Trainer/models`` for the inference hot path.
+
+Same names, argument meaning and return structures as the reference
+(Trainer/models/__init__.py, backbone.py, head.py, joiner.py,
+unet3d/model.py) so that ``scripts/demo_test.py`` / ``demo_get_feature.py`` /
+``train.py`` can bind to it, but every op runs in libbrainfm_hip.so:
+
+  build_model(gen_args, train_args, device) -> (gen_args, train_args, model, processors, criterion, postprocessor)
+  model(input_list, input_name='input', cond=[]) -> (outs, inputs)
+  model.backbone.get_feature(x) -> list of decoder feature maps
+  model.head(feat_list) -> {task: raw head output}
+  processor(outputs, samples) ; postprocessor(gen_args, train_args, outputs, samples, target, feats, tasks)
+
+The nn.Module tree exists to carry parameters under the reference's
+state-dict names (so reference checkpoints load unchanged); its torch
+``forward`` methods are never used.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .engine import UNetEngine, Tail, LABELS_FULL, LABELS_LEFT, features_per_level
+
+label_list_segmentation_brainseg_left = LABELS_LEFT
+label_list_segmentation_brainseg_with_extracerebral = LABELS_FULL
+
+
+# --------------------------------------------------------------------------- helpers
+def _cl_rows(t):
+    """(1,C,D,H,W) tensor -> (tensor_keepalive, data_ptr, row_stride, C, nvox) with channel stride 1.
+    Views cut out of a channels-last buffer are used in place; anything else is repacked."""
+    assert t.dim() == 5 and t.shape[0] == 1, tuple(t.shape)
+    _, c, d, h, w = t.shape
+    s = t.stride()
+    rs = s[4]
+    ok = (c == 1 or s[1] == 1) and s[3] == w * rs and s[2] == h * w * rs and rs >= c and t.dtype == torch.float32
+    if not ok:
+        t = t.to(torch.float32)[0].permute(1, 2, 3, 0).contiguous().permute(3, 0, 1, 2).unsqueeze(0)
+        rs = c
+    return t, t.data_ptr(), rs, c, d * h * w
+
+
+def _new_like_spatial(t, c=1, dtype=torch.float32):
+    _, _, d, h, w = t.shape
+    buf = torch.empty((d, h, w, c), dtype=dtype, device=t.device)
+    return buf, buf.permute(3, 0, 1, 2).unsqueeze(0)
+
+
+def _unary(op, t, a=0.0, b=0.0):
+    """Elementwise op on a (1,C,D,H,W) float tensor, channel by channel (C is 1..4 here)."""
+    lib = L.load()
+    t, p, rs, c, n = _cl_rows(t)
+    buf, view = _new_like_spatial(t, c)
+    for j in range(c):
+        L.check(lib.bfm_ew_unary(op, C.c_void_p(p + 4 * j), rs, C.c_void_p(buf.data_ptr() + 4 * j), c, n,
+                                 float(a), float(b), L.stream_ptr()), "ew_unary")
+    return view
+
+
+def _binary(op, x, y, a=0.0):
+    lib = L.load()
+    x, px, xs, c, n = _cl_rows(x)
+    y, py, ys, c2, _ = _cl_rows(y)
+    assert c == 1 and c2 == 1
+    buf, view = _new_like_spatial(x, 1)
+    L.check(lib.bfm_ew_binary(op, C.c_void_p(px), xs, C.c_void_p(py), ys, L.ptr(buf), 1, n, float(a),
+                              L.stream_ptr()), "ew_binary")
+    return view
+
+
+def _argmax_lut(prob, lut_list):
+    """LUT[argmax(prob, 1, keepdim=True)] -> (1,1,D,H,W) int64 (Trainer/models/__init__.py:347-349)."""
+    lib = L.load()
+    prob, p, rs, c, n = _cl_rows(prob)
+    lut = torch.tensor(lut_list, dtype=torch.int32, device=prob.device)
+    _, _, d, h, w = prob.shape
+    out = torch.empty((1, 1, d, h, w), dtype=torch.int64, device=prob.device)
+    L.check(lib.bfm_argmax_lut_cl(C.c_void_p(p), rs, c, L.ptr(lut), L.ptr(out), n, L.stream_ptr()), "argmax_lut")
+    return out
+
+
+# --------------------------------------------------------------------------- process_args
+def process_args(gen_args, train_args, task):
+    """Trainer/models/__init__.py:37-125 (task -> out_channels table), same side effects."""
+    gen_args.tasks = [key for (key, value) in vars(task).items() if value]
+    train_args.size = gen_args.generator.size
+    if gen_args.generator.left_hemis_only:
+        gen_args.label_list_segmentation = LABELS_LEFT
+    else:
+        gen_args.label_list_segmentation = LABELS_FULL
+    gen_args.n_labels = len(gen_args.label_list_segmentation)
+    unc = getattr(train_args.losses, "uncertainty", None) is not None
+    oc, names, aux, tgt = OrderedDict(), [], [], []
+    if "contrastive" not in gen_args.tasks:
+        for t in ("T1", "T2", "FLAIR", "CT"):
+            if t in gen_args.tasks:
+                oc[t] = 2 if unc else 1
+                names.append(t)
+                tgt.append(t)
+                if unc:
+                    aux.append(t + "_sigma")
+        if "bias_field" in gen_args.tasks:
+            oc["bias_field_log"] = 2 if unc else 1
+            names.append("bias_field")
+            tgt.append("bias_field")
+        if "segmentation" in gen_args.tasks:
+            oc["segmentation"] = gen_args.n_labels
+            names.append("label")
+            tgt.append("label")
+        if "distance" in gen_args.tasks:
+            if gen_args.generator.left_hemis_only:
+                oc["distance"] = 2
+                names += ["distance", "lp", "lw"]
+                tgt += ["distance", "lp", "lw"]
+            else:
+                oc["distance"] = 4
+                names += ["distance", "lp", "lw", "rp", "rw"]
+                tgt += ["distance", "lp", "lw", "rp", "rw"]
+        if "registration" in gen_args.tasks:
+            oc["registration"] = 3
+            names += ["registration", "regx", "regy", "regz"]
+            tgt += ["registration", "regx", "regy", "regz"]
+        if "surface" in gen_args.tasks:
+            oc["surface"] = 8
+            names.append("surface")
+            tgt.append("surface")
+        if "super_resolution" in gen_args.tasks:
+            oc["high_res_residual"] = 2 if unc else 1
+            names += ["high_res", "high_res_residual"]
+            tgt += ["high_res", "high_res_residual"]
+        if "pathology" in gen_args.tasks:
+            oc["pathology"] = 1
+            names.append("pathology")
+            tgt.append("pathology")
+        if "age" in gen_args.tasks:
+            oc["age"] = -1
+        if getattr(train_args.losses, "implicit_pathol", False):
+            names += ["implicit_pathol_orig", "implicit_pathol_pred"]
+    train_args.out_channels = oc
+    train_args.output_names = names
+    train_args.aux_output_names = aux
+    train_args.target_names = tgt
+    return gen_args, train_args
+
+
+# --------------------------------------------------------------------------- parameter tree
+class _SingleConv(nn.Module):
+    def __init__(self, cin, cout, num_groups):
+        super().__init__()
+        g = num_groups if cin >= num_groups else 1
+        assert cin % g == 0
+        self.groupnorm = nn.GroupNorm(g, cin)
+        self.conv = nn.Conv3d(cin, cout, 3, padding=1, bias=False)
+
+
+class _DoubleConv(nn.Module):
+    def __init__(self, cin, cout, encoder, num_groups):
+        super().__init__()
+        if encoder:
+            c1 = max(cout // 2, cin)
+            self.SingleConv1 = _SingleConv(cin, c1, num_groups)
+            self.SingleConv2 = _SingleConv(c1, cout, num_groups)
+        else:
+            self.SingleConv1 = _SingleConv(cin, cout, num_groups)
+            self.SingleConv2 = _SingleConv(cout, cout, num_groups)
+
+
+class _Block(nn.Module):
+    def __init__(self, cin, cout, encoder, num_groups):
+        super().__init__()
+        self.basic_module = _DoubleConv(cin, cout, encoder, num_groups)
+
+
+class UNet3D(nn.Module):
+    """Counterpart of UNet3D / AbstractUNet (unet3d/model.py:171-232) on the HIP engine."""
+
+    def __init__(self, in_channels, f_maps, layer_order="gcl", num_groups=8, num_levels=5, is_unit_vector=False,
+                 conv_padding=1, passes=3, **kwargs):
+        super().__init__()
+        if layer_order != "gcl" or conv_padding != 1:
+            raise NotImplementedError("only the shipped 'gcl' / padding=1 configuration is on the hot path")
+        self.f_maps = features_per_level(f_maps, num_levels) if isinstance(f_maps, int) else list(f_maps)
+        assert len(self.f_maps) > 1, "Required at least 2 levels in the U-Net"
+        self.in_channels = in_channels
+        self.num_groups = num_groups
+        self.is_unit_vector = is_unit_vector
+        self.passes = passes
+        enc = []
+        for i, co in enumerate(self.f_maps):
+            enc.append(_Block(in_channels if i == 0 else self.f_maps[i - 1], co, True, num_groups))
+        self.encoders = nn.ModuleList(enc)
+        rev = list(reversed(self.f_maps))
+        self.decoders = nn.ModuleList([_Block(rev[i] + rev[i + 1], rev[i + 1], False, num_groups)
+                                       for i in range(len(rev) - 1)])
+        self._engine = None
+        self._engine_key = None
+        self._extra_sd = {}
+
+    # engine is rebuilt whenever a parameter was modified or moved
+    def _version_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def engine(self, head=None):
+        key = (self._version_key(), None if head is None else head._version_key())
+        if self._engine is None or self._engine_key != key:
+            sd = {"backbone." + k: v.detach() for k, v in self.state_dict().items()}
+            if head is not None:
+                sd.update({"head." + k: v.detach() for k, v in head.state_dict().items()})
+            dev = next(self.parameters()).device
+            self._engine = UNetEngine(sd, self.in_channels, self.f_maps, len(self.f_maps), self.num_groups,
+                                      self.is_unit_vector, device=dev, passes=self.passes)
+            self._engine_key = key
+            self._tail_cache = {}
+        return self._engine
+
+    @torch.no_grad()
+    def _feats_cl(self, x, head=None):
+        eng = self.engine(head)
+        x_cl = eng.to_cl(x)
+        return eng, x_cl, eng.backbone_cl(x_cl, tuple(x.shape[2:]))
+
+    @torch.no_grad()
+    def get_feature(self, x):
+        """unet3d/model.py:195-209: list of decoder features (deepest first), last one unit-normalised."""
+        outs = []
+        for b in range(x.shape[0]):
+            eng, _, feats = self._feats_cl(x[b:b + 1])
+            bufs = [f for f, _ in feats]
+            if self.is_unit_vector:
+                bufs[-1] = normalize_cl(eng, bufs[-1], feats[-1][1])
+            outs.append([UNetEngine.as_ncdhw(f) for f in bufs])
+        if len(outs) == 1:
+            return outs[0]
+        return [torch.cat([o[i] for o in outs], 0) for i in range(len(outs[0]))]
+
+    def forward(self, x):
+        return self.get_feature(x)[-1]
+
+
+def normalize_cl(eng, feat_cl, dims):
+    """F.normalize(dim=1) alone (tail kernel with no heads)."""
+    D, H, W = dims
+    c = feat_cl.shape[-1]
+    if c > 64 or c % 4:
+        raise L.BfmError("unit_feat needs c_feat <= 64 and a multiple of 4 (got %d)" % c)
+    z = torch.zeros(1, dtype=torch.float32, device=feat_cl.device)
+    zi = torch.zeros(1, dtype=torch.int32, device=feat_cl.device)
+    desc = L.TailDesc(0, c, z.data_ptr(), z.data_ptr(), zi.data_ptr(), zi.data_ptr(), 0, 0, zi.data_ptr(), 0, 0, 0.0,
+                      1, -1, -1)
+    out = torch.empty_like(feat_cl)
+    L.check(eng.lib.bfm_tail_heads(L.ptr(feat_cl), None, D * H * W, C.byref(desc), L.ptr(out), None, None, None, None,
+                                   L.stream_ptr()), "normalize")
+    return out
+
+
+class TaskHead(nn.Module):
+    """TaskHead with task_f_maps=[c]: one 1x1x1 conv + bias per task (head.py:20-67)."""
+
+    def __init__(self, args, f_maps_list, out_channels, is_3d=True, out_feat_level=-1, exclude_keys=[], *kwargs):
+        super().__init__()
+        if len(f_maps_list) != 1:
+            raise NotImplementedError("hidden head layers (task_f_maps of length > 1) are not on the hot path")
+        self.out_feat_level = out_feat_level
+        self.out_channels = OrderedDict((k, v) for k, v in out_channels.items() if k not in exclude_keys)
+        self.out_names = self.out_channels.keys()
+        self.c_feat = f_maps_list[-1]
+        for name, n in self.out_channels.items():
+            if n <= 0:
+                raise NotImplementedError("pooled scalar heads (age) are outside the inference hot path")
+            self.add_module("final_conv_%s" % name, nn.Conv3d(self.c_feat, n, 1))
+        self._tail = None
+        self._tail_key = None
+        self.left_hemis_only = False
+        self.max_surf_distance = 3.0
+
+    def _version_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def tail(self, eng):
+        key = (id(eng), self._version_key(), self.left_hemis_only, self.max_surf_distance)
+        if self._tail is None or self._tail_key != key:
+            self._tail = Tail(eng, self.out_channels, self.left_hemis_only, self.max_surf_distance)
+            self._tail_key = key
+        return self._tail
+
+    def split_raw(self, raw_cl):
+        """(D,H,W,n_out) raw logits -> {task: (1,n,D,H,W) view}."""
+        out, r0 = OrderedDict(), 0
+        for name, n in self.out_channels.items():
+            out[name] = raw_cl[..., r0:r0 + n].permute(3, 0, 1, 2).unsqueeze(0)
+            r0 += n
+        return out
+
+    @torch.no_grad()
+    def forward(self, x, *kwargs):
+        """x: list of feature maps; uses x[out_feat_level] as is (already normalised by the backbone)."""
+        x = x[self.out_feat_level]
+        res = []
+        for b in range(x.shape[0]):
+            dev = x.device
+            sd = {"head." + k: v.detach() for k, v in self.state_dict().items()}
+            eng = _HeadOnlyEngine(sd, self.c_feat, dev)
+            tail = Tail(eng, self.out_channels, self.left_hemis_only, self.max_surf_distance)
+            feat_cl = x[b].permute(1, 2, 3, 0).contiguous().to(torch.float32)
+            raw, _ = tail.run_raw(feat_cl, tuple(x.shape[2:]), want_feat=False)
+            res.append(self.split_raw(raw))
+        if len(res) == 1:
+            return res[0]
+        return OrderedDict((k, torch.cat([r[k] for r in res], 0)) for k in res[0])
+
+
+class _HeadOnlyEngine:
+    """Just enough engine for Tail when the head is called on its own features."""
+
+    def __init__(self, sd, c_feat, device):
+        self.lib = L.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise L.BfmError("TaskHead needs a HIP device; the product path has no CPU fallback")
+        self.sd = sd
+        self.fm = [c_feat]
+        self.unit_feat = False
+
+
+# --------------------------------------------------------------------------- joiner / processors
+class MultiInputIndepJoiner(nn.Module):
+    """joiner.py:161-185.  Backbone and heads share one pass: the tail kernel normalises the
+    last feature map and evaluates every head while the features are in registers."""
+
+    def __init__(self, backbone, head, device, postfix=""):
+        super().__init__()
+        self.backbone = backbone.to(device)
+        self.head = head.to(device) if head is not None else None
+        self.postfix = postfix
+
+    @torch.no_grad()
+    def forward(self, input_list, input_name="input", cond=[]):
+        outs = []
+        for i, x in enumerate(input_list):
+            xin = x[input_name]
+            if len(cond) > 0:
+                xin = torch.concat([xin, cond[i]], dim=1)
+            per_b = []
+            for b in range(xin.shape[0]):
+                eng, x_cl, feats = self.backbone._feats_cl(xin[b:b + 1], self.head)
+                bufs = [f for f, _ in feats]
+                dims = feats[-1][1]
+                out = OrderedDict()
+                if self.head is not None:
+                    tail = self.head.tail(eng)
+                    raw, fnorm = tail.run_raw(bufs[-1], dims, want_feat=True)
+                    if fnorm is not None:
+                        bufs[-1] = fnorm
+                    heads = self.head.split_raw(raw)
+                elif self.backbone.is_unit_vector:
+                    bufs[-1] = normalize_cl(eng, bufs[-1], dims)
+                    heads = {}
+                else:
+                    heads = {}
+                out["feat" + self.postfix] = [UNetEngine.as_ncdhw(f) for f in bufs]
+                out.update(heads)
+                per_b.append(out)
+            if len(per_b) == 1:
+                outs.append(per_b[0])
+            else:
+                m = OrderedDict()
+                for k in per_b[0]:
+                    if isinstance(per_b[0][k], list):
+                        m[k] = [torch.cat([p[k][j] for p in per_b], 0) for j in range(len(per_b[0][k]))]
+                    else:
+                        m[k] = torch.cat([p[k] for p in per_b], 0)
+                outs.append(m)
+        return outs, [inp[input_name] for inp in input_list]
+
+
+class SegProcessor(nn.Module):
+    """joiner.py:69-77: softmax over channels."""
+
+    def forward(self, outputs, *kwargs):
+        lib = L.load()
+        for output in outputs:
+            t, p, rs, c, n = _cl_rows(output["segmentation"])
+            buf, view = _new_like_spatial(t, c)
+            L.check(lib.bfm_softmax_cl(C.c_void_p(p), rs, c, L.ptr(buf), c, n, L.stream_ptr()), "softmax")
+            output["segmentation"] = view
+        return outputs
+
+
+class DistProcessor(nn.Module):
+    """joiner.py:149-157: clamp to +-max_surf_distance."""
+
+    def __init__(self, gen_args):
+        super().__init__()
+        self.gen_args = gen_args
+
+    def forward(self, outputs, *kwargs):
+        m = float(self.gen_args.max_surf_distance)
+        for output in outputs:
+            output["distance"] = _unary(L.EW_CLAMP, output["distance"], -m, m)
+        return outputs
+
+
+class PatholProcessor(nn.Module):
+    """joiner.py:79-87: sigmoid."""
+
+    def forward(self, outputs, *kwargs):
+        for output in outputs:
+            output["pathology"] = _unary(L.EW_SIGMOID, output["pathology"])
+        return outputs
+
+
+class UncertaintyProcessor(nn.Module):
+    """joiner.py:44-55 (slicing only)."""
+
+    def __init__(self, output_names):
+        super().__init__()
+        self.output_names = output_names
+
+    def forward(self, outputs, *kwargs):
+        for name in self.output_names:
+            if "image" in name:
+                for output in outputs:
+                    output[name + "_sigma"] = output[name][:, 1][:, None]
+                    output[name] = output[name][:, 0][:, None]
+        return outputs
+
+
+def get_processors(gen_args, train_args, tasks, device, exclude_keys=[]):
+    """joiner.py:238-256."""
+    processors = []
+    if getattr(train_args.losses, "uncertainty", None) is not None:
+        processors.append(UncertaintyProcessor(train_args.output_names))
+    if getattr(train_args.losses, "implicit_pathol", False):
+        raise NotImplementedError("PatholSeg (implicit_pathol) needs external checkpoints; outside the hot path")
+    if "segmentation" in tasks and "segmentation" not in exclude_keys:
+        processors.append(SegProcessor())
+    if "distance" in tasks:
+        processors.append(DistProcessor(gen_args))
+    if "pathology" in tasks and "pathology" not in exclude_keys:
+        processors.append(PatholProcessor())
+    return processors
+
+
+def get_postprocessor(gen_args, train_args, outputs, samples, target, feats, tasks):
+    """Trainer/models/__init__.py:272-354, same mutation pattern, HIP elementwise kernels underneath."""
+    left = gen_args.generator.left_hemis_only
+    if "distance" in tasks and target is not None:
+        names = ["lp", "lw"] if left else ["lp", "lw", "rp", "rw"]
+        target.update({n: target["distance"][:, j][:, None] for j, n in enumerate(names)})
+        del target["distance"]
+    if "registration" in tasks and target is not None:
+        target.update({n: target["registration"][:, j][:, None] for j, n in enumerate(["regx", "regy", "regz"])})
+        del target["registration"]
+    if "CT" in tasks and target is not None:
+        target["CT"] = _unary(L.EW_AFFINE, target["CT"], 1000.0, 0.0)
+    if "segmentation" in tasks and target is not None:
+        target["label"] = _argmax_lut(target["segmentation"], gen_args.label_list_segmentation)
+
+    for i, output in enumerate(outputs):
+        if feats is not None:
+            output.update({"feat": feats[i]["feat"]})
+        if "super_resolution" in tasks:
+            output.update({"high_res": _binary(L.EW_ADD, output["high_res_residual"], samples[i]["input"])})
+            if "high_res_residual" in samples[i]:
+                samples[i].update({"high_res": _binary(L.EW_ADD, samples[i]["high_res_residual"], samples[i]["input"])})
+        if "bias_field" in tasks:
+            output.update({"bias_field": _unary(L.EW_EXP, output["bias_field_log"])})
+            del output["bias_field_log"]
+            if "bias_field_log" in samples[i]:
+                samples[i].update({"bias_field": _unary(L.EW_EXP, samples[i]["bias_field_log"])})
+                del samples[i]["bias_field_log"]
+        if "distance" in tasks:
+            d = output["distance"]
+            names = ["lp", "lw"] if left else ["lp", "lw", "rp", "rw"]
+            output.update({n: d[:, j][:, None] for j, n in enumerate(names)})
+            dd, p, rs, c, n = _cl_rows(d)
+            buf, view = _new_like_spatial(dd, 1)
+            L.check(L.load().bfm_fake_cortical(C.c_void_p(p), rs, c, L.ptr(buf), n, L.stream_ptr()), "fake_cortical")
+            output.update({"fake_cortical": view})
+            del output["distance"]
+        if "registration" in tasks:
+            r = output["registration"]
+            output.update({n: r[:, j][:, None] for j, n in enumerate(["regx", "regy", "regz"])})
+            del output["registration"]
+        if "segmentation" in tasks:
+            output["label"] = _argmax_lut(output["segmentation"], gen_args.label_list_segmentation)
+        if "CT" in tasks:
+            output["CT"] = _unary(L.EW_AFFINE, output["CT"], 1000.0, 0.0)
+    return outputs, samples, target
+
+
+# --------------------------------------------------------------------------- factory
+backbone_options = {"unet3d": UNet3D}
+
+
+def build_backbone(args, backbone, num_cond=0):
+    """backbone.py:21-26."""
+    if backbone not in backbone_options:
+        raise NotImplementedError("backbone '%s' is outside the hot path (only unet3d is shipped in the configs)" % backbone)
+    return backbone_options[backbone](args.in_channels + num_cond, args.f_maps, args.layer_order, args.num_groups,
+                                      args.num_levels, args.unit_feat, passes=getattr(args, "mfma_passes", 3))
+
+
+def get_head(train_args, f_maps_list, out_channels, is_3d, out_feat_level, stage=0, exclude_keys=[]):
+    """head.py:175-183 (plain unet3d branch)."""
+    return TaskHead(train_args, f_maps_list, out_channels, is_3d, out_feat_level, exclude_keys)
+
+
+def get_joiner(task, backbone, head, device, postfix=""):
+    return MultiInputIndepJoiner(backbone, head, device, postfix=postfix)
+
+
+def build_model(gen_args, train_args, device="cpu"):
+    """Trainer/models/__init__.py:404-420.  criterion is None: losses belong to the training
+    step (SURVEY 'next' row N2), not to this path."""
+    gen_args, train_args = process_args(gen_args, train_args, task=gen_args.task)
+    backbone = build_backbone(train_args, train_args.backbone)
+    head = get_head(train_args, train_args.task_f_maps, train_args.out_channels, True, -1)
+    head.left_hemis_only = bool(gen_args.generator.left_hemis_only)
+    head.max_surf_distance = float(gen_args.max_surf_distance)
+    model = get_joiner(gen_args.tasks, backbone, head, device)
+    processors = get_processors(gen_args, train_args, gen_args.tasks, device)
+    criterion = None
+    model.to(device)
+    return gen_args, train_args, model, processors, criterion, get_postprocessor
+
+
+# --------------------------------------------------------------------------- checkpoint loading
+def load_checkpoint(ckp_path, models, model_keys=["model"], to_print=False):
+    """utils/checkpoint.py:409-457 reduced to what inference needs: pick the first checkpoint key
+    containing 'model', then match parameter names by suffix (:558-571) so DDP 'module.' prefixes load."""
+    ckp = torch.load(ckp_path, map_location="cpu")
+    for model, mkey in zip(models, model_keys):
+        key = next((k for k in ckp if mkey in k), None)
+        sd = ckp[key] if key is not None else ckp
+        load_state_dict_by_suffix(model, sd)
+    return ckp
+
+
+def load_state_dict_by_suffix(model, loaded):
+    own = model.state_dict()
+    new = {}
+    lkeys = list(loaded.keys())
+    for k in own:
+        cands = [lk for lk in lkeys if lk == k or lk.endswith("." + k) or k.endswith("." + lk)]
+        if not cands:
+            raise KeyError("checkpoint has no tensor matching '%s'" % k)
+        lk = max(cands, key=len)
+        if tuple(loaded[lk].shape) != tuple(own[k].shape):
+            raise ValueError("shape mismatch for %s: %s vs %s" % (k, tuple(loaded[lk].shape), tuple(own[k].shape)))
+        new[k] = loaded[lk]
+    model.load_state_dict(new)
+    return model

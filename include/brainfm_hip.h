@@ -1,0 +1,183 @@
+/*
+ * brainfm_hip.h -- C ABI of libbrainfm_hip.so (gfx950 / MI355X).
+ *
+ * The reference (jhuldr/BrainFM) is pure Python on stock torch ops: it has no
+ * FFI of its own.  This header is therefore the boundary a maintainer would
+ * bind with ctypes; every entry point cites the reference
+ * call chain it replaces.  Conventions:
+ *   - all pointers are DEVICE pointers unless the name ends in _host;
+ *   - activations are fp32, channels-last-3D: index = ((z*H + y)*W + x)*C + c
+ *     (the reference's NCDHW tensors viewed with torch.channels_last_3d strides);
+ *   - no allocation, no global state, no host synchronisation inside a call:
+ *     the caller owns every buffer (including workspaces) and the stream;
+ *   - return value: 0 = launched, <0 = rejected before launch (BFM_E_*).
+ */
+#ifndef BRAINFM_HIP_H
+#define BRAINFM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* bfm_stream_t; /* hipStream_t */
+
+#define BFM_OK 0
+#define BFM_E_ARG (-1)      /* null pointer / non-positive size */
+#define BFM_E_SHAPE (-2)    /* shape not supported by this kernel family */
+#define BFM_E_WORKSPACE (-3)/* workspace too small */
+#define BFM_E_LAUNCH (-4)   /* hipGetLastError() != hipSuccess after launch */
+
+/* Nearest-neighbour upsampling source (F.interpolate(mode='nearest'),
+ * Trainer/models/unet3d/buildingblocks.py:361-363): low-res dims and per-axis
+ * index maps map?[dst] = min(floor(dst*in/out), in-1) plus replication counts
+ * rep?[src] = #{dst : map[dst]==src}.  All six arrays live on the device. */
+typedef struct {
+    int d, h, w;
+    const int32_t* mapD; const int32_t* mapH; const int32_t* mapW; /* len D,H,W of the hi-res grid */
+    const int32_t* repD; const int32_t* repH; const int32_t* repW; /* len d,h,w */
+} bfm_upsample_t;
+
+/* Library / build info: "brainfm_hip <version> gfx950". */
+const char* bfm_version(void);
+
+/* ---------------------------------------------------------------- GroupNorm
+ * nn.GroupNorm(G, C, eps) statistics (buildingblocks.py:48-60) over the
+ * virtual concatenation cat((A, nearest_up(B)), channel) of Decoder._joining
+ * (buildingblocks.py:265-276).  CB==0 / B==NULL for a plain tensor.
+ * Outputs the folded affine y = x*scale[c] + shift[c]
+ * (scale = gamma*rstd, shift = beta - mean*scale) and, per group, the largest
+ * |y| the folded affine can produce (bound[g]) which the MFMA convolution
+ * uses to pick a power-of-two operand scale.
+ * workspace: bfm_gn_stats_workspace(...) bytes. */
+size_t bfm_gn_stats_workspace(int CA, int CB, int D, int H, int W, const bfm_upsample_t* up);
+int bfm_gn_stats(const float* A, int CA, const float* B, int CB, int D, int H, int W,
+                 const bfm_upsample_t* up, const float* gamma, const float* beta, int G, float eps,
+                 float* scale, float* shift, float* bound, void* workspace, size_t workspace_bytes,
+                 bfm_stream_t stream);
+
+/* ------------------------------------------------------ 3x3x3 convolution
+ * SingleConv 'gcl' minus the statistics: y = LeakyReLU_slope( conv3d_p1(
+ *   x*scale + shift ) )  with x = cat((A, nearest_up(B))).  Zero padding is
+ * applied AFTER the affine, as nn.Conv3d pads GroupNorm's output
+ * (buildingblocks.py:31-60).  Weights: see bfm_pack_conv_weights_*.
+ *
+ * _direct: exact fp32 FMA, any Cin/Cout (stem Cin=1, odd widths).
+ *   wpacked layout [27][Cin][Cout] fp32.
+ * _mfma: implicit GEMM on v_mfma_f32_32x32x16_f16.  Requires CA%16==0,
+ *   CB%16==0, Cout%64==0.  passes=3 splits both operands into f16 hi+lo
+ *   (hi*hi + hi*lo + lo*hi, fp32 accumulate: ~2^-22 relative product error);
+ *   passes=1 uses hi only (fast mode, ~2^-11).  `bound` = G per-group bounds
+ *   from bfm_gn_stats (operand scale is derived from them on the device).
+ *   splitk>1 needs workspace of splitk*nvox*Cout*4 bytes. */
+size_t bfm_pack_conv_weights_direct_bytes(int Cin, int Cout);
+int bfm_pack_conv_weights_direct(const float* w_oidhw, int Cin, int Cout, float* wpacked, bfm_stream_t stream);
+size_t bfm_pack_conv_weights_mfma_bytes(int Cin, int Cout);
+/* wmax_abs_host = max|w| (host scalar); returns the power-of-two weight scale exponent in *wexp_host */
+int bfm_pack_conv_weights_mfma(const float* w_oidhw, int Cin, int Cout, float wmax_abs_host, void* wpacked,
+                               int* wexp_host, bfm_stream_t stream);
+
+int bfm_conv3x3x3_direct(const float* A, int CA, const float* B, int CB, int D, int H, int W,
+                         const bfm_upsample_t* up, const float* scale, const float* shift,
+                         const float* wpacked, int Cout, float slope, float* out, bfm_stream_t stream);
+
+size_t bfm_conv3x3x3_mfma_workspace(int Cin, int Cout, int D, int H, int W, int splitk);
+int bfm_conv3x3x3_mfma_plan(int Cin, int Cout, int D, int H, int W, int* cfg_out /*[8]*/);
+int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB, int D, int H, int W,
+                       const bfm_upsample_t* up, const float* scale, const float* shift, const float* bound,
+                       int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
+                       const int* cfg /*from _plan, or NULL*/, float* out, void* workspace,
+                       size_t workspace_bytes, bfm_stream_t stream);
+
+/* ------------------------------------------------------------- MaxPool3d(2)
+ * nn.MaxPool3d(kernel_size=2): stride 2, floor, no padding
+ * (buildingblocks.py:185-186).  in (D,H,W,C) -> out (D/2,H/2,W/2,C). */
+int bfm_maxpool2(const float* in, int C, int D, int H, int W, float* out, bfm_stream_t stream);
+
+/* ------------------------------------------------------------------- tail
+ * Everything after the last decoder, one pass over the 64-ch feature map:
+ * F.normalize(dim=1) (unet3d/model.py:207-208) -> TaskHead 1x1x1 convs + bias
+ * (head.py:52-59) -> SegProcessor softmax / DistProcessor clamp
+ * (joiner.py:69-77,149-157) -> get_postprocessor (Trainer/models/__init__.py:
+ * 272-354): exp, tanh cortical formula, LUT[argmax], CT*1000, residual+input.
+ * The head set is data: `roles[o]` gives the meaning of head output row o. */
+enum {
+    BFM_ROLE_PLAIN = 0,     /* write as is (T1, T2, FLAIR, regx/y/z, high_res_residual, *_sigma) */
+    BFM_ROLE_CT = 1,        /* x1000 */
+    BFM_ROLE_BIAS_LOG = 2,  /* exp */
+    BFM_ROLE_SEG = 3,       /* softmax member (contiguous run of n_seg rows) */
+    BFM_ROLE_DIST = 4,      /* clamp(+-max_dist); order lp, lw[, rp, rw] */
+    BFM_ROLE_SR = 5,        /* high_res_residual: also emits high_res = v + input */
+    BFM_ROLE_PATHOL = 6     /* sigmoid */
+};
+typedef struct {
+    int n_out;                  /* rows of head_w (sum of head channels) */
+    int c_feat;                 /* 64 */
+    const float* head_w;        /* [n_out][c_feat] */
+    const float* head_b;        /* [n_out] */
+    const int32_t* roles;       /* [n_out] BFM_ROLE_* */
+    const int32_t* out_slot;    /* [n_out] index into `maps` for this row, -1 = none */
+    int seg_first, n_seg;       /* rows of the segmentation head; n_seg==0 -> none */
+    const int32_t* seg_lut;     /* [n_seg] label list */
+    int n_dist;                 /* 0, 2 (left hemi) or 4 */
+    int dist_first;
+    float max_dist;
+    int unit_feat;              /* apply F.normalize before the heads */
+    int slot_high_res;          /* maps slot for residual+input, -1 = none */
+    int slot_fake_cortical;     /* maps slot, -1 = none */
+} bfm_tail_desc_t;
+
+int bfm_tail_heads(const float* feat, const float* input /*[nvox], may be NULL*/, int64_t nvox,
+                   const bfm_tail_desc_t* desc, float* feat_norm /*[nvox][c_feat] or NULL*/,
+                   float* const* maps /*device array of device pointers, each [nvox]*/,
+                   float* seg_prob /*[nvox][n_seg] or NULL*/, int64_t* label /*[nvox] or NULL*/,
+                   float* raw_out /*[nvox][n_out]: if set, write raw head logits only (TaskHead.forward)*/,
+                   bfm_stream_t stream);
+
+/* ----------------------------------------------------------------- stitch
+ * scripts/demo_test.py:88-119 without the NIfTI round trip:
+ *   full[k][range] += tile[k] * (tile_input != 0)   then   full[k] /= cnt.
+ * tile maps are [td*th*tw] fp32 (or int64 labels, summed as float like the
+ * reference, quirk Q5). */
+int bfm_stitch_accumulate(const float* tile, const int64_t* tile_label, const float* tile_input,
+                          int td, int th, int tw, float* full, int D, int H, int W,
+                          int z0, int y0, int x0, bfm_stream_t stream);
+/* tile_input == NULL in bfm_stitch_accumulate means "already masked".  bfm_mask_tile produces the
+ * masked, float-typed tile a rank ships to rank 0 in the multi-GPU path. */
+int bfm_mask_tile(const float* tile, const int64_t* tile_label, const float* tile_input, int64_t n, float* out,
+                  bfm_stream_t stream);
+int bfm_tile_count_add(float* cnt, int D, int H, int W, int z0, int z1, int y0, int y1, int x0, int x1,
+                       bfm_stream_t stream);
+int bfm_divide_by_count(float* full, const float* cnt, int64_t n, bfm_stream_t stream);
+
+/* ------------------------------------------------------------ elementwise
+ * Per-voxel helpers for the stand-alone processors / post-processor
+ * (joiner.py:69-77,149-157; Trainer/models/__init__.py:272-354) and the
+ * synthesis augmentations (Generator/utils.py:568-638).  Strides are in
+ * elements so channel slices of channels-last buffers are read in place. */
+enum {
+    BFM_EW_EXP = 0, BFM_EW_AFFINE = 1 /* x*a+b */, BFM_EW_CLAMP = 2 /* [a,b] */, BFM_EW_CLAMP_MIN = 3,
+    BFM_EW_GAMMA = 4 /* a*(x/a)^b, add_gamma_transform utils.py:568-572 */, BFM_EW_SIGMOID = 5,
+    BFM_EW_DIV = 6 /* x/a */, BFM_EW_NONZERO = 7 /* x!=0 ? 1:0 */, BFM_EW_SUB_DIV = 8 /* (x-a)/b */
+};
+enum {
+    BFM_EW_ADD = 0, BFM_EW_MUL = 1, BFM_EW_MUL_EXP = 2 /* x*exp(y), add_bias_field utils.py:585-587 */,
+    BFM_EW_AXPY_CLAMP0 = 3 /* max(x+a*y,0), add_noise utils.py:633-638 */, BFM_EW_AXPY = 4, BFM_EW_DIV2 = 5
+};
+int bfm_ew_unary(int op, const float* in, int64_t in_stride, float* out, int64_t out_stride, int64_t n,
+                 float a, float b, bfm_stream_t stream);
+int bfm_ew_binary(int op, const float* x, int64_t x_stride, const float* y, int64_t y_stride /*0 = broadcast*/,
+                  float* out, int64_t out_stride, int64_t n, float a, bfm_stream_t stream);
+int bfm_softmax_cl(const float* x, int64_t x_row_stride, int C, float* y, int64_t y_row_stride, int64_t n,
+                   bfm_stream_t stream);
+int bfm_argmax_lut_cl(const float* p, int64_t row_stride, int C, const int32_t* lut, int64_t* out, int64_t n,
+                      bfm_stream_t stream);
+int bfm_fake_cortical(const float* dist, int64_t row_stride, int n_dist, float* out, int64_t n,
+                      bfm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRAINFM_HIP_H */

@@ -1,0 +1,266 @@
+"""Parity of the HIP inference path (through the C ABI) against the CPU oracle and the golden
+vectors produced by the real reference.  Needs an MI355X: run with `-m gpu`."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz, sd_from_npz
+from oracle import unet_ref as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_PARITY = 1e-4      # max |a-b| / max|b| for fp32-grade paths (north star asks 1e-3)
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu-marked test needs a HIP device"
+    return torch.device("cuda:0")
+
+
+def _relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max()) / max(1e-6, float(np.abs(b).max()))
+
+
+def _session(d=None, sd=None, f_maps=8, levels=4, left=False, passes=3, groups=8):
+    from brainfm_amd import test_utils as TU
+    ga, ta = TU.default_inference_args(f_maps=f_maps, num_levels=levels, left_hemis_only=left, num_groups=groups)
+    if sd is None:
+        sd = sd_from_npz(d)
+    return TU.InferenceSession(ga, ta, _dev(), state_dict=sd, passes=passes)
+
+
+def _cmp_outputs(out, d, tol=TOL_PARITY, prefix="out/"):
+    keys = [k[len(prefix):] for k in d if k.startswith(prefix)]
+    assert sorted(keys) == sorted(k for k in out if k != "feat"), (sorted(keys), sorted(out.keys()))
+    for k in keys:
+        got = out[k].detach().cpu().numpy()
+        assert got.shape == d[prefix + k].shape, (k, got.shape, d[prefix + k].shape)
+        if k == "label":
+            assert out[k].dtype == torch.int64
+            mism = int((got != d[prefix + k]).sum())
+            assert mism == 0, "label mismatches: %d of %d" % (mism, got.size)
+        else:
+            e = _relerr(got, d[prefix + k])
+            assert e <= tol, (k, e)
+
+
+def test_library_loads_and_reports_gfx950():
+    from brainfm_amd import _lib as L
+    assert b"gfx950" in L.load().bfm_version()
+
+
+def test_mfma_fragment_layout_exact_integers():
+    """Small-integer operands are exact in fp16: any lane/row/column mix-up in the MFMA fragment
+    maps shows up as a bit difference against F.conv3d.  Asymmetric weights on purpose."""
+    from brainfm_amd import _lib as L
+    from brainfm_amd.engine import UNetEngine
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    for (cin, cout, dims) in [(16, 64, (5, 6, 19)), (32, 128, (4, 9, 16)), (48, 64, (8, 8, 32))]:
+        x = torch.randint(-3, 4, (1, cin) + dims, generator=g).float()
+        w = torch.randint(-2, 3, (cout, cin, 3, 3, 3), generator=g).float()
+        sd = {"backbone.encoders.0.basic_module.SingleConv1.groupnorm.weight": torch.ones(cin),
+              "backbone.encoders.0.basic_module.SingleConv1.groupnorm.bias": torch.zeros(cin),
+              "backbone.encoders.0.basic_module.SingleConv1.conv.weight": w}
+        eng = UNetEngine.__new__(UNetEngine)
+        eng.lib = L.load(); eng.device = dev; eng.num_groups = 8; eng.passes = 3; eng.eps = 1e-5; eng.slope = 0.01
+        eng._up_cache = {}; eng._ws = None; eng._plan_cache = {}; eng.force_direct = False
+        ly = eng._make_layer(sd, "backbone.encoders.0.basic_module.SingleConv1", cin, cout)
+        eng._pack(ly, True)
+        x_cl = x[0].permute(1, 2, 3, 0).contiguous().to(dev)
+        scale = torch.ones(cin, device=dev); shift = torch.zeros(cin, device=dev)
+        bound = torch.full((8,), 3.0, device=dev)
+        out = torch.empty(dims + (cout,), device=dev)
+        ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+        rc = eng.lib.bfm_conv3x3x3_mfma(L.ptr(x_cl), cin, None, 0, dims[0], dims[1], dims[2], None, L.ptr(scale),
+                                        L.ptr(shift), L.ptr(bound), 8, L.ptr(ly.wpacked), ly.wexp, cout, 1.0, 3, None,
+                                        L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr())
+        assert rc == 0
+        ref = torch.nn.functional.conv3d(x, w, padding=1)[0].permute(1, 2, 3, 0)
+        assert torch.equal(out.cpu(), ref), (cin, cout, dims, float((out.cpu() - ref).abs().max()))
+
+
+def test_full_width_blocks_vs_reference_golden():
+    """enc0 (direct stem + MFMA 32->64), pool + enc1 (MFMA 64->64, 64->128), decoder with folded
+    upsample+concat (MFMA 192->64, 64->64) against outputs of the reference's own modules."""
+    from brainfm_amd.engine import UNetEngine
+    d = load_npz("infer_layers.npz")
+    sd = {}
+    for blk, pre in (("enc0", "backbone.encoders.0."), ("enc1", "backbone.encoders.1."), ("dec", "backbone.decoders.0.")):
+        for k, v in d.items():
+            if k.startswith(blk + "/"):
+                sd[pre + k[len(blk) + 1:]] = torch.from_numpy(v)
+    eng = UNetEngine(sd, in_channels=1, f_maps=[64, 128], num_levels=2, num_groups=8, unit_feat=False, device=_dev())
+    x = torch.from_numpy(d["x"])
+    feats = eng.backbone_cl(eng.to_cl(x), tuple(x.shape[2:]))
+    e1 = UNetEngine.as_ncdhw(feats[0][0]).cpu().numpy()
+    y = UNetEngine.as_ncdhw(feats[1][0]).cpu().numpy()
+    assert _relerr(e1, d["e1"]) <= TOL_PARITY, _relerr(e1, d["e1"])
+    assert _relerr(y, d["y"]) <= TOL_PARITY, _relerr(y, d["y"])
+    # every conv of this net except the stem must have taken the MFMA path
+    kinds = [ly.kind for blk in eng.enc + eng.dec for ly in blk]
+    assert kinds == ["direct", "mfma", "mfma", "mfma", "mfma", "mfma"], kinds
+    # same net, exact-fp32 direct kernels only
+    eng2 = UNetEngine(sd, in_channels=1, f_maps=[64, 128], num_levels=2, num_groups=8, unit_feat=False, device=_dev())
+    eng2.force_direct = True
+    y2 = UNetEngine.as_ncdhw(eng2.backbone_cl(eng2.to_cl(x), tuple(x.shape[2:]))[1][0]).cpu().numpy()
+    assert _relerr(y2, d["y"]) <= TOL_PARITY
+
+
+def test_pool_and_upsample_index_rules():
+    from brainfm_amd import _lib as L
+    from brainfm_amd.engine import nearest_index_map
+    d = load_npz("infer_layers.npz")
+    dev = _dev()
+    p = torch.from_numpy(d["pool_in"])
+    x_cl = p[0].permute(1, 2, 3, 0).contiguous().to(dev)
+    out = torch.empty((2, 3, 1, 3), device=dev)
+    assert L.load().bfm_maxpool2(L.ptr(x_cl), 3, 5, 7, 3, L.ptr(out), L.stream_ptr()) == 0
+    assert np.array_equal(out.permute(3, 0, 1, 2).cpu().numpy()[None], d["pool_out"])
+    u = d["up_in"][0]
+    idx = [nearest_index_map(u.shape[1 + a], (5, 7, 10)[a]) for a in range(3)]
+    up = u[:, idx[0]][:, :, idx[1]][:, :, :, idx[2]]
+    assert np.array_equal(up[None], d["up_out"])
+    assert nearest_index_map(2, 5).tolist() == [0, 0, 0, 1, 1]
+    assert nearest_index_map(3, 7).tolist() == [0, 0, 0, 1, 1, 2, 2]
+
+
+def test_small_net_fused_path_all_outputs():
+    d = load_npz("infer_small.npz")
+    s = _session(d, f_maps=int(d["cfg"][0]), levels=int(d["cfg"][1]))
+    x = torch.from_numpy(d["x"]).to(_dev())
+    out, _ = s.forward_fused(x)
+    for i, f in enumerate(out["feat"]):
+        assert tuple(f.shape) == d["feat%d" % i].shape
+        assert _relerr(f.cpu().numpy(), d["feat%d" % i]) <= TOL_PARITY
+    _cmp_outputs(out, d)
+    # evaluate_image semantics: feature_only returns feat[-1]
+    f = s.evaluate(x, feature_only=True)
+    assert _relerr(f.cpu().numpy(), d["feat%d" % (len(out["feat"]) - 1)]) <= TOL_PARITY
+
+
+def test_small_net_reference_call_sequence():
+    """model(samples) -> processors -> postprocessor, exactly as utils/test_utils.py:302-307 drives them."""
+    d = load_npz("infer_small.npz")
+    s = _session(d, f_maps=int(d["cfg"][0]), levels=int(d["cfg"][1]))
+    x = torch.from_numpy(d["x"]).to(_dev())
+    samples = [{"input": x}]
+    outputs, inputs = s.model(samples)
+    assert inputs[0] is x
+    assert set(outputs[0].keys()) == {"feat", "T1", "T2", "FLAIR", "CT", "bias_field_log", "segmentation", "distance",
+                                      "registration", "high_res_residual"}
+    for p in s.processors:
+        outputs = p(outputs, samples)
+    outputs, _, _ = s.postprocessor(s.gen_args, s.train_args, outputs, samples, target=None, feats=None,
+                                    tasks=s.gen_args.tasks)
+    _cmp_outputs(outputs[0], d)
+    # backbone.get_feature and head on their own
+    feats = s.model.backbone.get_feature(x)
+    assert _relerr(feats[-1].cpu().numpy(), d["feat3"]) <= TOL_PARITY
+    heads = s.model.head(feats)
+    assert tuple(heads["segmentation"].shape) == (1, 56, 20, 18, 22)
+
+
+def test_left_hemis_head_set():
+    d = load_npz("infer_hemis.npz")
+    s = _session(d, f_maps=int(d["cfg"][0]), levels=int(d["cfg"][1]), left=True)
+    out, _ = s.forward_fused(torch.from_numpy(d["x"]).to(_dev()))
+    assert "rp" not in out and out["segmentation"].shape[1] == 18
+    _cmp_outputs(out, d)
+
+
+def test_tiled_stitch_toy_vs_reference_golden():
+    from brainfm_amd import test_utils as TU
+    d = load_npz("infer_tiled.npz")
+    f_maps, levels, groups, stride, win = [int(v) for v in d["cfg"]]
+    s = _session(d, f_maps=f_maps, levels=levels)
+    full = torch.from_numpy(d["full"]).to(_dev())
+    acc, ranges, cnt = TU.tiled_inference(full, s, [stride] * 3, [win] * 3)
+    assert np.array_equal(np.array(ranges), d["ranges"])
+    assert np.array_equal(cnt.cpu().numpy(), d["cnt"])
+    for k in [k[9:] for k in d if k.startswith("stitched/")]:
+        e = _relerr(acc[k].cpu().numpy(), d["stitched/" + k])
+        assert e <= 2e-4, (k, e)
+
+
+@pytest.mark.parametrize("passes,tol", [(3, TOL_PARITY), (1, 3e-2)])
+def test_mfma_network_vs_oracle(passes, tol):
+    """64-wide 3-level net (all convs but the stem on MFMA), volume with an exact-zero background,
+    against the CPU oracle; labels must be identical in parity mode."""
+    sd = O.random_state_dict(1, 64, 3, seed=5)
+    g = torch.Generator().manual_seed(9)
+    D, H, W = 32, 24, 40
+    zz, yy, xx = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(W), indexing="ij")
+    ell = (((zz - 15.5) / 14.) ** 2 + ((yy - 11.5) / 10.) ** 2 + ((xx - 19.5) / 17.) ** 2) <= 1
+    x = torch.rand(1, 1, D, H, W, generator=g) * ell[None, None]
+    ref = O.forward_all(x, sd, f_maps=64, num_levels=3)
+    s = _session(sd=sd, f_maps=64, levels=3, passes=passes)
+    out, _ = s.forward_fused(x.to(_dev()))
+    errs = {}
+    for k, v in ref.items():
+        if k == "feat":
+            for i, f in enumerate(v):
+                errs["feat%d" % i] = _relerr(out["feat"][i].cpu().numpy(), f.numpy())
+        elif k == "label":
+            mism = int((out[k].cpu() != v).sum())
+            errs["label_mismatch"] = mism
+        else:
+            errs[k] = _relerr(out[k].cpu().numpy(), v.numpy())
+    print("passes=%d" % passes, {k: (v if isinstance(v, int) else float("%.2e" % v)) for k, v in errs.items()})
+    worst = max(v for k, v in errs.items() if k != "label_mismatch")
+    assert worst <= tol, errs
+    if passes == 3:
+        assert errs["label_mismatch"] == 0, errs
+
+
+def test_split_k_deep_layer_vs_oracle():
+    """Deep-level shape (few voxels, many channels) takes the split-K path; also a concat source."""
+    from brainfm_amd.engine import UNetEngine
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    cs, cx, cout = 256, 512, 256
+    name = "backbone.decoders.0.basic_module.SingleConv1"
+    sd = {name + ".groupnorm.weight": 1 + 0.3 * (torch.rand(cs + cx, generator=g) - .5),
+          name + ".groupnorm.bias": 0.3 * (torch.rand(cs + cx, generator=g) - .5),
+          name + ".conv.weight": (torch.rand(cout, cs + cx, 3, 3, 3, generator=g) * 2 - 1) / np.sqrt(27 * (cs + cx))}
+    skip = torch.randn(1, cs, 5, 4, 5, generator=g)
+    low = torch.randn(1, cx, 2, 2, 2, generator=g)
+    cat = torch.cat((skip, torch.nn.functional.interpolate(low, size=(5, 4, 5), mode="nearest")), 1)
+    ref = O.single_conv(cat, sd, name)
+    eng = UNetEngine.__new__(UNetEngine)
+    from brainfm_amd import _lib as L
+    eng.lib = L.load(); eng.device = dev; eng.num_groups = 8; eng.passes = 3; eng.eps = 1e-5; eng.slope = 0.01
+    eng._up_cache = {}; eng._ws = None; eng._plan_cache = {}; eng.force_direct = False
+    ly = eng._make_layer(sd, name, cs + cx, cout)
+    out = eng.single_conv(ly, skip[0].permute(1, 2, 3, 0).contiguous().to(dev), (5, 4, 5),
+                          B=low[0].permute(1, 2, 3, 0).contiguous().to(dev), lo_dims=(2, 2, 2))
+    assert eng._plan(cs + cx, cout, (5, 4, 5))[5] > 1, "expected split-K for this shape"
+    got = out.permute(3, 0, 1, 2).cpu().numpy()[None]
+    assert _relerr(got, ref.numpy()) <= TOL_PARITY, _relerr(got, ref.numpy())
+
+
+def test_all_zero_tile_gives_groupnorm_bias_path():
+    """A tile of exact zeros (outside the head) has zero variance: GroupNorm outputs beta; must not NaN."""
+    sd = O.random_state_dict(1, 8, 3, seed=2)
+    x = torch.zeros(1, 1, 8, 12, 8)
+    ref = O.forward_all(x, sd, f_maps=8, num_levels=3)
+    s = _session(sd=sd, f_maps=8, levels=3)
+    out, _ = s.forward_fused(x.to(_dev()))
+    for k in ("T1", "bias_field", "fake_cortical", "regx"):
+        assert torch.isfinite(out[k]).all()
+        assert _relerr(out[k].cpu().numpy(), ref[k].numpy()) <= TOL_PARITY, k
+    assert torch.equal(out["label"].cpu(), ref["label"])
+
+
+def test_rejects_bad_arguments_before_launch():
+    from brainfm_amd import _lib as L
+    lib = L.load()
+    dev = _dev()
+    x = torch.zeros(8, device=dev)
+    assert lib.bfm_maxpool2(None, 4, 4, 4, 4, L.ptr(x), L.stream_ptr()) == -1
+    assert lib.bfm_conv3x3x3_mfma(L.ptr(x), 8, None, 0, 2, 2, 2, None, L.ptr(x), L.ptr(x), L.ptr(x), 1, L.ptr(x), 0, 64,
+                                  0.01, 3, None, L.ptr(x), None, 0, L.stream_ptr()) == -2   # CA % 16

@@ -1,0 +1,201 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol the header declares, host-side
+tiling logic matches the reference's golden interval lists, and the multi-rank tile sharding
+(gloo, world_size 2) reproduces the single-process stitched result bit for bit."""
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_npz
+
+
+def _header_symbols():
+    names = set()
+    inc = os.path.join(ROOT, "include")
+    for f in os.listdir(inc):
+        if f.endswith(".h"):
+            txt = open(os.path.join(inc, f)).read()
+            txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+            names |= set(re.findall(r"\b(bfm_[a-z0-9_]+)\s*\(", txt))
+    return names
+
+
+def test_library_exports_every_declared_symbol():
+    from brainfm_amd import _lib as L
+    if not os.path.exists(L.LIB_PATH):
+        from brainfm_amd import build
+        build.build(verbose=False)
+    lib = L.load()
+    declared = _header_symbols()
+    assert len(declared) >= 20
+    missing = [n for n in declared if not hasattr(lib, n)]
+    assert not missing, missing
+    unbound = [n for n in declared if n not in L.SIGNATURES]
+    assert not unbound, "declared in the header but not bound in _lib.py: %s" % unbound
+    assert b"gfx950" in lib.bfm_version()
+
+
+def test_product_path_has_no_cpu_fallback():
+    from brainfm_amd import _lib as L, test_utils as TU
+    from brainfm_amd.engine import UNetEngine
+    with pytest.raises(L.BfmError):
+        UNetEngine({}, device="cpu")
+    with pytest.raises(L.BfmError):
+        TU.evaluate_image(torch.zeros(1, 1, 8, 8, 8), None, device="cpu")
+
+
+def test_no_oracle_import_in_product():
+    pkg = os.path.join(ROOT, "brainfm_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "/root/reference" not in src, f
+
+
+def test_tiling_matches_reference_golden():
+    from brainfm_amd import test_utils as TU
+    d = load_npz("tiling_ranges.npz")
+    for n in (160, 200, 256):
+        img = torch.zeros(1, 1, n, n, n)
+        lst, cnt = TU.tiling(img, stride=[80] * 3, win_size=[160] * 3)
+        assert np.array_equal(np.array([r for _, r in lst]), d["ranges_%d" % n])
+        c = cnt.numpy()
+        assert np.array_equal(np.bincount(c.astype(np.int64).ravel(), minlength=9), d["cnt_%d_hist" % n])
+        assert np.array_equal(c[np.arange(n), np.arange(n), np.arange(n)], d["cnt_%d_diag" % n])
+        for t, ((x0, x1), (y0, y1), (z0, z1)) in lst[:3]:
+            assert tuple(t.shape[2:]) == (x1 - x0, y1 - y0, z1 - z0)
+    assert np.array_equal(np.array(TU.axis_intervals(512, 160, 80)), d["ranges_512_x"])
+    assert len(TU.tiling_ranges((256,) * 3, [80] * 3, [160] * 3)) == 27
+    assert len(TU.tiling_ranges((512,) * 3, [80] * 3, [160] * 3)) == 216
+    # ragged / tiny volumes
+    assert TU.axis_intervals(100, 160, 80) == [(0, 100)]
+    assert TU.axis_intervals(161, 160, 80) == [(0, 160), (81, 161)]
+
+
+def test_zero_crop_and_center_crop():
+    from brainfm_amd import test_utils as TU
+    v = torch.zeros(10, 12, 14)
+    v[2:7, 3:9, 4:5] = 1
+    assert tuple(TU.zero_crop(v).shape) == (5, 6, 1)
+    img, start, shp, aff = TU.center_crop(torch.rand(30, 20, 10), [16, 16, 16], aff=np.eye(4))
+    assert tuple(img.shape) == (1, 1, 16, 16, 10) and start == [7, 2, 0] and aff[0, 3] == 7
+
+
+def test_lpt_assignment_balances_tiles():
+    from brainfm_amd import test_utils as TU
+    ranges = TU.tiling_ranges((256,) * 3, [80] * 3, [160] * 3)
+    for world in (1, 2, 4, 8):
+        owner = TU.assign_tiles(ranges, world)
+        load = [sum(TU.tile_cost(r) for r, o in zip(ranges, owner) if o == k) for k in range(world)]
+        assert sum(load) == 32768000
+        assert max(load) <= max(160 ** 3, int(1.25 * sum(load) / world))
+    owner = TU.assign_tiles(ranges, 8)
+    big = [i for i, r in enumerate(ranges) if TU.tile_cost(r) == 160 ** 3][0]
+    assert sum(1 for o in owner if o == owner[big]) == 1      # the 160^3 tile gets a GPU to itself
+
+
+def test_default_args_and_process_args():
+    from brainfm_amd import test_utils as TU, models as M
+    ga, ta = TU.default_inference_args()
+    ga, ta = M.process_args(ga, ta, ga.task)
+    assert list(ta.out_channels.items()) == [("T1", 1), ("T2", 1), ("FLAIR", 1), ("CT", 1), ("bias_field_log", 1),
+                                             ("segmentation", 56), ("distance", 4), ("registration", 3),
+                                             ("high_res_residual", 1)]
+    ga, ta = TU.default_inference_args(left_hemis_only=True)
+    ga, ta = M.process_args(ga, ta, ga.task)
+    assert ta.out_channels["segmentation"] == 18 and ta.out_channels["distance"] == 2
+
+
+def test_state_dict_names_match_reference():
+    """The parameter tree must carry the reference's 84 state-dict names."""
+    from brainfm_amd import test_utils as TU, models as M
+    d = load_npz("infer_small.npz")
+    ga, ta = TU.default_inference_args(f_maps=8, num_levels=4)
+    _, _, model, _, _, _ = M.build_model(ga, ta, "cpu")
+    ref_keys = sorted(k[3:] for k in d if k.startswith("sd/"))
+    assert sorted(model.state_dict().keys()) == ref_keys
+    sd = {"module." + k[3:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("sd/")}   # DDP-style prefix
+    M.load_state_dict_by_suffix(model, sd)
+    k = "backbone.encoders.1.basic_module.SingleConv2.conv.weight"
+    assert torch.equal(model.state_dict()[k], sd["module." + k])
+
+
+# ----------------------------------------------------------------------------- gloo, world_size 2
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _HostOps:
+    """Stand-in per-tile evaluator and accumulator so the sharding / gather / ordering logic can run
+    without a GPU: the 'network' is a cheap deterministic function of the tile."""
+    keys = ["T1", "regx", "label"]
+
+    def run_tile(self, im):
+        x = im.reshape(-1).to(torch.float32)
+        m = (x != 0).float()
+        rows = [torch.sin(x * 3) * m * 1.37, (x * x + 0.1) * m, torch.floor(x * 50) * m]
+        return self.keys, torch.stack(rows, 0)
+
+    def add(self, acc, rows_j, rng, shape):
+        (x0, x1), (y0, y1), (z0, z1) = rng
+        acc[x0:x1, y0:y1, z0:z1] += rows_j.reshape(x1 - x0, y1 - y0, z1 - z0)
+
+    def finalize(self, acc, cnt):
+        acc /= cnt
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from brainfm_amd import test_utils as TU
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    torch.manual_seed(0)
+    full = torch.rand(1, 1, 40, 36, 44)
+    full[:, :, :6] = 0
+    acc, ranges, cnt = TU.tiled_inference_distributed(full, None, [12] * 3, [24] * 3, ops=_HostOps())
+    if rank == 0:
+        q.put({k: v.numpy() for k, v in acc.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_distributed_tiling_two_ranks_bitwise_equals_single():
+    import torch.multiprocessing as mp
+    from brainfm_amd import test_utils as TU
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process result with the same ops, reference tile order
+    torch.manual_seed(0)
+    full = torch.rand(1, 1, 40, 36, 44)
+    full[:, :, :6] = 0
+    ops = _HostOps()
+    shape = tuple(full.shape[2:])
+    ranges = TU.tiling_ranges(shape, [12] * 3, [24] * 3)
+    cnt = TU.count_volume(shape, ranges, "cpu")
+    acc = {k: torch.zeros(shape) for k in ops.keys}
+    for rng in ranges:
+        (x0, x1), (y0, y1), (z0, z1) = rng
+        _, rows = ops.run_tile(full[:, :, x0:x1, y0:y1, z0:z1])
+        for j, k in enumerate(ops.keys):
+            ops.add(acc[k], rows[j], rng, shape)
+    for k in ops.keys:
+        acc[k] /= cnt
+        assert np.array_equal(res[k], acc[k].numpy()), k
