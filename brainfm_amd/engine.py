@@ -49,6 +49,7 @@ class UNetEngine:
     ``head.final_conv_{task}.{weight,bias}``); a ``backbone.``-less or ``module.``-prefixed dict is accepted
     the way utils/checkpoint.py:558-571 suffix-matches names.
     """
+    prof = None
 
     def __init__(self, state_dict, in_channels=1, f_maps=64, num_levels=6, num_groups=8, unit_feat=True,
                  device="cuda", passes=3, eps=1e-5, slope=0.01):
