@@ -80,15 +80,20 @@ __device__ __forceinline__ void box_coords(const ConvParams& p, int q, int& d, i
     }
 }
 
-template <int WM, int WN, int NPASS>
+template <int WM, int WN, int NPASS, int NSLOT>
 __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(ConvParams p) {
     constexpr int NTHR = 64 * WM * WN;
+    constexpr int NW = WM * WN;                    // waves per workgroup
     constexpr int NPL = (NPASS == 3) ? 2 : 1;      // planes per k-half (hi[, lo])
+    constexpr int ROWFR = 12 * WN;                 // 1-KiB weight fragments per (kd,kh) row: 3 taps x 2 nb x 2 hl x WN
+    constexpr int KPR = ROWFR / NW;                // LDS-DMA instructions per wave per row
+    constexpr int DPF = NSLOT - 1;                 // rows the weight stream runs ahead
+    static_assert(ROWFR % NW == 0, "row fragments must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l32 = lane & 31, khalf = lane >> 5;
 
@@ -134,24 +139,36 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(ConvParams p) {
         a_off[mb] = (khalf * NPL) * p.plane_stride + vox * 16;
     }
 
-    // ---- staging bookkeeping: element e = tid + it*NTHR -> (halo voxel, channel quad)
+    // ---- staging bookkeeping: element e = tid + it*NTHR -> (halo voxel, channel quad).
+    // off[it] = element offset of the voxel's channel 0 in the current source tensor
+    // (-1: outside the volume -> staged as zero, -2: no such element), recomputed only when the
+    // source switches from the skip tensor to the upsampled low-res tensor.
     constexpr int MAX_IT = 12;
     const int n_el = p.nvox_lds * 4;
     const int q4 = tid & 3;                              // NTHR % 4 == 0 -> fixed per thread
-    int packed[MAX_IT];                                  // hz | hy<<10 | hx<<20, or -1
+    int off[MAX_IT];
+    auto compute_offsets = [&](bool fromB) {
 #pragma unroll
-    for (int it = 0; it < MAX_IT; ++it) {
-        int e = tid + it * NTHR;
-        packed[it] = -1;
-        if (e < n_el) {
-            int vox = e >> 2;
-            int hz = vox / (p.HT * p.WT);
-            int rem = vox - hz * (p.HT * p.WT);
-            int hy = rem / p.WT;
-            int hx = rem - hy * p.WT;
-            packed[it] = hz | (hy << 10) | (hx << 20);
+        for (int it = 0; it < MAX_IT; ++it) {
+            const int e = tid + it * NTHR;
+            off[it] = -2;
+            if (e < n_el) {
+                const int vox = e >> 2;
+                const int hz = vox / (p.HT * p.WT);
+                const int rem = vox - hz * (p.HT * p.WT);
+                const int hy = rem / p.WT;
+                const int hx = rem - hy * p.WT;
+                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+                off[it] = -1;
+                if (gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                    if (fromB) off[it] = ((p.up.mapD[gz] * p.up.h + p.up.mapH[gy]) * p.up.w + p.up.mapW[gx]) * p.CB;
+                    else off[it] = ((gz * p.H + gy) * p.W + gx) * p.CA;
+                }
+            }
         }
-    }
+    };
+    bool off_fromB = (split * p.kc_per_split * KC) >= p.CA;
+    compute_offsets(off_fromB);
     const int st_plane = ((q4 >> 1) * NPL) * p.plane_stride + (q4 & 1) * 8;
 
     floatx16 acc[2][2];
@@ -166,13 +183,36 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(ConvParams p) {
     const int kc_begin = split * p.kc_per_split;
     const int kc_end = min(p.KCN, kc_begin + p.kc_per_split);
 
+    // ---- weight stream: row R = (chunk, kd, kh); fragment f of a row -> LDS slot (R % NSLOT)
+    const int b_base = 2 * NPL * p.plane_stride;
+    const int total_rows = (kc_end - kc_begin) * 9;
+    auto issue_row = [&](int R) {
+        const int Rc = R < total_rows ? R : total_rows - 1;       // past the end: harmless reload, never read
+        const int kcR = kc_begin + Rc / 9, rr = Rc % 9;
+        const int slot = R % NSLOT;
+#pragma unroll
+        for (int i = 0; i < KPR; ++i) {
+            const int f = wave + i * NW;
+            const int j = f / 12, g = f - j * 12;
+            const uint4* src = p.wp + ((size_t)((nt * WN + j) * p.KCN + kcR) * 27 + rr * 3) * (4 * FRAG_U4) +
+                               g * FRAG_U4 + lane;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(lds + b_base +
+                                                                                      (slot * ROWFR + f) * 1024),
+                                             16, 0, 0);
+        }
+    };
+    if (total_rows > 0) {
+#pragma unroll
+        for (int R = 0; R < DPF; ++R) issue_row(R);
+    }
+
     for (int kc = kc_begin; kc < kc_end; ++kc) {
         // ================= stage chunk kc =================
         const int c0 = kc * KC;
         const bool fromB = c0 >= p.CA;
-        const float* src = fromB ? p.B : p.A;
-        const int cs = fromB ? p.CB : p.CA;              // channel stride of the source
-        const int cof = (fromB ? c0 - p.CA : c0) + q4 * 4;
+        if (fromB != off_fromB) { off_fromB = fromB; compute_offsets(fromB); }
+        const float* src = (fromB ? p.B + (c0 - p.CA) : p.A + c0) + q4 * 4;
         const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + c0 + q4 * 4);
         const float4 sh4 = *reinterpret_cast<const float4*>(p.shift + c0 + q4 * 4);
         const float sc[4] = {sc4.x * a_scale, sc4.y * a_scale, sc4.z * a_scale, sc4.w * a_scale};
@@ -182,34 +222,21 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(ConvParams p) {
 #pragma unroll
         for (int it0 = 0; it0 < MAX_IT; it0 += 4) {
             float4 v[4];
-            bool ok[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int pk = packed[it0 + u];
-                ok[u] = false;
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (pk >= 0) {
-                    int gz = z0 + (pk & 1023) - 1, gy = y0 + ((pk >> 10) & 1023) - 1, gx = x0 + (pk >> 20) - 1;
-                    if (gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                        int64_t off;
-                        if (fromB)
-                            off = (((int64_t)p.up.mapD[gz] * p.up.h + p.up.mapH[gy]) * p.up.w + p.up.mapW[gx]) * cs;
-                        else
-                            off = (((int64_t)gz * p.H + gy) * p.W + gx) * cs;
-                        v[u] = *reinterpret_cast<const float4*>(src + off + cof);
-                        ok[u] = true;
-                    }
-                }
+                if (off[it0 + u] >= 0) v[u] = *reinterpret_cast<const float4*>(src + off[it0 + u]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int e = tid + (it0 + u) * NTHR;
-                if (packed[it0 + u] >= 0) {
+                if (off[it0 + u] != -2) {
+                    const bool ok = off[it0 + u] >= 0;
                     float y[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
                     half4 hi, lo;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float t = ok[u] ? fmaf(y[i], sc[i], sh[i]) : 0.f;   // zero padding AFTER the affine
+                        float t = ok ? fmaf(y[i], sc[i], sh[i]) : 0.f;      // zero padding AFTER the affine
                         _Float16 hh = (_Float16)t;
                         hi[i] = hh;
                         lo[i] = (_Float16)(t - (float)hh);
@@ -223,49 +250,47 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(ConvParams p) {
         __syncthreads();
 
         // ================= 27 taps of MFMA on the staged chunk =================
-        const uint4* wb = p.wp + ((size_t)(ntw * p.KCN + kc) * 27) * (4 * FRAG_U4) + lane;
-
-        half8 a0[2][NPL], b0[2][NPL], a1[2][NPL], b1[2][NPL];
-
-        auto load_tap = [&](int tap, half8 (&a)[2][NPL], half8 (&b)[2][NPL]) {
-            const int kd = tap / 9, r9 = tap - kd * 9, kh = r9 / 3, kw = r9 - kh * 3;
-            const int toff = ((kd * p.HT + kh) * p.WT + kw) * 16;
-            const uint4* wt = wb + (size_t)tap * (4 * FRAG_U4);
+        // Weights stream through an LDS ring, one (kd,kh) row = 3 taps per slot, filled by LDS-DMA
+        // (global_load_lds_dwordx4: one packed 1-KiB fragment per wave-instruction) DPF rows ahead.
+        // Per row: own DMAs of this row landed (counted vmcnt) -> barrier (everyone's landed, and the
+        // slot consumed one row ago is free) -> refill that slot -> 36 MFMAs.
+        const int rbase = (kc - kc_begin) * 9;
+        for (int r = 0; r < 9; ++r) {
+            const int R = rbase + r;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KPR * (DPF - 1)) : "memory");
+            __builtin_amdgcn_s_barrier();
+            issue_row(R + DPF);
+            const unsigned char* bs = lds + b_base + ((R % NSLOT) * ROWFR + wn * 12) * 1024 + lane * 16;
+            const int kd = r / 3, kh = r - kd * 3;
+            const int roff = (kd * p.HT + kh) * p.WT * 16;
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int kw = 0; kw < 3; ++kw) {
+                half8 a[2][NPL], b[2][NPL];
 #pragma unroll
-                for (int hl = 0; hl < NPL; ++hl) {
-                    uint4 raw = wt[(nb * 2 + hl) * FRAG_U4];
-                    b[nb][hl] = *reinterpret_cast<half8*>(&raw);
-                }
+                for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+                    for (int hl = 0; hl < NPL; ++hl)
+                        b[nb][hl] = *reinterpret_cast<const half8*>(bs + (kw * 4 + nb * 2 + hl) * 1024);
 #pragma unroll
-                for (int hl = 0; hl < NPL; ++hl)
-                    a[mb][hl] = *reinterpret_cast<const half8*>(lds + a_off[mb] + hl * p.plane_stride + toff);
-        };
-        auto mma_tap = [&](half8 (&a)[2][NPL], half8 (&b)[2][NPL]) {
+                for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+                    for (int hl = 0; hl < NPL; ++hl)
+                        a[mb][hl] = *reinterpret_cast<const half8*>(lds + a_off[mb] + hl * p.plane_stride + roff +
+                                                                    kw * 16);
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    if constexpr (NPASS == 3) {
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][1], b[nb][0], acc[mb][nb], 0, 0, 0);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][0], b[nb][1], acc[mb][nb], 0, 0, 0);
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        if constexpr (NPASS == 3) {
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][1], b[nb][0], acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][0], b[nb][1], acc[mb][nb], 0, 0, 0);
+                        }
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][0], b[nb][0], acc[mb][nb], 0, 0, 0);
                     }
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][0], b[nb][0], acc[mb][nb], 0, 0, 0);
-                }
-        };
-
-        load_tap(0, a0, b0);
-        for (int tp = 0; tp < 13; ++tp) {               // taps 2tp (buf0) and 2tp+1 (buf1)
-            load_tap(2 * tp + 1, a1, b1);
-            mma_tap(a0, b0);
-            load_tap(2 * tp + 2, a0, b0);
-            mma_tap(a1, b1);
+            }
         }
-        mma_tap(a0, b0);                                // tap 26
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the run-ahead DMAs before the LDS is released
 
     // ================= epilogue =================
     const bool final_out = p.splitk == 1;
@@ -336,11 +361,14 @@ __global__ void pack_mfma(const float* __restrict__ w, int Cin, int Cout, int we
     }
 }
 
+constexpr int nslot_for(int WN) { return WN == 1 ? 3 : 2; }
+constexpr int ring_bytes(int WN) { return nslot_for(WN) * 12 * WN * 1024; }
+
 struct HostPlan {
     int WM, WN, TD, TH, TW, splitk;
 };
 
-constexpr int LDS_LIMIT = 64 * 1024;
+constexpr int LDS_LIMIT = 80 * 1024;      // two workgroups per CU (160 KiB)
 
 int plane_stride_for(int nvox) { return ((nvox * 16 + 63) / 64) * 64 + 32; }
 
@@ -357,7 +385,7 @@ HostPlan choose_plan(int Cin, int Cout, int D, int H, int W) {
             int td = std::min(D, rows / (tw * th));
             if (td < 1) continue;
             int nvox = (td + 2) * (th + 2) * (tw + 2);
-            if (4 * plane_stride_for(nvox) > LDS_LIMIT) continue;
+            if (4 * plane_stride_for(nvox) + ring_bytes(hp.WN) > LDS_LIMIT) continue;
             if (nvox * 4 > 12 * 64 * hp.WM * hp.WN) continue;          // MAX_IT staging slots
             double tiles = (double)bfm_cdiv(D, td) * bfm_cdiv(H, th) * bfm_cdiv(W, tw);
             double conflict = (tw % 16 == 0) ? 1.0 : 1.25;
@@ -383,8 +411,8 @@ HostPlan choose_plan(int Cin, int Cout, int D, int H, int W) {
 
 template <int WM, int WN>
 void launch(const ConvParams& p, int passes, dim3 grid, size_t smem, hipStream_t st) {
-    if (passes == 3) hipLaunchKernelGGL((conv_mfma<WM, WN, 3>), grid, dim3(64 * WM * WN), smem, st, p);
-    else hipLaunchKernelGGL((conv_mfma<WM, WN, 1>), grid, dim3(64 * WM * WN), smem, st, p);
+    if (passes == 3) hipLaunchKernelGGL((conv_mfma<WM, WN, 3, nslot_for(WN)>), grid, dim3(64 * WM * WN), smem, st, p);
+    else hipLaunchKernelGGL((conv_mfma<WM, WN, 1, nslot_for(WN)>), grid, dim3(64 * WM * WN), smem, st, p);
 }
 
 }  // namespace
@@ -478,7 +506,7 @@ extern "C" int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB
     p.tw_shift = is_pow2(hp.TW) ? ilog2(hp.TW) : -1;
     p.thw_shift = is_pow2(hp.TH * hp.TW) ? ilog2(hp.TH * hp.TW) : -1;
     const int npl = passes == 3 ? 2 : 1;
-    const size_t smem = (size_t)2 * npl * p.plane_stride;
+    const size_t smem = (size_t)2 * npl * p.plane_stride + ring_bytes(hp.WN);
     if (smem > (size_t)LDS_LIMIT) return BFM_E_SHAPE;
     if (p.nvox_lds * 4 > 12 * 64 * hp.WM * hp.WN) return BFM_E_SHAPE;
     const int64_t nvox = (int64_t)D * H * W;
@@ -491,6 +519,8 @@ extern "C" int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB
         p.out = out;
     }
     if ((int64_t)p.nMt * p.NT > 0x7fffffff) return BFM_E_SHAPE;
+    if (nvox * CA > 0x7fffffffLL || (CB > 0 && (int64_t)up->d * up->h * up->w * CB > 0x7fffffffLL))
+        return BFM_E_SHAPE;                                   // the staging path keeps 32-bit element offsets
     dim3 grid((unsigned)(p.nMt * p.NT), (unsigned)p.splitk);
     hipStream_t st = bfm_s(stream);
     if (hp.WM == 4) launch<4, 1>(p, passes, grid, smem, st);

@@ -103,7 +103,19 @@ __global__ void __launch_bounds__(TPB) gn_partial(const float* __restrict__ X, i
     const int r0 = t / CV, col = t % CV;
     Acc<VEC> a; a.init();
     if (active) {
-        for (int64_t v = v0 + r0; v < v1; v += RP) {
+        int64_t v = v0 + r0;
+        for (; v + 3 * (int64_t)RP < v1; v += 4 * (int64_t)RP) {      // 4 independent loads in flight
+            float x0[VEC], x1[VEC], x2[VEC], x3[VEC];
+            load_vec<VEC>(X + v * C + (size_t)col * VEC, x0);
+            load_vec<VEC>(X + (v + RP) * C + (size_t)col * VEC, x1);
+            load_vec<VEC>(X + (v + 2 * (int64_t)RP) * C + (size_t)col * VEC, x2);
+            load_vec<VEC>(X + (v + 3 * (int64_t)RP) * C + (size_t)col * VEC, x3);
+            a.add(x0, vox_weight(rep, v));
+            a.add(x1, vox_weight(rep, v + RP));
+            a.add(x2, vox_weight(rep, v + 2 * (int64_t)RP));
+            a.add(x3, vox_weight(rep, v + 3 * (int64_t)RP));
+        }
+        for (; v < v1; v += RP) {
             float x[VEC];
             load_vec<VEC>(X + v * C + (size_t)col * VEC, x);
             a.add(x, vox_weight(rep, v));
@@ -192,17 +204,21 @@ __global__ void __launch_bounds__(TPB) gn_finalize(PartTab ta, PartTab tb, int G
         __syncthreads();
     }
 
-    // group moments: fixed-order serial sum (cpg <= a few hundred)
+    // group moments: wave 0 folds the channel totals (strided, then an xor butterfly: fixed order)
     __shared__ float sh_mean, sh_rstd;
-    if (t == 0) {
+    if (t < 64) {
         double S = 0.0, Q = 0.0;
-        for (int c = 0; c < cpg; ++c) { S += chan_s[c]; Q += chan_q[c]; }
-        double n = count_per_channel * (double)cpg;
-        double mean = S / n;
-        double var = Q / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        sh_mean = (float)mean;
-        sh_rstd = (float)(1.0 / sqrt(var + (double)eps));
+        for (int c = t; c < cpg; c += 64) { S += chan_s[c]; Q += chan_q[c]; }
+        S = wave_reduce_sum(S);
+        Q = wave_reduce_sum(Q);
+        if (t == 0) {
+            double n = count_per_channel * (double)cpg;
+            double mean = S / n;
+            double var = Q / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            sh_mean = (float)mean;
+            sh_rstd = (float)(1.0 / sqrt(var + (double)eps));
+        }
     }
     __syncthreads();
     const float mean = sh_mean, rstd = sh_rstd;
@@ -216,11 +232,12 @@ __global__ void __launch_bounds__(TPB) gn_finalize(PartTab ta, PartTab tb, int G
         float b1 = fabsf(fmaf(chan_mx[cg], sc, sh));
         bmax = fmaxf(bmax, fmaxf(b0, b1));
     }
-    red_mx[t] = bmax;
+    bmax = wave_reduce_max(bmax);
+    if ((t & 63) == 0) red_mx[t >> 6] = bmax;
     __syncthreads();
     if (t == 0) {
         float b = 0.f;
-        for (int i = 0; i < TPB; ++i) b = fmaxf(b, red_mx[i]);
+        for (int i = 0; i < TPB / 64; ++i) b = fmaxf(b, red_mx[i]);
         bound[g] = b;
     }
 }
@@ -232,12 +249,13 @@ struct Plan {
 };
 
 int blocks_for(int64_t nvox, int C, int64_t* vpb) {
-    // enough blocks to stream from HBM, few enough that finalize stays cheap
-    int64_t target = 16;                       // min voxels per block
-    int64_t nb = bfm_cdiv64(nvox, target);
-    int64_t cap = 2048;
-    if ((int64_t)C * cap > (1 << 20)) cap = ((1 << 20) / C) > 8 ? ((1 << 20) / C) : 8;   // bound partial table size
-    if (nb > cap) nb = cap;
+    // enough blocks to stream from HBM (>= 8 waves/CU at 4 loads in flight each), few enough that the
+    // G-block finalize stays a few microseconds: nb * C ~ 32K partial entries
+    int64_t nb = 32768 / C;
+    if (nb > 2048) nb = 2048;
+    if (nb < 8) nb = 8;
+    int64_t by_vox = bfm_cdiv64(nvox, 16);     // at least 16 voxels per block
+    if (nb > by_vox) nb = by_vox;
     if (nb < 1) nb = 1;
     *vpb = bfm_cdiv64(nvox, nb);
     nb = bfm_cdiv64(nvox, *vpb);

@@ -1,0 +1,17 @@
+"""Summarise a rocprofv3 rocpd database (kernel trace) into a per-kernel table.
+usage: python scripts/prof_summary.py gpurun_out/prof_x/bench_results.db [steps_in_trace]"""
+import sqlite3
+import sys
+
+db = sys.argv[1]
+steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+c = sqlite3.connect(db)
+rows = list(c.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3, min(end-start)/1e3, "
+                      "max(end-start)/1e3 from kernels group by name order by 3 desc"))
+tot = sum(r[2] for r in rows)
+print("# rocprofv3 --kernel-trace summary of %s" % db)
+print("# total kernel time %.3f ms over %g step(s) -> %.3f ms/step" % (tot, steps, tot / steps))
+print("%-72s %7s %11s %6s %10s %10s %10s" % ("kernel", "calls", "total_ms", "%", "avg_us", "min_us", "max_us"))
+for r in rows:
+    name = r[0].replace("(anonymous namespace)::", "")
+    print("%-72s %7d %11.3f %6.1f %10.1f %10.1f %10.1f" % (name[:72], r[1], r[2], 100 * r[2] / tot, r[3], r[4], r[5]))
