@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libbrainfm_hip.so")
 ERR = {0: "BFM_OK", -1: "BFM_E_ARG", -2: "BFM_E_SHAPE", -3: "BFM_E_WORKSPACE", -4: "BFM_E_LAUNCH"}
 
 ROLE_PLAIN, ROLE_CT, ROLE_BIAS_LOG, ROLE_SEG, ROLE_DIST, ROLE_SR, ROLE_PATHOL = range(7)
-(EW_EXP, EW_AFFINE, EW_CLAMP, EW_CLAMP_MIN, EW_GAMMA, EW_SIGMOID, EW_DIV, EW_NONZERO, EW_SUB_DIV) = range(9)
+(EW_EXP, EW_AFFINE, EW_CLAMP, EW_CLAMP_MIN, EW_GAMMA, EW_SIGMOID, EW_DIV, EW_NONZERO, EW_SUB_DIV, EW_GE) = range(10)
 (EW_ADD, EW_MUL, EW_MUL_EXP, EW_AXPY_CLAMP0, EW_AXPY, EW_DIV2) = range(6)
 
 
@@ -32,6 +32,14 @@ class TailDesc(C.Structure):
                 ("seg_first", C.c_int), ("n_seg", C.c_int), ("seg_lut", C.c_void_p),
                 ("n_dist", C.c_int), ("dist_first", C.c_int), ("max_dist", C.c_float),
                 ("unit_feat", C.c_int), ("slot_high_res", C.c_int), ("slot_fake_cortical", C.c_int)]
+
+
+class ZoomAxis(C.Structure):
+    _fields_ = [("f", C.c_void_p), ("c", C.c_void_p), ("wf", C.c_void_p), ("wc", C.c_void_p)]
+
+
+class KSet(C.Structure):
+    _fields_ = [("k", C.c_void_p * 7), ("coef", C.c_float * 7), ("nk", C.c_int)]
 
 
 _P = C.c_void_p
@@ -61,7 +69,30 @@ SIGNATURES = {
     "bfm_ew_binary": (_I, [_I, _P, _L, _P, _L, _P, _L, _L, _F, _P]),
     "bfm_softmax_cl": (_I, [_P, _L, _I, _P, _L, _L, _P]),
     "bfm_argmax_lut_cl": (_I, [_P, _L, _I, _P, _P, _L, _P]),
+    "bfm_pathology_encode": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _L, _P, _P]),
     "bfm_fake_cortical": (_I, [_P, _L, _I, _P, _L, _P]),
+    "bfm_interp3d_linear": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _L, _F, _P, _P]),
+    "bfm_interp3d_nearest": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P]),
+    "bfm_deformed_atlas": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), _L, _P, _P]),
+    "bfm_zoom_linear": (_I, [_P, _I, _I, _I, _I, C.POINTER(ZoomAxis), _I, _I, _I, _P, _P]),
+    "bfm_conv1d_axis": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "bfm_grid_pull3d_linear": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, C.POINTER(_I), _I, _P, _P]),
+    "bfm_deform_grid_workspace": (_Z, [_I, _I, _I]),
+    "bfm_deform_grid": (_I, [_P, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_I), _P, _P, _P, _P, _P, _Z, _P]),
+    "bfm_label_gauss": (_I, [_P, _P, _P, _P, _L, _I, _P, _P]),
+    "bfm_onehot_lut": (_I, [_P, _P, _I, _I, _L, _P, _P]),
+    "bfm_perlin3d": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "bfm_radix_hist_f64": (_I, [_P, _L, C.c_uint64, _I, _P, _P]),
+    "bfm_threshold_mask_f64": (_I, [_P, _L, C.c_double, _P, _P, _P]),
+    "bfm_curl3d": (_I, [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P]),
+    "bfm_advect_upwind_rhs": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "bfm_rk_combine": (_I, [_P, _I, C.POINTER(KSet), _P, _L, _P]),
+    "bfm_reduce_workspace": (_Z, []),
+    "bfm_rk_error_sumsq": (_I, [C.POINTER(KSet), _P, _P, _I, C.c_double, C.c_double, _L, _P, _P, _Z, _P]),
+    "bfm_scaled_sumsq": (_I, [_P, _P, _I, _P, _I, C.c_double, C.c_double, _L, _P, _P, _Z, _P]),
+    "bfm_dopri5_dense_eval": (_I, [_P, _P, _I, C.POINTER(KSet), C.c_double, C.c_double, _P, _L, _P]),
+    "bfm_reduce_f32": (_I, [_I, _P, _P, _L, _P, _P, _Z, _P]),
+    "bfm_reduce_f64": (_I, [_I, _P, _P, _L, _P, _P, _Z, _P]),
     "bfm_stitch_accumulate": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bfm_mask_tile": (_I, [_P, _P, _P, _L, _P, _P]),
     "bfm_tile_count_add": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

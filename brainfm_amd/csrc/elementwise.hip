@@ -26,6 +26,7 @@ __global__ void ew_unary(int op, const float* __restrict__ in, int64_t is, float
             case BFM_EW_DIV: r = x / a; break;
             case BFM_EW_NONZERO: r = x != 0.f ? 1.f : 0.f; break;
             case BFM_EW_SUB_DIV: r = (x - a) / b; break;
+            case BFM_EW_GE: r = x >= a ? 1.f : 0.f; break;
             default: r = x;
         }
         out[i * os] = r;
@@ -88,7 +89,26 @@ __global__ void fake_cortical(const float* __restrict__ d, int64_t rs, int nd, f
     }
 }
 
+// encode_pathology (Generator/datasets.py:496-518): I + Pprob * (mu[round(P)] + sigma[round(P)] * randn), clamp >= 0
+__global__ void pathology_encode(const float* __restrict__ I, const float* __restrict__ P,
+                                 const float* __restrict__ Pprob, const float* __restrict__ rn, float mu0, float mu1,
+                                 float s0, float s1, int64_t n, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const bool one = rintf(P[i]) >= 1.f;
+        const float v = I[i] + Pprob[i] * ((one ? mu1 : mu0) + (one ? s1 : s0) * rn[i]);
+        out[i] = v < 0.f ? 0.f : v;
+    }
+}
+
 }  // namespace
+
+extern "C" int bfm_pathology_encode(const float* I, const float* P, const float* Pprob, const float* randn, float mu0,
+                                    float mu1, float s0, float s1, int64_t n, float* out, bfm_stream_t stream) {
+    if (!I || !P || !Pprob || !randn || !out || n <= 0) return BFM_E_ARG;
+    hipLaunchKernelGGL(pathology_encode, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), I, P, Pprob, randn, mu0, mu1, s0,
+                       s1, n, out);
+    return bfm_launch_status();
+}
 
 extern "C" int bfm_ew_unary(int op, const float* in, int64_t in_stride, float* out, int64_t out_stride, int64_t n,
                             float a, float b, bfm_stream_t stream) {

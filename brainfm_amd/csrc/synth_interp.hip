@@ -1,0 +1,437 @@
+// Gather / resample kernels of the synthesis path (all HBM-bound, one thread per output voxel,
+// lanes along the fastest axis so coordinate reads and result writes are coalesced).
+//
+//   interp3d_linear / nearest : fast_3D_interp_torch          Generator/utils.py:119-196
+//   zoom_linear               : myzoom_torch (3 passes fused)  Generator/utils.py:200-257
+//   conv1d_axis               : gaussian_blur_3d (one axis)    Generator/utils.py:74-94
+//   grid_pull3d_linear        : interpol iso1.pull3d           utils/interpol/iso1.py:28-133, bounds.py:24-89
+//   deform_grid               : BaseGen.deform_grid            Generator/datasets.py:264-303
+//   label_gauss / onehot_lut  : generate_sample / seg targets  Generator/datasets.py:366-372, utils.py:408-411
+//
+// Built with -ffp-contract=off: a*b + c*d stays mul, mul, add like the reference's eager torch ops,
+// which is what makes the fp32 results bit-identical to the CPU path.
+#include "bfm_common.h"
+
+namespace {
+
+inline int grid_for(int64_t n, int tpb = 256, int cap = 8192) {
+    int64_t b = bfm_cdiv64(n, tpb);
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+#define GRID_STRIDE(i, n) \
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
+
+__global__ void interp_linear(const float* __restrict__ X, int nx, int ny, int nz, int C,
+                              const float* __restrict__ II, const float* __restrict__ JJ,
+                              const float* __restrict__ KK, int64_t n, float defv, float* __restrict__ out) {
+    GRID_STRIDE(i, n) {
+        const float x = II[i], y = JJ[i], z = KK[i];
+        float* o = out + i * C;
+        const bool ok = (x > 0.f) && (y > 0.f) && (z > 0.f) && (x <= (float)(nx - 1)) && (y <= (float)(ny - 1)) &&
+                        (z <= (float)(nz - 1));
+        if (!ok) {
+            for (int c = 0; c < C; ++c) o[c] = defv;
+            continue;
+        }
+        const float fxf = floorf(x), fyf = floorf(y), fzf = floorf(z);
+        const int fx = (int)fxf, fy = (int)fyf, fz = (int)fzf;
+        const int cx = min(fx + 1, nx - 1), cy = min(fy + 1, ny - 1), cz = min(fz + 1, nz - 1);
+        const float wcx = x - fxf, wcy = y - fyf, wcz = z - fzf;
+        const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
+        const int64_t sx = (int64_t)ny * nz * C, sy = (int64_t)nz * C;
+        const float* p000 = X + fx * sx + fy * sy + (int64_t)fz * C;
+        const float* p100 = X + cx * sx + fy * sy + (int64_t)fz * C;
+        const float* p010 = X + fx * sx + cy * sy + (int64_t)fz * C;
+        const float* p110 = X + cx * sx + cy * sy + (int64_t)fz * C;
+        const float* p001 = X + fx * sx + fy * sy + (int64_t)cz * C;
+        const float* p101 = X + cx * sx + fy * sy + (int64_t)cz * C;
+        const float* p011 = X + fx * sx + cy * sy + (int64_t)cz * C;
+        const float* p111 = X + cx * sx + cy * sy + (int64_t)cz * C;
+        for (int c = 0; c < C; ++c) {
+            const float c00 = p000[c] * wfx + p100[c] * wcx;
+            const float c01 = p001[c] * wfx + p101[c] * wcx;
+            const float c10 = p010[c] * wfx + p110[c] * wcx;
+            const float c11 = p011[c] * wfx + p111[c] * wcx;
+            const float c0 = c00 * wfy + c10 * wcy;
+            const float c1 = c01 * wfy + c11 * wcy;
+            o[c] = c0 * wfz + c1 * wcz;
+        }
+    }
+}
+
+// get_deformed_atlas (utils/test_utils.py:45-57) fused: mask -> affine of 100*reg -> trilinear sample of the atlas
+struct Aff34 { float a[12]; };
+__global__ void deformed_atlas(const float* __restrict__ mask, const float* __restrict__ rx,
+                               const float* __restrict__ ry, const float* __restrict__ rz,
+                               const float* __restrict__ X, int nx, int ny, int nz, Aff34 A, int64_t n,
+                               float* __restrict__ out) {
+    GRID_STRIDE(i, n) {
+        float r = 0.f;
+        if (mask[i] > 0.f) {
+            const float xx = 100.f * rx[i], yy = 100.f * ry[i], zz = 100.f * rz[i];
+            const float x = ((A.a[0] * xx + A.a[1] * yy) + A.a[2] * zz) + A.a[3];
+            const float y = ((A.a[4] * xx + A.a[5] * yy) + A.a[6] * zz) + A.a[7];
+            const float z = ((A.a[8] * xx + A.a[9] * yy) + A.a[10] * zz) + A.a[11];
+            const bool ok = (x > 0.f) && (y > 0.f) && (z > 0.f) && (x <= (float)(nx - 1)) && (y <= (float)(ny - 1)) &&
+                            (z <= (float)(nz - 1));
+            if (ok) {
+                const float fxf = floorf(x), fyf = floorf(y), fzf = floorf(z);
+                const int fx = (int)fxf, fy = (int)fyf, fz = (int)fzf;
+                const int cx = min(fx + 1, nx - 1), cy = min(fy + 1, ny - 1), cz = min(fz + 1, nz - 1);
+                const float wcx = x - fxf, wcy = y - fyf, wcz = z - fzf;
+                const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
+                auto at = [&](int a, int b, int c) { return X[((int64_t)a * ny + b) * nz + c]; };
+                const float c00 = at(fx, fy, fz) * wfx + at(cx, fy, fz) * wcx;
+                const float c01 = at(fx, fy, cz) * wfx + at(cx, fy, cz) * wcx;
+                const float c10 = at(fx, cy, fz) * wfx + at(cx, cy, fz) * wcx;
+                const float c11 = at(fx, cy, cz) * wfx + at(cx, cy, cz) * wcx;
+                const float c0 = c00 * wfy + c10 * wcy;
+                const float c1 = c01 * wfy + c11 * wcy;
+                r = c0 * wfz + c1 * wcz;
+            }
+        }
+        out[i] = r;
+    }
+}
+
+// bit copy of 4-byte elements (int32 labels or fp32 values)
+__global__ void interp_nearest(const uint32_t* __restrict__ X, int nx, int ny, int nz, int C,
+                               const float* __restrict__ II, const float* __restrict__ JJ,
+                               const float* __restrict__ KK, int64_t n, uint32_t* __restrict__ out) {
+    GRID_STRIDE(i, n) {
+        int x = (int)rintf(II[i]), y = (int)rintf(JJ[i]), z = (int)rintf(KK[i]);    // half to even, like torch.round
+        x = min(max(x, 0), nx - 1); y = min(max(y, 0), ny - 1); z = min(max(z, 0), nz - 1);
+        const uint32_t* p = X + (((int64_t)x * ny + y) * nz + z) * C;
+        uint32_t* o = out + i * C;
+        for (int c = 0; c < C; ++c) o[c] = p[c];
+    }
+}
+
+struct ZoomTabs {
+    const int32_t *fx, *cx, *fy, *cy, *fz, *cz;
+    const float *wfx, *wcx, *wfy, *wcy, *wfz, *wcz;
+};
+
+__global__ void zoom_linear(const float* __restrict__ X, int nx, int ny, int nz, int C, ZoomTabs t, int ox, int oy,
+                            int oz, float* __restrict__ out) {
+    const int64_t n = (int64_t)ox * oy * oz * C;
+    GRID_STRIDE(i, n) {
+        const int c = (int)(i % C);
+        int64_t v = i / C;
+        const int k = (int)(v % oz); v /= oz;
+        const int j = (int)(v % oy);
+        const int ii = (int)(v / oy);
+        const int fx = t.fx[ii], cx = t.cx[ii], fy = t.fy[j], cy = t.cy[j], fz = t.fz[k], cz = t.cz[k];
+        const float wfx = t.wfx[ii], wcx = t.wcx[ii], wfy = t.wfy[j], wcy = t.wcy[j], wfz = t.wfz[k], wcz = t.wcz[k];
+        const int64_t sx = (int64_t)ny * nz * C, sy = (int64_t)nz * C;
+        auto at = [&](int a, int b, int d) { return X[a * sx + b * sy + (int64_t)d * C + c]; };
+        // pass order of the reference: x, then y, then z
+        const float a00 = wfx * at(fx, fy, fz) + wcx * at(cx, fy, fz);
+        const float a10 = wfx * at(fx, cy, fz) + wcx * at(cx, cy, fz);
+        const float a01 = wfx * at(fx, fy, cz) + wcx * at(cx, fy, cz);
+        const float a11 = wfx * at(fx, cy, cz) + wcx * at(cx, cy, cz);
+        const float b0 = wfy * a00 + wcy * a10;
+        const float b1 = wfy * a01 + wcy * a11;
+        out[i] = wfz * b0 + wcz * b1;
+    }
+}
+
+__global__ void conv1d_axis(const float* __restrict__ in, int nx, int ny, int nz, int axis,
+                            const float* __restrict__ kern, int klen, float* __restrict__ out) {
+    const int64_t n = (int64_t)nx * ny * nz;
+    const int half = klen / 2;
+    const int64_t stride = axis == 0 ? (int64_t)ny * nz : (axis == 1 ? nz : 1);
+    const int len = axis == 0 ? nx : (axis == 1 ? ny : nz);
+    GRID_STRIDE(i, n) {
+        const int z = (int)(i % nz);
+        const int y = (int)((i / nz) % ny);
+        const int x = (int)(i / ((int64_t)ny * nz));
+        const int pos = axis == 0 ? x : (axis == 1 ? y : z);
+        float acc = 0.f;
+        for (int j = 0; j < klen; ++j) {
+            const int q = pos + j - half;
+            if (q >= 0 && q < len) acc = fmaf(kern[j], in[i + (int64_t)(j - half) * stride], acc);
+        }
+        out[i] = acc;
+    }
+}
+
+// ---- interpol bounds (utils/interpol/bounds.py:24-89)
+__device__ __forceinline__ int imod(int a, int m) { int r = a % m; return r < 0 ? r + m : r; }
+
+__device__ __forceinline__ int bound_index(int i, int n, int b) {
+    switch (b) {
+        case 0: case 1: return min(max(i, 0), n - 1);
+        case 3: case 5: {
+            const int n2 = n * 2;
+            i = i < 0 ? n2 - 1 - imod(-i - 1, n2) : imod(i, n2);
+            return i >= n ? n2 - 1 - i : i;
+        }
+        case 2: {
+            if (n == 1) return 0;
+            const int n2 = (n - 1) * 2;
+            i = imod(abs(i), n2);
+            return i >= n ? n2 - i : i;
+        }
+        case 4: {
+            const int n2 = 2 * (n + 1);
+            i = i < 0 ? -i - 2 : i;
+            i = imod(i, n2);
+            i = i > n ? n2 - 2 - i : i;
+            i = i == -1 ? 0 : i;
+            return i == n ? n - 1 : i;
+        }
+        case 6: return imod(i, n);
+        default: return i;
+    }
+}
+
+__device__ __forceinline__ int bound_sign(int i, int n, int b) {
+    switch (b) {
+        case 4: {
+            if (n == 1) return 1;
+            const int n2 = 2 * (n + 1);
+            i = i < 0 ? n - 1 - i : i;
+            i = imod(i, n2);
+            int x = i == 0 ? 0 : 1;
+            x = (imod(i, n + 1) == n) ? 0 : x;
+            i = i / (n + 1);
+            return (i & 1) ? -x : x;
+        }
+        case 5: {
+            i = i < 0 ? n - 1 - i : i;
+            i = i / n;
+            return (i & 1) ? -1 : 1;
+        }
+        case 0: return (i < 0 || i >= n) ? 0 : 1;
+        default: return 1;
+    }
+}
+
+__global__ void grid_pull3d(const float* __restrict__ inp, int Bi, int C, int nx, int ny, int nz,
+                            const float* __restrict__ grid, int Bg, int64_t nout, int bx, int by, int bz, int extrap,
+                            int B, float* __restrict__ out) {
+    const int64_t n = (int64_t)B * nout;
+    GRID_STRIDE(i, n) {
+        const int b = (int)(i / nout);
+        const int64_t v = i - (int64_t)b * nout;
+        const float* g = grid + ((int64_t)(Bg == 1 ? 0 : b) * nout + v) * 3;
+        const float gx = g[0], gy = g[1], gz = g[2];
+        float mask = 1.f;
+        if (extrap == 0 || extrap == 2) {
+            const float thr = extrap == 2 ? 0.5f + 5e-2f : 5e-2f;
+            const bool in = (gx > -thr) && (gx < (float)(nx - 1) + thr) && (gy > -thr) && (gy < (float)(ny - 1) + thr) &&
+                            (gz > -thr) && (gz < (float)(nz - 1) + thr);
+            mask = in ? 1.f : 0.f;
+        }
+        const float fxf = floorf(gx), fyf = floorf(gy), fzf = floorf(gz);
+        const int x0 = (int)fxf, y0 = (int)fyf, z0 = (int)fzf;
+        const float wx = gx - fxf, wy = gy - fyf, wz = gz - fzf;
+        int ix[2] = {bound_index(x0, nx, bx), bound_index(x0 + 1, nx, bx)};
+        int iy[2] = {bound_index(y0, ny, by), bound_index(y0 + 1, ny, by)};
+        int iz[2] = {bound_index(z0, nz, bz), bound_index(z0 + 1, nz, bz)};
+        int sx[2] = {bound_sign(x0, nx, bx), bound_sign(x0 + 1, nx, bx)};
+        int sy[2] = {bound_sign(y0, ny, by), bound_sign(y0 + 1, ny, by)};
+        int sz[2] = {bound_sign(z0, nz, bz), bound_sign(z0 + 1, nz, bz)};
+        const float ux[2] = {1.f - wx, wx}, uy[2] = {1.f - wy, wy}, uz[2] = {1.f - wz, wz};
+        const int64_t vol = (int64_t)nx * ny * nz;
+        for (int c = 0; c < C; ++c) {
+            const float* src = inp + ((int64_t)(Bi == 1 ? 0 : b) * C + c) * vol;
+            float acc = 0.f;
+            bool first = true;
+            // corner order of iso1.pull3d: 000, 001, 010, 011, 100, 101, 110, 111 (x slowest)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        float val = src[((int64_t)ix[a] * ny + iy[bb]) * nz + iz[d]];
+                        val = val * (float)(sx[a] * sy[bb] * sz[d]);
+                        val = val * ((ux[a] * uy[bb]) * uz[d]);
+                        acc = first ? val : acc + val;
+                        first = false;
+                    }
+            out[((int64_t)b * C + c) * nout + v] = acc * mask;
+        }
+    }
+}
+
+struct Affine { float a[9]; float c[3]; int shp[3]; };
+
+// xx2 = A[r,0]*xx1 + A[r,1]*yy1 + A[r,2]*zz1 + c2[r], clamped to the source shape; block min/max partials
+__global__ void deform_grid_k(const float* __restrict__ F, int sx, int sy, int sz, Affine P, float* __restrict__ xx,
+                              float* __restrict__ yy, float* __restrict__ zz, float* __restrict__ part) {
+    const int64_t n = (int64_t)sx * sy * sz;
+    const float cx = (float)((sx - 1) / 2.0), cy = (float)((sy - 1) / 2.0), cz = (float)((sz - 1) / 2.0);
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    GRID_STRIDE(i, n) {
+        const int z = (int)(i % sz);
+        const int y = (int)((i / sz) % sy);
+        const int x = (int)(i / ((int64_t)sy * sz));
+        float x1 = (float)x - cx, y1 = (float)y - cy, z1 = (float)z - cz;
+        if (F) { x1 = x1 + F[i * 3 + 0]; y1 = y1 + F[i * 3 + 1]; z1 = z1 + F[i * 3 + 2]; }
+        float r[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float v = ((P.a[k * 3 + 0] * x1 + P.a[k * 3 + 1] * y1) + P.a[k * 3 + 2] * z1) + P.c[k];
+            v = v < 0.f ? 0.f : v;
+            const float hi = (float)(P.shp[k] - 1);
+            v = v > hi ? hi : v;
+            r[k] = v;
+            mn[k] = fminf(mn[k], v); mx[k] = fmaxf(mx[k], v);
+        }
+        xx[i] = r[0]; yy[i] = r[1]; zz[i] = r[2];
+    }
+    __shared__ float red[6][4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float a = wave_reduce_min(mn[k]), b = wave_reduce_max(mx[k]);
+        if ((threadIdx.x & 63) == 0) { red[k][threadIdx.x >> 6] = a; red[3 + k][threadIdx.x >> 6] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        float v = red[k][0];
+        for (int w = 1; w < 4; ++w) v = k < 3 ? fminf(v, red[k][w]) : fmaxf(v, red[k][w]);
+        part[(size_t)blockIdx.x * 6 + k] = v;
+    }
+}
+
+__global__ void minmax6_final(const float* __restrict__ part, int nb, float* __restrict__ out) {
+    const int k = threadIdx.x;
+    if (k < 6) {
+        float v = part[k];
+        for (int b = 1; b < nb; ++b) v = k < 3 ? fminf(v, part[(size_t)b * 6 + k]) : fmaxf(v, part[(size_t)b * 6 + k]);
+        out[k] = v;
+    }
+}
+
+__global__ void label_gauss(const float* __restrict__ G, const float* __restrict__ mus,
+                            const float* __restrict__ sigmas, const float* __restrict__ rn, int64_t n, int ntab,
+                            float* __restrict__ out) {
+    GRID_STRIDE(i, n) {
+        float g = G[i];
+        g = g == 77.f ? 2.f : g;                               // merge WM lesion into WM (datasets.py:368)
+        int l = (int)rintf(g);
+        l = min(max(l, 0), ntab - 1);
+        float v = mus[l] + sigmas[l] * rn[i];
+        out[i] = v < 0.f ? 0.f : v;
+    }
+}
+
+__global__ void onehot_lut(const int32_t* __restrict__ S, const int32_t* __restrict__ lut, int nlut, int nl, int64_t n,
+                           float* __restrict__ out) {
+    const int64_t tot = n * nl;
+    GRID_STRIDE(i, tot) {
+        const int64_t v = i / nl;
+        const int c = (int)(i - v * nl);
+        int s = S[v];
+        s = min(max(s, 0), nlut - 1);
+        out[i] = lut[s] == c ? 1.f : 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" int bfm_interp3d_linear(const float* X, int nx, int ny, int nz, int C, const float* II, const float* JJ,
+                                   const float* KK, int64_t n, float default_value, float* out, bfm_stream_t stream) {
+    if (!X || !II || !JJ || !KK || !out || nx <= 0 || ny <= 0 || nz <= 0 || C <= 0 || n <= 0) return BFM_E_ARG;
+    hipLaunchKernelGGL(interp_linear, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), X, nx, ny, nz, C, II, JJ, KK, n,
+                       default_value, out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_interp3d_nearest(const void* X, int nx, int ny, int nz, int C, const float* II, const float* JJ,
+                                    const float* KK, int64_t n, void* out, bfm_stream_t stream) {
+    if (!X || !II || !JJ || !KK || !out || nx <= 0 || ny <= 0 || nz <= 0 || C <= 0 || n <= 0) return BFM_E_ARG;
+    hipLaunchKernelGGL(interp_nearest, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), (const uint32_t*)X, nx, ny, nz,
+                       C, II, JJ, KK, n, (uint32_t*)out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_deformed_atlas(const float* mask, const float* regx, const float* regy, const float* regz,
+                                  const float* atlas, int nx, int ny, int nz, const float* A_host /*3x4 row-major*/,
+                                  int64_t n, float* out, bfm_stream_t stream) {
+    if (!mask || !regx || !regy || !regz || !atlas || !A_host || !out || nx <= 0 || ny <= 0 || nz <= 0 || n <= 0)
+        return BFM_E_ARG;
+    Aff34 A;
+    for (int i = 0; i < 12; ++i) A.a[i] = A_host[i];
+    hipLaunchKernelGGL(deformed_atlas, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), mask, regx, regy, regz, atlas, nx,
+                       ny, nz, A, n, out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_zoom_linear(const float* X, int nx, int ny, int nz, int C, const bfm_zoom_axis_t* ax, int ox,
+                               int oy, int oz, float* out, bfm_stream_t stream) {
+    if (!X || !ax || !out || nx <= 0 || ny <= 0 || nz <= 0 || C <= 0 || ox <= 0 || oy <= 0 || oz <= 0) return BFM_E_ARG;
+    for (int a = 0; a < 3; ++a)
+        if (!ax[a].f || !ax[a].c || !ax[a].wf || !ax[a].wc) return BFM_E_ARG;
+    ZoomTabs t{ax[0].f, ax[0].c, ax[1].f, ax[1].c, ax[2].f, ax[2].c, ax[0].wf, ax[0].wc, ax[1].wf, ax[1].wc,
+               ax[2].wf, ax[2].wc};
+    int64_t n = (int64_t)ox * oy * oz * C;
+    hipLaunchKernelGGL(zoom_linear, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), X, nx, ny, nz, C, t, ox, oy, oz, out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_conv1d_axis(const float* in, int nx, int ny, int nz, int axis, const float* kern, int klen,
+                               float* out, bfm_stream_t stream) {
+    if (!in || !kern || !out || nx <= 0 || ny <= 0 || nz <= 0 || axis < 0 || axis > 2 || klen <= 0 || !(klen & 1))
+        return BFM_E_ARG;
+    int64_t n = (int64_t)nx * ny * nz;
+    hipLaunchKernelGGL(conv1d_axis, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), in, nx, ny, nz, axis, kern, klen, out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_grid_pull3d_linear(const float* inp, int Bi, int C, int nx, int ny, int nz, const float* grid,
+                                      int Bg, int ox, int oy, int oz, const int* bound, int extrapolate, float* out,
+                                      bfm_stream_t stream) {
+    if (!inp || !grid || !out || !bound || Bi <= 0 || Bg <= 0 || C <= 0 || nx <= 0 || ny <= 0 || nz <= 0 || ox <= 0 ||
+        oy <= 0 || oz <= 0)
+        return BFM_E_ARG;
+    if (Bi != Bg && Bi != 1 && Bg != 1) return BFM_E_SHAPE;
+    for (int a = 0; a < 3; ++a) if (bound[a] < 0 || bound[a] > 6) return BFM_E_ARG;
+    if (extrapolate < 0 || extrapolate > 2) return BFM_E_ARG;
+    const int B = Bi > Bg ? Bi : Bg;
+    const int64_t nout = (int64_t)ox * oy * oz;
+    hipLaunchKernelGGL(grid_pull3d, dim3(grid_for(B * nout)), dim3(256), 0, bfm_s(stream), inp, Bi, C, nx, ny, nz, grid,
+                       Bg, nout, bound[0], bound[1], bound[2], extrapolate, B, out);
+    return bfm_launch_status();
+}
+
+extern "C" size_t bfm_deform_grid_workspace(int sx, int sy, int sz) {
+    return (size_t)grid_for((int64_t)sx * sy * sz, 256, 1024) * 6 * sizeof(float);
+}
+
+extern "C" int bfm_deform_grid(const float* F, int sx, int sy, int sz, const float* A_host, const float* c2_host,
+                               const int* shp_host, float* xx, float* yy, float* zz, float* minmax, void* workspace,
+                               size_t workspace_bytes, bfm_stream_t stream) {
+    if (!A_host || !c2_host || !shp_host || !xx || !yy || !zz || !minmax || !workspace || sx <= 0 || sy <= 0 || sz <= 0)
+        return BFM_E_ARG;
+    const int nb = grid_for((int64_t)sx * sy * sz, 256, 1024);
+    if (workspace_bytes < (size_t)nb * 6 * sizeof(float)) return BFM_E_WORKSPACE;
+    Affine P;
+    for (int i = 0; i < 9; ++i) P.a[i] = A_host[i];
+    for (int i = 0; i < 3; ++i) { P.c[i] = c2_host[i]; P.shp[i] = shp_host[i]; }
+    hipLaunchKernelGGL(deform_grid_k, dim3(nb), dim3(256), 0, bfm_s(stream), F, sx, sy, sz, P, xx, yy, zz,
+                       static_cast<float*>(workspace));
+    hipLaunchKernelGGL(minmax6_final, dim3(1), dim3(64), 0, bfm_s(stream), static_cast<const float*>(workspace), nb,
+                       minmax);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_label_gauss(const float* G, const float* mus, const float* sigmas, const float* randn, int64_t n,
+                               int ntab, float* out, bfm_stream_t stream) {
+    if (!G || !mus || !sigmas || !randn || !out || n <= 0 || ntab <= 0) return BFM_E_ARG;
+    hipLaunchKernelGGL(label_gauss, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), G, mus, sigmas, randn, n, ntab, out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_onehot_lut(const int32_t* S, const int32_t* lut, int nlut, int n_labels, int64_t n, float* out,
+                              bfm_stream_t stream) {
+    if (!S || !lut || !out || nlut <= 0 || n_labels <= 0 || n <= 0) return BFM_E_ARG;
+    hipLaunchKernelGGL(onehot_lut, dim3(grid_for(n * n_labels)), dim3(256), 0, bfm_s(stream), S, lut, nlut, n_labels, n,
+                       out);
+    return bfm_launch_status();
+}

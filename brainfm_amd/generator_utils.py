@@ -1,0 +1,310 @@
+"""Host-side mirror of ``Generator/utils.py`` (the kernels that feed training-data synthesis).
+
+Same function names, argument meaning and error behaviour as the reference; tensors stay
+torch tensors on the HIP device, the arithmetic runs in libbrainfm_hip.so:
+
+  fast_3D_interp_torch(X, II, JJ, KK, mode, default_value_linear)    Generator/utils.py:119-196
+  myzoom_torch(X, factor, aff)                                       :200-257
+  make_gaussian_kernel / gaussian_blur_3d                            :74-94
+  add_gamma_transform / add_bias_field / resample_resolution / add_noise   :568-638
+  make_affine_matrix / binarize / resolution_sampler                 :34-57,:65-72,:102-116
+  augment_pathology                                                  :542-560
+
+Random draws keep the reference's call order on ``np.random`` so a seeded host stream lines up;
+``torch.randn`` is drawn on the device (RNG-stream parity across devices is not a goal).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _f32(t, device=None):
+    t = torch.as_tensor(t)
+    if device is not None:
+        t = t.to(device)
+    return t.to(torch.float32).contiguous()
+
+
+def _require_cuda(t, what):
+    if t.device.type != "cuda":
+        raise L.BfmError("%s runs on a HIP device only; there is no CPU fallback in the product path" % what)
+
+
+# ----------------------------------------------------------------------------- sampling helpers (host)
+def resolution_sampler(low_res_only=False):
+    """Generator/utils.py:34-57 (host RNG only)."""
+    r = (np.random.rand() * 0.5) + 0.5 if low_res_only else np.random.rand()
+    if r < 0.25:
+        resolution = np.array([1.0, 1.0, 1.0]); thickness = np.array([1.0, 1.0, 1.0])
+    elif r < 0.5:
+        resolution = np.array([1.0, 1.0, 1.0]); thickness = np.array([1.0, 1.0, 1.0])
+        idx = np.random.randint(3)
+        resolution[idx] = 2.5 + 6 * np.random.rand()
+        thickness[idx] = np.min([resolution[idx], 4.0 + 2.0 * np.random.rand()])
+    elif r < 0.75:
+        resolution = np.array([1.3, 1.3, 4.8]) + 0.4 * np.random.rand(3)
+        thickness = resolution.copy()
+    else:
+        resolution = 2.0 + 3.0 * np.random.rand(3)
+        thickness = resolution.copy()
+    return resolution, thickness
+
+
+def make_affine_matrix(rot, sh, s):
+    """Generator/utils.py:102-116."""
+    Rx = np.array([[1, 0, 0], [0, np.cos(rot[0]), -np.sin(rot[0])], [0, np.sin(rot[0]), np.cos(rot[0])]])
+    Ry = np.array([[np.cos(rot[1]), 0, np.sin(rot[1])], [0, 1, 0], [-np.sin(rot[1]), 0, np.cos(rot[1])]])
+    Rz = np.array([[np.cos(rot[2]), -np.sin(rot[2]), 0], [np.sin(rot[2]), np.cos(rot[2]), 0], [0, 0, 1]])
+    SHx = np.array([[1, 0, 0], [sh[1], 1, 0], [sh[2], 0, 1]])
+    SHy = np.array([[1, sh[0], 0], [0, 1, 0], [0, sh[2], 1]])
+    SHz = np.array([[1, 0, sh[0]], [0, 1, sh[1]], [0, 0, 1]])
+    A = SHx @ SHy @ SHz @ Rx @ Ry @ Rz
+    A[0, :] = A[0, :] * s[0]
+    A[1, :] = A[1, :] * s[1]
+    A[2, :] = A[2, :] * s[2]
+    return A
+
+
+# ----------------------------------------------------------------------------- reductions / elementwise
+def _reduce(op, x, y=None):
+    lib = L.load()
+    x = x.contiguous()
+    ws = torch.empty(lib.bfm_reduce_workspace(), dtype=torch.uint8, device=x.device)
+    out = torch.empty(1, dtype=torch.float64, device=x.device)
+    L.check(lib.bfm_reduce_f32(op, L.ptr(x), L.ptr(y.contiguous()) if y is not None else None, x.numel(), L.ptr(out),
+                               L.ptr(ws), ws.numel(), L.stream_ptr()), "reduce")
+    return float(out.item())
+
+
+def tensor_min(x): return _reduce(0, x)
+def tensor_max(x): return _reduce(1, x)
+def tensor_sum(x): return _reduce(2, x)
+def tensor_dot(x, y): return _reduce(3, x, y)
+
+
+def ew_unary(op, x, a=0.0, b=0.0):
+    lib = L.load()
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    L.check(lib.bfm_ew_unary(op, L.ptr(x), 1, L.ptr(out), 1, x.numel(), float(a), float(b), L.stream_ptr()), "ew_unary")
+    return out
+
+
+def ew_binary(op, x, y, a=0.0):
+    lib = L.load()
+    x = x.contiguous(); y = y.contiguous()
+    out = torch.empty_like(x)
+    ys = 0 if y.numel() == 1 else 1
+    L.check(lib.bfm_ew_binary(op, L.ptr(x), 1, L.ptr(y), ys, L.ptr(out), 1, x.numel(), float(a), L.stream_ptr()),
+            "ew_binary")
+    return out
+
+
+def binarize(p, thres):
+    """Generator/utils.py:65-72: 1 where p >= thres*max(p) else 0 (dtype of p kept)."""
+    lib = L.load()
+    if p.dtype == torch.float64:
+        pc = p.contiguous()
+        from .shapeid import tensor_max_f64
+        t = thres * tensor_max_f64(pc)
+        masked = torch.empty_like(pc)
+        mask = torch.empty_like(pc)
+        L.check(lib.bfm_threshold_mask_f64(L.ptr(pc), pc.numel(), float(t), L.ptr(masked), L.ptr(mask),
+                                           L.stream_ptr()), "threshold_mask")
+        return mask
+    pf = p.to(torch.float32).contiguous()
+    t = float(np.float32(thres) * np.float32(tensor_max(pf)))
+    return ew_unary(L.EW_GE, pf, t).to(p.dtype)
+
+
+# ----------------------------------------------------------------------------- K10 / K11
+def fast_3D_interp_torch(X, II, JJ, KK, mode="linear", default_value_linear=0.0):
+    """Generator/utils.py:119-196.  X: (nx,ny,nz[,C]); II/JJ/KK: coordinate tensors of any common shape."""
+    if II is None:
+        return X
+    if mode not in ("linear", "nearest"):
+        raise Exception("mode must be linear or nearest")
+    _require_cuda(X, "fast_3D_interp_torch")
+    lib = L.load()
+    dev = X.device
+    squeeze = X.dim() == 3
+    Xc = (X[..., None] if squeeze else X)
+    nx, ny, nz, Cc = Xc.shape
+    II, JJ, KK = (_f32(t, dev) for t in (II, JJ, KK))
+    n = II.numel()
+    if mode == "nearest":
+        if II.dim() != 3:
+            # the reference indexes Y.shape[3]: it only works with 3-D coordinate grids in this mode
+            raise IndexError("tuple index out of range")
+        if Xc.dtype in (torch.int32, torch.float32):
+            src = Xc.contiguous()
+        elif Xc.dtype in (torch.int64, torch.int16, torch.uint8, torch.bool):
+            src = Xc.to(torch.int32).contiguous()
+        else:
+            src = Xc.to(torch.float32).contiguous()
+        out = torch.empty(tuple(II.shape) + (Cc,), dtype=src.dtype, device=dev)
+        L.check(lib.bfm_interp3d_nearest(L.ptr(src), nx, ny, nz, Cc, L.ptr(II), L.ptr(JJ), L.ptr(KK), n, L.ptr(out),
+                                         L.stream_ptr()), "interp3d_nearest")
+        out = out.to(Xc.dtype) if out.dtype != Xc.dtype else out
+        return out[..., 0] if out.shape[3] == 1 else out
+    dv = float(default_value_linear)
+    src = Xc.to(torch.float32).contiguous()
+    out = torch.empty(tuple(II.shape) + (Cc,), dtype=torch.float32, device=dev)
+    L.check(lib.bfm_interp3d_linear(L.ptr(src), nx, ny, nz, Cc, L.ptr(II), L.ptr(JJ), L.ptr(KK), n, dv, L.ptr(out),
+                                    L.stream_ptr()), "interp3d_linear")
+    return out[..., 0] if Cc == 1 else out
+
+
+# ----------------------------------------------------------------------------- K12
+def torch_cpu_arange_f32(start, end, step, vec=8):
+    """torch.arange(start, end, step, dtype=float32) exactly as ATen's CPU kernel evaluates it (the
+    reference builds its zoom tables this way, Generator/utils.py:208-210): pairs of 8-lane vectors are
+    float(float(start + step*idx) + lane*step); the remainder is float(start + step*idx)."""
+    cnt = int(math.ceil((end - start) / step))
+    out = np.empty(max(cnt, 0), dtype=np.float32)
+    i = 0
+    while cnt - i >= 2 * vec:
+        for _ in range(2):
+            base = np.float64(np.float32(start + step * i))
+            out[i:i + vec] = (base + np.arange(vec, dtype=np.float64) * step).astype(np.float32)
+            i += vec
+    out[i:] = (start + step * np.arange(i, cnt, dtype=np.float64)).astype(np.float32)
+    return out
+
+
+def zoom_tables(n, factor):
+    """Per-axis (floor idx, ceil idx, w_floor, w_ceil) of myzoom_torch, Generator/utils.py:205-235."""
+    delta = (1.0 - factor) / (2.0 * factor)
+    new = int(np.round(n * factor))
+    v = torch_cpu_arange_f32(delta, delta + new / factor, 1.0 / factor)[:new]
+    v = np.where(v < 0, np.float32(0), v)
+    v = np.where(v > n - 1, np.float32(n - 1), v).astype(np.float32)
+    f = np.floor(v).astype(np.int32)
+    c = np.minimum(f + 1, n - 1).astype(np.int32)
+    wc = (v - f.astype(np.float32)).astype(np.float32)
+    wf = (np.float32(1) - wc).astype(np.float32)
+    return f, c, wf, wc
+
+
+def myzoom_torch(X, factor, aff=None):
+    """Generator/utils.py:200-257: separable linear zoom (fused into one kernel)."""
+    _require_cuda(X, "myzoom_torch")
+    lib = L.load()
+    dev = X.device
+    squeeze = X.dim() == 3
+    Xc = (X[..., None] if squeeze else X).to(torch.float32).contiguous()
+    factor = np.asarray(factor, dtype=np.float64) * np.ones(3)
+    nx, ny, nz, Cc = Xc.shape
+    tabs, keep, newsize = [], [], []
+    axes = (L.ZoomAxis * 3)()
+    for a, n in enumerate((nx, ny, nz)):
+        f, c, wf, wc = zoom_tables(n, float(factor[a]))
+        newsize.append(len(f))
+        t = [torch.from_numpy(v).to(dev) for v in (f, c, wf, wc)]
+        keep.append(t)
+        axes[a] = L.ZoomAxis(*[v.data_ptr() for v in t])
+    out = torch.empty((newsize[0], newsize[1], newsize[2], Cc), dtype=torch.float32, device=dev)
+    L.check(lib.bfm_zoom_linear(L.ptr(Xc), nx, ny, nz, Cc, axes, newsize[0], newsize[1], newsize[2], L.ptr(out),
+                                L.stream_ptr()), "zoom_linear")
+    Y = out[..., 0] if Cc == 1 else out
+    if aff is not None:
+        aff_new = aff.copy()
+        aff_new[:-1] = aff_new[:-1] / factor
+        aff_new[:-1, -1] = aff_new[:-1, -1] - aff[:-1, :-1] @ (0.5 - 0.5 / (factor * np.ones(3)))
+        return Y, aff_new
+    return Y
+
+
+# ----------------------------------------------------------------------------- K13
+def make_gaussian_kernel(sigma, device):
+    """Generator/utils.py:74-82 (7-tap example in SURVEY appendix C)."""
+    sl = int(np.ceil(3 * sigma))
+    ts = np.linspace(-sl, sl, 2 * sl + 1).astype(np.float32)
+    g = np.exp((-(ts / np.float32(sigma)) ** 2 / 2)).astype(np.float32)
+    return torch.from_numpy((g / g.sum(dtype=np.float32)).astype(np.float32)).to(device)
+
+
+def gaussian_blur_3d(input, stds, device):
+    """Generator/utils.py:84-94: three zero-padded 1-D correlations."""
+    _require_cuda(input, "gaussian_blur_3d")
+    lib = L.load()
+    cur = input.to(torch.float32).contiguous()
+    nx, ny, nz = cur.shape
+    for ax in range(3):
+        if stds[ax] > 0:
+            k = make_gaussian_kernel(stds[ax], cur.device)
+            out = torch.empty_like(cur)
+            L.check(lib.bfm_conv1d_axis(L.ptr(cur), nx, ny, nz, ax, L.ptr(k), k.numel(), L.ptr(out), L.stream_ptr()),
+                    "conv1d_axis")
+            cur = out
+    return cur
+
+
+# ----------------------------------------------------------------------------- K14 augmentations
+def add_gamma_transform(I, aux_dict, cfg, device, **kwargs):
+    """Generator/utils.py:568-572: 300 * (I/300) ** exp(gamma_std * N(0,1))."""
+    gamma = float(np.exp(cfg.gamma_std * np.random.randn(1)[0]))
+    return ew_unary(L.EW_GAMMA, I.to(torch.float32), 300.0, gamma), aux_dict
+
+
+def add_bias_field(I, aux_dict, cfg, input_mode, setups, size, device, **kwargs):
+    """Generator/utils.py:574-589."""
+    if input_mode == "CT":
+        aux_dict.update({"high_res": I})
+        return I, aux_dict
+    bf_scale = cfg.bf_scale_min + np.random.rand(1) * (cfg.bf_scale_max - cfg.bf_scale_min)
+    size_BF_small = np.round(bf_scale * np.array(size)).astype(int).tolist()
+    if setups["photo_mode"]:
+        size_BF_small[1] = np.round(size[1] / setups["spac"]).astype(int)
+    amp = float(np.float32(cfg.bf_std_min + (cfg.bf_std_max - cfg.bf_std_min) * np.random.rand(1))[0])
+    BFsmall = ew_unary(L.EW_AFFINE, torch.randn(size_BF_small, dtype=torch.float, device=I.device), amp, 0.0)
+    BFlog = myzoom_torch(BFsmall, np.array(size) / size_BF_small)
+    I_bf = ew_binary(L.EW_MUL_EXP, I.to(torch.float32), BFlog)
+    aux_dict.update({"BFlog": BFlog, "high_res": I_bf})
+    return I_bf, aux_dict
+
+
+def resample_resolution(I, aux_dict, setups, res, size, device, **kwargs):
+    """Generator/utils.py:591-609: blur to the slice thickness, then trilinear sample on the low-res grid."""
+    stds = (0.85 + 0.3 * np.random.rand()) * np.log(5) / np.pi * setups["thickness"] / res
+    stds[setups["thickness"] <= res] = 0.0
+    I_blur = gaussian_blur_3d(I, stds, device)
+    new_size = (np.array(size) * res / setups["resolution"]).astype(int)
+    factors = np.array(new_size) / np.array(size)
+    delta = (1.0 - factors) / (2.0 * factors)
+    v = [np.arange(delta[a], delta[a] + new_size[a] / factors[a], 1 / factors[a])[:new_size[a]] for a in range(3)]
+    II, JJ, KK = np.meshgrid(v[0], v[1], v[2], sparse=False, indexing="ij")
+    dev = I.device
+    II = torch.tensor(II, dtype=torch.float, device=dev)
+    JJ = torch.tensor(JJ, dtype=torch.float, device=dev)
+    KK = torch.tensor(KK, dtype=torch.float, device=dev)
+    I_small = fast_3D_interp_torch(I_blur, II, JJ, KK)
+    aux_dict.update({"factors": factors})
+    return I_small, aux_dict
+
+
+def add_noise(I, aux_dict, cfg, device, **kwargs):
+    """Generator/utils.py:633-638: I + std * N(0,1), clamped at 0."""
+    noise_std = float(np.float32(cfg.noise_std_min + (cfg.noise_std_max - cfg.noise_std_min) * np.random.rand(1))[0])
+    rn = torch.randn(I.shape, dtype=torch.float, device=I.device)
+    return ew_binary(L.EW_AXPY_CLAMP0, I.to(torch.float32), rn, noise_std), aux_dict
+
+
+augmentation_funcs = {"gamma": add_gamma_transform, "bias_field": add_bias_field, "resample": resample_resolution,
+                      "noise": add_noise}
+
+
+# ----------------------------------------------------------------------------- pathology shape augmentation
+def augment_pathology(Pprob, pde_func, t, shape_gen_args, device):
+    """Generator/utils.py:542-560: advect the probability map along a random divergence-free field."""
+    from .shapeid import generate_velocity_3d, odeint_adjoint
+    Pprob = torch.squeeze(Pprob)
+    nt = np.random.randint(1, shape_gen_args.max_nt + 1)
+    if nt <= 1:
+        return Pprob
+    pde_func.V_dict = generate_velocity_3d(Pprob.shape, shape_gen_args.perlin_res, shape_gen_args.V_multiplier, device)
+    return odeint_adjoint(pde_func, Pprob[None], t[:nt], shape_gen_args.dt, method=shape_gen_args.integ_method)[-1, 0]

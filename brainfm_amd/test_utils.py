@@ -137,6 +137,24 @@ def center_crop(img, win_size=[220, 220, 220], zero_crop_first=False, aff=np.eye
     return img, [0, 0, 0], orig_shp, aff
 
 
+# ----------------------------------------------------------------------------- deformed atlas
+def get_deformed_atlas(brain_labels, regx, regy, regz, MNI, A):
+    """utils/test_utils.py:45-57 with the atlas volume and its inverse affine passed in (the reference reads
+    files/gca.mgz into module globals at import).  DEF[M] = trilinear(MNI, A @ (100*reg)) for M = labels>0,
+    one fused kernel."""
+    if regx.device.type != "cuda":
+        raise L.BfmError("get_deformed_atlas runs on a HIP device only; there is no CPU fallback in the product path")
+    Ah = np.asarray(torch.as_tensor(A).detach().cpu(), dtype=np.float32)[:3, :4].reshape(-1)
+    Ac = (C.c_float * 12)(*[float(v) for v in Ah])
+    f = lambda t: t.to(device=regx.device, dtype=torch.float32).contiguous()
+    mask, rx, ry, rz, atlas = f(brain_labels), f(regx), f(regy), f(regz), f(MNI)
+    out = torch.empty_like(rx)
+    L.check(L.load().bfm_deformed_atlas(L.ptr(mask), L.ptr(rx), L.ptr(ry), L.ptr(rz), L.ptr(atlas), atlas.shape[0],
+                                        atlas.shape[1], atlas.shape[2], Ac, rx.numel(), L.ptr(out), L.stream_ptr()),
+            "deformed_atlas")
+    return out
+
+
 # ----------------------------------------------------------------------------- sessions
 class InferenceSession:
     """Model + packed weights kept resident between calls (the reference rebuilds the 264 M-parameter

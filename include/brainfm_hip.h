@@ -160,7 +160,8 @@ int bfm_divide_by_count(float* full, const float* cnt, int64_t n, bfm_stream_t s
 enum {
     BFM_EW_EXP = 0, BFM_EW_AFFINE = 1 /* x*a+b */, BFM_EW_CLAMP = 2 /* [a,b] */, BFM_EW_CLAMP_MIN = 3,
     BFM_EW_GAMMA = 4 /* a*(x/a)^b, add_gamma_transform utils.py:568-572 */, BFM_EW_SIGMOID = 5,
-    BFM_EW_DIV = 6 /* x/a */, BFM_EW_NONZERO = 7 /* x!=0 ? 1:0 */, BFM_EW_SUB_DIV = 8 /* (x-a)/b */
+    BFM_EW_DIV = 6 /* x/a */, BFM_EW_NONZERO = 7 /* x!=0 ? 1:0 */, BFM_EW_SUB_DIV = 8 /* (x-a)/b */,
+    BFM_EW_GE = 9 /* x>=a ? 1:0, binarize utils.py:65-72 */
 };
 enum {
     BFM_EW_ADD = 0, BFM_EW_MUL = 1, BFM_EW_MUL_EXP = 2 /* x*exp(y), add_bias_field utils.py:585-587 */,
@@ -174,8 +175,86 @@ int bfm_softmax_cl(const float* x, int64_t x_row_stride, int C, float* y, int64_
                    bfm_stream_t stream);
 int bfm_argmax_lut_cl(const float* p, int64_t row_stride, int C, const int32_t* lut, int64_t* out, int64_t n,
                       bfm_stream_t stream);
+/* encode_pathology -- Generator/datasets.py:496-518 */
+int bfm_pathology_encode(const float* I, const float* P, const float* Pprob, const float* randn, float mu0, float mu1,
+                         float s0, float s1, int64_t n, float* out, bfm_stream_t stream);
 int bfm_fake_cortical(const float* dist, int64_t row_stride, int n_dist, float* out, int64_t n,
                       bfm_stream_t stream);
+
+/* ---------------------------------------------------------------- synthesis
+ * Gather / resample kernels of Generator/utils.py and utils/interpol (fp32, results bit-identical to the
+ * reference's CPU path where it is a fixed sequence of IEEE operations).  Volumes are (nx,ny,nz[,C])
+ * row-major with channels last, exactly the reference's layout. */
+/* fast_3D_interp_torch(X, II, JJ, KK, 'linear', default) -- Generator/utils.py:140-192: valid iff
+ * II>0 && II<=nx-1 (strict lower bound), upper corner clamped, invalid -> default_value. */
+int bfm_interp3d_linear(const float* X, int nx, int ny, int nz, int C, const float* II, const float* JJ,
+                        const float* KK, int64_t n, float default_value, float* out, bfm_stream_t stream);
+/* ... 'nearest' -- :124-138: round half to even, clamp; 4-byte elements copied bitwise (int32 or fp32). */
+int bfm_interp3d_nearest(const void* X, int nx, int ny, int nz, int C, const float* II, const float* JJ,
+                         const float* KK, int64_t n, void* out, bfm_stream_t stream);
+/* get_deformed_atlas -- utils/test_utils.py:45-57, fused: where mask>0, sample the atlas trilinearly at
+ * A(3x4) applied to 100*(regx,regy,regz); 0 elsewhere. */
+int bfm_deformed_atlas(const float* mask, const float* regx, const float* regy, const float* regz, const float* atlas,
+                       int nx, int ny, int nz, const float* A_host, int64_t n, float* out, bfm_stream_t stream);
+/* myzoom_torch -- Generator/utils.py:200-257.  Per-axis tables (floor index, ceil index, weights) are built
+ * by the host exactly as the reference builds them (torch.arange in fp32); the three passes are fused. */
+typedef struct { const int32_t* f; const int32_t* c; const float* wf; const float* wc; } bfm_zoom_axis_t;
+int bfm_zoom_linear(const float* X, int nx, int ny, int nz, int C, const bfm_zoom_axis_t* axes /*[3]*/, int ox, int oy,
+                    int oz, float* out, bfm_stream_t stream);
+/* one axis of gaussian_blur_3d -- Generator/utils.py:84-94: zero-padded 1-D correlation, odd kernel. */
+int bfm_conv1d_axis(const float* in, int nx, int ny, int nz, int axis, const float* kern, int klen, float* out,
+                    bfm_stream_t stream);
+/* interpol.grid_pull(interpolation='linear') -> iso1.pull3d -- utils/interpol/iso1.py:28-133.
+ * inp (Bi,C,nx,ny,nz), grid (Bg,ox,oy,oz,3), out (max(Bi,Bg),C,ox,oy,oz); bound[3] in 0..6
+ * (zero, replicate, dct1, dct2, dst1, dst2, dft -- bounds.py:8-15); extrapolate 0 no / 1 yes / 2 hist. */
+int bfm_grid_pull3d_linear(const float* inp, int Bi, int C, int nx, int ny, int nz, const float* grid, int Bg, int ox,
+                           int oy, int oz, const int* bound, int extrapolate, float* out, bfm_stream_t stream);
+/* BaseGen.deform_grid -- Generator/datasets.py:264-303: (xc+F) -> A*. + c2, clamp to the source shape, and the
+ * six global min/max (minmax = {min x,y,z, max x,y,z}, device).  F is [n][3] or NULL. */
+size_t bfm_deform_grid_workspace(int sx, int sy, int sz);
+int bfm_deform_grid(const float* F, int sx, int sy, int sz, const float* A_host /*[9]*/, const float* c2_host /*[3]*/,
+                    const int* shp_host /*[3]*/, float* xx, float* yy, float* zz, float* minmax /*[6]*/,
+                    void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+/* generate_sample core -- Generator/datasets.py:366-372: mus[round(G)] + sigmas[round(G)]*randn, clamp >= 0
+ * (label 77 merged into 2). */
+int bfm_label_gauss(const float* G, const float* mus, const float* sigmas, const float* randn, int64_t n, int ntab,
+                    float* out, bfm_stream_t stream);
+/* onehotmatrix[lut[S]] -- Generator/utils.py:408-411: out [n][n_labels]. */
+int bfm_onehot_lut(const int32_t* S, const int32_t* lut, int nlut, int n_labels, int64_t n, float* out,
+                   bfm_stream_t stream);
+
+/* Perlin noise on a lattice of host-drawn gradients -- ShapeID/perlin3d.py:38-83 (fp64, NumPy semantics).
+ * grad: [(rx+1)(ry+1)(rz+1)][3]. */
+int bfm_perlin3d(const double* grad, int sx, int sy, int sz, int rx, int ry, int rz, double* out, bfm_stream_t stream);
+/* np.percentile support (perlin3d.py:84-90): 16-bit digit histogram of the order-preserving key of each
+ * double among keys whose higher bits equal `prefix`; four passes select an order statistic. */
+int bfm_radix_hist_f64(const double* x, int64_t n, uint64_t prefix, int shift, uint32_t* hist65536, bfm_stream_t stream);
+int bfm_threshold_mask_f64(const double* x, int64_t n, double thr, double* masked, double* mask, bfm_stream_t stream);
+/* stream_3D(gradient_c(a), gradient_c(b), gradient_c(c)) * mult -- ShapeID/misc.py:66-80,198-259. */
+int bfm_curl3d(const double* a, const double* b, const double* c, int sx, int sy, int sz, float mult, float* Vx,
+               float* Vy, float* Vz, bfm_stream_t stream);
+/* AdvDiffPDE.forward, perf_pattern='adv', V_type='vector_div_free' -- ShapeID/DiffEqs/pde.py:616-640:
+ * out = -(Vx*dxC + Vy*dyC + Vz*dzC) with upwind differences of the (optionally Neumann-conditioned) field. */
+int bfm_advect_upwind_rhs(const void* C, int c_is_f64, const float* Vx, const float* Vy, const float* Vz, int sx,
+                          int sy, int sz, int neumann_bc, float* out, bfm_stream_t stream);
+/* Runge-Kutta tensor arithmetic of Dopri5Solver (ShapeID/DiffEqs/rk_common.py:22-61, misc.py:22-25,84-170,
+ * interp.py:5-65).  k[j] are fp32 stage derivatives, coef[j] the fp32 value of (dt*c_j). */
+typedef struct { const float* k[7]; float coef[7]; int nk; } bfm_kset_t;
+int bfm_rk_combine(const void* y0 /*NULL: out = sum*/, int is_f64, const bfm_kset_t* ks, void* out, int64_t n,
+                   bfm_stream_t stream);
+size_t bfm_reduce_workspace(void);
+int bfm_rk_error_sumsq(const bfm_kset_t* ks, const void* y0, const void* y1, int is_f64, double atol, double rtol,
+                       int64_t n, double* out, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+int bfm_scaled_sumsq(const void* a, const void* b /*may be NULL*/, int ab_is_f64, const void* y0, int y_is_f64,
+                     double atol, double rtol, int64_t n, double* out, void* workspace, size_t workspace_bytes,
+                     bfm_stream_t stream);
+int bfm_dopri5_dense_eval(const void* y0, const void* y1, int is_f64, const bfm_kset_t* mid, double dt, double x,
+                          void* out, int64_t n, bfm_stream_t stream);
+/* op: 0 min, 1 max, 2 sum(x), 3 sum(x*y); result in fp64 (deterministic two-stage reduction). */
+int bfm_reduce_f32(int op, const float* x, const float* y, int64_t n, double* out, void* workspace,
+                   size_t workspace_bytes, bfm_stream_t stream);
+int bfm_reduce_f64(int op, const double* x, const double* y, int64_t n, double* out, void* workspace,
+                   size_t workspace_bytes, bfm_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,245 @@
+"""Parity of the HIP synthesis kernels (through the C ABI / host mirrors) against the golden vectors
+of the real reference and the NumPy oracle.  Needs an MI355X: run with `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz
+from oracle import synth_ref as S
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t.to(dtype) if dtype is not None else t
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def _close(a, b, tol):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    e = float(np.abs(a - b).max()) / max(1e-6, float(np.abs(b).max()))
+    assert e <= tol, e
+
+
+def test_fast_3d_interp_bit_exact():
+    from brainfm_amd.generator_utils import fast_3D_interp_torch as interp
+    d = load_npz("synth_interp.npz")
+    II, JJ, KK = T(d["II"]), T(d["JJ"]), T(d["KK"])
+    assert np.array_equal(N(interp(T(d["X1"]), II, JJ, KK, "linear")), d["lin1"])
+    assert np.array_equal(N(interp(T(d["X1"]), II, JJ, KK, "linear", 7.5)), d["lin1_def"])
+    assert np.array_equal(N(interp(T(d["X3"]), II, JJ, KK, "linear")), d["lin3"])
+    assert np.array_equal(N(interp(T(d["X1"]), T(d["G3i"]), T(d["G3j"]), T(d["G3k"]))), d["lin_grid"])
+    g = [T(d["N3i"]), T(d["N3j"]), T(d["N3k"])]
+    out = interp(T(d["S"]), *g, "nearest")
+    assert out.dtype == torch.int32 and np.array_equal(N(out), d["near_i"])
+    assert np.array_equal(N(interp(T(d["X3"]), *g, "nearest")), d["near_f"])
+    Xc = T((np.arange(27).reshape(3, 3, 3) + 1).astype(np.float32))
+    p = T(d["appc_pts"])
+    assert np.array_equal(N(interp(Xc, p[:, 0].contiguous(), p[:, 1].contiguous(), p[:, 2].contiguous())), d["appc_lin"])
+    nn = T(np.array([0.5, 1.5, 2.5, -0.6], np.float32).reshape(4, 1, 1))
+    z = torch.zeros(4, 1, 1, device=DEV)
+    assert N(interp(Xc, nn, z, z, "nearest")).ravel().tolist() == [1, 19, 19, 1]
+    with pytest.raises(Exception, match="mode must be linear or nearest"):
+        interp(Xc, nn, z, z, "cubic")
+    assert interp(Xc, None, None, None) is Xc
+
+
+def test_myzoom_blur_and_augmentations():
+    from brainfm_amd import generator_utils as GU
+    from brainfm_amd import _lib as L
+    d = load_npz("synth_zoom_blur_aug.npz")
+    assert np.array_equal(N(GU.myzoom_torch(T(d["zx"]), d["zf"])), d["zy"])
+    assert np.array_equal(N(GU.myzoom_torch(T(d["zx2"]), d["zf2"])), d["zy2"])
+    assert np.array_equal(N(GU.myzoom_torch(T(d["zx3"]), d["zf3"])), d["zy3"])
+    z = GU.myzoom_torch(T(np.arange(4, dtype=np.float32).reshape(4, 1, 1)), np.array([2.5, 1, 1]))
+    assert np.array_equal(N(z), d["appc_zoom"])
+    _close(N(GU.make_gaussian_kernel(1.0, DEV)), d["gk1"], 1e-6)
+    _close(N(GU.gaussian_blur_3d(T(d["bI"]), d["bstd"], DEV)), d["bO"], 2e-6)
+    I = T(d["aug_I"])
+    _close(N(GU.ew_unary(L.EW_GAMMA, I, 300.0, float(d["aug_gamma"]))), d["aug_Ig"], 3e-6)
+    bflog = GU.myzoom_torch(T(d["bf_small"]), np.array([40, 40, 40]) / np.array(d["bf_small"].shape))
+    assert np.array_equal(N(bflog), d["bf_log"])
+    _close(N(GU.ew_binary(L.EW_MUL_EXP, I, bflog)), d["bf_I"], 2e-6)
+    shifted = GU.ew_unary(L.EW_AFFINE, I, 1.0, -100.0)
+    out = GU.ew_binary(L.EW_AXPY_CLAMP0, shifted, T(d["noise_randn"]), float(d["noise_std"][0]))
+    _close(N(out), d["noise_out"], 1e-6)
+    assert float(out.min()) >= 0
+    # reductions used by the augmentation chain
+    assert abs(GU.tensor_max(I) - float(d["aug_I"].max())) == 0
+    assert abs(GU.tensor_min(I) - float(d["aug_I"].min())) == 0
+    assert abs(GU.tensor_sum(I) - float(d["aug_I"].astype(np.float64).sum())) <= 1e-6 * float(d["aug_I"].sum())
+
+
+def test_resample_resolution_chain_with_reference_rng():
+    """resample_resolution draws one np.random value; with the same seed the whole chain must agree."""
+    from brainfm_amd import generator_utils as GU
+    d = load_npz("synth_zoom_blur_aug.npz")
+    np.random.seed(8)
+    setups = {"thickness": np.array([1.0, 4.2, 1.0]), "resolution": np.array([1.0, 3.5, 1.0])}
+    small, aux = GU.resample_resolution(T(d["aug_I"]), {}, setups, np.array([1.0, 1.0, 1.0]), [40, 40, 40], DEV)
+    assert np.array_equal(aux["factors"], d["rs_factors"])
+    _close(N(small), d["rs_small"], 3e-6)
+    assert np.array_equal(N(GU.myzoom_torch(T(d["rs_small"]), 1 / d["rs_factors"])), d["rs_back"])
+    # gamma with the reference's RNG draw
+    from argparse import Namespace
+    np.random.seed(5)
+    Ig, _ = GU.add_gamma_transform(T(d["aug_I"]), {}, Namespace(gamma_std=0.1), DEV)
+    _close(N(Ig), d["aug_Ig"], 3e-6)
+
+
+def test_perlin_percentile_curl_bit_exact():
+    from brainfm_amd import shapeid as SH
+    d = load_npz("synth_perlin_pde.npz")
+    shape, res = tuple(int(v) for v in d["p_shape"]), tuple(int(v) for v in d["p_res"])
+    g = SH.gradients_from_angles(d["p_theta"], d["p_phi"], (True, False, False))
+    assert np.array_equal(N(SH.perlin_from_gradients(shape, res, g, DEV)), d["p_noise"])
+    # with the reference's np.random stream the public entry point reproduces the golden directly
+    np.random.seed(11)
+    assert np.array_equal(N(SH.generate_perlin_noise_3d(shape, res, tileable=(True, False, False), device=DEV)),
+                          d["p_noise"])
+    np.random.seed(12)
+    pm, m = SH.generate_perlin_noise_3d(shape, res, tileable=(True, False, False), percentile=73.5, device=DEV)
+    assert np.array_equal(N(pm), d["pm_noise"]) and np.array_equal(N(m), d["pm_mask"])
+    np.random.seed(13)
+    assert np.array_equal(N(SH.generate_perlin_noise_3d((12, 12, 18), [3, 2, 3], device=DEV)), d["p2_noise"])
+    np.random.seed(14)
+    V = SH.generate_velocity_3d(shape, res, 500, DEV)
+    for k in ("Vx", "Vy", "Vz"):
+        assert V[k].dtype == torch.float32 and np.array_equal(N(V[k]), d[k]), k
+    with pytest.raises(ValueError):
+        SH.generate_perlin_noise_3d((10, 10, 10), [3, 2, 2], device=DEV)
+    # order statistics / percentile helper against numpy on an awkward array (duplicates, negatives)
+    x = np.concatenate([np.random.randn(5000), np.zeros(700), -np.ones(300)])
+    xt = T(x)
+    for q in (0.0, 12.5, 50.0, 73.5, 99.9, 100.0):
+        assert SH.percentile_linear(xt, q) == float(np.percentile(x, q)), q
+
+
+def test_advection_rhs_and_dopri5():
+    from brainfm_amd import shapeid as SH
+    d = load_npz("synth_perlin_pde.npz")
+    V = {"Vx": T(d["Vx40"]), "Vy": T(d["Vy40"]), "Vz": T(d["Vz40"])}
+    pde = SH.AdvDiffPDE(data_spacing=[1., 1., 1.], perf_pattern="adv", V_type="vector_div_free", V_dict=V,
+                        BC="neumann", dt=0.1, device=DEV)
+    assert np.array_equal(N(pde(torch.tensor(0.), T(d["C32"]))), d["rhs32"])
+    assert np.array_equal(N(pde(torch.tensor(0.), T(d["C64"]))), d["rhs64"])
+    t = torch.from_numpy(np.arange(10) * 0.1)
+    for tag, nt, tol in (("ode64", 6, 1e-6), ("ode32", 4, 3e-5)):
+        pde.nfe = 0
+        sol = SH.odeint_adjoint(pde, T(d[tag + "_y0"]), t[:nt], 0.1, method="dopri5")
+        assert sol.dtype == torch.from_numpy(d[tag + "_sol"]).dtype
+        assert tuple(sol.shape) == d[tag + "_sol"].shape
+        assert pde.nfe == int(d[tag + "_nfe"]), (pde.nfe, int(d[tag + "_nfe"]))
+        _close(N(sol), d[tag + "_sol"], tol)
+    with pytest.raises(NotImplementedError):
+        SH.odeint(pde, T(d["ode32_y0"]), t[:3], 0.1, method="rk4")
+    with pytest.raises(ValueError):
+        SH.odeint_adjoint(lambda t, y: y, T(d["ode32_y0"]), t[:3], 0.1)
+
+
+def test_grid_pull_all_bounds():
+    from brainfm_amd.interpol import grid_pull
+    d = load_npz("synth_grid_pull.npz")
+    vol, grid = T(d["vol"]), T(d["grid"])
+    for b in ["zero", "replicate", "dct1", "dct2", "dst1", "dst2", "dft"]:
+        for ex in (0, 1):
+            out = grid_pull(vol, grid, interpolation="linear", bound=b, extrapolate=bool(ex), prefilter=False)
+            _close(N(out), d["out_%s_%d" % (b, ex)], 1e-6)
+    X = T((np.arange(27).reshape(1, 1, 3, 3, 3) + 1).astype(np.float32))
+    pts = T(d["appc_pts"])
+    _close(N(grid_pull(X, pts, bound="zero", extrapolate=False)), d["appc_zero_0"], 1e-6)
+    _close(N(grid_pull(X, pts, bound="zero", extrapolate=True)), d["appc_zero_1"], 1e-6)
+    _close(N(grid_pull(X, pts, bound="dct2", extrapolate=True)), d["appc_dct2_1"], 1e-6)
+    # broadcasting rules of the high-level API: no batch / no channel
+    out = grid_pull(vol[0, 0], grid[0])
+    assert tuple(out.shape) == tuple(grid.shape[1:4])
+    _close(N(out), d["out_zero_0"][0, 0], 1e-6)
+    with pytest.raises(NotImplementedError):
+        grid_pull(vol, grid, interpolation="cubic")
+
+
+def test_deform_grid_atlas_contrast_onehot():
+    from argparse import Namespace
+    from brainfm_amd import generator as G, generator_utils as GU, test_utils as TU, _lib as L
+    d = load_npz("synth_deform_atlas.npz")
+    A = GU.make_affine_matrix(np.array([0.1, -0.2, 0.15]), np.array([0.05, -0.1, 0.02]), np.array([1.1, 0.9, 1.05]))
+    assert np.array_equal(A, d["affine_mat"])
+    F = GU.myzoom_torch(T(d["dg_Fsmall"]), np.array(d["dg_size"]) / np.array([3, 3, 3]))
+    assert np.array_equal(N(F), d["dg_F"])
+    gen = object.__new__(G.BaseGen)
+    gen.device = torch.device(DEV)
+    gen.size = [int(v) for v in d["dg_size"]]
+    xx, yy, zz, x1, y1, z1, x2, y2, z2 = gen.deform_grid([int(v) for v in d["dg_shp"]], d["dg_A"], d["dg_c2"], F)
+    assert [x1, y1, z1] == list(d["dg_lo"]) and [x2, y2, z2] == list(d["dg_hi"])
+    _close(N(xx), d["dg_xx"], 1e-6); _close(N(yy), d["dg_yy"], 1e-6); _close(N(zz), d["dg_zz"], 1e-6)
+    out = TU.get_deformed_atlas(T(d["at_mask"]), T(d["at_rx"]), T(d["at_ry"]), T(d["at_rz"]), T(d["at_MNI"]), d["at_A"])
+    _close(N(out), d["at_out"], 1e-6)
+    syn = torch.empty(d["cs_G"].shape, device=DEV)
+    Gt, mu, sg, rn = T(d["cs_G"]), T(d["cs_mus"]), T(d["cs_sigmas"]), T(d["cs_randn"])
+    assert L.load().bfm_label_gauss(L.ptr(Gt), L.ptr(mu), L.ptr(sg), L.ptr(rn), Gt.numel(), 256, L.ptr(syn),
+                                    L.stream_ptr()) == 0
+    assert np.array_equal(N(syn), d["cs_out"])
+    lut = torch.zeros(10000, dtype=torch.int32, device=DEV)
+    lut[:64] = T(d["oh_lut"]).to(torch.int32)
+    St = T(d["oh_S"]).to(torch.int32).contiguous()
+    oh = torch.empty(d["oh_out"].shape, device=DEV)
+    assert L.load().bfm_onehot_lut(L.ptr(St), L.ptr(lut), 10000, 56, St.numel(), L.ptr(oh), L.stream_ptr()) == 0
+    assert np.array_equal(N(oh), d["oh_out"])
+
+
+def _gen_args(size=(32, 32, 32)):
+    from argparse import Namespace
+    g = Namespace(size=list(size), photo_prob=0.2, max_rotation=15, max_shear=0.2, max_scaling=0.2,
+                  nonlin_scale_min=0.03, nonlin_scale_max=0.06, nonlin_std_max=4, bf_scale_min=0.02, bf_scale_max=0.04,
+                  bf_std_min=0.1, bf_std_max=0.6, gamma_std=0.1, noise_std_min=0.05, noise_std_max=1.,
+                  random_shift=False, nonlinear_transform=True, left_hemis_only=False, low_res_only=False, ct_prob=0,
+                  flip_prob=0., pathology_prob=1.0, random_shape_prob=1.0, augment_pathology=True, bspline_zooming=False,
+                  mild_samples=1, all_samples=2)
+    shp = Namespace(perlin_res=[2, 2, 2], integ_method="dopri5", bc="neumann", V_multiplier=40, dt=0.1, max_nt=4,
+                    pathol_thres=0.2, pathol_tol=1e-5, mask_percentile_min=85., mask_percentile_max=99.)
+    task = Namespace(T1=True, T2=False, FLAIR=False, CT=False, segmentation=True, distance=True, bias_field=True,
+                     registration=True, super_resolution=True, surface=False, pathology=True, contrastive=False)
+    return Namespace(generator=g, pathology_shape_generator=shp, task=task, max_surf_distance=3.0,
+                     augmentation_steps=["gamma", "bias_field", "resample", "noise"], dataset_option="brain_id",
+                     mix_synth_prob=0.)
+
+
+def test_generator_getitem_structure_and_properties():
+    """BrainIDGen.__getitem__ counterpart on an in-memory case: return structure, shapes, dtypes and the
+    invariants of the chain (inputs normalised to max 1, one-hot targets, clamped distances)."""
+    from brainfm_amd import generator as G
+    rs = np.random.RandomState(0)
+    shp = (48, 44, 52)
+    zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shp], indexing="ij")
+    ell = (((zz - 24) / 20.) ** 2 + ((yy - 22) / 18.) ** 2 + ((xx - 26) / 22.) ** 2) <= 1
+    seeds = rs.rand(30, 3) * np.array(shp)
+    lab = np.argmin(((np.stack([zz, yy, xx], -1)[..., None, :] - seeds) ** 2).sum(-1), -1)
+    gen_labels = (np.array([2, 3, 4, 41, 42, 17, 10, 11, 12, 13])[lab % 10] * ell).astype(np.float32)
+    seg = (np.array([2, 3, 4, 41, 42, 17, 10, 11, 12, 13])[lab % 10] * ell).astype(np.int32)
+    case = {"name": "toy", "Gen": gen_labels, "T1": rs.rand(*shp).astype(np.float32) * ell, "segmentation": seg,
+            "distance": [rs.rand(*shp).astype(np.float32) * 255 for _ in range(4)],
+            "registration": [rs.randn(*shp).astype(np.float32) * 500 for _ in range(3)]}
+    np.random.seed(3); torch.manual_seed(3)
+    ds = G.build_datasets(_gen_args(), DEV, cases=[case])["all"]
+    n, name, mode, target, samples = ds[0]
+    assert (n, name, mode) == (1, "synth", "synth") and len(samples) == 2
+    for s in samples:
+        assert tuple(s["input"].shape) == (1, 32, 32, 32) and s["input"].dtype == torch.float32
+        assert abs(float(s["input"].max()) - 1.0) < 1e-6 and float(s["input"].min()) >= 0
+        assert tuple(s["bias_field_log"].shape) == (1, 32, 32, 32)
+        assert tuple(s["high_res_residual"].shape) == (1, 32, 32, 32)
+        assert torch.isfinite(s["input"]).all()
+    assert tuple(target["segmentation"].shape) == (56, 32, 32, 32)
+    assert torch.equal(target["segmentation"].sum(0), torch.ones(32, 32, 32, device=DEV))
+    assert tuple(target["distance"].shape) == (4, 32, 32, 32) and float(target["distance"].abs().max()) <= 3.0
+    assert tuple(target["registration"].shape) == (3, 32, 32, 32)
+    assert tuple(target["T1"].shape) == (1, 32, 32, 32) and abs(float(target["T1"].max()) - 1) < 1e-6
+    p = target["pathology"]
+    assert (isinstance(p, float) and p == 0.) or set(np.unique(N(p))) <= {0.0, 1.0}
