@@ -6,8 +6,8 @@
 
 One step = one pass of the hot path over one synthetic 256^3 volume (27 overlapping tiles, win 160 /
 stride 80, all 9 task heads, fused tail, on-device stitching), input resident in HBM.  N>1 shards the
-tiles over ranks (weak scaling: every rank also runs its own volume? no -- see "scaling" below) and
-gathers the masked tile outputs to rank 0 over RCCL.  Prints ONE JSON line on rank 0.
+tiles of the SAME volume over ranks (strong scaling) and gathers the masked tile outputs to rank 0
+over RCCL.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
