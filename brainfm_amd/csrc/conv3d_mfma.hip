@@ -24,6 +24,8 @@
 //
 // Wave tile 64x64 (2x2 MFMA blocks), workgroup = WM x WN waves.
 #include "bfm_common.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -81,7 +83,7 @@ __device__ __forceinline__ void box_coords(const ConvParams& p, int q, int& d, i
 }
 
 template <int WM, int WN, int NPASS, int NSLOT>
-__global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(ConvParams p) {
+__global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(const ConvParams p) {
     constexpr int NTHR = 64 * WM * WN;
     constexpr int NW = WM * WN;                    // waves per workgroup
     constexpr int NPL = (NPASS == 3) ? 2 : 1;      // planes per k-half (hi[, lo])
@@ -317,6 +319,319 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(ConvParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wave-specialised, persistent variant: 8 waves per workgroup, one workgroup per CU, each workgroup
+// walks a strided list of output tiles.  Waves 0-3 (one per SIMD) only read LDS and issue MFMAs;
+// waves 4-7 (their SIMD partners) are loaders running ONE K-chunk ahead -- across tile boundaries
+// too, so a tile's first chunk is staged while the previous tile is still being multiplied and
+// stored: they write the next chunk's halo tile into the other half of a double-buffered A image
+// (global fp32 -> GroupNorm affine -> fp16 hi/lo planes) and stream the weight rows by LDS-DMA two
+// rows ahead.  VALU/VMEM work of the loaders runs beside the matrix pipe instead of in front of it.
+// One s_barrier per (kd,kh) row is the only synchronisation:
+//   loaders, before barrier R : counted vmcnt (DMA of row R landed) + lgkmcnt(0) (their ds_writes done)
+//   after barrier R           : consumers read B slot R%3 (and, at r==0, the A buffer written during the
+//                               previous chunk); loaders refill B slot (R+2)%3 -- consumed during row R-1 --
+//                               and stage 1-2 elements per thread of the next chunk into the A buffer the
+//                               consumers finished with one chunk ago.
+__device__ __forceinline__ void ws_tile_coords(const ConvParams& p, int lin, int& mt, int& nt) {
+    const int nblk = p.nMt * p.NT;
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = lin & 7, idx = lin >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    mt = bid / p.NT;
+    nt = bid - mt * p.NT;
+}
+
+template <int WM, int WN, int NPASS>
+__global__ void __launch_bounds__(512, 2) conv_mfma_ws(const ConvParams p) {
+    constexpr int NPL = (NPASS == 3) ? 2 : 1;
+    constexpr int ROWFR = 12 * WN;
+    constexpr int KPR = ROWFR / 4;                 // DMA instructions per loader wave per row
+    constexpr int PTHR = 256;                      // loader threads
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= 4;
+    const int split = blockIdx.y;
+    const int boxN = p.TD * p.TH * p.TW;
+    const int ntiles = p.nMt * p.NT;
+    const int G = gridDim.x;
+    const int my_tiles = (ntiles - (int)blockIdx.x + G - 1) / G;
+
+    float bmax = 0.f;
+    for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, p.bound[g]);
+    int aexp = 0;
+    if (bmax > 0.f && bmax < INFINITY) {
+        int ex;
+        (void)frexpf(bmax, &ex);
+        aexp = 14 - ex;
+        aexp = aexp > 60 ? 60 : (aexp < -60 ? -60 : aexp);
+    }
+    const float a_scale = ldexpf(1.0f, aexp);
+    const float dq = ldexpf(1.0f, -(aexp + p.wexp));
+
+    const int a_bytes = 2 * NPL * p.plane_stride;         // one A buffer
+    const int b_base = 2 * a_bytes;
+    const int kc_begin = split * p.kc_per_split;
+    const int kc_end = min(p.KCN, kc_begin + p.kc_per_split);
+    const int nchunks = kc_end - kc_begin;
+    const int total_chunks = my_tiles * nchunks;           // flattened (tile, chunk) sequence of this workgroup
+    const int total_rows = total_chunks * 9;
+    if (total_chunks <= 0) return;
+
+    if (producer) {
+        // =========================== loader waves ===========================
+        const int ptid = tid - 256;
+        const int pw = wave - 4;
+        constexpr int MAX_IT = 12;
+        const int n_el = p.nvox_lds * 4;
+        const int q4 = ptid & 3;
+        int off[MAX_IT];
+        int z0 = 0, y0 = 0, x0 = 0;
+        auto compute_offsets = [&](bool fromB) __attribute__((always_inline)) {
+#pragma unroll
+            for (int it = 0; it < MAX_IT; ++it) {
+                const int e = ptid + it * PTHR;
+                off[it] = -2;
+                if (e < n_el) {
+                    const int vox = e >> 2;
+                    const int hz = vox / (p.HT * p.WT);
+                    const int rem = vox - hz * (p.HT * p.WT);
+                    const int hy = rem / p.WT;
+                    const int hx = rem - hy * p.WT;
+                    const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+                    off[it] = -1;
+                    if (gz >= 0 && gz < p.D && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                        if (fromB) off[it] = ((p.up.mapD[gz] * p.up.h + p.up.mapH[gy]) * p.up.w + p.up.mapW[gx]) * p.CB;
+                        else off[it] = ((gz * p.H + gy) * p.W + gx) * p.CA;
+                    }
+                }
+            }
+        };
+        bool off_fromB = false;
+        const int st_plane = ((q4 >> 1) * NPL) * p.plane_stride + (q4 & 1) * 8;
+
+        float4 v[12];                                        // at most two of them live at a time (static indices)
+        float sc[4], sh[4];
+        const float* src = nullptr;
+        // chunk g of the flattened sequence: (tile g / nchunks, K-chunk g % nchunks)
+        auto begin_chunk = [&](int g) __attribute__((always_inline)) {
+            const int c = g % nchunks;
+            const int c0 = (kc_begin + c) * KC;
+            const bool fromB = c0 >= p.CA;
+            if (c == 0) {
+                int mt, nt;
+                ws_tile_coords(p, (int)blockIdx.x + (g / nchunks) * G, mt, nt);
+                const int tx = mt % p.nTx;
+                const int ty = (mt / p.nTx) % p.nTy;
+                const int tz = mt / (p.nTx * p.nTy);
+                z0 = tz * p.TD; y0 = ty * p.TH; x0 = tx * p.TW;
+                off_fromB = fromB;
+                compute_offsets(fromB);
+            } else if (fromB != off_fromB) {
+                off_fromB = fromB;
+                compute_offsets(fromB);
+            }
+            src = (fromB ? p.B + (c0 - p.CA) : p.A + c0) + q4 * 4;
+            const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + c0 + q4 * 4);
+            const float4 sh4 = *reinterpret_cast<const float4*>(p.shift + c0 + q4 * 4);
+            sc[0] = sc4.x * a_scale; sc[1] = sc4.y * a_scale; sc[2] = sc4.z * a_scale; sc[3] = sc4.w * a_scale;
+            sh[0] = sh4.x * a_scale; sh[1] = sh4.y * a_scale; sh[2] = sh4.z * a_scale; sh[3] = sh4.w * a_scale;
+        };
+        // element `it` (compile-time): one unconditional 16-B load (clamped offset) so that every wave issues
+        // the same number of VMEM instructions -- the counted vmcnt below depends on it
+        auto load_el = [&](auto itc) __attribute__((always_inline)) {
+            constexpr int it = decltype(itc)::value;
+            const int o = off[it] >= 0 ? off[it] : 0;
+            v[it] = *reinterpret_cast<const float4*>(src + o);
+        };
+        auto write_el = [&](auto itc, int buf) __attribute__((always_inline)) {
+            constexpr int it = decltype(itc)::value;
+            const int o = off[it];
+            const int e = ptid + it * PTHR;
+            if (o != -2) {
+                const bool ok = o >= 0;
+                float y[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+                half4 hi, lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float t = ok ? fmaf(y[i], sc[i], sh[i]) : 0.f;
+                    _Float16 hh = (_Float16)t;
+                    hi[i] = hh;
+                    lo[i] = (_Float16)(t - (float)hh);
+                }
+                unsigned char* dst = lds + buf * a_bytes + st_plane + (e >> 2) * 16;
+                *reinterpret_cast<half4*>(dst) = hi;
+                if constexpr (NPASS == 3) *reinterpret_cast<half4*>(dst + p.plane_stride) = lo;
+            }
+        };
+        auto issue_row = [&](int R) __attribute__((always_inline)) {
+            const int Rs = R < total_rows ? R : total_rows - 1;    // past the end: harmless reload into a free slot
+            const int g = Rs / 9, rr = Rs - g * 9;
+            int mt, nt;
+            ws_tile_coords(p, (int)blockIdx.x + (g / nchunks) * G, mt, nt);
+            const int kcR = kc_begin + g % nchunks;
+            const int slot = R % 3;
+#pragma unroll
+            for (int i = 0; i < KPR; ++i) {
+                const int f = pw + i * 4;
+                const int j = f / 12, gg = f - j * 12;
+                const uint4* wsrc = p.wp + ((size_t)((nt * WN + j) * p.KCN + kcR) * 27 + rr * 3) * (4 * FRAG_U4) +
+                                    gg * FRAG_U4 + lane;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wsrc,
+                                                 (__attribute__((address_space(3))) void*)(lds + b_base +
+                                                                                          (slot * ROWFR + f) * 1024),
+                                                 16, 0, 0);
+            }
+        };
+        auto for_el = [&](auto first, auto count, auto&& fn) __attribute__((always_inline)) {
+            constexpr int f0 = decltype(first)::value, n = decltype(count)::value;
+            if constexpr (n >= 1) fn(std::integral_constant<int, f0>{});
+            if constexpr (n >= 2) fn(std::integral_constant<int, f0 + 1>{});
+        };
+#define BFM_IC(n) std::integral_constant<int, n>{}
+
+        // prologue: chunk 0 of the first tile into A buffer 0; weight rows 0 and 1 into slots 0 and 1
+        begin_chunk(0);
+        for_el(BFM_IC(0), BFM_IC(2), [&](auto i) { load_el(i); });  for_el(BFM_IC(0), BFM_IC(2), [&](auto i) { write_el(i, 0); });
+        for_el(BFM_IC(2), BFM_IC(2), [&](auto i) { load_el(i); });  for_el(BFM_IC(2), BFM_IC(2), [&](auto i) { write_el(i, 0); });
+        for_el(BFM_IC(4), BFM_IC(2), [&](auto i) { load_el(i); });  for_el(BFM_IC(4), BFM_IC(2), [&](auto i) { write_el(i, 0); });
+        for_el(BFM_IC(6), BFM_IC(2), [&](auto i) { load_el(i); });  for_el(BFM_IC(6), BFM_IC(2), [&](auto i) { write_el(i, 0); });
+        for_el(BFM_IC(8), BFM_IC(2), [&](auto i) { load_el(i); });  for_el(BFM_IC(8), BFM_IC(2), [&](auto i) { write_el(i, 0); });
+        for_el(BFM_IC(10), BFM_IC(2), [&](auto i) { load_el(i); }); for_el(BFM_IC(10), BFM_IC(2), [&](auto i) { write_el(i, 0); });
+        issue_row(0);
+        issue_row(1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+        // Row schedule of the next chunk's staging (12 element slots per thread over rows 0..8):
+        //   loads : rows 0-3 -> 2 elements each (0..7), rows 4-7 -> 1 element each (8..11)
+        //   writes: one row after the load.
+        // Queue order inside a row: [writes of the previous row's loads] [this row's loads] [DMA of row R+2].
+        // Before barrier R the DMA of row R (issued two rows earlier, ahead of the previous row's loads and
+        // DMA) must have landed: vmcnt(loads of the previous row + KPR).
+        for (int g = 0; g < total_chunks; ++g) {
+            const bool more = g + 1 < total_chunks;
+            const int nbuf = (g + 1) & 1;
+            if (more) begin_chunk(g + 1);
+            auto row = [&](auto rc) __attribute__((always_inline)) {
+                constexpr int r = decltype(rc)::value;
+                constexpr int NL_PREV = r == 0 ? 0 : (r <= 4 ? 2 : 1);        // loads issued in row r-1
+                constexpr int NL = r <= 3 ? 2 : (r <= 7 ? 1 : 0);             // loads issued in row r
+                constexpr int F_PREV = r == 0 ? 0 : (r <= 4 ? 2 * (r - 1) : 8 + (r - 5));
+                constexpr int F = r <= 3 ? 2 * r : 8 + (r - 4);
+                const int R = g * 9 + r;
+                if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL_PREV + KPR) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KPR) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (more) {
+                    for_el(BFM_IC(F_PREV), BFM_IC(NL_PREV), [&](auto i) { write_el(i, nbuf); });
+                    for_el(BFM_IC(F), BFM_IC(NL), [&](auto i) { load_el(i); });
+                }
+                issue_row(R + 2);                                // always issued: the counted vmcnt relies on it
+            };
+            row(BFM_IC(0)); row(BFM_IC(1)); row(BFM_IC(2)); row(BFM_IC(3)); row(BFM_IC(4));
+            row(BFM_IC(5)); row(BFM_IC(6)); row(BFM_IC(7)); row(BFM_IC(8));
+        }
+#undef BFM_IC
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // =========================== MFMA waves ===========================
+    const int wm = wave / WN, wn = wave % WN;
+    const int l32 = lane & 31, khalf = lane >> 5;
+    int a_off[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        int q = wm * 64 + mb * 32 + row_perm(l32);
+        int d = 0, h = 0, w = 0;
+        if (q < boxN) box_coords(p, q, d, h, w);
+        int vox = (d * p.HT + h) * p.WT + w;
+        a_off[mb] = (khalf * NPL) * p.plane_stride + vox * 16;
+    }
+    floatx16 acc[2][2];
+    const bool final_out = p.splitk == 1;
+    float* obase = p.out + (final_out ? 0 : (int64_t)split * p.split_stride);
+
+    for (int g = 0; g < total_chunks; ++g) {
+        const int c = g % nchunks;
+        if (c == 0) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+        }
+        const unsigned char* abuf = lds + (g & 1) * a_bytes;
+        for (int r = 0; r < 9; ++r) {
+            const int R = g * 9 + r;
+            __builtin_amdgcn_s_barrier();
+            const unsigned char* bs = lds + b_base + ((R % 3) * ROWFR + wn * 12) * 1024 + lane * 16;
+            const int kd = r / 3, kh = r - kd * 3;
+            const int roff = (kd * p.HT + kh) * p.WT * 16;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                half8 a[2][NPL], b[2][NPL];
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int hl = 0; hl < NPL; ++hl)
+                        b[nb][hl] = *reinterpret_cast<const half8*>(bs + (kw * 4 + nb * 2 + hl) * 1024);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int hl = 0; hl < NPL; ++hl)
+                        a[mb][hl] = *reinterpret_cast<const half8*>(abuf + a_off[mb] + hl * p.plane_stride + roff +
+                                                                    kw * 16);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        if constexpr (NPASS == 3) {
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][1], b[nb][0], acc[mb][nb], 0, 0, 0);
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][0], b[nb][1], acc[mb][nb], 0, 0, 0);
+                        }
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mb][0], b[nb][0], acc[mb][nb], 0, 0, 0);
+                    }
+            }
+        }
+        if (c == nchunks - 1) {
+            // ---- epilogue of this tile (the loaders are already staging the next tile)
+            int mt, nt;
+            ws_tile_coords(p, (int)blockIdx.x + (g / nchunks) * G, mt, nt);
+            const int tx = mt % p.nTx;
+            const int ty = (mt / p.nTx) % p.nTy;
+            const int tz = mt / (p.nTx * p.nTy);
+            const int z0 = tz * p.TD, y0 = ty * p.TH, x0 = tx * p.TW;
+            const int ntw = nt * WN + wn;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int rr = (i >> 2) * 8 + khalf * 4 + (i & 3);
+                    const int q = wm * 64 + mb * 32 + row_perm(rr);
+                    if (q >= boxN) continue;
+                    int d, h, w;
+                    box_coords(p, q, d, h, w);
+                    const int gz = z0 + d, gy = y0 + h, gx = x0 + w;
+                    if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
+                    float* orow = obase + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + ntw * 64 + l32;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        float r = acc[mb][nb][i] * dq;
+                        if (final_out) r = r >= 0.f ? r : r * p.slope;
+                        orow[nb * 32] = r;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // sum split-K slabs in slab order, then LeakyReLU
 __global__ void splitk_reduce(const float* __restrict__ ws, int splitk, int64_t n4, int64_t stride4, float slope,
                               float* __restrict__ out) {
@@ -366,7 +681,11 @@ constexpr int ring_bytes(int WN) { return nslot_for(WN) * 12 * WN * 1024; }
 
 struct HostPlan {
     int WM, WN, TD, TH, TW, splitk;
+    int ver;        // 0: 4-wave kernel, 2 workgroups/CU; 1: wave-specialised 8-wave kernel, 1 workgroup/CU
 };
+
+constexpr int LDS_LIMIT_WS = 160 * 1024;
+int ws_smem(int npl, int plane_stride, int WN) { return 2 * (2 * npl * plane_stride) + 3 * 12 * WN * 1024; }
 
 constexpr int LDS_LIMIT = 80 * 1024;      // two workgroups per CU (160 KiB)
 
@@ -406,7 +725,24 @@ HostPlan choose_plan(int Cin, int Cout, int D, int H, int W) {
             hp.splitk = bfm_cdiv(KCN, per);
         }
     }
+    // kernel variant (measured on MI355X, profiles/): the wave-specialised persistent kernel wins once a
+    // tile has >= 8 K-chunks and needs no split-K; shallow-K layers keep the 2-workgroup/CU kernel.
+    hp.ver = (KCN >= 8 && hp.splitk == 1) ? 1 : 0;
+    if (const char* e = getenv("BFM_CONV_VER")) hp.ver = atoi(e);
     return hp;
+}
+
+template <int WM, int WN>
+void launch_ws(const ConvParams& p, int passes, dim3 grid, size_t smem, hipStream_t st) {
+    if (passes == 3) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_ws<WM, WN, 3>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_WS);
+        hipLaunchKernelGGL((conv_mfma_ws<WM, WN, 3>), grid, dim3(512), smem, st, p);
+    } else {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_ws<WM, WN, 1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_WS);
+        hipLaunchKernelGGL((conv_mfma_ws<WM, WN, 1>), grid, dim3(512), smem, st, p);
+    }
 }
 
 template <int WM, int WN>
@@ -447,7 +783,7 @@ extern "C" int bfm_conv3x3x3_mfma_plan(int Cin, int Cout, int D, int H, int W, i
     HostPlan hp = choose_plan(Cin, Cout, D, H, W);
     if (hp.TD == 0) return BFM_E_SHAPE;
     cfg[0] = hp.WM; cfg[1] = hp.WN; cfg[2] = hp.TD; cfg[3] = hp.TH; cfg[4] = hp.TW; cfg[5] = hp.splitk;
-    cfg[6] = 0; cfg[7] = 0;
+    cfg[6] = hp.ver; cfg[7] = 0;
     return BFM_OK;
 }
 
@@ -476,7 +812,7 @@ extern "C" int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB
     const int Cin = CA + CB;
     HostPlan hp;
     if (cfg) {
-        hp = HostPlan{cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5]};
+        hp = HostPlan{cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], cfg[6]};
     } else {
         hp = choose_plan(Cin, Cout, D, H, W);
     }
@@ -506,8 +842,10 @@ extern "C" int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB
     p.tw_shift = is_pow2(hp.TW) ? ilog2(hp.TW) : -1;
     p.thw_shift = is_pow2(hp.TH * hp.TW) ? ilog2(hp.TH * hp.TW) : -1;
     const int npl = passes == 3 ? 2 : 1;
-    const size_t smem = (size_t)2 * npl * p.plane_stride + ring_bytes(hp.WN);
-    if (smem > (size_t)LDS_LIMIT) return BFM_E_SHAPE;
+    const size_t smem = hp.ver == 1 ? (size_t)ws_smem(npl, p.plane_stride, hp.WN)
+                                    : (size_t)2 * npl * p.plane_stride + ring_bytes(hp.WN);
+    if (smem > (size_t)(hp.ver == 1 ? LDS_LIMIT_WS : LDS_LIMIT)) return BFM_E_SHAPE;
+    if (hp.ver != 0 && hp.ver != 1) return BFM_E_ARG;
     if (p.nvox_lds * 4 > 12 * 64 * hp.WM * hp.WN) return BFM_E_SHAPE;
     const int64_t nvox = (int64_t)D * H * W;
     p.split_stride = nvox * Cout;
@@ -521,10 +859,22 @@ extern "C" int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB
     if ((int64_t)p.nMt * p.NT > 0x7fffffff) return BFM_E_SHAPE;
     if (nvox * CA > 0x7fffffffLL || (CB > 0 && (int64_t)up->d * up->h * up->w * CB > 0x7fffffffLL))
         return BFM_E_SHAPE;                                   // the staging path keeps 32-bit element offsets
-    dim3 grid((unsigned)(p.nMt * p.NT), (unsigned)p.splitk);
+    unsigned gx = (unsigned)(p.nMt * p.NT);
+    if (hp.ver == 1) {
+        int cap = 256;                                         // one 8-wave workgroup per CU
+        const char* e = getenv("BFM_CONV_WS_GRID");
+        if (e && atoi(e) > 0) cap = atoi(e);
+        if ((int)gx > cap) gx = (unsigned)cap;
+    }
+    dim3 grid(gx, (unsigned)p.splitk);
     hipStream_t st = bfm_s(stream);
-    if (hp.WM == 4) launch<4, 1>(p, passes, grid, smem, st);
-    else launch<2, 2>(p, passes, grid, smem, st);
+    if (hp.ver == 1) {
+        if (hp.WM == 4) launch_ws<4, 1>(p, passes, grid, smem, st);
+        else launch_ws<2, 2>(p, passes, grid, smem, st);
+    } else {
+        if (hp.WM == 4) launch<4, 1>(p, passes, grid, smem, st);
+        else launch<2, 2>(p, passes, grid, smem, st);
+    }
     int rc = bfm_launch_status();
     if (rc != BFM_OK) return rc;
     if (p.splitk > 1) {
