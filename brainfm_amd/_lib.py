@@ -31,7 +31,8 @@ class TailDesc(C.Structure):
                 ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("roles", C.c_void_p), ("out_slot", C.c_void_p),
                 ("seg_first", C.c_int), ("n_seg", C.c_int), ("seg_lut", C.c_void_p),
                 ("n_dist", C.c_int), ("dist_first", C.c_int), ("max_dist", C.c_float),
-                ("unit_feat", C.c_int), ("slot_high_res", C.c_int), ("slot_fake_cortical", C.c_int)]
+                ("unit_feat", C.c_int), ("slot_high_res", C.c_int), ("slot_fake_cortical", C.c_int),
+                ("n_maps", C.c_int)]
 
 
 class ZoomAxis(C.Structure):
@@ -58,6 +59,8 @@ SIGNATURES = {
     "bfm_pack_conv_weights_direct": (_I, [_P, _I, _I, _P, _P]),
     "bfm_pack_conv_weights_mfma_bytes": (_Z, [_I, _I]),
     "bfm_pack_conv_weights_mfma": (_I, [_P, _I, _I, _F, _P, C.POINTER(_I), _P]),
+    "bfm_pack_conv_weights_mfma16_bytes": (_Z, [_I, _I]),
+    "bfm_pack_conv_weights_mfma16": (_I, [_P, _I, _I, _F, _P, C.POINTER(_I), _P]),
     "bfm_conv3x3x3_direct": (_I, [_P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _P, _I, _F, _P, _P]),
     "bfm_conv3x3x3_mfma_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
     "bfm_conv3x3x3_mfma_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),

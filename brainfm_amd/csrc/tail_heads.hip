@@ -29,6 +29,7 @@ constexpr int TPBT = 128;    // threads per block: 2 waves, 64 voxels (two 32-ro
 constexpr int CMAX = 64;     // c_feat upper bound
 constexpr int OMAX = 96;     // n_out upper bound (3 MFMA column blocks, LDS row)
 constexpr int LD = OMAX + 1; // LDS row stride in floats (odd: conflict-free column access)
+constexpr int NMAPS = 64;    // upper bound on output maps
 
 struct TailParams {
     const float* feat;
@@ -40,6 +41,7 @@ struct TailParams {
     float* seg_prob;
     int64_t* label;
     float* raw_out;
+    int n_maps;
 };
 
 __device__ __forceinline__ float fake_term(float w_or_p, float add, float gain) {
@@ -54,7 +56,13 @@ __device__ __forceinline__ float fake_term(float w_or_p, float add, float gain) 
 //      weights live in registers as MFMA B fragments for the whole kernel
 //   4. logits (+bias) back into the LDS rows, one thread per voxel applies the roles
 __global__ void __launch_bounds__(TPBT) tail_kernel(TailParams p) {
-    extern __shared__ float tile[];                 // [VPB][LD]
+    extern __shared__ float tile[];                 // [VPB][LD] then the per-head tables
+    // roles / slots / output pointers are read once per block into LDS: fetching them from global memory inside
+    // the per-head loop is a chain of dependent loads per output row (it dominated the first version)
+    int* s_role = reinterpret_cast<int*>(tile + VPB * LD);            // [OMAX]
+    int* s_slot = s_role + OMAX;                                       // [OMAX]
+    float** s_map = reinterpret_cast<float**>(s_slot + OMAX);          // [NMAPS]
+    int* s_lut = reinterpret_cast<int*>(s_map + NMAPS);                // [OMAX]
     const int C = p.d.c_feat;
     const int NO = p.d.n_out;
     const int t = threadIdx.x;
@@ -74,6 +82,11 @@ __global__ void __launch_bounds__(TPBT) tail_kernel(TailParams p) {
         for (int kk = 0; kk < CMAX / 2; ++kk)
             wfrag[nb][kk] = (nb < nnb && o < NO && kk < nkk) ? p.d.head_w[(size_t)o * C + 2 * kk + lh] : 0.f;
     }
+
+    for (int i = threadIdx.x; i < p.d.n_out; i += TPBT) { s_role[i] = p.d.roles[i]; s_slot[i] = p.d.out_slot[i]; }
+    for (int i = threadIdx.x; i < p.n_maps; i += TPBT) s_map[i] = p.maps[i];
+    for (int i = threadIdx.x; i < p.d.n_seg; i += TPBT) s_lut[i] = p.d.seg_lut[i];
+    __syncthreads();
 
     const int64_t ntiles = (p.nvox + VPB - 1) / VPB;
     for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
@@ -167,9 +180,9 @@ __global__ void __launch_bounds__(TPBT) tail_kernel(TailParams p) {
         float dist[4] = {0.f, 0.f, 0.f, 0.f};
         // ---- processors + post-processor per role
         for (int o = 0; o < NO; ++o) {
-            const int role = p.d.roles[o];
+            const int role = s_role[o];
             if (role == BFM_ROLE_SEG) continue;
-            const int slot = p.d.out_slot[o];
+            const int slot = s_slot[o];
             const float a = row[o];
             float r = a;
             if (role == BFM_ROLE_CT) r = a * 1000.f;
@@ -180,16 +193,16 @@ __global__ void __launch_bounds__(TPBT) tail_kernel(TailParams p) {
                 const int k = o - p.d.dist_first;
                 if (k == 0) dist[0] = r; else if (k == 1) dist[1] = r; else if (k == 2) dist[2] = r; else dist[3] = r;
             }
-            if (live && slot >= 0) p.maps[slot][v] = r;
+            if (live && slot >= 0) s_map[slot][v] = r;
             if (role == BFM_ROLE_SR && p.d.slot_high_res >= 0 && live && p.input)
-                p.maps[p.d.slot_high_res][v] = a + p.input[v];
+                s_map[p.d.slot_high_res][v] = a + p.input[v];
         }
 
         if (p.d.n_dist > 0 && p.d.slot_fake_cortical >= 0 && live) {
             // order lp, lw[, rp, rw]  (__init__.py:321-337)
             float fake = fake_term(dist[1], 0.3f, 70.f) + fake_term(dist[0], 0.f, 40.f);
             if (p.d.n_dist == 4) fake = fake + (fake_term(dist[3], 0.3f, 70.f) + fake_term(dist[2], 0.f, 40.f));
-            p.maps[p.d.slot_fake_cortical][v] = fake;
+            s_map[p.d.slot_fake_cortical][v] = fake;
         }
 
         if (p.d.n_seg > 0) {
@@ -207,7 +220,7 @@ __global__ void __launch_bounds__(TPBT) tail_kernel(TailParams p) {
                     sl[s] = pr;
                     if (pr > bp) { bp = pr; best = s; }      // first maximum wins (torch.argmax)
                 }
-                if (p.label) p.label[v] = (int64_t)p.d.seg_lut[best];
+                if (p.label) p.label[v] = (int64_t)s_lut[best];
             }
             if (p.seg_prob) {
                 __syncthreads();
@@ -237,10 +250,14 @@ extern "C" int bfm_tail_heads(const float* feat, const float* input, int64_t nvo
     if (desc->n_dist != 0 && desc->n_dist != 2 && desc->n_dist != 4) return BFM_E_SHAPE;
     if (reinterpret_cast<uintptr_t>(feat) & 15 || (feat_norm && (reinterpret_cast<uintptr_t>(feat_norm) & 15)))
         return BFM_E_ARG;
-    TailParams p{feat, input, nvox, *desc, feat_norm, maps, seg_prob, label, raw_out};
+    int n_maps = maps ? desc->n_maps : 0;
+    if (n_maps < 0 || n_maps > NMAPS) return BFM_E_SHAPE;
+    for (int o = 0; o < desc->n_out; ++o) (void)o;
+    if (maps && (desc->slot_high_res >= n_maps || desc->slot_fake_cortical >= n_maps)) return BFM_E_SHAPE;
+    TailParams p{feat, input, nvox, *desc, feat_norm, maps, seg_prob, label, raw_out, n_maps};
     int64_t nb = bfm_cdiv64(nvox, VPB);
     if (nb > 256 * 6) nb = 256 * 6;                  // persistent: the weight fragments are loaded once per block
-    const size_t smem = (size_t)VPB * LD * sizeof(float);
+    const size_t smem = (size_t)VPB * LD * sizeof(float) + (size_t)3 * OMAX * sizeof(int) + (size_t)NMAPS * sizeof(float*);
     hipLaunchKernelGGL(tail_kernel, dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p);
     return bfm_launch_status();
 }

@@ -38,7 +38,7 @@ def nearest_index_map(n_in, n_out):
 
 
 class _Layer:
-    __slots__ = ("name", "cin", "cout", "groups", "gamma", "beta", "kind", "wpacked", "wexp", "w_raw")
+    __slots__ = ("name", "cin", "cout", "groups", "gamma", "beta", "kind", "wpacked", "wexp", "w_raw", "packs")
 
 
 class UNetEngine:
@@ -67,6 +67,7 @@ class UNetEngine:
         self._up_cache = {}
         self._ws = None
         self._plan_cache = {}
+        self._tuned = set()
         self.force_direct = False
         self.prof = None            # bench.py: list collecting (start_event, end_event, flops, bytes) per MFMA conv launch
         sd = self._normalise_keys(state_dict)
@@ -114,30 +115,34 @@ class UNetEngine:
         ly.kind = None
         ly.wpacked = None
         ly.wexp = 0
+        ly.packs = {}
         return ly
 
     def _mfma_ok(self, ly, ca, cb):
         return (not self.force_direct) and ca % 16 == 0 and cb % 16 == 0 and ly.cout % 64 == 0
 
-    def _pack(self, ly, mfma):
-        kind = "mfma" if mfma else "direct"
-        if ly.kind == kind:
-            return
-        st = L.stream_ptr()
-        if mfma:
-            nbytes = self.lib.bfm_pack_conv_weights_mfma_bytes(ly.cin, ly.cout)
-            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            wexp = C.c_int(0)
-            wmax = float(ly.w_raw.abs().max().item())
-            L.check(self.lib.bfm_pack_conv_weights_mfma(L.ptr(ly.w_raw), ly.cin, ly.cout, wmax, L.ptr(buf),
-                                                        C.byref(wexp), st), "pack_mfma " + ly.name)
-            ly.wexp = wexp.value
-        else:
-            buf = torch.empty(27 * ly.cin * ly.cout, dtype=torch.float32, device=self.device)
-            L.check(self.lib.bfm_pack_conv_weights_direct(L.ptr(ly.w_raw), ly.cin, ly.cout, L.ptr(buf), st),
-                    "pack_direct " + ly.name)
-        ly.wpacked = buf
-        ly.kind = kind
+    def _pack(self, ly, mfma, ver=0):
+        """Pack (once per layout) and select the weights for this launch: 'direct' [27][Cin][Cout] fp32,
+        'mfma' 32x32x16 fragments (plan variants 0/1), 'mfma16' 16x16x32 tap-pair fragments (variant 2)."""
+        layout = "direct" if not mfma else ("mfma16" if ver == 2 else "mfma")
+        if layout not in ly.packs:
+            st = L.stream_ptr()
+            if mfma:
+                fn_b = self.lib.bfm_pack_conv_weights_mfma16_bytes if ver == 2 else self.lib.bfm_pack_conv_weights_mfma_bytes
+                fn_p = self.lib.bfm_pack_conv_weights_mfma16 if ver == 2 else self.lib.bfm_pack_conv_weights_mfma
+                buf = torch.empty(fn_b(ly.cin, ly.cout), dtype=torch.uint8, device=self.device)
+                wexp = C.c_int(0)
+                wmax = float(ly.w_raw.abs().max().item())
+                L.check(fn_p(L.ptr(ly.w_raw), ly.cin, ly.cout, wmax, L.ptr(buf), C.byref(wexp), st),
+                        "pack_%s %s" % (layout, ly.name))
+                ly.packs[layout] = (buf, wexp.value)
+            else:
+                buf = torch.empty(27 * ly.cin * ly.cout, dtype=torch.float32, device=self.device)
+                L.check(self.lib.bfm_pack_conv_weights_direct(L.ptr(ly.w_raw), ly.cin, ly.cout, L.ptr(buf), st),
+                        "pack_direct " + ly.name)
+                ly.packs[layout] = (buf, 0)
+        ly.wpacked, ly.wexp = ly.packs[layout]
+        ly.kind = "mfma" if mfma else "direct"
 
     # ------------------------------------------------------------------ helpers
     def _upsample_desc(self, lo, hi):
@@ -164,6 +169,36 @@ class UNetEngine:
             self._plan_cache[key] = cfg
         return self._plan_cache[key]
 
+    def _autotune(self, ly, key, launch):
+        """Pick the fastest of the three conv_mfma variants for this (Cin, Cout, dims) by timing them once on the
+        real operands (HIP events on the launch stream).  All variants compute the same result; the chip is
+        power-limited on this kernel, so which one wins is shape dependent (profiles/).  BFM_CONV_VER pins one."""
+        import os
+        cfg = self._plan_cache[key]
+        if key in self._tuned or os.environ.get("BFM_CONV_VER") or os.environ.get("BFM_CONV_TUNE", "1") == "0":
+            return cfg
+        best, best_ms = cfg[6], None
+        for ver in (0, 1, 2):
+            trial = (C.c_int * 8)(*list(cfg))
+            trial[6] = ver
+            try:
+                self._pack(ly, True, ver)
+                launch(trial)                                   # warm (also validates LDS / shape limits)
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+                ev[0].record()
+                launch(trial)
+                launch(trial)
+                ev[1].record()
+                ev[1].synchronize()
+                ms = ev[0].elapsed_time(ev[1])
+            except L.BfmError:
+                continue
+            if best_ms is None or ms < best_ms:
+                best, best_ms = ver, ms
+        cfg[6] = best
+        self._tuned.add(key)
+        return cfg
+
     # ------------------------------------------------------------------ one SingleConv
     def single_conv(self, ly, A, dims, B=None, lo_dims=None):
         """GroupNorm -> Conv3d(3,p=1) -> LeakyReLU on cat((A, nearest_up(B))).
@@ -189,8 +224,16 @@ class UNetEngine:
         L.check(self.lib.bfm_gn_stats(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(ly.gamma), L.ptr(ly.beta),
                                       ly.groups, self.eps, L.ptr(scale), L.ptr(shift), L.ptr(bound), L.ptr(ws),
                                       ws.numel(), st), "gn_stats " + ly.name)
-        self._pack(ly, mfma)
         out = torch.empty((D, H, W, ly.cout), dtype=torch.float32, device=self.device)
+        if mfma:
+            def _launch(c):
+                self._pack(ly, True, c[6])
+                L.check(self.lib.bfm_conv3x3x3_mfma(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(scale),
+                                                    L.ptr(shift), L.ptr(bound), ly.groups, L.ptr(ly.wpacked), ly.wexp,
+                                                    ly.cout, self.slope, self.passes, c, L.ptr(out), L.ptr(ws),
+                                                    ws.numel(), st), "conv_mfma " + ly.name)
+            cfg = self._autotune(ly, (ly.cin, ly.cout, tuple(dims)), _launch)
+        self._pack(ly, mfma, cfg[6] if cfg is not None else 0)
         if mfma:
             ev = None
             if self.prof is not None:
@@ -346,7 +389,7 @@ class Tail:
         self.desc = L.TailDesc(self.n_out, c_feat, self.head_w.data_ptr(), self.head_b.data_ptr(),
                                self.roles.data_ptr(), self.out_slot.data_ptr(), seg[0], seg[1],
                                self.seg_lut.data_ptr(), dist[1], dist[0], float(max_surf_distance),
-                               1 if eng.unit_feat else 0, self.slot_high_res, self.slot_fake)
+                               1 if eng.unit_feat else 0, self.slot_high_res, self.slot_fake, len(self.map_names))
 
     def run(self, feat_cl, dims, input_cl=None, want_feat=True, want_seg=True):
         """Fused tail.  feat_cl: (D,H,W,c_feat) raw last decoder output.

@@ -250,7 +250,7 @@ def normalize_cl(eng, feat_cl, dims):
     z = torch.zeros(1, dtype=torch.float32, device=feat_cl.device)
     zi = torch.zeros(1, dtype=torch.int32, device=feat_cl.device)
     desc = L.TailDesc(0, c, z.data_ptr(), z.data_ptr(), zi.data_ptr(), zi.data_ptr(), 0, 0, zi.data_ptr(), 0, 0, 0.0,
-                      1, -1, -1)
+                      1, -1, -1, 0)
     out = torch.empty_like(feat_cl)
     L.check(eng.lib.bfm_tail_heads(L.ptr(feat_cl), None, D * H * W, C.byref(desc), L.ptr(out), None, None, None, None,
                                    L.stream_ptr()), "normalize")

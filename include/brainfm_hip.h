@@ -79,6 +79,13 @@ size_t bfm_pack_conv_weights_mfma_bytes(int Cin, int Cout);
 int bfm_pack_conv_weights_mfma(const float* w_oidhw, int Cin, int Cout, float wmax_abs_host, void* wpacked,
                                int* wexp_host, bfm_stream_t stream);
 
+/* Layout for the v_mfma_f32_16x16x32_f16 kernel variant (plan cfg[6] == 2): K = 32 is a pair of taps x 16
+ * channels.  A layer planned with cfg[6] == 2 must be given weights packed by this function; cfg[6] in {0,1}
+ * takes bfm_pack_conv_weights_mfma's layout. */
+size_t bfm_pack_conv_weights_mfma16_bytes(int Cin, int Cout);
+int bfm_pack_conv_weights_mfma16(const float* w_oidhw, int Cin, int Cout, float wmax_abs_host, void* wpacked,
+                                 int* wexp_host, bfm_stream_t stream);
+
 int bfm_conv3x3x3_direct(const float* A, int CA, const float* B, int CB, int D, int H, int W,
                          const bfm_upsample_t* up, const float* scale, const float* shift,
                          const float* wpacked, int Cout, float slope, float* out, bfm_stream_t stream);
@@ -127,6 +134,7 @@ typedef struct {
     int unit_feat;              /* apply F.normalize before the heads */
     int slot_high_res;          /* maps slot for residual+input, -1 = none */
     int slot_fake_cortical;     /* maps slot, -1 = none */
+    int n_maps;                 /* length of the `maps` pointer array (every out_slot / slot_* is < n_maps) */
 } bfm_tail_desc_t;
 
 int bfm_tail_heads(const float* feat, const float* input /*[nvox], may be NULL*/, int64_t nvox,

@@ -31,7 +31,7 @@ for i in range(5):
 
 eng = UNetEngine.__new__(UNetEngine)
 eng.lib = L.load(); eng.device = dev; eng.num_groups = 8; eng.passes = passes; eng.eps = 1e-5; eng.slope = 0.01
-eng._up_cache = {}; eng._ws = None; eng._plan_cache = {}; eng.force_direct = False
+eng._up_cache = {}; eng._ws = None; eng._plan_cache = {}; eng._tuned = set(); eng.force_direct = False
 tot_ms, tot_fl = 0.0, 0.0
 print("%-8s %5s %5s %5s %4s | %-22s | %9s %9s %8s" % ("layer", "CA", "CB", "Cout", "D", "plan WMxWN box splitk", "ms", "TFLOP/s", "GB/s"))
 for name, ca, cb, cout, dd, lo in shapes:
@@ -54,7 +54,7 @@ for name, ca, cb, cout, dd, lo in shapes:
     fl, by = eng.prof[0][2], eng.prof[0][3]
     eng.prof = None
     cfg = eng._plan(ca + cb, cout, (dd,) * 3)
-    plan = "%dx%d (%d,%d,%d) k%d" % (cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5])
+    plan = "%dx%d (%d,%d,%d) k%d v%d" % (cfg[0], cfg[1], cfg[2], cfg[3], cfg[4], cfg[5], cfg[6])
     print("%-8s %5d %5d %5d %4d | %-22s | %9.3f %9.1f %8.0f" % (name, ca, cb, cout, dd, plan, ms, fl / ms / 1e9, by / ms / 1e6))
     tot_ms += ms; tot_fl += fl
     del A, B, ly

@@ -71,16 +71,17 @@ def test_mfma_fragment_layout_exact_integers():
               "backbone.encoders.0.basic_module.SingleConv1.conv.weight": w}
         eng = UNetEngine.__new__(UNetEngine)
         eng.lib = L.load(); eng.device = dev; eng.num_groups = 8; eng.passes = 3; eng.eps = 1e-5; eng.slope = 0.01
-        eng._up_cache = {}; eng._ws = None; eng._plan_cache = {}; eng.force_direct = False
+        eng._up_cache = {}; eng._ws = None; eng._plan_cache = {}; eng._tuned = set(); eng.force_direct = False
         ly = eng._make_layer(sd, "backbone.encoders.0.basic_module.SingleConv1", cin, cout)
-        eng._pack(ly, True)
+        cfgp = eng._plan(cin, cout, dims)
+        eng._pack(ly, True, cfgp[6])
         x_cl = x[0].permute(1, 2, 3, 0).contiguous().to(dev)
         scale = torch.ones(cin, device=dev); shift = torch.zeros(cin, device=dev)
         bound = torch.full((8,), 3.0, device=dev)
         out = torch.empty(dims + (cout,), device=dev)
         ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
         rc = eng.lib.bfm_conv3x3x3_mfma(L.ptr(x_cl), cin, None, 0, dims[0], dims[1], dims[2], None, L.ptr(scale),
-                                        L.ptr(shift), L.ptr(bound), 8, L.ptr(ly.wpacked), ly.wexp, cout, 1.0, 3, None,
+                                        L.ptr(shift), L.ptr(bound), 8, L.ptr(ly.wpacked), ly.wexp, cout, 1.0, 3, cfgp,
                                         L.ptr(out), L.ptr(ws), ws.numel(), L.stream_ptr())
         assert rc == 0
         ref = torch.nn.functional.conv3d(x, w, padding=1)[0].permute(1, 2, 3, 0)
@@ -237,7 +238,7 @@ def test_split_k_deep_layer_vs_oracle():
     eng = UNetEngine.__new__(UNetEngine)
     from brainfm_amd import _lib as L
     eng.lib = L.load(); eng.device = dev; eng.num_groups = 8; eng.passes = 3; eng.eps = 1e-5; eng.slope = 0.01
-    eng._up_cache = {}; eng._ws = None; eng._plan_cache = {}; eng.force_direct = False
+    eng._up_cache = {}; eng._ws = None; eng._plan_cache = {}; eng._tuned = set(); eng.force_direct = False
     ly = eng._make_layer(sd, name, cs + cx, cout)
     out = eng.single_conv(ly, skip[0].permute(1, 2, 3, 0).contiguous().to(dev), (5, 4, 5),
                           B=low[0].permute(1, 2, 3, 0).contiguous().to(dev), lo_dims=(2, 2, 2))
