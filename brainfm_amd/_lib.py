@@ -62,6 +62,7 @@ SIGNATURES = {
     "bfm_pack_conv_weights_mfma16_bytes": (_Z, [_I, _I]),
     "bfm_pack_conv_weights_mfma16": (_I, [_P, _I, _I, _F, _P, C.POINTER(_I), _P]),
     "bfm_conv3x3x3_direct": (_I, [_P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _P, _I, _F, _P, _P]),
+    "bfm_conv3x3x3_stem": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
     "bfm_conv3x3x3_mfma_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
     "bfm_conv3x3x3_mfma_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),
     "bfm_conv3x3x3_mfma": (_I, [_P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _P, _I, _P, _I, _I, _F, _I,
@@ -97,6 +98,7 @@ SIGNATURES = {
     "bfm_reduce_f32": (_I, [_I, _P, _P, _L, _P, _P, _Z, _P]),
     "bfm_reduce_f64": (_I, [_I, _P, _P, _L, _P, _P, _Z, _P]),
     "bfm_stitch_accumulate": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "bfm_stitch_accumulate_multi": (_I, [_P, _L, _P, _I, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bfm_mask_tile": (_I, [_P, _P, _P, _L, _P, _P]),
     "bfm_tile_count_add": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "bfm_divide_by_count": (_I, [_P, _P, _L, _P]),

@@ -86,6 +86,98 @@ __global__ void __launch_bounds__(TPB) conv_direct(const float* __restrict__ A, 
     }
 }
 
+// Cin == 1 stem (enc0.1: 1 -> 32 @ up to 160^3) as a K = 32 GEMM on the matrix core: the 27 taps (+5 zero
+// columns) are the K dimension, 32 consecutive voxels of one x-run the rows, Cout the columns.  The layer is
+// bound by its 128 B/voxel output; with v_mfma_f32_32x32x16_f16 (hi/lo split like conv_mfma, fp32-grade) the
+// arithmetic is ~6 MFMAs per 32 voxels and every store instruction writes two full 128-byte output lines.
+typedef _Float16 half8s __attribute__((ext_vector_type(8)));
+typedef float floatx16s __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(256) conv_stem_mfma(const float* __restrict__ A, int D, int H, int W,
+                                                      const float* __restrict__ scale,
+                                                      const float* __restrict__ shift,
+                                                      const float* __restrict__ bound,
+                                                      const float* __restrict__ wp /*[27][Cout]*/, int Cout,
+                                                      float slope, float* __restrict__ out, int64_t nblocks32) {
+    const int lane = threadIdx.x & 63;
+    const int l32 = lane & 31, kh = lane >> 5;
+    // operand scales (powers of two): activations from the GroupNorm bound, weights from max|w|
+    float bmax = bound[0];
+    int aexp = 0;
+    if (bmax > 0.f && bmax < INFINITY) { int ex; (void)frexpf(bmax, &ex); aexp = 14 - ex; aexp = aexp > 60 ? 60 : (aexp < -60 ? -60 : aexp); }
+    float wmax = 0.f;
+    for (int i = lane; i < 27 * Cout; i += 64) wmax = fmaxf(wmax, fabsf(wp[i]));
+    wmax = wave_reduce_max(wmax);
+    int wexp = 0;
+    if (wmax > 0.f && wmax < INFINITY) { int ex; (void)frexpf(wmax, &ex); wexp = 14 - ex; wexp = wexp > 60 ? 60 : (wexp < -60 ? -60 : wexp); }
+    const float sa = ldexpf(1.f, aexp), sw = ldexpf(1.f, wexp), dq = ldexpf(1.f, -(aexp + wexp));
+    const float sc = scale[0] * sa, sh = shift[0] * sa;
+    const int NB = Cout >> 5;                                   // 32-wide column blocks (1 or 2)
+
+    // B fragments: lane holds B[k = 16*ks + 8*kh + j][col = nb*32 + l32], k = tap index (>= 27 -> 0)
+    half8s bhi[2][2], blo[2][2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * ks + 8 * kh + j;
+                const float w = (k < 27 && nb < NB) ? wp[k * Cout + nb * 32 + l32] * sw : 0.f;
+                const _Float16 h = (_Float16)w;
+                bhi[nb][ks][j] = h;
+                blo[nb][ks][j] = (_Float16)(w - (float)h);
+            }
+
+    const int xb = (W + 31) >> 5;                               // 32-voxel row blocks per x-run
+    const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nw = (int64_t)gridDim.x * 4;
+    for (int64_t blk = gw; blk < nblocks32; blk += nw) {
+        const int bx = (int)(blk % xb);
+        const int64_t t = blk / xb;
+        const int y = (int)(t % H);
+        const int z = (int)(t / H);
+        const int x = bx * 32 + l32;                            // this lane's row (voxel) for the A operand
+        half8s ahi[2], alo[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * ks + 8 * kh + j;
+                const int kd = k / 9, r9 = k - kd * 9, kh3 = r9 / 3, kw = r9 - kh3 * 3;
+                const int zz = z + kd - 1, yy = y + kh3 - 1, xx = x + kw - 1;
+                const bool inb = k < 27 && zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
+                const float v = inb ? fmaf(A[((int64_t)zz * H + yy) * W + xx], sc, sh) : 0.f;
+                const _Float16 h = (_Float16)v;
+                ahi[ks][j] = h;
+                alo[ks][j] = (_Float16)(v - (float)h);
+            }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            if (nb >= NB) break;
+            floatx16s acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], bhi[nb][ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], blo[nb][ks], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bhi[nb][ks], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rr = (i & 3) + 8 * (i >> 2) + 4 * kh;     // C/D row of this register
+                const int xo = bx * 32 + rr;
+                if (xo < W) {
+                    float r = acc[i] * dq;
+                    r = r >= 0.f ? r : r * slope;
+                    out[(((int64_t)z * H + y) * W + xo) * Cout + nb * 32 + l32] = r;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" size_t bfm_pack_conv_weights_direct_bytes(int Cin, int Cout) {
@@ -110,5 +202,18 @@ extern "C" int bfm_conv3x3x3_direct(const float* A, int CA, const float* B, int 
     dim3 grid((unsigned)bfm_cdiv64(nvox, TPB), (unsigned)bfm_cdiv(Cout, COT));
     hipLaunchKernelGGL(conv_direct, grid, dim3(TPB), 0, bfm_s(stream), A, CA, B, CB, D, H, W, make_upview(up), scale,
                        shift, wpacked, Cout, slope, out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_conv3x3x3_stem(const float* A, int D, int H, int W, const float* scale, const float* shift,
+                                  const float* bound, const float* wpacked_direct, int Cout, float slope, float* out,
+                                  bfm_stream_t stream) {
+    if (!A || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || !wpacked_direct || !out) return BFM_E_ARG;
+    if (Cout != 32 && Cout != 64) return BFM_E_SHAPE;
+    const int64_t nblk = (int64_t)D * H * ((W + 31) / 32);
+    int64_t nb = bfm_cdiv64(nblk, 4);
+    if (nb > 256 * 16) nb = 256 * 16;
+    hipLaunchKernelGGL(conv_stem_mfma, dim3((unsigned)nb), dim3(256), 0, bfm_s(stream), A, D, H, W, scale, shift, bound,
+                       wpacked_direct, Cout, slope, out, nblk);
     return bfm_launch_status();
 }

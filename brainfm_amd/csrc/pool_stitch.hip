@@ -63,6 +63,29 @@ __global__ void stitch_kernel(const float* __restrict__ tile, const int64_t* __r
     }
 }
 
+// all stitched keys of one tile in a single launch: maps [n_maps][tvox] from the fused tail, sel[k] = map row of
+// key k (-1: the int64 label), full [K][D*H*W]
+__global__ void stitch_multi_kernel(const float* __restrict__ maps, int64_t map_stride, const int32_t* __restrict__ sel,
+                                    int K, const int64_t* __restrict__ label, const float* __restrict__ tin, int td,
+                                    int th, int tw, float* __restrict__ full, int D, int H, int W, int z0, int y0,
+                                    int x0) {
+    const int64_t n = (int64_t)td * th * tw;
+    const int64_t vol = (int64_t)D * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int x = (int)(i % tw);
+        int64_t t = i / tw;
+        int y = (int)(t % th);
+        int z = (int)(t / th);
+        const float m = tin[i] != 0.f ? 1.f : 0.f;
+        const int64_t o = ((int64_t)(z0 + z) * H + (y0 + y)) * W + (x0 + x);
+        for (int k = 0; k < K; ++k) {
+            const int r = sel[k];
+            const float v = r < 0 ? (float)(int)((float)label[i] * m) : maps[(int64_t)r * map_stride + i] * m;
+            full[(int64_t)k * vol + o] += v;
+        }
+    }
+}
+
 // tile output * (tile_input != 0), flattened (what a rank ships to rank 0)
 __global__ void mask_kernel(const float* __restrict__ tile, const int64_t* __restrict__ tile_label,
                             const float* __restrict__ tin, int64_t n, float* __restrict__ out) {
@@ -115,6 +138,18 @@ extern "C" int bfm_stitch_accumulate(const float* tile, const int64_t* tile_labe
     int64_t n = (int64_t)td * th * tw;
     hipLaunchKernelGGL(stitch_kernel, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), tile, tile_label, tile_input, td,
                        th, tw, full, H, W, z0, y0, x0);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_stitch_accumulate_multi(const float* maps, int64_t map_stride, const int32_t* sel, int K,
+                                           const int64_t* tile_label, const float* tile_input, int td, int th, int tw,
+                                           float* full, int D, int H, int W, int z0, int y0, int x0,
+                                           bfm_stream_t stream) {
+    if (!maps || !sel || K <= 0 || !tile_input || !full || td <= 0 || th <= 0 || tw <= 0) return BFM_E_ARG;
+    if (z0 < 0 || y0 < 0 || x0 < 0 || z0 + td > D || y0 + th > H || x0 + tw > W) return BFM_E_SHAPE;
+    int64_t n = (int64_t)td * th * tw;
+    hipLaunchKernelGGL(stitch_multi_kernel, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), maps, map_stride, sel, K,
+                       tile_label, tile_input, td, th, tw, full, D, H, W, z0, y0, x0);
     return bfm_launch_status();
 }
 

@@ -44,9 +44,16 @@ struct TailParams {
     int n_maps;
 };
 
+// exp on the hardware exp2 unit: |rel err| ~ 1e-6 for the argument ranges below (softmax <= 0, tanh via exp)
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float e = fast_exp(2.f * fminf(fmaxf(x, -15.f), 15.f));
+    return (e - 1.f) * __builtin_amdgcn_rcpf(e + 1.f);
+}
+
 __device__ __forceinline__ float fake_term(float w_or_p, float add, float gain) {
     // gain * (1 - (tanh(2*(v+add)) + 1) / 2)      (__init__.py:329-336, a = 2)
-    return gain * (1.f - (tanhf(2.f * (w_or_p + add)) + 1.f) / 2.f);
+    return gain * (1.f - (fast_tanh(2.f * (w_or_p + add)) + 1.f) / 2.f);
 }
 
 // Persistent: each block walks tiles of 128 voxels.  Per tile:
@@ -113,8 +120,8 @@ __global__ void __launch_bounds__(TPBT) tail_kernel(TailParams p) {
         if (p.d.unit_feat) {
             float ss = 0.f;
             for (int c = 0; c < C; ++c) ss = fmaf(row[c], row[c], ss);
-            const float denom = fmaxf(sqrtf(ss), 1e-12f);     // F.normalize eps
-            for (int c = 0; c < C; ++c) row[c] = row[c] / denom;
+            const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize eps; one division per voxel
+            for (int c = 0; c < C; ++c) row[c] = row[c] * inv;
         }
         __syncthreads();
 
@@ -213,10 +220,11 @@ __global__ void __launch_bounds__(TPBT) tail_kernel(TailParams p) {
                 float m = -INFINITY;
                 for (int s = 0; s < ns; ++s) m = fmaxf(m, sl[s]);
                 float sum = 0.f;
-                for (int s = 0; s < ns; ++s) { float e = expf(sl[s] - m); sl[s] = e; sum += e; }
+                for (int s = 0; s < ns; ++s) { float e = fast_exp(sl[s] - m); sl[s] = e; sum += e; }
+                const float rs = 1.f / sum;
                 float bp = -1.f;
                 for (int s = 0; s < ns; ++s) {
-                    float pr = sl[s] / sum;
+                    float pr = sl[s] * rs;
                     sl[s] = pr;
                     if (pr > bp) { bp = pr; best = s; }      // first maximum wins (torch.argmax)
                 }

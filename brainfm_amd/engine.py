@@ -249,6 +249,10 @@ class UNetEngine:
                 lo = 0 if B is None else lo_dims[0] * lo_dims[1] * lo_dims[2]
                 self.prof.append((ev[0], ev[1], 2.0 * 27 * ly.cin * ly.cout * nv,
                                   4.0 * (nv * ca + lo * cb + nv * ly.cout + 27 * ly.cin * ly.cout)))
+        elif ca == 1 and cb == 0 and ly.cout in (32, 64) and not self.force_direct:
+            L.check(self.lib.bfm_conv3x3x3_stem(L.ptr(A), D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
+                                                L.ptr(ly.wpacked), ly.cout, self.slope, L.ptr(out), st),
+                    "conv_stem " + ly.name)
         else:
             L.check(self.lib.bfm_conv3x3x3_direct(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(scale),
                                                   L.ptr(shift), L.ptr(ly.wpacked), ly.cout, self.slope, L.ptr(out),
@@ -407,6 +411,7 @@ class Tail:
         L.check(eng.lib.bfm_tail_heads(L.ptr(feat_cl), L.ptr(input_cl), nvox, C.byref(self.desc), L.ptr(feat_norm),
                                        L.ptr(ptrs), L.ptr(seg), L.ptr(label), None, L.stream_ptr()), "tail_heads")
         maps = OrderedDict((n, maps_buf[i]) for i, n in enumerate(self.map_names))
+        self.last_buf = maps_buf                      # [n_maps][D,H,W]: the stitcher consumes all rows in one launch
         return maps, feat_norm, seg, label
 
     def run_raw(self, feat_cl, dims, want_feat=True):

@@ -287,28 +287,37 @@ def tiled_inference(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 1
     shape = tuple(full_im.shape[2:])
     ranges = tiling_ranges(shape, stride, win_size)
     cnt = count_volume(shape, ranges, eng.device)
-    acc, keys = None, None
+    acc_buf, keys, sel = None, None, None
     for rng in ranges:
         (x0, x1), (y0, y1), (z0, z1) = rng
         im = full_im[:, :, x0:x1, y0:y1, z0:z1]
-        maps, label, x_cl = _run_tile(session, im)
-        if acc is None:
-            keys = [k for k in STITCH_KEYS if k in maps or (k == "label" and label is not None)]
-            acc = OrderedDict((k, torch.zeros(shape, dtype=torch.float32, device=eng.device)) for k in keys)
-        _stitch_tile(lib, acc, keys, maps, label, x_cl, rng, shape)
+        maps_buf, names, label, x_cl = _run_tile(session, im, raw=True)
+        if acc_buf is None:
+            keys = [k for k in STITCH_KEYS if k in names or (k == "label" and label is not None)]
+            sel = torch.tensor([names.index(k) if k != "label" else -1 for k in keys], dtype=torch.int32,
+                               device=eng.device)
+            acc_buf = torch.zeros((len(keys),) + shape, dtype=torch.float32, device=eng.device)
+        tv = (x1 - x0) * (y1 - y0) * (z1 - z0)
+        L.check(lib.bfm_stitch_accumulate_multi(L.ptr(maps_buf), tv, L.ptr(sel), len(keys), L.ptr(label), L.ptr(x_cl),
+                                                x1 - x0, y1 - y0, z1 - z0, L.ptr(acc_buf), shape[0], shape[1],
+                                                shape[2], x0, y0, z0, L.stream_ptr()), "stitch_multi")
     n = shape[0] * shape[1] * shape[2]
-    for k in keys:
-        L.check(lib.bfm_divide_by_count(L.ptr(acc[k]), L.ptr(cnt), n, L.stream_ptr()), "divide_by_count")
+    acc = OrderedDict()
+    for j, k in enumerate(keys):
+        L.check(lib.bfm_divide_by_count(L.ptr(acc_buf[j]), L.ptr(cnt), n, L.stream_ptr()), "divide_by_count")
+        acc[k] = acc_buf[j]
     return acc, ranges, cnt
 
 
-def _run_tile(session, im):
+def _run_tile(session, im, raw=False):
     eng = session.engine
     dims = tuple(im.shape[2:])
     x_cl = eng.to_cl(im)
     feats = eng.backbone_cl(x_cl, dims)
     tail = session.model.head.tail(eng)
     maps, _, _, label = tail.run(feats[-1][0], dims, input_cl=x_cl, want_feat=False, want_seg=False)
+    if raw:
+        return tail.last_buf, list(maps.keys()), label, x_cl
     return maps, label, x_cl
 
 

@@ -90,6 +90,12 @@ int bfm_conv3x3x3_direct(const float* A, int CA, const float* B, int CB, int D, 
                          const bfm_upsample_t* up, const float* scale, const float* shift,
                          const float* wpacked, int Cout, float slope, float* out, bfm_stream_t stream);
 
+/* Cin == 1 stem (enc0.1) as a K = 32 (27 taps + padding) GEMM on the matrix core, same split-fp16 numerics as
+ * _mfma; Cout in {32, 64}; weights in the _direct layout [27][Cout]; bound = the single GroupNorm bound. */
+int bfm_conv3x3x3_stem(const float* A, int D, int H, int W, const float* scale, const float* shift,
+                       const float* bound, const float* wpacked_direct, int Cout, float slope, float* out,
+                       bfm_stream_t stream);
+
 size_t bfm_conv3x3x3_mfma_workspace(int Cin, int Cout, int D, int H, int W, int splitk);
 int bfm_conv3x3x3_mfma_plan(int Cin, int Cout, int D, int H, int W, int* cfg_out /*[8]*/);
 int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB, int D, int H, int W,
@@ -152,6 +158,11 @@ int bfm_tail_heads(const float* feat, const float* input /*[nvox], may be NULL*/
 int bfm_stitch_accumulate(const float* tile, const int64_t* tile_label, const float* tile_input,
                           int td, int th, int tw, float* full, int D, int H, int W,
                           int z0, int y0, int x0, bfm_stream_t stream);
+/* All K stitched keys of one tile in one launch: maps [n_maps][td*th*tw] (row stride map_stride), sel[k] = map
+ * row feeding key k or -1 for the int64 label, full [K][D*H*W]. */
+int bfm_stitch_accumulate_multi(const float* maps, int64_t map_stride, const int32_t* sel, int K,
+                                const int64_t* tile_label, const float* tile_input, int td, int th, int tw, float* full,
+                                int D, int H, int W, int z0, int y0, int x0, bfm_stream_t stream);
 /* tile_input == NULL in bfm_stitch_accumulate means "already masked".  bfm_mask_tile produces the
  * masked, float-typed tile a rank ships to rank 0 in the multi-GPU path. */
 int bfm_mask_tile(const float* tile, const int64_t* tile_label, const float* tile_input, int64_t n, float* out,
