@@ -170,6 +170,35 @@ class InferenceSession:
             M.load_state_dict_by_suffix(self.model, state_dict)
         self.device = torch.device(device if not isinstance(device, int) else "cuda:%d" % device)
         self.tasks = self.gen_args.tasks
+        # hipGraph replay of the per-tile kernel sequence (about 80 launches, many of them a few microseconds long on
+        # the deep levels, where python submission is slower than the GPU): "auto" runs the first tile of a shape
+        # eagerly (this also tunes the conv variants), captures on the second, replays afterwards.
+        self.use_graphs = False
+        self._graph_seen = set()
+        self._graphs = {}
+        self._graph_pool = None
+
+    def graph_tile(self, im):
+        """Run one tile through backbone + tail via a captured hipGraph for its shape.
+        Returns what _run_tile(raw=True) returns; the buffers are static per shape and are overwritten by the
+        next replay of the same (or, the pool being shared, any) shape, so consume them on the same stream first."""
+        dims = tuple(im.shape[2:])
+        if dims not in self._graph_seen:
+            self._graph_seen.add(dims)
+            return _run_tile(self, im, raw=True)
+        if dims not in self._graphs:
+            static_in = torch.empty(tuple(im.shape), dtype=torch.float32, device=self.device)
+            static_in.copy_(im)
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._graph_pool):
+                outs = _run_tile(self, static_in, raw=True)
+            self._graphs[dims] = (g, static_in, outs)
+        g, static_in, outs = self._graphs[dims]
+        static_in.copy_(im)
+        g.replay()
+        return outs
 
     @property
     def engine(self):
@@ -278,9 +307,12 @@ def _stitch_tile(lib, acc, keys, maps, label, x_cl, rng, shape):
 
 
 @torch.no_grad()
-def tiled_inference(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 160]):
+def tiled_inference(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 160], graphs=None):
     """scripts/demo_test.py:66-119 on the device: per tile infer -> mask -> accumulate; then /cnt.
-    full_im: (1,1,D,H,W) on the session's device.  Returns ({key: (D,H,W) fp32}, ranges, cnt)."""
+    full_im: (1,1,D,H,W) on the session's device.  Returns ({key: (D,H,W) fp32}, ranges, cnt).
+    graphs: replay a captured hipGraph per tile shape (default: session.use_graphs); same kernels, same results."""
+    if graphs is None:
+        graphs = session.use_graphs
     lib = L.load()
     eng = session.engine
     full_im = full_im.to(device=eng.device, dtype=torch.float32)
@@ -291,7 +323,7 @@ def tiled_inference(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 1
     for rng in ranges:
         (x0, x1), (y0, y1), (z0, z1) = rng
         im = full_im[:, :, x0:x1, y0:y1, z0:z1]
-        maps_buf, names, label, x_cl = _run_tile(session, im, raw=True)
+        maps_buf, names, label, x_cl = session.graph_tile(im) if graphs else _run_tile(session, im, raw=True)
         if acc_buf is None:
             keys = [k for k in STITCH_KEYS if k in names or (k == "label" and label is not None)]
             sel = torch.tensor([names.index(k) if k != "label" else -1 for k in keys], dtype=torch.int32,
@@ -307,6 +339,27 @@ def tiled_inference(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 1
         L.check(lib.bfm_divide_by_count(L.ptr(acc_buf[j]), L.ptr(cnt), n, L.stream_ptr()), "divide_by_count")
         acc[k] = acc_buf[j]
     return acc, ranges, cnt
+
+
+@torch.no_grad()
+def prepare_tile_graphs(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 160], world=1, rank=0):
+    """Tune + capture the hipGraph of every tile shape this rank will see (first tile of each shape, run twice:
+    eager, then capture + replay).  Optional: tiled_inference does the same lazily on the first volumes."""
+    shape = tuple(full_im.shape[2:])
+    ranges = tiling_ranges(shape, stride, win_size)
+    owner = assign_tiles(ranges, world)
+    done = set()
+    for i, rng in enumerate(ranges):
+        dims = tuple(b - a for a, b in rng)
+        if owner[i] != rank or dims in done:
+            continue
+        done.add(dims)
+        (x0, x1), (y0, y1), (z0, z1) = rng
+        im = full_im[:, :, x0:x1, y0:y1, z0:z1].to(device=session.device, dtype=torch.float32)
+        while dims not in session._graphs:
+            session.graph_tile(im)
+    torch.cuda.synchronize(session.device)
+    return sorted(done)
 
 
 def _run_tile(session, im, raw=False):
@@ -329,7 +382,11 @@ class HipStitchOps:
         self.lib = L.load()
 
     def run_tile(self, im):
-        maps, label, x_cl = _run_tile(self.session, im)
+        if self.session.use_graphs:
+            maps_buf, names, label, x_cl = self.session.graph_tile(im)
+            maps = OrderedDict((nm, maps_buf[i]) for i, nm in enumerate(names))
+        else:
+            maps, label, x_cl = _run_tile(self.session, im)
         keys = [k for k in STITCH_KEYS if k in maps or (k == "label" and label is not None)]
         n = x_cl.numel()
         rows = torch.empty((len(keys), n), dtype=torch.float32, device=x_cl.device)

@@ -1,16 +1,25 @@
 """Summarise a rocprofv3 rocpd database (kernel trace) into a per-kernel table.
-usage: python scripts/prof_summary.py gpurun_out/prof_x/bench_results.db [steps_in_trace]"""
+usage: python scripts/prof_summary.py gpurun_out/prof_x/bench_results.db [steps_in_trace] [tail_ms]
+tail_ms > 0 keeps only the kernels that start within the last tail_ms of the trace (the timed steps, leaving out
+the warm-up with its one-off autotune trial launches)."""
 import sqlite3
 import sys
 
 db = sys.argv[1]
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+tail_ms = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
 c = sqlite3.connect(db)
+where = ""
+if tail_ms > 0:
+    t_end = list(c.execute("select max(end) from kernels"))[0][0]
+    where = " where start >= %d" % (t_end - int(tail_ms * 1e6))
 rows = list(c.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3, min(end-start)/1e3, "
-                      "max(end-start)/1e3 from kernels group by name order by 3 desc"))
+                      "max(end-start)/1e3 from kernels" + where + " group by name order by 3 desc"))
+span = list(c.execute("select (max(end)-min(start))/1e6 from kernels" + where))[0][0]
 tot = sum(r[2] for r in rows)
-print("# rocprofv3 --kernel-trace summary of %s" % db)
-print("# total kernel time %.3f ms over %g step(s) -> %.3f ms/step" % (tot, steps, tot / steps))
+print("# rocprofv3 --kernel-trace summary of %s%s" % (db, (" (last %.0f ms)" % tail_ms) if tail_ms > 0 else ""))
+print("# total kernel time %.3f ms over %g step(s) -> %.3f ms/step; wall span %.3f ms -> %.3f ms/step" %
+      (tot, steps, tot / steps, span, span / steps))
 print("%-72s %7s %11s %6s %10s %10s %10s" % ("kernel", "calls", "total_ms", "%", "avg_us", "min_us", "max_us"))
 for r in rows:
     name = r[0].replace("(anonymous namespace)::", "")
