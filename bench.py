@@ -136,15 +136,17 @@ def main():
     # the same step is run once more eagerly right after it with every conv launch issued `reps` times back to back
     # inside one HIP event pair on the launch stream (idempotent; back-to-back so the bracket holds kernel time rather
     # than python submission gaps).  Launch duration = bracket / reps.
-    eng.prof = []
-    eng.prof_reps = args.roofline_reps
-    g = sess.use_graphs
-    sess.use_graphs = False
-    step()
-    torch.cuda.synchronize()
-    sess.use_graphs = g
-    prof = eng.prof
-    eng.prof = None
+    prof = []
+    if args.roofline_reps > 0:                      # 0: skip (used for rocprofv3 runs that should hold the timed steps only)
+        eng.prof = []
+        eng.prof_reps = args.roofline_reps
+        g = sess.use_graphs
+        sess.use_graphs = False
+        step()
+        torch.cuda.synchronize()
+        sess.use_graphs = g
+        prof = eng.prof
+        eng.prof = None
     k_ms = sum(a.elapsed_time(b) / r for a, b, _, _, r in prof)
     k_fl = sum(f for _, _, f, _, _ in prof)
     k_by = sum(b for _, _, _, b, _ in prof)

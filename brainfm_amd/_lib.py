@@ -32,7 +32,7 @@ class TailDesc(C.Structure):
                 ("seg_first", C.c_int), ("n_seg", C.c_int), ("seg_lut", C.c_void_p),
                 ("n_dist", C.c_int), ("dist_first", C.c_int), ("max_dist", C.c_float),
                 ("unit_feat", C.c_int), ("slot_high_res", C.c_int), ("slot_fake_cortical", C.c_int),
-                ("n_maps", C.c_int)]
+                ("n_maps", C.c_int), ("head_wmax", C.c_float)]
 
 
 class ZoomAxis(C.Structure):

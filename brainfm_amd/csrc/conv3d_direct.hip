@@ -93,12 +93,14 @@ __global__ void __launch_bounds__(TPB) conv_direct(const float* __restrict__ A, 
 typedef _Float16 half8s __attribute__((ext_vector_type(8)));
 typedef float floatx16s __attribute__((ext_vector_type(16)));
 
-__global__ void __launch_bounds__(256) conv_stem_mfma(const float* __restrict__ A, int D, int H, int W,
-                                                      const float* __restrict__ scale,
-                                                      const float* __restrict__ shift,
-                                                      const float* __restrict__ bound,
-                                                      const float* __restrict__ wp /*[27][Cout]*/, int Cout,
-                                                      float slope, float* __restrict__ out, int64_t nblocks32) {
+template <int NB>
+__global__ void __launch_bounds__(256, 3) conv_stem_mfma(const float* __restrict__ A, int D, int H, int W,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         const float* __restrict__ bound,
+                                                         const float* __restrict__ wp /*[27][Cout]*/, float slope,
+                                                         float* __restrict__ out, int64_t nblocks32) {
+    constexpr int Cout = NB * 32;
     const int lane = threadIdx.x & 63;
     const int l32 = lane & 31, kh = lane >> 5;
     // operand scales (powers of two): activations from the GroupNorm bound, weights from max|w|
@@ -112,49 +114,69 @@ __global__ void __launch_bounds__(256) conv_stem_mfma(const float* __restrict__ 
     if (wmax > 0.f && wmax < INFINITY) { int ex; (void)frexpf(wmax, &ex); wexp = 14 - ex; wexp = wexp > 60 ? 60 : (wexp < -60 ? -60 : wexp); }
     const float sa = ldexpf(1.f, aexp), sw = ldexpf(1.f, wexp), dq = ldexpf(1.f, -(aexp + wexp));
     const float sc = scale[0] * sa, sh = shift[0] * sa;
-    const int NB = Cout >> 5;                                   // 32-wide column blocks (1 or 2)
 
     // B fragments: lane holds B[k = 16*ks + 8*kh + j][col = nb*32 + l32], k = tap index (>= 27 -> 0)
-    half8s bhi[2][2], blo[2][2];
+    half8s bhi[NB][2], blo[NB][2];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * ks + 8 * kh + j;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 16 * ks + 8 * kh + j;
-                const float w = (k < 27 && nb < NB) ? wp[k * Cout + nb * 32 + l32] * sw : 0.f;
+            for (int nb = 0; nb < NB; ++nb) {
+                const float w = k < 27 ? wp[k * Cout + nb * 32 + l32] * sw : 0.f;
                 const _Float16 h = (_Float16)w;
                 bhi[nb][ks][j] = h;
                 blo[nb][ks][j] = (_Float16)(w - (float)h);
             }
+        }
 
     const int xb = (W + 31) >> 5;                               // 32-voxel row blocks per x-run
     const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * 4;
-    for (int64_t blk = gw; blk < nblocks32; blk += nw) {
+
+    // gather of one row block: raw input values (the GroupNorm affine is applied later, zero padding stays exact)
+    auto gather = [&](int64_t blk, float (&raw)[16], unsigned& mask) __attribute__((always_inline)) {
         const int bx = (int)(blk % xb);
         const int64_t t = blk / xb;
-        const int y = (int)(t % H);
-        const int z = (int)(t / H);
-        const int x = bx * 32 + l32;                            // this lane's row (voxel) for the A operand
+        const int y = (int)(t % H), z = (int)(t / H);
+        const int x = bx * 32 + l32;
+        mask = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            // tap k = 16*(q>>3) + 8*kh + (q&7): both candidates are compile-time constants, kh selects
+            const int k0 = 16 * (q >> 3) + (q & 7), k1 = k0 + 8;
+            const int dz = kh ? (k1 / 9 - 1) : (k0 / 9 - 1);
+            const int dy = kh ? ((k1 % 9) / 3 - 1) : ((k0 % 9) / 3 - 1);
+            const int dx = kh ? (k1 % 3 - 1) : (k0 % 3 - 1);
+            const bool tap = kh ? (k1 < 27) : (k0 < 27);
+            const int zz = z + dz, yy = y + dy, xx = x + dx;
+            const bool inb = tap && (unsigned)zz < (unsigned)D && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+            raw[q] = inb ? A[((int64_t)zz * H + yy) * W + xx] : 0.f;
+            mask |= inb ? (1u << q) : 0u;
+        }
+    };
+
+    float raw[16];
+    unsigned mask = 0;
+    if (gw < nblocks32) gather(gw, raw, mask);
+    for (int64_t blk = gw; blk < nblocks32; blk += nw) {
+        float nraw[16];
+        unsigned nmask = 0;
+        if (blk + nw < nblocks32) gather(blk + nw, nraw, nmask);    // in flight while this block is multiplied / stored
         half8s ahi[2], alo[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int q = 0; q < 16; ++q) {
+            const float v = (mask >> q) & 1u ? fmaf(raw[q], sc, sh) : 0.f;
+            const _Float16 h = (_Float16)v;
+            ahi[q >> 3][q & 7] = h;
+            alo[q >> 3][q & 7] = (_Float16)(v - (float)h);
+        }
+        const int bx = (int)(blk % xb);
+        const int64_t t = blk / xb;
+        float* orow = out + (t * W + bx * 32) * Cout;               // t = z*H + y
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 16 * ks + 8 * kh + j;
-                const int kd = k / 9, r9 = k - kd * 9, kh3 = r9 / 3, kw = r9 - kh3 * 3;
-                const int zz = z + kd - 1, yy = y + kh3 - 1, xx = x + kw - 1;
-                const bool inb = k < 27 && zz >= 0 && zz < D && yy >= 0 && yy < H && xx >= 0 && xx < W;
-                const float v = inb ? fmaf(A[((int64_t)zz * H + yy) * W + xx], sc, sh) : 0.f;
-                const _Float16 h = (_Float16)v;
-                ahi[ks][j] = h;
-                alo[ks][j] = (_Float16)(v - (float)h);
-            }
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            if (nb >= NB) break;
+        for (int nb = 0; nb < NB; ++nb) {
             floatx16s acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -167,14 +189,16 @@ __global__ void __launch_bounds__(256) conv_stem_mfma(const float* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int rr = (i & 3) + 8 * (i >> 2) + 4 * kh;     // C/D row of this register
-                const int xo = bx * 32 + rr;
-                if (xo < W) {
+                if (bx * 32 + rr < W) {
                     float r = acc[i] * dq;
                     r = r >= 0.f ? r : r * slope;
-                    out[(((int64_t)z * H + y) * W + xo) * Cout + nb * 32 + l32] = r;
+                    orow[rr * Cout + nb * 32 + l32] = r;
                 }
             }
         }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) raw[q] = nraw[q];
+        mask = nmask;
     }
 }
 
@@ -213,7 +237,11 @@ extern "C" int bfm_conv3x3x3_stem(const float* A, int D, int H, int W, const flo
     const int64_t nblk = (int64_t)D * H * ((W + 31) / 32);
     int64_t nb = bfm_cdiv64(nblk, 4);
     if (nb > 256 * 16) nb = 256 * 16;
-    hipLaunchKernelGGL(conv_stem_mfma, dim3((unsigned)nb), dim3(256), 0, bfm_s(stream), A, D, H, W, scale, shift, bound,
-                       wpacked_direct, Cout, slope, out, nblk);
+    if (Cout == 32)
+        hipLaunchKernelGGL(conv_stem_mfma<1>, dim3((unsigned)nb), dim3(256), 0, bfm_s(stream), A, D, H, W, scale, shift,
+                           bound, wpacked_direct, slope, out, nblk);
+    else
+        hipLaunchKernelGGL(conv_stem_mfma<2>, dim3((unsigned)nb), dim3(256), 0, bfm_s(stream), A, D, H, W, scale, shift,
+                           bound, wpacked_direct, slope, out, nblk);
     return bfm_launch_status();
 }

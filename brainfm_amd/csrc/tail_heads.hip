@@ -10,25 +10,24 @@
 // caller asks for is written (15 fp32 maps + int64 label = 68 B/voxel; the
 // 56-channel softmax and the normalised features are optional).
 //
-// 128 voxels per tile, persistent workgroups.  The [128][c_feat] feature tile
-// is loaded with coalesced float4 reads into LDS (odd row stride: conflict-free
-// column access); the head GEMM runs on the fp32 matrix core
-// (v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 FMA chain) with the weights held
-// in registers as B fragments; the logits return to the LDS rows and one thread
-// per voxel applies softmax / argmax / exp / tanh / clamp.
-// raw_out != NULL turns the call into TaskHead.forward alone (raw logits,
-// [nvox][n_out]) for callers that run the reference's processors separately.
+// One wave owns 64 voxels at a time and never synchronises with another wave.  Each lane pulls its half of a
+// voxel's feature row straight into registers in the layout v_mfma_f32_32x32x2_f32 wants for A (the K order of a
+// dot product is free, so lane (row, half) simply takes 32 consecutive channels), normalises it with one
+// cross-half shuffle, and the head GEMM runs on the fp32 matrix core (bit-for-bit an fp32 FMA chain) against
+// weights held in registers as B fragments.  The logits go to a wave-private LDS slab [64][n_out|1] (odd stride:
+// conflict-free), from which one lane per voxel applies softmax / argmax / exp / tanh / clamp and writes the maps
+// coalesced.  raw_out != NULL turns the call into TaskHead.forward alone (raw logits, [nvox][n_out]).
 #include "bfm_common.h"
 
 namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8t __attribute__((ext_vector_type(8)));
 
-constexpr int VPB = 128;     // voxels per tile
-constexpr int TPBT = 128;    // threads per block: 2 waves, 64 voxels (two 32-row MFMA blocks) each
+constexpr int WPB = 4;       // waves per block (independent)
+constexpr int TPBT = 64 * WPB;
 constexpr int CMAX = 64;     // c_feat upper bound
-constexpr int OMAX = 96;     // n_out upper bound (3 MFMA column blocks, LDS row)
-constexpr int LD = OMAX + 1; // LDS row stride in floats (odd: conflict-free column access)
+constexpr int OMAX = 96;     // n_out upper bound (3 MFMA column blocks)
 constexpr int NMAPS = 64;    // upper bound on output maps
 
 struct TailParams {
@@ -56,108 +55,148 @@ __device__ __forceinline__ float fake_term(float w_or_p, float add, float gain) 
     return gain * (1.f - (fast_tanh(2.f * (w_or_p + add)) + 1.f) / 2.f);
 }
 
-// Persistent: each block walks tiles of 128 voxels.  Per tile:
-//   1. coalesced float4 load of the [128][C] feature tile into LDS
-//   2. one thread per voxel: L2 norm, normalise the row in place (F.normalize)
-//   3. head GEMM [128 x C] x [C x n_out] on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain); the
-//      weights live in registers as MFMA B fragments for the whole kernel
-//   4. logits (+bias) back into the LDS rows, one thread per voxel applies the roles
-__global__ void __launch_bounds__(TPBT) tail_kernel(TailParams p) {
-    extern __shared__ float tile[];                 // [VPB][LD] then the per-head tables
-    // roles / slots / output pointers are read once per block into LDS: fetching them from global memory inside
-    // the per-head loop is a chain of dependent loads per output row (it dominated the first version)
-    int* s_role = reinterpret_cast<int*>(tile + VPB * LD);            // [OMAX]
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS operations of one wave execute in order; this only stops the compiler from moving accesses across
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// SPLIT (used when unit_feat: the normalised row is bounded by 1, so one power-of-two scale fits every voxel): the
+// head GEMM runs as three v_mfma_f32_32x32x16_f16 passes on hi/lo halves (a_lo*w_hi + a_hi*w_lo + a_hi*w_hi, fp32
+// accumulate: ~2^-22 relative per product, the same scheme as conv_mfma) -- 5x fewer matrix-core cycles than the
+// fp32 MFMA chain, which is kept for unnormalised features whose range is unknown.
+template <bool SPLIT>
+__global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int wexp) {
+    extern __shared__ float smem[];                 // [WPB][64][ld] logits, then the per-head tables
+    int* s_role = reinterpret_cast<int*>(smem + WPB * 64 * ld);        // [OMAX]
     int* s_slot = s_role + OMAX;                                       // [OMAX]
-    float** s_map = reinterpret_cast<float**>(s_slot + OMAX);          // [NMAPS]
-    int* s_lut = reinterpret_cast<int*>(s_map + NMAPS);                // [OMAX]
+    int* s_plain = s_slot + OMAX;                                      // [OMAX] non-segmentation outputs, compacted
+    int* s_lut = s_plain + OMAX;                                       // [OMAX]
+    float** s_map = reinterpret_cast<float**>(s_lut + OMAX);           // [NMAPS]
+    __shared__ int s_nplain;
     const int C = p.d.c_feat;
     const int NO = p.d.n_out;
-    const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l32 = lane & 31, lh = lane >> 5;
-    const int nkk = C >> 1;                         // MFMA k-steps (2 channels each)
+    const int half = C >> 1;                        // channels per lane (K of the MFMA chain per half)
     const int nnb = (NO + 31) >> 5;                 // 32-wide output column blocks
 
-    // ---- head weights as B fragments: B[k = lh][n = l32] of step kk, block nb = W[nb*32+l32][2kk+lh]
-    float wfrag[3][CMAX / 2];
+    // ---- head weights as B fragments.  fp32 chain: B[k = lh][n = l32] of step kk, block nb = W[nb*32+l32][lh*half+kk];
+    // split: k-step ks (16 wide), lane slot 8*lh + j  <->  channel lh*half + 8*ks + j  (the same channel order as A)
+    float wfrag[SPLIT ? 1 : 3][SPLIT ? 1 : CMAX / 2];
+    half8t whi[SPLIT ? 3 : 1][SPLIT ? CMAX / 16 : 1], wlo[SPLIT ? 3 : 1][SPLIT ? CMAX / 16 : 1];
     float bias[3];
+    const float wscale = ldexpf(1.f, wexp);
+    const float ascale = 16384.f;                   // |normalised feature| <= 1
+    const float dq = ldexpf(1.f, -(wexp + 14));
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb) {
         const int o = nb * 32 + l32;
         bias[nb] = (nb < nnb && o < NO) ? p.d.head_b[o] : 0.f;
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int kk = 0; kk < CMAX / 2; ++kk)
-            wfrag[nb][kk] = (nb < nnb && o < NO && kk < nkk) ? p.d.head_w[(size_t)o * C + 2 * kk + lh] : 0.f;
+            for (int ks = 0; ks < CMAX / 16; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int kk = 8 * ks + j;
+                    const float w = (nb < nnb && o < NO && kk < half) ? p.d.head_w[(size_t)o * C + lh * half + kk] * wscale : 0.f;
+                    const _Float16 h = (_Float16)w;
+                    whi[nb][ks][j] = h;
+                    wlo[nb][ks][j] = (_Float16)(w - (float)h);
+                }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < CMAX / 2; ++kk)
+                wfrag[nb][kk] = (nb < nnb && o < NO && kk < half) ? p.d.head_w[(size_t)o * C + lh * half + kk] : 0.f;
+        }
     }
-
-    for (int i = threadIdx.x; i < p.d.n_out; i += TPBT) { s_role[i] = p.d.roles[i]; s_slot[i] = p.d.out_slot[i]; }
+    for (int i = threadIdx.x; i < NO; i += TPBT) { s_role[i] = p.d.roles[i]; s_slot[i] = p.d.out_slot[i]; }
     for (int i = threadIdx.x; i < p.n_maps; i += TPBT) s_map[i] = p.maps[i];
     for (int i = threadIdx.x; i < p.d.n_seg; i += TPBT) s_lut[i] = p.d.seg_lut[i];
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int o = 0; o < NO; ++o)
+            if (p.d.roles[o] != BFM_ROLE_SEG) s_plain[n++] = o;
+        s_nplain = n;
+    }
     __syncthreads();
+    const int nplain = s_nplain;
+    float* slab = smem + wave * 64 * ld;            // this wave's [64][ld] logits
+    float* row = slab + lane * ld;
 
-    const int64_t ntiles = (p.nvox + VPB - 1) / VPB;
-    for (int64_t tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
-        const int64_t v0 = tix * VPB;
-        const int nv = (int)min<int64_t>(VPB, p.nvox - v0);
-        __syncthreads();                            // previous tile fully consumed
-        {
-            const int C4 = C >> 2;
-            const float4* src = reinterpret_cast<const float4*>(p.feat + v0 * C);
-            const int n4 = nv * C4;
-            for (int i = t; i < n4; i += TPBT) {
-                float4 q = src[i];
-                int r = i / C4, c = (i - r * C4) * 4;
-                float* dst = tile + r * LD + c;
-                dst[0] = q.x; dst[1] = q.y; dst[2] = q.z; dst[3] = q.w;
-            }
-            // rows beyond nv: zero so the MFMA reads defined values
-            for (int i = t + nv * C; i < VPB * C; i += TPBT) tile[(i / C) * LD + (i % C)] = 0.f;
-        }
-        __syncthreads();
-
-        const bool live = t < nv;
-        float* row = tile + t * LD;
-        if (p.d.unit_feat) {
-            float ss = 0.f;
-            for (int c = 0; c < C; ++c) ss = fmaf(row[c], row[c], ss);
-            const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize eps; one division per voxel
-            for (int c = 0; c < C; ++c) row[c] = row[c] * inv;
-        }
-        __syncthreads();
-
-        if (p.feat_norm) {                                    // optional: normalised features, coalesced
-            const int C4 = C >> 2;
-            float4* dst = reinterpret_cast<float4*>(p.feat_norm + v0 * C);
-            const int n4 = nv * C4;
-            for (int i = t; i < n4; i += TPBT) {
-                int r = i / C4, c = (i - r * C4) * 4;
-                const float* s = tile + r * LD + c;
-                dst[i] = make_float4(s[0], s[1], s[2], s[3]);
-            }
-        }
-
-        // ---- head GEMM: this wave owns voxel rows [64*wave, 64*wave+64)
-        if (NO > 0) {
+    const int64_t nchunks = (p.nvox + 63) >> 6;
+    for (int64_t cix = (int64_t)blockIdx.x * WPB + wave; cix < nchunks; cix += (int64_t)gridDim.x * WPB) {
+        const int64_t v0 = cix << 6;
+        const int nv = (int)min<int64_t>(64, p.nvox - v0);
+#pragma unroll 1
+        for (int mb = 0; mb < 2; ++mb) {
+            const int r = mb * 32 + l32;            // this lane's voxel row inside the chunk
+            const bool rlive = r < nv;
+            float av[CMAX / 2];
+            const float4* src = reinterpret_cast<const float4*>(p.feat + (v0 + (rlive ? r : 0)) * C + lh * half);
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const int r0 = wave * 64 + mb * 32;
-                const float* arow = tile + (r0 + l32) * LD + lh;
+            for (int j = 0; j < CMAX / 8; ++j) {
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rlive && 4 * j < half) q = src[j];
+                av[4 * j] = q.x; av[4 * j + 1] = q.y; av[4 * j + 2] = q.z; av[4 * j + 3] = q.w;
+            }
+            if (p.d.unit_feat) {
+                float ss = 0.f;
+#pragma unroll
+                for (int c = 0; c < CMAX / 2; ++c) ss = fmaf(av[c], av[c], ss);
+                ss += __shfl_xor(ss, 32);
+                const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);   // F.normalize eps; one division per voxel
+#pragma unroll
+                for (int c = 0; c < CMAX / 2; ++c) av[c] = av[c] * inv;
+            }
+            if (p.feat_norm && rlive) {               // optional: normalised features
+                float4* dst = reinterpret_cast<float4*>(p.feat_norm + (v0 + r) * C + lh * half);
+#pragma unroll
+                for (int j = 0; j < CMAX / 8; ++j)
+                    if (4 * j < half) dst[j] = make_float4(av[4 * j], av[4 * j + 1], av[4 * j + 2], av[4 * j + 3]);
+            }
+            if (NO > 0) {
                 floatx16 acc[3];
 #pragma unroll
                 for (int nb = 0; nb < 3; ++nb)
 #pragma unroll
                     for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+                if constexpr (SPLIT) {
 #pragma unroll
-                for (int kk = 0; kk < CMAX / 2; ++kk) {
-                    if (kk < nkk) {
-                        const float a = arow[2 * kk];
+                    for (int ks = 0; ks < CMAX / 16; ++ks) {
+                        if (8 * ks < half) {
+                            half8t ahi, alo;
 #pragma unroll
-                        for (int nb = 0; nb < 3; ++nb)
-                            if (nb < nnb)
-                                acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wfrag[nb][kk], acc[nb], 0, 0, 0);
+                            for (int j = 0; j < 8; ++j) {
+                                const float a = av[8 * ks + j] * ascale;
+                                const _Float16 h = (_Float16)a;
+                                ahi[j] = h;
+                                alo[j] = (_Float16)(a - (float)h);
+                            }
+#pragma unroll
+                            for (int nb = 0; nb < 3; ++nb)
+                                if (nb < nnb) {
+                                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, whi[nb][ks], acc[nb], 0, 0, 0);
+                                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wlo[nb][ks], acc[nb], 0, 0, 0);
+                                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, whi[nb][ks], acc[nb], 0, 0, 0);
+                                }
+                        }
+                    }
+#pragma unroll
+                    for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[nb][i] = acc[nb][i] * dq;
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < CMAX / 2; ++kk) {
+                        if (kk < half) {
+#pragma unroll
+                            for (int nb = 0; nb < 3; ++nb)
+                                if (nb < nnb)
+                                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], wfrag[nb][kk], acc[nb], 0, 0, 0);
+                        }
                     }
                 }
-                // the wave's own rows: all A reads above are consumed before these writes (data dependence)
 #pragma unroll
                 for (int nb = 0; nb < 3; ++nb) {
                     if (nb < nnb) {
@@ -165,30 +204,32 @@ __global__ void __launch_bounds__(TPBT) tail_kernel(TailParams p) {
 #pragma unroll
                         for (int i = 0; i < 16; ++i) {
                             const int rr = (i & 3) + 8 * (i >> 2) + 4 * lh;
-                            if (o < NO) tile[(r0 + rr) * LD + o] = acc[nb][i] + bias[nb];
+                            if (o < NO) slab[(mb * 32 + rr) * ld + o] = acc[nb][i] + bias[nb];
                         }
                     }
                 }
             }
         }
-        __syncthreads();
+        wave_lds_sync();
 
         if (p.raw_out) {                                      // TaskHead.forward only: raw logits, channels-last
             const int n = nv * NO;
             float* dst = p.raw_out + v0 * NO;
-            for (int i = t; i < n; i += TPBT) {
+            for (int i = lane; i < n; i += 64) {
                 int r = i / NO, o = i - r * NO;
-                dst[i] = tile[r * LD + o];
+                dst[i] = slab[r * ld + o];
             }
+            wave_lds_sync();
             continue;
         }
 
-        const int64_t v = v0 + t;
+        const bool live = lane < nv;
+        const int64_t v = v0 + lane;
         float dist[4] = {0.f, 0.f, 0.f, 0.f};
-        // ---- processors + post-processor per role
-        for (int o = 0; o < NO; ++o) {
+        // ---- processors + post-processor per role (segmentation rows are handled below)
+        for (int j = 0; j < nplain; ++j) {
+            const int o = s_plain[j];
             const int role = s_role[o];
-            if (role == BFM_ROLE_SEG) continue;
             const int slot = s_slot[o];
             const float a = row[o];
             float r = a;
@@ -215,8 +256,34 @@ __global__ void __launch_bounds__(TPBT) tail_kernel(TailParams p) {
         if (p.d.n_seg > 0) {
             const int ns = p.d.n_seg;
             float* sl = row + p.d.seg_first;
-            int best = 0;
-            if (live) {
+            if (live && ns <= 64) {
+                // the whole logit row in registers: one batch of LDS reads, then max / exp / sum / argmax without
+                // a load in any dependence chain (padded entries are -inf -> exp 0, never the maximum)
+                float sv[64];
+#pragma unroll
+                for (int s = 0; s < 64; ++s) sv[s] = s < ns ? sl[s] : -INFINITY;
+                float m = -INFINITY;
+#pragma unroll
+                for (int s = 0; s < 64; ++s) m = fmaxf(m, sv[s]);
+                float sum = 0.f;
+#pragma unroll
+                for (int s = 0; s < 64; ++s) { sv[s] = fast_exp(sv[s] - m); sum += sv[s]; }
+                const float rs = 1.f / sum;
+                float bp = -1.f;
+                int best = 0;
+#pragma unroll
+                for (int s = 0; s < 64; ++s) {
+                    sv[s] = sv[s] * rs;
+                    if (sv[s] > bp) { bp = sv[s]; best = s; }    // first maximum wins (torch.argmax)
+                }
+                if (p.seg_prob) {
+#pragma unroll
+                    for (int s = 0; s < 64; ++s)
+                        if (s < ns) sl[s] = sv[s];
+                }
+                if (p.label) p.label[v] = (int64_t)s_lut[best];
+            } else if (live) {
+                int best = 0;
                 float m = -INFINITY;
                 for (int s = 0; s < ns; ++s) m = fmaxf(m, sl[s]);
                 float sum = 0.f;
@@ -231,15 +298,16 @@ __global__ void __launch_bounds__(TPBT) tail_kernel(TailParams p) {
                 if (p.label) p.label[v] = (int64_t)s_lut[best];
             }
             if (p.seg_prob) {
-                __syncthreads();
+                wave_lds_sync();
                 const int n = nv * ns;
                 float* dst = p.seg_prob + v0 * ns;
-                for (int i = t; i < n; i += TPBT) {
-                    int r = i / ns, s = i - r * ns;
-                    dst[i] = tile[r * LD + p.d.seg_first + s];
+                for (int i = lane; i < n; i += 64) {
+                    int r = i / ns, s2 = i - r * ns;
+                    dst[i] = slab[r * ld + p.d.seg_first + s2];
                 }
             }
         }
+        wave_lds_sync();                                      // slab fully consumed before the next chunk's logits
     }
 }
 
@@ -253,7 +321,7 @@ extern "C" int bfm_tail_heads(const float* feat, const float* input, int64_t nvo
     if (!maps && !raw_out && !feat_norm) return BFM_E_ARG;
     if (desc->n_out < 0 || desc->n_out > OMAX || (desc->n_out > 0 && !maps && !raw_out)) return BFM_E_SHAPE;
     if (desc->n_seg > 0 && (desc->seg_first < 0 || desc->seg_first + desc->n_seg > desc->n_out)) return BFM_E_SHAPE;
-    if (desc->c_feat <= 0 || desc->c_feat > CMAX || desc->c_feat % 4 != 0) return BFM_E_SHAPE;
+    if (desc->c_feat <= 0 || desc->c_feat > CMAX || desc->c_feat % 8 != 0) return BFM_E_SHAPE;
     if (desc->n_seg < 0 || (desc->n_seg > 0 && !desc->seg_lut)) return BFM_E_SHAPE;
     if (desc->n_dist != 0 && desc->n_dist != 2 && desc->n_dist != 4) return BFM_E_SHAPE;
     if (reinterpret_cast<uintptr_t>(feat) & 15 || (feat_norm && (reinterpret_cast<uintptr_t>(feat_norm) & 15)))
@@ -263,9 +331,30 @@ extern "C" int bfm_tail_heads(const float* feat, const float* input, int64_t nvo
     for (int o = 0; o < desc->n_out; ++o) (void)o;
     if (maps && (desc->slot_high_res >= n_maps || desc->slot_fake_cortical >= n_maps)) return BFM_E_SHAPE;
     TailParams p{feat, input, nvox, *desc, feat_norm, maps, seg_prob, label, raw_out, n_maps};
-    int64_t nb = bfm_cdiv64(nvox, VPB);
-    if (nb > 256 * 6) nb = 256 * 6;                  // persistent: the weight fragments are loaded once per block
-    const size_t smem = (size_t)VPB * LD * sizeof(float) + (size_t)3 * OMAX * sizeof(int) + (size_t)NMAPS * sizeof(float*);
-    hipLaunchKernelGGL(tail_kernel, dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p);
+    const int ld = (desc->n_out > 0 ? desc->n_out : 1) | 1;        // odd row stride: conflict-free column access
+    int64_t nb = bfm_cdiv64(bfm_cdiv64(nvox, 64), WPB);
+    if (nb > 256 * 2) nb = 256 * 2;                  // persistent: the weight fragments are loaded once per wave
+    const size_t smem = (size_t)WPB * 64 * ld * sizeof(float) + (size_t)4 * OMAX * sizeof(int) +
+                        (size_t)NMAPS * sizeof(float*);
+    if (smem > 160 * 1024) return BFM_E_SHAPE;
+    if (smem > 64 * 1024 &&
+        (hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<true>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<false>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess))
+        return BFM_E_LAUNCH;
+    // split-f16 path: weights scaled so that max|w| * 2^wexp < 2^15 (head_wmax from the descriptor)
+    int wexp = 0;
+    const bool split = desc->unit_feat && desc->head_wmax > 0.f && desc->head_wmax < INFINITY && desc->c_feat % 16 == 0;
+    if (split) {
+        int ex;
+        (void)frexpf(desc->head_wmax, &ex);
+        wexp = 14 - ex;
+        wexp = wexp > 60 ? 60 : (wexp < -60 ? -60 : wexp);
+    }
+    if (split)
+        hipLaunchKernelGGL(tail_kernel<true>, dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, wexp);
+    else
+        hipLaunchKernelGGL(tail_kernel<false>, dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, 0);
     return bfm_launch_status();
 }

@@ -399,7 +399,8 @@ class Tail:
         self.desc = L.TailDesc(self.n_out, c_feat, self.head_w.data_ptr(), self.head_b.data_ptr(),
                                self.roles.data_ptr(), self.out_slot.data_ptr(), seg[0], seg[1],
                                self.seg_lut.data_ptr(), dist[1], dist[0], float(max_surf_distance),
-                               1 if eng.unit_feat else 0, self.slot_high_res, self.slot_fake, len(self.map_names))
+                               1 if eng.unit_feat else 0, self.slot_high_res, self.slot_fake, len(self.map_names),
+                               float(self.head_w.abs().max().item()) if self.n_out else 0.0)
 
     def run(self, feat_cl, dims, input_cl=None, want_feat=True, want_seg=True):
         """Fused tail.  feat_cl: (D,H,W,c_feat) raw last decoder output.

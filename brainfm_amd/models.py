@@ -245,8 +245,8 @@ def normalize_cl(eng, feat_cl, dims):
     """F.normalize(dim=1) alone (tail kernel with no heads)."""
     D, H, W = dims
     c = feat_cl.shape[-1]
-    if c > 64 or c % 4:
-        raise L.BfmError("unit_feat needs c_feat <= 64 and a multiple of 4 (got %d)" % c)
+    if c > 64 or c % 8:
+        raise L.BfmError("unit_feat needs c_feat <= 64 and a multiple of 8 (got %d)" % c)
     z = torch.zeros(1, dtype=torch.float32, device=feat_cl.device)
     zi = torch.zeros(1, dtype=torch.int32, device=feat_cl.device)
     desc = L.TailDesc(0, c, z.data_ptr(), z.data_ptr(), zi.data_ptr(), zi.data_ptr(), 0, 0, zi.data_ptr(), 0, 0, 0.0,

@@ -141,6 +141,8 @@ typedef struct {
     int slot_high_res;          /* maps slot for residual+input, -1 = none */
     int slot_fake_cortical;     /* maps slot, -1 = none */
     int n_maps;                 /* length of the `maps` pointer array (every out_slot / slot_* is < n_maps) */
+    float head_wmax;            /* max |head_w| (host knows it): > 0 with unit_feat selects the split-f16 matrix-core
+                                   path (fp32-grade, like conv3x3x3_mfma); 0 keeps the exact fp32 MFMA chain */
 } bfm_tail_desc_t;
 
 int bfm_tail_heads(const float* feat, const float* input /*[nvox], may be NULL*/, int64_t nvox,
