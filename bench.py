@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--passes", type=int, default=3, help="3 = fp32-grade split-f16 MFMA (parity mode), 1 = fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-path", action="store_true",
+                    help="run the multi-GPU code path (pack, RCCL gather, root accumulation) even with one rank")
     ap.add_argument("--no-graphs", action="store_true", help="submit every kernel from python instead of hipGraph replay")
     ap.add_argument("--roofline-reps", type=int, default=3,
                     help="back-to-back launches per HIP-event bracket in the instrumented conv pass")
@@ -93,8 +95,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.dist_path
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     n = args.size
@@ -108,7 +114,7 @@ def main():
     sess.use_graphs = not args.no_graphs
 
     def step():
-        if world > 1:
+        if use_dist:
             return TU.tiled_inference_distributed(full, sess, stride, win)
         return TU.tiled_inference(full, sess, stride, win)
 
@@ -117,13 +123,13 @@ def main():
         TU.prepare_tile_graphs(full, sess, stride, win, world=world, rank=rank)   # setup, like weight packing
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -187,7 +193,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

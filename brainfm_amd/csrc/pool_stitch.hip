@@ -76,13 +76,37 @@ __global__ void stitch_multi_kernel(const float* __restrict__ maps, int64_t map_
         int64_t t = i / tw;
         int y = (int)(t % th);
         int z = (int)(t / th);
-        const float m = tin[i] != 0.f ? 1.f : 0.f;
         const int64_t o = ((int64_t)(z0 + z) * H + (y0 + y)) * W + (x0 + x);
+        if (tin == nullptr) {                       // rows already masked and float typed (shipped by a peer rank)
+            for (int k = 0; k < K; ++k) full[(int64_t)k * vol + o] += maps[(int64_t)sel[k] * map_stride + i];
+            continue;
+        }
+        const float m = tin[i] != 0.f ? 1.f : 0.f;
         for (int k = 0; k < K; ++k) {
             const int r = sel[k];
             const float v = r < 0 ? (float)(int)((float)label[i] * m) : maps[(int64_t)r * map_stride + i] * m;
             full[(int64_t)k * vol + o] += v;
         }
+    }
+}
+
+// all K stitched keys of one tile, masked and float typed, packed [K][n]: what a rank ships to rank 0
+__global__ void pack_multi_kernel(const float* __restrict__ maps, int64_t map_stride, const int32_t* __restrict__ sel,
+                                  int K, const int64_t* __restrict__ label, const float* __restrict__ tin, int64_t n,
+                                  float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float m = tin[i] != 0.f ? 1.f : 0.f;
+        for (int k = 0; k < K; ++k) {
+            const int r = sel[k];
+            out[(int64_t)k * n + i] = r < 0 ? (float)(int)((float)label[i] * m) : maps[(int64_t)r * map_stride + i] * m;
+        }
+    }
+}
+
+__global__ void divide_multi_kernel(float* __restrict__ full, const float* __restrict__ cnt, int64_t vol, int K) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < vol; i += (int64_t)gridDim.x * blockDim.x) {
+        const float c = cnt[i];
+        for (int k = 0; k < K; ++k) full[(int64_t)k * vol + i] = full[(int64_t)k * vol + i] / c;
     }
 }
 
@@ -145,7 +169,7 @@ extern "C" int bfm_stitch_accumulate_multi(const float* maps, int64_t map_stride
                                            const int64_t* tile_label, const float* tile_input, int td, int th, int tw,
                                            float* full, int D, int H, int W, int z0, int y0, int x0,
                                            bfm_stream_t stream) {
-    if (!maps || !sel || K <= 0 || !tile_input || !full || td <= 0 || th <= 0 || tw <= 0) return BFM_E_ARG;
+    if (!maps || !sel || K <= 0 || !full || td <= 0 || th <= 0 || tw <= 0) return BFM_E_ARG;
     if (z0 < 0 || y0 < 0 || x0 < 0 || z0 + td > D || y0 + th > H || x0 + tw > W) return BFM_E_SHAPE;
     int64_t n = (int64_t)td * th * tw;
     hipLaunchKernelGGL(stitch_multi_kernel, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), maps, map_stride, sel, K,
@@ -174,5 +198,20 @@ extern "C" int bfm_tile_count_add(float* cnt, int D, int H, int W, int z0, int z
 extern "C" int bfm_divide_by_count(float* full, const float* cnt, int64_t n, bfm_stream_t stream) {
     if (!full || !cnt || n <= 0) return BFM_E_ARG;
     hipLaunchKernelGGL(divide_kernel, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), full, cnt, n);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_pack_tile_multi(const float* maps, int64_t map_stride, const int32_t* sel, int K,
+                                   const int64_t* tile_label, const float* tile_input, int64_t n, float* out,
+                                   bfm_stream_t stream) {
+    if (!maps || !sel || K <= 0 || !tile_input || !out || n <= 0) return BFM_E_ARG;
+    hipLaunchKernelGGL(pack_multi_kernel, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), maps, map_stride, sel, K,
+                       tile_label, tile_input, n, out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_divide_by_count_multi(float* full, const float* cnt, int64_t vol, int K, bfm_stream_t stream) {
+    if (!full || !cnt || vol <= 0 || K <= 0) return BFM_E_ARG;
+    hipLaunchKernelGGL(divide_multi_kernel, dim3(grid_for(vol)), dim3(256), 0, bfm_s(stream), full, cnt, vol, K);
     return bfm_launch_status();
 }

@@ -178,6 +178,12 @@ class InferenceSession:
         self._graphs = {}
         self._graph_pool = None
 
+    def stitch_keys(self):
+        """The keys tiled inference stitches for this head set, in STITCH_KEYS order."""
+        tail = self.model.head.tail(self.engine)
+        names = set(tail.map_names)
+        return [k for k in STITCH_KEYS if k in names or (k == "label" and tail.desc.n_seg > 0)]
+
     def graph_tile(self, im):
         """Run one tile through backbone + tail via a captured hipGraph for its shape.
         Returns what _run_tile(raw=True) returns; the buffers are static per shape and are overwritten by the
@@ -334,10 +340,8 @@ def tiled_inference(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 1
                                                 x1 - x0, y1 - y0, z1 - z0, L.ptr(acc_buf), shape[0], shape[1],
                                                 shape[2], x0, y0, z0, L.stream_ptr()), "stitch_multi")
     n = shape[0] * shape[1] * shape[2]
-    acc = OrderedDict()
-    for j, k in enumerate(keys):
-        L.check(lib.bfm_divide_by_count(L.ptr(acc_buf[j]), L.ptr(cnt), n, L.stream_ptr()), "divide_by_count")
-        acc[k] = acc_buf[j]
+    L.check(lib.bfm_divide_by_count_multi(L.ptr(acc_buf), L.ptr(cnt), n, len(keys), L.stream_ptr()), "divide_by_count")
+    acc = OrderedDict((k, acc_buf[j]) for j, k in enumerate(keys))
     return acc, ranges, cnt
 
 
@@ -375,35 +379,46 @@ def _run_tile(session, im, raw=False):
 
 
 class HipStitchOps:
-    """Device-side pack / accumulate used by the multi-GPU path (HIP kernels)."""
+    """Device-side pack / accumulate used by the multi-GPU path (HIP kernels, one launch per tile each)."""
 
     def __init__(self, session):
         self.session = session
         self.lib = L.load()
+        self._sel = {}
 
-    def run_tile(self, im):
+    def _identity(self, k, dev):
+        if (k, dev) not in self._sel:
+            self._sel[(k, dev)] = torch.arange(k, dtype=torch.int32, device=dev)
+        return self._sel[(k, dev)]
+
+    def run_tile(self, im, out=None):
+        """Masked, float typed [K][n] rows of one tile (written into ``out`` when given: the send buffer)."""
         if self.session.use_graphs:
             maps_buf, names, label, x_cl = self.session.graph_tile(im)
-            maps = OrderedDict((nm, maps_buf[i]) for i, nm in enumerate(names))
         else:
-            maps, label, x_cl = _run_tile(self.session, im)
-        keys = [k for k in STITCH_KEYS if k in maps or (k == "label" and label is not None)]
+            maps_buf, names, label, x_cl = _run_tile(self.session, im, raw=True)
+        keys = [k for k in STITCH_KEYS if k in names or (k == "label" and label is not None)]
+        skey = (tuple(names), label is not None)
+        if skey not in self._sel:
+            self._sel[skey] = torch.tensor([names.index(k) if k != "label" else -1 for k in keys], dtype=torch.int32,
+                                           device=x_cl.device)
         n = x_cl.numel()
-        rows = torch.empty((len(keys), n), dtype=torch.float32, device=x_cl.device)
-        for j, k in enumerate(keys):
-            L.check(self.lib.bfm_mask_tile(None if k == "label" else L.ptr(maps[k]),
-                                           L.ptr(label) if k == "label" else None, L.ptr(x_cl), n, L.ptr(rows[j]),
-                                           L.stream_ptr()), "mask_tile")
-        return keys, rows
+        rows = out if out is not None else torch.empty(len(keys) * n, dtype=torch.float32, device=x_cl.device)
+        L.check(self.lib.bfm_pack_tile_multi(L.ptr(maps_buf), n, L.ptr(self._sel[skey]), len(keys), L.ptr(label),
+                                             L.ptr(x_cl), n, L.ptr(rows), L.stream_ptr()), "pack_tile_multi")
+        return keys, rows.view(len(keys), n)
 
-    def add(self, acc, rows_j, rng, shape):
+    def add_all(self, acc_buf, rows, rng, shape):
+        """acc_buf [K][D,H,W] += rows [K][n] of one tile (already masked)."""
         (x0, x1), (y0, y1), (z0, z1) = rng
-        rows_j = rows_j.contiguous()
-        L.check(self.lib.bfm_stitch_accumulate(L.ptr(rows_j), None, None, x1 - x0, y1 - y0, z1 - z0, L.ptr(acc),
-                                               shape[0], shape[1], shape[2], x0, y0, z0, L.stream_ptr()), "stitch")
+        k, n = rows.shape
+        L.check(self.lib.bfm_stitch_accumulate_multi(L.ptr(rows), n, L.ptr(self._identity(k, rows.device)), k, None,
+                                                     None, x1 - x0, y1 - y0, z1 - z0, L.ptr(acc_buf), shape[0],
+                                                     shape[1], shape[2], x0, y0, z0, L.stream_ptr()), "stitch_multi")
 
-    def finalize(self, acc, cnt):
-        L.check(self.lib.bfm_divide_by_count(L.ptr(acc), L.ptr(cnt), acc.numel(), L.stream_ptr()), "divide")
+    def finalize_all(self, acc_buf, cnt):
+        L.check(self.lib.bfm_divide_by_count_multi(L.ptr(acc_buf), L.ptr(cnt), cnt.numel(), acc_buf.shape[0],
+                                                   L.stream_ptr()), "divide_multi")
 
 
 @torch.no_grad()
@@ -426,37 +441,55 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
     owner = assign_tiles(ranges, world)
     mine = [i for i in range(len(ranges)) if owner[i] == rank]
     dev = full_im.device
-    packed, keys = [], None
+    direct = hasattr(ops, "add_all")                           # HIP ops write straight into the send buffer
+    nkeys = getattr(ops, "n_keys", None)
+    if nkeys is None and session is not None:
+        nkeys = len(session.stitch_keys())
+    vox = [sum(tile_cost(ranges[i]) for i in range(len(ranges)) if owner[i] == r) for r in range(world)]
+    packed, keys, buf, off = [], None, None, 0
+    if direct and nkeys is not None:
+        buf = torch.zeros(max(max(vox) * nkeys, 1), dtype=torch.float32, device=dev)
     for i in mine:
         (x0, x1), (y0, y1), (z0, z1) = ranges[i]
-        keys, rows = ops.run_tile(full_im[:, :, x0:x1, y0:y1, z0:z1])
-        packed.append(rows.reshape(-1))
-    nk = torch.tensor([0 if keys is None else len(keys)], device=dev)
-    dist.all_reduce(nk, op=dist.ReduceOp.MAX, group=group)
-    nkeys = int(nk.item())
-    sizes = [sum(tile_cost(ranges[i]) for i in range(len(ranges)) if owner[i] == r) * nkeys for r in range(world)]
-    pad = max(sizes) if sizes else 0
-    buf = torch.zeros(max(pad, 1), dtype=torch.float32, device=dev)
-    if packed:
-        flat = torch.cat(packed)
-        buf[:flat.numel()] = flat
+        im = full_im[:, :, x0:x1, y0:y1, z0:z1]
+        if buf is not None:
+            n = tile_cost(ranges[i]) * nkeys
+            keys, _ = ops.run_tile(im, out=buf[off:off + n])
+            off += n
+        else:
+            keys, rows = ops.run_tile(im)
+            packed.append(rows.reshape(-1))
+    if buf is None:
+        nk = torch.tensor([0 if keys is None else len(keys)], device=dev)
+        dist.all_reduce(nk, op=dist.ReduceOp.MAX, group=group)
+        nkeys = int(nk.item())
+        buf = torch.zeros(max(max(vox) * nkeys, 1), dtype=torch.float32, device=dev)
+        if packed:
+            flat = torch.cat(packed)
+            buf[:flat.numel()] = flat
     gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
     dist.gather(buf, gathered, dst=0, group=group)
     if rank != 0:
         return None, ranges, None
     if keys is None:
-        keys = [k for k in STITCH_KEYS][:nkeys]
-    acc = OrderedDict((k, torch.zeros(shape, dtype=torch.float32, device=dev)) for k in keys)
+        keys = (session.stitch_keys() if session is not None else [k for k in STITCH_KEYS])[:nkeys]
+    acc_buf = torch.zeros((nkeys,) + shape, dtype=torch.float32, device=dev)
     offs = [0] * world
     for i, rng in enumerate(ranges):                          # reference tile order
         r = owner[i]
-        (x0, x1), (y0, y1), (z0, z1) = rng
         nv = tile_cost(rng)
         rows = gathered[r][offs[r]:offs[r] + nv * nkeys].reshape(nkeys, nv)
         offs[r] += nv * nkeys
-        for j, k in enumerate(keys):
-            ops.add(acc[k], rows[j], rng, shape)
+        if direct:
+            ops.add_all(acc_buf, rows, rng, shape)
+        else:
+            for j in range(nkeys):
+                ops.add(acc_buf[j], rows[j], rng, shape)
     cnt = count_volume(shape, ranges, dev)
-    for k in keys:
-        ops.finalize(acc[k], cnt)
+    if direct:
+        ops.finalize_all(acc_buf, cnt)
+    else:
+        for j in range(nkeys):
+            ops.finalize(acc_buf[j], cnt)
+    acc = OrderedDict((k, acc_buf[j]) for j, k in enumerate(keys))
     return acc, ranges, cnt

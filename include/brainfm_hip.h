@@ -161,7 +161,8 @@ int bfm_stitch_accumulate(const float* tile, const int64_t* tile_label, const fl
                           int td, int th, int tw, float* full, int D, int H, int W,
                           int z0, int y0, int x0, bfm_stream_t stream);
 /* All K stitched keys of one tile in one launch: maps [n_maps][td*th*tw] (row stride map_stride), sel[k] = map
- * row feeding key k or -1 for the int64 label, full [K][D*H*W]. */
+ * row feeding key k or -1 for the int64 label, full [K][D*H*W].  tile_input == NULL: the rows are already masked
+ * and float typed (what bfm_pack_tile_multi produced on a peer rank); sel must then be >= 0. */
 int bfm_stitch_accumulate_multi(const float* maps, int64_t map_stride, const int32_t* sel, int K,
                                 const int64_t* tile_label, const float* tile_input, int td, int th, int tw, float* full,
                                 int D, int H, int W, int z0, int y0, int x0, bfm_stream_t stream);
@@ -172,6 +173,11 @@ int bfm_mask_tile(const float* tile, const int64_t* tile_label, const float* til
 int bfm_tile_count_add(float* cnt, int D, int H, int W, int z0, int z1, int y0, int y1, int x0, int x1,
                        bfm_stream_t stream);
 int bfm_divide_by_count(float* full, const float* cnt, int64_t n, bfm_stream_t stream);
+/* the K keys of one tile, masked (x tile_input != 0) and float typed, packed [K][n]: the multi-GPU shipping form */
+int bfm_pack_tile_multi(const float* maps, int64_t map_stride, const int32_t* sel, int K, const int64_t* tile_label,
+                        const float* tile_input, int64_t n, float* out, bfm_stream_t stream);
+/* full [K][vol] /= cnt [vol], one launch */
+int bfm_divide_by_count_multi(float* full, const float* cnt, int64_t vol, int K, bfm_stream_t stream);
 
 /* ------------------------------------------------------------ elementwise
  * Per-voxel helpers for the stand-alone processors / post-processor

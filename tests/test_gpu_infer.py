@@ -210,6 +210,36 @@ def test_tiled_graph_replay_equals_eager_bit_for_bit():
             assert torch.equal(acc[k], ref[k]), k
 
 
+def test_distributed_path_one_rank_rccl_equals_single_gpu_path():
+    """The multi-GPU code path (pack -> RCCL gather -> root accumulation in reference tile order) on a one-rank
+    group must reproduce tiled_inference bit for bit (the 2-rank ordering logic is covered on CPU with gloo)."""
+    import socket
+    import torch.distributed as dist
+    from brainfm_amd import test_utils as TU
+    d = load_npz("infer_tiled.npz")
+    f_maps, levels, groups, stride, win = [int(v) for v in d["cfg"]]
+    s = _session(d, f_maps=f_maps, levels=levels)
+    full = torch.from_numpy(d["full"]).to(_dev())
+    ref, _, _ = TU.tiled_inference(full, s, [stride] * 3, [win] * 3, graphs=False)
+    ref = {k: v.clone() for k, v in ref.items()}
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=_dev())
+    try:
+        for graphs in (False, True):
+            s.use_graphs = graphs
+            acc, _, cnt = TU.tiled_inference_distributed(full, s, [stride] * 3, [win] * 3)
+            assert list(acc.keys()) == list(ref.keys())
+            for k in ref:
+                assert torch.equal(acc[k], ref[k]), (k, graphs)
+    finally:
+        s.use_graphs = False
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("passes,tol", [(3, TOL_NET), (1, 5e-2)])
 def test_mfma_network_vs_oracle(passes, tol):
     """64-wide 3-level net (all convs but the stem on MFMA), volume with an exact-zero background,
