@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--passes", type=int, default=3, help="3 = fp32-grade split-f16 MFMA (parity mode), 1 = fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layer-table", default=None, help="write the per-layer conv timing table of the instrumented pass here")
     ap.add_argument("--dist-path", action="store_true",
                     help="run the multi-GPU code path (pack, RCCL gather, root accumulation) even with one rank")
     ap.add_argument("--no-graphs", action="store_true", help="submit every kernel from python instead of hipGraph replay")
@@ -153,9 +154,24 @@ def main():
         sess.use_graphs = g
         prof = eng.prof
         eng.prof = None
-    k_ms = sum(a.elapsed_time(b) / r for a, b, _, _, r in prof)
-    k_fl = sum(f for _, _, f, _, _ in prof)
-    k_by = sum(b for _, _, _, b, _ in prof)
+    k_ms = sum(p[0].elapsed_time(p[1]) / p[4] for p in prof)
+    k_fl = sum(p[2] for p in prof)
+    k_by = sum(p[3] for p in prof)
+    if args.layer_table and rank == 0:
+        tab = {}
+        for p in prof:
+            e = tab.setdefault(p[5], [0, 0.0, 0.0])
+            e[0] += 1
+            e[1] += p[0].elapsed_time(p[1]) / p[4]
+            e[2] += p[2]
+        with open(args.layer_table, "w") as f:
+            f.write("# conv launches of one step grouped by (layer, Cin, Cout, dims, plan[WM,WN,TD,TH,TW,splitk,ver,0])\n")
+            f.write("%-12s %5s %5s %-16s %-28s %5s %10s %8s %7s\n" % ("layer", "cin", "cout", "dims", "plan", "n", "ms_total",
+                                                                  "us_avg", "TF/s"))
+            for key, (cnt, ms, fl) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
+                f.write("%-12s %5d %5d %-16s %-28s %5d %10.3f %8.1f %7.1f\n" % (
+                    key[0], key[1], key[2], "x".join(map(str, key[3])), ",".join(map(str, key[4])), cnt, ms,
+                    ms * 1e3 / cnt, fl / (ms * 1e-3) / 1e12))
     agg = torch.tensor([k_ms, k_fl, k_by, float(len(prof))], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(agg)

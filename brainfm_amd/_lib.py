@@ -62,6 +62,9 @@ SIGNATURES = {
     "bfm_pack_conv_weights_mfma16_bytes": (_Z, [_I, _I]),
     "bfm_pack_conv_weights_mfma16": (_I, [_P, _I, _I, _F, _P, C.POINTER(_I), _P]),
     "bfm_conv3x3x3_direct": (_I, [_P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _P, _I, _F, _P, _P]),
+    "bfm_pack_conv_weights_upfold_bytes": (C.c_size_t, [_I, _I, _I]),
+    "bfm_pack_conv_weights_upfold": (_I, [_P, _I, _I, _I, _F, _I, _P, _P, _P]),
+    "bfm_conv3x3x3_upfold": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P]),
     "bfm_conv3x3x3_stem": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
     "bfm_conv3x3x3_mfma_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
     "bfm_conv3x3x3_mfma_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),

@@ -53,6 +53,7 @@ struct ConvParams {
     int nvox_lds, plane_stride;     // LDS geometry (plane_stride in bytes)
     int tw_shift, thw_shift;        // >=0 when TW / TH*TW are powers of two
     int64_t split_stride;           // elements between split-K slabs
+    int accum;                      // 1: add what `out` already holds (the up-folded low-res half) before LeakyReLU
 };
 
 // lane (= MFMA row) -> position inside the 32-row block such that every
@@ -182,6 +183,27 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(const ConvParams p)
             for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
 
     const int ntw = nt * WN + wn;                        // 64-column tile of this wave
+    if (p.accum && p.splitk == 1) {
+        // accumulate mode: start from what `out` holds (the up-folded half), in the accumulator's scaled domain; the
+        // loads are issued here so that their latency hides under the K loop instead of the epilogue
+        const float inv_dq = ldexpf(1.0f, aexp + p.wexp);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rr = (i >> 2) * 8 + khalf * 4 + (i & 3);
+                const int q = wm * 64 + mb * 32 + row_perm(rr);
+                if (q >= boxN) continue;
+                int d, h, w;
+                box_coords(p, q, d, h, w);
+                const int gz = z0 + d, gy = y0 + h, gx = x0 + w;
+                if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
+                const float* orow = p.out + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + ntw * 64 + l32;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) acc[mb][nb][i] = orow[nb * 32] * inv_dq;
+            }
+        }
+    }
     const int kc_begin = split * p.kc_per_split;
     const int kc_end = min(p.KCN, kc_begin + p.kc_per_split);
 
@@ -312,7 +334,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(const ConvParams p)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
                 float r = acc[mb][nb][i] * dq;
-                if (final_out) r = r >= 0.f ? r : r * p.slope;
+                if (final_out) r = r >= 0.f ? r : r * p.slope;     // accumulate mode preloaded `out` into acc
                 orow[nb * 32] = r;
             }
         }
@@ -421,6 +443,24 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma16(const ConvParams 
             for (int i = 0; i < 4; ++i) acc[rb][cb][i] = 0.f;
 
     const int ntw = nt * WN + wn;
+    if (p.accum && p.splitk == 1) {                      // accumulate mode: see conv_mfma
+        const float inv_dq = ldexpf(1.0f, aexp + p.wexp);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = wm * 64 + rb * 16 + kg * 4 + i;
+                if (q >= boxN) continue;
+                int d, h, w;
+                box_coords(p, q, d, h, w);
+                const int gz = z0 + d, gy = y0 + h, gx = x0 + w;
+                if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
+                const float* orow = p.out + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + ntw * 64 + l16;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) acc[rb][cb][i] = orow[cb * 16] * inv_dq;
+            }
+        }
+    }
     const int kc_begin = split * p.kc_per_split;
     const int kc_end = min(p.KCN, kc_begin + p.kc_per_split);
     const int b_base = 2 * NPL * p.plane_stride;
@@ -546,7 +586,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma16(const ConvParams 
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 float r = acc[rb][cb][i] * dq;
-                if (final_out) r = r >= 0.f ? r : r * p.slope;
+                if (final_out) r = r >= 0.f ? r : r * p.slope;     // accumulate mode preloaded `out` into acc
                 orow[cb * 16] = r;
             }
         }
@@ -886,7 +926,10 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_ws(const ConvParams p) {
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) {
                         float r = acc[mb][nb][i] * dq;
-                        if (final_out) r = r >= 0.f ? r : r * p.slope;
+                        if (final_out) {
+                            if (p.accum) r = r + orow[nb * 32];
+                            r = r >= 0.f ? r : r * p.slope;
+                        }
                         orow[nb * 32] = r;
                     }
                 }
@@ -897,13 +940,17 @@ __global__ void __launch_bounds__(512, 2) conv_mfma_ws(const ConvParams p) {
 
 // sum split-K slabs in slab order, then LeakyReLU
 __global__ void splitk_reduce(const float* __restrict__ ws, int splitk, int64_t n4, int64_t stride4, float slope,
-                              float* __restrict__ out) {
+                              int accum, float* __restrict__ out) {
     const float4* w4 = reinterpret_cast<const float4*>(ws);
     float4* o4 = reinterpret_cast<float4*>(out);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 s = w4[i];
         for (int k = 1; k < splitk; ++k) {
             float4 t = w4[i + k * stride4];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        if (accum) {
+            float4 t = o4[i];
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
         s.x = s.x >= 0.f ? s.x : s.x * slope; s.y = s.y >= 0.f ? s.y : s.y * slope;
@@ -1126,6 +1173,7 @@ extern "C" int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB
     p.scale = scale; p.shift = shift; p.bound = bound; p.G = G;
     p.wp = reinterpret_cast<const uint4*>(wpacked);
     p.wexp = wexp; p.Cout = Cout; p.slope = slope;
+    p.accum = (cfg && (cfg[7] & 1)) ? 1 : 0;
     p.TD = hp.TD; p.TH = hp.TH; p.TW = hp.TW; p.HT = hp.TH + 2; p.WT = hp.TW + 2;
     const int nTz = bfm_cdiv(D, hp.TD);
     p.nTy = bfm_cdiv(H, hp.TH); p.nTx = bfm_cdiv(W, hp.TW);
@@ -1183,7 +1231,7 @@ extern "C" int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB
         int64_t n4 = nvox * Cout / 4;
         int nb = (int)std::min<int64_t>(2048, bfm_cdiv64(n4, 256));
         hipLaunchKernelGGL(splitk_reduce, dim3(nb), dim3(256), 0, st, static_cast<const float*>(workspace), p.splitk,
-                           n4, p.split_stride / 4, slope, out);
+                           n4, p.split_stride / 4, slope, p.accum, out);
         rc = bfm_launch_status();
     }
     return rc;

@@ -1,0 +1,368 @@
+// The upsampled half of a decoder's first convolution, with the nearest 2x upsample folded into the weights.
+//
+// Decoder._joining (Trainer/models/unet3d/buildingblocks.py:265-276, 361-363) feeds
+// cat((skip, nearest_up_2x(x))) to a 3x3x3 conv.  On the upsampled channels every low-res voxel is seen 8 times,
+// so along each axis the three taps of an output voxel of parity p land on only two low-res voxels:
+//      p = 0:  (i-1, i, i)   -> weights ( w[-1],        w[0] + w[+1] )
+//      p = 1:  (i, i, i+1)   -> weights ( w[-1] + w[0], w[+1]        )
+// (zero padding outside [0, 2n) maps exactly onto low-res indices -1 and n).  Each of the 8 output parity classes
+// is therefore a 2x2x2 convolution over the low-res tensor with pre-summed weights: 8 taps instead of 27 on these
+// channels -- 3.375x fewer matrix-core FLOPs on two thirds of the decoder's input channels -- and the 8x smaller
+// low-res box is what gets staged.  Summing weights first changes rounding at the fp32 epsilon level only.
+//
+// GEMM view: M = low-res voxels (a BDxBHxBW box of 128 per workgroup), N = 8 classes x Cout, K = 8 taps x CB.
+// 8 waves per workgroup, wave = parity class (4x2 blocks of 32x32: 128 rows x 64 couts); the class's weight
+// fragments are private to the wave and stream L2 -> VGPR two taps ahead.  Same split-fp16 numerics as
+// conv3d_mfma.hip (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulate).
+// The result (no activation) is written to the interleaved full-res positions of `out`; the skip half of the
+// convolution then runs through bfm_conv3x3x3_mfma with the accumulate flag (cfg[7] bit 0) and applies LeakyReLU.
+#include "bfm_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int KC = 16;
+constexpr int NTHR = 512;
+
+struct UpParams {
+    const float* B;
+    int CB, d, h, w;                 // low-res tensor (channels-last)
+    const float *scale, *shift;      // GroupNorm affine of the B channels (already offset by CA)
+    const float* bound;
+    int G;
+    const uint4* wp;
+    int wexp, Cout;
+    float* out;                      // [2d][2h][2w][Cout]
+    int BD, BH, BW, HT, WT;          // low-res box and its halo'd extents
+    int bw_shift, bhw_shift;
+    int nTy, nTx, nMt, NT, KCB;
+    int nvox_lds, plane_stride;
+};
+
+__device__ __forceinline__ int row_perm(int l) {        // same lane -> row order as conv_mfma (conflict-free b128)
+    if (l < 4) return l;
+    if (l < 12) return l + 12;
+    if (l < 16) return l - 8;
+    if (l < 20) return l + 8;
+    if (l < 28) return l - 12;
+    return l;
+}
+
+__device__ __forceinline__ void box_coords(const UpParams& p, int q, int& bd, int& bh, int& bw) {
+    bd = q >> p.bhw_shift;
+    const int rem = q & ((1 << p.bhw_shift) - 1);
+    bh = rem >> p.bw_shift;
+    bw = rem & ((1 << p.bw_shift) - 1);
+}
+
+template <int NPASS>
+__global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
+    constexpr int NPL = (NPASS == 3) ? 2 : 1;
+    constexpr int NF = 2 * NPL;                       // weight fragments per tap: 2 column blocks x (hi[, lo])
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int cls = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = output parity class (pz,py,px)
+    const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+    const int l32 = lane & 31, khalf = lane >> 5;
+
+    int bid = blockIdx.x;
+    {
+        const int nblk = p.nMt * p.NT;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = bid / p.NT, nt = bid - mt * p.NT;
+    const int tx = mt % p.nTx;
+    const int ty = (mt / p.nTx) % p.nTy;
+    const int tz = mt / (p.nTx * p.nTy);
+    const int z0 = tz * p.BD, y0 = ty * p.BH, x0 = tx * p.BW;      // low-res box origin
+
+    float bmax = 0.f;
+    for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, p.bound[g]);
+    int aexp = 0;
+    if (bmax > 0.f && bmax < INFINITY) {
+        int ex;
+        (void)frexpf(bmax, &ex);
+        aexp = 14 - ex;
+        aexp = aexp > 60 ? 60 : (aexp < -60 ? -60 : aexp);
+    }
+    const float a_scale = ldexpf(1.0f, aexp);
+    const float dq = ldexpf(1.0f, -(aexp + p.wexp));
+
+    // per-lane A base offsets of the four 32-row blocks: row (bd,bh,bw) of class (pz,py,px), tap (0,0,0) reads the
+    // halo'd box at (bd+pz, bh+py, bw+px)
+    int a_off[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        int bd, bh, bw;
+        box_coords(p, mb * 32 + row_perm(l32), bd, bh, bw);
+        a_off[mb] = (khalf * NPL) * p.plane_stride + (((bd + pz) * p.HT + (bh + py)) * p.WT + (bw + px)) * 16;
+    }
+
+    // staging bookkeeping: element e = tid + it*NTHR -> (halo voxel, channel quad)
+    constexpr int MAX_IT = 4;
+    const int n_el = p.nvox_lds * 4;
+    const int q4 = tid & 3;
+    int off[MAX_IT];
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        const int e = tid + it * NTHR;
+        off[it] = -2;
+        if (e < n_el) {
+            const int vox = e >> 2;
+            const int hz = vox / (p.HT * p.WT);
+            const int rem = vox - hz * (p.HT * p.WT);
+            const int hy = rem / p.WT;
+            const int hx = rem - hy * p.WT;
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+            off[it] = -1;
+            if (gz >= 0 && gz < p.d && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w)
+                off[it] = ((gz * p.h + gy) * p.w + gx) * p.CB;
+        }
+    }
+    const int st_plane = ((q4 >> 1) * NPL) * p.plane_stride + (q4 & 1) * 8;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+    // this wave's weight stream: S = KCB*8 steps (chunk-major, tap-minor), NF fragments of 64 x uint4 per step
+    const int S = p.KCB * 8;
+    const uint4* wbase = p.wp + (size_t)(nt * 8 + cls) * S * (NF * 64) + lane;
+    uint4 wq[3][NF];
+    auto fetch = [&](int s, uint4 (&dst)[NF]) __attribute__((always_inline)) {
+        const int sc = s < S ? s : S - 1;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) dst[f] = wbase[(size_t)sc * (NF * 64) + f * 64];
+    };
+    fetch(0, wq[0]);
+    fetch(1, wq[1]);
+
+    // one K-chunk; PH = (kc*8) % 3 is the ring phase, passed as a compile-time constant so that every register-set
+    // index below is static (the chunk loop is unrolled by three: 8 % 3 == 2 advances the phase by two per chunk)
+    auto do_chunk = [&](int kc, auto ph_tag) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph_tag)::value;
+        const int c0 = kc * KC;
+        const float* src = p.B + c0 + q4 * 4;
+        const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + c0 + q4 * 4);
+        const float4 sh4 = *reinterpret_cast<const float4*>(p.shift + c0 + q4 * 4);
+        const float sc[4] = {sc4.x * a_scale, sc4.y * a_scale, sc4.z * a_scale, sc4.w * a_scale};
+        const float sh[4] = {sh4.x * a_scale, sh4.y * a_scale, sh4.z * a_scale, sh4.w * a_scale};
+        __syncthreads();                                 // previous chunk's readers are done
+#pragma unroll
+        for (int u0 = 0; u0 < MAX_IT; u0 += 2) {
+            float4 v[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (off[u0 + u] >= 0) v[u] = *reinterpret_cast<const float4*>(src + off[u0 + u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + (u0 + u) * NTHR;
+                if (off[u0 + u] != -2) {
+                    const bool ok = off[u0 + u] >= 0;
+                    float y[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    half4 hi, lo;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float t = ok ? fmaf(y[i], sc[i], sh[i]) : 0.f;      // zero padding AFTER the affine
+                        _Float16 hh = (_Float16)t;
+                        hi[i] = hh;
+                        lo[i] = (_Float16)(t - (float)hh);
+                    }
+                    unsigned char* dst = lds + st_plane + (e >> 2) * 16;
+                    *reinterpret_cast<half4*>(dst) = hi;
+                    if constexpr (NPASS == 3) *reinterpret_cast<half4*>(dst + p.plane_stride) = lo;
+                }
+            }
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            // ring of three register sets: step s = kc*8 + t uses set (s % 3) and refills the set used one step ago
+            const int s = kc * 8 + t;
+            const int ta = t >> 2, tb = (t >> 1) & 1, tc = t & 1;
+            const int toff = ((ta * p.HT + tb) * p.WT + tc) * 16;
+            const int cur = (PH + t) % 3;                     // compile-time after unrolling
+            uint4 bw[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) bw[f] = wq[cur][f];
+            fetch(s + 2, wq[(cur + 2) % 3]);
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                half8 a[NPL];
+#pragma unroll
+                for (int hl = 0; hl < NPL; ++hl)
+                    a[hl] = *reinterpret_cast<const half8*>(lds + a_off[mb] + hl * p.plane_stride + toff);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const half8 bhi = __builtin_bit_cast(half8, bw[nb * NPL]);
+                    if constexpr (NPASS == 3) {
+                        const half8 blo = __builtin_bit_cast(half8, bw[nb * NPL + 1]);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bhi, acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], blo, acc[mb][nb], 0, 0, 0);
+                    }
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bhi, acc[mb][nb], 0, 0, 0);
+                }
+            }
+        }
+    };
+    for (int kc = 0; kc < p.KCB; kc += 3) {
+        do_chunk(kc, std::integral_constant<int, 0>{});
+        if (kc + 1 < p.KCB) do_chunk(kc + 1, std::integral_constant<int, 2>{});
+        if (kc + 2 < p.KCB) do_chunk(kc + 2, std::integral_constant<int, 1>{});
+    }
+
+    // epilogue: class (pz,py,px) of low-res voxel (zl,yl,xl) is full-res voxel (2zl+pz, 2yl+py, 2xl+px)
+    const int H2 = 2 * p.h, W2 = 2 * p.w;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rr = (i >> 2) * 8 + khalf * 4 + (i & 3);
+            int bd, bh, bw;
+            box_coords(p, mb * 32 + row_perm(rr), bd, bh, bw);
+            const int zl = z0 + bd, yl = y0 + bh, xl = x0 + bw;
+            if (zl >= p.d || yl >= p.h || xl >= p.w) continue;
+            float* orow = p.out + (((int64_t)(2 * zl + pz) * H2 + (2 * yl + py)) * W2 + (2 * xl + px)) * p.Cout +
+                          nt * 64 + l32;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) orow[nb * 32] = acc[mb][nb][i] * dq;
+        }
+    }
+}
+
+// packed[ntile64][class 8][kc][tap 8][nb 2][hl][lane] (uint4 = 8 halfs): lane l holds
+// B[k = 8*(l>>5)+j][n = l&31] = Wfold_class[co = ntile*64 + nb*32 + (l&31)][ci = CA + kc*16 + 8*(l>>5) + j][tap] * 2^wexp
+// where Wfold sums the original taps that land on the same low-res voxel (fixed order: kd, kh, kw ascending).
+__global__ void pack_upfold(const float* __restrict__ w, int Cin, int CA, int CB, int Cout, int wexp, int npl,
+                            uint4* __restrict__ out) {
+    const int KCB = CB / KC;
+    const int nf = 2 * npl;
+    const int64_t n = (int64_t)(Cout / 64) * 8 * KCB * 8 * nf * 64;
+    const float s = ldexpf(1.0f, wexp);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        int64_t r = i >> 6;
+        const int f = (int)(r % nf); r /= nf;
+        const int t = (int)(r & 7); r >>= 3;
+        const int kc = (int)(r % KCB); r /= KCB;
+        const int cls = (int)(r & 7); r >>= 3;
+        const int ntile = (int)r;
+        const int nb = f / npl, hl = f - nb * npl;
+        const int co = ntile * 64 + nb * 32 + (lane & 31);
+        const int ci0 = CA + kc * KC + 8 * (lane >> 5);
+        const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+        const int ta = t >> 2, tb = (t >> 1) & 1, tc = t & 1;
+        // original taps along one axis for (parity, folded tap): p=0: {0} | {1,2};  p=1: {0,1} | {2}
+        const int zlo = pz == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2), zhi = pz == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
+        const int ylo = py == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2), yhi = py == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
+        const int xlo = px == 0 ? (tc == 0 ? 0 : 1) : (tc == 0 ? 0 : 2), xhi = px == 0 ? (tc == 0 ? 0 : 2) : (tc == 0 ? 1 : 2);
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* wc = w + ((size_t)co * Cin + ci0 + j) * 27;
+            float sum = 0.f;
+            for (int kd = zlo; kd <= zhi; ++kd)
+                for (int kh = ylo; kh <= yhi; ++kh)
+                    for (int kw = xlo; kw <= xhi; ++kw) sum += wc[kd * 9 + kh * 3 + kw];
+            const float x = sum * s;
+            const _Float16 hh = (_Float16)x;
+            v[j] = hl == 0 ? hh : (_Float16)(x - (float)hh);
+        }
+        out[i] = __builtin_bit_cast(uint4, v);
+    }
+}
+
+int ilog2i(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
+
+// low-res box of 128 voxels (powers of two) wasting the fewest rows on the volume's edges
+void choose_box(int d, int h, int w, int& BD, int& BH, int& BW) {
+    static const int opts[][3] = {{2, 4, 16}, {4, 2, 16}, {4, 4, 8}, {2, 8, 8}, {8, 2, 8}, {8, 4, 4}, {4, 8, 4},
+                                  {1, 8, 16}, {8, 1, 16}, {2, 2, 32}, {1, 4, 32}, {4, 1, 32}};
+    int64_t best = -1;
+    for (auto& o : opts) {
+        if ((o[0] + 2) * (o[1] + 2) * (o[2] + 2) * 4 > 4 * NTHR) continue;
+        int64_t cost = (int64_t)bfm_cdiv(d, o[0]) * bfm_cdiv(h, o[1]) * bfm_cdiv(w, o[2]);
+        // tie-break towards long x-runs (coalesced staging, conflict-free A reads)
+        cost = cost * 64 - o[2];
+        if (best < 0 || cost < best) { best = cost; BD = o[0]; BH = o[1]; BW = o[2]; }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t bfm_pack_conv_weights_upfold_bytes(int CB, int Cout, int passes) {
+    if (CB <= 0 || Cout <= 0 || CB % KC || Cout % 64) return 0;
+    const int npl = passes == 3 ? 2 : 1;
+    return (size_t)(Cout / 64) * 8 * (CB / KC) * 8 * 2 * npl * 64 * sizeof(uint4);
+}
+
+extern "C" int bfm_pack_conv_weights_upfold(const float* w_oidhw, int CA, int CB, int Cout, float wmax_abs_host,
+                                            int passes, void* wpacked, int* wexp_host, bfm_stream_t stream) {
+    if (!w_oidhw || !wpacked || !wexp_host || CA < 0 || CB <= 0 || Cout <= 0) return BFM_E_ARG;
+    if (CB % KC || Cout % 64 || (passes != 1 && passes != 3)) return BFM_E_SHAPE;
+    int wexp = 0;
+    if (wmax_abs_host > 0.f && wmax_abs_host < INFINITY) {
+        int ex;
+        (void)frexpf(8.f * wmax_abs_host, &ex);               // a folded weight sums up to 8 taps
+        wexp = 14 - ex;
+        wexp = wexp > 60 ? 60 : (wexp < -60 ? -60 : wexp);
+    }
+    *wexp_host = wexp;
+    const int npl = passes == 3 ? 2 : 1;
+    const int64_t n = (int64_t)(Cout / 64) * 8 * (CB / KC) * 8 * 2 * npl * 64;
+    int nb = (int)std::min<int64_t>(4096, bfm_cdiv64(n, 256));
+    hipLaunchKernelGGL(pack_upfold, dim3(nb), dim3(256), 0, bfm_s(stream), w_oidhw, CA + CB, CA, CB, Cout, wexp, npl,
+                       static_cast<uint4*>(wpacked));
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_conv3x3x3_upfold(const float* B, int CB, int d, int h, int w, const float* scale_b,
+                                    const float* shift_b, const float* bound, int G, const void* wpacked, int wexp,
+                                    int Cout, int passes, float* out, bfm_stream_t stream) {
+    if (!B || CB <= 0 || d <= 0 || h <= 0 || w <= 0 || !scale_b || !shift_b || !bound || G <= 0 || !wpacked || !out)
+        return BFM_E_ARG;
+    if (CB % KC || Cout % 64 || Cout <= 0) return BFM_E_SHAPE;
+    if (passes != 1 && passes != 3) return BFM_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(B) & 15) || (reinterpret_cast<uintptr_t>(scale_b) & 15) ||
+        (reinterpret_cast<uintptr_t>(shift_b) & 15) || (reinterpret_cast<uintptr_t>(wpacked) & 15) ||
+        (reinterpret_cast<uintptr_t>(out) & 15))
+        return BFM_E_ARG;
+    if ((int64_t)d * h * w * CB > 0x7fffffffLL) return BFM_E_SHAPE;       // 32-bit staging offsets
+    UpParams p{};
+    p.B = B; p.CB = CB; p.d = d; p.h = h; p.w = w;
+    p.scale = scale_b; p.shift = shift_b; p.bound = bound; p.G = G;
+    p.wp = static_cast<const uint4*>(wpacked);
+    p.wexp = wexp; p.Cout = Cout; p.out = out;
+    choose_box(d, h, w, p.BD, p.BH, p.BW);
+    p.HT = p.BH + 2; p.WT = p.BW + 2;
+    p.bw_shift = ilog2i(p.BW); p.bhw_shift = ilog2i(p.BH * p.BW);
+    const int nTz = bfm_cdiv(d, p.BD);
+    p.nTy = bfm_cdiv(h, p.BH); p.nTx = bfm_cdiv(w, p.BW);
+    p.nMt = nTz * p.nTy * p.nTx;
+    p.NT = Cout / 64;
+    p.KCB = CB / KC;
+    p.nvox_lds = (p.BD + 2) * p.HT * p.WT;
+    if (p.nvox_lds * 4 > 4 * NTHR) return BFM_E_SHAPE;
+    p.plane_stride = ((p.nvox_lds * 16 + 255) / 256) * 256 + 16;          // +16: planes start on different banks
+    const int npl = passes == 3 ? 2 : 1;
+    const size_t smem = (size_t)2 * npl * p.plane_stride + 64;
+    if ((int64_t)p.nMt * p.NT > 0x7fffffff) return BFM_E_SHAPE;
+    dim3 grid((unsigned)(p.nMt * p.NT));
+    if (passes == 3) hipLaunchKernelGGL(conv_upfold<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+    else hipLaunchKernelGGL(conv_upfold<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+    return bfm_launch_status();
+}

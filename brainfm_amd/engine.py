@@ -11,6 +11,7 @@ tensors handed back to callers are NCDHW *views* of those buffers
 (torch.channels_last_3d strides), so shapes and values match the reference.
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -38,7 +39,7 @@ def nearest_index_map(n_in, n_out):
 
 
 class _Layer:
-    __slots__ = ("name", "cin", "cout", "groups", "gamma", "beta", "kind", "wpacked", "wexp", "w_raw", "packs")
+    __slots__ = ("name", "cin", "cout", "groups", "gamma", "beta", "kind", "wpacked", "wexp", "w_raw", "packs", "skip")
 
 
 class UNetEngine:
@@ -50,6 +51,9 @@ class UNetEngine:
     the way utils/checkpoint.py:558-571 suffix-matches names.
     """
     prof = None
+    prof_reps = 1
+    use_upfold = False
+    upfold_min = 4000
 
     def __init__(self, state_dict, in_channels=1, f_maps=64, num_levels=6, num_groups=8, unit_feat=True,
                  device="cuda", passes=3, eps=1e-5, slope=0.01):
@@ -69,6 +73,9 @@ class UNetEngine:
         self._plan_cache = {}
         self._tuned = set()
         self.force_direct = False
+        # decoder first convs with an exact 2x upsample: fold the upsample into the weights (conv3d_upfold.hip)
+        self.use_upfold = os.environ.get("BFM_UPFOLD", "1") != "0"
+        self.upfold_min = int(os.environ.get("BFM_UPFOLD_MIN", "4000"))   # fewest low-res voxels worth the launch
         self.prof_reps = 1
         self.prof = None            # bench.py: list collecting (start_event, end_event, flops, bytes) per MFMA conv launch
         sd = self._normalise_keys(state_dict)
@@ -117,6 +124,7 @@ class UNetEngine:
         ly.wpacked = None
         ly.wexp = 0
         ly.packs = {}
+        ly.skip = None
         return ly
 
     def _mfma_ok(self, ly, ca, cb):
@@ -220,6 +228,9 @@ class UNetEngine:
         bound = torch.empty(ly.groups, dtype=torch.float32, device=self.device)
         wsb = self.lib.bfm_gn_stats_workspace(ca, cb, D, H, W, upp)
         mfma = self._mfma_ok(ly, ca, cb)
+        if (mfma and B is not None and self.use_upfold and tuple(dims) == tuple(2 * v for v in lo_dims)
+                and lo_dims[0] * lo_dims[1] * lo_dims[2] >= self.upfold_min):
+            return self._single_conv_upfold(ly, A, dims, B, lo_dims, upp, scale, shift, bound, wsb)
         cfg = None
         wsc = 0
         if mfma:
@@ -258,7 +269,9 @@ class UNetEngine:
                 nv = D * H * W
                 lo = 0 if B is None else lo_dims[0] * lo_dims[1] * lo_dims[2]
                 self.prof.append((ev[0], ev[1], 2.0 * 27 * ly.cin * ly.cout * nv,
-                                  4.0 * (nv * ca + lo * cb + nv * ly.cout + 27 * ly.cin * ly.cout), reps))
+                                  4.0 * (nv * ca + lo * cb + nv * ly.cout + 27 * ly.cin * ly.cout), reps,
+                                  (ly.name.replace("backbone.", "").replace(".basic_module.SingleConv", "."), ly.cin,
+                                   ly.cout, tuple(dims), tuple(cfg))))
         elif ca == 1 and cb == 0 and ly.cout in (32, 64) and not self.force_direct:
             L.check(self.lib.bfm_conv3x3x3_stem(L.ptr(A), D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
                                                 L.ptr(ly.wpacked), ly.cout, self.slope, L.ptr(out), st),
@@ -267,6 +280,83 @@ class UNetEngine:
             L.check(self.lib.bfm_conv3x3x3_direct(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(scale),
                                                   L.ptr(shift), L.ptr(ly.wpacked), ly.cout, self.slope, L.ptr(out),
                                                   st), "conv_direct " + ly.name)
+        return out
+
+    def _skip_layer(self, ly, ca):
+        """The skip-channel half of a decoder's first conv as a layer of its own (weights w[:, :ca])."""
+        if ly.skip is None:
+            sk = _Layer()
+            sk.name, sk.cin, sk.cout, sk.groups = ly.name + "[skip]", ca, ly.cout, ly.groups
+            sk.gamma, sk.beta = ly.gamma, ly.beta
+            sk.w_raw = ly.w_raw[:, :ca].contiguous()
+            sk.kind, sk.wpacked, sk.wexp, sk.packs, sk.skip = None, None, 0, {}, None
+            ly.skip = sk
+        return ly.skip
+
+    def _single_conv_upfold(self, ly, A, dims, B, lo_dims, upp, scale, shift, bound, wsb):
+        """cat((skip, up2x(x))) -> GN -> conv -> LeakyReLU as: GN stats over the virtual concat, the upsampled
+        channels through bfm_conv3x3x3_upfold (8 folded taps on the low-res tensor), the skip channels through
+        bfm_conv3x3x3_mfma accumulating onto that."""
+        D, H, W = dims
+        ca, cb = A.shape[-1], B.shape[-1]
+        st = L.stream_ptr()
+        sk = self._skip_layer(ly, ca)
+        key = (ca, ly.cout, tuple(dims))
+        cfg0 = self._plan(ca, ly.cout, dims)
+        wsc = self.lib.bfm_conv3x3x3_mfma_workspace(ca, ly.cout, D, H, W, cfg0[5])
+        ws = self._workspace(max(wsb, wsc))
+        L.check(self.lib.bfm_gn_stats(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(ly.gamma), L.ptr(ly.beta),
+                                      ly.groups, self.eps, L.ptr(scale), L.ptr(shift), L.ptr(bound), L.ptr(ws),
+                                      ws.numel(), st), "gn_stats " + ly.name)
+        out = torch.empty((D, H, W, ly.cout), dtype=torch.float32, device=self.device)
+        if "upfold" not in ly.packs:
+            nbytes = self.lib.bfm_pack_conv_weights_upfold_bytes(cb, ly.cout, self.passes)
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            wexp = C.c_int(0)
+            wmax = float(ly.w_raw[:, ca:].abs().max().item())
+            L.check(self.lib.bfm_pack_conv_weights_upfold(L.ptr(ly.w_raw), ca, cb, ly.cout, wmax, self.passes,
+                                                          L.ptr(buf), C.byref(wexp), st), "pack_upfold " + ly.name)
+            ly.packs["upfold"] = (buf, wexp.value)
+        wup, wexp_up = ly.packs["upfold"]
+
+        def _launch_skip(c):
+            self._pack(sk, True, c[6])
+            L.check(self.lib.bfm_conv3x3x3_mfma(L.ptr(A), ca, None, 0, D, H, W, None, L.ptr(scale), L.ptr(shift),
+                                                L.ptr(bound), ly.groups, L.ptr(sk.wpacked), sk.wexp, ly.cout,
+                                                self.slope, self.passes, c, L.ptr(out), L.ptr(ws), ws.numel(), st),
+                    "conv_mfma " + sk.name)
+        cfg0 = self._autotune(sk, key, _launch_skip)           # trials write plain results; overwritten below
+        cfg = (C.c_int * 8)(*list(cfg0))
+        cfg[7] = 1                                              # accumulate onto the upsampled half
+        self._pack(sk, True, cfg[6])
+        sc_b, sh_b = scale[ca:], shift[ca:]
+        nv = D * H * W
+        lo = lo_dims[0] * lo_dims[1] * lo_dims[2]
+        tag = ly.name.replace("backbone.", "").replace(".basic_module.SingleConv", ".")
+        reps = max(1, int(self.prof_reps)) if self.prof is not None else 1
+        ev = None
+        if self.prof is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        for _ in range(reps):
+            L.check(self.lib.bfm_conv3x3x3_upfold(L.ptr(B), cb, lo_dims[0], lo_dims[1], lo_dims[2], L.ptr(sc_b),
+                                                  L.ptr(sh_b), L.ptr(bound), ly.groups, L.ptr(wup), wexp_up, ly.cout,
+                                                  self.passes, L.ptr(out), st), "conv_upfold " + ly.name)
+        if ev is not None:
+            ev[1].record()
+            self.prof.append((ev[0], ev[1], 2.0 * 27 * cb * ly.cout * nv, 4.0 * (lo * cb + nv * ly.cout), reps,
+                              (tag + "up", cb, ly.cout, tuple(dims), (0,) * 8)))
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        for _ in range(reps):
+            L.check(self.lib.bfm_conv3x3x3_mfma(L.ptr(A), ca, None, 0, D, H, W, None, L.ptr(scale), L.ptr(shift),
+                                                L.ptr(bound), ly.groups, L.ptr(sk.wpacked), sk.wexp, ly.cout,
+                                                self.slope, self.passes, cfg, L.ptr(out), L.ptr(ws), ws.numel(), st),
+                    "conv_mfma " + sk.name)
+        if ev is not None:
+            ev[1].record()
+            self.prof.append((ev[0], ev[1], 2.0 * 27 * ca * ly.cout * nv, 4.0 * (nv * ca + 2 * nv * ly.cout), reps,
+                              (tag + "sk", ca, ly.cout, tuple(dims), tuple(cfg))))
         return out
 
     def maxpool(self, X, dims):

@@ -98,6 +98,21 @@ int bfm_conv3x3x3_stem(const float* A, int D, int H, int W, const float* scale, 
 
 size_t bfm_conv3x3x3_mfma_workspace(int Cin, int Cout, int D, int H, int W, int splitk);
 int bfm_conv3x3x3_mfma_plan(int Cin, int Cout, int D, int H, int W, int* cfg_out /*[8]*/);
+/* cfg[7] bit 0 ("accumulate"): add what `out` already holds before the LeakyReLU -- used for the skip half of a
+ * decoder's first conv after bfm_conv3x3x3_upfold wrote the upsampled half. */
+
+/* Decoder._joining + SingleConv (buildingblocks.py:265-276, 361-363), upsampled half only, for exact 2x nearest
+ * upsampling (full-res dims == 2 x low-res dims): the 27 taps over the 8-fold replicated low-res tensor collapse to
+ * 8 taps per output parity class with pre-summed weights (3.375x fewer FLOPs, the low-res box is what gets staged).
+ * B [d][h][w][CB] low-res; scale_b/shift_b = the GroupNorm affine of channels CA.. of the concatenation; bound/G as
+ * for _mfma; writes sum over (taps, B channels) WITHOUT activation to out [2d][2h][2w][Cout].  Follow with
+ * bfm_conv3x3x3_mfma(A = skip, CB = 0, cfg[7] |= 1) on the skip channels' weights. */
+size_t bfm_pack_conv_weights_upfold_bytes(int CB, int Cout, int passes);
+int bfm_pack_conv_weights_upfold(const float* w_oidhw /*[Cout][CA+CB][27]*/, int CA, int CB, int Cout,
+                                 float wmax_abs_host, int passes, void* wpacked, int* wexp_host, bfm_stream_t stream);
+int bfm_conv3x3x3_upfold(const float* B, int CB, int d, int h, int w, const float* scale_b, const float* shift_b,
+                         const float* bound, int G, const void* wpacked, int wexp, int Cout, int passes, float* out,
+                         bfm_stream_t stream);
 int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB, int D, int H, int W,
                        const bfm_upsample_t* up, const float* scale, const float* shift, const float* bound,
                        int G, const void* wpacked, int wexp, int Cout, float slope, int passes,

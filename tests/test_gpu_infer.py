@@ -270,6 +270,29 @@ def test_mfma_network_vs_oracle(passes, tol):
         assert errs["label_mismatch"] == 0, errs
 
 
+@pytest.mark.parametrize("lo", [(8, 8, 16), (9, 10, 12), (10, 5, 21)])
+def test_upsample_folded_decoder_conv_equals_generic_path(lo):
+    """Decoder first conv with the 2x nearest upsample folded into 8-tap weights (conv3d_upfold.hip + accumulate)
+    against the generic two-source implicit GEMM on the same operands: equal up to fp32 rounding of the weight
+    sums, on boxes that do not divide the low-res extents and with zero padding on every face."""
+    sd = O.random_state_dict(1, 64, 3, seed=11)
+    s = _session(sd=sd, f_maps=64, levels=3)
+    eng = s.engine
+    ly = eng.dec[-1][0]                                     # 128 (upsampled) + 64 (skip) -> 64
+    hi = tuple(2 * v for v in lo)
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(hi + (64,), generator=g).to(_dev())
+    B = (torch.randn(lo + (128,), generator=g) * 2 + 0.3).to(_dev())
+    eng.upfold_min = 1
+    eng.use_upfold = False
+    ref = eng.single_conv(ly, A, hi, B=B, lo_dims=lo).clone()
+    eng.use_upfold = True
+    got = eng.single_conv(ly, A, hi, B=B, lo_dims=lo)
+    assert ly.skip is not None and "upfold" in ly.packs
+    e = _relerr(got.cpu().numpy(), ref.cpu().numpy())
+    assert e <= 2e-6, e
+
+
 def test_split_k_deep_layer_vs_oracle():
     """Deep-level shape (few voxels, many channels) takes the split-K path; also a concat source."""
     from brainfm_amd.engine import UNetEngine
