@@ -65,6 +65,14 @@ SIGNATURES = {
     "bfm_pack_conv_weights_upfold_bytes": (C.c_size_t, [_I, _I, _I]),
     "bfm_pack_conv_weights_upfold": (_I, [_P, _I, _I, _I, _F, _I, _P, _P, _P]),
     "bfm_conv3x3x3_upfold": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P]),
+    "bfm_moment_rows_bytes": (_Z, [_I, _I]),
+    "bfm_conv3x3x3_mfma_rows": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),
+    "bfm_conv3x3x3_mfma_ex": (_I, [_P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _P, _I, _P, _I, _I, _F, _I,
+                                   C.POINTER(_I), _P, _P, _Z, _P, _P]),
+    "bfm_conv3x3x3_stem_rows": (_I, [_I, _I, _I]),
+    "bfm_conv3x3x3_stem_ex": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P, _P]),
+    "bfm_gn_stats_rows_workspace": (_Z, [_I, _I, _I, _I]),
+    "bfm_gn_stats_rows": (_I, [_P, _I, _I, _P, _I, _I, C.c_double, _L, _P, _P, _I, _F, _P, _P, _P, _P, _Z, _P]),
     "bfm_conv3x3x3_stem": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
     "bfm_conv3x3x3_mfma_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
     "bfm_conv3x3x3_mfma_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),

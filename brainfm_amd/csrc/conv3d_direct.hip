@@ -99,7 +99,9 @@ __global__ void __launch_bounds__(256, 3) conv_stem_mfma(const float* __restrict
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ bound,
                                                          const float* __restrict__ wp /*[27][Cout]*/, float slope,
-                                                         float* __restrict__ out, int64_t nblocks32) {
+                                                         float* __restrict__ out, int64_t nblocks32,
+                                                         double* __restrict__ rsum, double* __restrict__ rsq,
+                                                         float* __restrict__ rmn, float* __restrict__ rmx) {
     constexpr int Cout = NB * 32;
     const int lane = threadIdx.x & 63;
     const int l32 = lane & 31, kh = lane >> 5;
@@ -157,6 +159,12 @@ __global__ void __launch_bounds__(256, 3) conv_stem_mfma(const float* __restrict
         }
     };
 
+    // optional moment rows of the output: one row per wave ([gridDim.x*4][Cout]), see conv3d_mfma.hip
+    double ms[NB], mq[NB];
+    float mmn[NB], mmx[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) { ms[nb] = 0.0; mq[nb] = 0.0; mmn[nb] = INFINITY; mmx[nb] = -INFINITY; }
+
     float raw[16];
     unsigned mask = 0;
     if (gw < nblocks32) gather(gw, raw, mask);
@@ -193,12 +201,30 @@ __global__ void __launch_bounds__(256, 3) conv_stem_mfma(const float* __restrict
                     float r = acc[i] * dq;
                     r = r >= 0.f ? r : r * slope;
                     orow[rr * Cout + nb * 32 + l32] = r;
+                    if (rsum) {
+                        const double rd = (double)r;
+                        ms[nb] += rd; mq[nb] += rd * rd;
+                        mmn[nb] = fminf(mmn[nb], r); mmx[nb] = fmaxf(mmx[nb], r);
+                    }
                 }
             }
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) raw[q] = nraw[q];
         mask = nmask;
+    }
+    if (rsum) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            ms[nb] += __shfl_xor(ms[nb], 32);
+            mq[nb] += __shfl_xor(mq[nb], 32);
+            mmn[nb] = fminf(mmn[nb], __shfl_xor(mmn[nb], 32));
+            mmx[nb] = fmaxf(mmx[nb], __shfl_xor(mmx[nb], 32));
+            if (kh == 0) {
+                const size_t o = (size_t)gw * Cout + nb * 32 + l32;
+                rsum[o] = ms[nb]; rsq[o] = mq[nb]; rmn[o] = mmn[nb]; rmx[o] = mmx[nb];
+            }
+        }
     }
 }
 
@@ -229,19 +255,50 @@ extern "C" int bfm_conv3x3x3_direct(const float* A, int CA, const float* B, int 
     return bfm_launch_status();
 }
 
-extern "C" int bfm_conv3x3x3_stem(const float* A, int D, int H, int W, const float* scale, const float* shift,
-                                  const float* bound, const float* wpacked_direct, int Cout, float slope, float* out,
-                                  bfm_stream_t stream) {
-    if (!A || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || !wpacked_direct || !out) return BFM_E_ARG;
-    if (Cout != 32 && Cout != 64) return BFM_E_SHAPE;
+namespace {
+int64_t stem_grid(int D, int H, int W) {
     const int64_t nblk = (int64_t)D * H * ((W + 31) / 32);
     int64_t nb = bfm_cdiv64(nblk, 4);
     if (nb > 256 * 16) nb = 256 * 16;
+    return nb;
+}
+}  // namespace
+
+// rows of the output-moment table bfm_conv3x3x3_stem_ex writes (one per wave of the launch)
+extern "C" int bfm_conv3x3x3_stem_rows(int D, int H, int W) {
+    if (D <= 0 || H <= 0 || W <= 0) return 0;
+    return (int)(stem_grid(D, H, W) * 4);
+}
+
+extern "C" int bfm_conv3x3x3_stem_ex(const float* A, int D, int H, int W, const float* scale, const float* shift,
+                                     const float* bound, const float* wpacked_direct, int Cout, float slope,
+                                     float* out, void* moment_rows, bfm_stream_t stream) {
+    if (!A || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || !wpacked_direct || !out) return BFM_E_ARG;
+    if (Cout != 32 && Cout != 64) return BFM_E_SHAPE;
+    const int64_t nblk = (int64_t)D * H * ((W + 31) / 32);
+    const int64_t nb = stem_grid(D, H, W);
+    double *rsum = nullptr, *rsq = nullptr;
+    float *rmn = nullptr, *rmx = nullptr;
+    if (moment_rows) {
+        if (reinterpret_cast<uintptr_t>(moment_rows) & 7) return BFM_E_ARG;
+        char* rb = static_cast<char*>(moment_rows);
+        const size_t n = (size_t)nb * 4 * Cout;
+        rsum = reinterpret_cast<double*>(rb);
+        rsq = reinterpret_cast<double*>(rb + n * 8);
+        rmn = reinterpret_cast<float*>(rb + n * 16);
+        rmx = reinterpret_cast<float*>(rb + n * 20);
+    }
     if (Cout == 32)
         hipLaunchKernelGGL(conv_stem_mfma<1>, dim3((unsigned)nb), dim3(256), 0, bfm_s(stream), A, D, H, W, scale, shift,
-                           bound, wpacked_direct, slope, out, nblk);
+                           bound, wpacked_direct, slope, out, nblk, rsum, rsq, rmn, rmx);
     else
         hipLaunchKernelGGL(conv_stem_mfma<2>, dim3((unsigned)nb), dim3(256), 0, bfm_s(stream), A, D, H, W, scale, shift,
-                           bound, wpacked_direct, slope, out, nblk);
+                           bound, wpacked_direct, slope, out, nblk, rsum, rsq, rmn, rmx);
     return bfm_launch_status();
+}
+
+extern "C" int bfm_conv3x3x3_stem(const float* A, int D, int H, int W, const float* scale, const float* shift,
+                                  const float* bound, const float* wpacked_direct, int Cout, float slope, float* out,
+                                  bfm_stream_t stream) {
+    return bfm_conv3x3x3_stem_ex(A, D, H, W, scale, shift, bound, wpacked_direct, Cout, slope, out, nullptr, stream);
 }

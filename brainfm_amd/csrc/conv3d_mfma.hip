@@ -54,7 +54,49 @@ struct ConvParams {
     int tw_shift, thw_shift;        // >=0 when TW / TH*TW are powers of two
     int64_t split_stride;           // elements between split-K slabs
     int accum;                      // 1: add what `out` already holds (the up-folded low-res half) before LeakyReLU
+    // optional moment rows of the OUTPUT (one row per M tile, [nMt][Cout]): {sum, sumsq} fp64, {min, max} fp32.  The
+    // consumer's GroupNorm reduces these instead of re-reading the activation (gn_stats.hip: bfm_gn_stats_rows).
+    double *rsum, *rsq;
+    float *rmn, *rmx;
 };
+
+// Cross-wave fold of per-wave column moments and the row store.  Called by every thread of the workgroup after
+// the K loop; `lds` is free by then (a barrier separates the last MFMA reads from these writes).
+// s/q/mn/mx: this lane's totals for column `col` (0..63 of the wave's 64-column tile), valid when `writer`.
+template <int WM, int WN>
+__device__ __forceinline__ void store_moment_row(const ConvParams& p, unsigned char* lds, int tid, int wm, int wn,
+                                                 bool writer, const int (&col)[4], int ncol, const double (&s)[4],
+                                                 const double (&q)[4], const float (&mn)[4], const float (&mx)[4],
+                                                 int mt, int nt) {
+    double* ls = reinterpret_cast<double*>(lds);                 // [WM*WN][64]
+    double* lq = ls + WM * WN * 64;
+    float* lmn = reinterpret_cast<float*>(lq + WM * WN * 64);
+    float* lmx = lmn + WM * WN * 64;
+    __syncthreads();
+    if (writer) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < ncol) {
+                const int i = (wm * WN + wn) * 64 + col[j];
+                ls[i] = s[j]; lq[i] = q[j]; lmn[i] = mn[j]; lmx[i] = mx[j];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 64 * WN) {
+        const int w2 = tid >> 6, c = tid & 63;
+        double S = 0.0, Q = 0.0;
+        float MN = INFINITY, MX = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+            const int i = (m * WN + w2) * 64 + c;
+            S += ls[i]; Q += lq[i];
+            MN = fminf(MN, lmn[i]); MX = fmaxf(MX, lmx[i]);
+        }
+        const size_t o = (size_t)mt * p.Cout + (nt * WN + w2) * 64 + c;
+        p.rsum[o] = S; p.rsq[o] = Q; p.rmn[o] = MN; p.rmx[o] = MX;
+    }
+}
 
 // lane (= MFMA row) -> position inside the 32-row block such that every
 // ds_read_b128 lane group {0-3,12-15,20-27} / {4-11,16-19,28-31} reads 16
@@ -318,7 +360,11 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(const ConvParams p)
 
     // ================= epilogue =================
     const bool final_out = p.splitk == 1;
+    const bool want_rows = final_out && p.rsum != nullptr;
     float* obase = p.out + (final_out ? 0 : (int64_t)split * p.split_stride);
+    // per-lane partial moments of <= 32 stored values per column in fp32 (then fp64 across lanes, waves and tiles)
+    float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
+    float mmn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mmx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
@@ -336,8 +382,26 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(const ConvParams p)
                 float r = acc[mb][nb][i] * dq;
                 if (final_out) r = r >= 0.f ? r : r * p.slope;     // accumulate mode preloaded `out` into acc
                 orow[nb * 32] = r;
+                if (want_rows) {
+                    fs[nb] += r; fq[nb] = fmaf(r, r, fq[nb]);
+                    mmn[nb] = fminf(mmn[nb], r); mmx[nb] = fmaxf(mmx[nb], r);
+                }
             }
         }
+    }
+    if (want_rows) {                                         // uniform per workgroup
+        double ms[4], mq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ms[j] = (double)fs[j]; mq[j] = (double)fq[j]; }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {                     // the other k-half holds the other rows of the same column
+            ms[nb] += __shfl_xor(ms[nb], 32);
+            mq[nb] += __shfl_xor(mq[nb], 32);
+            mmn[nb] = fminf(mmn[nb], __shfl_xor(mmn[nb], 32));
+            mmx[nb] = fmaxf(mmx[nb], __shfl_xor(mmx[nb], 32));
+        }
+        const int cols[4] = {l32, 32 + l32, 0, 0};
+        store_moment_row<WM, WN>(p, lds, tid, wm, wn, khalf == 0, cols, 2, ms, mq, mmn, mmx, mt, nt);
     }
 }
 
@@ -571,7 +635,10 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma16(const ConvParams 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     const bool final_out = p.splitk == 1;
+    const bool want_rows = final_out && p.rsum != nullptr;
     float* obase = p.out + (final_out ? 0 : (int64_t)split * p.split_stride);
+    float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};      // <= 16 values per column per lane in fp32
+    float mmn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mmx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
 #pragma unroll
@@ -588,8 +655,29 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma16(const ConvParams 
                 float r = acc[rb][cb][i] * dq;
                 if (final_out) r = r >= 0.f ? r : r * p.slope;     // accumulate mode preloaded `out` into acc
                 orow[cb * 16] = r;
+                if (want_rows) {
+                    fs[cb] += r; fq[cb] = fmaf(r, r, fq[cb]);
+                    mmn[cb] = fminf(mmn[cb], r); mmx[cb] = fmaxf(mmx[cb], r);
+                }
             }
         }
+    }
+    if (want_rows) {
+        double ms[4], mq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ms[j] = (double)fs[j]; mq[j] = (double)fq[j]; }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {                     // the four k-groups hold different rows of the same column
+#pragma unroll
+            for (int m = 16; m <= 32; m <<= 1) {
+                ms[cb] += __shfl_xor(ms[cb], m);
+                mq[cb] += __shfl_xor(mq[cb], m);
+                mmn[cb] = fminf(mmn[cb], __shfl_xor(mmn[cb], m));
+                mmx[cb] = fmaxf(mmx[cb], __shfl_xor(mmx[cb], m));
+            }
+        }
+        const int cols[4] = {l16, 16 + l16, 32 + l16, 48 + l16};
+        store_moment_row<WM, WN>(p, lds, tid, wm, wn, kg == 0, cols, 4, ms, mq, mmn, mmx, mt, nt);
     }
 }
 
@@ -1139,11 +1227,38 @@ extern "C" size_t bfm_conv3x3x3_mfma_workspace(int Cin, int Cout, int D, int H, 
     return (size_t)splitk * D * H * W * Cout * sizeof(float);
 }
 
+// rows of the output-moment table a launch with this plan writes (0: this plan cannot emit them)
+extern "C" int bfm_conv3x3x3_mfma_rows(int Cin, int Cout, int D, int H, int W, const int* cfg) {
+    if (!cfg || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    if (cfg[6] == 1) return 0;                                  // the persistent variant does not emit rows
+    int splitk = cfg[5] < 1 ? 1 : cfg[5];
+    const int KCN = Cin / KC;
+    if (splitk > KCN) splitk = KCN;
+    if (splitk > 1 && bfm_cdiv(KCN, bfm_cdiv(KCN, splitk)) > 1) return 0;
+    if (cfg[2] < 1 || cfg[3] < 1 || cfg[4] < 1) return 0;
+    return bfm_cdiv(D, cfg[2]) * bfm_cdiv(H, cfg[3]) * bfm_cdiv(W, cfg[4]);
+}
+
+extern "C" int bfm_conv3x3x3_mfma_ex(const float* A, int CA, const float* B, int CB, int D, int H, int W,
+                                     const bfm_upsample_t* up, const float* scale, const float* shift,
+                                     const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope,
+                                     int passes, const int* cfg, float* out, void* workspace, size_t workspace_bytes,
+                                     void* moment_rows, bfm_stream_t stream);
+
 extern "C" int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB, int D, int H, int W,
                                   const bfm_upsample_t* up, const float* scale, const float* shift,
                                   const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope,
                                   int passes, const int* cfg, float* out, void* workspace, size_t workspace_bytes,
                                   bfm_stream_t stream) {
+    return bfm_conv3x3x3_mfma_ex(A, CA, B, CB, D, H, W, up, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes,
+                                 cfg, out, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int bfm_conv3x3x3_mfma_ex(const float* A, int CA, const float* B, int CB, int D, int H, int W,
+                                     const bfm_upsample_t* up, const float* scale, const float* shift,
+                                     const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope,
+                                     int passes, const int* cfg, float* out, void* workspace, size_t workspace_bytes,
+                                     void* moment_rows, bfm_stream_t stream) {
     if (!A || CA <= 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || G <= 0 || !wpacked || !out)
         return BFM_E_ARG;
     if (CB < 0 || (CB > 0 && (!B || !up || !up->mapD || !up->mapH || !up->mapW || up->d <= 0 || up->h <= 0 ||
@@ -1203,6 +1318,16 @@ extern "C" int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB
         p.out = static_cast<float*>(workspace);
     } else {
         p.out = out;
+    }
+    if (moment_rows) {
+        if (p.splitk != 1 || hp.ver == 1) return BFM_E_SHAPE;  // see bfm_conv3x3x3_mfma_rows
+        if (reinterpret_cast<uintptr_t>(moment_rows) & 7) return BFM_E_ARG;
+        char* rb = static_cast<char*>(moment_rows);
+        const size_t n = (size_t)p.nMt * Cout;
+        p.rsum = reinterpret_cast<double*>(rb);
+        p.rsq = reinterpret_cast<double*>(rb + n * 8);
+        p.rmn = reinterpret_cast<float*>(rb + n * 16);
+        p.rmx = reinterpret_cast<float*>(rb + n * 20);
     }
     if ((int64_t)p.nMt * p.NT > 0x7fffffff) return BFM_E_SHAPE;
     if (nvox * CA > 0x7fffffffLL || (CB > 0 && (int64_t)up->d * up->h * up->w * CB > 0x7fffffffLL))

@@ -149,7 +149,54 @@ struct PartTab {
     const double *psum, *psq;
     const float *pmin, *pmax;
     int nb, C;
+    double wgt;                        // uniform replication weight of this source's voxels (1, or 8 for an exact 2x upsample)
 };
+
+// Moment rows written by a producer's epilogue (conv_mfma*, conv_stem_mfma): [nrows][C] of {sum, sumsq} (fp64) and
+// {min, max} (fp32), one row per producer tile.  rows_reduce folds them to at most RR_MAX rows in fixed order so
+// that gn_finalize stays a few microseconds; the activation itself is never re-read.
+constexpr int RR_MAX = 128;
+
+__global__ void __launch_bounds__(TPB) rows_reduce(const double* __restrict__ rsum, const double* __restrict__ rsq,
+                                                   const float* __restrict__ rmn, const float* __restrict__ rmx,
+                                                   int nrows, int C, int rows_per_block, double* __restrict__ psum,
+                                                   double* __restrict__ psq, float* __restrict__ pmin,
+                                                   float* __restrict__ pmax) {
+    extern __shared__ double smem_d[];
+    const int t = threadIdx.x;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(nrows, r0 + rows_per_block);
+    const int CP = C < TPB ? C : TPB;              // columns in flight
+    const int RP = TPB / CP;                        // rows in flight
+    double* ls = smem_d;
+    double* lq = ls + TPB;
+    float* lmn = reinterpret_cast<float*>(lq + TPB);
+    float* lmx = lmn + TPB;
+    for (int cb = 0; cb < C; cb += CP) {
+        const int col = cb + t % CP, part = t / CP;
+        double sv = 0.0, qv = 0.0;
+        float mn = INFINITY, mx = -INFINITY;
+        if (part < RP && col < C) {
+            for (int r = r0 + part; r < r1; r += RP) {
+                const size_t i = (size_t)r * C + col;
+                sv += rsum[i]; qv += rsq[i];
+                mn = fminf(mn, rmn[i]); mx = fmaxf(mx, rmx[i]);
+            }
+        }
+        ls[t] = sv; lq[t] = qv; lmn[t] = mn; lmx[t] = mx;
+        __syncthreads();
+        if (part == 0 && col < C) {
+            for (int pp = 1; pp < RP; ++pp) {
+                const int i = pp * CP + (t % CP);
+                sv += ls[i]; qv += lq[i];
+                mn = fminf(mn, lmn[i]); mx = fmaxf(mx, lmx[i]);
+            }
+            const size_t o = (size_t)blockIdx.x * C + col;
+            psum[o] = sv; psq[o] = qv; pmin[o] = mn; pmax[o] = mx;
+        }
+        __syncthreads();
+    }
+}
 
 // One block per group.  Dynamic LDS: chan_s[cpg], chan_q[cpg] (double), chan_mn[cpg], chan_mx[cpg] (float),
 // red_s[TPB], red_q[TPB] (double), red_mn[TPB], red_mx[TPB] (float)
@@ -190,6 +237,7 @@ __global__ void __launch_bounds__(TPB) gn_finalize(PartTab ta, PartTab tb, int G
                 s += T.psum[i]; q += T.psq[i];
                 mn = fminf(mn, T.pmin[i]); mx = fmaxf(mx, T.pmax[i]);
             }
+            s *= T.wgt; q *= T.wgt;
         }
         red_s[t] = s; red_q[t] = q; red_mn[t] = mn; red_mx[t] = mx;
         __syncthreads();
@@ -332,15 +380,88 @@ extern "C" int bfm_gn_stats(const float* A, int CA, const float* B, int CB, int 
     RepView none{D, H, W, nullptr, nullptr, nullptr};
     launch_partial(A, CA, nvoxA, p.nbA, p.vpbA, none, ws, p.offA_sum, p.offA_sq, p.offA_mn, p.offA_mx, st);
     PartTab ta{reinterpret_cast<double*>(ws + p.offA_sum), reinterpret_cast<double*>(ws + p.offA_sq),
-               reinterpret_cast<float*>(ws + p.offA_mn), reinterpret_cast<float*>(ws + p.offA_mx), p.nbA, CA};
-    PartTab tb{nullptr, nullptr, nullptr, nullptr, 0, 0};
+               reinterpret_cast<float*>(ws + p.offA_mn), reinterpret_cast<float*>(ws + p.offA_mx), p.nbA, CA, 1.0};
+    PartTab tb{nullptr, nullptr, nullptr, nullptr, 0, 0, 1.0};
     if (CB > 0) {
         RepView rep{up->d, up->h, up->w, up->repD, up->repH, up->repW};
         launch_partial(B, CB, nvoxB, p.nbB, p.vpbB, rep, ws, p.offB_sum, p.offB_sq, p.offB_mn, p.offB_mx, st);
         tb = PartTab{reinterpret_cast<double*>(ws + p.offB_sum), reinterpret_cast<double*>(ws + p.offB_sq),
-                     reinterpret_cast<float*>(ws + p.offB_mn), reinterpret_cast<float*>(ws + p.offB_mx), p.nbB, CB};
+                     reinterpret_cast<float*>(ws + p.offB_mn), reinterpret_cast<float*>(ws + p.offB_mx), p.nbB, CB, 1.0};
     }
     hipLaunchKernelGGL(gn_finalize, dim3(G), dim3(TPB), fin_smem, st, ta, tb, G, (double)nvoxA, eps, gamma, beta,
                        scale, shift, bound);
+    return bfm_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Statistics from producer-written moment rows (no pass over the activation).
+namespace {
+
+struct RowsView {
+    const double *sum, *sq;
+    const float *mn, *mx;
+};
+
+RowsView rows_view(const void* rows, int nrows, int C) {
+    const char* b = static_cast<const char*>(rows);
+    const size_t n = (size_t)nrows * C;
+    return RowsView{reinterpret_cast<const double*>(b), reinterpret_cast<const double*>(b + n * 8),
+                    reinterpret_cast<const float*>(b + n * 16), reinterpret_cast<const float*>(b + n * 20)};
+}
+
+size_t rows_ws_bytes(int nrows, int C) {            // reduced table (only when nrows > RR_MAX)
+    if (nrows <= RR_MAX) return 0;
+    return (((size_t)RR_MAX * C * 24) + 255) & ~(size_t)255;
+}
+
+// returns the table gn_finalize should read; launches rows_reduce into ws when the row count is large
+PartTab rows_source(const void* rows, int nrows, int C, double wgt, char* ws, hipStream_t st) {
+    RowsView v = rows_view(rows, nrows, C);
+    if (nrows <= RR_MAX) return PartTab{v.sum, v.sq, v.mn, v.mx, nrows, C, wgt};
+    const int rpb = bfm_cdiv(nrows, RR_MAX);
+    const int nb = bfm_cdiv(nrows, rpb);
+    const size_t n = (size_t)RR_MAX * C;
+    double* ps = reinterpret_cast<double*>(ws);
+    double* pq = reinterpret_cast<double*>(ws + n * 8);
+    float* pn = reinterpret_cast<float*>(ws + n * 16);
+    float* px = reinterpret_cast<float*>(ws + n * 20);
+    hipLaunchKernelGGL(rows_reduce, dim3(nb), dim3(TPB), (size_t)TPB * 24, st, v.sum, v.sq, v.mn, v.mx, nrows, C, rpb,
+                       ps, pq, pn, px);
+    return PartTab{ps, pq, pn, px, nb, C, wgt};
+}
+
+}  // namespace
+
+extern "C" size_t bfm_moment_rows_bytes(int nrows, int C) {
+    if (nrows <= 0 || C <= 0) return 0;
+    return (size_t)nrows * C * 24;
+}
+
+extern "C" size_t bfm_gn_stats_rows_workspace(int nrowsA, int CA, int nrowsB, int CB) {
+    return rows_ws_bytes(nrowsA, CA) + (CB > 0 ? rows_ws_bytes(nrowsB, CB) : 0) + 256;
+}
+
+extern "C" int bfm_gn_stats_rows(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB,
+                                 double weightB, int64_t nvox, const float* gamma, const float* beta, int G, float eps,
+                                 float* scale, float* shift, float* bound, void* workspace, size_t workspace_bytes,
+                                 bfm_stream_t stream) {
+    if (!rowsA || nrowsA <= 0 || CA <= 0 || nvox <= 0 || !gamma || !beta || !scale || !shift || !bound) return BFM_E_ARG;
+    if (CB < 0 || (CB > 0 && (!rowsB || nrowsB <= 0 || !(weightB > 0.0)))) return BFM_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(rowsA) & 7) || (CB > 0 && (reinterpret_cast<uintptr_t>(rowsB) & 7))) return BFM_E_ARG;
+    const int Ctot = CA + CB;
+    if (G <= 0 || Ctot % G != 0) return BFM_E_SHAPE;
+    const int cpg = Ctot / G;
+    const size_t fin_smem = (size_t)cpg * 24 + (size_t)TPB * 24;
+    if (fin_smem > 64 * 1024) return BFM_E_SHAPE;
+    const size_t needA = rows_ws_bytes(nrowsA, CA), needB = CB > 0 ? rows_ws_bytes(nrowsB, CB) : 0;
+    if (needA + needB > 0 && (!workspace || workspace_bytes < needA + needB)) return BFM_E_WORKSPACE;
+    if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 7)) return BFM_E_ARG;
+    hipStream_t st = bfm_s(stream);
+    char* ws = static_cast<char*>(workspace);
+    PartTab ta = rows_source(rowsA, nrowsA, CA, 1.0, ws, st);
+    PartTab tb{nullptr, nullptr, nullptr, nullptr, 0, 0, 1.0};
+    if (CB > 0) tb = rows_source(rowsB, nrowsB, CB, weightB, ws + needA, st);
+    hipLaunchKernelGGL(gn_finalize, dim3(G), dim3(TPB), fin_smem, st, ta, tb, G, (double)nvox, eps, gamma, beta, scale,
+                       shift, bound);
     return bfm_launch_status();
 }

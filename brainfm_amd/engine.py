@@ -54,6 +54,7 @@ class UNetEngine:
     prof_reps = 1
     use_upfold = False
     upfold_min = 4000
+    fuse_stats = False
 
     def __init__(self, state_dict, in_channels=1, f_maps=64, num_levels=6, num_groups=8, unit_feat=True,
                  device="cuda", passes=3, eps=1e-5, slope=0.01):
@@ -76,6 +77,8 @@ class UNetEngine:
         # decoder first convs with an exact 2x upsample: fold the upsample into the weights (conv3d_upfold.hip)
         self.use_upfold = os.environ.get("BFM_UPFOLD", "1") != "0"
         self.upfold_min = int(os.environ.get("BFM_UPFOLD_MIN", "4000"))   # fewest low-res voxels worth the launch
+        # GroupNorm moments from rows the producing conv wrote in its epilogue instead of a pass over the activation
+        self.fuse_stats = os.environ.get("BFM_FUSE_STATS", "1") != "0"
         self.prof_reps = 1
         self.prof = None            # bench.py: list collecting (start_event, end_event, flops, bytes) per MFMA conv launch
         sd = self._normalise_keys(state_dict)
@@ -212,6 +215,39 @@ class UNetEngine:
         self._tuned.add(key)
         return cfg
 
+    def _gn_stats(self, ly, A, ca, B, cb, dims, lo_dims, upp, scale, shift, bound, ws_min):
+        """GroupNorm scale/shift/bound of cat((A, up(B))).  Uses the producers' moment rows when every source has
+        them (and the upsample is an exact 2x, so every low-res voxel weighs 8); otherwise reads the tensors."""
+        D, H, W = dims
+        st = L.stream_ptr()
+        ra = getattr(A, "_bfm_rows", None) if self.fuse_stats else None
+        rb = getattr(B, "_bfm_rows", None) if (self.fuse_stats and B is not None) else None
+        exact2 = B is None or tuple(dims) == tuple(2 * v for v in lo_dims)
+        if ra is not None and (B is None or (rb is not None and exact2)):
+            need = self.lib.bfm_gn_stats_rows_workspace(ra[1], ca, rb[1] if rb is not None else 0, cb)
+            ws = self._workspace(max(need, ws_min))
+            L.check(self.lib.bfm_gn_stats_rows(L.ptr(ra[0]), ra[1], ca, L.ptr(rb[0]) if rb is not None else None,
+                                               rb[1] if rb is not None else 0, cb, 8.0, D * H * W, L.ptr(ly.gamma),
+                                               L.ptr(ly.beta), ly.groups, self.eps, L.ptr(scale), L.ptr(shift),
+                                               L.ptr(bound), L.ptr(ws), ws.numel(), st), "gn_stats_rows " + ly.name)
+            return ws
+        wsb = self.lib.bfm_gn_stats_workspace(ca, cb, D, H, W, upp)
+        ws = self._workspace(max(wsb, ws_min))
+        L.check(self.lib.bfm_gn_stats(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(ly.gamma), L.ptr(ly.beta),
+                                      ly.groups, self.eps, L.ptr(scale), L.ptr(shift), L.ptr(bound), L.ptr(ws),
+                                      ws.numel(), st), "gn_stats " + ly.name)
+        return ws
+
+    def _rows_for(self, cin, cout, dims, cfg):
+        """(buffer, nrows) for the producer's output-moment rows, or None when this plan cannot emit them."""
+        if not self.fuse_stats:
+            return None
+        n = self.lib.bfm_conv3x3x3_mfma_rows(cin, cout, dims[0], dims[1], dims[2], cfg)
+        if n <= 0:
+            return None
+        buf = torch.empty(self.lib.bfm_moment_rows_bytes(n, cout), dtype=torch.uint8, device=self.device)
+        return (buf, n)
+
     # ------------------------------------------------------------------ one SingleConv
     def single_conv(self, ly, A, dims, B=None, lo_dims=None):
         """GroupNorm -> Conv3d(3,p=1) -> LeakyReLU on cat((A, nearest_up(B))).
@@ -226,20 +262,16 @@ class UNetEngine:
         scale = torch.empty(ly.cin, dtype=torch.float32, device=self.device)
         shift = torch.empty(ly.cin, dtype=torch.float32, device=self.device)
         bound = torch.empty(ly.groups, dtype=torch.float32, device=self.device)
-        wsb = self.lib.bfm_gn_stats_workspace(ca, cb, D, H, W, upp)
         mfma = self._mfma_ok(ly, ca, cb)
         if (mfma and B is not None and self.use_upfold and tuple(dims) == tuple(2 * v for v in lo_dims)
                 and lo_dims[0] * lo_dims[1] * lo_dims[2] >= self.upfold_min):
-            return self._single_conv_upfold(ly, A, dims, B, lo_dims, upp, scale, shift, bound, wsb)
+            return self._single_conv_upfold(ly, A, dims, B, lo_dims, upp, scale, shift, bound)
         cfg = None
         wsc = 0
         if mfma:
             cfg = self._plan(ly.cin, ly.cout, dims)
             wsc = self.lib.bfm_conv3x3x3_mfma_workspace(ly.cin, ly.cout, D, H, W, cfg[5])
-        ws = self._workspace(max(wsb, wsc))
-        L.check(self.lib.bfm_gn_stats(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(ly.gamma), L.ptr(ly.beta),
-                                      ly.groups, self.eps, L.ptr(scale), L.ptr(shift), L.ptr(bound), L.ptr(ws),
-                                      ws.numel(), st), "gn_stats " + ly.name)
+        ws = self._gn_stats(ly, A, ca, B, cb, dims, lo_dims, upp, scale, shift, bound, wsc)
         out = torch.empty((D, H, W, ly.cout), dtype=torch.float32, device=self.device)
         if mfma:
             def _launch(c):
@@ -253,6 +285,7 @@ class UNetEngine:
         if mfma:
             ev = None
             reps = 1
+            rows = self._rows_for(ly.cin, ly.cout, dims, cfg)
             if self.prof is not None:
                 # instrumented pass (bench.py): the launch is issued prof_reps times back to back inside one HIP
                 # event pair (the result is idempotent), so the bracket holds kernel time, not host submission gaps
@@ -260,10 +293,14 @@ class UNetEngine:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
             for _ in range(reps):
-                L.check(self.lib.bfm_conv3x3x3_mfma(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(scale),
-                                                    L.ptr(shift), L.ptr(bound), ly.groups, L.ptr(ly.wpacked), ly.wexp,
-                                                    ly.cout, self.slope, self.passes, cfg, L.ptr(out), L.ptr(ws),
-                                                    ws.numel(), st), "conv_mfma " + ly.name)
+                L.check(self.lib.bfm_conv3x3x3_mfma_ex(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(scale),
+                                                       L.ptr(shift), L.ptr(bound), ly.groups, L.ptr(ly.wpacked),
+                                                       ly.wexp, ly.cout, self.slope, self.passes, cfg, L.ptr(out),
+                                                       L.ptr(ws), ws.numel(),
+                                                       L.ptr(rows[0]) if rows is not None else None, st),
+                        "conv_mfma " + ly.name)
+            if rows is not None:
+                out._bfm_rows = rows
             if ev is not None:
                 ev[1].record()
                 nv = D * H * W
@@ -273,9 +310,17 @@ class UNetEngine:
                                   (ly.name.replace("backbone.", "").replace(".basic_module.SingleConv", "."), ly.cin,
                                    ly.cout, tuple(dims), tuple(cfg))))
         elif ca == 1 and cb == 0 and ly.cout in (32, 64) and not self.force_direct:
-            L.check(self.lib.bfm_conv3x3x3_stem(L.ptr(A), D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
-                                                L.ptr(ly.wpacked), ly.cout, self.slope, L.ptr(out), st),
+            rows = None
+            if self.fuse_stats:
+                n = self.lib.bfm_conv3x3x3_stem_rows(D, H, W)
+                rows = (torch.empty(self.lib.bfm_moment_rows_bytes(n, ly.cout), dtype=torch.uint8,
+                                    device=self.device), n)
+            L.check(self.lib.bfm_conv3x3x3_stem_ex(L.ptr(A), D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
+                                                   L.ptr(ly.wpacked), ly.cout, self.slope, L.ptr(out),
+                                                   L.ptr(rows[0]) if rows is not None else None, st),
                     "conv_stem " + ly.name)
+            if rows is not None:
+                out._bfm_rows = rows
         else:
             L.check(self.lib.bfm_conv3x3x3_direct(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(scale),
                                                   L.ptr(shift), L.ptr(ly.wpacked), ly.cout, self.slope, L.ptr(out),
@@ -293,7 +338,7 @@ class UNetEngine:
             ly.skip = sk
         return ly.skip
 
-    def _single_conv_upfold(self, ly, A, dims, B, lo_dims, upp, scale, shift, bound, wsb):
+    def _single_conv_upfold(self, ly, A, dims, B, lo_dims, upp, scale, shift, bound):
         """cat((skip, up2x(x))) -> GN -> conv -> LeakyReLU as: GN stats over the virtual concat, the upsampled
         channels through bfm_conv3x3x3_upfold (8 folded taps on the low-res tensor), the skip channels through
         bfm_conv3x3x3_mfma accumulating onto that."""
@@ -304,10 +349,7 @@ class UNetEngine:
         key = (ca, ly.cout, tuple(dims))
         cfg0 = self._plan(ca, ly.cout, dims)
         wsc = self.lib.bfm_conv3x3x3_mfma_workspace(ca, ly.cout, D, H, W, cfg0[5])
-        ws = self._workspace(max(wsb, wsc))
-        L.check(self.lib.bfm_gn_stats(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(ly.gamma), L.ptr(ly.beta),
-                                      ly.groups, self.eps, L.ptr(scale), L.ptr(shift), L.ptr(bound), L.ptr(ws),
-                                      ws.numel(), st), "gn_stats " + ly.name)
+        ws = self._gn_stats(ly, A, ca, B, cb, dims, lo_dims, upp, scale, shift, bound, wsc)
         out = torch.empty((D, H, W, ly.cout), dtype=torch.float32, device=self.device)
         if "upfold" not in ly.packs:
             nbytes = self.lib.bfm_pack_conv_weights_upfold_bytes(cb, ly.cout, self.passes)
@@ -348,11 +390,15 @@ class UNetEngine:
                               (tag + "up", cb, ly.cout, tuple(dims), (0,) * 8)))
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
+        rows = self._rows_for(ca, ly.cout, dims, cfg)
         for _ in range(reps):
-            L.check(self.lib.bfm_conv3x3x3_mfma(L.ptr(A), ca, None, 0, D, H, W, None, L.ptr(scale), L.ptr(shift),
-                                                L.ptr(bound), ly.groups, L.ptr(sk.wpacked), sk.wexp, ly.cout,
-                                                self.slope, self.passes, cfg, L.ptr(out), L.ptr(ws), ws.numel(), st),
+            L.check(self.lib.bfm_conv3x3x3_mfma_ex(L.ptr(A), ca, None, 0, D, H, W, None, L.ptr(scale), L.ptr(shift),
+                                                   L.ptr(bound), ly.groups, L.ptr(sk.wpacked), sk.wexp, ly.cout,
+                                                   self.slope, self.passes, cfg, L.ptr(out), L.ptr(ws), ws.numel(),
+                                                   L.ptr(rows[0]) if rows is not None else None, st),
                     "conv_mfma " + sk.name)
+        if rows is not None:
+            out._bfm_rows = rows
         if ev is not None:
             ev[1].record()
             self.prof.append((ev[0], ev[1], 2.0 * 27 * ca * ly.cout * nv, 4.0 * (nv * ca + 2 * nv * ly.cout), reps,

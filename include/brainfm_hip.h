@@ -96,6 +96,31 @@ int bfm_conv3x3x3_stem(const float* A, int D, int H, int W, const float* scale, 
                        const float* bound, const float* wpacked_direct, int Cout, float slope, float* out,
                        bfm_stream_t stream);
 
+/* Output-moment rows.  A producer (conv3x3x3_mfma_ex / conv3x3x3_stem_ex) can write, next to its output, one row
+ * per tile of per-channel {sum, sumsq} (fp64) and {min, max} (fp32) of the values it stored: buffer of
+ * bfm_moment_rows_bytes(nrows, Cout) bytes laid out sum[nrows][C] | sumsq[nrows][C] | min[nrows][C] | max[nrows][C].
+ * The consumer's GroupNorm (nn.GroupNorm in the next SingleConv, buildingblocks.py:48-60) then reduces the rows with
+ * bfm_gn_stats_rows instead of re-reading the activation.  Deterministic: fixed reduction order, no atomics.
+ * bfm_conv3x3x3_mfma_rows returns 0 when the plan cannot emit rows (split-K or the persistent variant). */
+size_t bfm_moment_rows_bytes(int nrows, int C);
+int bfm_conv3x3x3_mfma_rows(int Cin, int Cout, int D, int H, int W, const int* cfg);
+int bfm_conv3x3x3_mfma_ex(const float* A, int CA, const float* B, int CB, int D, int H, int W,
+                          const bfm_upsample_t* up, const float* scale, const float* shift, const float* bound,
+                          int G, const void* wpacked, int wexp, int Cout, float slope, int passes, const int* cfg,
+                          float* out, void* workspace, size_t workspace_bytes, void* moment_rows /*or NULL*/,
+                          bfm_stream_t stream);
+int bfm_conv3x3x3_stem_rows(int D, int H, int W);
+int bfm_conv3x3x3_stem_ex(const float* A, int D, int H, int W, const float* scale, const float* shift,
+                          const float* bound, const float* wpacked_direct, int Cout, float slope, float* out,
+                          void* moment_rows /*or NULL*/, bfm_stream_t stream);
+/* GroupNorm scale/shift/bound from moment rows.  Source A: rowsA [nrowsA][CA]; optional source B (the low-res half of
+ * a decoder concat, every voxel replicated weightB times by the nearest upsample: 8 for an exact 2x): rowsB.
+ * nvox = voxels per channel of the normalised tensor (D*H*W of the full-res grid). */
+size_t bfm_gn_stats_rows_workspace(int nrowsA, int CA, int nrowsB, int CB);
+int bfm_gn_stats_rows(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB, double weightB,
+                      int64_t nvox, const float* gamma, const float* beta, int G, float eps, float* scale,
+                      float* shift, float* bound, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+
 size_t bfm_conv3x3x3_mfma_workspace(int Cin, int Cout, int D, int H, int W, int splitk);
 int bfm_conv3x3x3_mfma_plan(int Cin, int Cout, int D, int H, int W, int* cfg_out /*[8]*/);
 /* cfg[7] bit 0 ("accumulate"): add what `out` already holds before the LeakyReLU -- used for the skip half of a

@@ -293,6 +293,50 @@ def test_upsample_folded_decoder_conv_equals_generic_path(lo):
     assert e <= 2e-6, e
 
 
+@pytest.mark.parametrize("ver", [0, 2])
+def test_producer_moment_rows_equal_activation_moments(ver, monkeypatch):
+    """The per-tile {sum, sumsq, min, max} rows written by the stem / conv epilogues must be the moments of the
+    stored activation (sums to fp32-partial accuracy; min/max exact), and GroupNorm from rows must reproduce GroupNorm from the
+    tensors on a decoder concat (two sources, the low-res one weighted 8)."""
+    monkeypatch.setenv("BFM_CONV_VER", str(ver))
+    sd = O.random_state_dict(1, 64, 3, seed=13)
+    s = _session(sd=sd, f_maps=64, levels=3)
+    eng = s.engine
+    eng.fuse_stats = True
+    eng.use_upfold = False
+    g = torch.Generator().manual_seed(4)
+    dims = (24, 20, 36)
+    x = torch.rand(dims + (1,), generator=g).to(_dev())
+    a = eng.single_conv(eng.enc[0][0], x, dims)                  # stem: 1 -> 32
+    b = eng.single_conv(eng.enc[0][1], a, dims)                  # 32 -> 64, GroupNorm from the stem's rows
+    for t in (a, b):
+        assert hasattr(t, "_bfm_rows"), "producer did not emit moment rows"
+        buf, n = t._bfm_rows
+        c = t.shape[-1]
+        k = n * c
+        rs = buf[:k * 8].view(torch.float64).view(n, c).sum(0)
+        rq = buf[k * 8:k * 16].view(torch.float64).view(n, c).sum(0)
+        rmn = buf[k * 16:k * 20].view(torch.float32).view(n, c).min(0)[0]
+        rmx = buf[k * 20:k * 24].view(torch.float32).view(n, c).max(0)[0]
+        td = t.double().reshape(-1, c)
+        # conv epilogues sum <= 32 values per lane in fp32 before going to fp64: ~1e-7 of sum|x| worst case
+        tol_s = 2e-7 * float(td.abs().sum(0).max())
+        tol_q = 2e-7 * float((td * td).sum(0).max())
+        assert float((rs - td.sum(0)).abs().max()) <= tol_s
+        assert float((rq - (td * td).sum(0)).abs().max()) <= tol_q
+        assert torch.equal(rmn, t.reshape(-1, c).min(0)[0]) and torch.equal(rmx, t.reshape(-1, c).max(0)[0])
+    # decoder concat: skip b (64 ch, rows) + low-res tensor (128 ch, rows) upsampled exactly 2x
+    lo = (12, 10, 18)
+    p1, _ = eng.maxpool(b, dims)
+    low = eng.single_conv(eng.enc[1][1], eng.single_conv(eng.enc[1][0], p1, lo), lo)      # 64 -> 64 -> 128 @ lo
+    assert hasattr(low, "_bfm_rows")
+    ly = eng.dec[-1][0]
+    got = eng.single_conv(ly, b, dims, B=low, lo_dims=lo).clone()
+    eng.fuse_stats = False
+    ref = eng.single_conv(ly, b, dims, B=low, lo_dims=lo)
+    assert _relerr(got.cpu().numpy(), ref.cpu().numpy()) <= 1e-6
+
+
 def test_split_k_deep_layer_vs_oracle():
     """Deep-level shape (few voxels, many channels) takes the split-K path; also a concat source."""
     from brainfm_amd.engine import UNetEngine
