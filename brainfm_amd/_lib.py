@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_HERE, "libbrainfm_hip.so")
 ERR = {0: "BFM_OK", -1: "BFM_E_ARG", -2: "BFM_E_SHAPE", -3: "BFM_E_WORKSPACE", -4: "BFM_E_LAUNCH"}
 
 ROLE_PLAIN, ROLE_CT, ROLE_BIAS_LOG, ROLE_SEG, ROLE_DIST, ROLE_SR, ROLE_PATHOL = range(7)
-(EW_EXP, EW_AFFINE, EW_CLAMP, EW_CLAMP_MIN, EW_GAMMA, EW_SIGMOID, EW_DIV, EW_NONZERO, EW_SUB_DIV, EW_GE) = range(10)
+(EW_EXP, EW_AFFINE, EW_CLAMP, EW_CLAMP_MIN, EW_GAMMA, EW_SIGMOID, EW_DIV, EW_NONZERO, EW_SUB_DIV, EW_GE,
+ EW_NAN_TO_NUM) = range(11)
 (EW_ADD, EW_MUL, EW_MUL_EXP, EW_AXPY_CLAMP0, EW_AXPY, EW_DIV2) = range(6)
 
 
@@ -73,6 +74,9 @@ SIGNATURES = {
     "bfm_conv3x3x3_stem_ex": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P, _P]),
     "bfm_gn_stats_rows_workspace": (_Z, [_I, _I, _I, _I]),
     "bfm_gn_stats_rows": (_I, [_P, _I, _I, _P, _I, _I, C.c_double, _L, _P, _P, _I, _F, _P, _P, _P, _P, _Z, _P]),
+    "bfm_permute_flip3d": (_I, [_P, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _P, _P]),
+    "bfm_bbox_nonzero": (_I, [_P, _I, _I, _I, _F, _P, _P]),
+    "bfm_mean_lastdim": (_I, [_P, _L, _I, _P, _P]),
     "bfm_conv3x3x3_stem": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
     "bfm_conv3x3x3_mfma_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
     "bfm_conv3x3x3_mfma_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),

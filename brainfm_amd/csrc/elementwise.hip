@@ -27,6 +27,7 @@ __global__ void ew_unary(int op, const float* __restrict__ in, int64_t is, float
             case BFM_EW_NONZERO: r = x != 0.f ? 1.f : 0.f; break;
             case BFM_EW_SUB_DIV: r = (x - a) / b; break;
             case BFM_EW_GE: r = x >= a ? 1.f : 0.f; break;
+            case BFM_EW_NAN_TO_NUM: r = x != x ? 0.f : (x == INFINITY ? 3.402823466e+38f : (x == -INFINITY ? -3.402823466e+38f : x)); break;
             default: r = x;
         }
         out[i * os] = r;

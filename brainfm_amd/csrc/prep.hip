@@ -1,0 +1,106 @@
+// Small device kernels of the pre-processing chain around the inference path (utils/test_utils.py:235-284
+// prepare_image): axis permutation + flips of align_volume_to_ref (utils/misc.py:1207-1247), the
+// bounding box of zero_crop (utils/test_utils.py:60-72) and the channel mean of multi-frame inputs.  All HBM-bound.
+#include "bfm_common.h"
+#include <climits>
+
+namespace {
+
+struct PF {
+    int n[3];        // input dims
+    int o[3];        // output dims
+    int perm[3];
+    int flip[3];
+};
+
+__global__ void permute_flip_kernel(const float* __restrict__ in, PF p, float* __restrict__ out) {
+    const int64_t total = (int64_t)p.o[0] * p.o[1] * p.o[2];
+    const int64_t sx = (int64_t)p.n[1] * p.n[2], sy = p.n[2];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int idx[3];
+        idx[2] = (int)(i % p.o[2]);
+        const int64_t t = i / p.o[2];
+        idx[1] = (int)(t % p.o[1]);
+        idx[0] = (int)(t / p.o[1]);
+        int j[3] = {0, 0, 0};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) j[p.perm[a]] = p.flip[a] ? p.o[a] - 1 - idx[a] : idx[a];
+        out[i] = in[j[0] * sx + j[1] * sy + j[2]];
+    }
+}
+
+__global__ void bbox_init_kernel(int32_t* box) {
+    if (threadIdx.x < 3) box[threadIdx.x] = INT_MAX;
+    else if (threadIdx.x < 6) box[threadIdx.x] = 0;
+}
+
+// integer min/max atomics: the result does not depend on the order of arrival
+__global__ void bbox_kernel(const float* __restrict__ in, int nx, int ny, int nz, float tol, int32_t* box) {
+    const int64_t total = (int64_t)nx * ny * nz;
+    int lo[3] = {INT_MAX, INT_MAX, INT_MAX}, hi[3] = {0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (in[i] > tol) {
+            const int z = (int)(i % nz);
+            const int64_t t = i / nz;
+            const int y = (int)(t % ny);
+            const int x = (int)(t / ny);
+            lo[0] = min(lo[0], x); lo[1] = min(lo[1], y); lo[2] = min(lo[2], z);
+            hi[0] = max(hi[0], x + 1); hi[1] = max(hi[1], y + 1); hi[2] = max(hi[2], z + 1);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        int l = lo[a], h = hi[a];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            l = min(l, __shfl_xor(l, m));
+            h = max(h, __shfl_xor(h, m));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (l != INT_MAX) atomicMin(&box[a], l);
+            if (h != 0) atomicMax(&box[3 + a], h);
+        }
+    }
+}
+
+__global__ void mean_lastdim_kernel(const float* __restrict__ in, int64_t n, int c, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int j = 0; j < c; ++j) s += in[i * c + j];
+        out[i] = s / (float)c;
+    }
+}
+
+int grid_for(int64_t n) { return (int)std::min<int64_t>(4096, bfm_cdiv64(n, 256)); }
+
+}  // namespace
+
+extern "C" int bfm_permute_flip3d(const float* in, int nx, int ny, int nz, const int* perm, const int* flip, float* out,
+                                  bfm_stream_t stream) {
+    if (!in || !out || !perm || !flip || nx <= 0 || ny <= 0 || nz <= 0) return BFM_E_ARG;
+    int seen[3] = {0, 0, 0};
+    for (int a = 0; a < 3; ++a) {
+        if (perm[a] < 0 || perm[a] > 2 || seen[perm[a]]) return BFM_E_ARG;
+        seen[perm[a]] = 1;
+    }
+    PF p;
+    p.n[0] = nx; p.n[1] = ny; p.n[2] = nz;
+    for (int a = 0; a < 3; ++a) { p.perm[a] = perm[a]; p.flip[a] = flip[a] ? 1 : 0; p.o[a] = p.n[perm[a]]; }
+    const int64_t n = (int64_t)nx * ny * nz;
+    hipLaunchKernelGGL(permute_flip_kernel, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), in, p, out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_bbox_nonzero(const float* in, int nx, int ny, int nz, float tol, int32_t* box, bfm_stream_t stream) {
+    if (!in || !box || nx <= 0 || ny <= 0 || nz <= 0) return BFM_E_ARG;
+    hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, bfm_s(stream), box);
+    const int64_t n = (int64_t)nx * ny * nz;
+    hipLaunchKernelGGL(bbox_kernel, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), in, nx, ny, nz, tol, box);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_mean_lastdim(const float* in, int64_t n, int c, float* out, bfm_stream_t stream) {
+    if (!in || !out || n <= 0 || c <= 0) return BFM_E_ARG;
+    hipLaunchKernelGGL(mean_lastdim_kernel, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), in, n, c, out);
+    return bfm_launch_status();
+}

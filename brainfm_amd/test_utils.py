@@ -19,6 +19,8 @@ import torch
 
 from . import _lib as L
 from . import cfg as _cfg
+from . import generator_utils as GU
+from . import misc as MI
 from . import models as M
 from .engine import UNetEngine
 
@@ -53,8 +55,17 @@ def default_inference_args(f_maps=64, num_levels=6, left_hemis_only=False, size=
 
 # ----------------------------------------------------------------------------- tiling (host logic)
 def zero_crop(orig, tol=0, crop_range_lst=None):
-    """utils/test_utils.py:60-90."""
-    if crop_range_lst is None:
+    """utils/test_utils.py:60-90.  On the device the bounding box of (orig > tol) comes from one reduction kernel
+    instead of torch.argwhere's coordinate list."""
+    if crop_range_lst is None and orig.is_cuda and orig.dim() == 3:
+        src = orig.to(torch.float32).contiguous()
+        box = torch.empty(6, dtype=torch.int32, device=orig.device)
+        L.check(L.load().bfm_bbox_nonzero(L.ptr(src), src.shape[0], src.shape[1], src.shape[2], float(tol), L.ptr(box),
+                                          L.stream_ptr()), "bbox_nonzero")
+        x0, y0, z0, x1, y1, z1 = [int(v) for v in box.tolist()]
+        if x0 > x1:
+            raise RuntimeError("zero_crop: no voxel above tol")      # the reference's argwhere().min() raises here too
+    elif crop_range_lst is None:
         coords = torch.argwhere(orig > tol)
         x0, y0, z0 = coords.min(dim=0)[0]
         x1, y1, z1 = coords.max(dim=0)[0] + 1
@@ -135,6 +146,106 @@ def center_crop(img, win_size=[220, 220, 220], zero_crop_first=False, aff=np.eye
     if permuted:
         return torch.permute(img, (0, 2, 3, 4, 1)), [0, 0, 0], orig_shp, aff
     return img, [0, 0, 0], orig_shp, aff
+
+
+# ----------------------------------------------------------------------------- prepare_image
+_VOLUME_READER = None
+
+
+def set_volume_reader(fn):
+    """Register ``fn(path, im_only=False, dtype='float') -> (ndarray, affine)``: the one host-side hook the reference
+    fills with utils.misc.MRIread (nibabel); file formats are outside this package."""
+    global _VOLUME_READER
+    _VOLUME_READER = fn
+
+
+def _read_volume(img, is_label):
+    if isinstance(img, (tuple, list)) and len(img) == 2:
+        return np.asarray(img[0]), np.asarray(img[1], dtype=np.float64)
+    if _VOLUME_READER is None:
+        raise L.BfmError("prepare_image got a path but no volume reader is registered: call "
+                         "brainfm_amd.test_utils.set_volume_reader(utils.misc.MRIread) or pass (array, affine)")
+    return _VOLUME_READER(img, im_only=False, dtype="int" if is_label else "float")
+
+
+def add_bias_field(I, bf_scale_min=0.02, bf_scale_max=0.04, bf_std_min=0.1, bf_std_max=0.6, device="cpu"):
+    """utils/test_utils.py:191-199 (test-time variant: draws its own field)."""
+    bf_scale = bf_scale_min + np.random.rand(1) * (bf_scale_max - bf_scale_min)
+    size_BF_small = np.round(bf_scale * np.array(I.shape)).astype(int).tolist()
+    amp = float(np.float32(bf_std_min + (bf_std_max - bf_std_min) * np.random.rand(1))[0])
+    noise = torch.randn(size_BF_small, dtype=torch.float).to(I.device)    # host generator: same stream as the reference on CPU
+    BFsmall = GU.ew_unary(L.EW_AFFINE, noise, amp, 0.0)
+    BFlog = GU.myzoom_torch(BFsmall, np.array(I.shape) / size_BF_small)
+    BF = GU.ew_unary(L.EW_EXP, BFlog)
+    I_bf = GU.ew_binary(L.EW_MUL, I.to(torch.float32), BF)
+    return I_bf, BF
+
+
+def resample(I, orig_res=[1., 1., 1.], new_res=[1., 1., 1.]):
+    """utils/test_utils.py:201-224: sample on the coarse grid, zoom back to the original size."""
+    if not isinstance(orig_res, list):
+        orig_res = [orig_res, orig_res, orig_res]
+    if not isinstance(new_res, list):
+        new_res = [new_res, new_res, new_res]
+    resolution = np.array(new_res)
+    new_size = (np.array(I.shape) * orig_res / resolution).astype(int)
+    factors = np.array(new_size) / np.array(I.shape)
+    delta = (1.0 - factors) / (2.0 * factors)
+    v = [np.arange(delta[a], delta[a] + new_size[a] / factors[a], 1 / factors[a])[:new_size[a]] for a in range(3)]
+    II, JJ, KK = np.meshgrid(v[0], v[1], v[2], sparse=False, indexing="ij")
+    II = torch.tensor(II, dtype=torch.float, device=I.device)
+    JJ = torch.tensor(JJ, dtype=torch.float, device=I.device)
+    KK = torch.tensor(KK, dtype=torch.float, device=I.device)
+    I_resize = GU.fast_3D_interp_torch(I, II, JJ, KK, "linear")
+    return GU.myzoom_torch(I_resize, 1 / factors)
+
+
+def prepare_image(img_path, win_size=None, zero_crop_first=False, spacing=None, add_bf=False, is_CT=False,
+                  is_label=False, rescale=True, hemis_mask=None, im_only=False, device="cuda"):
+    """utils/test_utils.py:235-284 with every array operation on the device.  ``img_path`` is a path (needs
+    set_volume_reader) or an in-memory ``(array, affine)`` pair.  Returns what the reference returns:
+    final, orig, high_res, bf, aff, crop_start, orig_shp."""
+    device = _resolve_device(device)
+    if torch.device(device).type != "cuda":
+        raise L.BfmError("prepare_image runs on a HIP device only; there is no CPU fallback in the product path")
+    im, aff = _read_volume(img_path, is_label)
+    aff = np.array(aff, dtype=np.float64)
+    im = torch.as_tensor(np.squeeze(im), dtype=torch.int if is_label else torch.float32).to(device)
+    lib = L.load()
+    st = L.stream_ptr
+    if not is_label:
+        im = GU.ew_unary(L.EW_NAN_TO_NUM, im)
+    if im.dim() > 3:                                         # averaging the RGB / frames
+        flat = im.to(torch.float32).contiguous()
+        n = flat.numel() // flat.shape[-1]
+        out = torch.empty(flat.shape[:-1], dtype=torch.float32, device=flat.device)
+        L.check(lib.bfm_mean_lastdim(L.ptr(flat), n, flat.shape[-1], L.ptr(out), st()), "mean_lastdim")
+        im = out
+    if is_CT and rescale:
+        im = GU.ew_unary(L.EW_CLAMP, im, 0.0, 80.0)
+    if not is_label and rescale:
+        im = GU.ew_unary(L.EW_AFFINE, im, 1.0, -float(GU.tensor_min(im)))
+        im = GU.ew_unary(L.EW_DIV, im, float(GU.tensor_max(im)))
+    im, aff = MI.torch_resize(im, aff, 1.)
+    orig, aff_before_crop = MI.align_volume_to_ref(im, aff, aff_ref=np.eye(4), return_aff=True, n_dims=3)
+    orig, crop_start, orig_shp, aff = center_crop(orig, win_size, zero_crop_first=zero_crop_first, aff=aff_before_crop)
+    if add_bf and not is_CT:
+        high_res, bf = add_bias_field(im, device=device)
+        bf, _ = MI.align_volume_to_ref(bf, aff_before_crop, aff_ref=np.eye(4), return_aff=True, n_dims=3)
+        bf, crop_start, orig_shp, _ = center_crop(bf, win_size, zero_crop_first=zero_crop_first, aff=aff_before_crop)
+    else:
+        high_res, bf = im, None
+    final = resample(high_res, new_res=spacing) if spacing is not None else high_res
+    high_res, _ = MI.align_volume_to_ref(high_res, aff_before_crop, aff_ref=np.eye(4), return_aff=True, n_dims=3)
+    high_res, crop_start, orig_shp, _ = center_crop(high_res, win_size, zero_crop_first=zero_crop_first,
+                                                    aff=aff_before_crop)
+    final, _ = MI.align_volume_to_ref(final, aff_before_crop, aff_ref=np.eye(4), return_aff=True, n_dims=3)
+    final, crop_start, orig_shp, _ = center_crop(final, win_size, zero_crop_first=zero_crop_first, aff=aff_before_crop)
+    if hemis_mask is not None:
+        final[hemis_mask == 0] = 0
+    if im_only:
+        return final
+    return final, orig, high_res, bf, aff, crop_start, orig_shp
 
 
 # ----------------------------------------------------------------------------- deformed atlas

@@ -228,7 +228,8 @@ enum {
     BFM_EW_EXP = 0, BFM_EW_AFFINE = 1 /* x*a+b */, BFM_EW_CLAMP = 2 /* [a,b] */, BFM_EW_CLAMP_MIN = 3,
     BFM_EW_GAMMA = 4 /* a*(x/a)^b, add_gamma_transform utils.py:568-572 */, BFM_EW_SIGMOID = 5,
     BFM_EW_DIV = 6 /* x/a */, BFM_EW_NONZERO = 7 /* x!=0 ? 1:0 */, BFM_EW_SUB_DIV = 8 /* (x-a)/b */,
-    BFM_EW_GE = 9 /* x>=a ? 1:0, binarize utils.py:65-72 */
+    BFM_EW_GE = 9 /* x>=a ? 1:0, binarize utils.py:65-72 */,
+    BFM_EW_NAN_TO_NUM = 10 /* torch.nan_to_num defaults, utils/test_utils.py:239 */
 };
 enum {
     BFM_EW_ADD = 0, BFM_EW_MUL = 1, BFM_EW_MUL_EXP = 2 /* x*exp(y), add_bias_field utils.py:585-587 */,
@@ -271,6 +272,18 @@ int bfm_zoom_linear(const float* X, int nx, int ny, int nz, int C, const bfm_zoo
 /* one axis of gaussian_blur_3d -- Generator/utils.py:84-94: zero-padded 1-D correlation, odd kernel. */
 int bfm_conv1d_axis(const float* in, int nx, int ny, int nz, int axis, const float* kern, int klen, float* out,
                     bfm_stream_t stream);
+/* Pre-processing around the inference path (utils/test_utils.py:235-284 prepare_image).
+ * permute_flip3d: align_volume_to_ref's swapaxes + flips (utils/misc.py:1207-1247) in one gather:
+ *   out dims = (n[perm[0]], n[perm[1]], n[perm[2]]); out[i0,i1,i2] = in[j], j[perm[a]] = flip[a] ? n[perm[a]]-1-ia : ia.
+ * bbox_nonzero: zero_crop's torch.argwhere(x > tol) min/max (utils/test_utils.py:60-72): box[6] = {x0,y0,z0,x1,y1,z1}
+ *   (x1 exclusive); all-background volumes give x0 > x1.
+ * mean_lastdim: im.mean(dim=-1) for multi-frame inputs (utils/test_utils.py:243). */
+int bfm_permute_flip3d(const float* in, int nx, int ny, int nz, const int* perm /*[3] host*/,
+                       const int* flip /*[3] host*/, float* out, bfm_stream_t stream);
+int bfm_bbox_nonzero(const float* in, int nx, int ny, int nz, float tol, int32_t* box /*[6] device*/,
+                     bfm_stream_t stream);
+int bfm_mean_lastdim(const float* in, int64_t n, int c, float* out, bfm_stream_t stream);
+
 /* interpol.grid_pull(interpolation='linear') -> iso1.pull3d -- utils/interpol/iso1.py:28-133.
  * inp (Bi,C,nx,ny,nz), grid (Bg,ox,oy,oz,3), out (max(Bi,Bg),C,ox,oy,oz); bound[3] in 0..6
  * (zero, replicate, dct1, dct2, dst1, dst2, dft -- bounds.py:8-15); extrapolate 0 no / 1 yes / 2 hist. */

@@ -199,3 +199,35 @@ def test_distributed_tiling_two_ranks_bitwise_equals_single():
     for k in ops.keys:
         acc[k] /= cnt
         assert np.array_equal(res[k], acc[k].numpy()), k
+
+
+def test_prepare_image_host_plans_match_reference():
+    """Host halves of the pre-processing chain against vectors from the reference's torch_resize /
+    align_volume_to_ref: target size, aligned affine, axis permutation + flips reproduced with numpy on the golden
+    resized volume, and the centre-crop origin."""
+    from brainfm_amd import misc as MI
+    from brainfm_amd import test_utils as TU
+    d = load_npz("prep_image.npz")
+    for name in ("A", "B", "C"):
+        vol, aff = d[name + "/vol"], d[name + "/aff"]
+        newsize, sigmas = MI.resize_plan(vol.shape, aff, 1.0)
+        assert tuple(newsize) == d[name + "/resized"].shape
+        if name == "C":
+            assert (sigmas > 0).all()                        # 0.7/0.8 mm -> 1 mm is a down-sampling: pre-blur on
+        perm, flip, aff_al = MI.align_plan(d[name + "/resized"].shape, d[name + "/aff_resized"], np.eye(4))
+        assert np.allclose(aff_al, d[name + "/aff_aligned"], rtol=0, atol=1e-12)
+        al = np.transpose(d[name + "/resized"], perm)
+        for a in range(3):
+            if flip[a]:
+                al = np.flip(al, a)
+        assert np.array_equal(al, d[name + "/aligned"])
+    # anisotropic zoom tables: lengths and clamping
+    f, c, wf, wc = MI.aniso_zoom_tables(22, 44)
+    assert len(f) == 44 and f.min() == 0 and c.max() == 21 and np.allclose(wf + wc, 1)
+    # centre crop bookkeeping (indexing only, CPU tensors are fine here)
+    al = torch.from_numpy(d["A/aligned"].copy())
+    # (prepare_image's returned crop_start / affine belong to its LAST crop, of the un-aligned `final`, and the
+    # affine object is shifted in place by every crop: reference quirk, reproduced end to end in the GPU test)
+    crop, start, shp, aff_out = TU.center_crop(al, [32, 32, 32], aff=d["A/aff_aligned"].copy())
+    assert list(start) == [(al.shape[i] - 32) // 2 for i in range(3)] and tuple(shp) == tuple(al.shape)
+    assert np.array_equal(crop[0, 0].numpy(), d["A/orig"][0, 0])
