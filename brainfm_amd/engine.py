@@ -135,11 +135,20 @@ class UNetEngine:
 
     def _pack(self, ly, mfma, ver=0):
         """Pack (once per layout) and select the weights for this launch: 'direct' [27][Cin][Cout] fp32,
-        'mfma' 32x32x16 fragments (plan variants 0/1), 'mfma16' 16x16x32 tap-pair fragments (variant 2)."""
-        layout = "direct" if not mfma else ("mfma16" if ver == 2 else "mfma")
+        'mfma' 32x32x16 fragments (plan variants 0/1), 'mfma16' 16x16x32 tap-pair fragments (variant 2),
+        'wino' F(2,3)-along-x transformed fragments (variant 3, single-source layers only)."""
+        layout = "direct" if not mfma else ("wino" if ver == 3 else ("mfma16" if ver == 2 else "mfma"))
         if layout not in ly.packs:
             st = L.stream_ptr()
-            if mfma:
+            if layout == "wino":
+                nbytes = self.lib.bfm_pack_conv_weights_wino_bytes(ly.cin, ly.cout, self.passes)
+                buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+                wexp = C.c_int(0)
+                wmax = float(ly.w_raw.abs().max().item())
+                L.check(self.lib.bfm_pack_conv_weights_wino(L.ptr(ly.w_raw), ly.cin, ly.cout, wmax, self.passes,
+                                                            L.ptr(buf), C.byref(wexp), st), "pack_wino " + ly.name)
+                ly.packs[layout] = (buf, wexp.value)
+            elif mfma:
                 fn_b = self.lib.bfm_pack_conv_weights_mfma16_bytes if ver == 2 else self.lib.bfm_pack_conv_weights_mfma_bytes
                 fn_p = self.lib.bfm_pack_conv_weights_mfma16 if ver == 2 else self.lib.bfm_pack_conv_weights_mfma
                 buf = torch.empty(fn_b(ly.cin, ly.cout), dtype=torch.uint8, device=self.device)
@@ -173,24 +182,26 @@ class UNetEngine:
             self._ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def _plan(self, cin, cout, dims):
-        key = (cin, cout, tuple(dims))
+    def _plan(self, cin, cout, dims, two_src=False, accum=False):
+        key = (cin, cout, tuple(dims), bool(two_src), bool(accum))
         if key not in self._plan_cache:
             cfg = (C.c_int * 8)()
             L.check(self.lib.bfm_conv3x3x3_mfma_plan(cin, cout, dims[0], dims[1], dims[2], cfg), "mfma_plan")
+            if two_src and cfg[6] == 3:                          # BFM_CONV_VER=3: Winograd takes one source
+                cfg[6] = 0
             self._plan_cache[key] = cfg
         return self._plan_cache[key]
 
     def _autotune(self, ly, key, launch):
-        """Pick the fastest of the three conv_mfma variants for this (Cin, Cout, dims) by timing them once on the
-        real operands (HIP events on the launch stream).  All variants compute the same result; the chip is
+        """Pick the fastest conv variant (0 conv_mfma, 1 conv_mfma_ws, 2 conv_mfma16, 3 conv_wino) for this
+        (Cin, Cout, dims, two-source) by timing them once on the real operands (HIP events on the launch stream).  All variants compute the same result; the chip is
         power-limited on this kernel, so which one wins is shape dependent (profiles/).  BFM_CONV_VER pins one."""
         import os
         cfg = self._plan_cache[key]
         if key in self._tuned or os.environ.get("BFM_CONV_VER") or os.environ.get("BFM_CONV_TUNE", "1") == "0":
             return cfg
         best, best_ms = cfg[6], None
-        for ver in (0, 1, 2):
+        for ver in ((0, 1, 2) if key[3] else (0, 1, 2, 3)):       # Winograd: single-source layers only
             trial = (C.c_int * 8)(*list(cfg))
             trial[6] = ver
             try:
@@ -238,6 +249,25 @@ class UNetEngine:
                                       ws.numel(), st), "gn_stats " + ly.name)
         return ws
 
+    def _conv_launch(self, ly, A, ca, B, cb, dims, upp, scale, shift, bound, groups, cfg, out, ws, rows=None):
+        """One launch of the planned variant of GN-apply + conv + LeakyReLU (cfg[6]: 0/1/2 conv_mfma family,
+        3 Winograd; cfg[7] bit 0: accumulate onto `out`)."""
+        D, H, W = dims
+        st = L.stream_ptr()
+        self._pack(ly, True, cfg[6])
+        if cfg[6] == 3:
+            if cb:
+                raise L.BfmError("the Winograd variant takes one source")
+            L.check(self.lib.bfm_conv3x3x3_wino(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound), groups,
+                                                L.ptr(ly.wpacked), ly.wexp, ly.cout, self.slope, self.passes,
+                                                cfg[7] & 1, L.ptr(out), st), "conv_wino " + ly.name)
+            return
+        L.check(self.lib.bfm_conv3x3x3_mfma_ex(L.ptr(A), ca, L.ptr(B) if cb else None, cb, D, H, W, upp if cb else None,
+                                               L.ptr(scale), L.ptr(shift), L.ptr(bound), groups, L.ptr(ly.wpacked),
+                                               ly.wexp, ly.cout, self.slope, self.passes, cfg, L.ptr(out), L.ptr(ws),
+                                               ws.numel(), L.ptr(rows[0]) if rows is not None else None, st),
+                "conv_mfma " + ly.name)
+
     def _rows_for(self, cin, cout, dims, cfg):
         """(buffer, nrows) for the producer's output-moment rows, or None when this plan cannot emit them."""
         if not self.fuse_stats:
@@ -269,18 +299,14 @@ class UNetEngine:
         cfg = None
         wsc = 0
         if mfma:
-            cfg = self._plan(ly.cin, ly.cout, dims)
+            cfg = self._plan(ly.cin, ly.cout, dims, B is not None)
             wsc = self.lib.bfm_conv3x3x3_mfma_workspace(ly.cin, ly.cout, D, H, W, cfg[5])
         ws = self._gn_stats(ly, A, ca, B, cb, dims, lo_dims, upp, scale, shift, bound, wsc)
         out = torch.empty((D, H, W, ly.cout), dtype=torch.float32, device=self.device)
         if mfma:
             def _launch(c):
-                self._pack(ly, True, c[6])
-                L.check(self.lib.bfm_conv3x3x3_mfma(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(scale),
-                                                    L.ptr(shift), L.ptr(bound), ly.groups, L.ptr(ly.wpacked), ly.wexp,
-                                                    ly.cout, self.slope, self.passes, c, L.ptr(out), L.ptr(ws),
-                                                    ws.numel(), st), "conv_mfma " + ly.name)
-            cfg = self._autotune(ly, (ly.cin, ly.cout, tuple(dims)), _launch)
+                self._conv_launch(ly, A, ca, B, cb, dims, upp, scale, shift, bound, ly.groups, c, out, ws)
+            cfg = self._autotune(ly, (ly.cin, ly.cout, tuple(dims), B is not None, False), _launch)
         self._pack(ly, mfma, cfg[6] if cfg is not None else 0)
         if mfma:
             ev = None
@@ -293,12 +319,7 @@ class UNetEngine:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
             for _ in range(reps):
-                L.check(self.lib.bfm_conv3x3x3_mfma_ex(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(scale),
-                                                       L.ptr(shift), L.ptr(bound), ly.groups, L.ptr(ly.wpacked),
-                                                       ly.wexp, ly.cout, self.slope, self.passes, cfg, L.ptr(out),
-                                                       L.ptr(ws), ws.numel(),
-                                                       L.ptr(rows[0]) if rows is not None else None, st),
-                        "conv_mfma " + ly.name)
+                self._conv_launch(ly, A, ca, B, cb, dims, upp, scale, shift, bound, ly.groups, cfg, out, ws, rows)
             if rows is not None:
                 out._bfm_rows = rows
             if ev is not None:
@@ -346,8 +367,9 @@ class UNetEngine:
         ca, cb = A.shape[-1], B.shape[-1]
         st = L.stream_ptr()
         sk = self._skip_layer(ly, ca)
-        key = (ca, ly.cout, tuple(dims))
-        cfg0 = self._plan(ca, ly.cout, dims)
+        key = (ca, ly.cout, tuple(dims), False, True)           # tuned in accumulate mode (its epilogue differs)
+        cfg0 = self._plan(ca, ly.cout, dims, False, True)
+        cfg0[7] = 1
         wsc = self.lib.bfm_conv3x3x3_mfma_workspace(ca, ly.cout, D, H, W, cfg0[5])
         ws = self._gn_stats(ly, A, ca, B, cb, dims, lo_dims, upp, scale, shift, bound, wsc)
         out = torch.empty((D, H, W, ly.cout), dtype=torch.float32, device=self.device)
@@ -362,14 +384,8 @@ class UNetEngine:
         wup, wexp_up = ly.packs["upfold"]
 
         def _launch_skip(c):
-            self._pack(sk, True, c[6])
-            L.check(self.lib.bfm_conv3x3x3_mfma(L.ptr(A), ca, None, 0, D, H, W, None, L.ptr(scale), L.ptr(shift),
-                                                L.ptr(bound), ly.groups, L.ptr(sk.wpacked), sk.wexp, ly.cout,
-                                                self.slope, self.passes, c, L.ptr(out), L.ptr(ws), ws.numel(), st),
-                    "conv_mfma " + sk.name)
-        cfg0 = self._autotune(sk, key, _launch_skip)           # trials write plain results; overwritten below
-        cfg = (C.c_int * 8)(*list(cfg0))
-        cfg[7] = 1                                              # accumulate onto the upsampled half
+            self._conv_launch(sk, A, ca, None, 0, dims, None, scale, shift, bound, ly.groups, c, out, ws)
+        cfg = self._autotune(sk, key, _launch_skip)             # trials accumulate onto garbage; overwritten below
         self._pack(sk, True, cfg[6])
         sc_b, sh_b = scale[ca:], shift[ca:]
         nv = D * H * W
@@ -392,11 +408,7 @@ class UNetEngine:
             ev[0].record()
         rows = self._rows_for(ca, ly.cout, dims, cfg)
         for _ in range(reps):
-            L.check(self.lib.bfm_conv3x3x3_mfma_ex(L.ptr(A), ca, None, 0, D, H, W, None, L.ptr(scale), L.ptr(shift),
-                                                   L.ptr(bound), ly.groups, L.ptr(sk.wpacked), sk.wexp, ly.cout,
-                                                   self.slope, self.passes, cfg, L.ptr(out), L.ptr(ws), ws.numel(),
-                                                   L.ptr(rows[0]) if rows is not None else None, st),
-                    "conv_mfma " + sk.name)
+            self._conv_launch(sk, A, ca, None, 0, dims, None, scale, shift, bound, ly.groups, cfg, out, ws, rows)
         if rows is not None:
             out._bfm_rows = rows
         if ev is not None:

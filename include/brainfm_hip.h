@@ -96,6 +96,17 @@ int bfm_conv3x3x3_stem(const float* A, int D, int H, int W, const float* scale, 
                        const float* bound, const float* wpacked_direct, int Cout, float slope, float* out,
                        bfm_stream_t stream);
 
+/* Winograd F(2,3)-along-x variant of the single-source 3x3x3 conv (SingleConv 'gcl', buildingblocks.py:31-60):
+ * 4 transformed positions x 9 (kd,kh) taps for every pair of x-neighbouring outputs = 1.5x fewer matrix-core FLOPs
+ * than bfm_conv3x3x3_mfma, same split-fp16 products, fp32 transforms (fp32-grade, not bit-identical to _mfma).
+ * No second source, no split-K; `accumulate` as cfg[7] bit 0 of _mfma.  Weights packed by _pack_conv_weights_wino. */
+size_t bfm_pack_conv_weights_wino_bytes(int Cin, int Cout, int passes);
+int bfm_pack_conv_weights_wino(const float* w_oidhw, int Cin, int Cout, float wmax_abs_host, int passes, void* wpacked,
+                               int* wexp_host, bfm_stream_t stream);
+int bfm_conv3x3x3_wino(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
+                       const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
+                       int accumulate, float* out, bfm_stream_t stream);
+
 /* Output-moment rows.  A producer (conv3x3x3_mfma_ex / conv3x3x3_stem_ex) can write, next to its output, one row
  * per tile of per-channel {sum, sumsq} (fp64) and {min, max} (fp32) of the values it stored: buffer of
  * bfm_moment_rows_bytes(nrows, Cout) bytes laid out sum[nrows][C] | sumsq[nrows][C] | min[nrows][C] | max[nrows][C].

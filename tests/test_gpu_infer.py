@@ -337,6 +337,45 @@ def test_producer_moment_rows_equal_activation_moments(ver, monkeypatch):
     assert _relerr(got.cpu().numpy(), ref.cpu().numpy()) <= 1e-6
 
 
+@pytest.mark.parametrize("dims", [(8, 8, 32), (7, 9, 21), (12, 5, 10)])
+def test_winograd_variant_equals_direct_variant(dims, monkeypatch):
+    """conv_wino (F(2,3) along x, 1.5x fewer MFMAs) against conv_mfma on the same operands, including odd widths
+    (a pair whose second voxel is outside), boxes that do not divide the volume, and accumulate mode."""
+    sd = O.random_state_dict(1, 64, 3, seed=17)
+    s = _session(sd=sd, f_maps=64, levels=3)
+    eng = s.engine
+    eng.fuse_stats = False
+    ly = eng.dec[-1][1]                                     # 64 -> 64, single source
+    g = torch.Generator().manual_seed(8)
+    A = (torch.randn(dims + (64,), generator=g) * 1.7 + 0.2).to(_dev())
+    monkeypatch.setenv("BFM_CONV_VER", "0")
+    ref = eng.single_conv(ly, A, dims).clone()
+    eng._plan_cache.clear()
+    monkeypatch.setenv("BFM_CONV_VER", "3")
+    got = eng.single_conv(ly, A, dims)
+    assert "wino" in ly.packs
+    e = _relerr(got.cpu().numpy(), ref.cpu().numpy())
+    assert e <= 5e-6, e
+    # accumulate mode: out <- LeakyReLU(conv + out_before)
+    import ctypes as C
+    from brainfm_amd import _lib as L
+    D, H, W = dims
+    scale = torch.rand(64, device=_dev()) + 0.5
+    shift = torch.randn(64, device=_dev()) * 0.1
+    bound = torch.full((ly.groups,), 8.0, device=_dev())
+    prev = torch.randn(dims + (64,), generator=g).to(_dev())
+    outs = []
+    for ver in (0, 3):
+        cfg = (C.c_int * 8)()
+        L.check(eng.lib.bfm_conv3x3x3_mfma_plan(64, 64, D, H, W, cfg), "plan")
+        cfg[6], cfg[7] = ver, 1
+        o = prev.clone()
+        ws = torch.empty(1 << 20, dtype=torch.uint8, device=_dev())
+        eng._conv_launch(ly, A, 64, None, 0, dims, None, scale, shift, bound, ly.groups, cfg, o, ws)
+        outs.append(o)
+    assert _relerr(outs[1].cpu().numpy(), outs[0].cpu().numpy()) <= 5e-6
+
+
 def test_split_k_deep_layer_vs_oracle():
     """Deep-level shape (few voxels, many channels) takes the split-K path; also a concat source."""
     from brainfm_amd.engine import UNetEngine
