@@ -19,6 +19,7 @@
 // applies LeakyReLU and stores 128-byte row segments.  Single-source inputs only (CB == 0), no split-K.
 #include "bfm_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -66,6 +67,8 @@ template <int NPASS>
 __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
     constexpr int NPL = (NPASS == 3) ? 2 : 1;
     constexpr int NF = 2 * NPL;
+    constexpr int BATCH = (NPASS == 3) ? 1 : 3;      // staging items loaded together (register budget: 128 accumulators)
+    constexpr int NSET = 3;                           // weight register sets: NSET-1 taps ahead
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -148,16 +151,17 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
     // ring of three register sets, two steps ahead (9 % 3 == 0: the set index is the tap index mod 3)
     const int S = p.KCN * 9;
     const uint4* wbase = p.wp + (size_t)(nt * 4 + pos) * S * (NF * 64) + lane;
-    uint4 wq[3][NF];
+    uint4 wq[NSET][NF];
     auto fetch = [&](int s, uint4 (&dst)[NF]) __attribute__((always_inline)) {
         const int sc = s < S ? s : S - 1;
 #pragma unroll
         for (int f = 0; f < NF; ++f) dst[f] = wbase[(size_t)sc * (NF * 64) + f * 64];
     };
     fetch(0, wq[0]);
-    fetch(1, wq[1]);
+    if constexpr (NSET == 3) fetch(1, wq[1]);
 
-    for (int kc = 0; kc < p.KCN; ++kc) {
+    auto do_chunk = [&](int kc, auto par_tag) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_tag)::value;
         const int c0 = kc * KC;
         const float* src = p.A + c0 + q4 * 4;
         const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + c0 + q4 * 4);
@@ -165,42 +169,55 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
         const float sc[4] = {sc4.x * a_scale, sc4.y * a_scale, sc4.z * a_scale, sc4.w * a_scale};
         const float sh[4] = {sh4.x * a_scale, sh4.y * a_scale, sh4.z * a_scale, sh4.w * a_scale};
         __syncthreads();                                 // previous chunk's readers are done
+        // batches of BATCH items: all global loads of a batch are in flight before the first is consumed
 #pragma unroll
-        for (int it = 0; it < MAX_IT; ++it) {
-            if (msk[it] < 0) continue;
-            float4 v[4];
+        for (int b0 = 0; b0 < MAX_IT; b0 += BATCH) {
+            float4 v[BATCH][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (msk[it] & (1 << i)) v[i] = *reinterpret_cast<const float4*>(src + off0[it] + i * p.CA);
-            }
-            float dd[4][4];                              // [x position][channel]: affine, zero padding after it
+            for (int u = 0; u < BATCH; ++u) {
+                const int it = b0 + u;
+                if (it >= MAX_IT) break;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool ok = msk[it] & (1 << i);
-                const float y[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) dd[i][c] = ok ? fmaf(y[c], sc[c], sh[c]) : 0.f;
-            }
-            const int e = tid + it * NTHR;
-            unsigned char* dst = lds + st_plane + (e >> 2) * 16;
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                half4 hi, lo;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float t = ps == 0 ? dd[0][c] - dd[2][c]
-                                  : ps == 1 ? dd[1][c] + dd[2][c]
-                                  : ps == 2 ? dd[2][c] - dd[1][c]
-                                            : dd[1][c] - dd[3][c];
-                    const _Float16 hh = (_Float16)t;
-                    hi[c] = hh;
-                    lo[c] = (_Float16)(t - (float)hh);
+                for (int i = 0; i < 4; ++i) {
+                    v[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (msk[it] >= 0 && (msk[it] & (1 << i)))
+                        v[u][i] = *reinterpret_cast<const float4*>(src + off0[it] + i * p.CA);
                 }
-                unsigned char* dp = dst + (ps * 2 * NPL) * p.plane_stride;
-                *reinterpret_cast<half4*>(dp) = hi;
-                if constexpr (NPASS == 3) *reinterpret_cast<half4*>(dp + p.plane_stride) = lo;
             }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int it = b0 + u;
+                if (it >= MAX_IT) break;
+                if (msk[it] < 0) continue;
+                float dd[4][4];                          // [x position][channel]: affine, zero padding after it
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ok = msk[it] & (1 << i);
+                    const float y[4] = {v[u][i].x, v[u][i].y, v[u][i].z, v[u][i].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dd[i][c] = ok ? fmaf(y[c], sc[c], sh[c]) : 0.f;
+                }
+                const int e = tid + it * NTHR;
+                unsigned char* dst = lds + st_plane + (e >> 2) * 16;
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    half4 hi, lo;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float t = ps == 0 ? dd[0][c] - dd[2][c]
+                                      : ps == 1 ? dd[1][c] + dd[2][c]
+                                      : ps == 2 ? dd[2][c] - dd[1][c]
+                                                : dd[1][c] - dd[3][c];
+                        const _Float16 hh = (_Float16)t;
+                        hi[c] = hh;
+                        lo[c] = (_Float16)(t - (float)hh);
+                    }
+                    unsigned char* dp = dst + (ps * 2 * NPL) * p.plane_stride;
+                    *reinterpret_cast<half4*>(dp) = hi;
+                    if constexpr (NPASS == 3) *reinterpret_cast<half4*>(dp + p.plane_stride) = lo;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);           // keep the next batch's loads from being hoisted (registers)
         }
         __syncthreads();
 
@@ -209,12 +226,13 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
             const int s = kc * 9 + t;
             const int kd = t / 3, kh = t - kd * 3;
             const int toff = (kd * p.HT + kh) * p.PW * 16;
-            constexpr int dummy = 0; (void)dummy;
-            const int cur = t % 3;
+            // 9 taps per chunk: with 3 sets the set index is t % 3; with 2 sets the parity of the global step
+            // alternates per chunk, so the chunk loop body is instantiated for both parities (PAR)
+            const int cur = NSET == 3 ? t % 3 : (PAR + t) & 1;
             uint4 bw[NF];
 #pragma unroll
             for (int f = 0; f < NF; ++f) bw[f] = wq[cur][f];
-            fetch(s + 2, wq[(cur + 2) % 3]);
+            fetch(s + NSET - 1, wq[(cur + NSET - 1) % NSET]);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 half8 a[NPL];
@@ -232,6 +250,14 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bhi, acc[mb][nb], 0, 0, 0);
                 }
             }
+        }
+    };
+    if constexpr (NSET == 3) {
+        for (int kc = 0; kc < p.KCN; ++kc) do_chunk(kc, std::integral_constant<int, 0>{});
+    } else {
+        for (int kc = 0; kc < p.KCN; kc += 2) {            // 9 steps per chunk: the parity flips every chunk
+            do_chunk(kc, std::integral_constant<int, 0>{});
+            if (kc + 1 < p.KCN) do_chunk(kc + 1, std::integral_constant<int, 1>{});
         }
     }
 
