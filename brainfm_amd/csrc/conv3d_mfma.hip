@@ -1231,7 +1231,7 @@ extern "C" size_t bfm_conv3x3x3_mfma_workspace(int Cin, int Cout, int D, int H, 
 // rows of the output-moment table a launch with this plan writes (0: this plan cannot emit them)
 extern "C" int bfm_conv3x3x3_mfma_rows(int Cin, int Cout, int D, int H, int W, const int* cfg) {
     if (!cfg || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    if (cfg[6] == 1 || cfg[6] == 3) return 0;                   // the persistent / Winograd variants do not emit rows
+    if (cfg[6] == 1 || cfg[6] >= 3) return 0;                   // the persistent / Winograd variants do not emit rows
     int splitk = cfg[5] < 1 ? 1 : cfg[5];
     const int KCN = Cin / KC;
     if (splitk > KCN) splitk = KCN;

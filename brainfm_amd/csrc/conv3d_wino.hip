@@ -45,6 +45,7 @@ struct WinoParams {
     int pw_shift, thp_shift;         // log2(PW), log2(TH*PW)
     int nTy, nTx, nMt, NT, KCN;
     int npos_lds, plane_stride;      // (TD+2)*HT*PW positions; bytes per plane
+    int ws_buf_bytes;                // persistent kernel: bytes per LDS buffer
 };
 
 __device__ __forceinline__ int row_perm(int l) {        // as conv_mfma: each 16-lane b128 group reads 16 consecutive positions
@@ -299,6 +300,319 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-specialised persistent form of conv_wino: 8 waves per workgroup, one workgroup per CU.  Waves 0-3 are the
+// four Winograd positions and only multiply (LDS A reads, weights L2 -> VGPR, MFMA); waves 4-7 only stage: they
+// have no accumulators, so all 20 global loads of a chunk are in flight at once, and they fill buffer (g+1)&1 while
+// the MFMA waves consume buffer g&1.  One workgroup barrier per K-chunk separates the two; on a tile's last chunk
+// the output transform borrows the buffer the MFMA waves just finished with (all 512 threads form y0/y1 and store).
+// In the 4-wave kernel the matrix pipe is busy 39 % of the time (staging latency is exposed: the accumulators leave
+// no registers to batch loads); here staging hides under the other waves' MFMAs.
+template <int NPASS>
+__global__ void __launch_bounds__(512, 1) conv_wino_ws(const WinoParams p) {
+    constexpr int NPL = (NPASS == 3) ? 2 : 1;
+    constexpr int NF = 2 * NPL;
+    constexpr int MAX_IT = 5;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int pos = wave & 3;
+    const int l32 = lane & 31, khalf = lane >> 5;
+    const int buf_bytes = p.ws_buf_bytes;                      // >= 8*NPL*plane_stride and >= the output-transform scratch
+
+    const int nblk = p.nMt * p.NT;
+    const int ntile = (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int G = ntile * p.KCN;
+    auto tile_coords = [&](int k, int& mt, int& nt) __attribute__((always_inline)) {
+        int vb = (int)blockIdx.x + k * (int)gridDim.x;
+        if (vb >= nblk) vb = nblk - 1;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = vb & 7, idx = vb >> 3;
+        const int b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        mt = b / p.NT;
+        nt = b - mt * p.NT;
+    };
+    auto tile_origin = [&](int mt, int& z0, int& y0, int& x0) __attribute__((always_inline)) {
+        const int tx = mt % p.nTx;
+        const int ty = (mt / p.nTx) % p.nTy;
+        const int tz = mt / (p.nTx * p.nTy);
+        z0 = tz * p.TD; y0 = ty * p.TH; x0 = tx * p.TW;
+    };
+
+    float bmax = 0.f;
+    for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, p.bound[g]);
+    int aexp = 0;
+    if (bmax > 0.f && bmax < INFINITY) {
+        int ex;
+        (void)frexpf(bmax, &ex);
+        aexp = 13 - ex;
+        aexp = aexp > 60 ? 60 : (aexp < -60 ? -60 : aexp);
+    }
+    const float a_scale = ldexpf(1.0f, aexp);
+    const float dq = ldexpf(1.0f, -(aexp + p.wexp));
+
+    // ---------------- loader state
+    const int ltid = tid & 255;
+    const int q4 = ltid & 3;
+    const int n_el = p.npos_lds * 4;
+    const int st_plane = ((q4 >> 1) * NPL) * p.plane_stride + (q4 & 1) * 8;
+    int off0[MAX_IT], msk[MAX_IT];
+    auto set_tile = [&](int k) __attribute__((always_inline)) {
+        int mt, nt, z0, y0, x0;
+        tile_coords(k, mt, nt);
+        tile_origin(mt, z0, y0, x0);
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it) {
+            const int e = ltid + it * 256;
+            off0[it] = 0;
+            msk[it] = -1;
+            if (e < n_el) {
+                const int ps = e >> 2;
+                const int j = ps & ((1 << p.pw_shift) - 1);
+                const int r = ps >> p.pw_shift;
+                const int hz = r / p.HT, hy = r - hz * p.HT;
+                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + 2 * j - 1;
+                int m = 0;
+                if (gz >= 0 && gz < p.D && gy >= 0 && gy < p.H) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (gx + i >= 0 && gx + i < p.W) m |= 1 << i;
+                }
+                msk[it] = m;
+                off0[it] = ((gz * p.H + gy) * p.W + gx) * p.CA;
+            }
+        }
+    };
+    int tile_set = -1;
+    struct ItemRegs { float4 v[MAX_IT][4]; int m[MAX_IT]; };
+    // issue the global loads of item g (its tile's offsets are recomputed when the tile changes)
+    auto load_item = [&](int g, ItemRegs& r) __attribute__((always_inline)) {
+        const int tk = g / p.KCN;
+        if (tk != tile_set) { set_tile(tk); tile_set = tk; }
+        const float* src = p.A + (g % p.KCN) * KC + q4 * 4;
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it) {
+            r.m[it] = msk[it];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                r.v[it][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (msk[it] >= 0 && (msk[it] & (1 << i)))
+                    r.v[it][i] = *reinterpret_cast<const float4*>(src + off0[it] + i * p.CA);
+            }
+        }
+    };
+    // affine + zero padding + Winograd input transform + hi/lo split + LDS writes of a loaded item
+    auto write_item = [&](int g, const ItemRegs& r, unsigned char* buf) __attribute__((always_inline)) {
+        const int c0 = (g % p.KCN) * KC;
+        const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + c0 + q4 * 4);
+        const float4 sh4 = *reinterpret_cast<const float4*>(p.shift + c0 + q4 * 4);
+        const float sc[4] = {sc4.x * a_scale, sc4.y * a_scale, sc4.z * a_scale, sc4.w * a_scale};
+        const float sh[4] = {sh4.x * a_scale, sh4.y * a_scale, sh4.z * a_scale, sh4.w * a_scale};
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it) {
+            if (r.m[it] < 0) continue;
+            float dd[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = r.m[it] & (1 << i);
+                const float y[4] = {r.v[it][i].x, r.v[it][i].y, r.v[it][i].z, r.v[it][i].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dd[i][c] = ok ? fmaf(y[c], sc[c], sh[c]) : 0.f;
+            }
+            const int e = ltid + it * 256;
+            unsigned char* dst = buf + st_plane + (e >> 2) * 16;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                half4 hi, lo;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float t = ps == 0 ? dd[0][c] - dd[2][c]
+                                  : ps == 1 ? dd[1][c] + dd[2][c]
+                                  : ps == 2 ? dd[2][c] - dd[1][c]
+                                            : dd[1][c] - dd[3][c];
+                    const _Float16 hh = (_Float16)t;
+                    hi[c] = hh;
+                    lo[c] = (_Float16)(t - (float)hh);
+                }
+                unsigned char* dp = dst + (ps * 2 * NPL) * p.plane_stride;
+                *reinterpret_cast<half4*>(dp) = hi;
+                if constexpr (NPASS == 3) *reinterpret_cast<half4*>(dp + p.plane_stride) = lo;
+            }
+        }
+    };
+
+    // ---------------- consumer state
+    int a_off[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        int d, h, j;
+        pair_coords(p, mb * 32 + row_perm(l32), d, h, j);
+        a_off[mb] = ((pos * 2 + khalf) * NPL) * p.plane_stride + ((d * p.HT + h) * p.PW + j) * 16;
+    }
+    const int S = p.KCN * 9;
+    const uint4* wcur = p.wp + lane;
+    const uint4* wnxt = p.wp + lane;
+    bool has_next = false;
+    auto set_wbase = [&](int k) __attribute__((always_inline)) {     // tile k current, k+1 next
+        int mt, nt;
+        tile_coords(k, mt, nt);
+        wcur = p.wp + (size_t)(nt * 4 + pos) * S * (NF * 64) + lane;
+        has_next = (k + 1) < ntile;
+        tile_coords(k + 1, mt, nt);
+        wnxt = p.wp + (size_t)(nt * 4 + pos) * S * (NF * 64) + lane;
+    };
+    uint4 wq[3][NF];
+    auto fetch = [&](int sl, uint4 (&dst)[NF]) __attribute__((always_inline)) {   // sl: step within the current tile
+        const uint4* base = wcur;
+        int s2 = sl;
+        if (sl >= S) {
+            if (has_next) { base = wnxt; s2 = sl - S; }
+            else s2 = S - 1;
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) dst[f] = base[(size_t)s2 * (NF * 64) + f * 64];
+    };
+
+    // the read/transform/store half of one output-transform round, executed by all 512 threads
+    auto epilogue_round = [&](int tk, int nb, const float* m) __attribute__((always_inline)) {
+        int mt, nt, z0, y0, x0;
+        tile_coords(tk, mt, nt);
+        tile_origin(mt, z0, y0, x0);
+        const int col = tid & 31, row0 = tid >> 5;                   // 16 row groups
+#pragma unroll 4
+        for (int it = 0; it < 8; ++it) {
+            const int q = row0 + 16 * it;
+            int d, h, j;
+            pair_coords(p, q, d, h, j);
+            const int gz = z0 + d, gy = y0 + h, gx = x0 + 2 * j;
+            if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
+            const float m0 = m[(0 * 128 + q) * MLD + col], m1 = m[(1 * 128 + q) * MLD + col];
+            const float m2 = m[(2 * 128 + q) * MLD + col], m3 = m[(3 * 128 + q) * MLD + col];
+            float* o = p.out + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + nt * 64 + nb * 32 + col;
+            float y0v = ((m0 + m1) + m2) * dq;
+            float y1v = ((m1 - m2) - m3) * dq;
+            if (p.accum) y0v = y0v + o[0];
+            y0v = y0v >= 0.f ? y0v : y0v * p.slope;
+            o[0] = y0v;
+            if (gx + 1 < p.W) {
+                if (p.accum) y1v = y1v + o[p.Cout];
+                y1v = y1v >= 0.f ? y1v : y1v * p.slope;
+                o[p.Cout] = y1v;
+            }
+        }
+    };
+
+    // The two roles run separate loops with the SAME barrier sequence: one barrier after the prologue, one at the end
+    // of every item, and four more (two per 32-column round) on a tile's last chunk.
+    if (loader) {
+        // items are loaded two ahead of the MFMA waves and written one ahead: the global latency of item g+2 hides under
+        // the conversion of item g+1 (two register sets, the loop is unrolled by two so that their roles are static)
+        ItemRegs ra, rb;
+        load_item(0, ra);
+        write_item(0, ra, lds);
+        if (1 < G) load_item(1, ra);
+        __syncthreads();
+        auto iteration = [&](int g, ItemRegs& rcur, ItemRegs& rnxt) __attribute__((always_inline)) {
+            // rcur holds item g+1 (loaded earlier); rnxt receives item g+2
+            if (g + 2 < G) load_item(g + 2, rnxt);
+            if (g + 1 < G) write_item(g + 1, rcur, lds + ((g + 1) & 1) * buf_bytes);
+            if (g % p.KCN == p.KCN - 1) {
+                const float* m = reinterpret_cast<const float*>(lds + (g & 1) * buf_bytes);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    __syncthreads();
+                    __syncthreads();
+                    epilogue_round(g / p.KCN, nb, m);
+                }
+            }
+            __syncthreads();
+        };
+        for (int g = 0; g < G; g += 2) {
+            iteration(g, ra, rb);
+            if (g + 1 < G) iteration(g + 1, rb, ra);
+        }
+    } else {
+        floatx16 acc[4][2];
+        set_wbase(0);
+        fetch(0, wq[0]);
+        fetch(1, wq[1]);
+        __syncthreads();
+        for (int g = 0; g < G; ++g) {
+            const int kc = g % p.KCN, tk = g / p.KCN;
+            unsigned char* cur = lds + (g & 1) * buf_bytes;
+            if (kc == 0) {
+                if (g > 0) set_wbase(tk);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+            }
+            // 36 steps (tap, row block), fully unrolled.  This wave is alone on its SIMD's matrix pipe, so the A fragments
+            // of the next step are read before the current step's MFMAs are issued, and the MFMAs alternate between
+            // the two column blocks so that no MFMA waits for the accumulator written by the one just before it.
+            half8 a_cur[NPL], a_nxt[NPL];
+#pragma unroll
+            for (int hl = 0; hl < NPL; ++hl)
+                a_cur[hl] = *reinterpret_cast<const half8*>(cur + a_off[0] + hl * p.plane_stride);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int curset = t % 3;
+                uint4 bw[NF];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) bw[f] = wq[curset][f];
+                fetch(kc * 9 + t + 2, wq[(curset + 2) % 3]);
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const int step = t * 4 + mb + 1;               // the step whose A fragments are fetched now
+                    if (step < 36) {
+                        const int t2 = step >> 2, mb2 = step & 3;
+                        const int kd2 = t2 / 3, kh2 = t2 - kd2 * 3;
+                        const int toff2 = (kd2 * p.HT + kh2) * p.PW * 16;
+#pragma unroll
+                        for (int hl = 0; hl < NPL; ++hl)
+                            a_nxt[hl] = *reinterpret_cast<const half8*>(cur + a_off[mb2] + hl * p.plane_stride + toff2);
+                    }
+                    const half8 bhi0 = __builtin_bit_cast(half8, bw[0]);
+                    const half8 bhi1 = __builtin_bit_cast(half8, bw[NPL]);
+                    if constexpr (NPASS == 3) {
+                        const half8 blo0 = __builtin_bit_cast(half8, bw[1]);
+                        const half8 blo1 = __builtin_bit_cast(half8, bw[NPL + 1]);
+                        acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1], bhi0, acc[mb][0], 0, 0, 0);
+                        acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1], bhi1, acc[mb][1], 0, 0, 0);
+                        acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], blo0, acc[mb][0], 0, 0, 0);
+                        acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], blo1, acc[mb][1], 0, 0, 0);
+                    }
+                    acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], bhi0, acc[mb][0], 0, 0, 0);
+                    acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], bhi1, acc[mb][1], 0, 0, 0);
+#pragma unroll
+                    for (int hl = 0; hl < NPL; ++hl) a_cur[hl] = a_nxt[hl];
+                }
+            }
+            if (kc == p.KCN - 1) {
+                float* m = reinterpret_cast<float*>(cur);              // [4 positions][128 pairs][MLD]
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    __syncthreads();                                   // A planes / previous round consumed
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const int rr = (i >> 2) * 8 + khalf * 4 + (i & 3);
+                            m[(pos * 128 + mb * 32 + row_perm(rr)) * MLD + l32] = acc[mb][nb][i];
+                        }
+                    __syncthreads();
+                    epilogue_round(tk, nb, m);
+                }
+            }
+            __syncthreads();                                           // item g+1 staged, item g consumed
+        }
+    }
+}
+
 // packed[ntile64][pos 4][kc][(kd,kh) 9][nb 2][hl][lane] (uint4 = 8 halfs): lane l holds
 // B[k = 8*(l>>5)+j][n = l&31] = U_pos[co = ntile*64 + nb*32 + (l&31)][ci = kc*16 + 8*(l>>5) + j][kd][kh] * 2^wexp,
 // U = G g along kw: (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2)
@@ -381,7 +695,9 @@ extern "C" int bfm_pack_conv_weights_wino(const float* w_oidhw, int Cin, int Cou
 
 extern "C" int bfm_conv3x3x3_wino(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                                   const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope,
-                                  int passes, int accumulate, float* out, bfm_stream_t stream) {
+                                  int passes, int flags, float* out, bfm_stream_t stream) {
+    const int accumulate = flags & 1;
+    const bool persistent = (flags & 2) != 0;
     if (!A || CA <= 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || G <= 0 || !wpacked || !out)
         return BFM_E_ARG;
     if (CA % KC || Cout % 64 || Cout <= 0) return BFM_E_SHAPE;
@@ -419,6 +735,27 @@ extern "C" int bfm_conv3x3x3_wino(const float* A, int CA, int D, int H, int W, c
         hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             80 * 1024);
         attr_done = true;
+    }
+    if (persistent) {
+        size_t buf = (size_t)8 * npl * p.plane_stride;
+        if (buf < epi) buf = epi;
+        buf = (buf + 255) & ~(size_t)255;
+        p.ws_buf_bytes = (int)buf;
+        const size_t smem2 = 2 * buf;                                  // two buffers
+        if (smem2 > 160 * 1024) return BFM_E_SHAPE;
+        static bool attr2 = false;
+        if (!attr2) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_ws<3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_ws<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr2 = true;
+        }
+        int nwg = p.nMt * p.NT;
+        if (nwg > 256) nwg = 256;                                     // one 8-wave workgroup per CU
+        if (passes == 3) hipLaunchKernelGGL(conv_wino_ws<3>, dim3(nwg), dim3(512), smem2, bfm_s(stream), p);
+        else hipLaunchKernelGGL(conv_wino_ws<1>, dim3(nwg), dim3(512), smem2, bfm_s(stream), p);
+        return bfm_launch_status();
     }
     dim3 grid((unsigned)(p.nMt * p.NT));
     if (passes == 3) hipLaunchKernelGGL(conv_wino<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);

@@ -137,7 +137,7 @@ class UNetEngine:
         """Pack (once per layout) and select the weights for this launch: 'direct' [27][Cin][Cout] fp32,
         'mfma' 32x32x16 fragments (plan variants 0/1), 'mfma16' 16x16x32 tap-pair fragments (variant 2),
         'wino' F(2,3)-along-x transformed fragments (variant 3, single-source layers only)."""
-        layout = "direct" if not mfma else ("wino" if ver == 3 else ("mfma16" if ver == 2 else "mfma"))
+        layout = "direct" if not mfma else ("wino" if ver in (3, 4) else ("mfma16" if ver == 2 else "mfma"))
         if layout not in ly.packs:
             st = L.stream_ptr()
             if layout == "wino":
@@ -187,7 +187,7 @@ class UNetEngine:
         if key not in self._plan_cache:
             cfg = (C.c_int * 8)()
             L.check(self.lib.bfm_conv3x3x3_mfma_plan(cin, cout, dims[0], dims[1], dims[2], cfg), "mfma_plan")
-            if two_src and cfg[6] == 3:                          # BFM_CONV_VER=3: Winograd takes one source
+            if two_src and cfg[6] in (3, 4):                     # BFM_CONV_VER=3/4: Winograd takes one source
                 cfg[6] = 0
             self._plan_cache[key] = cfg
         return self._plan_cache[key]
@@ -201,7 +201,9 @@ class UNetEngine:
         if key in self._tuned or os.environ.get("BFM_CONV_VER") or os.environ.get("BFM_CONV_TUNE", "1") == "0":
             return cfg
         best, best_ms = cfg[6], None
-        for ver in ((0, 1, 2) if key[3] else (0, 1, 2, 3)):       # Winograd: single-source layers only
+        # Winograd (3) takes single-source layers only; its wave-specialised form (4, BFM_CONV_VER=4) has not beaten it
+        # on any shape measured so far, so it is not timed here
+        for ver in ((0, 1, 2) if key[3] else (0, 1, 2, 3)):
             trial = (C.c_int * 8)(*list(cfg))
             trial[6] = ver
             try:
@@ -255,12 +257,13 @@ class UNetEngine:
         D, H, W = dims
         st = L.stream_ptr()
         self._pack(ly, True, cfg[6])
-        if cfg[6] == 3:
+        if cfg[6] in (3, 4):
             if cb:
                 raise L.BfmError("the Winograd variant takes one source")
             L.check(self.lib.bfm_conv3x3x3_wino(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound), groups,
                                                 L.ptr(ly.wpacked), ly.wexp, ly.cout, self.slope, self.passes,
-                                                cfg[7] & 1, L.ptr(out), st), "conv_wino " + ly.name)
+                                                (cfg[7] & 1) | (2 if cfg[6] == 4 else 0), L.ptr(out), st),
+                    "conv_wino " + ly.name)
             return
         L.check(self.lib.bfm_conv3x3x3_mfma_ex(L.ptr(A), ca, L.ptr(B) if cb else None, cb, D, H, W, upp if cb else None,
                                                L.ptr(scale), L.ptr(shift), L.ptr(bound), groups, L.ptr(ly.wpacked),

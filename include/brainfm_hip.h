@@ -105,7 +105,8 @@ int bfm_pack_conv_weights_wino(const float* w_oidhw, int Cin, int Cout, float wm
                                int* wexp_host, bfm_stream_t stream);
 int bfm_conv3x3x3_wino(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                        const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
-                       int accumulate, float* out, bfm_stream_t stream);
+                       int flags /* bit 0: accumulate onto out; bit 1: wave-specialised persistent kernel */,
+                       float* out, bfm_stream_t stream);
 
 /* Output-moment rows.  A producer (conv3x3x3_mfma_ex / conv3x3x3_stem_ex) can write, next to its output, one row
  * per tile of per-channel {sum, sumsq} (fp64) and {min, max} (fp32) of the values it stored: buffer of

@@ -337,8 +337,9 @@ def test_producer_moment_rows_equal_activation_moments(ver, monkeypatch):
     assert _relerr(got.cpu().numpy(), ref.cpu().numpy()) <= 1e-6
 
 
+@pytest.mark.parametrize("wver", [3, 4])
 @pytest.mark.parametrize("dims", [(8, 8, 32), (7, 9, 21), (12, 5, 10)])
-def test_winograd_variant_equals_direct_variant(dims, monkeypatch):
+def test_winograd_variant_equals_direct_variant(dims, wver, monkeypatch):
     """conv_wino (F(2,3) along x, 1.5x fewer MFMAs) against conv_mfma on the same operands, including odd widths
     (a pair whose second voxel is outside), boxes that do not divide the volume, and accumulate mode."""
     sd = O.random_state_dict(1, 64, 3, seed=17)
@@ -351,7 +352,7 @@ def test_winograd_variant_equals_direct_variant(dims, monkeypatch):
     monkeypatch.setenv("BFM_CONV_VER", "0")
     ref = eng.single_conv(ly, A, dims).clone()
     eng._plan_cache.clear()
-    monkeypatch.setenv("BFM_CONV_VER", "3")
+    monkeypatch.setenv("BFM_CONV_VER", str(wver))           # 3: 4-wave kernel, 4: wave-specialised persistent kernel
     got = eng.single_conv(ly, A, dims)
     assert "wino" in ly.packs
     e = _relerr(got.cpu().numpy(), ref.cpu().numpy())
@@ -365,7 +366,7 @@ def test_winograd_variant_equals_direct_variant(dims, monkeypatch):
     bound = torch.full((ly.groups,), 8.0, device=_dev())
     prev = torch.randn(dims + (64,), generator=g).to(_dev())
     outs = []
-    for ver in (0, 3):
+    for ver in (0, wver):
         cfg = (C.c_int * 8)()
         L.check(eng.lib.bfm_conv3x3x3_mfma_plan(64, 64, D, H, W, cfg), "plan")
         cfg[6], cfg[7] = ver, 1
