@@ -19,6 +19,7 @@ import torch
 
 from . import _lib as L
 from . import generator_utils as GU
+from . import interpol as IP
 from .engine import LABELS_FULL, LABELS_LEFT
 from .shapeid import AdvDiffPDE, generate_shape_3d
 
@@ -351,10 +352,10 @@ class BaseGen(torch.utils.data.Dataset):
             I_def, aux = GU.augmentation_funcs[fn](I=I_def, aux_dict=aux, cfg=self.gen_args.generator,
                                                    input_mode=input_mode, setups=setups, size=self.size, res=res,
                                                    device=self.device)
-        if getattr(self.synth_args, "bspline_zooming", False):
-            raise NotImplementedError("bspline_zooming needs the cubic prefilter (SURVEY 'next' row N4); every shipped "
-                                      "config sets it False")
-        I_def = GU.myzoom_torch(I_def, 1 / aux["factors"]) if "factors" in aux else I_def
+        if getattr(self.synth_args, "bspline_zooming", False):          # Generator/datasets.py:337-338
+            I_def = IP.resize(I_def, shape=list(self.size), anchor="edge", interpolation=3, bound="dct2", prefilter=True)
+        else:
+            I_def = GU.myzoom_torch(I_def, 1 / aux["factors"]) if "factors" in aux else I_def
         maxi = GU.tensor_max(I_def)
         I_final = GU.ew_unary(L.EW_DIV, I_def, maxi)
         fl = (lambda t: torch.flip(t, [0])) if setups["flip"] else (lambda t: t)

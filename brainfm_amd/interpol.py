@@ -66,3 +66,132 @@ def grid_pull(input, grid, interpolation="linear", bound="zero", extrapolate=Fal
                                             L.stream_ptr()), "grid_pull3d_linear")
     out_channel = [channel] if channel else ([1] if batch else [])
     return out.reshape(*batch, *out_channel, *grid_spatial)
+
+
+# ----------------------------------------------------------------------------- resize (bspline_zooming)
+_SPLINE_BOUND = {"nearest": 1, "replicate": 1, "repeat": 1, "border": 1, "dct2": 3, "reflect": 3, "reflection": 3,
+                 "neumann": 3, 1: 1, 3: 3}
+
+
+def _prefilter_scalars(n):
+    """The host scalars of coeff.py's cubic DCT-II prefilter for a line of n samples (:55-60, :141-175, :218-226)."""
+    import math
+    z = math.sqrt(3.0) - 2.0
+    gain = (1.0 - z) * (1.0 - 1.0 / z)
+    polen = z ** n
+    pole_last = polen * (1 + 1 / (z + polen * polen))
+    init_scale = z / (1 - polen * polen)
+    final_scale = z / (z - 1)
+    zt = torch.as_tensor(z, dtype=torch.float32)
+    w = (zt.pow(torch.arange(1, n - 1, dtype=torch.float32)) +
+         zt.pow(torch.arange(2 * n - 2, n, -1, dtype=torch.float32)))            # fp32 table exactly as the reference builds it
+    return z, gain, pole_last, init_scale, final_scale, w
+
+
+def spline_coeff_nd(inp, bound="dct2", order=3, dim=3, inplace=False):
+    """utils/interpol/coeff.py:315-344 for cubic splines with DCT-II ('nearest' / 'dct2') conditions, 3-D volumes."""
+    if inp.device.type != "cuda":
+        raise L.BfmError("spline_coeff_nd runs on a HIP device only")
+    if order in (0, 1):
+        return inp if inplace else inp.clone()
+    if order != 3 or dim != 3:
+        raise NotImplementedError("only cubic 3-D prefiltering is implemented")
+    b = bound if isinstance(bound, (str, int)) else bound[0]
+    b = _SPLINE_BOUND.get(b.lower() if isinstance(b, str) else b)
+    if b is None:
+        raise NotImplementedError("spline prefilter: only 'nearest'/'dct2' boundary conditions")
+    lead = inp.shape[:-3]
+    vols = inp.to(torch.float32).reshape((-1,) + tuple(inp.shape[-3:])).contiguous()
+    if not inplace or vols.data_ptr() != inp.data_ptr():
+        vols = vols.clone()
+    lib = L.load()
+    nx, ny, nz = vols.shape[-3:]
+    for v in vols:
+        for axis, n in enumerate((nx, ny, nz)):
+            if n == 1:
+                continue
+            z, gain, pole_last, init_scale, final_scale, w = _prefilter_scalars(n)
+            wd = w.to(inp.device) if n > 2 else None
+            L.check(lib.bfm_bspline3_prefilter_axis(L.ptr(v), nx, ny, nz, axis, b, z, gain, L.ptr(wd), pole_last,
+                                                    init_scale, final_scale, L.stream_ptr()), "bspline3_prefilter")
+    return vols.reshape(tuple(lead) + (nx, ny, nz))
+
+
+def _make_list(x, n=None):
+    x = list(x) if isinstance(x, (list, tuple)) else [x]
+    if n is not None and len(x) < n:
+        x = x + [x[-1]] * (n - len(x))
+    return x
+
+
+def resize(image, factor=None, shape=None, anchor="c", interpolation=1, prefilter=True, **kwargs):
+    """utils/interpol/resize.py:13-119.  image: (..., X, Y, Z).  Cubic (interpolation=3) runs as prefilter + three
+    separable 4-tap passes; linear builds the grid and goes through grid_pull like the reference."""
+    if image.device.type != "cuda":
+        raise L.BfmError("resize runs on a HIP device only; there is no CPU fallback in the product path")
+    factor = _make_list(factor) if factor else []
+    shape = _make_list(shape) if shape else []
+    anchor = _make_list(anchor)
+    nb_dim = max(len(factor), len(shape), len(anchor)) or (image.dim() - 2)
+    if nb_dim != 3:
+        raise NotImplementedError("only 3-D resize is implemented")
+    anchor = [a[0].lower() for a in _make_list(anchor, nb_dim)]
+    inshape = image.shape[-nb_dim:]
+    if factor:
+        factor = _make_list(factor, nb_dim)
+    elif not shape:
+        raise ValueError("One of `factor` or `shape` must be provided")
+    if shape:
+        shape = _make_list(shape, nb_dim)
+    else:
+        shape = [int(i * f) for i, f in zip(inshape, factor)]
+    if not factor:
+        factor = [o / i for o, i in zip(shape, inshape)]
+    lin = []
+    for anch, f, inshp, outshp in zip(anchor, factor, inshape, shape):         # fp32 on the host: same values as torch CPU
+        if anch == "c":
+            lin.append(torch.linspace(0, inshp - 1, outshp, dtype=torch.float32))
+        elif anch == "e":
+            scale = inshp / outshp
+            shift = 0.5 * (scale - 1)
+            lin.append(torch.arange(0., outshp, dtype=torch.float32) * scale + shift)
+        elif anch == "f":
+            lin.append(torch.arange(0., outshp, dtype=torch.float32) / f)
+        elif anch == "l":
+            shift = (inshp - 1) - (outshp - 1) / f
+            lin.append(torch.arange(0., outshp, dtype=torch.float32) / f + shift)
+        else:
+            raise ValueError("Unknown anchor {}".format(anch))
+    bound = kwargs.get("bound", "nearest")
+    order = kwargs.get("interpolation", interpolation)
+    prefilter = kwargs.get("prefilter", prefilter)
+    if order in (1, "linear"):
+        grid = torch.stack(torch.meshgrid(*[v.to(image.device) for v in lin], indexing="ij"), dim=-1)
+        return grid_pull(image, grid, interpolation=1, bound=bound, extrapolate=kwargs.get("extrapolate", True))
+    if order not in (3, "cubic"):
+        raise NotImplementedError("resize: interpolation orders 1 and 3 are implemented")
+    if not kwargs.get("extrapolate", True):
+        raise NotImplementedError("resize: cubic path assumes extrapolate=True (the reference default here)")
+    b = bound if isinstance(bound, (str, int)) else bound[0]
+    b = _SPLINE_BOUND.get(b.lower() if isinstance(b, str) else b)
+    if b is None:
+        raise NotImplementedError("resize: cubic path supports 'nearest'/'dct2' bounds")
+    coeff = spline_coeff_nd(image, bound=b, order=3, dim=3) if prefilter else image.to(torch.float32)
+    lead = coeff.shape[:-3]
+    vols = coeff.reshape((-1,) + tuple(coeff.shape[-3:])).contiguous()
+    lib = L.load()
+    coords = [v.to(image.device) for v in lin]
+    outs = []
+    for v in vols:
+        cur = v
+        dims = list(v.shape)
+        for axis in range(3):
+            nxt_dims = list(dims)
+            nxt_dims[axis] = shape[axis]
+            nxt = torch.empty(nxt_dims, dtype=torch.float32, device=image.device)
+            L.check(lib.bfm_bspline3_resample_axis(L.ptr(cur), dims[0], dims[1], dims[2], axis, L.ptr(coords[axis]),
+                                                   shape[axis], b, L.ptr(nxt), L.stream_ptr()), "bspline3_resample")
+            cur, dims = nxt, nxt_dims
+        outs.append(cur)
+    out = torch.stack(outs, 0) if len(outs) > 1 else outs[0][None]
+    return out.reshape(tuple(lead) + tuple(shape))

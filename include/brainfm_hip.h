@@ -296,6 +296,18 @@ int bfm_bbox_nonzero(const float* in, int nx, int ny, int nz, float tol, int32_t
                      bfm_stream_t stream);
 int bfm_mean_lastdim(const float* in, int64_t n, int c, float* out, bfm_stream_t stream);
 
+/* interpol.resize(interpolation=3, prefilter=True) -- utils/interpol/resize.py:13-119, coeff.py:254-344, nd.py:36-142
+ * (Generator/datasets.py:337-338, `bspline_zooming`).  One axis at a time, in place for the prefilter.
+ * prefilter: bound 1 ('nearest') or 3 ('dct2') -> DCT-II conditions; the host passes the scalars the reference derives
+ * from the pole z = sqrt(3)-2 (gain (1-z)(1-1/z), pole_last, init_scale z/(1-z^2n), final_scale z/(z-1)) and the
+ * fp32 table init_w[i-1] = z^i + z^(2n-1-i), i = 1..n-2.  resample: out[o] = sum of 4 cubic B-spline taps around
+ * coord[o] (fp32 source coordinates of the output samples along `axis`), indices reflected (3) or clamped (1). */
+int bfm_bspline3_prefilter_axis(float* vol, int nx, int ny, int nz, int axis, int bound, float pole, float gain,
+                                const float* init_w, float pole_last, float init_scale, float final_scale,
+                                bfm_stream_t stream);
+int bfm_bspline3_resample_axis(const float* in, int nx, int ny, int nz, int axis, const float* coord, int n_out,
+                               int bound, float* out, bfm_stream_t stream);
+
 /* interpol.grid_pull(interpolation='linear') -> iso1.pull3d -- utils/interpol/iso1.py:28-133.
  * inp (Bi,C,nx,ny,nz), grid (Bg,ox,oy,oz,3), out (max(Bi,Bg),C,ox,oy,oz); bound[3] in 0..6
  * (zero, replicate, dct1, dct2, dst1, dst2, dft -- bounds.py:8-15); extrapolate 0 no / 1 yes / 2 hist. */

@@ -537,3 +537,62 @@ def deformed_atlas(brain_labels, regx, regy, regz, MNI, A):
     out = np.zeros_like(regx, dtype=F32)
     out[M] = vals
     return out
+
+
+# ----------------------------------------------------------------------------- cubic B-spline resize
+def bspline3_prefilter_dct2(x):
+    """utils/interpol/coeff.py:254-344 for order 3, DCT-II ('nearest' / 'dct2') conditions, every axis of a 3-D array
+    (gain, initial condition :141-175, causal recursion, final condition :218-226, anticausal recursion); fp64."""
+    import math
+    z = math.sqrt(3.0) - 2.0
+    c = np.array(x, dtype=np.float64)
+    for axis in range(c.ndim):
+        n = c.shape[axis]
+        if n == 1:
+            continue
+        c = np.moveaxis(c, axis, 0).copy()
+        c *= (1.0 - z) * (1.0 - 1.0 / z)
+        polen = z ** n
+        pole_last = polen * (1 + 1 / (z + polen * polen))
+        i = np.arange(1, n - 1)
+        w = z ** i + z ** (2 * n - 1 - i)
+        c0 = np.tensordot(w, c[1:-1], axes=(0, 0)) + (c[0] + pole_last * c[-1])
+        c[0] = c0 * (z / (1 - polen * polen)) + c[0]
+        for k in range(1, n):
+            c[k] += z * c[k - 1]
+        c[-1] = c[-1] * (z / (z - 1))
+        for k in range(n - 2, -1, -1):
+            c[k] = z * (c[k + 1] - c[k])
+        c = np.moveaxis(c, 0, axis)
+    return c
+
+
+def _bspline3_w(x):
+    x = np.abs(x)
+    return np.where(x < 1, (x * x * (x - 2.0) * 3.0 + 4.0) / 6.0, (2.0 - x) ** 3 / 6.0)
+
+
+def resize_cubic_ref(x, shape, anchor="e"):
+    """utils/interpol/resize.py:13-119 with interpolation=3, bound='dct2', prefilter=True, extrapolate=True, evaluated
+    separably in fp64 (nd.py:36-142: nodes floor(g-1)..+3, weights splines.py:40-43, DCT-II index bounds.py:33-38)."""
+    c = bspline3_prefilter_dct2(x)
+    for axis in range(3):
+        n, m = c.shape[axis], shape[axis]
+        if anchor[0] == "e":
+            scale = n / m
+            g = (np.arange(m, dtype=np.float32) * np.float32(scale) + np.float32(0.5 * (scale - 1))).astype(np.float64)
+        else:
+            g = np.linspace(0, n - 1, m, dtype=np.float32).astype(np.float64)
+        g0 = np.floor(g - 1)
+        out = 0
+        for node in range(4):
+            idx = (g0 + node).astype(np.int64)
+            n2 = 2 * n
+            idx = np.where(idx < 0, n2 - 1 - ((-idx - 1) % n2), idx % n2)
+            idx = np.where(idx >= n, n2 - 1 - idx, idx)
+            wgt = _bspline3_w(g - g0 - node)
+            shp = [1, 1, 1]
+            shp[axis] = m
+            out = out + np.take(c, idx, axis=axis) * wgt.reshape(shp)
+        c = out
+    return c

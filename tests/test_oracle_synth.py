@@ -120,3 +120,16 @@ def test_deform_grid_atlas_contrast_onehot():
     assert np.array_equal(S.synth_from_labels(d["cs_G"], d["cs_mus"], d["cs_sigmas"], d["cs_randn"]), d["cs_out"])
     lut = np.zeros(10000, np.int64); lut[:64] = d["oh_lut"]
     assert np.array_equal(S.onehot_lut(d["oh_S"], lut, 56), d["oh_out"])
+
+
+def test_cubic_bspline_resize_oracle_vs_reference_golden():
+    """The oracle's separable fp64 restatement of interpol.resize(interpolation=3, bound='dct2', prefilter=True)
+    against the reference's own (fp32, 64-tap) evaluation: prefilter coefficients and resized volumes."""
+    d = load_npz("interpol_resize.npz")
+    for name, anchor in (("up", "e"), ("down", "e"), ("centers", "c")):
+        x = d[name + "/x"]
+        coeff = S.bspline3_prefilter_dct2(x)
+        assert np.abs(coeff - d[name + "/coeff"]).max() <= 2e-5 * np.abs(d[name + "/coeff"]).max()
+        y = S.resize_cubic_ref(x, [int(v) for v in d[name + "/shape"]], anchor)
+        assert y.shape == d[name + "/y"].shape
+        assert np.abs(y - d[name + "/y"]).max() <= 2e-5 * np.abs(d[name + "/y"]).max(), name
