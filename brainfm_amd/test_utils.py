@@ -149,12 +149,14 @@ def center_crop(img, win_size=[220, 220, 220], zero_crop_first=False, aff=np.eye
 
 
 # ----------------------------------------------------------------------------- prepare_image
-_VOLUME_READER = None
+from . import volio as _volio                       # NIfTI-1 / MGH reader-writer, no nibabel needed
+
+_VOLUME_READER = _volio.MRIread
 
 
 def set_volume_reader(fn):
-    """Register ``fn(path, im_only=False, dtype='float') -> (ndarray, affine)``: the one host-side hook the reference
-    fills with utils.misc.MRIread (nibabel); file formats are outside this package."""
+    """Replace the reader ``fn(path, im_only=False, dtype='float') -> (ndarray, affine)`` used for path arguments
+    (default: brainfm_amd.volio.MRIread; the reference's nibabel-based utils.misc.MRIread plugs in here too)."""
     global _VOLUME_READER
     _VOLUME_READER = fn
 
@@ -162,9 +164,6 @@ def set_volume_reader(fn):
 def _read_volume(img, is_label):
     if isinstance(img, (tuple, list)) and len(img) == 2:
         return np.asarray(img[0]), np.asarray(img[1], dtype=np.float64)
-    if _VOLUME_READER is None:
-        raise L.BfmError("prepare_image got a path but no volume reader is registered: call "
-                         "brainfm_amd.test_utils.set_volume_reader(utils.misc.MRIread) or pass (array, affine)")
     return _VOLUME_READER(img, im_only=False, dtype="int" if is_label else "float")
 
 

@@ -231,3 +231,61 @@ def test_prepare_image_host_plans_match_reference():
     crop, start, shp, aff_out = TU.center_crop(al, [32, 32, 32], aff=d["A/aff_aligned"].copy())
     assert list(start) == [(al.shape[i] - 32) // 2 for i in range(3)] and tuple(shp) == tuple(al.shape)
     assert np.array_equal(crop[0, 0].numpy(), d["A/orig"][0, 0])
+
+
+def test_volume_io_nifti_mgh_roundtrip_and_format_fields(tmp_path):
+    """brainfm_amd.volio against the file-format definitions: NIfTI-1 / MGH round trips, header fields a
+    third-party reader relies on, a hand-built big-endian qform-only NIfTI with intensity scaling, cropped reads."""
+    import gzip
+    import struct
+    from brainfm_amd import volio as V
+    rng = np.random.RandomState(3)
+    aff = np.array([[0., -1.2, 0., 30.], [1.0, 0., 0., -20.], [0., 0., -2.0, 5.], [0., 0., 0., 1.]])
+    for ext, dt in ((".nii", np.float32), (".nii.gz", np.int16), (".nii", np.uint8), (".mgz", np.float32), (".mgz", np.int16)):
+        vol = (rng.rand(7, 5, 9) * 100).astype(dt)
+        f = str(tmp_path / ("v_%s%s" % (np.dtype(dt).name, ext)))
+        V.MRIwrite(vol, aff, f)
+        got, a2 = V.MRIread(f)
+        assert got.dtype == np.float64 and np.array_equal(got, vol.astype(np.float64))
+        assert np.allclose(a2, aff, atol=1e-5)
+        assert np.array_equal(V.MRIread(f, dtype="int", im_only=True), vol.astype(np.float64).astype("int"))
+        img = V.load(f)
+        assert np.array_equal(img.dataobj[1:6, 2:4, 3:8], got[1:6, 2:4, 3:8])
+    # header fields of a written NIfTI-1
+    f = str(tmp_path / "fields.nii")
+    V.MRIwrite(np.zeros((4, 3, 2), np.float32), aff, f)
+    raw = open(f, "rb").read()
+    assert struct.unpack("<i", raw[:4])[0] == 348 and raw[344:348] == b"n+1\x00"
+    assert struct.unpack("<8h", raw[40:56])[:4] == (3, 4, 3, 2)
+    assert struct.unpack("<2h", raw[70:74]) == (16, 32) and struct.unpack("<f", raw[108:112])[0] == 352.0
+    assert struct.unpack("<2h", raw[252:256]) == (0, 2)
+    assert np.allclose(struct.unpack("<12f", raw[280:328]), aff[:3].reshape(-1))
+    assert np.allclose(struct.unpack("<8f", raw[76:108])[1:4], [1.0, 1.2, 2.0]) and len(raw) == 352 + 4 * 24
+    # hand-built big-endian, qform only: 90 degrees about z (b,c,d = 0,0,sin45), zooms (1,2,3), qfac -1, y = 2*raw - 1
+    hdr = bytearray(348)
+    struct.pack_into(">i", hdr, 0, 348)
+    struct.pack_into(">8h", hdr, 40, 3, 2, 3, 4, 1, 1, 1, 1)
+    struct.pack_into(">2h", hdr, 70, 4, 16)
+    struct.pack_into(">8f", hdr, 76, -1.0, 1.0, 2.0, 3.0, 1, 1, 1, 1)
+    struct.pack_into(">f", hdr, 108, 352.0)
+    struct.pack_into(">2f", hdr, 112, 2.0, -1.0)
+    struct.pack_into(">2h", hdr, 252, 1, 0)
+    struct.pack_into(">6f", hdr, 256, 0.0, 0.0, np.sqrt(0.5), 10.0, 20.0, 30.0)
+    hdr[344:348] = b"n+1\x00"
+    data = np.arange(24, dtype=">i2")
+    f = str(tmp_path / "be.nii.gz")
+    with gzip.open(f, "wb") as fh:
+        fh.write(bytes(hdr) + b"\x00" * 4 + data.tobytes())
+    got, a2 = V.MRIread(f)
+    assert got.shape == (2, 3, 4) and np.array_equal(got, 2.0 * np.arange(24).reshape((2, 3, 4), order="F") - 1.0)
+    expect = np.array([[0., -2., 0., 10.], [1., 0., 0., 20.], [0., 0., -3., 30.], [0., 0., 0., 1.]])
+    assert np.allclose(a2, expect, atol=1e-6)
+    # MGH without geometry: FreeSurfer's default LIA orientation, centre at the origin
+    hdr = bytearray(284)
+    struct.pack_into(">7i", hdr, 0, 1, 2, 2, 2, 1, 0, 0)
+    f = str(tmp_path / "plain.mgz")
+    with gzip.open(f, "wb") as fh:
+        fh.write(bytes(hdr) + bytes(range(8)))
+    got, a2 = V.MRIread(f)
+    assert np.array_equal(got.reshape(-1, order="F"), np.arange(8.0))
+    assert np.allclose(a2, [[-1, 0, 0, 1], [0, 0, 1, -1], [0, -1, 0, 1], [0, 0, 0, 1]])
