@@ -296,3 +296,21 @@ def test_cubic_bspline_resize_vs_reference_golden(name, anchor):
     # linear resize goes through grid_pull
     y1 = IP.resize(x, shape=shape, anchor=anchor, interpolation=1, bound="dct2")
     assert tuple(y1.shape) == tuple(shape)
+
+
+@pytest.mark.gpu
+def test_prepare_image_from_nifti_file_equals_in_memory(tmp_path):
+    """File boundary: a volume written with brainfm_amd.volio.MRIwrite and read back through the default
+    reader gives the same prepare_image result as the in-memory (array, affine) form."""
+    from brainfm_amd import test_utils as TU, volio as V
+    d = load_npz("prep_image.npz")
+    vol, aff = d["A/vol"], d["A/aff"]
+    f = str(tmp_path / "case_A.nii.gz")
+    V.MRIwrite(vol, aff, f)
+    a = TU.prepare_image(f, win_size=[32, 32, 32], device="cuda:0")
+    b = TU.prepare_image((vol.copy(), aff.copy()), win_size=[32, 32, 32], device="cuda:0")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and np.allclose(a[4], b[4], atol=1e-5)
+    out = str(tmp_path / "final.nii.gz")
+    V.MRIwrite(a[0][0, 0].cpu().numpy(), a[4], out)
+    back, aff_back = V.MRIread(out)
+    assert np.array_equal(back.astype(np.float32), a[0][0, 0].cpu().numpy()) and np.allclose(aff_back, a[4], atol=1e-4)
