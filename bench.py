@@ -177,6 +177,17 @@ def main():
         dist.all_reduce(agg)
     k_ms, k_fl, k_by, k_n = [float(v) for v in agg.tolist()]
     achieved = k_fl / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+    # HBM traffic of the conv kernels: rocprofv3 PMC passes cannot run inside this process; the committed summary of the
+    # same workload (scripts/pmc_traffic.py, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md) is reported per launch
+    traffic, traffic_note = None, None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_conv_hbm_traffic.json")
+    if os.path.exists(tpath) and args.size == 256:
+        try:
+            tj = json.load(open(tpath))
+            traffic = tj["kernels"]["conv"]["hbm_bytes_per_launch"]
+            traffic_note = "profiles/r01_conv_hbm_traffic.json: " + tj["source"]
+        except Exception:
+            traffic = None
     peak = 2500.0                                            # dense f16 MFMA, MI355X_MICROARCH.md
     if rank == 0:
         tile_vox = sum(TU.tile_cost(r) for r in ranges)
@@ -197,7 +208,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "conv_mfma* (the %d conv launches of one step, all variants)" % int(k_n),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "kernel_ms_per_step": k_ms / max(world, 1), "avg_launch_us": k_ms * 1e3 / max(k_n, 1),
-                         "traffic": None, "algorithmic_bytes_per_step": k_by,
+                         "traffic": traffic, "traffic_source": traffic_note,
+                         "algorithmic_bytes_per_launch": k_by / max(k_n, 1), "algorithmic_bytes_per_step": k_by,
                          "note": "achieved = algorithmic conv FLOPs of one step / summed launch durations; durations "
                                  "from HIP events around %d back-to-back launches of each conv in an instrumented "
                                  "eager replay of the step right after the timed region; the kernel issues %dx the "

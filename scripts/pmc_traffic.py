@@ -1,0 +1,47 @@
+"""HBM traffic of the conv kernels of one bench step from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate
+passes as MI355X_MICROARCH.md prescribes: the TCC block cannot hold both).  Units: KB per dispatch; on gfx950
+FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled here.  Only the dispatches of the LAST step
+(after the last run of count_add_kernel launches, which open a step) are kept.
+usage: python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+import csv
+import json
+import sys
+
+
+def last_step(path, counter):
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    last = max(i for i, r in enumerate(rows) if "count_add_kernel" in r["Kernel_Name"])
+    first = last
+    while first > 0 and "count_add_kernel" in rows[first - 1]["Kernel_Name"]:
+        first -= 1
+    return rows[first:]
+
+
+def family(name):
+    for k in ("conv_upfold", "conv_wino", "conv_mfma16", "conv_mfma_ws", "conv_mfma", "conv_stem"):
+        if k in name:
+            return "conv"
+    return None
+
+
+fetch = last_step(sys.argv[1], "FETCH_SIZE")
+write = last_step(sys.argv[2], "WRITE_SIZE")
+out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) on bench.py --steps 1 --warmup 1 "
+                 "--no-graphs --roofline-reps 0 --no-cpu-baseline; last step only; FETCH_SIZE x2 (gfx950 correction)",
+       "kernels": {}}
+for rows, key, mult in ((fetch, "fetch_bytes", 2.0), (write, "write_bytes", 1.0)):
+    for r in rows:
+        fam = family(r["Kernel_Name"])
+        if fam is None:
+            continue
+        e = out["kernels"].setdefault(fam, {"launches_fetch_pass": 0, "launches_write_pass": 0, "fetch_bytes": 0.0,
+                                            "write_bytes": 0.0})
+        e[key] += float(r["Counter_Value"]) * 1024.0 * mult
+        e["launches_fetch_pass" if key == "fetch_bytes" else "launches_write_pass"] += 1
+for fam, e in out["kernels"].items():
+    n = max(e["launches_fetch_pass"], 1)
+    e["hbm_bytes_per_step"] = e["fetch_bytes"] + e["write_bytes"]
+    e["hbm_bytes_per_launch"] = e["hbm_bytes_per_step"] / n
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out, indent=1))
