@@ -45,6 +45,8 @@ struct WinoParams {
     int pw_shift, thp_shift;         // log2(PW), log2(TH*PW)
     int nTy, nTx, nMt, NT, KCN;
     int npos_lds, plane_stride;      // (TD+2)*HT*PW positions; bytes per plane
+    double *rsum, *rsq;              // optional output-moment rows [nMt][Cout] (see conv3d_mfma.hip), 4-wave kernel only
+    float *rmn, *rmx;
     int ws_buf_bytes;                // persistent kernel: bytes per LDS buffer
 };
 
@@ -276,6 +278,7 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
                 m[(pos * 128 + mb * 32 + row_perm(rr)) * MLD + l32] = acc[mb][nb][i];
             }
         __syncthreads();
+        float fs = 0.f, fq = 0.f, fmn = INFINITY, fmx = -INFINITY;   // this thread's column, its 16 pairs (<= 32 values)
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
             const int q = row0 + 8 * it;
@@ -291,10 +294,33 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
             if (p.accum) y0v = y0v + o[0];
             y0v = y0v >= 0.f ? y0v : y0v * p.slope;
             o[0] = y0v;
+            fs += y0v; fq = fmaf(y0v, y0v, fq); fmn = fminf(fmn, y0v); fmx = fmaxf(fmx, y0v);
             if (gx + 1 < p.W) {
                 if (p.accum) y1v = y1v + o[p.Cout];
                 y1v = y1v >= 0.f ? y1v : y1v * p.slope;
                 o[p.Cout] = y1v;
+                fs += y1v; fq = fmaf(y1v, y1v, fq); fmn = fminf(fmn, y1v); fmx = fmaxf(fmx, y1v);
+            }
+        }
+        if (p.rsum != nullptr) {
+            // moment row of this tile: fold the 8 row groups of every column in fixed order (scratch behind m)
+            double* ls = reinterpret_cast<double*>(lds + 4 * 128 * MLD * sizeof(float));   // [8][32]
+            double* lq = ls + 256;
+            float* lmn = reinterpret_cast<float*>(lq + 256);
+            float* lmx = lmn + 256;
+            ls[row0 * 32 + col] = (double)fs; lq[row0 * 32 + col] = (double)fq;
+            lmn[row0 * 32 + col] = fmn; lmx[row0 * 32 + col] = fmx;
+            __syncthreads();
+            if (tid < 32) {
+                double S = 0.0, Q = 0.0;
+                float MN = INFINITY, MX = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    S += ls[r * 32 + tid]; Q += lq[r * 32 + tid];
+                    MN = fminf(MN, lmn[r * 32 + tid]); MX = fmaxf(MX, lmx[r * 32 + tid]);
+                }
+                const size_t o = (size_t)mt * p.Cout + nt * 64 + nb * 32 + tid;
+                p.rsum[o] = S; p.rsq[o] = Q; p.rmn[o] = MN; p.rmx[o] = MX;
             }
         }
     }
@@ -693,9 +719,29 @@ extern "C" int bfm_pack_conv_weights_wino(const float* w_oidhw, int Cin, int Cou
     return bfm_launch_status();
 }
 
+// rows of the output-moment table the 4-wave kernel writes for this volume (its own box choice), 0 if it cannot run
+extern "C" int bfm_conv3x3x3_wino_rows(int D, int H, int W, int passes) {
+    int TD, TH, TW;
+    if (D <= 0 || H <= 0 || W <= 0 || !choose_box(D, H, W, passes == 3 ? 2 : 1, TD, TH, TW)) return 0;
+    return bfm_cdiv(D, TD) * bfm_cdiv(H, TH) * bfm_cdiv(W, TW);
+}
+
+extern "C" int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W, const float* scale,
+                                     const float* shift, const float* bound, int G, const void* wpacked, int wexp,
+                                     int Cout, float slope, int passes, int flags, float* out, void* moment_rows,
+                                     bfm_stream_t stream);
+
 extern "C" int bfm_conv3x3x3_wino(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                                   const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope,
                                   int passes, int flags, float* out, bfm_stream_t stream) {
+    return bfm_conv3x3x3_wino_ex(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out,
+                                 nullptr, stream);
+}
+
+extern "C" int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W, const float* scale,
+                                     const float* shift, const float* bound, int G, const void* wpacked, int wexp,
+                                     int Cout, float slope, int passes, int flags, float* out, void* moment_rows,
+                                     bfm_stream_t stream) {
     const int accumulate = flags & 1;
     const bool persistent = (flags & 2) != 0;
     if (!A || CA <= 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || G <= 0 || !wpacked || !out)
@@ -724,8 +770,18 @@ extern "C" int bfm_conv3x3x3_wino(const float* A, int CA, int D, int H, int W, c
     p.npos_lds = (p.TD + 2) * p.HT * p.PW;
     p.plane_stride = ((p.npos_lds * 16 + 255) / 256) * 256 + 16;
     size_t smem = (size_t)8 * npl * p.plane_stride;
-    const size_t epi = (size_t)4 * 128 * MLD * sizeof(float);
+    const size_t epi = (size_t)4 * 128 * MLD * sizeof(float) + 6144;    // output-transform scratch + moment-row fold
     if (smem < epi) smem = epi;
+    if (moment_rows) {
+        if (persistent) return BFM_E_SHAPE;
+        if (reinterpret_cast<uintptr_t>(moment_rows) & 7) return BFM_E_ARG;
+        char* rb = static_cast<char*>(moment_rows);
+        const size_t n = (size_t)p.nMt * Cout;
+        p.rsum = reinterpret_cast<double*>(rb);
+        p.rsq = reinterpret_cast<double*>(rb + n * 8);
+        p.rmn = reinterpret_cast<float*>(rb + n * 16);
+        p.rmx = reinterpret_cast<float*>(rb + n * 20);
+    }
     if (smem > 80 * 1024) return BFM_E_SHAPE;
     if ((int64_t)p.nMt * p.NT > 0x7fffffff) return BFM_E_SHAPE;
     static bool attr_done = false;

@@ -260,9 +260,10 @@ class UNetEngine:
         if cfg[6] in (3, 4):
             if cb:
                 raise L.BfmError("the Winograd variant takes one source")
-            L.check(self.lib.bfm_conv3x3x3_wino(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound), groups,
-                                                L.ptr(ly.wpacked), ly.wexp, ly.cout, self.slope, self.passes,
-                                                (cfg[7] & 1) | (2 if cfg[6] == 4 else 0), L.ptr(out), st),
+            L.check(self.lib.bfm_conv3x3x3_wino_ex(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
+                                                   groups, L.ptr(ly.wpacked), ly.wexp, ly.cout, self.slope, self.passes,
+                                                   (cfg[7] & 1) | (2 if cfg[6] == 4 else 0), L.ptr(out),
+                                                   L.ptr(rows[0]) if rows is not None else None, st),
                     "conv_wino " + ly.name)
             return
         L.check(self.lib.bfm_conv3x3x3_mfma_ex(L.ptr(A), ca, L.ptr(B) if cb else None, cb, D, H, W, upp if cb else None,
@@ -275,7 +276,10 @@ class UNetEngine:
         """(buffer, nrows) for the producer's output-moment rows, or None when this plan cannot emit them."""
         if not self.fuse_stats:
             return None
-        n = self.lib.bfm_conv3x3x3_mfma_rows(cin, cout, dims[0], dims[1], dims[2], cfg)
+        if cfg[6] == 3:
+            n = self.lib.bfm_conv3x3x3_wino_rows(dims[0], dims[1], dims[2], self.passes)
+        else:
+            n = self.lib.bfm_conv3x3x3_mfma_rows(cin, cout, dims[0], dims[1], dims[2], cfg)
         if n <= 0:
             return None
         buf = torch.empty(self.lib.bfm_moment_rows_bytes(n, cout), dtype=torch.uint8, device=self.device)

@@ -108,6 +108,11 @@ int bfm_conv3x3x3_wino(const float* A, int CA, int D, int H, int W, const float*
                        int flags /* bit 0: accumulate onto out; bit 1: wave-specialised persistent kernel */,
                        float* out, bfm_stream_t stream);
 
+int bfm_conv3x3x3_wino_rows(int D, int H, int W, int passes);   /* moment rows of the 4-wave kernel (0: cannot run) */
+int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
+                          const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
+                          int flags, float* out, void* moment_rows /*or NULL; 4-wave kernel only*/, bfm_stream_t stream);
+
 /* Output-moment rows.  A producer (conv3x3x3_mfma_ex / conv3x3x3_stem_ex) can write, next to its output, one row
  * per tile of per-channel {sum, sumsq} (fp64) and {min, max} (fp32) of the values it stored: buffer of
  * bfm_moment_rows_bytes(nrows, Cout) bytes laid out sum[nrows][C] | sumsq[nrows][C] | min[nrows][C] | max[nrows][C].

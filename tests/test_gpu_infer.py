@@ -293,7 +293,7 @@ def test_upsample_folded_decoder_conv_equals_generic_path(lo):
     assert e <= 2e-6, e
 
 
-@pytest.mark.parametrize("ver", [0, 2])
+@pytest.mark.parametrize("ver", [0, 2, 3])
 def test_producer_moment_rows_equal_activation_moments(ver, monkeypatch):
     """The per-tile {sum, sumsq, min, max} rows written by the stem / conv epilogues must be the moments of the
     stored activation (sums to fp32-partial accuracy; min/max exact), and GroupNorm from rows must reproduce GroupNorm from the
