@@ -639,6 +639,252 @@ __global__ void __launch_bounds__(512, 1) conv_wino_ws(const WinoParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 8-wave, software-pipelined form: wave = (position, half of the tile's pair rows), so a wave holds 2x2 accumulator
+// blocks (64 registers) and has room to keep the NEXT chunk's global loads in flight while it multiplies the current
+// one: loads for chunk k+1 are issued before the MFMA loop of chunk k and converted (affine, transform, split, LDS
+// write) after it.  Only that conversion (~a quarter of the MFMA time) stays exposed.  One workgroup per CU.
+template <int NPASS>
+__global__ void __launch_bounds__(512, 1) conv_wino8(const WinoParams p) {
+    constexpr int NPL = (NPASS == 3) ? 2 : 1;
+    constexpr int NF = 2 * NPL;
+    constexpr int MAX_IT = 3;                                      // ceil(5*256 / 512): staging items per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pos = wave & 3, mh = wave >> 2;                      // Winograd position, row half
+    const int l32 = lane & 31, khalf = lane >> 5;
+
+    int bid = blockIdx.x;
+    {
+        const int nblk = p.nMt * p.NT;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = bid / p.NT, nt = bid - mt * p.NT;
+    const int tx = mt % p.nTx;
+    const int ty = (mt / p.nTx) % p.nTy;
+    const int tz = mt / (p.nTx * p.nTy);
+    const int z0 = tz * p.TD, y0 = ty * p.TH, x0 = tx * p.TW;
+
+    float bmax = 0.f;
+    for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, p.bound[g]);
+    int aexp = 0;
+    if (bmax > 0.f && bmax < INFINITY) {
+        int ex;
+        (void)frexpf(bmax, &ex);
+        aexp = 13 - ex;
+        aexp = aexp > 60 ? 60 : (aexp < -60 ? -60 : aexp);
+    }
+    const float a_scale = ldexpf(1.0f, aexp);
+    const float dq = ldexpf(1.0f, -(aexp + p.wexp));
+
+    int a_off[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        int d, h, j;
+        pair_coords(p, (mh * 2 + mb) * 32 + row_perm(l32), d, h, j);
+        a_off[mb] = ((pos * 2 + khalf) * NPL) * p.plane_stride + ((d * p.HT + h) * p.PW + j) * 16;
+    }
+
+    const int n_el = p.npos_lds * 4;
+    const int q4 = tid & 3;
+    int off0[MAX_IT], msk[MAX_IT];
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        const int e = tid + it * 512;
+        off0[it] = 0;
+        msk[it] = -1;
+        if (e < n_el) {
+            const int ps = e >> 2;
+            const int j = ps & ((1 << p.pw_shift) - 1);
+            const int r = ps >> p.pw_shift;
+            const int hz = r / p.HT, hy = r - hz * p.HT;
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + 2 * j - 1;
+            int m = 0;
+            if (gz >= 0 && gz < p.D && gy >= 0 && gy < p.H) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (gx + i >= 0 && gx + i < p.W) m |= 1 << i;
+            }
+            msk[it] = m;
+            off0[it] = ((gz * p.H + gy) * p.W + gx) * p.CA;
+        }
+    }
+    const int st_plane = ((q4 >> 1) * NPL) * p.plane_stride + (q4 & 1) * 8;
+
+    float4 v[MAX_IT][4];
+    auto load_chunk = [&](int kc) __attribute__((always_inline)) {
+        const float* src = p.A + kc * KC + q4 * 4;
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[it][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (msk[it] >= 0 && (msk[it] & (1 << i)))
+                    v[it][i] = *reinterpret_cast<const float4*>(src + off0[it] + i * p.CA);
+            }
+    };
+    auto write_chunk = [&](int kc) __attribute__((always_inline)) {
+        const int c0 = kc * KC;
+        const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + c0 + q4 * 4);
+        const float4 sh4 = *reinterpret_cast<const float4*>(p.shift + c0 + q4 * 4);
+        const float sc[4] = {sc4.x * a_scale, sc4.y * a_scale, sc4.z * a_scale, sc4.w * a_scale};
+        const float sh[4] = {sh4.x * a_scale, sh4.y * a_scale, sh4.z * a_scale, sh4.w * a_scale};
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it) {
+            if (msk[it] < 0) continue;
+            float dd[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = msk[it] & (1 << i);
+                const float y[4] = {v[it][i].x, v[it][i].y, v[it][i].z, v[it][i].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dd[i][c] = ok ? fmaf(y[c], sc[c], sh[c]) : 0.f;
+            }
+            const int e = tid + it * 512;
+            unsigned char* dst = lds + st_plane + (e >> 2) * 16;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                half4 hi, lo;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float t = ps == 0 ? dd[0][c] - dd[2][c]
+                                  : ps == 1 ? dd[1][c] + dd[2][c]
+                                  : ps == 2 ? dd[2][c] - dd[1][c]
+                                            : dd[1][c] - dd[3][c];
+                    const _Float16 hh = (_Float16)t;
+                    hi[c] = hh;
+                    lo[c] = (_Float16)(t - (float)hh);
+                }
+                unsigned char* dp = dst + (ps * 2 * NPL) * p.plane_stride;
+                *reinterpret_cast<half4*>(dp) = hi;
+                if constexpr (NPASS == 3) *reinterpret_cast<half4*>(dp + p.plane_stride) = lo;
+            }
+        }
+    };
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
+
+    const int S = p.KCN * 9;
+    const uint4* wbase = p.wp + (size_t)(nt * 4 + pos) * S * (NF * 64) + lane;
+    uint4 wq[3][NF];
+    auto fetch = [&](int s, uint4 (&dst)[NF]) __attribute__((always_inline)) {
+        const int sc = s < S ? s : S - 1;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) dst[f] = wbase[(size_t)sc * (NF * 64) + f * 64];
+    };
+    fetch(0, wq[0]);
+    fetch(1, wq[1]);
+
+    load_chunk(0);
+    write_chunk(0);
+    __syncthreads();
+    for (int kc = 0; kc < p.KCN; ++kc) {
+        if (kc + 1 < p.KCN) load_chunk(kc + 1);                    // in flight during the MFMA loop below
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int kd = t / 3, kh = t - kd * 3;
+            const int toff = (kd * p.HT + kh) * p.PW * 16;
+            const int cur = t % 3;
+            uint4 bw[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) bw[f] = wq[cur][f];
+            fetch(kc * 9 + t + 2, wq[(cur + 2) % 3]);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                half8 a[NPL];
+#pragma unroll
+                for (int hl = 0; hl < NPL; ++hl)
+                    a[hl] = *reinterpret_cast<const half8*>(lds + a_off[mb] + hl * p.plane_stride + toff);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const half8 bhi = __builtin_bit_cast(half8, bw[nb * NPL]);
+                    if constexpr (NPASS == 3) {
+                        const half8 blo = __builtin_bit_cast(half8, bw[nb * NPL + 1]);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bhi, acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], blo, acc[mb][nb], 0, 0, 0);
+                    }
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bhi, acc[mb][nb], 0, 0, 0);
+                }
+            }
+        }
+        if (kc + 1 < p.KCN) {
+            __syncthreads();                                       // every wave is done reading the planes
+            write_chunk(kc + 1);
+            __syncthreads();
+        }
+    }
+
+    // ================= epilogue: output transform through LDS (all 512 threads) =================
+    float* m = reinterpret_cast<float*>(lds);                      // [4 positions][128 pairs][MLD]
+    const int col = tid & 31, row0 = tid >> 5;                     // 16 row groups
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        __syncthreads();
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rr = (i >> 2) * 8 + khalf * 4 + (i & 3);
+                m[(pos * 128 + (mh * 2 + mb) * 32 + row_perm(rr)) * MLD + l32] = acc[mb][nb][i];
+            }
+        __syncthreads();
+        float fs = 0.f, fq = 0.f, fmn = INFINITY, fmx = -INFINITY;
+#pragma unroll 4
+        for (int it = 0; it < 8; ++it) {
+            const int q = row0 + 16 * it;
+            int d, h, j;
+            pair_coords(p, q, d, h, j);
+            const int gz = z0 + d, gy = y0 + h, gx = x0 + 2 * j;
+            if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
+            const float m0 = m[(0 * 128 + q) * MLD + col], m1 = m[(1 * 128 + q) * MLD + col];
+            const float m2 = m[(2 * 128 + q) * MLD + col], m3 = m[(3 * 128 + q) * MLD + col];
+            float* o = p.out + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + nt * 64 + nb * 32 + col;
+            float y0v = ((m0 + m1) + m2) * dq;
+            float y1v = ((m1 - m2) - m3) * dq;
+            if (p.accum) y0v = y0v + o[0];
+            y0v = y0v >= 0.f ? y0v : y0v * p.slope;
+            o[0] = y0v;
+            fs += y0v; fq = fmaf(y0v, y0v, fq); fmn = fminf(fmn, y0v); fmx = fmaxf(fmx, y0v);
+            if (gx + 1 < p.W) {
+                if (p.accum) y1v = y1v + o[p.Cout];
+                y1v = y1v >= 0.f ? y1v : y1v * p.slope;
+                o[p.Cout] = y1v;
+                fs += y1v; fq = fmaf(y1v, y1v, fq); fmn = fminf(fmn, y1v); fmx = fmaxf(fmx, y1v);
+            }
+        }
+        if (p.rsum != nullptr) {
+            double* ls = reinterpret_cast<double*>(lds + 4 * 128 * MLD * sizeof(float));   // [16][32]
+            double* lq = ls + 512;
+            float* lmn = reinterpret_cast<float*>(lq + 512);
+            float* lmx = lmn + 512;
+            ls[row0 * 32 + col] = (double)fs; lq[row0 * 32 + col] = (double)fq;
+            lmn[row0 * 32 + col] = fmn; lmx[row0 * 32 + col] = fmx;
+            __syncthreads();
+            if (tid < 32) {
+                double SS = 0.0, Q = 0.0;
+                float MN = INFINITY, MX = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    SS += ls[r * 32 + tid]; Q += lq[r * 32 + tid];
+                    MN = fminf(MN, lmn[r * 32 + tid]); MX = fmaxf(MX, lmx[r * 32 + tid]);
+                }
+                const size_t o = (size_t)mt * p.Cout + nt * 64 + nb * 32 + tid;
+                p.rsum[o] = SS; p.rsq[o] = Q; p.rmn[o] = MN; p.rmx[o] = MX;
+            }
+        }
+    }
+}
+
 // packed[ntile64][pos 4][kc][(kd,kh) 9][nb 2][hl][lane] (uint4 = 8 halfs): lane l holds
 // B[k = 8*(l>>5)+j][n = l&31] = U_pos[co = ntile*64 + nb*32 + (l&31)][ci = kc*16 + 8*(l>>5) + j][kd][kh] * 2^wexp,
 // U = G g along kw: (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2)
@@ -744,6 +990,7 @@ extern "C" int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W
                                      bfm_stream_t stream) {
     const int accumulate = flags & 1;
     const bool persistent = (flags & 2) != 0;
+    const bool eight = (flags & 4) != 0;
     if (!A || CA <= 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || G <= 0 || !wpacked || !out)
         return BFM_E_ARG;
     if (CA % KC || Cout % 64 || Cout <= 0) return BFM_E_SHAPE;
@@ -814,6 +1061,23 @@ extern "C" int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W
         return bfm_launch_status();
     }
     dim3 grid((unsigned)(p.nMt * p.NT));
+    if (eight) {
+        size_t smem8 = (size_t)8 * npl * p.plane_stride;
+        const size_t epi8 = (size_t)4 * 128 * MLD * sizeof(float) + 12288;
+        if (smem8 < epi8) smem8 = epi8;
+        if (smem8 > 160 * 1024) return BFM_E_SHAPE;
+        static bool attr8 = false;
+        if (!attr8) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024);
+            attr8 = true;
+        }
+        if (passes == 3) hipLaunchKernelGGL(conv_wino8<3>, grid, dim3(512), smem8, bfm_s(stream), p);
+        else hipLaunchKernelGGL(conv_wino8<1>, grid, dim3(512), smem8, bfm_s(stream), p);
+        return bfm_launch_status();
+    }
     if (passes == 3) hipLaunchKernelGGL(conv_wino<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
     else hipLaunchKernelGGL(conv_wino<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
     return bfm_launch_status();

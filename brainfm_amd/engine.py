@@ -137,7 +137,7 @@ class UNetEngine:
         """Pack (once per layout) and select the weights for this launch: 'direct' [27][Cin][Cout] fp32,
         'mfma' 32x32x16 fragments (plan variants 0/1), 'mfma16' 16x16x32 tap-pair fragments (variant 2),
         'wino' F(2,3)-along-x transformed fragments (variant 3, single-source layers only)."""
-        layout = "direct" if not mfma else ("wino" if ver in (3, 4) else ("mfma16" if ver == 2 else "mfma"))
+        layout = "direct" if not mfma else ("wino" if ver in (3, 4, 5) else ("mfma16" if ver == 2 else "mfma"))
         if layout not in ly.packs:
             st = L.stream_ptr()
             if layout == "wino":
@@ -187,7 +187,7 @@ class UNetEngine:
         if key not in self._plan_cache:
             cfg = (C.c_int * 8)()
             L.check(self.lib.bfm_conv3x3x3_mfma_plan(cin, cout, dims[0], dims[1], dims[2], cfg), "mfma_plan")
-            if two_src and cfg[6] in (3, 4):                     # BFM_CONV_VER=3/4: Winograd takes one source
+            if two_src and cfg[6] in (3, 4, 5):                     # BFM_CONV_VER=3/4: Winograd takes one source
                 cfg[6] = 0
             self._plan_cache[key] = cfg
         return self._plan_cache[key]
@@ -257,12 +257,12 @@ class UNetEngine:
         D, H, W = dims
         st = L.stream_ptr()
         self._pack(ly, True, cfg[6])
-        if cfg[6] in (3, 4):
+        if cfg[6] in (3, 4, 5):
             if cb:
                 raise L.BfmError("the Winograd variant takes one source")
             L.check(self.lib.bfm_conv3x3x3_wino_ex(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
                                                    groups, L.ptr(ly.wpacked), ly.wexp, ly.cout, self.slope, self.passes,
-                                                   (cfg[7] & 1) | (2 if cfg[6] == 4 else 0), L.ptr(out),
+                                                   (cfg[7] & 1) | (2 if cfg[6] == 4 else 0) | (4 if cfg[6] == 5 else 0), L.ptr(out),
                                                    L.ptr(rows[0]) if rows is not None else None, st),
                     "conv_wino " + ly.name)
             return
@@ -276,7 +276,7 @@ class UNetEngine:
         """(buffer, nrows) for the producer's output-moment rows, or None when this plan cannot emit them."""
         if not self.fuse_stats:
             return None
-        if cfg[6] == 3:
+        if cfg[6] in (3, 5):
             n = self.lib.bfm_conv3x3x3_wino_rows(dims[0], dims[1], dims[2], self.passes)
         else:
             n = self.lib.bfm_conv3x3x3_mfma_rows(cin, cout, dims[0], dims[1], dims[2], cfg)

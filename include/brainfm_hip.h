@@ -105,7 +105,8 @@ int bfm_pack_conv_weights_wino(const float* w_oidhw, int Cin, int Cout, float wm
                                int* wexp_host, bfm_stream_t stream);
 int bfm_conv3x3x3_wino(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                        const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
-                       int flags /* bit 0: accumulate onto out; bit 1: wave-specialised persistent kernel */,
+                       int flags /* bit 0: accumulate onto out; bit 1: wave-specialised persistent kernel; bit 2: 8-wave
+                                    software-pipelined kernel */,
                        float* out, bfm_stream_t stream);
 
 int bfm_conv3x3x3_wino_rows(int D, int H, int W, int passes);   /* moment rows of the 4-wave kernel (0: cannot run) */

@@ -28,7 +28,7 @@ for passes in (3, 1):
     ly.name, ly.cin, ly.cout, ly.groups = "bench", cin, cout, 8
     ly.w_raw = (torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05).contiguous()
     ly.packs, ly.kind, ly.wpacked, ly.wexp, ly.skip = {}, None, None, 0, None
-    for ver in (0, 1, 2, 3, 4):
+    for ver in (0, 1, 2, 3, 4, 5):
         cfg = (C.c_int * 8)()
         L.check(lib.bfm_conv3x3x3_mfma_plan(cin, cout, D, H, W, cfg), "plan")
         cfg[6] = ver

@@ -293,7 +293,7 @@ def test_upsample_folded_decoder_conv_equals_generic_path(lo):
     assert e <= 2e-6, e
 
 
-@pytest.mark.parametrize("ver", [0, 2, 3])
+@pytest.mark.parametrize("ver", [0, 2, 3, 5])
 def test_producer_moment_rows_equal_activation_moments(ver, monkeypatch):
     """The per-tile {sum, sumsq, min, max} rows written by the stem / conv epilogues must be the moments of the
     stored activation (sums to fp32-partial accuracy; min/max exact), and GroupNorm from rows must reproduce GroupNorm from the
@@ -337,7 +337,7 @@ def test_producer_moment_rows_equal_activation_moments(ver, monkeypatch):
     assert _relerr(got.cpu().numpy(), ref.cpu().numpy()) <= 1e-6
 
 
-@pytest.mark.parametrize("wver", [3, 4])
+@pytest.mark.parametrize("wver", [3, 4, 5])
 @pytest.mark.parametrize("dims", [(8, 8, 32), (7, 9, 21), (12, 5, 10)])
 def test_winograd_variant_equals_direct_variant(dims, wver, monkeypatch):
     """conv_wino (F(2,3) along x, 1.5x fewer MFMAs) against conv_mfma on the same operands, including odd widths
