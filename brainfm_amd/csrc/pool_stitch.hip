@@ -5,10 +5,17 @@ namespace {
 
 // nn.MaxPool3d(kernel_size=2): window 2, stride 2, floor, no padding
 // (Trainer/models/unet3d/buildingblocks.py:185-186).  Channels-last, float4 per lane.
+// Optional output-moment rows (see conv3d_mfma.hip / gn_stats.hip): one row per block, so that the GroupNorm of the
+// next SingleConv does not re-read the pooled tensor.  Needs VEC == 4 and a grid whose thread count is a multiple of
+// C/4 (then a thread keeps the same 4 channels across its grid-stride loop).
 template <int VEC>
 __global__ void maxpool2_kernel(const float* __restrict__ in, int C, int D, int H, int W, int d, int h, int w,
-                                float* __restrict__ out) {
+                                float* __restrict__ out, double* __restrict__ rsum, double* __restrict__ rsq,
+                                float* __restrict__ rmn, float* __restrict__ rmx) {
     const int CV = C / VEC;
+    float fs[VEC], fq[VEC], fmn[VEC], fmx[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) { fs[k] = 0.f; fq[k] = 0.f; fmn[k] = INFINITY; fmx[k] = -INFINITY; }
     const int64_t n = (int64_t)d * h * w * CV;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         int cv = (int)(i % CV);
@@ -43,6 +50,42 @@ __global__ void maxpool2_kernel(const float* __restrict__ in, int C, int D, int 
         float* o = out + v * C + (int64_t)cv * VEC;
         if constexpr (VEC == 4) *reinterpret_cast<float4*>(o) = make_float4(m[0], m[1], m[2], m[3]);
         else *o = m[0];
+        if (rsum) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                fs[k] += m[k]; fq[k] = fmaf(m[k], m[k], fq[k]);
+                fmn[k] = fminf(fmn[k], m[k]); fmx[k] = fmaxf(fmx[k], m[k]);
+            }
+        }
+    }
+    if (rsum) {                                                  // uniform; VEC == 4 guaranteed by the host
+        extern __shared__ double pool_smem[];
+        double* ls = pool_smem;                                  // [256][VEC]
+        double* lq = ls + 256 * VEC;
+        float* lmn = reinterpret_cast<float*>(lq + 256 * VEC);
+        float* lmx = lmn + 256 * VEC;
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            ls[t * VEC + k] = (double)fs[k]; lq[t * VEC + k] = (double)fq[k];
+            lmn[t * VEC + k] = fmn[k]; lmx[t * VEC + k] = fmx[k];
+        }
+        __syncthreads();
+        const int per = 256 / CV;                                // threads of this block that share a channel group
+        for (int c = t; c < C; c += 256) {
+            const int cv = c / VEC, k = c - cv * VEC;
+            // thread t' = cv0 + j*CV holds channel group cv0 = (first global thread id + t') % CV; the block's first
+            // thread id is a multiple of 256, itself a multiple of CV, so cv0 == t' % CV
+            double S = 0.0, Q = 0.0;
+            float MN = INFINITY, MX = -INFINITY;
+            for (int j = 0; j < per; ++j) {
+                const int tt = cv + j * CV;
+                S += ls[tt * VEC + k]; Q += lq[tt * VEC + k];
+                MN = fminf(MN, lmn[tt * VEC + k]); MX = fmaxf(MX, lmx[tt * VEC + k]);
+            }
+            const size_t o = (size_t)blockIdx.x * C + c;
+            rsum[o] = S; rsq[o] = Q; rmn[o] = MN; rmx[o] = MX;
+        }
     }
 }
 
@@ -144,14 +187,44 @@ inline int grid_for(int64_t n, int tpb = 256, int cap = 4096) {
 
 }  // namespace
 
-extern "C" int bfm_maxpool2(const float* in, int C, int D, int H, int W, float* out, bfm_stream_t stream) {
+// rows of the output-moment table bfm_maxpool2_ex writes (0: this shape cannot emit them)
+extern "C" int bfm_maxpool2_rows(int C, int D, int H, int W) {
+    if (C <= 0 || C % 4 || D < 2 || H < 2 || W < 2) return 0;
+    const int CV = C / 4;
+    if (CV > 256 || 256 % CV) return 0;
+    return grid_for((int64_t)(D / 2) * (H / 2) * (W / 2) * CV);
+}
+
+extern "C" int bfm_maxpool2_ex(const float* in, int C, int D, int H, int W, float* out, void* moment_rows,
+                               bfm_stream_t stream) {
     if (!in || !out || C <= 0 || D < 2 || H < 2 || W < 2) return BFM_E_ARG;
     int d = D / 2, h = H / 2, w = W / 2;
     bool v4 = (C % 4 == 0) && !((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15);
     int64_t n = (int64_t)d * h * w * (v4 ? C / 4 : C);
-    if (v4) hipLaunchKernelGGL(maxpool2_kernel<4>, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), in, C, D, H, W, d, h, w, out);
-    else hipLaunchKernelGGL(maxpool2_kernel<1>, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), in, C, D, H, W, d, h, w, out);
+    const int nb = grid_for(n);
+    double *rsum = nullptr, *rsq = nullptr;
+    float *rmn = nullptr, *rmx = nullptr;
+    size_t smem = 0;
+    if (moment_rows) {
+        if (!v4 || bfm_maxpool2_rows(C, D, H, W) != nb) return BFM_E_SHAPE;
+        if (reinterpret_cast<uintptr_t>(moment_rows) & 7) return BFM_E_ARG;
+        char* rb = static_cast<char*>(moment_rows);
+        const size_t k = (size_t)nb * C;
+        rsum = reinterpret_cast<double*>(rb);
+        rsq = reinterpret_cast<double*>(rb + k * 8);
+        rmn = reinterpret_cast<float*>(rb + k * 16);
+        rmx = reinterpret_cast<float*>(rb + k * 20);
+        smem = (size_t)256 * 4 * 24;
+    }
+    if (v4) hipLaunchKernelGGL(maxpool2_kernel<4>, dim3(nb), dim3(256), smem, bfm_s(stream), in, C, D, H, W, d, h, w, out,
+                               rsum, rsq, rmn, rmx);
+    else hipLaunchKernelGGL(maxpool2_kernel<1>, dim3(nb), dim3(256), 0, bfm_s(stream), in, C, D, H, W, d, h, w, out, rsum,
+                            rsq, rmn, rmx);
     return bfm_launch_status();
+}
+
+extern "C" int bfm_maxpool2(const float* in, int C, int D, int H, int W, float* out, bfm_stream_t stream) {
+    return bfm_maxpool2_ex(in, C, D, H, W, out, nullptr, stream);
 }
 
 extern "C" int bfm_stitch_accumulate(const float* tile, const int64_t* tile_label, const float* tile_input, int td,

@@ -428,7 +428,15 @@ class UNetEngine:
         D, H, W = dims
         c = X.shape[-1]
         out = torch.empty((D // 2, H // 2, W // 2, c), dtype=torch.float32, device=self.device)
-        L.check(self.lib.bfm_maxpool2(L.ptr(X), c, D, H, W, L.ptr(out), L.stream_ptr()), "maxpool2")
+        rows = None
+        if self.fuse_stats:
+            n = self.lib.bfm_maxpool2_rows(c, D, H, W)
+            if n > 0:
+                rows = (torch.empty(self.lib.bfm_moment_rows_bytes(n, c), dtype=torch.uint8, device=self.device), n)
+        L.check(self.lib.bfm_maxpool2_ex(L.ptr(X), c, D, H, W, L.ptr(out), L.ptr(rows[0]) if rows is not None else None,
+                                         L.stream_ptr()), "maxpool2")
+        if rows is not None:
+            out._bfm_rows = rows
         return out, (D // 2, H // 2, W // 2)
 
     # ------------------------------------------------------------------ backbone

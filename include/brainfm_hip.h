@@ -127,6 +127,9 @@ int bfm_conv3x3x3_mfma_ex(const float* A, int CA, const float* B, int CB, int D,
                           int G, const void* wpacked, int wexp, int Cout, float slope, int passes, const int* cfg,
                           float* out, void* workspace, size_t workspace_bytes, void* moment_rows /*or NULL*/,
                           bfm_stream_t stream);
+int bfm_maxpool2_rows(int C, int D, int H, int W);
+int bfm_maxpool2_ex(const float* in, int C, int D, int H, int W, float* out, void* moment_rows /*or NULL*/,
+                    bfm_stream_t stream);
 int bfm_conv3x3x3_stem_rows(int D, int H, int W);
 int bfm_conv3x3x3_stem_ex(const float* A, int D, int H, int W, const float* scale, const float* shift,
                           const float* bound, const float* wpacked_direct, int Cout, float slope, float* out,

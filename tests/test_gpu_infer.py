@@ -328,6 +328,12 @@ def test_producer_moment_rows_equal_activation_moments(ver, monkeypatch):
     # decoder concat: skip b (64 ch, rows) + low-res tensor (128 ch, rows) upsampled exactly 2x
     lo = (12, 10, 18)
     p1, _ = eng.maxpool(b, dims)
+    assert hasattr(p1, "_bfm_rows")                           # the pool kernel emits rows too
+    buf, n = p1._bfm_rows
+    k = n * 64
+    assert torch.allclose(buf[:k * 8].view(torch.float64).view(n, 64).sum(0), p1.double().reshape(-1, 64).sum(0),
+                          rtol=1e-6, atol=1e-4)
+    assert torch.equal(buf[k * 20:k * 24].view(torch.float32).view(n, 64).max(0)[0], p1.reshape(-1, 64).max(0)[0])
     low = eng.single_conv(eng.enc[1][1], eng.single_conv(eng.enc[1][0], p1, lo), lo)      # 64 -> 64 -> 128 @ lo
     assert hasattr(low, "_bfm_rows")
     ly = eng.dec[-1][0]
