@@ -86,6 +86,8 @@ SIGNATURES = {
     "bfm_conv3x3x3_wino_ex": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _P]),
     "bfm_maxpool2_rows": (_I, [_I, _I, _I, _I]),
     "bfm_maxpool2_ex": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "bfm_grid_push3d_linear": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, C.POINTER(_I), _I, _P, _P]),
+    "bfm_grid_grad3d_linear": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, C.POINTER(_I), _I, _P, _P]),
     "bfm_conv3x3x3_stem": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
     "bfm_conv3x3x3_mfma_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
     "bfm_conv3x3x3_mfma_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),

@@ -258,6 +258,105 @@ __global__ void grid_pull3d(const float* __restrict__ inp, int Bi, int C, int nx
     }
 }
 
+// iso1.push3d (utils/interpol/iso1.py:136-265): the adjoint of pull3d -- every source voxel scatters its value to the
+// 8 corners around its grid coordinate.  out [B][C][nx*ny*nz] must be zero on entry.  fp32 atomics: the summation order
+// (and so the last bit) is not reproducible, like torch's scatter_add_ on a GPU.
+__global__ void grid_push3d(const float* __restrict__ inp, int Bi, int C, const float* __restrict__ grid, int Bg,
+                            int64_t nin, int nx, int ny, int nz, int bx, int by, int bz, int extrap, int B,
+                            float* __restrict__ out) {
+    const int64_t n = (int64_t)B * nin;
+    const int64_t vol = (int64_t)nx * ny * nz;
+    GRID_STRIDE(i, n) {
+        const int b = (int)(i / nin);
+        const int64_t v = i - (int64_t)b * nin;
+        const float* g = grid + ((int64_t)(Bg == 1 ? 0 : b) * nin + v) * 3;
+        const float gx = g[0], gy = g[1], gz = g[2];
+        float mask = 1.f;
+        if (extrap == 0 || extrap == 2) {
+            const float thr = extrap == 2 ? 0.5f + 5e-2f : 5e-2f;
+            const bool in = (gx > -thr) && (gx < (float)(nx - 1) + thr) && (gy > -thr) && (gy < (float)(ny - 1) + thr) &&
+                            (gz > -thr) && (gz < (float)(nz - 1) + thr);
+            mask = in ? 1.f : 0.f;
+        }
+        const float fxf = floorf(gx), fyf = floorf(gy), fzf = floorf(gz);
+        const int x0 = (int)fxf, y0 = (int)fyf, z0 = (int)fzf;
+        const float wx = gx - fxf, wy = gy - fyf, wz = gz - fzf;
+        int ix[2] = {bound_index(x0, nx, bx), bound_index(x0 + 1, nx, bx)};
+        int iy[2] = {bound_index(y0, ny, by), bound_index(y0 + 1, ny, by)};
+        int iz[2] = {bound_index(z0, nz, bz), bound_index(z0 + 1, nz, bz)};
+        int sx[2] = {bound_sign(x0, nx, bx), bound_sign(x0 + 1, nx, bx)};
+        int sy[2] = {bound_sign(y0, ny, by), bound_sign(y0 + 1, ny, by)};
+        int sz[2] = {bound_sign(z0, nz, bz), bound_sign(z0 + 1, nz, bz)};
+        const float ux[2] = {1.f - wx, wx}, uy[2] = {1.f - wy, wy}, uz[2] = {1.f - wz, wz};
+        for (int c = 0; c < C; ++c) {
+            const float val = inp[((int64_t)(Bi == 1 ? 0 : b) * C + c) * nin + v];
+            float* dst = out + ((int64_t)b * C + c) * vol;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        float t = val * (float)(sx[a] * sy[bb] * sz[d]);
+                        t = t * mask;
+                        t = t * ((ux[a] * uy[bb]) * uz[d]);
+                        atomicAdd(dst + ((int64_t)ix[a] * ny + iy[bb]) * nz + iz[d], t);
+                    }
+        }
+    }
+}
+
+// iso1.grad3d (utils/interpol/iso1.py:268-387): spatial gradient of the trilinear interpolant at the grid coordinates,
+// out [B][C][nout][3].
+__global__ void grid_grad3d(const float* __restrict__ inp, int Bi, int C, int nx, int ny, int nz,
+                            const float* __restrict__ grid, int Bg, int64_t nout, int bx, int by, int bz, int extrap,
+                            int B, float* __restrict__ out) {
+    const int64_t n = (int64_t)B * nout;
+    GRID_STRIDE(i, n) {
+        const int b = (int)(i / nout);
+        const int64_t v = i - (int64_t)b * nout;
+        const float* g = grid + ((int64_t)(Bg == 1 ? 0 : b) * nout + v) * 3;
+        const float gx = g[0], gy = g[1], gz = g[2];
+        float mask = 1.f;
+        if (extrap == 0 || extrap == 2) {
+            const float thr = extrap == 2 ? 0.5f + 5e-2f : 5e-2f;
+            const bool in = (gx > -thr) && (gx < (float)(nx - 1) + thr) && (gy > -thr) && (gy < (float)(ny - 1) + thr) &&
+                            (gz > -thr) && (gz < (float)(nz - 1) + thr);
+            mask = in ? 1.f : 0.f;
+        }
+        const float fxf = floorf(gx), fyf = floorf(gy), fzf = floorf(gz);
+        const int x0 = (int)fxf, y0 = (int)fyf, z0 = (int)fzf;
+        const float wx = gx - fxf, wy = gy - fyf, wz = gz - fzf;
+        int ix[2] = {bound_index(x0, nx, bx), bound_index(x0 + 1, nx, bx)};
+        int iy[2] = {bound_index(y0, ny, by), bound_index(y0 + 1, ny, by)};
+        int iz[2] = {bound_index(z0, nz, bz), bound_index(z0 + 1, nz, bz)};
+        int sx[2] = {bound_sign(x0, nx, bx), bound_sign(x0 + 1, nx, bx)};
+        int sy[2] = {bound_sign(y0, ny, by), bound_sign(y0 + 1, ny, by)};
+        int sz[2] = {bound_sign(z0, nz, bz), bound_sign(z0 + 1, nz, bz)};
+        const float ux[2] = {1.f - wx, wx}, uy[2] = {1.f - wy, wy}, uz[2] = {1.f - wz, wz};
+        const float dx[2] = {-1.f, 1.f};
+        const int64_t vol = (int64_t)nx * ny * nz;
+        for (int c = 0; c < C; ++c) {
+            const float* src = inp + ((int64_t)(Bi == 1 ? 0 : b) * C + c) * vol;
+            float ax = 0.f, ay = 0.f, az = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        float val = src[((int64_t)ix[a] * ny + iy[bb]) * nz + iz[d]];
+                        val = val * (float)(sx[a] * sy[bb] * sz[d]);
+                        ax = fmaf(val, dx[a] * (uy[bb] * uz[d]), ax);
+                        ay = fmaf(val, dx[bb] * (ux[a] * uz[d]), ay);
+                        az = fmaf(val, dx[d] * (ux[a] * uy[bb]), az);
+                    }
+            float* o = out + (((int64_t)b * C + c) * nout + v) * 3;
+            o[0] = ax * mask; o[1] = ay * mask; o[2] = az * mask;
+        }
+    }
+}
+
 struct Affine { float a[9]; float c[3]; int shp[3]; };
 
 // xx2 = A[r,0]*xx1 + A[r,1]*yy1 + A[r,2]*zz1 + c2[r], clamped to the source shape; block min/max partials
@@ -433,5 +532,37 @@ extern "C" int bfm_onehot_lut(const int32_t* S, const int32_t* lut, int nlut, in
     if (!S || !lut || !out || nlut <= 0 || n_labels <= 0 || n <= 0) return BFM_E_ARG;
     hipLaunchKernelGGL(onehot_lut, dim3(grid_for(n * n_labels)), dim3(256), 0, bfm_s(stream), S, lut, nlut, n_labels, n,
                        out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_grid_push3d_linear(const float* inp, int Bi, int C, int ix, int iy, int iz, const float* grid, int Bg,
+                                      int nx, int ny, int nz, const int* bound, int extrapolate, float* out_zeroed,
+                                      bfm_stream_t stream) {
+    if (!inp || !grid || !out_zeroed || !bound || Bi <= 0 || Bg <= 0 || C <= 0 || ix <= 0 || iy <= 0 || iz <= 0 ||
+        nx <= 0 || ny <= 0 || nz <= 0)
+        return BFM_E_ARG;
+    if (Bi != Bg && Bi != 1 && Bg != 1) return BFM_E_SHAPE;
+    for (int a = 0; a < 3; ++a) if (bound[a] < 0 || bound[a] > 6) return BFM_E_ARG;
+    if (extrapolate < 0 || extrapolate > 2) return BFM_E_ARG;
+    const int B = Bi > Bg ? Bi : Bg;
+    const int64_t nin = (int64_t)ix * iy * iz;
+    hipLaunchKernelGGL(grid_push3d, dim3(grid_for(B * nin)), dim3(256), 0, bfm_s(stream), inp, Bi, C, grid, Bg, nin, nx,
+                       ny, nz, bound[0], bound[1], bound[2], extrapolate, B, out_zeroed);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_grid_grad3d_linear(const float* inp, int Bi, int C, int nx, int ny, int nz, const float* grid,
+                                      int Bg, int ox, int oy, int oz, const int* bound, int extrapolate, float* out,
+                                      bfm_stream_t stream) {
+    if (!inp || !grid || !out || !bound || Bi <= 0 || Bg <= 0 || C <= 0 || nx <= 0 || ny <= 0 || nz <= 0 || ox <= 0 ||
+        oy <= 0 || oz <= 0)
+        return BFM_E_ARG;
+    if (Bi != Bg && Bi != 1 && Bg != 1) return BFM_E_SHAPE;
+    for (int a = 0; a < 3; ++a) if (bound[a] < 0 || bound[a] > 6) return BFM_E_ARG;
+    if (extrapolate < 0 || extrapolate > 2) return BFM_E_ARG;
+    const int B = Bi > Bg ? Bi : Bg;
+    const int64_t nout = (int64_t)ox * oy * oz;
+    hipLaunchKernelGGL(grid_grad3d, dim3(grid_for(B * nout)), dim3(256), 0, bfm_s(stream), inp, Bi, C, nx, ny, nz, grid,
+                       Bg, nout, bound[0], bound[1], bound[2], extrapolate, B, out);
     return bfm_launch_status();
 }

@@ -2,8 +2,8 @@
 path: ``grid_pull`` with linear interpolation -> ``iso1.pull3d`` (utils/interpol/api.py:137-200,
 autograd.py:125-152, pushpull.py:35-66, iso1.py:28-133, bounds.py:24-89, jit_utils.py:241-255).
 
-Forward only: the generator never differentiates through it (SURVEY 'next' row N4 covers push/grad
-and the B-spline prefilter).
+grid_pull / grid_push are differentiable to first order through grid_push / grid_grad; grid_grad itself
+is forward only.
 """
 import ctypes as C
 
@@ -33,6 +33,130 @@ def _bound_list(bound):
     return out[:3]
 
 
+def _prep(input, grid, dim=3):
+    """api.py:81-118 _preproc: broadcast batch dims, default channel of 1.  Returns (x (B,C,*in), g (B,*out,3), info)."""
+    grid_spatial = tuple(grid.shape[-dim - 1:-1])
+    grid_batch = tuple(grid.shape[:-dim - 1])
+    in_spatial = tuple(input.shape[-dim:])
+    channel = 0 if input.dim() == dim else input.shape[-dim - 1]
+    in_batch = tuple(input.shape[:-dim - 1]) if input.dim() > dim else ()
+    batch = torch.broadcast_shapes(grid_batch, in_batch)
+    g = grid.to(torch.float32).expand(*batch, *grid_spatial, dim).reshape(-1, *grid_spatial, dim).contiguous()
+    x = input.to(torch.float32).expand(*batch, channel or 1, *in_spatial).reshape(-1, channel or 1, *in_spatial).contiguous()
+    return x, g, (batch, channel, in_spatial, grid_spatial)
+
+
+def _opts(interpolation, bound, extrapolate):
+    orders = interpolation if isinstance(interpolation, (list, tuple)) else [interpolation]
+    if any(_INTER.get(o, o) != 1 for o in orders):
+        raise NotImplementedError("only first-order (linear) interpolation is implemented for pull/push/grad")
+    ext = {False: 0, True: 1, "no": 0, "yes": 1, "hist": 2}.get(extrapolate, extrapolate)
+    return (C.c_int * 3)(*_bound_list(bound)), int(ext)
+
+
+def _pull_raw(x, g, b, ext):
+    B, Cc = x.shape[0], x.shape[1]
+    gs = tuple(g.shape[1:4])
+    out = torch.empty((B, Cc) + gs, dtype=torch.float32, device=x.device)
+    L.check(L.load().bfm_grid_pull3d_linear(L.ptr(x), B, Cc, x.shape[2], x.shape[3], x.shape[4], L.ptr(g), B, gs[0],
+                                            gs[1], gs[2], b, ext, L.ptr(out), L.stream_ptr()), "grid_pull3d_linear")
+    return out
+
+
+def _push_raw(x, g, shape, b, ext):
+    B, Cc = x.shape[0], x.shape[1]
+    out = torch.zeros((B, Cc) + tuple(shape), dtype=torch.float32, device=x.device)
+    L.check(L.load().bfm_grid_push3d_linear(L.ptr(x), B, Cc, x.shape[2], x.shape[3], x.shape[4], L.ptr(g), B, shape[0],
+                                            shape[1], shape[2], b, ext, L.ptr(out), L.stream_ptr()), "grid_push3d_linear")
+    return out
+
+
+def _grad_raw(x, g, b, ext):
+    B, Cc = x.shape[0], x.shape[1]
+    gs = tuple(g.shape[1:4])
+    out = torch.empty((B, Cc) + gs + (3,), dtype=torch.float32, device=x.device)
+    L.check(L.load().bfm_grid_grad3d_linear(L.ptr(x), B, Cc, x.shape[2], x.shape[3], x.shape[4], L.ptr(g), B, gs[0],
+                                            gs[1], gs[2], b, ext, L.ptr(out), L.stream_ptr()), "grid_grad3d_linear")
+    return out
+
+
+class _GridPull(torch.autograd.Function):
+    """autograd.py:125-152 + pushpull.py:262-285: d/dinput = push(grad), d/dgrid = sum_c grad * grid_grad(input)."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, ext):
+        ctx.opt = (b, ext)
+        ctx.save_for_backward(x, g)
+        return _pull_raw(x, g, b, ext)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, g = ctx.saved_tensors
+        b, ext = ctx.opt
+        grad = grad.contiguous().to(torch.float32)
+        gi = _push_raw(grad, g, x.shape[2:], b, ext) if ctx.needs_input_grad[0] else None
+        gg = (_grad_raw(x, g, b, ext) * grad.unsqueeze(-1)).sum(dim=1) if ctx.needs_input_grad[1] else None
+        return gi, gg, None, None
+
+
+class _GridPush(torch.autograd.Function):
+    """autograd.py:155-190 + pushpull.py:288-310: d/dinput = pull(grad), d/dgrid = sum_c input * grid_grad(grad)."""
+
+    @staticmethod
+    def forward(ctx, x, g, shape, b, ext):
+        ctx.opt = (b, ext)
+        ctx.save_for_backward(x, g)
+        return _push_raw(x, g, shape, b, ext)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, g = ctx.saved_tensors
+        b, ext = ctx.opt
+        grad = grad.contiguous().to(torch.float32)
+        gi = _pull_raw(grad, g, b, ext) if ctx.needs_input_grad[0] else None
+        gg = (_grad_raw(grad, g, b, ext) * x.unsqueeze(-1)).sum(dim=1) if ctx.needs_input_grad[1] else None
+        return gi, gg, None, None, None
+
+
+def _require_cuda(t, what):
+    if t.device.type != "cuda":
+        raise L.BfmError("%s runs on a HIP device only; there is no CPU fallback in the product path" % what)
+
+
+def grid_push(input, grid, shape=None, interpolation="linear", bound="zero", extrapolate=False, prefilter=False):
+    """api.py:203-275: splat `input` (..., [channel], *spatial) at the coordinates `grid` (..., *spatial, 3) into a
+    volume of `shape` (default: the input's spatial shape).  Differentiable w.r.t. input and grid."""
+    _require_cuda(input, "grid_push")
+    b, ext = _opts(interpolation, bound, extrapolate)
+    x, g, (batch, channel, in_spatial, grid_spatial) = _prep(input, grid)
+    if in_spatial != grid_spatial:
+        raise ValueError("Input and grid should have the same spatial shape")
+    shape = tuple(int(v) for v in (shape if shape is not None else in_spatial))
+    out = _GridPush.apply(x, g, shape, b, ext)
+    out_channel = [channel] if channel else ([1] if batch else [])
+    return out.reshape(*batch, *out_channel, *shape)
+
+
+def grid_count(grid, shape=None, interpolation="linear", bound="zero", extrapolate=False):
+    """api.py:278-340: push of an image of ones (the Jacobian-free 'count' image)."""
+    _require_cuda(grid, "grid_count")
+    gs = tuple(grid.shape[-4:-1])
+    ones = torch.ones(tuple(grid.shape[:-4]) + (1,) + gs, dtype=torch.float32, device=grid.device)
+    out = grid_push(ones, grid, shape, interpolation, bound, extrapolate)
+    return out
+
+
+def grid_grad(input, grid, interpolation="linear", bound="zero", extrapolate=False, prefilter=False):
+    """api.py:343-412: spatial gradient of the interpolated image at `grid`: (..., [channel], *spatial_out, 3).
+    Forward only (its own backward needs pushgrad / hess, not implemented)."""
+    _require_cuda(input, "grid_grad")
+    b, ext = _opts(interpolation, bound, extrapolate)
+    x, g, (batch, channel, in_spatial, grid_spatial) = _prep(input.detach(), grid.detach())
+    out = _grad_raw(x, g, b, ext)
+    out_channel = [channel] if channel else ([1] if batch else [])
+    return out.reshape(*batch, *out_channel, *grid_spatial, 3)
+
+
 def grid_pull(input, grid, interpolation="linear", bound="zero", extrapolate=False, prefilter=False):
     """Sample `input` at the voxel coordinates in `grid`.
 
@@ -47,23 +171,9 @@ def grid_pull(input, grid, interpolation="linear", bound="zero", extrapolate=Fal
         raise NotImplementedError("only 3-D grids are on the hot path")
     if input.device.type != "cuda":
         raise L.BfmError("grid_pull runs on a HIP device only; there is no CPU fallback in the product path")
-    dim = 3
-    # _preproc (api.py:81-118): broadcast batch dims, default channel of 1
-    grid_spatial = tuple(grid.shape[-dim - 1:-1])
-    grid_batch = tuple(grid.shape[:-dim - 1])
-    in_spatial = tuple(input.shape[-dim:])
-    channel = 0 if input.dim() == dim else input.shape[-dim - 1]
-    in_batch = tuple(input.shape[:-dim - 1]) if input.dim() > dim else ()
-    batch = torch.broadcast_shapes(grid_batch, in_batch)
-    g = grid.to(torch.float32).expand(*batch, *grid_spatial, dim).reshape(-1, *grid_spatial, dim).contiguous()
-    x = input.to(torch.float32).expand(*batch, channel or 1, *in_spatial).reshape(-1, channel or 1, *in_spatial).contiguous()
-    B, Cc = x.shape[0], x.shape[1]
-    ext = {False: 0, True: 1, "no": 0, "yes": 1, "hist": 2}.get(extrapolate, extrapolate)
-    b = (C.c_int * 3)(*_bound_list(bound))
-    out = torch.empty((B, Cc) + grid_spatial, dtype=torch.float32, device=x.device)
-    L.check(L.load().bfm_grid_pull3d_linear(L.ptr(x), B, Cc, in_spatial[0], in_spatial[1], in_spatial[2], L.ptr(g), B,
-                                            grid_spatial[0], grid_spatial[1], grid_spatial[2], b, int(ext), L.ptr(out),
-                                            L.stream_ptr()), "grid_pull3d_linear")
+    b, ext = _opts(interpolation, bound, extrapolate)
+    x, g, (batch, channel, in_spatial, grid_spatial) = _prep(input, grid)
+    out = _GridPull.apply(x, g, b, ext)                          # differentiable w.r.t. input and grid (first order)
     out_channel = [channel] if channel else ([1] if batch else [])
     return out.reshape(*batch, *out_channel, *grid_spatial)
 

@@ -293,6 +293,15 @@ int bfm_zoom_linear(const float* X, int nx, int ny, int nz, int C, const bfm_zoo
 /* one axis of gaussian_blur_3d -- Generator/utils.py:84-94: zero-padded 1-D correlation, odd kernel. */
 int bfm_conv1d_axis(const float* in, int nx, int ny, int nz, int axis, const float* kern, int klen, float* out,
                     bfm_stream_t stream);
+/* interpol.grid_push / grid_grad (order 1, 3-D) -- utils/interpol/iso1.py:136-387; with grid_pull they make
+ * grid_pull / grid_push differentiable to first order (autograd.py:125-190, pushpull.py:262-310).
+ * push: inp (Bi,C,ix,iy,iz) scattered through grid (Bg,ix,iy,iz,3) into out (B,C,nx,ny,nz), which MUST be zero on
+ * entry (fp32 atomics).  grad: out (B,C,ox,oy,oz,3). */
+int bfm_grid_push3d_linear(const float* inp, int Bi, int C, int ix, int iy, int iz, const float* grid, int Bg, int nx,
+                           int ny, int nz, const int* bound, int extrapolate, float* out_zeroed, bfm_stream_t stream);
+int bfm_grid_grad3d_linear(const float* inp, int Bi, int C, int nx, int ny, int nz, const float* grid, int Bg, int ox,
+                           int oy, int oz, const int* bound, int extrapolate, float* out, bfm_stream_t stream);
+
 /* Pre-processing around the inference path (utils/test_utils.py:235-284 prepare_image).
  * permute_flip3d: align_volume_to_ref's swapaxes + flips (utils/misc.py:1207-1247) in one gather:
  *   out dims = (n[perm[0]], n[perm[1]], n[perm[2]]); out[i0,i1,i2] = in[j], j[perm[a]] = flip[a] ? n[perm[a]]-1-ia : ia.

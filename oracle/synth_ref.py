@@ -596,3 +596,74 @@ def resize_cubic_ref(x, shape, anchor="e"):
             out = out + np.take(c, idx, axis=axis) * wgt.reshape(shp)
         c = out
     return c
+
+
+# ----------------------------------------------------------------------------- grid_push / grid_grad
+def _corner_terms(grid, shape, bound, extrapolate):
+    """Shared by the push / grad restatements: per-axis (index0, index1, sign0, sign1, weight) and the in-bounds mask
+    of iso1's get_weights_and_indices / inbounds_mask_3d (utils/interpol/iso1.py, jit_utils.py:241-255)."""
+    nx, ny, nz = shape
+    bnds = [BOUND[bound]] * 3 if isinstance(bound, str) else ([int(bound)] * 3 if np.isscalar(bound) else
+                                                               [BOUND[b] if isinstance(b, str) else int(b) for b in bound])
+    ext = {False: 0, True: 1, "hist": 2}.get(extrapolate, extrapolate)
+    g = np.asarray(grid, np.float64).reshape(grid.shape[0], -1, 3)
+    gx, gy, gz = g[..., 0], g[..., 1], g[..., 2]
+    mask = np.ones(gx.shape)
+    if ext in (0, 2):
+        thr = 5e-2 if ext == 0 else 0.5 + 5e-2
+        mask = ((gx > -thr) & (gx < nx - 1 + thr) & (gy > -thr) & (gy < ny - 1 + thr) &
+                (gz > -thr) & (gz < nz - 1 + thr)).astype(np.float64)
+    axes = []
+    for gq, n, b in ((gx, nx, bnds[0]), (gy, ny, bnds[1]), (gz, nz, bnds[2])):
+        g0 = np.floor(gq).astype(np.int64)
+        s0, s1 = _bound_sign(g0, n, b), _bound_sign(g0 + 1, n, b)
+        s0 = np.ones(g0.shape) if s0 is None else s0.astype(np.float64)
+        s1 = np.ones(g0.shape) if s1 is None else s1.astype(np.float64)
+        axes.append((_bound_index(g0, n, b), _bound_index(g0 + 1, n, b), s0, s1, gq - np.floor(gq)))
+    return axes, mask
+
+
+def grid_push_linear(inp, grid, shape, bound="zero", extrapolate=False):
+    """interpol.grid_push(interpolation=1) -> iso1.push3d (utils/interpol/iso1.py:136-265), fp64.
+    inp (B,C,iX,iY,iZ), grid (B,iX,iY,iZ,3) -> (B,C,*shape)."""
+    inp = np.asarray(inp, np.float64)
+    B, Cc = inp.shape[:2]
+    nx, ny, nz = shape
+    axes, mask = _corner_terms(grid, shape, bound, extrapolate)
+    flat = inp.reshape(B, Cc, -1)
+    out = np.zeros((B, Cc, nx * ny * nz))
+    for cx in (0, 1):
+        for cy in (0, 1):
+            for cz in (0, 1):
+                (ix, sx, wx), (iy, sy, wy), (iz, sz, wz) = [
+                    (a[1] if c else a[0], a[3] if c else a[2], a[4] if c else 1.0 - a[4]) for a, c in zip(axes, (cx, cy, cz))]
+                idx = iz + iy * nz + ix * (ny * nz)
+                val = flat * (sx * sy * sz * mask * wx * wy * wz)[:, None, :]
+                for b in range(B):
+                    for c in range(Cc):
+                        np.add.at(out[b, c], idx[b], val[b, c])
+    return out.reshape(B, Cc, nx, ny, nz)
+
+
+def grid_grad_linear(inp, grid, bound="zero", extrapolate=False):
+    """interpol.grid_grad(interpolation=1) -> iso1.grad3d (utils/interpol/iso1.py:268-387), fp64.
+    inp (B,C,X,Y,Z), grid (B,oX,oY,oZ,3) -> (B,C,oX,oY,oZ,3)."""
+    inp = np.asarray(inp, np.float64)
+    B, Cc, nx, ny, nz = inp.shape
+    axes, mask = _corner_terms(grid, (nx, ny, nz), bound, extrapolate)
+    flat = inp.reshape(B, Cc, -1)
+    out = np.zeros((B, Cc, axes[0][0].shape[-1], 3))
+    for cx in (0, 1):
+        for cy in (0, 1):
+            for cz in (0, 1):
+                (ix, sx, wx), (iy, sy, wy), (iz, sz, wz) = [
+                    (a[1] if c else a[0], a[3] if c else a[2], a[4] if c else 1.0 - a[4]) for a, c in zip(axes, (cx, cy, cz))]
+                idx = iz + iy * nz + ix * (ny * nz)
+                val = np.take_along_axis(flat, np.broadcast_to(idx[:, None, :], (B, Cc, idx.shape[-1])), axis=-1)
+                val = val * (sx * sy * sz)[:, None, :]
+                dx, dy, dz = (1.0 if cx else -1.0), (1.0 if cy else -1.0), (1.0 if cz else -1.0)
+                out[..., 0] += val * (dx * wy * wz)[:, None, :]
+                out[..., 1] += val * (dy * wx * wz)[:, None, :]
+                out[..., 2] += val * (dz * wx * wy)[:, None, :]
+    out *= mask[:, None, :, None]
+    return out.reshape(B, Cc, *grid.shape[1:4], 3)

@@ -314,3 +314,43 @@ def test_prepare_image_from_nifti_file_equals_in_memory(tmp_path):
     V.MRIwrite(a[0][0, 0].cpu().numpy(), a[4], out)
     back, aff_back = V.MRIread(out)
     assert np.array_equal(back.astype(np.float32), a[0][0, 0].cpu().numpy()) and np.allclose(aff_back, a[4], atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_grid_push_grad_count_and_first_order_backward_vs_reference_golden():
+    """interpol.grid_push / grid_count / grid_grad on the device for every boundary condition, and the first-order
+    backward of grid_pull / grid_push (d/dinput through the adjoint kernel, d/dgrid through grid_grad), against the
+    vendored torch-interpol run on the CPU (fp32 atomics in push: tolerance, not bit equality)."""
+    from brainfm_amd import interpol as IP
+    d = load_npz("interpol_pushgrad.npz")
+    dev = "cuda:0"
+    vol, grid, src = (torch.from_numpy(d[k]).to(dev) for k in ("vol", "grid", "src"))
+    ins = tuple(vol.shape[2:])
+
+    def close(got, ref, what):
+        err = float(np.abs(got.detach().cpu().numpy() - ref).max())
+        assert err <= 2e-5 * max(1.0, float(np.abs(ref).max())), (what, err)
+
+    for bound in range(7):
+        for ext in (0, 1):
+            k = "b%d_e%d/" % (bound, ext)
+            close(IP.grid_push(src, grid, list(ins), 1, bound, bool(ext)), d[k + "push"], k + "push")
+            close(IP.grid_grad(vol, grid, 1, bound, bool(ext)), d[k + "grad"], k + "grad")
+            close(IP.grid_push(src, grid, list(ins), 1, bound, bool(ext)),
+                  S.grid_push_linear(d["src"], d["grid"], ins, bound, bool(ext)), k + "push-vs-oracle")
+            if k + "count" in d:
+                close(IP.grid_count(grid, list(ins), 1, bound, bool(ext)), d[k + "count"], k + "count")
+                v = vol.clone().requires_grad_(True)
+                gr = grid.clone().requires_grad_(True)
+                y = IP.grid_pull(v, gr, 1, bound, bool(ext))
+                w = torch.sin(torch.arange(y.numel(), dtype=torch.float32)).reshape(y.shape).to(dev)
+                (y * w).sum().backward()
+                close(v.grad, d[k + "pull_dinput"], k + "pull_dinput")
+                close(gr.grad, d[k + "pull_dgrid"], k + "pull_dgrid")
+                s_ = src.clone().requires_grad_(True)
+                gr = grid.clone().requires_grad_(True)
+                y = IP.grid_push(s_, gr, list(ins), 1, bound, bool(ext))
+                w2 = torch.cos(torch.arange(y.numel(), dtype=torch.float32)).reshape(y.shape).to(dev)
+                (y * w2).sum().backward()
+                close(s_.grad, d[k + "push_dinput"], k + "push_dinput")
+                close(gr.grad, d[k + "push_dgrid"], k + "push_dgrid")

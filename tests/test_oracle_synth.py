@@ -133,3 +133,17 @@ def test_cubic_bspline_resize_oracle_vs_reference_golden():
         y = S.resize_cubic_ref(x, [int(v) for v in d[name + "/shape"]], anchor)
         assert y.shape == d[name + "/y"].shape
         assert np.abs(y - d[name + "/y"]).max() <= 2e-5 * np.abs(d[name + "/y"]).max(), name
+
+
+def test_grid_push_grad_oracle_vs_reference_golden():
+    """fp64 restatements of iso1.push3d / grad3d against the vendored torch-interpol (fp32) for all seven boundary
+    conditions, with and without extrapolation."""
+    d = load_npz("interpol_pushgrad.npz")
+    vol, grid, src = d["vol"], d["grid"], d["src"]
+    for bound in range(7):
+        for ext in (0, 1):
+            k = "b%d_e%d/" % (bound, ext)
+            push = S.grid_push_linear(src, grid, vol.shape[2:], bound, bool(ext))
+            assert np.abs(push - d[k + "push"]).max() <= 2e-5 * max(1.0, np.abs(d[k + "push"]).max()), k
+            grad = S.grid_grad_linear(vol, grid, bound, bool(ext))
+            assert np.abs(grad - d[k + "grad"]).max() <= 2e-5 * max(1.0, np.abs(d[k + "grad"]).max()), k
