@@ -48,6 +48,9 @@ __global__ void bbox_kernel(const float* __restrict__ in, int nx, int ny, int nz
             hi[0] = max(hi[0], x + 1); hi[1] = max(hi[1], y + 1); hi[2] = max(hi[2], z + 1);
         }
     }
+    // wave fold, then block fold through LDS: one atomic pair per block and axis instead of one per wave (65k waves
+    // hammering six addresses serialise)
+    __shared__ int s_lo[3][4], s_hi[3][4];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         int l = lo[a], h = hi[a];
@@ -56,10 +59,15 @@ __global__ void bbox_kernel(const float* __restrict__ in, int nx, int ny, int nz
             l = min(l, __shfl_xor(l, m));
             h = max(h, __shfl_xor(h, m));
         }
-        if ((threadIdx.x & 63) == 0) {
-            if (l != INT_MAX) atomicMin(&box[a], l);
-            if (h != 0) atomicMax(&box[3 + a], h);
-        }
+        if ((threadIdx.x & 63) == 0) { s_lo[a][threadIdx.x >> 6] = l; s_hi[a][threadIdx.x >> 6] = h; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        int l = INT_MAX, h = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { l = min(l, s_lo[a][w]); h = max(h, s_hi[a][w]); }
+        if (l != INT_MAX) atomicMin(&box[a], l);
+        if (h != 0) atomicMax(&box[3 + a], h);
     }
 }
 
@@ -95,7 +103,8 @@ extern "C" int bfm_bbox_nonzero(const float* in, int nx, int ny, int nz, float t
     if (!in || !box || nx <= 0 || ny <= 0 || nz <= 0) return BFM_E_ARG;
     hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, bfm_s(stream), box);
     const int64_t n = (int64_t)nx * ny * nz;
-    hipLaunchKernelGGL(bbox_kernel, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), in, nx, ny, nz, tol, box);
+    const int nb = std::min(grid_for(n), 512);       // same-address atomics serialise: few blocks, long grid-stride loops
+    hipLaunchKernelGGL(bbox_kernel, dim3(nb), dim3(256), 0, bfm_s(stream), in, nx, ny, nz, tol, box);
     return bfm_launch_status();
 }
 

@@ -233,11 +233,21 @@ __global__ void reduce_partial(int op, const TX* __restrict__ x, const TX* __res
     }
 }
 
+// one wave: lane l folds a contiguous run of partials in order, lane 0 then folds the 64 lane results in order
+// (deterministic; a single thread walking all partials cost ~110 us of dependent loads per reduction)
 __global__ void reduce_final(int op, const double* __restrict__ part, int nb, double* __restrict__ out) {
-    if (threadIdx.x == 0) {
-        double r = part[0];
-        for (int i = 1; i < nb; ++i) r = op == 0 ? fmin(r, part[i]) : (op == 1 ? fmax(r, part[i]) : r + part[i]);
-        out[0] = r;
+    __shared__ double lanes[64];
+    const int l = threadIdx.x;
+    const int chunk = (nb + 63) / 64;
+    const int i0 = l * chunk, i1 = min(nb, i0 + chunk);
+    double r = op == 0 ? INFINITY : (op == 1 ? -INFINITY : 0.0);
+    for (int i = i0; i < i1; ++i) r = op == 0 ? fmin(r, part[i]) : (op == 1 ? fmax(r, part[i]) : r + part[i]);
+    lanes[l] = r;
+    __syncthreads();
+    if (l == 0) {
+        double t = lanes[0];
+        for (int i = 1; i < 64; ++i) t = op == 0 ? fmin(t, lanes[i]) : (op == 1 ? fmax(t, lanes[i]) : t + lanes[i]);
+        out[0] = t;
     }
 }
 

@@ -190,6 +190,19 @@ def zoom_tables(n, factor):
     return f, c, wf, wc
 
 
+_ZOOM_CACHE = {}
+
+
+def _zoom_tables_dev(n, factor, dev):
+    """Device copies of zoom_tables(n, factor), cached: the same few (size, factor) pairs recur for every sample."""
+    key = (int(n), float(factor), str(dev))
+    if key not in _ZOOM_CACHE:
+        if len(_ZOOM_CACHE) > 256:
+            _ZOOM_CACHE.clear()
+        _ZOOM_CACHE[key] = [torch.from_numpy(v).to(dev) for v in zoom_tables(n, float(factor))]
+    return _ZOOM_CACHE[key]
+
+
 def myzoom_torch(X, factor, aff=None):
     """Generator/utils.py:200-257: separable linear zoom (fused into one kernel)."""
     _require_cuda(X, "myzoom_torch")
@@ -202,9 +215,8 @@ def myzoom_torch(X, factor, aff=None):
     tabs, keep, newsize = [], [], []
     axes = (L.ZoomAxis * 3)()
     for a, n in enumerate((nx, ny, nz)):
-        f, c, wf, wc = zoom_tables(n, float(factor[a]))
-        newsize.append(len(f))
-        t = [torch.from_numpy(v).to(dev) for v in (f, c, wf, wc)]
+        t = _zoom_tables_dev(n, float(factor[a]), dev)
+        newsize.append(len(t[0]))
         keep.append(t)
         axes[a] = L.ZoomAxis(*[v.data_ptr() for v in t])
     out = torch.empty((newsize[0], newsize[1], newsize[2], Cc), dtype=torch.float32, device=dev)
@@ -220,8 +232,21 @@ def myzoom_torch(X, factor, aff=None):
 
 
 # ----------------------------------------------------------------------------- K13
+_GAUSS_CACHE = {}
+
+
 def make_gaussian_kernel(sigma, device):
-    """Generator/utils.py:74-82 (7-tap example in SURVEY appendix C)."""
+    """Generator/utils.py:74-82 (7-tap example in SURVEY appendix C); device copies cached per sigma."""
+    key = (float(sigma), str(device))
+    if key in _GAUSS_CACHE:
+        return _GAUSS_CACHE[key]
+    if len(_GAUSS_CACHE) > 256:
+        _GAUSS_CACHE.clear()
+    _GAUSS_CACHE[key] = _make_gaussian_kernel(sigma, device)
+    return _GAUSS_CACHE[key]
+
+
+def _make_gaussian_kernel(sigma, device):
     sl = int(np.ceil(3 * sigma))
     ts = np.linspace(-sl, sl, 2 * sl + 1).astype(np.float32)
     g = np.exp((-(ts / np.float32(sigma)) ** 2 / 2)).astype(np.float32)

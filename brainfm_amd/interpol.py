@@ -183,6 +183,18 @@ _SPLINE_BOUND = {"nearest": 1, "replicate": 1, "repeat": 1, "border": 1, "dct2":
                  "neumann": 3, 1: 1, 3: 3}
 
 
+_PREFILTER_CACHE = {}
+
+
+def _prefilter_scalars_dev(n, dev):
+    """_prefilter_scalars with the fp32 table already on the device, cached per (n, device)."""
+    key = (int(n), str(dev))
+    if key not in _PREFILTER_CACHE:
+        z, gain, pole_last, init_scale, final_scale, w = _prefilter_scalars(n)
+        _PREFILTER_CACHE[key] = (z, gain, pole_last, init_scale, final_scale, w.to(dev) if n > 2 else None)
+    return _PREFILTER_CACHE[key]
+
+
 def _prefilter_scalars(n):
     """The host scalars of coeff.py's cubic DCT-II prefilter for a line of n samples (:55-60, :141-175, :218-226)."""
     import math
@@ -220,8 +232,7 @@ def spline_coeff_nd(inp, bound="dct2", order=3, dim=3, inplace=False):
         for axis, n in enumerate((nx, ny, nz)):
             if n == 1:
                 continue
-            z, gain, pole_last, init_scale, final_scale, w = _prefilter_scalars(n)
-            wd = w.to(inp.device) if n > 2 else None
+            z, gain, pole_last, init_scale, final_scale, wd = _prefilter_scalars_dev(n, inp.device)
             L.check(lib.bfm_bspline3_prefilter_axis(L.ptr(v), nx, ny, nz, axis, b, z, gain, L.ptr(wd), pole_last,
                                                     init_scale, final_scale, L.stream_ptr()), "bspline3_prefilter")
     return vols.reshape(tuple(lead) + (nx, ny, nz))

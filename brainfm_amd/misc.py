@@ -81,6 +81,19 @@ def aniso_zoom_tables(n, newsize):
     return f, c, wf, wc
 
 
+_ANISO_CACHE = {}
+_GAUSS_CACHE = {}
+
+
+def _aniso_tables_dev(n, newsize, dev):
+    key = (int(n), int(newsize), str(dev))
+    if key not in _ANISO_CACHE:
+        if len(_ANISO_CACHE) > 256:
+            _ANISO_CACHE.clear()
+        _ANISO_CACHE[key] = [torch.from_numpy(v).to(dev) for v in aniso_zoom_tables(n, newsize)]
+    return _ANISO_CACHE[key]
+
+
 def myzoom_torch_anisotropic(X, aff, newsize):
     """utils/misc.py:1051-1116: separable linear zoom to an explicit size (one fused kernel)."""
     GU._require_cuda(X, "myzoom_torch_anisotropic")
@@ -94,7 +107,7 @@ def myzoom_torch_anisotropic(X, aff, newsize):
     keep = []
     axes = (L.ZoomAxis * 3)()
     for a, n in enumerate((nx, ny, nz)):
-        t = [torch.from_numpy(v).to(dev) for v in aniso_zoom_tables(n, newsize[a])]
+        t = _aniso_tables_dev(n, newsize[a], dev)
         if len(t[0]) != newsize[a]:
             raise L.BfmError("zoom table length %d != requested size %d" % (len(t[0]), newsize[a]))
         keep.append(t)
@@ -139,10 +152,13 @@ def torch_resize(I, aff, resolution, power_factor_at_half_width=5, dtype=torch.f
         nx, ny, nz = cur.shape
         for d in range(3):
             if sigmas[d] > 0:
-                sl = np.ceil(sigmas[d] * 2.5).astype(int)
-                v = np.arange(-sl, sl + 1)
-                gauss = np.exp((-(v / sigmas[d]) ** 2 / 2))
-                kernel = torch.tensor(gauss / np.sum(gauss), device=cur.device, dtype=torch.float32)
+                gkey = (float(sigmas[d]), str(cur.device))
+                if gkey not in _GAUSS_CACHE:
+                    sl = np.ceil(sigmas[d] * 2.5).astype(int)
+                    v = np.arange(-sl, sl + 1)
+                    gauss = np.exp((-(v / sigmas[d]) ** 2 / 2))
+                    _GAUSS_CACHE[gkey] = torch.tensor(gauss / np.sum(gauss), device=cur.device, dtype=torch.float32)
+                kernel = _GAUSS_CACHE[gkey]
                 nxt = torch.empty_like(cur)
                 L.check(lib.bfm_conv1d_axis(L.ptr(cur), nx, ny, nz, d, L.ptr(kernel), kernel.numel(), L.ptr(nxt),
                                             L.stream_ptr()), "conv1d_axis")
