@@ -200,6 +200,7 @@ __global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
 #pragma unroll
             for (int f = 0; f < NF; ++f) bw[f] = wq[cur][f];
             fetch(s + 2, wq[(cur + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);           // pin the prefetch: the scheduler would sink it to its first use
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 half8 a[NPL];

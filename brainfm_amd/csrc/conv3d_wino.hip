@@ -45,6 +45,7 @@ struct WinoParams {
     int pw_shift, thp_shift;         // log2(PW), log2(TH*PW)
     int nTy, nTx, nMt, NT, KCN;
     int npos_lds, plane_stride;      // (TD+2)*HT*PW positions; bytes per plane
+    int dbg;                         // experiments only (BFM_WINO_DBG)
     double *rsum, *rsq;              // optional output-moment rows [nMt][Cout] (see conv3d_mfma.hip), 4-wave kernel only
     float *rmn, *rmx;
     int ws_buf_bytes;                // persistent kernel: bytes per LDS buffer
@@ -64,6 +65,27 @@ __device__ __forceinline__ void pair_coords(const WinoParams& p, int q, int& d, 
     const int rem = q & ((1 << p.thp_shift) - 1);
     h = rem >> p.pw_shift;
     j = rem & ((1 << p.pw_shift) - 1);
+}
+
+// x = hi + lo in fp16 for four values, two per instruction: hi by v_cvt_pkrtz_f16_f32 (truncation: x - hi is then exact
+// in fp32 and at most 2^-10 |x|), lo likewise; the neglected lo*lo product stays below 2^-20 relative.
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+template <bool LO>
+__device__ __forceinline__ void split_store4(const float (&t)[4], unsigned char* dp, int plane_stride) {
+    const fp16x2_t h01 = __builtin_amdgcn_cvt_pkrtz(t[0], t[1]);
+    const fp16x2_t h23 = __builtin_amdgcn_cvt_pkrtz(t[2], t[3]);
+    uint2 hv;
+    hv.x = __builtin_bit_cast(unsigned, h01);
+    hv.y = __builtin_bit_cast(unsigned, h23);
+    *reinterpret_cast<uint2*>(dp) = hv;
+    if constexpr (LO) {
+        const fp16x2_t l01 = __builtin_amdgcn_cvt_pkrtz(t[0] - (float)h01[0], t[1] - (float)h01[1]);
+        const fp16x2_t l23 = __builtin_amdgcn_cvt_pkrtz(t[2] - (float)h23[0], t[3] - (float)h23[1]);
+        uint2 lv;
+        lv.x = __builtin_bit_cast(unsigned, l01);
+        lv.y = __builtin_bit_cast(unsigned, l23);
+        *reinterpret_cast<uint2*>(dp + plane_stride) = lv;
+    }
 }
 
 template <int NPASS>
@@ -161,7 +183,7 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
         for (int f = 0; f < NF; ++f) dst[f] = wbase[(size_t)sc * (NF * 64) + f * 64];
     };
     fetch(0, wq[0]);
-    if constexpr (NSET == 3) fetch(1, wq[1]);
+    fetch(1, wq[1]);
 
     auto do_chunk = [&](int kc, auto par_tag) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
@@ -193,31 +215,35 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
                 if (it >= MAX_IT) break;
                 if (msk[it] < 0) continue;
                 float dd[4][4];                          // [x position][channel]: affine, zero padding after it
+                if (msk[it] == 15) {                     // interior item (the common case): no padding selects
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bool ok = msk[it] & (1 << i);
-                    const float y[4] = {v[u][i].x, v[u][i].y, v[u][i].z, v[u][i].w};
+                    for (int i = 0; i < 4; ++i) {
+                        const float y[4] = {v[u][i].x, v[u][i].y, v[u][i].z, v[u][i].w};
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) dd[i][c] = ok ? fmaf(y[c], sc[c], sh[c]) : 0.f;
+                        for (int c = 0; c < 4; ++c) dd[i][c] = fmaf(y[c], sc[c], sh[c]);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bool ok = msk[it] & (1 << i);
+                        const float y[4] = {v[u][i].x, v[u][i].y, v[u][i].z, v[u][i].w};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dd[i][c] = ok ? fmaf(y[c], sc[c], sh[c]) : 0.f;
+                    }
                 }
                 const int e = tid + it * NTHR;
                 unsigned char* dst = lds + st_plane + (e >> 2) * 16;
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
-                    half4 hi, lo;
+                    float t[4];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float t = ps == 0 ? dd[0][c] - dd[2][c]
-                                      : ps == 1 ? dd[1][c] + dd[2][c]
-                                      : ps == 2 ? dd[2][c] - dd[1][c]
-                                                : dd[1][c] - dd[3][c];
-                        const _Float16 hh = (_Float16)t;
-                        hi[c] = hh;
-                        lo[c] = (_Float16)(t - (float)hh);
-                    }
+                    for (int c = 0; c < 4; ++c)
+                        t[c] = ps == 0 ? dd[0][c] - dd[2][c]
+                             : ps == 1 ? dd[1][c] + dd[2][c]
+                             : ps == 2 ? dd[2][c] - dd[1][c]
+                                       : dd[1][c] - dd[3][c];
                     unsigned char* dp = dst + (ps * 2 * NPL) * p.plane_stride;
-                    *reinterpret_cast<half4*>(dp) = hi;
-                    if constexpr (NPASS == 3) *reinterpret_cast<half4*>(dp + p.plane_stride) = lo;
+                    split_store4<NPASS == 3>(t, dp, p.plane_stride);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);           // keep the next batch's loads from being hoisted (registers)
@@ -231,11 +257,16 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
             const int toff = (kd * p.HT + kh) * p.PW * 16;
             // 9 taps per chunk: with 3 sets the set index is t % 3; with 2 sets the parity of the global step
             // alternates per chunk, so the chunk loop body is instantiated for both parities (PAR)
-            const int cur = NSET == 3 ? t % 3 : (PAR + t) & 1;
+            const int cur = t % 3;
             uint4 bw[NF];
 #pragma unroll
             for (int f = 0; f < NF; ++f) bw[f] = wq[cur][f];
-            fetch(s + NSET - 1, wq[(cur + NSET - 1) % NSET]);
+            // Issue the loads of tap t+2 HERE and pin them: left alone, the scheduler sinks each load to just before
+            // its first use (shorter live ranges) and the L2 latency is paid at every tap (ISA: vmcnt(0) four MFMAs
+            // after the load).  An opaque inline-asm load would be faster still but is unsafe: the allocator may move
+            // or spill a register whose load is still in flight.
+            fetch(s + 2, wq[(cur + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 half8 a[NPL];
@@ -1006,6 +1037,7 @@ extern "C" int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W
     p.scale = scale; p.shift = shift; p.bound = bound; p.G = G;
     p.wp = static_cast<const uint4*>(wpacked);
     p.wexp = wexp; p.Cout = Cout; p.slope = slope; p.out = out; p.accum = accumulate ? 1 : 0;
+    { const char* e = getenv("BFM_WINO_DBG"); p.dbg = e ? atoi(e) : 0; }
     if (!choose_box(D, H, W, npl, p.TD, p.TH, p.TW)) return BFM_E_SHAPE;
     p.HT = p.TH + 2; p.PW = p.TW / 2;
     p.pw_shift = ilog2i(p.PW); p.thp_shift = ilog2i(p.TH * p.PW);
