@@ -821,6 +821,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino8(const WinoParams p) {
     __syncthreads();
     for (int kc = 0; kc < p.KCN; ++kc) {
         if (kc + 1 < p.KCN) load_chunk(kc + 1);                    // in flight during the MFMA loop below
+        __builtin_amdgcn_sched_barrier(0);                         // ... provided the scheduler does not sink the loads
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int kd = t / 3, kh = t - kd * 3;
@@ -830,6 +831,7 @@ __global__ void __launch_bounds__(512, 1) conv_wino8(const WinoParams p) {
 #pragma unroll
             for (int f = 0; f < NF; ++f) bw[f] = wq[cur][f];
             fetch(kc * 9 + t + 2, wq[(cur + 2) % 3]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 half8 a[NPL];
