@@ -60,6 +60,15 @@ __device__ __forceinline__ int row_perm(int l) {        // as conv_mfma: each 16
     return l;
 }
 
+__device__ __forceinline__ int row_unperm(int q) {      // inverse of row_perm
+    if (q < 4) return q;
+    if (q < 8) return q + 8;
+    if (q < 16) return q + 12;
+    if (q < 24) return q - 12;
+    if (q < 28) return q - 8;
+    return q;
+}
+
 __device__ __forceinline__ void pair_coords(const WinoParams& p, int q, int& d, int& h, int& j) {
     d = q >> p.thp_shift;
     const int rem = q & ((1 << p.thp_shift) - 1);
@@ -296,7 +305,8 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
     }
 
     // ================= epilogue: output transform through LDS =================
-    float* m = reinterpret_cast<float*>(lds);                      // [4 positions][128 pairs][MLD]
+    float* m = reinterpret_cast<float*>(lds);                      // [4 positions][128 accumulator rows][MLD]
+    float* mw = m + (pos * 128 + khalf * 4) * MLD + l32;           // this lane's write base
     const int col = tid & 31, row0 = tid >> 5;
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
@@ -304,10 +314,8 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rr = (i >> 2) * 8 + khalf * 4 + (i & 3);
-                m[(pos * 128 + mb * 32 + row_perm(rr)) * MLD + l32] = acc[mb][nb][i];
-            }
+            for (int i = 0; i < 16; ++i)                            // accumulator row order (compile-time offsets);
+                mw[(mb * 32 + (i >> 2) * 8 + (i & 3)) * MLD] = acc[mb][nb][i];   // the reader undoes row_perm
         __syncthreads();
         float fs = 0.f, fq = 0.f, fmn = INFINITY, fmx = -INFINITY;   // this thread's column, its 16 pairs (<= 32 values)
 #pragma unroll 4
@@ -317,8 +325,9 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
             pair_coords(p, q, d, h, j);
             const int gz = z0 + d, gy = y0 + h, gx = x0 + 2 * j;
             if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
-            const float m0 = m[(0 * 128 + q) * MLD + col], m1 = m[(1 * 128 + q) * MLD + col];
-            const float m2 = m[(2 * 128 + q) * MLD + col], m3 = m[(3 * 128 + q) * MLD + col];
+            const int qr = (q & ~31) + row_unperm(q & 31);           // accumulator row holding pair q
+            const float m0 = m[(0 * 128 + qr) * MLD + col], m1 = m[(1 * 128 + qr) * MLD + col];
+            const float m2 = m[(2 * 128 + qr) * MLD + col], m3 = m[(3 * 128 + qr) * MLD + col];
             float* o = p.out + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + nt * 64 + nb * 32 + col;
             float y0v = ((m0 + m1) + m2) * dq;
             float y1v = ((m1 - m2) - m3) * dq;
