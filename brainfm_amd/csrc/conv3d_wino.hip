@@ -311,6 +311,24 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         __syncthreads();                                           // A planes (or the previous round) fully consumed
+        // accumulate mode: what `out` holds is fetched now, so that its latency hides under the LDS exchange
+        float prev0[16], prev1[16];
+        if (p.accum) {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int q = row0 + 8 * it;
+                int d, h, j;
+                pair_coords(p, q, d, h, j);
+                const int gz = z0 + d, gy = y0 + h, gx = x0 + 2 * j;
+                prev0[it] = 0.f;
+                prev1[it] = 0.f;
+                if (gz < p.D && gy < p.H && gx < p.W) {
+                    const float* o = p.out + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + nt * 64 + nb * 32 + col;
+                    prev0[it] = o[0];
+                    if (gx + 1 < p.W) prev1[it] = o[p.Cout];
+                }
+            }
+        }
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -318,7 +336,7 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
                 mw[(mb * 32 + (i >> 2) * 8 + (i & 3)) * MLD] = acc[mb][nb][i];   // the reader undoes row_perm
         __syncthreads();
         float fs = 0.f, fq = 0.f, fmn = INFINITY, fmx = -INFINITY;   // this thread's column, its 16 pairs (<= 32 values)
-#pragma unroll 4
+#pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int q = row0 + 8 * it;
             int d, h, j;
@@ -331,12 +349,12 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
             float* o = p.out + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + nt * 64 + nb * 32 + col;
             float y0v = ((m0 + m1) + m2) * dq;
             float y1v = ((m1 - m2) - m3) * dq;
-            if (p.accum) y0v = y0v + o[0];
+            if (p.accum) y0v = y0v + prev0[it];
             y0v = y0v >= 0.f ? y0v : y0v * p.slope;
             o[0] = y0v;
             fs += y0v; fq = fmaf(y0v, y0v, fq); fmn = fminf(fmn, y0v); fmx = fmaxf(fmx, y0v);
             if (gx + 1 < p.W) {
-                if (p.accum) y1v = y1v + o[p.Cout];
+                if (p.accum) y1v = y1v + prev1[it];
                 y1v = y1v >= 0.f ? y1v : y1v * p.slope;
                 o[p.Cout] = y1v;
                 fs += y1v; fq = fmaf(y1v, y1v, fq); fmn = fminf(fmn, y1v); fmx = fmaxf(fmx, y1v);
