@@ -92,12 +92,14 @@ def test_lpt_assignment_balances_tiles():
     ranges = TU.tiling_ranges((256,) * 3, [80] * 3, [160] * 3)
     for world in (1, 2, 4, 8):
         owner = TU.assign_tiles(ranges, world)
-        load = [sum(TU.tile_cost(r) for r, o in zip(ranges, owner) if o == k) for k in range(world)]
-        assert sum(load) == 32768000
-        assert max(load) <= max(160 ** 3, int(1.25 * sum(load) / world))
-    owner = TU.assign_tiles(ranges, 8)
-    big = [i for i, r in enumerate(ranges) if TU.tile_cost(r) == 160 ** 3][0]
-    assert sum(1 for o in owner if o == owner[big]) == 1      # the 160^3 tile gets a GPU to itself
+        assert sorted(set(owner)) == list(range(world))
+        assert sum(TU.tile_cost(r) for r in ranges) == 32768000
+        cost = [sum(TU.tile_time(r) for r, o in zip(ranges, owner) if o == k) for k in range(world)]
+        # modelled cost (voxels + per-tile overhead) within 15 % of the mean, or bounded by the one 160^3 tile
+        assert max(cost) <= max(TU.tile_time(((0, 160),) * 3) + TU.tile_time(((0, 80),) * 3), 1.15 * sum(cost) / world)
+        if world > 1:                                         # rank 0 also gathers and accumulates: never the heaviest
+            assert cost[0] <= max(cost[1:])
+    assert TU.assign_tiles(ranges, 8) == TU.assign_tiles(ranges, 8)
 
 
 def test_default_args_and_process_args():
