@@ -220,6 +220,11 @@ def main():
             line["cpu_baseline"] = cpu_baseline(sd, full, n)
         else:
             line["cpu_baseline"] = None
+        try:                                                  # librccl's version banner sits in the C stdio buffer and
+            import ctypes                                     # would otherwise land after the JSON line at exit
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
