@@ -191,6 +191,43 @@ def test_tiled_stitch_toy_vs_reference_golden():
         assert e <= TOL_NET, (k, e)
 
 
+def test_tiled_ragged_odd_volume_vs_oracle():
+    """A volume whose extents are neither multiples of the stride nor of 2^levels (odd tiles: floor pooling, non-2x
+    nearest upsampling, ragged last windows, a zero slab for the mask rule) through tiled_inference against the
+    oracle's tiling + per-tile forward + stitching on the CPU; 16-wide 3-level net (MFMA path on the inner layers)."""
+    from brainfm_amd import test_utils as TU
+    sd = O.random_state_dict(1, 16, 3, seed=23)
+    g = torch.Generator().manual_seed(5)
+    full = torch.rand(1, 1, 45, 38, 51, generator=g)
+    full[:, :, :, :5] = 0
+    stride, win = [14, 14, 14], [27, 27, 27]
+    ref, ranges_ref, cnt_ref = O.tiled_inference(full, sd, stride, win, f_maps=16, num_levels=3)
+    s = _session(sd=sd, f_maps=16, levels=3)
+    acc, ranges, cnt = TU.tiled_inference(full.to(_dev()), s, stride, win)
+    assert [tuple(map(tuple, r)) for r in ranges] == [tuple(map(tuple, r)) for r in ranges_ref]
+    assert np.array_equal(cnt.cpu().numpy(), np.asarray(cnt_ref))
+    for k, v in ref.items():
+        e = _relerr(acc[k].cpu().numpy(), np.asarray(v))
+        assert e <= (2e-2 if k == "label" else TOL_NET), (k, e)   # label: float average of ints, a flip moves it by 1/cnt
+
+
+def test_evaluate_batch_of_two_equals_two_single_calls():
+    """evaluate() on a batch (B,1,s,r,c) is the reference's per-sample loop: identical to two single calls."""
+    sd = O.random_state_dict(1, 8, 3, seed=29)
+    s = _session(sd=sd, f_maps=8, levels=3)
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(2, 1, 16, 24, 16, generator=g).to(_dev())
+    both = s.evaluate(x, feature_only=False)
+    for b in range(2):
+        one = s.evaluate(x[b:b + 1], feature_only=False)
+        for k in one:
+            if k == "feat":
+                for fa, fb in zip(both[k], one[k]):
+                    assert torch.equal(fa[b:b + 1], fb)
+            else:
+                assert torch.equal(both[k][b:b + 1], one[k]), k
+
+
 def test_tiled_graph_replay_equals_eager_bit_for_bit():
     """hipGraph replay per tile shape runs the same kernels on the same operands: the stitched maps must be
     identical to the eager submission, also for a second volume pushed through the captured graphs."""
