@@ -1,0 +1,219 @@
+"""Backward pass of the U-Net backbone on the HIP kernels (first correct version).
+
+The reference trains through torch autograd over ``Trainer/models/unet3d/buildingblocks.py`` (SingleConv 'gcl' :31-60,
+MaxPool3d :185-186, nearest upsample + concat :265-276,361-363) and ``unet3d/model.py:195-209`` (get_feature with the
+L2-normalised last map).  Here the forward pass of ``UNetEngine`` is re-run in *training mode* -- same kernels, but every
+SingleConv keeps a tape (its inputs, the GroupNorm affine, mean / rstd, its output) -- and ``backbone_backward`` walks
+the tapes in reverse:
+
+    dP  = dY * LeakyReLU'(Y)                              bfm_lrelu_bwd
+    dW  = correlate(GN(x), dP)                            bfm_conv3x3x3_wgrad   (exact-fp32 matrix cores)
+    dXn = conv3x3x3(dP, W^T, taps mirrored)               the forward conv kernels on transposed weights
+    dx, dgamma, dbeta = GroupNorm backward                bfm_gn_bwd  (the low-res half sums over its replica boxes)
+    MaxPool3d backward                                    bfm_maxpool2_bwd
+
+What this does not cover yet: the task heads and losses (criterion.py), AMP loss scaling, the optimiser, DDP.
+Gradients are returned under the reference's parameter names.
+"""
+import ctypes as C
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .engine import _Layer
+
+
+class ConvTape:
+    __slots__ = ("ly", "A", "B", "dims", "lo_dims", "scale", "shift", "mean", "rstd", "out")
+
+
+def _start_tables(eng, lo, hi):
+    """Per low-res index: first full-res index mapped to it (exclusive prefix sum of the replication counts)."""
+    key = ("start", tuple(lo), tuple(hi))
+    if key not in eng._up_cache:
+        from .engine import nearest_index_map
+        tabs = []
+        for a in range(3):
+            m = nearest_index_map(lo[a], hi[a])
+            rep = np.bincount(m, minlength=lo[a])
+            start = np.concatenate([[0], np.cumsum(rep)[:-1]]).astype(np.int32)
+            tabs.append(torch.from_numpy(start).to(eng.device))
+        eng._up_cache[key] = tabs
+    return eng._up_cache[key]
+
+
+def train_single_conv(eng, ly, A, dims, B=None, lo_dims=None):
+    """Forward of one SingleConv in training mode: same kernels as inference (generic two-source implicit GEMM),
+    GroupNorm statistics from the tensors, everything the backward needs kept on the tape."""
+    D, H, W = dims
+    ca = A.shape[-1]
+    cb = 0 if B is None else B.shape[-1]
+    st = L.stream_ptr()
+    up = eng._upsample_desc(lo_dims, dims) if B is not None else None
+    upp = C.byref(up) if up is not None else None
+    dev = eng.device
+    scale = torch.empty(ly.cin, dtype=torch.float32, device=dev)
+    shift = torch.empty(ly.cin, dtype=torch.float32, device=dev)
+    bound = torch.empty(ly.groups, dtype=torch.float32, device=dev)
+    mean = torch.empty(ly.groups, dtype=torch.float32, device=dev)
+    rstd = torch.empty(ly.groups, dtype=torch.float32, device=dev)
+    mfma = eng._mfma_ok(ly, ca, cb)
+    cfg, wsc = None, 0
+    if mfma:
+        cfg = eng._plan(ly.cin, ly.cout, dims, B is not None)
+        wsc = eng.lib.bfm_conv3x3x3_mfma_workspace(ly.cin, ly.cout, D, H, W, cfg[5])
+    ws = eng._workspace(max(eng.lib.bfm_gn_stats_workspace(ca, cb, D, H, W, upp), wsc))
+    L.check(eng.lib.bfm_gn_stats_train(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(ly.gamma), L.ptr(ly.beta),
+                                       ly.groups, eng.eps, L.ptr(scale), L.ptr(shift), L.ptr(bound), L.ptr(mean),
+                                       L.ptr(rstd), L.ptr(ws), ws.numel(), st), "gn_stats_train " + ly.name)
+    out = torch.empty((D, H, W, ly.cout), dtype=torch.float32, device=dev)
+    if mfma:
+        eng._conv_launch(ly, A, ca, B, cb, dims, upp, scale, shift, bound, ly.groups, cfg, out, ws)
+    else:
+        eng._pack(ly, False)
+        L.check(eng.lib.bfm_conv3x3x3_direct(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(scale), L.ptr(shift),
+                                             L.ptr(ly.wpacked), ly.cout, eng.slope, L.ptr(out), st),
+                "conv_direct " + ly.name)
+    t = ConvTape()
+    t.ly, t.A, t.B, t.dims, t.lo_dims = ly, A, B, tuple(dims), (tuple(lo_dims) if lo_dims is not None else None)
+    t.scale, t.shift, t.mean, t.rstd, t.out = scale, shift, mean, rstd, out
+    return out, t
+
+
+def _dgrad_layer(eng, ly):
+    """The transposed, tap-mirrored weights of `ly` as a layer of their own: conv(dP, W') = d(loss)/d(conv input)."""
+    dg = _Layer()
+    dg.name, dg.cin, dg.cout, dg.groups = ly.name + "[dgrad]", ly.cout, ly.cin, 1
+    dg.gamma, dg.beta = None, None
+    dg.w_raw = ly.w_raw.permute(1, 0, 2, 3, 4).flip(2, 3, 4).contiguous()
+    dg.kind, dg.wpacked, dg.wexp, dg.packs, dg.skip = None, None, 0, {}, None
+    return dg
+
+
+def backward_single_conv(eng, t, dY, need_input_grad=True):
+    """Returns (dA, dB, grads) for one taped SingleConv; dB is the gradient of the LOW-RES tensor (or None)."""
+    ly = t.ly
+    D, H, W = t.dims
+    nv = D * H * W
+    ca = t.A.shape[-1]
+    cb = 0 if t.B is None else t.B.shape[-1]
+    dev = eng.device
+    st = L.stream_ptr()
+    lib = eng.lib
+    dY = dY.contiguous()
+    dP = torch.empty_like(dY)
+    L.check(lib.bfm_lrelu_bwd(L.ptr(dY), L.ptr(t.out), dY.numel(), eng.slope, L.ptr(dP), st), "lrelu_bwd")
+    up = eng._upsample_desc(t.lo_dims, t.dims) if t.B is not None else None
+    upp = C.byref(up) if up is not None else None
+    # ---- weight gradient
+    wsb = lib.bfm_conv3x3x3_wgrad_workspace(ly.cin, ly.cout, D, H, W)
+    ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
+    dW = torch.empty((ly.cout, ly.cin, 3, 3, 3), dtype=torch.float32, device=dev)
+    L.check(lib.bfm_conv3x3x3_wgrad(L.ptr(dP), ly.cout, L.ptr(t.A), ca, L.ptr(t.B), cb, D, H, W, upp, L.ptr(t.scale),
+                                    L.ptr(t.shift), L.ptr(dW), L.ptr(ws), ws.numel(), st), "conv_wgrad " + ly.name)
+    grads = OrderedDict()
+    grads[ly.name + ".conv.weight"] = dW
+    if not need_input_grad and ly.cin < 8:
+        # the stem: dgamma / dbeta of its one-channel GroupNorm still need dXn; it is cheap (Cout' = 1)
+        pass
+    # ---- data gradient w.r.t. the normalised input: forward conv kernels on transposed weights, identity affine
+    dg = ly.packs.get("dgrad_layer")                             # transposed weights live with their layer
+    if dg is None:
+        dg = ly.packs["dgrad_layer"] = _dgrad_layer(eng, ly)
+    ones = torch.ones(ly.cout, dtype=torch.float32, device=dev)
+    zeros = torch.zeros(ly.cout, dtype=torch.float32, device=dev)
+    bnd = torch.maximum(dP.max(), -dP.min()).reshape(1).to(torch.float32)
+    dXn = torch.empty((D, H, W, ly.cin), dtype=torch.float32, device=dev)
+    if ly.cout % 16 == 0 and ly.cin % 64 == 0:
+        cfg = (C.c_int * 8)(*list(eng._plan(ly.cout, ly.cin, t.dims, False)))
+        if cfg[6] > 2:
+            cfg[6] = 0
+        wsc = lib.bfm_conv3x3x3_mfma_workspace(ly.cout, ly.cin, D, H, W, cfg[5])
+        ws2 = torch.empty(max(wsc, 256), dtype=torch.uint8, device=dev)
+        eng._pack(dg, True, cfg[6])
+        L.check(lib.bfm_conv3x3x3_mfma_ex(L.ptr(dP), ly.cout, None, 0, D, H, W, None, L.ptr(ones), L.ptr(zeros),
+                                          L.ptr(bnd), 1, L.ptr(dg.wpacked), dg.wexp, ly.cin, 1.0, eng.passes, cfg,
+                                          L.ptr(dXn), L.ptr(ws2), ws2.numel(), None, st), "conv dgrad " + ly.name)
+    else:
+        eng._pack(dg, False)
+        L.check(lib.bfm_conv3x3x3_direct(L.ptr(dP), ly.cout, None, 0, D, H, W, None, L.ptr(ones), L.ptr(zeros),
+                                         L.ptr(dg.wpacked), ly.cin, 1.0, L.ptr(dXn), st), "conv dgrad(direct) " + ly.name)
+    # ---- GroupNorm backward
+    dA = torch.empty((D, H, W, ca), dtype=torch.float32, device=dev)
+    dB = torch.empty(tuple(t.lo_dims) + (cb,), dtype=torch.float32, device=dev) if cb else None
+    dgamma = torch.empty(ly.cin, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(ly.cin, dtype=torch.float32, device=dev)
+    starts = _start_tables(eng, t.lo_dims, t.dims) if cb else [None, None, None]
+    wsg = torch.empty(lib.bfm_gn_bwd_workspace(ly.cin, D, H, W), dtype=torch.uint8, device=dev)
+    L.check(lib.bfm_gn_bwd(L.ptr(dXn), L.ptr(t.A), ca, L.ptr(t.B), cb, D, H, W, upp, L.ptr(starts[0]), L.ptr(starts[1]),
+                           L.ptr(starts[2]), L.ptr(t.mean), L.ptr(t.rstd), L.ptr(ly.gamma), ly.groups, L.ptr(dA),
+                           L.ptr(dB), L.ptr(dgamma), L.ptr(dbeta), L.ptr(wsg), wsg.numel(), st), "gn_bwd " + ly.name)
+    grads[ly.name + ".groupnorm.weight"] = dgamma
+    grads[ly.name + ".groupnorm.bias"] = dbeta
+    return dA, dB, grads
+
+
+def backbone_forward_train(eng, x_cl, dims):
+    """UNetEngine.backbone_cl in training mode.  Returns (feats, tape): feats as backbone_cl (deepest first, the last
+    one not normalised), tape = what backbone_backward needs."""
+    tape = {"enc": [], "dec": [], "pool": []}
+    skips = []
+    x, d = x_cl, tuple(dims)
+    for i, (l1, l2) in enumerate(eng.enc):
+        if i > 0:
+            xin, din = x, d
+            x, d = eng.maxpool(x, d)
+            tape["pool"].append((xin, din))
+        x, t1 = train_single_conv(eng, l1, x, d)
+        x, t2 = train_single_conv(eng, l2, x, d)
+        tape["enc"].append((t1, t2))
+        skips.insert(0, (x, d))
+    skips = skips[1:]
+    feats = [(x, d)]
+    for (l1, l2), (skip, sd_) in zip(eng.dec, skips):
+        y, t1 = train_single_conv(eng, l1, skip, sd_, B=x, lo_dims=d)
+        x, t2 = train_single_conv(eng, l2, y, sd_)
+        d = sd_
+        tape["dec"].append((t1, t2))
+        feats.append((x, d))
+    return feats, tape
+
+
+def backbone_backward(eng, tape, dfeats):
+    """dfeats: gradients w.r.t. the decoder feature maps returned by backbone_forward_train (same order, channels-last;
+    None = zero).  Returns {parameter name: gradient}."""
+    grads = OrderedDict()
+    nlev = len(tape["enc"])
+    dskip = [None] * nlev                       # gradient flowing into encoder level i's output from its decoder use
+    # decoders, last to first: dec[j] consumes skip level (nlev-2-j) and the previous x
+    g = dfeats[-1]
+    for j in range(len(tape["dec"]) - 1, -1, -1):
+        t1, t2 = tape["dec"][j]
+        if g is None:
+            g = torch.zeros_like(t2.out)
+        dy, _, gr = backward_single_conv(eng, t2, g)
+        grads.update(gr)
+        dsk, dlow, gr = backward_single_conv(eng, t1, dy)
+        grads.update(gr)
+        dskip[nlev - 2 - j] = dsk
+        g = dlow
+        if dfeats[j] is not None:
+            g = g + dfeats[j]
+    # g is now the gradient w.r.t. the deepest encoder output
+    for i in range(nlev - 1, -1, -1):
+        t1, t2 = tape["enc"][i]
+        if dskip[i] is not None:
+            g = g + dskip[i] if g is not None else dskip[i]
+        dy, _, gr = backward_single_conv(eng, t2, g)
+        grads.update(gr)
+        dx, _, gr = backward_single_conv(eng, t1, dy, need_input_grad=i > 0)
+        grads.update(gr)
+        if i > 0:
+            xin, din = tape["pool"][i - 1]
+            dIn = torch.empty_like(xin)
+            L.check(eng.lib.bfm_maxpool2_bwd(L.ptr(xin), L.ptr(dx.contiguous()), xin.shape[-1], din[0], din[1], din[2],
+                                             L.ptr(dIn), L.stream_ptr()), "maxpool2_bwd")
+            g = dIn
+    return grads

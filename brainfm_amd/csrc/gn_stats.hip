@@ -203,7 +203,8 @@ __global__ void __launch_bounds__(TPB) rows_reduce(const double* __restrict__ rs
 __global__ void __launch_bounds__(TPB) gn_finalize(PartTab ta, PartTab tb, int G, double count_per_channel,
                                                    float eps, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, float* __restrict__ scale,
-                                                   float* __restrict__ shift, float* __restrict__ bound) {
+                                                   float* __restrict__ shift, float* __restrict__ bound,
+                                                   float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     extern __shared__ double smem_d[];
     const int t = threadIdx.x;
     const int g = blockIdx.x;
@@ -266,6 +267,8 @@ __global__ void __launch_bounds__(TPB) gn_finalize(PartTab ta, PartTab tb, int G
             if (var < 0.0) var = 0.0;
             sh_mean = (float)mean;
             sh_rstd = (float)(1.0 / sqrt(var + (double)eps));
+            if (mean_out) mean_out[g] = sh_mean;                   // kept for the backward pass (training)
+            if (rstd_out) rstd_out[g] = sh_rstd;
         }
     }
     __syncthreads();
@@ -348,10 +351,10 @@ extern "C" size_t bfm_gn_stats_workspace(int CA, int CB, int D, int H, int W, co
     return make_plan(CA, CB, nvoxA, nvoxB).total;
 }
 
-extern "C" int bfm_gn_stats(const float* A, int CA, const float* B, int CB, int D, int H, int W,
-                            const bfm_upsample_t* up, const float* gamma, const float* beta, int G, float eps,
-                            float* scale, float* shift, float* bound, void* workspace, size_t workspace_bytes,
-                            bfm_stream_t stream) {
+extern "C" int bfm_gn_stats_train(const float* A, int CA, const float* B, int CB, int D, int H, int W,
+                                  const bfm_upsample_t* up, const float* gamma, const float* beta, int G, float eps,
+                                  float* scale, float* shift, float* bound, float* mean_out, float* rstd_out,
+                                  void* workspace, size_t workspace_bytes, bfm_stream_t stream) {
     if (!A || CA <= 0 || D <= 0 || H <= 0 || W <= 0 || !gamma || !beta || !scale || !shift || !bound || !workspace)
         return BFM_E_ARG;
     if (CB < 0 || (CB > 0 && (!B || !up || up->d <= 0 || up->h <= 0 || up->w <= 0 || !up->repD || !up->repH ||
@@ -389,8 +392,16 @@ extern "C" int bfm_gn_stats(const float* A, int CA, const float* B, int CB, int 
                      reinterpret_cast<float*>(ws + p.offB_mn), reinterpret_cast<float*>(ws + p.offB_mx), p.nbB, CB, 1.0};
     }
     hipLaunchKernelGGL(gn_finalize, dim3(G), dim3(TPB), fin_smem, st, ta, tb, G, (double)nvoxA, eps, gamma, beta,
-                       scale, shift, bound);
+                       scale, shift, bound, mean_out, rstd_out);
     return bfm_launch_status();
+}
+
+extern "C" int bfm_gn_stats(const float* A, int CA, const float* B, int CB, int D, int H, int W,
+                            const bfm_upsample_t* up, const float* gamma, const float* beta, int G, float eps,
+                            float* scale, float* shift, float* bound, void* workspace, size_t workspace_bytes,
+                            bfm_stream_t stream) {
+    return bfm_gn_stats_train(A, CA, B, CB, D, H, W, up, gamma, beta, G, eps, scale, shift, bound, nullptr, nullptr,
+                              workspace, workspace_bytes, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -462,6 +473,6 @@ extern "C" int bfm_gn_stats_rows(const void* rowsA, int nrowsA, int CA, const vo
     PartTab tb{nullptr, nullptr, nullptr, nullptr, 0, 0, 1.0};
     if (CB > 0) tb = rows_source(rowsB, nrowsB, CB, weightB, ws + needA, st);
     hipLaunchKernelGGL(gn_finalize, dim3(G), dim3(TPB), fin_smem, st, ta, tb, G, (double)nvox, eps, gamma, beta, scale,
-                       shift, bound);
+                       shift, bound, nullptr, nullptr);
     return bfm_launch_status();
 }

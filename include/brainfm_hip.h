@@ -57,6 +57,11 @@ int bfm_gn_stats(const float* A, int CA, const float* B, int CB, int D, int H, i
                  const bfm_upsample_t* up, const float* gamma, const float* beta, int G, float eps,
                  float* scale, float* shift, float* bound, void* workspace, size_t workspace_bytes,
                  bfm_stream_t stream);
+/* same, also returning the per-group mean and 1/sqrt(var+eps) (G floats each) that the backward pass needs */
+int bfm_gn_stats_train(const float* A, int CA, const float* B, int CB, int D, int H, int W, const bfm_upsample_t* up,
+                       const float* gamma, const float* beta, int G, float eps, float* scale, float* shift,
+                       float* bound, float* mean_out, float* rstd_out, void* workspace, size_t workspace_bytes,
+                       bfm_stream_t stream);
 
 /* ------------------------------------------------------ 3x3x3 convolution
  * SingleConv 'gcl' minus the statistics: y = LeakyReLU_slope( conv3d_p1(
@@ -377,6 +382,26 @@ int bfm_reduce_f32(int op, const float* x, const float* y, int64_t n, double* ou
                    size_t workspace_bytes, bfm_stream_t stream);
 int bfm_reduce_f64(int op, const double* x, const double* y, int64_t n, double* out, void* workspace,
                    size_t workspace_bytes, bfm_stream_t stream);
+
+/* ---- backward pass of the SingleConv block and its neighbours (first correct version) -------------------
+ * The reference trains through torch autograd over buildingblocks.py:31-60 (GroupNorm -> Conv3d -> LeakyReLU),
+ * :185-186 (MaxPool3d(2)), :265-276,361-363 (nearest upsample + concat).
+ *   lrelu_bwd    dP = dY * (Y > 0 ? 1 : slope)                 (n % 4 == 0)
+ *   wgrad        dW[co][ci][27] = sum_v dP[v][co] * GN(x)[v+tap][ci]   (exact fp32 matrix cores, fixed split order)
+ *   data grad    = bfm_conv3x3x3_mfma / _direct on the transposed, tap-mirrored weights with identity affine, slope 1
+ *   gn_bwd       dXn -> dA (skip channels), dB (low-res channels: sum over the replica box), dgamma, dbeta
+ *   maxpool2_bwd gradient to the first maximum of each 2x2x2 window (scan order dz,dy,dx), zeros elsewhere */
+int bfm_lrelu_bwd(const float* dY, const float* Y, int64_t n, float slope, float* dP, bfm_stream_t stream);
+size_t bfm_conv3x3x3_wgrad_workspace(int Cin, int Cout, int D, int H, int W);
+int bfm_conv3x3x3_wgrad(const float* dP, int Cout, const float* A, int CA, const float* B, int CB, int D, int H, int W,
+                        const bfm_upsample_t* up, const float* scale, const float* shift, float* dW /*[Cout][Cin][27]*/,
+                        void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+size_t bfm_gn_bwd_workspace(int C, int D, int H, int W);
+int bfm_gn_bwd(const float* dXn, const float* A, int CA, const float* B, int CB, int D, int H, int W,
+               const bfm_upsample_t* up, const int32_t* startD, const int32_t* startH, const int32_t* startW,
+               const float* mean, const float* rstd, const float* gamma, int G, float* dA, float* dB, float* dgamma,
+               float* dbeta, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+int bfm_maxpool2_bwd(const float* in, const float* dOut, int C, int D, int H, int W, float* dIn, bfm_stream_t stream);
 
 #ifdef __cplusplus
 }
