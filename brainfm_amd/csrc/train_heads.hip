@@ -1,0 +1,454 @@
+// Training-side kernels around the backbone: the losses of Trainer/models/criterion.py with their
+// gradients w.r.t. the raw head outputs, the backward of the 1x1x1 task heads + F.normalize, and the optimiser step.
+//
+//   losses (criterion.py:111-124, 178-186, 215-273, 282-294; losses.py:10-11, 27-74):
+//     l1        mean(|o - t| * w)                                   T1/T2/FLAIR/CT/SR/distance/registration/bias_field_log
+//     grad_l1   mean|d_x o - d_x t| + mean|d_y ..| + mean|d_z ..|    forward differences, last slice zero (GradientLoss)
+//     seg       CE = mean_v( -sum_c log(max(p,1e-5)) * w_c * t_c ),  Dice = sum_c w_c (1 - 2 sum_v p t / max(sum_v (p+t), 1e-5))
+//               with p = softmax(logits)  (SegProcessor, joiner.py:69-77)
+//   Every loss kernel ADDS  coef * dL/d(raw)  into its columns of dRaw ([nvox][n_out], channels-last) and returns the
+//   loss value in fp64; reductions are two-stage with a fixed order.
+//   heads:   raw = Fn W^T + b,  Fn = F.normalize(feat)  (head.py:52-59, model.py:207)
+//   AdamW:   torch.optim.AdamW semantics (decoupled weight decay), one fused elementwise kernel.
+#include "bfm_common.h"
+
+#define GRID_STRIDE(i, n) \
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (int64_t)(n); i += (int64_t)gridDim.x * blockDim.x)
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+constexpr int RB = 1024;                         // partial blocks of the reductions
+
+__device__ __forceinline__ double block_sum(double v, double* red) {        // 256 threads, fixed tree
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ void final_sum_kernel(const double* __restrict__ part, int nb, double scale, double* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 256) s += part[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+// ----------------------------------------------------------------------------- L1
+// out column `co` of raw vs target [nvox] (optional weight [nvox]); clampv > 0: the prediction is clamp(o, +-clampv)
+// first (DistProcessor), whose gradient is zero where it clamps
+__global__ void __launch_bounds__(256) l1_kernel(const float* __restrict__ raw, int n_out, int co,
+                                                 const float* __restrict__ target, const float* __restrict__ weight,
+                                                 const float* __restrict__ mask_mul, int64_t nvox, float clampv,
+                                                 int l2, float coef, float* __restrict__ dRaw,
+                                                 double* __restrict__ part) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    GRID_STRIDE(v, nvox) {
+        float o = raw[v * n_out + co];
+        bool live = true;
+        if (clampv > 0.f) {
+            if (o > clampv) { o = clampv; live = false; }
+            else if (o < -clampv) { o = -clampv; live = false; }
+        }
+        const float m = mask_mul ? mask_mul[v] : 1.f;        // bias field: both sides are multiplied by the soft mask
+        const float w = weight ? weight[v] : 1.f;
+        const float d = o * m - target[v] * m;
+        acc += (double)((l2 ? d * d : fabsf(d)) * w);
+        const float sg = l2 ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        if (live && dRaw) dRaw[v * n_out + co] += coef * sg * w * m;
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+// ----------------------------------------------------------------------------- gradient L1 (GradientLoss 'l1')
+__global__ void __launch_bounds__(256) grad_l1_kernel(const float* __restrict__ raw, int n_out, int co,
+                                                      const float* __restrict__ target, const float* __restrict__ weight,
+                                                      int D, int H, int W, float coef, float* __restrict__ dRaw,
+                                                      double* __restrict__ part) {
+    __shared__ double red[256];
+    const int64_t nvox = (int64_t)D * H * W;
+    double acc = 0.0;
+    GRID_STRIDE(v, nvox) {
+        const int x = (int)(v % W);
+        const int64_t t2 = v / W;
+        const int y = (int)(t2 % H), z = (int)(t2 / H);
+        const float o = raw[v * n_out + co], t = target[v];
+        const float w = weight ? weight[v] : 1.f;
+        float g = 0.f;                                        // d(sum of the three terms)/d(o at v), own contributions
+        // forward differences along the fastest (x), middle (y) and slowest (z) axis; zero on the last slice
+        if (x + 1 < W) {
+            const float d = (raw[(v + 1) * n_out + co] - o) - (target[v + 1] - t);
+            acc += (double)(fabsf(d) * w);
+            g -= (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * w;
+        }
+        if (y + 1 < H) {
+            const float d = (raw[(v + W) * n_out + co] - o) - (target[v + W] - t);
+            acc += (double)(fabsf(d) * w);
+            g -= (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * w;
+        }
+        if (z + 1 < D) {
+            const int64_t s = (int64_t)H * W;
+            const float d = (raw[(v + s) * n_out + co] - o) - (target[v + s] - t);
+            acc += (double)(fabsf(d) * w);
+            g -= (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * w;
+        }
+        // contributions of the differences anchored at the previous voxel along each axis (weight of THAT voxel)
+        if (x > 0) {
+            const float d = (o - raw[(v - 1) * n_out + co]) - (t - target[v - 1]);
+            g += (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * (weight ? weight[v - 1] : 1.f);
+        }
+        if (y > 0) {
+            const float d = (o - raw[(v - W) * n_out + co]) - (t - target[v - W]);
+            g += (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * (weight ? weight[v - W] : 1.f);
+        }
+        if (z > 0) {
+            const int64_t s = (int64_t)H * W;
+            const float d = (o - raw[(v - s) * n_out + co]) - (t - target[v - s]);
+            g += (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * (weight ? weight[v - s] : 1.f);
+        }
+        if (dRaw) dRaw[v * n_out + co] += coef * g;
+    }
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+// ----------------------------------------------------------------------------- segmentation: CE + Dice on softmax
+// pass 1: probabilities P [nvox][ns] (written out) and per-block partials of CE      part: [nb][1 + 2*ns], slot 0
+__global__ void __launch_bounds__(256) seg_fwd_kernel(const float* __restrict__ raw, int n_out, int c0, int ns,
+                                                      const float* __restrict__ target /*[ns][nvox] one-hot / soft (NCDHW)*/,
+                                                      const float* __restrict__ wce /*[ns]*/, int64_t nvox,
+                                                      float* __restrict__ P, double* __restrict__ part) {
+    __shared__ double red[256];
+    double ce = 0.0;
+    GRID_STRIDE(v, nvox) {
+        const float* r = raw + v * n_out + c0;
+        float m = -INFINITY;
+        for (int c = 0; c < ns; ++c) m = fmaxf(m, r[c]);
+        float sum = 0.f;
+        for (int c = 0; c < ns; ++c) sum += expf(r[c] - m);
+        const float inv = 1.f / sum;
+        for (int c = 0; c < ns; ++c) {
+            const float p = expf(r[c] - m) * inv;
+            P[v * ns + c] = p;
+            ce -= (double)(logf(fmaxf(p, 1e-5f)) * wce[c] * target[(int64_t)c * nvox + v]);
+        }
+    }
+    ce = block_sum(ce, red);
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.x * (1 + 2 * ns)] = ce;
+}
+
+// pass 1b: per-class sums  sum_v p*t  and  sum_v (p+t)  of one voxel chunk; thread = (voxel lane j, class c), fixed order
+__global__ void __launch_bounds__(256) seg_class_sums_kernel(const float* __restrict__ P, const float* __restrict__ target,
+                                                             int ns, int64_t nvox, int64_t vox_per_block,
+                                                             double* __restrict__ part) {
+    __shared__ double s_pt[256], s_ps[256];
+    const int nj = 256 / ns;
+    const int t = threadIdx.x, j = t / ns, c = t - j * ns;
+    const int64_t v0 = (int64_t)blockIdx.x * vox_per_block, v1 = min(nvox, v0 + vox_per_block);
+    double a = 0.0, b = 0.0;
+    if (j < nj)
+        for (int64_t v = v0 + j; v < v1; v += nj) {
+            const float p = P[v * ns + c], tc = target[(int64_t)c * nvox + v];
+            a += (double)(p * tc);
+            b += (double)(p + tc);
+        }
+    s_pt[t] = a;
+    s_ps[t] = b;
+    __syncthreads();
+    if (t < ns) {
+        double sa = 0.0, sb = 0.0;
+        for (int k = 0; k < nj; ++k) { sa += s_pt[k * ns + t]; sb += s_ps[k * ns + t]; }
+        part[(int64_t)blockIdx.x * (1 + 2 * ns) + 1 + t] = sa;
+        part[(int64_t)blockIdx.x * (1 + 2 * ns) + 1 + ns + t] = sb;
+    }
+}
+
+// fold the per-block partials: out[0] = CE sum, out[1..ns] = sum p*t, out[1+ns..] = sum (p+t)
+__global__ void seg_fold_kernel(const double* __restrict__ part, int nb, int ns, double* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= 1 + 2 * ns) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += part[(int64_t)b * (1 + 2 * ns) + k];
+    out[k] = s;
+}
+
+// pass 2: d(w_ce*CE_mean + w_dice*Dice)/d(logits) through the softmax, added into dRaw
+__global__ void seg_bwd_kernel(const float* __restrict__ P, const float* __restrict__ target, int ns,
+                               const float* __restrict__ wce, const float* __restrict__ wdice,
+                               const double* __restrict__ sums, int64_t nvox, float coef_ce /* weight/(nvox) */,
+                               float coef_dice, int n_out, int c0, float* __restrict__ dRaw) {
+    GRID_STRIDE(v, nvox) {
+        const float* p = P + v * ns;
+        const float* t = target + v;                          // class c at t[c * nvox]
+        // dL/dp_c
+        float dot = 0.f;
+        for (int c = 0; c < ns; ++c) {
+            const float pc = p[c];
+            float g = 0.f;
+            if (pc > 1e-5f) g -= coef_ce * wce[c] * t[(int64_t)c * nvox] / pc;               // clamp(min=1e-5) kills the gradient below it
+            const double num = sums[1 + c], den = sums[1 + ns + c];
+            if (den > 1e-5) g += coef_dice * wdice[c] * (float)(-2.0 * ((double)t[(int64_t)c * nvox] * den - num) / (den * den));
+            dot += g * pc;
+        }
+        for (int c = 0; c < ns; ++c) {
+            const float pc = p[c];
+            float g = 0.f;
+            if (pc > 1e-5f) g -= coef_ce * wce[c] * t[(int64_t)c * nvox] / pc;
+            const double num = sums[1 + c], den = sums[1 + ns + c];
+            if (den > 1e-5) g += coef_dice * wdice[c] * (float)(-2.0 * ((double)t[(int64_t)c * nvox] * den - num) / (den * den));
+            dRaw[v * n_out + c0 + c] += pc * (g - dot);                         // softmax Jacobian
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- task heads backward
+// dFn[v][c] = sum_o dRaw[v][o] * W[o][c];   weights in LDS
+__global__ void __launch_bounds__(256) head_dfeat_kernel(const float* __restrict__ dRaw, const float* __restrict__ Wt,
+                                                         int n_out, int C, int64_t nvox, float* __restrict__ dFn) {
+    extern __shared__ float wl[];                             // [n_out][C]
+    for (int i = threadIdx.x; i < n_out * C; i += 256) wl[i] = Wt[i];
+    __syncthreads();
+    const int64_t n = nvox * C;
+    GRID_STRIDE(i, n) {
+        const int c = (int)(i % C);
+        const int64_t v = i / C;
+        float s = 0.f;
+        for (int o = 0; o < n_out; ++o) s = fmaf(dRaw[v * n_out + o], wl[o * C + c], s);
+        dFn[i] = s;
+    }
+}
+
+// dW[o][c] = sum_v dRaw[v][o] * Fn[v][c]  on the exact-fp32 matrix core; one wave per (split, o-block, c-block)
+__global__ void __launch_bounds__(64) head_wgrad_kernel(const float* __restrict__ dRaw, const float* __restrict__ Fn,
+                                                        int n_out, int C, int64_t nvox, int64_t vox_per_split,
+                                                        float* __restrict__ part /*[S][n_out][C]*/) {
+    const int lane = threadIdx.x, l32 = lane & 31, lh = lane >> 5;
+    const int ob = blockIdx.y, cb = blockIdx.z;
+    const int o = ob * 32 + l32, c = cb * 32 + l32;
+    floatx16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int64_t v0 = (int64_t)blockIdx.x * vox_per_split, v1 = min(nvox, v0 + vox_per_split);
+    for (int64_t v = v0; v < v1; v += 2) {
+        const int64_t vv = v + lh;
+        const float a = (vv < v1 && o < n_out) ? dRaw[vv * n_out + o] : 0.f;
+        const float b = (vv < v1 && c < C) ? Fn[vv * C + c] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    float* out = part + (int64_t)blockIdx.x * n_out * C;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int row = ob * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+        if (row < n_out && c < C) out[(int64_t)row * C + c] = acc[i];
+    }
+}
+
+__global__ void fold_splits_kernel(const float* __restrict__ part, int S, int64_t n, float* __restrict__ out) {
+    GRID_STRIDE(i, n) {
+        float s = part[i];
+        for (int k = 1; k < S; ++k) s += part[i + (int64_t)k * n];
+        out[i] = s;
+    }
+}
+
+// db[o] = sum_v dRaw[v][o]: per-block partial column sums in fp64, then folded
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ X, int n_out, int64_t nvox,
+                                                     int64_t vox_per_block, double* __restrict__ part) {
+    const int64_t v0 = (int64_t)blockIdx.x * vox_per_block, v1 = min(nvox, v0 + vox_per_block);
+    for (int o = threadIdx.x; o < n_out; o += 256) {
+        double s = 0.0;
+        for (int64_t v = v0; v < v1; ++v) s += (double)X[v * n_out + o];
+        part[(int64_t)blockIdx.x * n_out + o] = s;
+    }
+}
+__global__ void colsum_fold_kernel(const double* __restrict__ part, int nb, int n_out, float* __restrict__ out) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n_out) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += part[(int64_t)b * n_out + o];
+    out[o] = (float)s;
+}
+
+// F.normalize backward: f^ = f / max(|f|, eps);  df = (dF^ - f^ <dF^, f^>) / max(|f|, eps)   (|f| > eps branch)
+__global__ void normalize_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ dFn, int C, int64_t nvox,
+                                     float eps, float* __restrict__ dfeat) {
+    GRID_STRIDE(v, nvox) {
+        const float* f = feat + v * C;
+        const float* g = dFn + v * C;
+        float ss = 0.f;
+        for (int c = 0; c < C; ++c) ss = fmaf(f[c], f[c], ss);
+        const float nrm = sqrtf(ss);
+        if (nrm > eps) {
+            const float inv = 1.f / nrm;
+            float dot = 0.f;
+            for (int c = 0; c < C; ++c) dot = fmaf(g[c], f[c] * inv, dot);
+            for (int c = 0; c < C; ++c) dfeat[v * C + c] = (g[c] - f[c] * inv * dot) * inv;
+        } else {
+            for (int c = 0; c < C; ++c) dfeat[v * C + c] = g[c] / eps;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- optimiser / scaler helpers
+// torch.optim.AdamW (amsgrad off, maximize off): p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+// p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                             float bias1, float bias2_sqrt, float grad_scale) {
+    GRID_STRIDE(i, n) {
+        const float gi = g[i] * grad_scale;
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bias2_sqrt + eps;
+        pi = pi - (lr / bias1) * (mi / denom);
+        p[i] = pi;
+    }
+}
+
+// sum of squares + non-finite flag of a gradient tensor (clip_gradients / GradScaler.unscale_)
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ part,
+                                                    int* __restrict__ nonfinite) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    bool bad = false;
+    GRID_STRIDE(i, n) {
+        const float x = g[i];
+        if (!(fabsf(x) <= 3.402823466e+38f)) bad = true;
+        acc += (double)x * (double)x;
+    }
+    if (bad) atomicOr(nonfinite, 1);
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+int grid_for(int64_t n, int cap = 4096) { return (int)std::min<int64_t>(cap, std::max<int64_t>(1, bfm_cdiv64(n, 256))); }
+
+}  // namespace
+
+extern "C" size_t bfm_loss_workspace(int ns) { return (size_t)RB * (1 + 2 * (ns > 0 ? ns : 0)) * sizeof(double) + 4096; }
+
+extern "C" int bfm_loss_l1(const float* raw, int n_out, int co, const float* target, const float* weight,
+                           const float* mask_mul, int64_t nvox, float clampv, int l2, float coef, float* dRaw,
+                           double* loss_out, void* workspace, size_t workspace_bytes, bfm_stream_t stream) {
+    if (!raw || !target || !loss_out || !workspace || nvox <= 0 || co < 0 || co >= n_out) return BFM_E_ARG;
+    if (workspace_bytes < bfm_loss_workspace(0)) return BFM_E_WORKSPACE;
+    double* part = static_cast<double*>(workspace);
+    const int nb = grid_for(nvox, RB);
+    hipLaunchKernelGGL(l1_kernel, dim3(nb), dim3(256), 0, bfm_s(stream), raw, n_out, co, target, weight, mask_mul, nvox,
+                       clampv, l2, coef / (float)nvox, dRaw, part);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, bfm_s(stream), part, nb, 1.0 / (double)nvox, loss_out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_loss_grad_l1(const float* raw, int n_out, int co, const float* target, const float* weight, int D,
+                                int H, int W, float coef, float* dRaw, double* loss_out, void* workspace,
+                                size_t workspace_bytes, bfm_stream_t stream) {
+    if (!raw || !target || !loss_out || !workspace || D <= 0 || H <= 0 || W <= 0 || co < 0 || co >= n_out)
+        return BFM_E_ARG;
+    if (workspace_bytes < bfm_loss_workspace(0)) return BFM_E_WORKSPACE;
+    double* part = static_cast<double*>(workspace);
+    const int64_t nvox = (int64_t)D * H * W;
+    const int nb = grid_for(nvox, RB);
+    hipLaunchKernelGGL(grad_l1_kernel, dim3(nb), dim3(256), 0, bfm_s(stream), raw, n_out, co, target, weight, D, H, W,
+                       coef / (float)nvox, dRaw, part);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, bfm_s(stream), part, nb, 1.0 / (double)nvox, loss_out);
+    return bfm_launch_status();
+}
+
+// loss_out[0] = CE (mean over voxels), loss_out[1] = Dice; P = softmax probabilities [nvox][ns] (scratch / output)
+extern "C" int bfm_loss_seg(const float* raw, int n_out, int c0, int ns, const float* target, const float* wce,
+                            const float* wdice, int64_t nvox, float coef_ce, float coef_dice, float* P, float* dRaw,
+                            double* loss_out, void* workspace, size_t workspace_bytes, bfm_stream_t stream) {
+    if (!raw || !target || !wce || !wdice || !P || !loss_out || !workspace || nvox <= 0 || ns <= 0 || c0 < 0 ||
+        c0 + ns > n_out)
+        return BFM_E_ARG;
+    if (workspace_bytes < bfm_loss_workspace(ns)) return BFM_E_WORKSPACE;
+    double* part = static_cast<double*>(workspace);
+    const int nb = grid_for(nvox, RB);
+    hipStream_t st = bfm_s(stream);
+    const int64_t vpb = bfm_cdiv64(nvox, nb);
+    if (ns > 256 || bfm_cdiv64(nvox, vpb) > nb) return BFM_E_SHAPE;
+    hipLaunchKernelGGL(seg_fwd_kernel, dim3(nb), dim3(256), 0, st, raw, n_out, c0, ns, target, wce, nvox, P, part);
+    // blocks past the last voxel chunk still write zeros: the fold below reads all nb rows
+    hipLaunchKernelGGL(seg_class_sums_kernel, dim3(nb), dim3(256), 0, st, P, target, ns, nvox, vpb, part);
+    double* sums = part + (size_t)RB * (1 + 2 * ns);             // [1 + 2 ns]
+    hipLaunchKernelGGL(seg_fold_kernel, dim3(bfm_cdiv(1 + 2 * ns, 64)), dim3(64), 0, st, part, nb, ns, sums);
+    if (dRaw)
+        hipLaunchKernelGGL(seg_bwd_kernel, dim3(grid_for(nvox)), dim3(256), 0, st, P, target, ns, wce, wdice, sums, nvox,
+                           coef_ce / (float)nvox, coef_dice, n_out, c0, dRaw);
+    // loss values are finished on the host from `sums` (CE mean and the Dice sum need wdice): copy them out
+    hipMemcpyAsync(loss_out, sums, (size_t)(1 + 2 * ns) * sizeof(double), hipMemcpyDeviceToDevice, st);
+    return bfm_launch_status();
+}
+
+extern "C" size_t bfm_head_bwd_workspace(int n_out, int C, int64_t nvox) {
+    const int S = (int)std::min<int64_t>(256, std::max<int64_t>(1, nvox / 4096));
+    return (size_t)S * n_out * C * sizeof(float) + (size_t)RB * n_out * sizeof(double) + 256;
+}
+
+extern "C" int bfm_head_bwd(const float* dRaw, const float* Fn, const float* head_w, int n_out, int C, int64_t nvox,
+                            float* dW, float* db, float* dFn, void* workspace, size_t workspace_bytes,
+                            bfm_stream_t stream) {
+    if (!dRaw || !Fn || !head_w || !dW || !db || !dFn || !workspace || n_out <= 0 || C <= 0 || nvox <= 0) return BFM_E_ARG;
+    if (workspace_bytes < bfm_head_bwd_workspace(n_out, C, nvox)) return BFM_E_WORKSPACE;
+    if ((size_t)n_out * C * sizeof(float) > 64 * 1024) return BFM_E_SHAPE;
+    hipStream_t st = bfm_s(stream);
+    hipLaunchKernelGGL(head_dfeat_kernel, dim3(grid_for(nvox * C)), dim3(256), (size_t)n_out * C * sizeof(float), st, dRaw,
+                       head_w, n_out, C, nvox, dFn);
+    const int S = (int)std::min<int64_t>(256, std::max<int64_t>(1, nvox / 4096));
+    int64_t vps = bfm_cdiv64(nvox, S);
+    vps += vps & 1;                                              // even: the K pair never straddles two splits
+    const int S2 = (int)bfm_cdiv64(nvox, vps);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3(S2, bfm_cdiv(n_out, 32), bfm_cdiv(C, 32)), dim3(64), 0, st, dRaw, Fn, n_out, C,
+                       nvox, vps, part);
+    hipLaunchKernelGGL(fold_splits_kernel, dim3(grid_for((int64_t)n_out * C)), dim3(256), 0, st, part, S2,
+                       (int64_t)n_out * C, dW);
+    double* cpart = reinterpret_cast<double*>(static_cast<char*>(workspace) + (((size_t)S * n_out * C * sizeof(float) + 255) & ~(size_t)255));
+    const int nb = grid_for(nvox, RB);
+    const int64_t vpb = bfm_cdiv64(nvox, nb);
+    const int nb2 = (int)bfm_cdiv64(nvox, vpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3(nb2), dim3(256), 0, st, dRaw, n_out, nvox, vpb, cpart);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(bfm_cdiv(n_out, 64)), dim3(64), 0, st, cpart, nb2, n_out, db);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_normalize_bwd(const float* feat, const float* dFn, int C, int64_t nvox, float eps, float* dfeat,
+                                 bfm_stream_t stream) {
+    if (!feat || !dFn || !dfeat || C <= 0 || nvox <= 0) return BFM_E_ARG;
+    hipLaunchKernelGGL(normalize_bwd_kernel, dim3(grid_for(nvox)), dim3(256), 0, bfm_s(stream), feat, dFn, C, nvox, eps, dfeat);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int step, float grad_scale, bfm_stream_t stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return BFM_E_ARG;
+    const float bias1 = 1.f - powf(beta1, (float)step);
+    const float bias2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, bias1, bias2_sqrt, grad_scale);
+    return bfm_launch_status();
+}
+
+// out[0] = sum of squares (fp64), nonfinite[0] |= 1 if any element is inf / nan
+extern "C" int bfm_grad_sumsq(const float* g, int64_t n, double* out, int32_t* nonfinite, void* workspace,
+                              size_t workspace_bytes, bfm_stream_t stream) {
+    if (!g || !out || !nonfinite || !workspace || n <= 0) return BFM_E_ARG;
+    if (workspace_bytes < bfm_loss_workspace(0)) return BFM_E_WORKSPACE;
+    double* part = static_cast<double*>(workspace);
+    const int nb = grid_for(n, RB);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, bfm_s(stream), g, n, part, nonfinite);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, bfm_s(stream), part, nb, 1.0, out);
+    return bfm_launch_status();
+}

@@ -1,0 +1,347 @@
+"""One training iteration of the multi-task U-Net on the HIP kernels.
+
+Mirrors the reference's iteration -- Trainer/engine.py:96-147:
+
+    outputs, _ = model(samples)                       -> backward.backbone_forward_train + Tail.run_raw   (per sample)
+    outputs = processor(outputs, ...)                 -> softmax / clamp folded into the loss kernels
+    loss_dict = criterion(outputs, target, samples)   -> bfm_loss_l1 / bfm_loss_grad_l1 / bfm_loss_seg
+    losses = sum(loss_dict[k] * weight_dict[k])
+    scaler.scale(losses).backward()                   -> bfm_head_bwd, bfm_normalize_bwd, backward.backbone_backward
+    scaler.unscale_(optimizer); clip_gradients(...)   -> bfm_grad_sumsq (+ non-finite flag), per-parameter coefficient
+    scaler.step(optimizer); scaler.update()           -> bfm_adamw_step, LossScaler.update
+
+with the criterion of Trainer/models/criterion.py (SetMultiCriterion: sum over the samples / all_samples) restricted to
+the supervised dense heads: T1 T2 FLAIR CT (+_grad, optional <key>_DM weights), SR(+_grad), distance, registration
+(+_grad), bias_field_log (l1 | l2, soft mask 1 - seg[:, 0]), seg_ce, seg_dice.  Any other loss name raises.
+
+Everything numeric runs in the HIP library; torch holds buffers, adds the per-sample gradients and runs the RCCL
+all-reduce.  There is no CPU path: without the extension or a HIP device construction fails.
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import _lib as L
+from . import backward as BW
+
+IMAGE_KEYS = ("T1", "T2", "FLAIR", "CT")
+SUPPORTED = set(IMAGE_KEYS) | {k + "_grad" for k in IMAGE_KEYS} | {
+    "SR", "SR_grad", "distance", "registration", "registration_grad", "bias_field_log", "seg_ce", "seg_dice"}
+
+
+class LossScaler:
+    """torch.cuda.amp.GradScaler's state machine (scripts/train.py:164, Trainer/engine.py:139-147): the loss is
+    multiplied by `scale`, gradients are divided by it before clipping, a step with a non-finite gradient is skipped and
+    halves the scale, `growth_interval` clean steps in a row double it."""
+
+    def __init__(self, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        self.scale = float(init_scale) if enabled else 1.0
+        self.growth_factor, self.backoff_factor = float(growth_factor), float(backoff_factor)
+        self.growth_interval = int(growth_interval)
+        self.enabled = bool(enabled)
+        self._good = 0
+
+    def update(self, found_inf):
+        if not self.enabled:
+            return
+        if found_inf:
+            self.scale *= self.backoff_factor
+            self._good = 0
+        else:
+            self._good += 1
+            if self._good == self.growth_interval:
+                self.scale *= self.growth_factor
+                self._good = 0
+
+
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0.0):
+    """utils/misc.py:1265-1276: linear warm-up then half a cosine, one value per iteration."""
+    import numpy as np
+    warm_iters = warmup_epochs * niter_per_ep
+    warm = np.linspace(start_warmup_value, base_value, warm_iters) if warmup_epochs > 0 else np.array([])
+    it = np.arange(epochs * niter_per_ep - warm_iters)
+    sched = final_value + 0.5 * (base_value - final_value) * (1 + np.cos(np.pi * it / len(it)))
+    return np.concatenate((warm, sched))
+
+
+def allreduce_mean_(grads, group=None):
+    """DDP's gradient averaging (scripts/train.py:153-158) as ONE flat all-reduce over all parameters: xGMI rings are
+    per-link bound, so a single ~100 MB bucket beats many small ones.  In place; no-op without a process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return grads
+    keys = list(grads.keys())
+    flat = torch.cat([grads[k].reshape(-1) for k in keys])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= dist.get_world_size(group)
+    off = 0
+    for k in keys:
+        n = grads[k].numel()
+        grads[k].copy_(flat[off:off + n].view_as(grads[k]))
+        off += n
+    return grads
+
+
+class TrainStep:
+    """Parameters live in the engine (layer .w_raw / .gamma / .beta) and the tail (head_w / head_b); `step` updates
+    them in place and drops the packed-weight caches so that the next forward repacks."""
+
+    def __init__(self, engine, tail, loss_names, loss_weights, weights_ce, all_samples, max_surf_distance=3.0,
+                 bias_field_log_type="l2", lr=1e-4, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, clip_max_norm=0.0,
+                 scaler=None):
+        bad = [n for n in loss_names if n not in SUPPORTED]
+        if bad:
+            raise L.BfmError("losses outside the HIP training path: %s" % bad)
+        self.eng, self.tail = engine, tail
+        self.lib = engine.lib
+        self.dev = engine.device
+        self.loss_names = list(loss_names)
+        self.loss_weights = dict(loss_weights)
+        self.all_samples = float(all_samples)
+        self.max_dist = float(max_surf_distance)
+        self.bias_l2 = 1 if bias_field_log_type == "l2" else 0
+        self.wce = torch.as_tensor(weights_ce).to(device=self.dev, dtype=torch.float32).contiguous()
+        self.lr, self.wd, self.betas, self.eps, self.clip = float(lr), float(weight_decay), betas, float(eps), float(clip_max_norm)
+        self.scaler = scaler if scaler is not None else LossScaler(enabled=False)
+        self.t = 0
+        self.state = {}                                   # name -> (m, v)
+        nseg = tail.desc.n_seg
+        self._ws = torch.empty(self.lib.bfm_loss_workspace(max(nseg, 1)), dtype=torch.uint8, device=self.dev)
+
+    # ------------------------------------------------------------------ parameters
+    def parameters(self):
+        """{reference parameter name: device tensor (views for the heads)}."""
+        p = OrderedDict()
+        for pair in self.eng.enc + self.eng.dec:
+            for ly in pair:
+                p[ly.name + ".groupnorm.weight"] = ly.gamma
+                p[ly.name + ".groupnorm.bias"] = ly.beta
+                p[ly.name + ".conv.weight"] = ly.w_raw
+        for task, (r0, n) in self.tail.row_of.items():
+            p["head.final_conv_%s.weight" % task] = self.tail.head_w[r0:r0 + n]
+            p["head.final_conv_%s.bias" % task] = self.tail.head_b[r0:r0 + n]
+        return p
+
+    def _weights_changed(self):
+        for pair in self.eng.enc + self.eng.dec:
+            for ly in pair:
+                ly.packs.clear()
+                ly.wpacked, ly.kind, ly.skip = None, None, None
+        self.tail.desc.head_wmax = float(self.tail.head_w.abs().max().item())
+
+    # ------------------------------------------------------------------ losses
+    def _col(self, task, j=0):
+        r0, n = self.tail.row_of[task]
+        if j >= n:
+            raise L.BfmError("head '%s' has %d channels" % (task, n))
+        return r0 + j
+
+    def _t(self, x, shape_tail):
+        x = torch.as_tensor(x).to(device=self.dev, dtype=torch.float32).contiguous()
+        if tuple(x.shape[-3:]) != tuple(shape_tail):
+            raise L.BfmError("target of shape %s does not match the volume %s" % (tuple(x.shape), tuple(shape_tail)))
+        return x
+
+    def _sample_losses(self, raw, dims, target, sample, dRaw, vals, scale):
+        """Launch every loss of one sample; values land in `vals` (device fp64, one slot list per loss name)."""
+        lib, st = self.lib, L.stream_ptr()
+        D, H, W = dims
+        nvox = D * H * W
+        n_out = self.tail.n_out
+        ws, wsn = L.ptr(self._ws), self._ws.numel()
+        slots = {}
+        k = 0
+
+        def slot(name, n=1):
+            nonlocal k
+            slots.setdefault(name, []).append((k, n))
+            k += n
+            return C.c_void_p(vals.data_ptr() + 8 * (k - n))
+
+        for name in self.loss_names:
+            coef = scale * self.loss_weights.get("loss_" + name, 0.0) / self.all_samples
+            if name in IMAGE_KEYS or (name.endswith("_grad") and name[:-5] in IMAGE_KEYS) or name in ("SR", "SR_grad"):
+                is_grad = name.endswith("_grad")
+                key = name[:-5] if is_grad else name
+                if key == "SR":
+                    head, tgt, wt = "high_res_residual", sample.get("high_res_residual"), None
+                else:
+                    head, tgt = key, target.get(key)
+                    wt = (1.0 - self._t(target[key + "_DM"], dims)) if (key + "_DM") in target else None
+                if tgt is None or head not in self.tail.row_of:
+                    continue                                          # criterion.py:274-281: shape mismatch -> 0
+                tgt = self._t(tgt, dims)
+                co = self._col(head)
+                if is_grad:
+                    L.check(lib.bfm_loss_grad_l1(L.ptr(raw), n_out, co, L.ptr(tgt), L.ptr(wt), D, H, W, coef, L.ptr(dRaw),
+                                                 slot(name), ws, wsn, st), "loss_grad_l1 " + name)
+                else:
+                    L.check(lib.bfm_loss_l1(L.ptr(raw), n_out, co, L.ptr(tgt), L.ptr(wt), None, nvox, 0.0, 0, coef,
+                                            L.ptr(dRaw), slot(name), ws, wsn, st), "loss_l1 " + name)
+            elif name in ("distance", "registration", "registration_grad"):
+                head = "registration" if name.startswith("registration") else "distance"
+                if head not in target or head not in self.tail.row_of:
+                    continue
+                nch = self.tail.row_of[head][1]
+                tgt = self._t(target[head], dims).reshape(-1, D, H, W)
+                if tgt.shape[0] != nch:
+                    continue
+                for j in range(nch):
+                    co = self._col(head, j)
+                    if name == "registration_grad":
+                        L.check(lib.bfm_loss_grad_l1(L.ptr(raw), n_out, co, L.ptr(tgt[j]), None, D, H, W, coef / nch,
+                                                     L.ptr(dRaw), slot(name), ws, wsn, st), "loss_grad_l1 " + name)
+                    else:
+                        clampv = self.max_dist if head == "distance" else 0.0
+                        L.check(lib.bfm_loss_l1(L.ptr(raw), n_out, co, L.ptr(tgt[j]), None, None, nvox, clampv, 0,
+                                                coef / nch, L.ptr(dRaw), slot(name), ws, wsn, st), "loss_l1 " + name)
+            elif name == "bias_field_log":
+                if "bias_field_log" not in sample or "bias_field_log" not in self.tail.row_of:
+                    continue
+                mask = 1.0 - self._t(target["segmentation"], dims).reshape(-1, D, H, W)[0]
+                tgt = self._t(sample["bias_field_log"], dims)
+                L.check(lib.bfm_loss_l1(L.ptr(raw), n_out, self._col("bias_field_log"), L.ptr(tgt), None, L.ptr(mask), nvox,
+                                        0.0, self.bias_l2, coef, L.ptr(dRaw), slot(name), ws, wsn, st), "loss bias_field_log")
+            elif name == "seg_ce":
+                # CE and Dice share the softmax: one launch covers both names
+                r0, ns = self.tail.row_of["segmentation"]
+                tgt = self._t(target["segmentation"], dims).reshape(ns, D, H, W)
+                c_dice = (scale * self.loss_weights.get("loss_seg_dice", 0.0) / self.all_samples
+                          if "seg_dice" in self.loss_names else 0.0)
+                P = torch.empty((nvox, ns), dtype=torch.float32, device=self.dev)
+                L.check(lib.bfm_loss_seg(L.ptr(raw), n_out, r0, ns, L.ptr(tgt), L.ptr(self.wce), L.ptr(self.wce), nvox,
+                                         coef, c_dice, L.ptr(P), L.ptr(dRaw), slot("seg", 1 + 2 * ns), ws, wsn, st), "loss_seg")
+            elif name == "seg_dice":
+                if "seg_ce" not in self.loss_names:
+                    r0, ns = self.tail.row_of["segmentation"]
+                    tgt = self._t(target["segmentation"], dims).reshape(ns, D, H, W)
+                    P = torch.empty((nvox, ns), dtype=torch.float32, device=self.dev)
+                    L.check(lib.bfm_loss_seg(L.ptr(raw), n_out, r0, ns, L.ptr(tgt), L.ptr(self.wce), L.ptr(self.wce), nvox,
+                                             0.0, coef, L.ptr(P), L.ptr(dRaw), slot("seg", 1 + 2 * ns), ws, wsn, st), "loss_seg")
+        return slots, k
+
+    def _finish_losses(self, per_sample, nvox):
+        """Host side of SetMultiCriterion: fold channels / samples of the fp64 slots into {loss_<name>: value}."""
+        out = OrderedDict()
+        wdice = self.wce.double().cpu()
+        for slots, vals in per_sample:
+            v = vals.cpu()
+            for name, lst in slots.items():
+                if name == "seg":
+                    (k0, n), = lst
+                    ns = (n - 1) // 2
+                    ce = float(v[k0]) / nvox
+                    num, den = v[k0 + 1:k0 + 1 + ns], v[k0 + 1 + ns:k0 + 1 + 2 * ns]
+                    dice = float((wdice * (1.0 - 2.0 * num / torch.clamp(den, min=1e-5))).sum())
+                    if "seg_ce" in self.loss_names:
+                        out["loss_seg_ce"] = out.get("loss_seg_ce", 0.0) + ce / self.all_samples
+                    if "seg_dice" in self.loss_names:
+                        out["loss_seg_dice"] = out.get("loss_seg_dice", 0.0) + dice / self.all_samples
+                else:
+                    val = sum(float(v[k0]) for k0, _ in lst) / len(lst)
+                    out["loss_" + name] = out.get("loss_" + name, 0.0) + val / self.all_samples
+        # keep the criterion's loss order
+        return OrderedDict((("loss_" + n), out["loss_" + n]) for n in self.loss_names if ("loss_" + n) in out)
+
+    # ------------------------------------------------------------------ forward + backward
+    def loss_and_grads(self, xs, target, samples):
+        """xs: list of (1,C,D,H,W) inputs (one per augmented sample); target / samples as the reference's dicts
+        (NCDHW tensors).  Returns (loss_dict, total, grads) with grads = d(scale * total)/d(parameter) summed over the
+        samples (scale = the loss scaler's)."""
+        eng, tail, lib = self.eng, self.tail, self.lib
+        scale = self.scaler.scale
+        grads = None
+        per_sample = []
+        nvox = None
+        for x, sample in zip(xs, samples):
+            dims = tuple(x.shape[-3:])
+            nvox = dims[0] * dims[1] * dims[2]
+            st = L.stream_ptr()
+            x_cl = eng.to_cl(x)
+            feats, tape = BW.backbone_forward_train(eng, x_cl, dims)
+            feat_last = feats[-1][0]
+            raw, fn = tail.run_raw(feat_last, dims, want_feat=True)
+            if fn is None:
+                fn = feat_last
+            dRaw = torch.zeros_like(raw)
+            vals = torch.zeros(4 * len(self.loss_names) + 2 * tail.n_out + 8, dtype=torch.float64, device=self.dev)
+            slots, _ = self._sample_losses(raw, dims, target, sample, dRaw, vals, scale)
+            per_sample.append((slots, vals))
+            # heads
+            n_out, cf = tail.n_out, tail.c_feat
+            dW = torch.empty((n_out, cf), dtype=torch.float32, device=self.dev)
+            db = torch.empty(n_out, dtype=torch.float32, device=self.dev)
+            dFn = torch.empty((nvox, cf), dtype=torch.float32, device=self.dev)
+            wsb = torch.empty(lib.bfm_head_bwd_workspace(n_out, cf, nvox), dtype=torch.uint8, device=self.dev)
+            L.check(lib.bfm_head_bwd(L.ptr(dRaw), L.ptr(fn), L.ptr(tail.head_w), n_out, cf, nvox, L.ptr(dW), L.ptr(db),
+                                     L.ptr(dFn), L.ptr(wsb), wsb.numel(), st), "head_bwd")
+            if eng.unit_feat:
+                dfeat = torch.empty_like(dFn)
+                L.check(lib.bfm_normalize_bwd(L.ptr(feat_last), L.ptr(dFn), cf, nvox, 1e-12, L.ptr(dfeat), st), "normalize_bwd")
+            else:
+                dfeat = dFn
+            g = BW.backbone_backward(eng, tape, [None] * (len(feats) - 1) + [dfeat.view(dims + (cf,))])
+            for task, (r0, n) in tail.row_of.items():
+                g["head.final_conv_%s.weight" % task] = dW[r0:r0 + n]
+                g["head.final_conv_%s.bias" % task] = db[r0:r0 + n]
+            if grads is None:
+                grads = g
+            else:
+                for k_, v_ in g.items():
+                    grads[k_] = grads[k_] + v_
+        loss_dict = self._finish_losses(per_sample, nvox)
+        total = sum(v * self.loss_weights.get(k, 0.0) for k, v in loss_dict.items() if k in self.loss_weights)
+        return loss_dict, total, grads
+
+    # ------------------------------------------------------------------ optimiser
+    def apply(self, grads, lr=None, weight_decay=None):
+        """unscale -> per-parameter clip (utils/misc.py:1329-1338) -> AdamW -> scaler.update.  Returns
+        (stepped, norms): stepped is False when a non-finite gradient made the scaler skip the step."""
+        lib, st = self.lib, L.stream_ptr()
+        lr = self.lr if lr is None else float(lr)
+        wd = self.wd if weight_decay is None else float(weight_decay)
+        params = self.parameters()
+        names = [k for k in params if k in grads]
+        sums = torch.zeros(len(names), dtype=torch.float64, device=self.dev)
+        flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        for i, k in enumerate(names):
+            g = grads[k] = grads[k].contiguous()
+            L.check(lib.bfm_grad_sumsq(L.ptr(g), g.numel(), C.c_void_p(sums.data_ptr() + 8 * i), L.ptr(flag),
+                                       L.ptr(self._ws), self._ws.numel(), st), "grad_sumsq " + k)
+        inv = 1.0 / self.scaler.scale
+        found_inf = bool(flag.item())
+        norms = [math.sqrt(v) * inv if math.isfinite(v) else float("inf") for v in sums.cpu().tolist()]
+        found_inf = found_inf or any(not math.isfinite(v) for v in norms)
+        if found_inf:
+            self.scaler.update(True)
+            return False, norms
+        self.t += 1
+        for k, nrm in zip(names, norms):
+            p, g = params[k], grads[k]
+            coef = inv
+            if self.clip > 0:
+                c = self.clip / (nrm + 1e-6)
+                if c < 1:
+                    coef *= c
+            if k not in self.state:
+                self.state[k] = (torch.zeros(p.numel(), dtype=torch.float32, device=self.dev),
+                                 torch.zeros(p.numel(), dtype=torch.float32, device=self.dev))
+            m, v = self.state[k]
+            if not p.is_contiguous():
+                raise L.BfmError("parameter %s is not contiguous" % k)
+            L.check(lib.bfm_adamw_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, self.betas[0], self.betas[1],
+                                       self.eps, wd, self.t, coef, st), "adamw " + k)
+        self._weights_changed()
+        self.scaler.update(False)
+        return True, norms
+
+    def step(self, xs, target, samples, lr=None, weight_decay=None, group=None):
+        """One full iteration (Trainer/engine.py:96-147).  Returns (loss_dict, total, stepped)."""
+        loss_dict, total, grads = self.loss_and_grads(xs, target, samples)
+        if not math.isfinite(total):
+            return loss_dict, total, False                     # engine.py:129-136: non-finite loss -> skip the iteration
+        allreduce_mean_(grads, group)
+        stepped, _ = self.apply(grads, lr, weight_decay)
+        return loss_dict, total, stepped

@@ -403,6 +403,40 @@ int bfm_gn_bwd(const float* dXn, const float* A, int CA, const float* B, int CB,
                float* dbeta, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
 int bfm_maxpool2_bwd(const float* in, const float* dOut, int C, int D, int H, int W, float* dIn, bfm_stream_t stream);
 
+/* ---- losses, task-head backward and optimiser step (the rest of one training iteration) -------------------
+ * Replaces, for the supervised heads, Trainer/models/criterion.py:111-124,178-186,215-294 + losses.py:10-74 (loss values
+ * and, through autograd, their gradients), head.py:52-59 + model.py:207 (1x1x1 heads over F.normalize'd features),
+ * torch.optim.AdamW and the clip/unscale reductions of Trainer/engine.py:128-147.
+ * raw / dRaw are the channels-last head outputs [nvox][n_out] of bfm_tail (raw mode); targets and weights keep the
+ * reference's NCDHW layout (one channel = nvox contiguous floats; seg target [ns][nvox]). Every loss ADDS
+ * coef * dL/draw into its columns of dRaw (NULL: value only) and writes the loss value(s) in fp64 (device memory).
+ *   l1       mean(|o*m - t*m| * w); o clamped to +-clampv first when clampv > 0 (DistProcessor); weight, mask_mul optional
+ *   grad_l1  mean|dx(o) - dx(t)|w + mean|dy ..|w + mean|dz ..|w, forward differences, zero on the last slice
+ *   seg      p = softmax(raw[c0:c0+ns]);  loss_out[0] = sum_v CE_v, loss_out[1..ns] = sum_v p t, loss_out[1+ns..] =
+ *            sum_v (p+t); gradient of coef_ce * mean_v CE + coef_dice * Dice. P [nvox][ns] receives the probabilities. */
+size_t bfm_loss_workspace(int ns);
+int bfm_loss_l1(const float* raw, int n_out, int co, const float* target, const float* weight, const float* mask_mul,
+                int64_t nvox, float clampv, int l2 /* 1: mean squared error (bias_field_log_type 'l2') */, float coef,
+                float* dRaw, double* loss_out, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+int bfm_loss_grad_l1(const float* raw, int n_out, int co, const float* target, const float* weight, int D, int H, int W,
+                     float coef, float* dRaw, double* loss_out, void* workspace, size_t workspace_bytes,
+                     bfm_stream_t stream);
+int bfm_loss_seg(const float* raw, int n_out, int c0, int ns, const float* target, const float* wce, const float* wdice,
+                 int64_t nvox, float coef_ce, float coef_dice, float* P, float* dRaw, double* loss_out /*[1+2ns]*/,
+                 void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+/* dW [n_out][C], db [n_out], dFn [nvox][C] from dRaw [nvox][n_out] and the normalised features Fn [nvox][C] */
+size_t bfm_head_bwd_workspace(int n_out, int C, int64_t nvox);
+int bfm_head_bwd(const float* dRaw, const float* Fn, const float* head_w, int n_out, int C, int64_t nvox, float* dW,
+                 float* db, float* dFn, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+int bfm_normalize_bwd(const float* feat, const float* dFn, int C, int64_t nvox, float eps, float* dfeat,
+                      bfm_stream_t stream);
+/* torch.optim.AdamW step t (1-based) on one flat parameter; g is multiplied by grad_scale first (unscale * clip) */
+int bfm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, float grad_scale, bfm_stream_t stream);
+/* out[0] = sum g^2 (fp64); nonfinite[0] |= 1 when g holds inf/nan (GradScaler.unscale_ / clip_grad_norm_) */
+int bfm_grad_sumsq(const float* g, int64_t n, double* out, int32_t* nonfinite, void* workspace, size_t workspace_bytes,
+                   bfm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

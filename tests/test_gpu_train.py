@@ -1,0 +1,171 @@
+"""one training iteration on the HIP kernels against the golden vectors made by running the reference
+(model -> processors -> SetMultiCriterion -> backward -> clip_gradients -> AdamW, float64) and against the oracle.
+Needs an MI355X: run with `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import sd_from_npz
+from oracle import train_ref as T
+from test_oracle_train import load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "gpu-marked test needs a HIP device"
+    return torch.device("cuda:0")
+
+
+def _build(c, scaler=None, clip=None):
+    from brainfm_amd import test_utils as TU
+    from brainfm_amd import train as TR
+    d = c["d"]
+    ga, ta = TU.default_inference_args(f_maps=c["f_maps"], num_levels=c["levels"], left_hemis_only=True,
+                                       num_groups=c["groups"])
+    s = TU.InferenceSession(ga, ta, _dev(), state_dict=sd_from_npz(d), passes=3)
+    step = TR.TrainStep(s.engine, s.model.head.tail(s.engine), c["loss_names"], c["loss_weights"], d["weights_ce"], c["all_samples"],
+                        max_surf_distance=c["max_dist"], bias_field_log_type="l2" if c["bias_l2"] else "l1",
+                        lr=c["lr"], weight_decay=c["wd"], betas=(c["b1"], c["b2"]), eps=c["eps"],
+                        clip_max_norm=c["clip"] if clip is None else clip, scaler=scaler)
+    target = {k[7:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("target/")}
+    xs = [torch.from_numpy(d["x%d" % i]) for i in range(c["n_samples"])]
+    samples = [{"bias_field_log": torch.from_numpy(d["bias_field_log%d" % i]),
+                "high_res_residual": torch.from_numpy(d["high_res_residual%d" % i])} for i in range(c["n_samples"])]
+    return step, xs, target, samples
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(1e-12, np.abs(b).max()))
+
+
+def test_training_iteration_vs_reference_golden():
+    """Loss dictionary, every parameter gradient, the per-parameter clipping norms and the parameters after one AdamW
+    step, for two augmented samples of a 3-level net with the full demo head set (clamped distance head included)."""
+    c = load_case()
+    d = c["d"]
+    step, xs, target, samples = _build(c)
+    loss_dict, total, grads = step.loss_and_grads(xs, target, samples)
+    assert list(loss_dict.keys()) == ["loss_" + n for n in c["loss_names"]]
+    for k, v in loss_dict.items():
+        ref = float(d["loss/" + k])
+        assert abs(v - ref) <= 1e-4 * max(abs(ref), 1e-3), (k, v, ref)            # fp32 forward, fp64 reduction
+    assert abs(total - float(d["loss_total"])) <= 1e-4 * float(d["loss_total"])
+    assert set(grads.keys()) == set(c["names"])
+    worst = {k: _rel(grads[k].reshape(d["grad/" + k].shape).cpu().numpy(), d["grad/" + k]) for k in c["names"]}
+    print("max rel grad err vs reference fp64: %.2e (%s)" % (max(worst.values()), max(worst, key=worst.get)))
+    # |.|-type losses have sign() gradients: a voxel whose residual rounds across zero in fp32 flips a whole 1/N
+    # contribution, so the tolerance is looser than for the smooth backbone test (5e-4)
+    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    assert not bad, bad
+    before = {k: v.clone() for k, v in step.parameters().items()}
+    mine = {k: grads[k].double().cpu() for k in c["names"]}
+    stepped, norms = step.apply(grads)
+    assert stepped and step.t == 1
+    assert np.allclose(norms, d["clip_norms"], rtol=2e-3, atol=1e-7)
+    after = step.parameters()
+    clipped, _ = T.clip_gradients(mine, c["clip"])
+    for k in c["names"]:
+        ref_delta = d["after/" + k] - d["sd/" + k].astype(np.float64)
+        got_delta = (after[k].double() - before[k].double()).reshape(ref_delta.shape).cpu().numpy()
+        # step 1 of Adam moves every weight by lr * g/(|g| + eps): ill-conditioned where |g| ~ eps = 1e-8, so the
+        # reference's move is compared where its clipped gradient is well above eps ...
+        well = np.abs(d["clipped/" + k]) > 1e-6
+        assert np.abs(got_delta - ref_delta)[well].max(initial=0.0) <= 2e-2 * c["lr"], k
+        # ... and everywhere against the oracle's AdamW applied to THIS path's gradient (clip coefficient, lr, weight
+        # decay and bias corrections wired as in the reference), to fp32 rounding of the parameter
+        p0 = before[k].double().cpu()
+        p1, _, _ = T.adamw_step(p0, clipped[k].reshape(p0.shape), torch.zeros_like(p0), torch.zeros_like(p0), 1, c["lr"],
+                                c["b1"], c["b2"], c["eps"], c["wd"])
+        assert float((after[k].double().cpu() - p1).abs().max()) <= 2e-3 * c["lr"] + 2e-7 * float(p0.abs().max()), k
+    # the next forward must see the new weights (packed-weight caches dropped)
+    l2, total2, _ = step.loss_and_grads(xs, target, samples)
+    assert total2 != total
+
+
+def test_losses_match_oracle_on_random_heads():
+    """The loss kernels alone: values and d/d(raw) against torch autograd of the restated criterion in float64, on
+    random head outputs (no network), with weights, the bias-field mask, the distance clamp and an l1 bias loss."""
+    from brainfm_amd import _lib as L
+    c = load_case()
+    d = c["d"]
+    step, xs, target, samples = _build(c)
+    step.bias_l2 = 0
+    dims = tuple(xs[0].shape[-3:])
+    nvox = dims[0] * dims[1] * dims[2]
+    tail = step.tail
+    g = torch.Generator().manual_seed(5)
+    raw = torch.randn((nvox, tail.n_out), generator=g) * 1.5
+    raw_d = raw.to(_dev())
+    dRaw = torch.zeros_like(raw_d)
+    vals = torch.zeros(4 * len(step.loss_names) + 2 * tail.n_out + 8, dtype=torch.float64, device=_dev())
+    slots, _ = step._sample_losses(raw_d, dims, target, samples[0], dRaw, vals, 1.0)
+    got = step._finish_losses([(slots, vals)], nvox)
+    # oracle: same raw values as NCDHW head outputs, float64 autograd
+    r64 = raw.double().requires_grad_(True)
+    out = {}
+    for task, (r0, n) in tail.row_of.items():
+        out[task] = r64[:, r0:r0 + n].t().reshape((1, n) + dims)
+    out = T.processors(out, c["max_dist"])
+    t64 = {k: v.double() for k, v in target.items()}
+    s64 = {k: v.double() for k, v in samples[0].items()}
+    wce = torch.from_numpy(d["weights_ce"]).double()
+    ld = T.multi_criterion([out], t64, [s64], c["loss_names"], wce, c["all_samples"], bias_l2=False)
+    tot = sum(ld[k] * c["loss_weights"][k] for k in ld)
+    tot.backward()
+    for k, v in ld.items():
+        v = float(v.detach())
+        assert abs(got[k] - v) <= 2e-6 * max(abs(v), 1e-3), (k, got[k], v)
+    ref = r64.grad.numpy()
+    err = np.abs(dRaw.cpu().numpy().astype(np.float64) - ref)
+    # sign() gradients can flip only where the fp32 residual is exactly at a rounding boundary: allow a handful
+    tol = 1e-5 * np.abs(ref).max()
+    assert (err > tol).mean() < 1e-4, ((err > tol).sum(), err.max(), np.abs(ref).max())
+
+
+def test_adamw_kernel_matches_torch_optim():
+    """bfm_adamw_step over three steps against torch.optim.AdamW (the reference's optimiser, Trainer/models/__init__.py
+    :362-366) on the same device."""
+    from brainfm_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(10007, generator=g)
+    p_ref = torch.nn.Parameter(p0.clone().to(_dev()))
+    opt = torch.optim.AdamW([p_ref], lr=3e-3, weight_decay=0.1, betas=(0.9, 0.999), eps=1e-8)
+    p = p0.clone().to(_dev())
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    for t in range(1, 4):
+        gr = torch.randn(10007, generator=g).to(_dev()) * (10.0 ** (t - 3))
+        p_ref.grad = gr.clone()
+        opt.step()
+        L.check(lib.bfm_adamw_step(L.ptr(p), L.ptr(gr), L.ptr(m), L.ptr(v), p.numel(), 3e-3, 0.9, 0.999, 1e-8, 0.1, t, 1.0,
+                                   L.stream_ptr()), "adamw")
+        assert float((p - p_ref.detach()).abs().max()) <= 2e-6, t
+
+
+def test_loss_scaler_skips_nonfinite_and_unscales():
+    """GradScaler semantics: scaled backward gives the same update as the unscaled one (power-of-two scale), an inf
+    gradient skips the step and halves the scale."""
+    from brainfm_amd import train as TR
+    c = load_case()
+    a, xs, target, samples = _build(c)
+    b, _, _, _ = _build(c, scaler=TR.LossScaler(init_scale=1024.0, growth_interval=1))
+    la, ta, ga = a.loss_and_grads(xs, target, samples)
+    lb, tb, gb = b.loss_and_grads(xs, target, samples)
+    assert ta == tb
+    k = "backbone.decoders.1.basic_module.SingleConv2.conv.weight"
+    assert _rel((gb[k] / 1024.0).cpu().numpy(), ga[k].cpu().numpy()) <= 1e-5
+    a.apply(ga)
+    ok, _ = b.apply(gb)
+    assert ok and b.scaler.scale == 2048.0                       # growth_interval = 1 clean step
+    pa, pb = a.parameters(), b.parameters()
+    for key in pa:
+        assert float((pa[key] - pb[key]).abs().max()) <= 2e-2 * c["lr"], key
+    _, _, gb = b.loss_and_grads(xs, target, samples)
+    gb[k][0, 0, 0, 0, 0] = float("inf")
+    before = b.parameters()[k].clone()
+    ok, _ = b.apply(gb)
+    assert not ok and b.scaler.scale == 1024.0 and b.t == 1
+    assert torch.equal(before, b.parameters()[k])

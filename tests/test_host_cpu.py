@@ -291,3 +291,66 @@ def test_volume_io_nifti_mgh_roundtrip_and_format_fields(tmp_path):
     got, a2 = V.MRIread(f)
     assert np.array_equal(got.reshape(-1, order="F"), np.arange(8.0))
     assert np.allclose(a2, [[-1, 0, 0, 1], [0, 0, 1, -1], [0, -1, 0, 1], [0, 0, 0, 1]])
+
+
+def _allreduce_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from brainfm_amd import train as TR
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = {"a": torch.randn(3, 5, generator=g), "b": torch.randn(7, generator=g), "c": torch.randn(2, 2, 2, generator=g)}
+    TR.allreduce_mean_(grads)
+    if rank == 0:
+        q.put({k: v.numpy() for k, v in grads.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_two_ranks_is_the_mean():
+    """N2 multi-GPU: the flat-bucket gradient all-reduce (DDP's averaging) over 2 gloo ranks."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_allreduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = {}
+    for rank in range(2):
+        g = torch.Generator().manual_seed(100 + rank)
+        for k, shp in (("a", (3, 5)), ("b", (7,)), ("c", (2, 2, 2))):
+            exp[k] = exp.get(k, 0) + torch.randn(*shp, generator=g) / 2
+    for k in exp:
+        assert np.allclose(res[k], exp[k].numpy(), atol=1e-7), k
+
+
+def test_loss_scaler_and_cosine_schedule_host_logic():
+    from brainfm_amd import train as TR
+    s = TR.LossScaler(init_scale=8.0, growth_interval=2)
+    s.update(False)
+    assert s.scale == 8.0
+    s.update(False)
+    assert s.scale == 16.0
+    s.update(True)
+    assert s.scale == 8.0
+    s.update(False)
+    s.update(True)                                  # an inf resets the clean-step counter
+    s.update(False)
+    assert s.scale == 4.0
+    off = TR.LossScaler(enabled=False)
+    off.update(True)
+    assert off.scale == 1.0
+    # utils/misc.py:1265-1276 on a hand-computed case: 2 epochs x 4 iterations, 1 warm-up epoch
+    sch = TR.cosine_scheduler(1.0, 0.0, 2, 4, warmup_epochs=1)
+    assert len(sch) == 8
+    assert np.allclose(sch[:4], [0.0, 1 / 3, 2 / 3, 1.0])
+    assert np.allclose(sch[4:], 0.5 * (1 + np.cos(np.pi * np.arange(4) / 4)))
+    import pytest
+    from brainfm_amd import _lib as L
+    with pytest.raises(L.BfmError):
+        TR.TrainStep(None, None, ["contrastive"], {}, [1.0], 1)
