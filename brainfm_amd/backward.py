@@ -85,9 +85,16 @@ def train_single_conv(eng, ly, A, dims, B=None, lo_dims=None):
 def _dgrad_layer(eng, ly):
     """The transposed, tap-mirrored weights of `ly` as a layer of their own: conv(dP, W') = d(loss)/d(conv input)."""
     dg = _Layer()
-    dg.name, dg.cin, dg.cout, dg.groups = ly.name + "[dgrad]", ly.cout, ly.cin, 1
     dg.gamma, dg.beta = None, None
-    dg.w_raw = ly.w_raw.permute(1, 0, 2, 3, 4).flip(2, 3, 4).contiguous()
+    w = ly.w_raw.permute(1, 0, 2, 3, 4).flip(2, 3, 4)
+    cout = ly.cin
+    if ly.cin % 64 and ly.cout % 16 == 0:
+        # the matrix-core conv needs Cout % 64 == 0: zero output channels are cheaper than the direct kernel (level 0:
+        # 64 -> 32 at 128^3 took 170 ms direct, 2 ms padded to 64 -> 64; the one-channel stem 17 ms -> 1 ms)
+        cout = (ly.cin + 63) // 64 * 64
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, 0, 0, cout - ly.cin))
+    dg.name, dg.cin, dg.cout, dg.groups = ly.name + "[dgrad]", ly.cout, cout, 1
+    dg.w_raw = w.contiguous()
     dg.kind, dg.wpacked, dg.wexp, dg.packs, dg.skip = None, None, 0, {}, None
     return dg
 
@@ -125,17 +132,19 @@ def backward_single_conv(eng, t, dY, need_input_grad=True):
     ones = torch.ones(ly.cout, dtype=torch.float32, device=dev)
     zeros = torch.zeros(ly.cout, dtype=torch.float32, device=dev)
     bnd = torch.maximum(dP.max(), -dP.min()).reshape(1).to(torch.float32)
-    dXn = torch.empty((D, H, W, ly.cin), dtype=torch.float32, device=dev)
-    if ly.cout % 16 == 0 and ly.cin % 64 == 0:
-        cfg = (C.c_int * 8)(*list(eng._plan(ly.cout, ly.cin, t.dims, False)))
+    dXn = torch.empty((D, H, W, dg.cout), dtype=torch.float32, device=dev)
+    if ly.cout % 16 == 0 and dg.cout % 64 == 0:
+        cfg = (C.c_int * 8)(*list(eng._plan(ly.cout, dg.cout, t.dims, False)))
         if cfg[6] > 2:
             cfg[6] = 0
-        wsc = lib.bfm_conv3x3x3_mfma_workspace(ly.cout, ly.cin, D, H, W, cfg[5])
+        wsc = lib.bfm_conv3x3x3_mfma_workspace(ly.cout, dg.cout, D, H, W, cfg[5])
         ws2 = torch.empty(max(wsc, 256), dtype=torch.uint8, device=dev)
         eng._pack(dg, True, cfg[6])
         L.check(lib.bfm_conv3x3x3_mfma_ex(L.ptr(dP), ly.cout, None, 0, D, H, W, None, L.ptr(ones), L.ptr(zeros),
-                                          L.ptr(bnd), 1, L.ptr(dg.wpacked), dg.wexp, ly.cin, 1.0, eng.passes, cfg,
+                                          L.ptr(bnd), 1, L.ptr(dg.wpacked), dg.wexp, dg.cout, 1.0, eng.passes, cfg,
                                           L.ptr(dXn), L.ptr(ws2), ws2.numel(), None, st), "conv dgrad " + ly.name)
+        if dg.cout != ly.cin:
+            dXn = dXn[..., :ly.cin].contiguous()
     else:
         eng._pack(dg, False)
         L.check(lib.bfm_conv3x3x3_direct(L.ptr(dP), ly.cout, None, 0, D, H, W, None, L.ptr(ones), L.ptr(zeros),

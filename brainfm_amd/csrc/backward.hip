@@ -46,107 +46,172 @@ struct WgParams {
     int rows_per_split;               // (z,y) rows per split
 };
 
-// One wave per (row split, (kd,kh), 32x32 block of (co, ci)); the three kw taps share the dP fragment.
 // v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain): A[i=co][k] = dP[voxel k][co], B[k][j=ci] = Xn[voxel k + tap][ci],
-// K = two x-neighbouring voxels per step -- both fragments are plain coalesced channel-last reads.
-__global__ void __launch_bounds__(64) conv_wgrad_kernel(const WgParams p) {
-    const int lane = threadIdx.x;
-    const int l32 = lane & 31, lh = lane >> 5;
-    const int split = blockIdx.x;
-    const int kdh = blockIdx.y;
-    const int kd = kdh / 3, kh = kdh - kd * 3;
+// K = two x-neighbouring voxels per step.
+// LDS-tiled persistent version for Cout % 64 == 0, CA % 32 == 0, Cin % 32 == 0 (every layer of the full-width net but
+// the stem).  A workgroup (8 waves) owns a 64 (co) x 32 (ci) x 27 (tap) block of dW and walks 4x4x16-voxel tiles of
+// the volume: dP tile [256][64] and the GroupNorm-applied input tile with its halo [6*6*18][32] are staged once in LDS
+// (145 KB), then wave (cob, tg) runs 128 K-steps (two x-neighbouring voxels each) x 7 taps of v_mfma_f32_32x32x2_f32
+// with both fragments read conflict-free from LDS (32 consecutive floats per half wave).  Staging is ~2 % of a tile's
+// MFMA time, so a single buffer with two barriers per tile is enough.  Accumulators stay in registers across all of a
+// workgroup's tiles; one partial per workgroup column (fixed order -> bit-reproducible).
+constexpr int WT_Z = 4, WT_Y = 4, WT_X = 16;
+constexpr int WH_Z = WT_Z + 2, WH_Y = WT_Y + 2, WH_X = WT_X + 2;
+constexpr int WT_VOX = WT_Z * WT_Y * WT_X;                 // 256
+constexpr int WH_VOX = WH_Z * WH_Y * WH_X;                 // 648
+constexpr int WG2_THREADS = 512;
+constexpr int WG2_LDS = (WT_VOX * 64 + WH_VOX * 32) * (int)sizeof(float);
+
+struct Wg2Params {
+    WgParams b;
+    int nbz, nby, nbx, ntiles;
+};
+
+__global__ void __launch_bounds__(WG2_THREADS) conv_wgrad_tiled_kernel(const Wg2Params q) {
+    extern __shared__ float wg_lds[];
+    const WgParams& p = q.b;
+    float* dPs = wg_lds;                                   // [256][64]
+    float* Xs = wg_lds + WT_VOX * 64;                      // [648][32]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l32 = lane & 31, lh = lane >> 5;
+    const int cob = wave & 1, tg = wave >> 1;              // taps [7 tg, 7 tg + 7) (the last group has 6)
+    const int t0 = tg * 7, nt = tg == 3 ? 6 : 7;
     const int Cin = p.CA + p.CB;
-    const int nci = Cin >> 5;
-    const int cob = blockIdx.z / nci, cib = blockIdx.z - cob * nci;
-    const int co = cob * 32 + l32;                         // A-fragment row of this lane
-    const int ci = cib * 32 + l32;                         // B-fragment column of this lane
-    const bool fromB = ci >= p.CA;
-    const float sc = p.scale[ci], sh = p.shift[ci];
-
-    floatx16 acc[3];
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 64;
+    const bool fromB = ci0 >= p.CA;
+    int toff[7];
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int j = 0; j < 7; ++j) {
+        const int t = min(t0 + j, 26);
+        const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+        toff[j] = ((kd * WH_Y + kh) * WH_X + kw) * 32;
+    }
+    floatx16 acc[7];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
-    const int nrows = p.D * p.H;
-    const int r0 = split * p.rows_per_split;
-    const int r1 = min(nrows, r0 + p.rows_per_split);
-    for (int r = r0; r < r1; ++r) {
-        const int z = r / p.H, y = r - z * p.H;
-        const int zz = z + kd - 1, yy = y + kh - 1;
-        const bool row_ok = zz >= 0 && zz < p.D && yy >= 0 && yy < p.H;    // wave-uniform
-        if (!row_ok) continue;                                            // the whole input row is padding: adds 0
-        const float* dprow = p.dP + ((int64_t)(z * p.H + y) * p.W) * p.Cout + co;
-        const float* xrow;
-        int xstride;
-        if (!fromB) {
-            xrow = p.A + ((int64_t)(zz * p.H + yy) * p.W) * p.CA + ci;
-            xstride = p.CA;
-        } else {
-            xrow = p.B + ((int64_t)(p.up.mapD[zz] * p.up.h + p.up.mapH[yy]) * p.up.w) * p.CB + (ci - p.CA);
-            xstride = p.CB;
+    // staging roles (512 threads): dP quad (tid & 15), input quad (tid & 7) are fixed per thread
+    const int xq = tid & 7;
+    const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + ci0 + xq * 4);
+    const float4 sh4 = *reinterpret_cast<const float4*>(p.shift + ci0 + xq * 4);
+
+    for (int tile = blockIdx.x; tile < q.ntiles; tile += gridDim.x) {
+        const int bx = tile % q.nbx;
+        const int t2 = tile / q.nbx;
+        const int by = t2 % q.nby, bz = t2 / q.nby;
+        const int z0 = bz * WT_Z, y0 = by * WT_Y, x0 = bx * WT_X;
+        __syncthreads();                                   // the previous tile's reads are done
+        for (int i = tid; i < WT_VOX * 16; i += WG2_THREADS) {
+            const int v = i >> 4, c4 = i & 15;
+            const int zl = v >> 6, yl = (v >> 4) & 3, xl = v & 15;
+            const int z = z0 + zl, y = y0 + yl, x = x0 + xl;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (z < p.D && y < p.H && x < p.W)
+                val = *reinterpret_cast<const float4*>(p.dP + ((int64_t)(z * p.H + y) * p.W + x) * p.Cout + co0 + c4 * 4);
+            *reinterpret_cast<float4*>(dPs + v * 64 + c4 * 4) = val;
         }
-        for (int x = 0; x < p.W; x += 2) {
-            const int xv = x + lh;                                        // this lane's voxel of the K pair
-            const float a = xv < p.W ? dprow[(int64_t)xv * p.Cout] : 0.f;
+        for (int i = tid; i < WH_VOX * 8; i += WG2_THREADS) {
+            const int hv = i >> 3;
+            const int hz = hv / (WH_Y * WH_X);
+            const int r = hv - hz * (WH_Y * WH_X);
+            const int hy = r / WH_X, hx = r - hy * WH_X;
+            const int zz = z0 + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (zz >= 0 && zz < p.D && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
+                const float* src = fromB
+                    ? p.B + ((int64_t)(p.up.mapD[zz] * p.up.h + p.up.mapH[yy]) * p.up.w + p.up.mapW[xx]) * p.CB + (ci0 - p.CA)
+                    : p.A + ((int64_t)(zz * p.H + yy) * p.W + xx) * p.CA + ci0;
+                const float4 x4 = *reinterpret_cast<const float4*>(src + xq * 4);
+                val = make_float4(fmaf(x4.x, sc4.x, sh4.x), fmaf(x4.y, sc4.y, sh4.y), fmaf(x4.z, sc4.z, sh4.z),
+                                  fmaf(x4.w, sc4.w, sh4.w));
+            }
+            *reinterpret_cast<float4*>(Xs + hv * 32 + xq * 4) = val;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < WT_Z * WT_Y; ++r) {
+            const int zl = r >> 2, yl = r & 3;
+            const float* arow = dPs + (r * WT_X + lh) * 64 + cob * 32 + l32;
+            const float* brow = Xs + ((zl * WH_Y + yl) * WH_X + lh) * 32 + l32;
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int xx = xv + kw - 1;
-                float b = 0.f;
-                if (xv < p.W && xx >= 0 && xx < p.W) {
-                    const int xs = fromB ? p.up.mapW[xx] : xx;
-                    b = fmaf(xrow[(int64_t)xs * xstride], sc, sh);
+            for (int xp = 0; xp < WT_X / 2; ++xp) {
+                const float a = arow[xp * 2 * 64];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const float b = brow[xp * 2 * 32 + toff[j]];
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
                 }
-                acc[kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[kw], 0, 0, 0);
             }
         }
     }
-    float* out = p.part + (int64_t)split * p.Cout * Cin * 27;
+    float* out = p.part + (int64_t)blockIdx.x * p.Cout * Cin * 27;
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw)
+    for (int j = 0; j < 7; ++j) {
+        if (j >= nt) break;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int row = (i & 3) + 8 * (i >> 2) + 4 * lh;              // co within the block
-            out[((int64_t)(cob * 32 + row) * Cin + ci) * 27 + kdh * 3 + kw] = acc[kw][i];
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * lh;
+            out[((int64_t)(co0 + cob * 32 + row) * Cin + ci0 + l32) * 27 + t0 + j] = acc[j][i];
         }
+    }
 }
 
-// narrow inputs (the stem, Cin = 1): one block per (co, ci), threads stride over voxels, 27 taps each
-__global__ void __launch_bounds__(256) conv_wgrad_narrow_kernel(const WgParams p) {
+// Narrow layers (Cin or Cout not a multiple of 32: the stem of the full net, every layer of the 8/16-wide test nets) on
+// the same fp32 matrix core: dW as a [Cout] x [Cin*27] matrix, one wave per (voxel-row split, 32 rows, 32 columns);
+// the B fragment column of a lane is its own (ci, tap) pair, gathered straight from the (cached) input.
+__global__ void __launch_bounds__(64) conv_wgrad_cols_kernel(const WgParams p) {
+    const int lane = threadIdx.x, l32 = lane & 31, lh = lane >> 5;
     const int Cin = p.CA + p.CB;
-    const int co = blockIdx.x / Cin, ci = blockIdx.x - co * Cin;
+    const int ncol = Cin * 27;
+    const int co = blockIdx.y * 32 + l32;
+    const int col = blockIdx.z * 32 + l32;
+    const bool col_ok = col < ncol;
+    const int ci = col_ok ? col / 27 : 0;
+    const int tap = col_ok ? col - ci * 27 : 0;
+    const int kd = tap / 9 - 1, kh = (tap / 3) % 3 - 1, kw = tap % 3 - 1;
+    const bool fromB = ci >= p.CA;
     const float sc = p.scale[ci], sh = p.shift[ci];
-    double acc[27];
+    floatx16 acc;
 #pragma unroll
-    for (int t = 0; t < 27; ++t) acc[t] = 0.0;
-    const int64_t nvox = (int64_t)p.D * p.H * p.W;
-    for (int64_t v = threadIdx.x; v < nvox; v += 256) {
-        const int x = (int)(v % p.W);
-        const int64_t t2 = v / p.W;
-        const int y = (int)(t2 % p.H), z = (int)(t2 / p.H);
-        const float g = p.dP[v * p.Cout + co];
-#pragma unroll
-        for (int t = 0; t < 27; ++t) {
-            const int zz = z + t / 9 - 1, yy = y + (t / 3) % 3 - 1, xx = x + t % 3 - 1;
-            if (zz < 0 || zz >= p.D || yy < 0 || yy >= p.H || xx < 0 || xx >= p.W) continue;
-            const float xv = ci < p.CA ? p.A[((int64_t)(zz * p.H + yy) * p.W + xx) * p.CA + ci]
-                                       : p.B[((int64_t)(p.up.mapD[zz] * p.up.h + p.up.mapH[yy]) * p.up.w + p.up.mapW[xx]) * p.CB + (ci - p.CA)];
-            acc[t] += (double)g * (double)fmaf(xv, sc, sh);
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int nrows = p.D * p.H;
+    const int r0 = blockIdx.x * p.rows_per_split, r1 = min(nrows, r0 + p.rows_per_split);
+    for (int r = r0; r < r1; ++r) {
+        const int z = r / p.H, y = r - z * p.H;
+        const int zz = z + kd, yy = y + kh;
+        const bool row_ok = col_ok && zz >= 0 && zz < p.D && yy >= 0 && yy < p.H;
+        const float* dprow = p.dP + ((int64_t)(z * p.H + y) * p.W) * p.Cout + co;
+        const float* xrow = nullptr;
+        int xstride = 0;
+        if (row_ok) {
+            if (!fromB) {
+                xrow = p.A + ((int64_t)(zz * p.H + yy) * p.W) * p.CA + ci;
+                xstride = p.CA;
+            } else {
+                xrow = p.B + ((int64_t)(p.up.mapD[zz] * p.up.h + p.up.mapH[yy]) * p.up.w) * p.CB + (ci - p.CA);
+                xstride = p.CB;
+            }
+        }
+        for (int x = 0; x < p.W; x += 2) {
+            const int xv = x + lh;
+            const float a = (xv < p.W && co < p.Cout) ? dprow[(int64_t)xv * p.Cout] : 0.f;
+            const int xx = xv + kw;
+            float b = 0.f;
+            if (row_ok && xv < p.W && xx >= 0 && xx < p.W) {
+                const int xs = fromB ? p.up.mapW[xx] : xx;
+                b = fmaf(xrow[(int64_t)xs * xstride], sc, sh);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
     }
-    __shared__ double red[256];
+    float* out = p.part + (int64_t)blockIdx.x * p.Cout * ncol;
+    if (col_ok)
 #pragma unroll
-    for (int t = 0; t < 27; ++t) {
-        red[threadIdx.x] = acc[t];
-        __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-            __syncthreads();
+        for (int i = 0; i < 16; ++i) {
+            const int row = blockIdx.y * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
+            if (row < p.Cout) out[(int64_t)row * ncol + col] = acc[i];
         }
-        if (threadIdx.x == 0) p.part[((int64_t)co * Cin + ci) * 27 + t] = (float)red[0];
-        __syncthreads();
-    }
 }
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int S, int64_t n, float* __restrict__ dW) {
@@ -206,6 +271,81 @@ __global__ void __launch_bounds__(256) gn_bwd_partial_kernel(const GnbParams p, 
             part[((int64_t)blockIdx.x * C + c) * 2 + 1] = s2;
         }
         __syncthreads();
+    }
+}
+
+// the same partial sums with four channels per thread (C, CA, CB multiples of 4, C/4 <= 256) and four voxels in
+// flight: the scalar version above ran at 150 GB/s (one dependent fp64 chain and one 4-byte load per thread at a time)
+__global__ void __launch_bounds__(256) gn_bwd_partial4_kernel(const GnbParams p, int64_t vox_per_block,
+                                                              double* __restrict__ part) {
+    extern __shared__ double sm[];                        // [256][8]
+    const int C = p.CA + p.CB;
+    const int CQall = C >> 2;
+    const int t = threadIdx.x;
+    const int64_t nvox = (int64_t)p.D * p.H * p.W;
+    const int64_t v0 = (int64_t)blockIdx.x * vox_per_block, v1 = min(nvox, v0 + vox_per_block);
+    const int cpg = C / p.G;
+    for (int q0 = 0; q0 < CQall; q0 += 256) {             // channel chunks of 1024 (the deep decoder layers have 3072)
+        const int CQ = min(256, CQall - q0);
+        const int RP = 256 / CQ;
+        const int q = t % CQ, lane_v = t / CQ;
+        const int c = (q0 + q) * 4;
+        double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+        if (lane_v < RP) {
+            float mu[4], rs[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { mu[k] = p.mean[(c + k) / cpg]; rs[k] = p.rstd[(c + k) / cpg]; }
+            const bool fromB = c >= p.CA;
+            auto src = [&](int64_t v) -> const float* {
+                if (!fromB) return p.A + v * p.CA + c;
+                const int x = (int)(v % p.W);
+                const int64_t t2 = v / p.W;
+                const int y = (int)(t2 % p.H), z = (int)(t2 / p.H);
+                return p.B + ((int64_t)(p.up.mapD[z] * p.up.h + p.up.mapH[y]) * p.up.w + p.up.mapW[x]) * p.CB + (c - p.CA);
+            };
+            int64_t v = v0 + lane_v;
+            for (; v + 3 * (int64_t)RP < v1; v += 4 * (int64_t)RP) {
+                float4 xv[4], g[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    xv[u] = *reinterpret_cast<const float4*>(src(v + (int64_t)u * RP));
+                    g[u] = *reinterpret_cast<const float4*>(p.dXn + (v + (int64_t)u * RP) * C + c);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, gs[4] = {g[u].x, g[u].y, g[u].z, g[u].w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        s1[k] += (double)gs[k];
+                        s2[k] += (double)gs[k] * (double)((xs[k] - mu[k]) * rs[k]);
+                    }
+                }
+            }
+            for (; v < v1; v += RP) {
+                const float4 xv = *reinterpret_cast<const float4*>(src(v));
+                const float4 g = *reinterpret_cast<const float4*>(p.dXn + v * C + c);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, gs[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    s1[k] += (double)gs[k];
+                    s2[k] += (double)gs[k] * (double)((xs[k] - mu[k]) * rs[k]);
+                }
+            }
+        }
+        __syncthreads();                                  // the previous chunk's reads of sm are done
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { sm[t * 8 + 2 * k] = s1[k]; sm[t * 8 + 2 * k + 1] = s2[k]; }
+        __syncthreads();
+        if (t < CQ) {
+            for (int r = 1; r < RP; ++r)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s1[k] += sm[(r * CQ + t) * 8 + 2 * k]; s2[k] += sm[(r * CQ + t) * 8 + 2 * k + 1]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                part[((int64_t)blockIdx.x * C + c + k) * 2] = s1[k];
+                part[((int64_t)blockIdx.x * C + c + k) * 2 + 1] = s2[k];
+            }
+        }
     }
 }
 
@@ -319,15 +459,39 @@ extern "C" int bfm_lrelu_bwd(const float* dY, const float* Y, int64_t n, float s
     return bfm_launch_status();
 }
 
+namespace {
+struct WgPlan { int kind; int S; int rows_per_split; int nbz, nby, nbx, ntiles; };    // kind 0 tiled, 1 columns
+WgPlan wgrad_plan(int CA, int Cin, int Cout, int D, int H, int W) {
+    WgPlan pl{};
+    if (Cout % 64 == 0 && Cin % 32 == 0 && CA % 32 == 0) {
+        pl.kind = 0;
+        pl.nbz = bfm_cdiv(D, WT_Z); pl.nby = bfm_cdiv(H, WT_Y); pl.nbx = bfm_cdiv(W, WT_X);
+        pl.ntiles = pl.nbz * pl.nby * pl.nbx;
+        const int cols = (Cin / 32) * (Cout / 64);
+        int S = 512 / cols;                               // two full rounds of one workgroup per CU, never a third
+        if (S > pl.ntiles) S = pl.ntiles;
+        if (S < 1) S = 1;
+        const int per = bfm_cdiv(pl.ntiles, S);
+        pl.S = bfm_cdiv(pl.ntiles, per);                  // every workgroup gets `per` tiles, the last maybe fewer
+    } else {
+        pl.kind = 1;
+        const int nrows = D * H;
+        const int blocks = bfm_cdiv(Cout, 32) * bfm_cdiv(Cin * 27, 32);
+        int S = bfm_cdiv(2048, blocks);
+        if (S > nrows) S = nrows;
+        if (S < 1) S = 1;
+        pl.rows_per_split = bfm_cdiv(nrows, S);
+        pl.S = bfm_cdiv(nrows, pl.rows_per_split);
+    }
+    return pl;
+}
+}  // namespace
+
 extern "C" size_t bfm_conv3x3x3_wgrad_workspace(int Cin, int Cout, int D, int H, int W) {
     if (Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    if (Cin % 32 || Cout % 32) return (size_t)Cout * Cin * 27 * sizeof(float);
-    const int nrows = D * H;
-    const int blocks = 9 * (Cout / 32) * (Cin / 32);
-    int S = bfm_cdiv(2048, blocks);
-    if (S > nrows) S = nrows;
-    if (S < 1) S = 1;
-    return (size_t)S * Cout * Cin * 27 * sizeof(float);
+    // the split count does not depend on CA (only the kernel choice does): take the larger of the two plans
+    const WgPlan a = wgrad_plan(Cin, Cin, Cout, D, H, W), b = wgrad_plan(1, Cin, Cout, D, H, W);
+    return (size_t)(a.S > b.S ? a.S : b.S) * Cout * Cin * 27 * sizeof(float);
 }
 
 extern "C" int bfm_conv3x3x3_wgrad(const float* dP, int Cout, const float* A, int CA, const float* B, int CB, int D,
@@ -344,30 +508,37 @@ extern "C" int bfm_conv3x3x3_wgrad(const float* dP, int Cout, const float* A, in
     p.part = static_cast<float*>(workspace);
     hipStream_t st = bfm_s(stream);
     const int64_t n = (int64_t)Cout * Cin * 27;
-    if (Cin % 32 || Cout % 32 || CA % 32) {                      // narrow layers (the stem): double accumulation, one split
-        p.S = 1;
-        hipLaunchKernelGGL(conv_wgrad_narrow_kernel, dim3(Cout * Cin), dim3(256), 0, st, p);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(n)), dim3(256), 0, st, p.part, 1, n, dW);
-        return bfm_launch_status();
+    const WgPlan pl = wgrad_plan(CA, Cin, Cout, D, H, W);
+    p.S = pl.S;
+    if (pl.kind == 0) {
+        Wg2Params q{};
+        q.b = p; q.nbz = pl.nbz; q.nby = pl.nby; q.nbx = pl.nbx; q.ntiles = pl.ntiles;
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_tiled_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, WG2_LDS) != hipSuccess)
+                return BFM_E_LAUNCH;
+            attr = true;
+        }
+        hipLaunchKernelGGL(conv_wgrad_tiled_kernel, dim3(pl.S, Cin / 32, Cout / 64), dim3(WG2_THREADS), WG2_LDS, st, q);
+    } else {
+        p.rows_per_split = pl.rows_per_split;
+        hipLaunchKernelGGL(conv_wgrad_cols_kernel, dim3(pl.S, bfm_cdiv(Cout, 32), bfm_cdiv(Cin * 27, 32)), dim3(64), 0, st, p);
     }
-    const int nrows = D * H;
-    const int blocks = 9 * (Cout / 32) * (Cin / 32);
-    int S = bfm_cdiv(2048, blocks);
-    if (S > nrows) S = nrows;
-    if (S < 1) S = 1;
-    p.rows_per_split = bfm_cdiv(nrows, S);
-    p.S = bfm_cdiv(nrows, p.rows_per_split);
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(p.S, 9, (Cout / 32) * (Cin / 32)), dim3(64), 0, st, p);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(n)), dim3(256), 0, st, p.part, p.S, n, dW);
     return bfm_launch_status();
 }
 
-extern "C" size_t bfm_gn_bwd_workspace(int C, int D, int H, int W) {
-    const int64_t nvox = (int64_t)D * H * W;
-    int64_t nb = bfm_cdiv64(nvox, 2048);
+// partial blocks of the GroupNorm backward sums: 16 voxels or more each, at most 1024 (the deep levels have 64..4096
+// voxels with up to 3072 channels: one or two blocks of 2048 voxels took 3.4 / 7.2 ms there)
+static int64_t gnb_blocks(int64_t nvox) {
+    int64_t nb = bfm_cdiv64(nvox, 16);
     if (nb > 1024) nb = 1024;
-    if (nb < 1) nb = 1;
-    return (size_t)nb * C * 2 * sizeof(double) + 256;
+    return nb < 1 ? 1 : nb;
+}
+
+extern "C" size_t bfm_gn_bwd_workspace(int C, int D, int H, int W) {
+    return (size_t)gnb_blocks((int64_t)D * H * W) * C * 2 * sizeof(double) + 256;
 }
 
 // dXn [D][H][W][CA+CB] -> dA [D][H][W][CA], dB [d][h][w][CB] (when CB > 0), dgamma/dbeta [CA+CB].
@@ -390,9 +561,7 @@ extern "C" int bfm_gn_bwd(const float* dXn, const float* A, int CA, const float*
     p.D = D; p.H = H; p.W = W; p.G = G; p.mean = mean; p.rstd = rstd; p.gamma = gamma;
     hipStream_t st = bfm_s(stream);
     const int64_t nvox = (int64_t)D * H * W;
-    int64_t nb = bfm_cdiv64(nvox, 2048);
-    if (nb > 1024) nb = 1024;
-    if (nb < 1) nb = 1;
+    int64_t nb = gnb_blocks(nvox);
     const int64_t vpb = bfm_cdiv64(nvox, nb);
     nb = bfm_cdiv64(nvox, vpb);
     char* ws = static_cast<char*>(workspace);
@@ -400,7 +569,10 @@ extern "C" int bfm_gn_bwd(const float* dXn, const float* A, int CA, const float*
     float* m1 = reinterpret_cast<float*>(ws + (size_t)nb * C * 16);
     float* m2 = m1 + 32;
     if (G > 32) return BFM_E_SHAPE;
-    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3((unsigned)nb), dim3(256), 256 * 16, st, p, vpb, part);
+    if (CA % 4 == 0 && CB % 4 == 0)
+        hipLaunchKernelGGL(gn_bwd_partial4_kernel, dim3((unsigned)nb), dim3(256), 256 * 64, st, p, vpb, part);
+    else
+        hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3((unsigned)nb), dim3(256), 256 * 16, st, p, vpb, part);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), (size_t)C * 16, st, part, (int)nb, C, G, (double)nvox,
                        gamma, dgamma, dbeta, m1, m2);
     hipLaunchKernelGGL(gn_bwd_apply_a_kernel, dim3(grid_for(nvox * CA)), dim3(256), 0, st, p, m1, m2, dA);

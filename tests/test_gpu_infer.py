@@ -501,5 +501,8 @@ def test_backbone_backward_vs_fp64_autograd(f_maps, levels, dims):
         got = grads[k].reshape(ref.shape).cpu().numpy().astype(np.float64)
         worst[k] = float(np.abs(got - ref).max() / max(1e-9, np.abs(ref).max()))
     print("max rel grad err vs fp64 %.2e over %d tensors" % (max(worst.values()), len(worst)))
-    bad = {k: v for k, v in worst.items() if v > 5e-4}       # the one-channel stem GroupNorm sums cancel the most
+    # the one-channel stem GroupNorm's dgamma is a sum over all voxels that cancels to ~1e-3 of its terms: torch's own
+    # fp32 autograd is 7e-3 off there; everything else stays an order of magnitude tighter
+    stem = "backbone.encoders.0.basic_module.SingleConv1.groupnorm."
+    bad = {k: v for k, v in worst.items() if v > (3e-3 if k.startswith(stem) else 5e-4)}
     assert not bad, bad
