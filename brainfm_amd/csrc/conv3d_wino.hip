@@ -308,9 +308,71 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
     float* m = reinterpret_cast<float*>(lds);                      // [4 positions][128 accumulator rows][MLD]
     float* mw = m + (pos * 128 + khalf * 4) * MLD + l32;           // this lane's write base
     const int col = tid & 31, row0 = tid >> 5;
+    // Interior boxes (all of a 160^3 tile but its last slabs) take a path without per-item index arithmetic: the
+    // thread's 16 pairs are q = row0 + 8 it, and with power-of-two box sides the coordinates of q split into a
+    // per-thread part (from row0, computed once) and a wave-uniform part (from it, on the scalar unit); the address
+    // is then uniform base + one 32-bit lane offset.  The general path spent ~1600 of the epilogue's 3200 vector
+    // instructions per box on q -> (d,h,j) -> address chains, 480 of them quarter-rate 32/64-bit multiplies -- more
+    // vector work than the four K-chunks of a 64-channel layer's main loop.
+    const bool interior = z0 + p.TD <= p.D && y0 + p.TH <= p.H && x0 + p.TW <= p.W;      // wave-uniform
+    const int th_shift = p.thp_shift - p.pw_shift;
+    unsigned off_t = 0;
+    int un0 = 0, un3 = 0;
+    if (interior) {
+        const int jt = p.pw_shift >= 3 ? row0 : (row0 & ((1 << p.pw_shift) - 1));
+        const int rt = p.pw_shift >= 3 ? 0 : (row0 >> p.pw_shift);
+        const int h_t = rt & ((1 << th_shift) - 1), d_t = rt >> th_shift;
+        off_t = (unsigned)(((d_t * p.H + h_t) * p.W + 2 * jt) * p.Cout + col);
+        un0 = row_unperm(row0);                                    // accumulator row of pair (q & 31) = row0
+        un3 = row_unperm(row0 + 24);                               //                              = row0 + 24
+    }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         __syncthreads();                                           // A planes (or the previous round) fully consumed
+        float fs = 0.f, fq = 0.f, fmn = INFINITY, fmx = -INFINITY;   // this thread's column, its 16 pairs (<= 32 values)
+        if (interior) {
+            float* ob = p.out + nt * 64 + nb * 32;
+            float prev0[16], prev1[16];
+            if (p.accum) {
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int qu = 8 * it;
+                    const int j_u = qu & ((1 << p.pw_shift) - 1), r_u = qu >> p.pw_shift;
+                    const int h_u = r_u & ((1 << th_shift) - 1), d_u = r_u >> th_shift;
+                    const float* o = ob + (((int64_t)(z0 + d_u) * p.H + (y0 + h_u)) * p.W + x0 + 2 * j_u) * p.Cout;
+                    prev0[it] = o[off_t];
+                    prev1[it] = o[off_t + (unsigned)p.Cout];
+                }
+            }
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    mw[(mb * 32 + (i >> 2) * 8 + (i & 3)) * MLD] = acc[mb][nb][i];
+            __syncthreads();
+            const float* mr = m + col;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int qu = 8 * it;
+                const int j_u = qu & ((1 << p.pw_shift) - 1), r_u = qu >> p.pw_shift;
+                const int h_u = r_u & ((1 << th_shift) - 1), d_u = r_u >> th_shift;
+                float* o = ob + (((int64_t)(z0 + d_u) * p.H + (y0 + h_u)) * p.W + x0 + 2 * j_u) * p.Cout;
+                // accumulator row holding pair q: (q & ~31) + row_unperm(q & 31), q & 31 = row0 + 8 (it & 3)
+                const int sub = it & 3;
+                const int qr = (qu & ~31) + (sub == 0 ? un0 : sub == 1 ? row0 + 8 + 12 : sub == 2 ? row0 + 16 - 12 : un3);
+                const float m0 = mr[(0 * 128 + qr) * MLD], m1 = mr[(1 * 128 + qr) * MLD];
+                const float m2 = mr[(2 * 128 + qr) * MLD], m3 = mr[(3 * 128 + qr) * MLD];
+                float y0v = ((m0 + m1) + m2) * dq;
+                float y1v = ((m1 - m2) - m3) * dq;
+                if (p.accum) { y0v = y0v + prev0[it]; y1v = y1v + prev1[it]; }
+                y0v = y0v >= 0.f ? y0v : y0v * p.slope;
+                y1v = y1v >= 0.f ? y1v : y1v * p.slope;
+                o[off_t] = y0v;
+                o[off_t + (unsigned)p.Cout] = y1v;
+                fs += y0v; fq = fmaf(y0v, y0v, fq); fmn = fminf(fmn, y0v); fmx = fmaxf(fmx, y0v);
+                fs += y1v; fq = fmaf(y1v, y1v, fq); fmn = fminf(fmn, y1v); fmx = fmaxf(fmx, y1v);
+            }
+        } else {
         // accumulate mode: what `out` holds is fetched now, so that its latency hides under the LDS exchange
         float prev0[16], prev1[16];
         if (p.accum) {
@@ -335,7 +397,6 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
             for (int i = 0; i < 16; ++i)                            // accumulator row order (compile-time offsets);
                 mw[(mb * 32 + (i >> 2) * 8 + (i & 3)) * MLD] = acc[mb][nb][i];   // the reader undoes row_perm
         __syncthreads();
-        float fs = 0.f, fq = 0.f, fmn = INFINITY, fmx = -INFINITY;   // this thread's column, its 16 pairs (<= 32 values)
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int q = row0 + 8 * it;
@@ -359,6 +420,7 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
                 o[p.Cout] = y1v;
                 fs += y1v; fq = fmaf(y1v, y1v, fq); fmn = fminf(fmn, y1v); fmx = fmaxf(fmx, y1v);
             }
+        }
         }
         if (p.rsum != nullptr) {
             // moment row of this tile: fold the 8 row groups of every column in fixed order (scratch behind m)
