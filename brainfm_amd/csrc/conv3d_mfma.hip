@@ -1335,9 +1335,7 @@ extern "C" int bfm_conv3x3x3_mfma_ex(const float* A, int CA, const float* B, int
         return BFM_E_SHAPE;                                   // the staging path keeps 32-bit element offsets
     unsigned gx = (unsigned)(p.nMt * p.NT);
     if (hp.ver == 1) {
-        int cap = 256;                                         // one 8-wave workgroup per CU
-        const char* e = getenv("BFM_CONV_WS_GRID");
-        if (e && atoi(e) > 0) cap = atoi(e);
+        const int cap = 256;                                   // one 8-wave workgroup per CU
         if ((int)gx > cap) gx = (unsigned)cap;
     }
     dim3 grid(gx, (unsigned)p.splitk);

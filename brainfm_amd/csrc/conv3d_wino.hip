@@ -45,7 +45,6 @@ struct WinoParams {
     int pw_shift, thp_shift;         // log2(PW), log2(TH*PW)
     int nTy, nTx, nMt, NT, KCN;
     int npos_lds, plane_stride;      // (TD+2)*HT*PW positions; bytes per plane
-    int dbg;                         // experiments only (BFM_WINO_DBG)
     double *rsum, *rsq;              // optional output-moment rows [nMt][Cout] (see conv3d_mfma.hip), 4-wave kernel only
     float *rmn, *rmx;
     int ws_buf_bytes;                // persistent kernel: bytes per LDS buffer
@@ -1128,7 +1127,6 @@ extern "C" int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W
     p.scale = scale; p.shift = shift; p.bound = bound; p.G = G;
     p.wp = static_cast<const uint4*>(wpacked);
     p.wexp = wexp; p.Cout = Cout; p.slope = slope; p.out = out; p.accum = accumulate ? 1 : 0;
-    { const char* e = getenv("BFM_WINO_DBG"); p.dbg = e ? atoi(e) : 0; }
     if (!choose_box(D, H, W, npl, p.TD, p.TH, p.TW)) return BFM_E_SHAPE;
     p.HT = p.TH + 2; p.PW = p.TW / 2;
     p.pw_shift = ilog2i(p.PW); p.thp_shift = ilog2i(p.TH * p.PW);

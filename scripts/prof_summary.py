@@ -1,16 +1,25 @@
 """Summarise a rocprofv3 rocpd database (kernel trace) into a per-kernel table.
-usage: python scripts/prof_summary.py gpurun_out/prof_x/bench_results.db [steps_in_trace] [tail_ms]
+usage: python scripts/prof_summary.py gpurun_out/prof_x/bench_results.db [steps_in_trace] [tail_ms] [marker]
 tail_ms > 0 keeps only the kernels that start within the last tail_ms of the trace (the timed steps, leaving out
-the warm-up with its one-off autotune trial launches)."""
+the warm-up with its one-off autotune trial launches).  With a marker (a kernel-name substring that occurs once per
+step, e.g. divide_multi) the window is exactly the last `steps` steps: from the end of the (steps+1)-th last marker
+kernel to the end of the last one (tail_ms is then ignored)."""
 import sqlite3
 import sys
 
 db = sys.argv[1]
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 tail_ms = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+marker = sys.argv[4] if len(sys.argv) > 4 else None
 c = sqlite3.connect(db)
 where = ""
-if tail_ms > 0:
+if marker:
+    ends = [r[0] for r in c.execute("select end from kernels where name like ? order by start", ("%" + marker + "%",))]
+    n = int(steps)
+    if len(ends) < n + 1:
+        raise SystemExit("marker '%s' occurs %d times, need %d" % (marker, len(ends), n + 1))
+    where = " where start >= %d and end <= %d" % (ends[-n - 1], ends[-1])
+elif tail_ms > 0:
     t_end = list(c.execute("select max(end) from kernels"))[0][0]
     where = " where start >= %d" % (t_end - int(tail_ms * 1e6))
 rows = list(c.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3, min(end-start)/1e3, "
