@@ -169,3 +169,52 @@ def test_loss_scaler_skips_nonfinite_and_unscales():
     ok, _ = b.apply(gb)
     assert not ok and b.scaler.scale == 1024.0 and b.t == 1
     assert torch.equal(before, b.parameters()[k])
+
+
+def test_generator_feeds_training_steps_and_loss_decreases():
+    """BASELINE config 4 at one GPU and toy size: an item of the on-device generator (ShapeID pathology + deformation +
+    interpol warp + augmentation chain, tests/test_gpu_synth.py) goes through the reference's collate convention
+    (batch dimension added) into TrainStep.step; five AdamW steps on that one item lower the weighted total."""
+    import test_gpu_synth as SY
+    from brainfm_amd import generator as G
+    from brainfm_amd import test_utils as TU
+    from brainfm_amd import train as TR
+    from oracle import unet_ref as O
+    rs = np.random.RandomState(0)
+    shp = (48, 44, 52)
+    zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shp], indexing="ij")
+    ell = (((zz - 24) / 20.) ** 2 + ((yy - 22) / 18.) ** 2 + ((xx - 26) / 22.) ** 2) <= 1
+    seeds = rs.rand(30, 3) * np.array(shp)
+    lab = np.argmin(((np.stack([zz, yy, xx], -1)[..., None, :] - seeds) ** 2).sum(-1), -1)
+    ids = np.array([2, 3, 4, 41, 42, 17, 10, 11, 12, 13])[lab % 10] * ell
+    case = {"name": "toy", "Gen": ids.astype(np.float32), "T1": rs.rand(*shp).astype(np.float32) * ell,
+            "segmentation": ids.astype(np.int32),
+            "distance": [rs.rand(*shp).astype(np.float32) * 255 for _ in range(4)],
+            "registration": [rs.randn(*shp).astype(np.float32) * 500 for _ in range(3)]}
+    np.random.seed(3)
+    torch.manual_seed(3)
+    ga = SY._gen_args()
+    ga.task.pathology = False
+    ds = G.build_datasets(ga, "cuda:0", cases=[case])["all"]
+    _, _, _, target, samples = ds[0]
+    target = {k: (v[None] if isinstance(v, torch.Tensor) else v) for k, v in target.items()}      # collate: batch dim
+    samples = [{k: (v[None] if isinstance(v, torch.Tensor) else v) for k, v in s.items()} for s in samples]
+    tasks = dict(T1=True, T2=False, FLAIR=False, CT=False, segmentation=True, distance=True, bias_field=True,
+                 registration=True, super_resolution=True, surface=False, pathology=False, contrastive=False)
+    gi, ti = TU.default_inference_args(f_maps=8, num_levels=3, tasks=tasks, size=(32, 32, 32))
+    oc = O.default_out_channels(tasks=[k if k != "bias_field" else "bias_field" for k, v in tasks.items() if v])
+    sd = O.random_state_dict(1, 8, 3, out_channels=oc, seed=9)
+    s = TU.InferenceSession(gi, ti, _dev(), state_dict=sd, passes=3)
+    tail = s.model.head.tail(s.engine)
+    names = ["T1", "T1_grad", "seg_ce", "seg_dice", "distance", "bias_field_log", "registration", "registration_grad",
+             "SR", "SR_grad"]
+    nseg = tail.desc.n_seg
+    step = TR.TrainStep(s.engine, tail, names, {"loss_" + n: 1.0 for n in names}, torch.full((nseg,), 1.0 / nseg),
+                        all_samples=len(samples), lr=2e-3, scaler=TR.LossScaler(init_scale=256.0))
+    totals = []
+    for it in range(5):
+        ld, tot, ok = step.step([x["input"] for x in samples], target, samples)
+        assert ok and np.isfinite(tot) and set(ld) == {"loss_" + n for n in names}
+        totals.append(tot)
+    print("totals", [round(t, 4) for t in totals])
+    assert totals[-1] < totals[0]
