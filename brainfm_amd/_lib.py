@@ -92,6 +92,7 @@ SIGNATURES = {
     "bfm_lrelu_bwd": (_I, [_P, _P, _L, _F, _P, _P]),
     "bfm_conv3x3x3_wgrad_workspace": (_Z, [_I, _I, _I, _I, _I]),
     "bfm_conv3x3x3_wgrad": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _P, _P, _Z, _P]),
+    "bfm_conv3x3x3_wgrad_ex": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _P, _P, _I, _I, _P, _P, _Z, _P]),
     "bfm_gn_bwd_workspace": (_Z, [_I, _I, _I, _I]),
     "bfm_gn_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "bfm_maxpool2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),

@@ -16,6 +16,7 @@ What this does not cover yet: the task heads and losses (criterion.py), AMP loss
 Gradients are returned under the reference's parameter names.
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -25,8 +26,11 @@ from . import _lib as L
 from .engine import _Layer
 
 
+WGRAD_PASSES = int(os.environ.get("BFM_WGRAD_PASSES", "3"))     # 3: split-fp16 matrix core; 0: exact fp32 matrix core
+
+
 class ConvTape:
-    __slots__ = ("ly", "A", "B", "dims", "lo_dims", "scale", "shift", "mean", "rstd", "out")
+    __slots__ = ("ly", "A", "B", "dims", "lo_dims", "scale", "shift", "mean", "rstd", "out", "bound")
 
 
 def _start_tables(eng, lo, hi):
@@ -78,7 +82,7 @@ def train_single_conv(eng, ly, A, dims, B=None, lo_dims=None):
                 "conv_direct " + ly.name)
     t = ConvTape()
     t.ly, t.A, t.B, t.dims, t.lo_dims = ly, A, B, tuple(dims), (tuple(lo_dims) if lo_dims is not None else None)
-    t.scale, t.shift, t.mean, t.rstd, t.out = scale, shift, mean, rstd, out
+    t.scale, t.shift, t.mean, t.rstd, t.out, t.bound = scale, shift, mean, rstd, out, bound
     return out, t
 
 
@@ -114,12 +118,14 @@ def backward_single_conv(eng, t, dY, need_input_grad=True):
     L.check(lib.bfm_lrelu_bwd(L.ptr(dY), L.ptr(t.out), dY.numel(), eng.slope, L.ptr(dP), st), "lrelu_bwd")
     up = eng._upsample_desc(t.lo_dims, t.dims) if t.B is not None else None
     upp = C.byref(up) if up is not None else None
-    # ---- weight gradient
+    bnd = torch.maximum(dP.max(), -dP.min()).reshape(1).to(torch.float32)
+    # ---- weight gradient (split-fp16 matrix-core kernel on the wide layers, exact fp32 one elsewhere / on request)
     wsb = lib.bfm_conv3x3x3_wgrad_workspace(ly.cin, ly.cout, D, H, W)
     ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
     dW = torch.empty((ly.cout, ly.cin, 3, 3, 3), dtype=torch.float32, device=dev)
-    L.check(lib.bfm_conv3x3x3_wgrad(L.ptr(dP), ly.cout, L.ptr(t.A), ca, L.ptr(t.B), cb, D, H, W, upp, L.ptr(t.scale),
-                                    L.ptr(t.shift), L.ptr(dW), L.ptr(ws), ws.numel(), st), "conv_wgrad " + ly.name)
+    L.check(lib.bfm_conv3x3x3_wgrad_ex(L.ptr(dP), ly.cout, L.ptr(t.A), ca, L.ptr(t.B), cb, D, H, W, upp, L.ptr(t.scale),
+                                       L.ptr(t.shift), L.ptr(bnd), L.ptr(t.bound), ly.groups, WGRAD_PASSES, L.ptr(dW),
+                                       L.ptr(ws), ws.numel(), st), "conv_wgrad " + ly.name)
     grads = OrderedDict()
     grads[ly.name + ".conv.weight"] = dW
     if not need_input_grad and ly.cin < 8:
@@ -131,7 +137,6 @@ def backward_single_conv(eng, t, dY, need_input_grad=True):
         dg = ly.packs["dgrad_layer"] = _dgrad_layer(eng, ly)
     ones = torch.ones(ly.cout, dtype=torch.float32, device=dev)
     zeros = torch.zeros(ly.cout, dtype=torch.float32, device=dev)
-    bnd = torch.maximum(dP.max(), -dP.min()).reshape(1).to(torch.float32)
     dXn = torch.empty((D, H, W, dg.cout), dtype=torch.float32, device=dev)
     if ly.cout % 16 == 0 and dg.cout % 64 == 0:
         cfg = (C.c_int * 8)(*list(eng._plan(ly.cout, dg.cout, t.dims, False)))

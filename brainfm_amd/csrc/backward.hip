@@ -148,11 +148,307 @@ __global__ void __launch_bounds__(WG2_THREADS) conv_wgrad_tiled_kernel(const Wg2
     float* out = p.part + (int64_t)blockIdx.x * p.Cout * Cin * 27;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
-        if (j >= nt) break;
+        if (j >= nt) continue;                             // (a break here keeps the loop rolled and acc[] in scratch)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = (i & 3) + 8 * (i >> 2) + 4 * lh;
             out[((int64_t)(co0 + cob * 32 + row) * Cin + ci0 + l32) * 27 + t0 + j] = acc[j][i];
+        }
+    }
+}
+
+// Split-fp16 version of the tiled weight gradient (three v_mfma_f32_32x32x16_f16 per product: hi*hi + hi*lo + lo*hi,
+// fp32 accumulation; same scheme and accuracy class as the forward conv kernels, ~2.5x the fp32 matrix-core rate).
+// The reduction index of dW is the voxel, and a 16-deep MFMA wants 8 consecutive K values per lane: K = the 16 x
+// positions of one tile row, so the tiles live TRANSPOSED in LDS ([row][channel][x], fp16 hi and lo planes, x pairs
+// packed per dword at staging time with v_cvt_pkrtz).  The three kw taps of an input row come from ONE 5-dword read
+// per plane: kw=0 -> dwords 0..3, kw=2 -> dwords 1..4, kw=1 -> v_alignbit of neighbouring dwords (the 2-byte shift).
+// Workgroup = 8 waves = 2 co-blocks x 4 tap groups (7,7,7,6) on a 64 (co) x 32 (ci) x 27 block of dW, persistent over
+// 2x4x16-voxel tiles; the next tile's global loads are in flight during the MFMA phase (prefetch registers), the
+// convert + LDS store sits between two barriers.  Row pitches are padded by 8 dwords so that the staging writes (lanes =
+// x-pair x row) hit 32 distinct banks.
+typedef _Float16 wg_half8 __attribute__((ext_vector_type(8)));
+typedef __fp16 wg_fp16x2 __attribute__((ext_vector_type(2)));
+constexpr int HT_Z = 2, HT_Y = 4, HT_X = 16;
+constexpr int HR = HT_Z * HT_Y;                            // 8 tile rows
+constexpr int HHY = HT_Y + 2;
+constexpr int HHR = (HT_Z + 2) * HHY;                      // 24 halo rows
+constexpr int DP_ROW = 64 * 8 + 8;                         // dwords per dP row: 64 channels x 8 x-pairs, padded
+constexpr int DP_PLANE = HR * DP_ROW;
+constexpr int X_CH = 12;                                   // dwords per channel of an input row: hx 0..17 (+pad), 48 B
+constexpr int X_ROW = 32 * X_CH + 8;
+constexpr int X_PLANE = HHR * X_ROW;
+constexpr int WG3_LDS = (2 * DP_PLANE + 2 * X_PLANE) * 4;  // 108.5 KB
+constexpr int WG3_THREADS = 512;
+constexpr int X_ITEMS = HHR * 9 * 8;                       // (halo row, hx pair, channel quad) = 1728
+
+struct Wg3Params {
+    WgParams b;
+    int nbz, nby, nbx, ntiles;
+    const float* dp_bound;            // [1]  max |dP|
+    const float* x_bound;             // [G]  max |GroupNorm-applied input| per group
+    int G;
+};
+
+__device__ __forceinline__ int pow2_exp_for(float bmax) {  // e with bmax * 2^e in [2^12, 2^13)
+    int e = 0;
+    if (bmax > 0.f && bmax < INFINITY) {
+        int ex;
+        (void)frexpf(bmax, &ex);
+        e = 13 - ex;
+        e = e > 60 ? 60 : (e < -60 ? -60 : e);
+    }
+    return e;
+}
+
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const wg_fp16x2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const wg_fp16x2 l = __builtin_amdgcn_cvt_pkrtz(a - (float)h[0], b - (float)h[1]);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// One tile's MFMAs of wave (cob, g).  Every wave runs the SAME code (specialising per tap group with if / else around the
+// accumulators made the allocator keep two copies of them: 36 spills with nothing else live): group g owns the input rows
+// (kd,kh) = 2g and 2g+1 with all three kw (compile-time fragment shapes, run-time LDS row offsets) and, for g < 3, tap
+// (2,2,kw=g) with a wave-uniform select of the fragment shape.
+__device__ __forceinline__ void wg3_frags(const uint32_t* xb, int kw, wg_half8& b_hi, wg_half8& b_lo, const uint4& h,
+                                          uint32_t h4, const uint4& l, uint32_t l4) {
+    uint4 bh, bl;
+    if (kw == 0) {
+        bh = h; bl = l;
+    } else if (kw == 2) {
+        bh = make_uint4(h.y, h.z, h.w, h4);
+        bl = make_uint4(l.y, l.z, l.w, l4);
+    } else {
+        bh = make_uint4(__builtin_amdgcn_alignbit(h.y, h.x, 16), __builtin_amdgcn_alignbit(h.z, h.y, 16),
+                        __builtin_amdgcn_alignbit(h.w, h.z, 16), __builtin_amdgcn_alignbit(h4, h.w, 16));
+        bl = make_uint4(__builtin_amdgcn_alignbit(l.y, l.x, 16), __builtin_amdgcn_alignbit(l.z, l.y, 16),
+                        __builtin_amdgcn_alignbit(l.w, l.z, 16), __builtin_amdgcn_alignbit(l4, l.w, 16));
+    }
+    b_hi = __builtin_bit_cast(wg_half8, bh);
+    b_lo = __builtin_bit_cast(wg_half8, bl);
+    (void)xb;
+}
+
+__device__ __forceinline__ void wg3_mfma_phase(const uint32_t* __restrict__ dPs, const uint32_t* __restrict__ Xs,
+                                               floatx16 (&acc)[7], int cob, int g, int l32, int lh) {
+    int offR[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 2 * g + i;
+        const int kd = row / 3, kh = row - kd * 3;
+        offR[i] = (kd * HHY + kh) * X_ROW;
+    }
+    offR[2] = (2 * HHY + 2) * X_ROW;
+#pragma unroll 1
+    for (int r = 0; r < HR; ++r) {
+        const int zl = r / HT_Y, yl = r - zl * HT_Y;
+        const uint32_t* ap = dPs + r * DP_ROW + (cob * 32 + l32) * 8 + 4 * lh;
+        const wg_half8 a_hi = __builtin_bit_cast(wg_half8, *reinterpret_cast<const uint4*>(ap));
+        const wg_half8 a_lo = __builtin_bit_cast(wg_half8, *reinterpret_cast<const uint4*>(ap + DP_PLANE));
+        const uint32_t* base = Xs + (zl * HHY + yl) * X_ROW + l32 * X_CH + 4 * lh;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t* xb = base + offR[i];
+            const uint4 h = *reinterpret_cast<const uint4*>(xb);
+            const uint32_t h4 = xb[4];
+            const uint4 l = *reinterpret_cast<const uint4*>(xb + X_PLANE);
+            const uint32_t l4 = xb[X_PLANE + 4];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                wg_half8 b_hi, b_lo;
+                wg3_frags(xb, kw, b_hi, b_lo, h, h4, l, l4);
+                const int j = i * 3 + kw;
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[j], 0, 0, 0);
+            }
+        }
+        if (g < 3) {                                               // wave-uniform
+            const uint32_t* xb = base + offR[2];
+            const uint4 h = *reinterpret_cast<const uint4*>(xb);
+            const uint32_t h4 = xb[4];
+            const uint4 l = *reinterpret_cast<const uint4*>(xb + X_PLANE);
+            const uint32_t l4 = xb[X_PLANE + 4];
+            wg_half8 b_hi, b_lo;
+            if (g == 0) wg3_frags(xb, 0, b_hi, b_lo, h, h4, l, l4);
+            else if (g == 1) wg3_frags(xb, 1, b_hi, b_lo, h, h4, l, l4);
+            else wg3_frags(xb, 2, b_hi, b_lo, h, h4, l, l4);
+            acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[6], 0, 0, 0);
+            acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[6], 0, 0, 0);
+            acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[6], 0, 0, 0);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(WG3_THREADS) conv_wgrad_f16_kernel(const Wg3Params q) {
+    extern __shared__ uint32_t wg3_lds[];
+    const WgParams& p = q.b;
+    uint32_t* dPs = wg3_lds;
+    uint32_t* Xs = wg3_lds + 2 * DP_PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cob = wave & 1, tg = wave >> 1;
+    const int Cin = p.CA + p.CB;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 64;
+    const bool fromB = ci0 >= p.CA;
+
+    float xb = 0.f;
+    for (int g = 0; g < q.G; ++g) xb = fmaxf(xb, q.x_bound[g]);
+    const int ea = pow2_exp_for(q.dp_bound[0]), ex = pow2_exp_for(xb);
+    const float sa = ldexpf(1.0f, ea), sx = ldexpf(1.0f, ex), dq = ldexpf(1.0f, -(ea + ex));
+
+    floatx16 acc[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+    // ---- staging roles.  A thread keeps ONE channel quad for all its items (one scale/shift quad in registers):
+    //   lane = q4 + 4 * sub: four lanes read 64 contiguous bytes of a voxel; within a wave instruction the LDS dword
+    //   address is row*ROW + (4q + k')*CH + xp with k' = (k + q4) & 3 (channel order rotated per lane), which spreads the
+    //   four quads over distinct banks (channel pitches are multiples of 4 dwords, so un-rotated they would collide).
+    //   dP:    quad = 4 (wave & 3) + q4, rows 4 (wave >> 2) + 2 s + (sub >> 3), x pair = sub & 7          (2 items)
+    //   input: quad = 4 (wave & 1) + q4, position = 16 (wave >> 1) + sub + 64 s -> (halo row, hx pair)    (4 items)
+    const int q4 = lane & 3, sub = lane >> 2;
+    const int d_q = 4 * (wave & 3) + q4, d_xp = sub & 7, d_r0 = 4 * (wave >> 2) + (sub >> 3);
+    const int x_qd = 4 * (wave & 1) + q4, x_pos0 = 16 * (wave >> 1) + sub;
+    // rotate a 4-vector by q4 with two select stages (a chain of ?: on a lane-dependent index becomes branches)
+    const bool rot1 = q4 & 1, rot2 = q4 & 2;
+    auto rot4 = [&](const float (&v)[4], float (&u)[4]) __attribute__((always_inline)) {
+        float w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[k] = rot1 ? v[(k + 1) & 3] : v[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) u[k] = rot2 ? w[(k + 2) & 3] : w[k];
+    };
+    float sc[4], sh[4];                                    // already rotated: sc[k] belongs to channel (k + q4) & 3
+    {
+        const float4 a = *reinterpret_cast<const float4*>(p.scale + ci0 + x_qd * 4);
+        const float4 b = *reinterpret_cast<const float4*>(p.shift + ci0 + x_qd * 4);
+        const float a4[4] = {a.x * sx, a.y * sx, a.z * sx, a.w * sx}, b4[4] = {b.x * sx, b.y * sx, b.z * sx, b.w * sx};
+        rot4(a4, sc);
+        rot4(b4, sh);
+    }
+
+    // All loads are unconditional (coordinates clamped into the volume, validity kept as mask bits): straight-line code,
+    // twelve 16-byte loads in flight per thread.
+    float4 pd[2][2], px[4][2];
+    unsigned okmask = 0;                                   // bits 0..7: input item s element e (2 s + e); 8..11: dP
+    auto load_tile = [&](int tile) __attribute__((always_inline)) {
+        const int bx = tile % q.nbx;
+        const int t2 = tile / q.nbx;
+        const int by = t2 % q.nby, bz = t2 / q.nby;
+        const int z0 = bz * HT_Z, y0 = by * HT_Y, x0 = bx * HT_X;
+        okmask = 0;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int r = d_r0 + 2 * s;
+            const int z = z0 + r / HT_Y, y = y0 + r % HT_Y, x = x0 + 2 * d_xp;
+            const bool rok = z < p.D && y < p.H;
+            const int zc = min(z, p.D - 1), yc = min(y, p.H - 1);
+            const float* row = p.dP + ((int64_t)(zc * p.H + yc) * p.W) * p.Cout + co0 + d_q * 4;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int xe = x + e;
+                pd[s][e] = *reinterpret_cast<const float4*>(row + (int64_t)min(xe, p.W - 1) * p.Cout);
+                okmask |= (rok && xe < p.W) ? (1u << (8 + 2 * s + e)) : 0u;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int pos = min(x_pos0 + 64 * s, HHR * 9 - 1);         // slots past the end redo the last item (not stored)
+            const int hrow = pos / 9, hxp = pos - hrow * 9;
+            const int zz = z0 + hrow / HHY - 1, yy = y0 + hrow % HHY - 1, xx = x0 + 2 * hxp - 1;
+            const bool rok = zz >= 0 && zz < p.D && yy >= 0 && yy < p.H;
+            const int zc = min(max(zz, 0), p.D - 1), yc = min(max(yy, 0), p.H - 1);
+            const float* row;
+            int stride;
+            if (fromB) {                                               // wave-uniform
+                row = p.B + ((int64_t)(p.up.mapD[zc] * p.up.h + p.up.mapH[yc]) * p.up.w) * p.CB + (ci0 - p.CA) + x_qd * 4;
+                stride = p.CB;
+            } else {
+                row = p.A + ((int64_t)(zc * p.H + yc) * p.W) * p.CA + ci0 + x_qd * 4;
+                stride = p.CA;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int xe = xx + e;
+                int xc = min(max(xe, 0), p.W - 1);
+                if (fromB) xc = p.up.mapW[xc];
+                px[s][e] = *reinterpret_cast<const float4*>(row + (int64_t)xc * stride);
+                okmask |= (rok && xe >= 0 && xe < p.W) ? (1u << (2 * s + e)) : 0u;
+            }
+        }
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float m0 = (okmask >> (8 + 2 * s)) & 1u ? sa : 0.f, m1 = (okmask >> (9 + 2 * s)) & 1u ? sa : 0.f;
+            const float v0[4] = {pd[s][0].x, pd[s][0].y, pd[s][0].z, pd[s][0].w};
+            const float v1[4] = {pd[s][1].x, pd[s][1].y, pd[s][1].z, pd[s][1].w};
+            float u0[4], u1[4];
+            rot4(v0, u0);
+            rot4(v1, u1);
+            uint32_t* dst = dPs + (d_r0 + 2 * s) * DP_ROW + (d_q * 4) * 8 + d_xp;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t hi, lo;
+                split_pair(u0[k] * m0, u1[k] * m1, hi, lo);
+                uint32_t* d = dst + ((k + q4) & 3) * 8;               // the channel this rotated slot belongs to
+                d[0] = hi;
+                d[DP_PLANE] = lo;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int pos = x_pos0 + 64 * s;
+            const bool live = pos < HHR * 9;
+            const int posc = min(pos, HHR * 9 - 1);
+            const int hrow = posc / 9, hxp = posc - hrow * 9;
+            const float v0[4] = {px[s][0].x, px[s][0].y, px[s][0].z, px[s][0].w};
+            const float v1[4] = {px[s][1].x, px[s][1].y, px[s][1].z, px[s][1].w};
+            float u0[4], u1[4];
+            rot4(v0, u0);
+            rot4(v1, u1);
+            const bool ok0 = (okmask >> (2 * s)) & 1u, ok1 = (okmask >> (2 * s + 1)) & 1u;
+            uint32_t* dst = Xs + hrow * X_ROW + (x_qd * 4) * X_CH + hxp;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = ok0 ? fmaf(u0[k], sc[k], sh[k]) : 0.f;       // zero padding comes after the affine
+                const float b = ok1 ? fmaf(u1[k], sc[k], sh[k]) : 0.f;
+                uint32_t hi, lo;
+                split_pair(a, b, hi, lo);
+                uint32_t* d = dst + ((k + q4) & 3) * X_CH;
+                if (live) {
+                    d[0] = hi;
+                    d[X_PLANE] = lo;
+                }
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < q.ntiles) load_tile(tile);
+    for (; tile < q.ntiles; tile += gridDim.x) {
+        __syncthreads();                                   // the previous tile's fragment reads are done
+        store_tile();
+        __syncthreads();
+        const int nxt = tile + gridDim.x;
+        if (nxt < q.ntiles) load_tile(nxt);                // in flight while the matrix core works
+        __builtin_amdgcn_sched_barrier(0);
+        wg3_mfma_phase(dPs, Xs, acc, cob, tg, l32, lh);
+    }
+    float* out = p.part + (int64_t)blockIdx.x * p.Cout * Cin * 27;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        if (j == 6 && tg == 3) continue;                              // group 3 has no seventh tap
+        const int tap = j < 6 ? (2 * tg + j / 3) * 3 + j % 3 : 24 + tg;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * lh;
+            out[((int64_t)(co0 + cob * 32 + row) * Cin + ci0 + l32) * 27 + tap] = acc[j][i] * dq;
         }
     }
 }
@@ -460,12 +756,12 @@ extern "C" int bfm_lrelu_bwd(const float* dY, const float* Y, int64_t n, float s
 }
 
 namespace {
-struct WgPlan { int kind; int S; int rows_per_split; int nbz, nby, nbx, ntiles; };    // kind 0 tiled, 1 columns
-WgPlan wgrad_plan(int CA, int Cin, int Cout, int D, int H, int W) {
+struct WgPlan { int kind; int S; int rows_per_split; int nbz, nby, nbx, ntiles; };    // kind 0 tiled (fp32 or f16 tiles), 1 columns
+WgPlan wgrad_plan(int CA, int Cin, int Cout, int D, int H, int W, bool f16 = false) {
     WgPlan pl{};
     if (Cout % 64 == 0 && Cin % 32 == 0 && CA % 32 == 0) {
         pl.kind = 0;
-        pl.nbz = bfm_cdiv(D, WT_Z); pl.nby = bfm_cdiv(H, WT_Y); pl.nbx = bfm_cdiv(W, WT_X);
+        pl.nbz = bfm_cdiv(D, f16 ? HT_Z : WT_Z); pl.nby = bfm_cdiv(H, f16 ? HT_Y : WT_Y); pl.nbx = bfm_cdiv(W, f16 ? HT_X : WT_X);
         pl.ntiles = pl.nbz * pl.nby * pl.nbx;
         const int cols = (Cin / 32) * (Cout / 64);
         int S = 512 / cols;                               // two full rounds of one workgroup per CU, never a third
@@ -490,13 +786,19 @@ WgPlan wgrad_plan(int CA, int Cin, int Cout, int D, int H, int W) {
 extern "C" size_t bfm_conv3x3x3_wgrad_workspace(int Cin, int Cout, int D, int H, int W) {
     if (Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     // the split count does not depend on CA (only the kernel choice does): take the larger of the two plans
-    const WgPlan a = wgrad_plan(Cin, Cin, Cout, D, H, W), b = wgrad_plan(1, Cin, Cout, D, H, W);
-    return (size_t)(a.S > b.S ? a.S : b.S) * Cout * Cin * 27 * sizeof(float);
+    const WgPlan a = wgrad_plan(Cin, Cin, Cout, D, H, W), b = wgrad_plan(1, Cin, Cout, D, H, W),
+                 c = wgrad_plan(Cin, Cin, Cout, D, H, W, true);
+    int S = a.S > b.S ? a.S : b.S;
+    if (c.S > S) S = c.S;
+    return (size_t)S * Cout * Cin * 27 * sizeof(float);
 }
 
-extern "C" int bfm_conv3x3x3_wgrad(const float* dP, int Cout, const float* A, int CA, const float* B, int CB, int D,
-                                   int H, int W, const bfm_upsample_t* up, const float* scale, const float* shift,
-                                   float* dW, void* workspace, size_t workspace_bytes, bfm_stream_t stream) {
+extern "C" int bfm_conv3x3x3_wgrad_ex(const float* dP, int Cout, const float* A, int CA, const float* B, int CB, int D,
+                                      int H, int W, const bfm_upsample_t* up, const float* scale, const float* shift,
+                                      const float* dp_bound, const float* x_bound, int G, int passes, float* dW,
+                                      void* workspace, size_t workspace_bytes, bfm_stream_t stream) {
+    if (passes != 0 && passes != 3) return BFM_E_ARG;
+    if (passes == 3 && (!dp_bound || !x_bound || G <= 0)) return BFM_E_ARG;
     if (!dP || !A || !scale || !shift || !dW || !workspace || Cout <= 0 || CA <= 0 || D <= 0 || H <= 0 || W <= 0)
         return BFM_E_ARG;
     if (CB < 0 || (CB > 0 && (!B || !up || !up->mapD || !up->mapH || !up->mapW))) return BFM_E_ARG;
@@ -508,9 +810,22 @@ extern "C" int bfm_conv3x3x3_wgrad(const float* dP, int Cout, const float* A, in
     p.part = static_cast<float*>(workspace);
     hipStream_t st = bfm_s(stream);
     const int64_t n = (int64_t)Cout * Cin * 27;
-    const WgPlan pl = wgrad_plan(CA, Cin, Cout, D, H, W);
+    const bool f16 = passes == 3 && Cout % 64 == 0 && Cin % 32 == 0 && CA % 32 == 0;
+    const WgPlan pl = wgrad_plan(CA, Cin, Cout, D, H, W, f16);
     p.S = pl.S;
-    if (pl.kind == 0) {
+    if (f16) {
+        Wg3Params q{};
+        q.b = p; q.nbz = pl.nbz; q.nby = pl.nby; q.nbx = pl.nbx; q.ntiles = pl.ntiles;
+        q.dp_bound = dp_bound; q.x_bound = x_bound; q.G = G;
+        static bool attr3 = false;
+        if (!attr3) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_f16_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS) != hipSuccess)
+                return BFM_E_LAUNCH;
+            attr3 = true;
+        }
+        hipLaunchKernelGGL(conv_wgrad_f16_kernel, dim3(pl.S, Cin / 32, Cout / 64), dim3(WG3_THREADS), WG3_LDS, st, q);
+    } else if (pl.kind == 0) {
         Wg2Params q{};
         q.b = p; q.nbz = pl.nbz; q.nby = pl.nby; q.nbx = pl.nbx; q.ntiles = pl.ntiles;
         static bool attr = false;
@@ -527,6 +842,13 @@ extern "C" int bfm_conv3x3x3_wgrad(const float* dP, int Cout, const float* A, in
     }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(n)), dim3(256), 0, st, p.part, p.S, n, dW);
     return bfm_launch_status();
+}
+
+extern "C" int bfm_conv3x3x3_wgrad(const float* dP, int Cout, const float* A, int CA, const float* B, int CB, int D,
+                                   int H, int W, const bfm_upsample_t* up, const float* scale, const float* shift,
+                                   float* dW, void* workspace, size_t workspace_bytes, bfm_stream_t stream) {
+    return bfm_conv3x3x3_wgrad_ex(dP, Cout, A, CA, B, CB, D, H, W, up, scale, shift, nullptr, nullptr, 0, 0, dW, workspace,
+                                  workspace_bytes, stream);
 }
 
 // partial blocks of the GroupNorm backward sums: 16 voxels or more each, at most 1024 (the deep levels have 64..4096

@@ -396,6 +396,13 @@ size_t bfm_conv3x3x3_wgrad_workspace(int Cin, int Cout, int D, int H, int W);
 int bfm_conv3x3x3_wgrad(const float* dP, int Cout, const float* A, int CA, const float* B, int CB, int D, int H, int W,
                         const bfm_upsample_t* up, const float* scale, const float* shift, float* dW /*[Cout][Cin][27]*/,
                         void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+/* passes = 0: exact fp32 matrix core (= bfm_conv3x3x3_wgrad).  passes = 3: split-fp16 (hi*hi + hi*lo + lo*hi, fp32
+ * accumulate -- the forward kernels' accuracy class) on layers with Cout % 64 == 0, CA % 32 == 0, Cin % 32 == 0, the fp32
+ * kernel elsewhere; needs dp_bound [1] = max |dP| and x_bound [G] = max |GroupNorm-applied input| per group (device). */
+int bfm_conv3x3x3_wgrad_ex(const float* dP, int Cout, const float* A, int CA, const float* B, int CB, int D, int H, int W,
+                           const bfm_upsample_t* up, const float* scale, const float* shift, const float* dp_bound,
+                           const float* x_bound, int G, int passes, float* dW, void* workspace, size_t workspace_bytes,
+                           bfm_stream_t stream);
 size_t bfm_gn_bwd_workspace(int C, int D, int H, int W);
 int bfm_gn_bwd(const float* dXn, const float* A, int CA, const float* B, int CB, int D, int H, int W,
                const bfm_upsample_t* up, const int32_t* startD, const int32_t* startH, const int32_t* startW,
