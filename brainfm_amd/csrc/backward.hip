@@ -650,24 +650,38 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const double* __re
                                                               double count_per_channel, const float* __restrict__ gamma,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ m1, float* __restrict__ m2) {
-    extern __shared__ double sm[];                        // [C][2]: gamma*s1, gamma*s2
+    // one block per group: threads = (channel of the group) x (row lane); rows folded in a fixed order
+    extern __shared__ double sm[];                        // [256][2] partials, then [cpg][2]: gamma*s1, gamma*s2
     const int t = threadIdx.x;
-    for (int c = t; c < C; c += 256) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int b = 0; b < nb; ++b) { s1 += part[((int64_t)b * C + c) * 2]; s2 += part[((int64_t)b * C + c) * 2 + 1]; }
-        dbeta[c] = (float)s1;
-        dgamma[c] = (float)s2;
-        sm[c * 2] = (double)gamma[c] * s1;
-        sm[c * 2 + 1] = (double)gamma[c] * s2;
-    }
-    __syncthreads();
+    const int g = blockIdx.x;
     const int cpg = C / G;
-    for (int g = t; g < G; g += 256) {
-        double a = 0.0, b = 0.0;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += sm[c * 2]; b += sm[c * 2 + 1]; }
+    double ga = 0.0, gb = 0.0;                            // thread 0: group sums over channel chunks
+    for (int c0 = 0; c0 < cpg; c0 += 256) {
+        const int CP = min(256, cpg - c0);
+        const int RP = 256 / CP;
+        const int ci = t % CP, rl = t / CP;
+        const int c = g * cpg + c0 + ci;
+        double s1 = 0.0, s2 = 0.0;
+        if (rl < RP)
+            for (int b = rl; b < nb; b += RP) { s1 += part[((int64_t)b * C + c) * 2]; s2 += part[((int64_t)b * C + c) * 2 + 1]; }
+        __syncthreads();
+        sm[t * 2] = s1; sm[t * 2 + 1] = s2;
+        __syncthreads();
+        if (t < CP) {
+            for (int r = 1; r < RP; ++r) { s1 += sm[(r * CP + t) * 2]; s2 += sm[(r * CP + t) * 2 + 1]; }
+            dbeta[c] = (float)s1;
+            dgamma[c] = (float)s2;
+        }
+        __syncthreads();
+        if (t < CP) { sm[t * 2] = (double)gamma[c] * s1; sm[t * 2 + 1] = (double)gamma[c] * s2; }
+        __syncthreads();
+        if (t == 0)
+            for (int k = 0; k < CP; ++k) { ga += sm[k * 2]; gb += sm[k * 2 + 1]; }
+    }
+    if (t == 0) {
         const double n = count_per_channel * (double)cpg;
-        m1[g] = (float)(a / n);
-        m2[g] = (float)(b / n);
+        m1[g] = (float)(ga / n);
+        m2[g] = (float)(gb / n);
     }
 }
 
@@ -877,7 +891,6 @@ extern "C" int bfm_gn_bwd(const float* dXn, const float* A, int CA, const float*
     const int C = CA + CB;
     if (C % G) return BFM_E_SHAPE;
     if (workspace_bytes < bfm_gn_bwd_workspace(C, D, H, W)) return BFM_E_WORKSPACE;
-    if ((size_t)C * 16 > 64 * 1024) return BFM_E_SHAPE;
     GnbParams p{};
     p.dXn = dXn; p.A = A; p.B = B; p.CA = CA; p.CB = CB; p.up = make_upview(up);
     p.D = D; p.H = H; p.W = W; p.G = G; p.mean = mean; p.rstd = rstd; p.gamma = gamma;
@@ -895,7 +908,7 @@ extern "C" int bfm_gn_bwd(const float* dXn, const float* A, int CA, const float*
         hipLaunchKernelGGL(gn_bwd_partial4_kernel, dim3((unsigned)nb), dim3(256), 256 * 64, st, p, vpb, part);
     else
         hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3((unsigned)nb), dim3(256), 256 * 16, st, p, vpb, part);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(256), (size_t)C * 16, st, part, (int)nb, C, G, (double)nvox,
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(G), dim3(256), 256 * 16, st, part, (int)nb, C, G, (double)nvox,
                        gamma, dgamma, dbeta, m1, m2);
     hipLaunchKernelGGL(gn_bwd_apply_a_kernel, dim3(grid_for(nvox * CA)), dim3(256), 0, st, p, m1, m2, dA);
     if (CB > 0) {
