@@ -26,6 +26,7 @@ from . import _lib as L
 from .engine import _Layer
 
 
+TRAIN_FAST = os.environ.get("BFM_TRAIN_FAST", "1") != "0"
 WGRAD_PASSES = int(os.environ.get("BFM_WGRAD_PASSES", "3"))     # 3: split-fp16 matrix core; 0: exact fp32 matrix core
 
 
@@ -139,15 +140,17 @@ def backward_single_conv(eng, t, dY, need_input_grad=True):
     zeros = torch.zeros(ly.cout, dtype=torch.float32, device=dev)
     dXn = torch.empty((D, H, W, dg.cout), dtype=torch.float32, device=dev)
     if ly.cout % 16 == 0 and dg.cout % 64 == 0:
-        cfg = (C.c_int * 8)(*list(eng._plan(ly.cout, dg.cout, t.dims, False)))
-        if cfg[6] > 2:
-            cfg[6] = 0
+        # the data gradient is a plain single-source conv of dP with the transposed weights: it goes through the
+        # engine's own launcher, so it is autotuned over the same variants as a forward layer (Winograd included)
+        key = (ly.cout, dg.cout, tuple(t.dims), False, False)
+        cfg = eng._plan(ly.cout, dg.cout, t.dims, False)
         wsc = lib.bfm_conv3x3x3_mfma_workspace(ly.cout, dg.cout, D, H, W, cfg[5])
         ws2 = torch.empty(max(wsc, 256), dtype=torch.uint8, device=dev)
-        eng._pack(dg, True, cfg[6])
-        L.check(lib.bfm_conv3x3x3_mfma_ex(L.ptr(dP), ly.cout, None, 0, D, H, W, None, L.ptr(ones), L.ptr(zeros),
-                                          L.ptr(bnd), 1, L.ptr(dg.wpacked), dg.wexp, dg.cout, 1.0, eng.passes, cfg,
-                                          L.ptr(dXn), L.ptr(ws2), ws2.numel(), None, st), "conv dgrad " + ly.name)
+
+        def _launch(c):
+            eng._conv_launch(dg, dP, ly.cout, None, 0, t.dims, None, ones, zeros, bnd, 1, c, dXn, ws2, None, slope=1.0)
+        cfg = eng._autotune(dg, key, _launch)
+        _launch(cfg)
         if dg.cout != ly.cin:
             dXn = dXn[..., :ly.cin].contiguous()
     else:
@@ -169,9 +172,39 @@ def backward_single_conv(eng, t, dY, need_input_grad=True):
     return dA, dB, grads
 
 
-def backbone_forward_train(eng, x_cl, dims):
+def backbone_forward_train(eng, x_cl, dims, fast=None):
     """UNetEngine.backbone_cl in training mode.  Returns (feats, tape): feats as backbone_cl (deepest first, the last
-    one not normalised), tape = what backbone_backward needs."""
+    one not normalised), tape = what backbone_backward needs.
+    fast: run the inference layer path itself (autotuned variants, Winograd, up-folded decoder convs, GroupNorm moments
+    from producer rows) with the engine's tape hook collecting inputs / scale / shift / mean / rstd / outputs; otherwise
+    the generic two-source kernels of train_single_conv (BFM_TRAIN_FAST=0 makes that the default)."""
+    if fast is None:
+        fast = TRAIN_FAST
+    if fast:
+        eng.tape = []
+        try:
+            feats = eng.backbone_cl(x_cl, dims)
+            rec = eng.tape
+        finally:
+            eng.tape = None
+        tape = {"enc": [], "dec": [], "pool": []}
+        convs = []
+        for r in rec:
+            if "pool_in" in r:
+                tape["pool"].append((r["pool_in"], r["pool_dims"]))
+                continue
+            t = ConvTape()
+            t.ly, t.A, t.B, t.dims, t.lo_dims = r["ly"], r["A"], r["B"], r["dims"], r["lo_dims"]
+            t.scale, t.shift, t.mean, t.rstd, t.out, t.bound = r["scale"], r["shift"], r["mean"], r["rstd"], r["out"], r["bound"]
+            convs.append(t)
+        ne = len(eng.enc)
+        if len(convs) != 2 * (ne + len(eng.dec)):
+            raise L.BfmError("training tape has %d conv records, expected %d" % (len(convs), 2 * (ne + len(eng.dec))))
+        for i in range(ne):
+            tape["enc"].append((convs[2 * i], convs[2 * i + 1]))
+        for j in range(len(eng.dec)):
+            tape["dec"].append((convs[2 * ne + 2 * j], convs[2 * ne + 2 * j + 1]))
+        return feats, tape
     tape = {"enc": [], "dec": [], "pool": []}
     skips = []
     x, d = x_cl, tuple(dims)

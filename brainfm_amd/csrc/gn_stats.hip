@@ -452,10 +452,10 @@ extern "C" size_t bfm_gn_stats_rows_workspace(int nrowsA, int CA, int nrowsB, in
     return rows_ws_bytes(nrowsA, CA) + (CB > 0 ? rows_ws_bytes(nrowsB, CB) : 0) + 256;
 }
 
-extern "C" int bfm_gn_stats_rows(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB,
-                                 double weightB, int64_t nvox, const float* gamma, const float* beta, int G, float eps,
-                                 float* scale, float* shift, float* bound, void* workspace, size_t workspace_bytes,
-                                 bfm_stream_t stream) {
+extern "C" int bfm_gn_stats_rows_train(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB,
+                                       double weightB, int64_t nvox, const float* gamma, const float* beta, int G,
+                                       float eps, float* scale, float* shift, float* bound, float* mean_out,
+                                       float* rstd_out, void* workspace, size_t workspace_bytes, bfm_stream_t stream) {
     if (!rowsA || nrowsA <= 0 || CA <= 0 || nvox <= 0 || !gamma || !beta || !scale || !shift || !bound) return BFM_E_ARG;
     if (CB < 0 || (CB > 0 && (!rowsB || nrowsB <= 0 || !(weightB > 0.0)))) return BFM_E_ARG;
     if ((reinterpret_cast<uintptr_t>(rowsA) & 7) || (CB > 0 && (reinterpret_cast<uintptr_t>(rowsB) & 7))) return BFM_E_ARG;
@@ -473,6 +473,14 @@ extern "C" int bfm_gn_stats_rows(const void* rowsA, int nrowsA, int CA, const vo
     PartTab tb{nullptr, nullptr, nullptr, nullptr, 0, 0, 1.0};
     if (CB > 0) tb = rows_source(rowsB, nrowsB, CB, weightB, ws + needA, st);
     hipLaunchKernelGGL(gn_finalize, dim3(G), dim3(TPB), fin_smem, st, ta, tb, G, (double)nvox, eps, gamma, beta, scale,
-                       shift, bound, nullptr, nullptr);
+                       shift, bound, mean_out, rstd_out);
     return bfm_launch_status();
+}
+
+extern "C" int bfm_gn_stats_rows(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB,
+                                 double weightB, int64_t nvox, const float* gamma, const float* beta, int G, float eps,
+                                 float* scale, float* shift, float* bound, void* workspace, size_t workspace_bytes,
+                                 bfm_stream_t stream) {
+    return bfm_gn_stats_rows_train(rowsA, nrowsA, CA, rowsB, nrowsB, CB, weightB, nvox, gamma, beta, G, eps, scale, shift,
+                                   bound, nullptr, nullptr, workspace, workspace_bytes, stream);
 }

@@ -51,6 +51,7 @@ class UNetEngine:
     the way utils/checkpoint.py:558-571 suffix-matches names.
     """
     prof = None
+    tape = None                 # training (backward.py): list that single_conv / maxpool append their records to
     prof_reps = 1
     use_upfold = False
     upfold_min = 4000
@@ -236,39 +237,53 @@ class UNetEngine:
         ra = getattr(A, "_bfm_rows", None) if self.fuse_stats else None
         rb = getattr(B, "_bfm_rows", None) if (self.fuse_stats and B is not None) else None
         exact2 = B is None or tuple(dims) == tuple(2 * v for v in lo_dims)
+        mean = rstd = None
+        if self.tape is not None:
+            mean = torch.empty(ly.groups, dtype=torch.float32, device=self.device)
+            rstd = torch.empty(ly.groups, dtype=torch.float32, device=self.device)
+            self._last_moments = (mean, rstd)
         if ra is not None and (B is None or (rb is not None and exact2)):
             need = self.lib.bfm_gn_stats_rows_workspace(ra[1], ca, rb[1] if rb is not None else 0, cb)
             ws = self._workspace(max(need, ws_min))
-            L.check(self.lib.bfm_gn_stats_rows(L.ptr(ra[0]), ra[1], ca, L.ptr(rb[0]) if rb is not None else None,
-                                               rb[1] if rb is not None else 0, cb, 8.0, D * H * W, L.ptr(ly.gamma),
-                                               L.ptr(ly.beta), ly.groups, self.eps, L.ptr(scale), L.ptr(shift),
-                                               L.ptr(bound), L.ptr(ws), ws.numel(), st), "gn_stats_rows " + ly.name)
+            L.check(self.lib.bfm_gn_stats_rows_train(L.ptr(ra[0]), ra[1], ca, L.ptr(rb[0]) if rb is not None else None,
+                                                     rb[1] if rb is not None else 0, cb, 8.0, D * H * W, L.ptr(ly.gamma),
+                                                     L.ptr(ly.beta), ly.groups, self.eps, L.ptr(scale), L.ptr(shift),
+                                                     L.ptr(bound), L.ptr(mean), L.ptr(rstd), L.ptr(ws), ws.numel(), st),
+                    "gn_stats_rows " + ly.name)
             return ws
         wsb = self.lib.bfm_gn_stats_workspace(ca, cb, D, H, W, upp)
         ws = self._workspace(max(wsb, ws_min))
-        L.check(self.lib.bfm_gn_stats(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(ly.gamma), L.ptr(ly.beta),
-                                      ly.groups, self.eps, L.ptr(scale), L.ptr(shift), L.ptr(bound), L.ptr(ws),
-                                      ws.numel(), st), "gn_stats " + ly.name)
+        L.check(self.lib.bfm_gn_stats_train(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(ly.gamma), L.ptr(ly.beta),
+                                            ly.groups, self.eps, L.ptr(scale), L.ptr(shift), L.ptr(bound), L.ptr(mean),
+                                            L.ptr(rstd), L.ptr(ws), ws.numel(), st), "gn_stats " + ly.name)
         return ws
 
-    def _conv_launch(self, ly, A, ca, B, cb, dims, upp, scale, shift, bound, groups, cfg, out, ws, rows=None):
+    def _record(self, ly, A, B, dims, lo_dims, scale, shift, bound, out):
+        """Training tape entry of one SingleConv (backward.ConvTape fields)."""
+        if self.tape is not None:
+            mean, rstd = self._last_moments
+            self.tape.append(dict(ly=ly, A=A, B=B, dims=tuple(dims), lo_dims=tuple(lo_dims) if lo_dims is not None else None,
+                                  scale=scale, shift=shift, bound=bound, mean=mean, rstd=rstd, out=out))
+
+    def _conv_launch(self, ly, A, ca, B, cb, dims, upp, scale, shift, bound, groups, cfg, out, ws, rows=None, slope=None):
         """One launch of the planned variant of GN-apply + conv + LeakyReLU (cfg[6]: 0/1/2 conv_mfma family,
         3 Winograd; cfg[7] bit 0: accumulate onto `out`)."""
         D, H, W = dims
         st = L.stream_ptr()
+        slope = self.slope if slope is None else float(slope)
         self._pack(ly, True, cfg[6])
         if cfg[6] in (3, 4, 5):
             if cb:
                 raise L.BfmError("the Winograd variant takes one source")
             L.check(self.lib.bfm_conv3x3x3_wino_ex(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
-                                                   groups, L.ptr(ly.wpacked), ly.wexp, ly.cout, self.slope, self.passes,
+                                                   groups, L.ptr(ly.wpacked), ly.wexp, ly.cout, slope, self.passes,
                                                    (cfg[7] & 1) | (2 if cfg[6] == 4 else 0) | (4 if cfg[6] == 5 else 0), L.ptr(out),
                                                    L.ptr(rows[0]) if rows is not None else None, st),
                     "conv_wino " + ly.name)
             return
         L.check(self.lib.bfm_conv3x3x3_mfma_ex(L.ptr(A), ca, L.ptr(B) if cb else None, cb, D, H, W, upp if cb else None,
                                                L.ptr(scale), L.ptr(shift), L.ptr(bound), groups, L.ptr(ly.wpacked),
-                                               ly.wexp, ly.cout, self.slope, self.passes, cfg, L.ptr(out), L.ptr(ws),
+                                               ly.wexp, ly.cout, slope, self.passes, cfg, L.ptr(out), L.ptr(ws),
                                                ws.numel(), L.ptr(rows[0]) if rows is not None else None, st),
                 "conv_mfma " + ly.name)
 
@@ -353,6 +368,7 @@ class UNetEngine:
             L.check(self.lib.bfm_conv3x3x3_direct(L.ptr(A), ca, L.ptr(B), cb, D, H, W, upp, L.ptr(scale),
                                                   L.ptr(shift), L.ptr(ly.wpacked), ly.cout, self.slope, L.ptr(out),
                                                   st), "conv_direct " + ly.name)
+        self._record(ly, A, B, dims, lo_dims, scale, shift, bound, out)
         return out
 
     def _skip_layer(self, ly, ca):
@@ -422,6 +438,7 @@ class UNetEngine:
             ev[1].record()
             self.prof.append((ev[0], ev[1], 2.0 * 27 * ca * ly.cout * nv, 4.0 * (nv * ca + 2 * nv * ly.cout), reps,
                               (tag + "sk", ca, ly.cout, tuple(dims), tuple(cfg))))
+        self._record(ly, A, B, dims, lo_dims, scale, shift, bound, out)
         return out
 
     def maxpool(self, X, dims):
@@ -437,6 +454,8 @@ class UNetEngine:
                                          L.stream_ptr()), "maxpool2")
         if rows is not None:
             out._bfm_rows = rows
+        if self.tape is not None:
+            self.tape.append(dict(pool_in=X, pool_dims=tuple(dims)))
         return out, (D // 2, H // 2, W // 2)
 
     # ------------------------------------------------------------------ backbone

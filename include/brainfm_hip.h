@@ -146,6 +146,11 @@ size_t bfm_gn_stats_rows_workspace(int nrowsA, int CA, int nrowsB, int CB);
 int bfm_gn_stats_rows(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB, double weightB,
                       int64_t nvox, const float* gamma, const float* beta, int G, float eps, float* scale,
                       float* shift, float* bound, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+/* the same with the per-group mean / rstd kept for the backward pass (NULL: not wanted) */
+int bfm_gn_stats_rows_train(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB, double weightB,
+                            int64_t nvox, const float* gamma, const float* beta, int G, float eps, float* scale,
+                            float* shift, float* bound, float* mean_out, float* rstd_out, void* workspace,
+                            size_t workspace_bytes, bfm_stream_t stream);
 
 size_t bfm_conv3x3x3_mfma_workspace(int Cin, int Cout, int D, int H, int W, int splitk);
 int bfm_conv3x3x3_mfma_plan(int Cin, int Cout, int D, int H, int W, int* cfg_out /*[8]*/);
