@@ -554,68 +554,92 @@ def _exchange_buffer(session, name, numel, dev):
     return t
 
 
+DIST_ROUNDS = os.environ.get("BFM_DIST_ROUNDS", "1") != "0"
+
+
 @torch.no_grad()
 def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 160], group=None,
-                                ops=None):
+                                ops=None, rounds=None):
     """Tiles are independent (GroupNorm statistics are per tile), so they shard over ranks with no
-    data-path collective; one gather to rank 0 at the end carries every rank's masked tile outputs, and
-    rank 0 accumulates them in the reference's tile order so the result is bit-identical to the
-    single-GPU path (fp32 += is order dependent where cnt reaches 8).
+    data-path collective; gathers to rank 0 carry every rank's masked tile outputs, and rank 0 accumulates them
+    in the reference's tile order so the result is bit-identical to the single-GPU path (fp32 += is order
+    dependent where cnt reaches 8).
+    rounds (default, BFM_DIST_ROUNDS=0 turns it off): every rank runs its tiles largest first and round k -- the k-th
+    tile of every rank -- leaves in its own asynchronous gather as soon as it is computed, so the transfers ride under
+    the next round's kernels and only the last (smallest) round's is exposed; otherwise ONE gather at the end.  With
+    27 tiles on 8 GPUs a rank computes ~20 ms and ships ~280 MB: the single gather would add ~1/3 to the step.
     Every rank holds full_im.  Returns (acc, ranges, cnt) on rank 0, (None, ranges, None) elsewhere.
     ``ops`` (run_tile/add/finalize) defaults to the HIP kernels; the gloo unit tests inject host ops
     to exercise the sharding / ordering logic without a GPU."""
     import torch.distributed as dist
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
+    if rounds is None:
+        rounds = DIST_ROUNDS
     if ops is None:
         ops = HipStitchOps(session)
     shape = tuple(full_im.shape[2:])
     ranges = tiling_ranges(shape, stride, win_size)
     owner = assign_tiles(ranges, world)
-    mine = [i for i in range(len(ranges)) if owner[i] == rank]
     dev = full_im.device
     direct = hasattr(ops, "add_all")                           # HIP ops write straight into the send buffer
     nkeys = getattr(ops, "n_keys", None)
+    if nkeys is None and hasattr(ops, "keys"):
+        nkeys = len(ops.keys)
     if nkeys is None and session is not None:
         nkeys = len(session.stitch_keys())
-    vox = [sum(tile_cost(ranges[i]) for i in range(len(ranges)) if owner[i] == r) for r in range(world)]
-    packed, keys, buf, off = [], None, None, 0
-    if direct and nkeys is not None:
-        buf = _exchange_buffer(session, "send", max(max(vox) * nkeys, 1), dev)     # padding is never read: no fill
-    for i in mine:
-        (x0, x1), (y0, y1), (z0, z1) = ranges[i]
-        im = full_im[:, :, x0:x1, y0:y1, z0:z1]
-        if buf is not None:
+    if nkeys is None:
+        nkeys = len(STITCH_KEYS)
+    # per rank: its tiles, largest first (ties in reference order); slot[i] = (round, offset in that round's buffer)
+    tiles_of = [sorted([i for i in range(len(ranges)) if owner[i] == r], key=lambda i: (-tile_cost(ranges[i]), i))
+                for r in range(world)]
+    nrounds = max(len(t) for t in tiles_of) if rounds else 1
+    round_of, off_of = {}, {}
+    round_numel = [0] * nrounds
+    for r in range(world):
+        fill = [0] * nrounds
+        for k, i in enumerate(tiles_of[r]):
+            kk = k if rounds else 0
+            round_of[i], off_of[i] = kk, fill[kk]
+            fill[kk] += tile_cost(ranges[i]) * nkeys
+        for kk in range(nrounds):
+            round_numel[kk] = max(round_numel[kk], fill[kk], 1)
+
+    def _buf(name, numel):
+        if session is not None and direct:
+            return _exchange_buffer(session, name, numel, dev)     # persistent; padding is never read: no fill
+        return torch.zeros(numel, dtype=torch.float32, device=dev)
+
+    keys = None
+    works, gathered = [], []
+    mine = tiles_of[rank]
+    for kk in range(nrounds):
+        sbuf = _buf("send%d" % kk, round_numel[kk])
+        todo = [i for i in mine if round_of[i] == kk]
+        for i in todo:
+            (x0, x1), (y0, y1), (z0, z1) = ranges[i]
+            im = full_im[:, :, x0:x1, y0:y1, z0:z1]
             n = tile_cost(ranges[i]) * nkeys
-            keys, _ = ops.run_tile(im, out=buf[off:off + n])
-            off += n
-        else:
-            keys, rows = ops.run_tile(im)
-            packed.append(rows.reshape(-1))
-    if buf is None:
-        nk = torch.tensor([0 if keys is None else len(keys)], device=dev)
-        dist.all_reduce(nk, op=dist.ReduceOp.MAX, group=group)
-        nkeys = int(nk.item())
-        buf = torch.zeros(max(max(vox) * nkeys, 1), dtype=torch.float32, device=dev)
-        if packed:
-            flat = torch.cat(packed)
-            buf[:flat.numel()] = flat
-    if rank == 0 and direct and session is not None:
-        gathered = [_exchange_buffer(session, "recv%d" % r, buf.numel(), dev) for r in range(world)]
-    else:
-        gathered = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, gathered, dst=0, group=group)
+            if direct:
+                keys, _ = ops.run_tile(im, out=sbuf[off_of[i]:off_of[i] + n])
+            else:
+                keys, rows = ops.run_tile(im)
+                if len(keys) != nkeys:
+                    raise RuntimeError("ops.run_tile returned %d maps, expected %d" % (len(keys), nkeys))
+                sbuf[off_of[i]:off_of[i] + n] = rows.reshape(-1)
+        g = [_buf("recv%d_%d" % (kk, r), round_numel[kk]) for r in range(world)] if rank == 0 else None
+        gathered.append(g)
+        works.append(dist.gather(sbuf, g, dst=0, group=group, async_op=True))
+    for w in works:
+        w.wait()
     if rank != 0:
         return None, ranges, None
     if keys is None:
         keys = (session.stitch_keys() if session is not None else [k for k in STITCH_KEYS])[:nkeys]
     acc_buf = torch.zeros((nkeys,) + shape, dtype=torch.float32, device=dev)
-    offs = [0] * world
     for i, rng in enumerate(ranges):                          # reference tile order
-        r = owner[i]
         nv = tile_cost(rng)
-        rows = gathered[r][offs[r]:offs[r] + nv * nkeys].reshape(nkeys, nv)
-        offs[r] += nv * nkeys
+        rows = gathered[round_of[i]][owner[i]][off_of[i]:off_of[i] + nv * nkeys].reshape(nkeys, nv)
         if direct:
             ops.add_all(acc_buf, rows, rng, shape)
         else:

@@ -164,8 +164,11 @@ def _worker(rank, world, port, q):
     torch.manual_seed(0)
     full = torch.rand(1, 1, 40, 36, 44)
     full[:, :, :6] = 0
-    acc, ranges, cnt = TU.tiled_inference_distributed(full, None, [12] * 3, [24] * 3, ops=_HostOps())
+    acc, ranges, cnt = TU.tiled_inference_distributed(full, None, [12] * 3, [24] * 3, ops=_HostOps())   # round-wise gathers
+    acc1, _, _ = TU.tiled_inference_distributed(full, None, [12] * 3, [24] * 3, ops=_HostOps(), rounds=False)
     if rank == 0:
+        for k in acc:
+            assert torch.equal(acc[k], acc1[k]), k            # one gather at the end gives the same bits
         q.put({k: v.numpy() for k, v in acc.items()})
     dist.barrier()
     dist.destroy_process_group()
