@@ -19,6 +19,13 @@ ly = _Layer(); ly.name, ly.cin, ly.cout, ly.groups = "bench", cin, cout, 8
 ly.w_raw = (torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05).contiguous()
 ly.packs, ly.kind, ly.wpacked, ly.wexp, ly.skip = {}, None, None, 0, None
 cfg = (C.c_int * 8)(); L.check(lib.bfm_conv3x3x3_mfma_plan(cin, cout, D, H, W, cfg), "plan"); cfg[6] = ver
+eng._conv_launch(ly, A, cin, None, 0, (D, H, W), None, scale, shift, bound, 8, cfg, out, ws)      # warm (packs weights)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
 for _ in range(reps):
     eng._conv_launch(ly, A, cin, None, 0, (D, H, W), None, scale, shift, bound, 8, cfg, out, ws)
+e1.record()
 torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+print("ver %d %dx%dx%d %d->%d: %.3f ms  %.1f TFLOP/s algorithmic" % (ver, D, H, W, cin, cout, ms, 2.0 * 27 * cin * cout * D * H * W / ms / 1e9))
