@@ -51,6 +51,8 @@ class UNetEngine:
     the way utils/checkpoint.py:558-571 suffix-matches names.
     """
     prof = None
+    lane = 0
+    _ws_lanes = None
     tape = None                 # training (backward.py): list that single_conv / maxpool append their records to
     prof_reps = 1
     use_upfold = False
@@ -71,7 +73,9 @@ class UNetEngine:
         self.eps = float(eps)
         self.slope = float(slope)
         self._up_cache = {}
-        self._ws = None
+        self._ws_lanes = {}
+        self._ws_retired = []
+        self.lane = 0
         self._plan_cache = {}
         self._tuned = set()
         self.force_direct = False
@@ -178,10 +182,16 @@ class UNetEngine:
         return self._up_cache[key][0]
 
     def _workspace(self, nbytes):
+        """Scratch of the current lane (tiles of different lanes run concurrently on their own streams)."""
         nbytes = max(int(nbytes), 256)
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=self.device)
-        return self._ws
+        if self._ws_lanes is None:
+            self._ws_lanes, self._ws_retired = {}, []
+        ws = self._ws_lanes.get(self.lane)
+        if ws is None or ws.numel() < nbytes:
+            if ws is not None:
+                self._ws_retired.append(ws)       # captured graphs of smaller shapes keep pointing into it
+            ws = self._ws_lanes[self.lane] = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=self.device)
+        return ws
 
     def _plan(self, cin, cout, dims, two_src=False, accum=False):
         key = (cin, cout, tuple(dims), bool(two_src), bool(accum))

@@ -286,7 +286,18 @@ class InferenceSession:
         self.use_graphs = False
         self._graph_seen = set()
         self._graphs = {}
-        self._graph_pool = None
+        self._graph_pool = {}
+        # Tiles of one volume are independent until they are stitched: with lanes > 1 consecutive tiles replay their
+        # graphs on separate streams (own static buffers, own scratch), so that one tile's small kernels (GroupNorm
+        # finalize, split-K reduce, pooling: ~10 % of a step at 8 blocks each) and kernel tails run under the other
+        # tile's convolutions.  Stitching stays on the caller's stream in the reference's tile order.
+        self.lanes = max(1, int(os.environ.get("BFM_LANES", "2")))
+        self._lane_streams = []
+
+    def lane_streams(self, n):
+        while len(self._lane_streams) < n:
+            self._lane_streams.append(torch.cuda.Stream(device=self.device))
+        return self._lane_streams[:n]
 
     def stitch_keys(self):
         """The keys tiled inference stitches for this head set, in STITCH_KEYS order."""
@@ -294,27 +305,41 @@ class InferenceSession:
         names = set(tail.map_names)
         return [k for k in STITCH_KEYS if k in names or (k == "label" and tail.desc.n_seg > 0)]
 
-    def graph_tile(self, im):
-        """Run one tile through backbone + tail via a captured hipGraph for its shape.
-        Returns what _run_tile(raw=True) returns; the buffers are static per shape and are overwritten by the
-        next replay of the same (or, the pool being shared, any) shape, so consume them on the same stream first."""
+    def graph_tile(self, im, lane=0):
+        """Run one tile through backbone + tail via a captured hipGraph for its shape (one graph, one set of static
+        buffers and one scratch area per lane).  Returns what _run_tile(raw=True) returns; the buffers are static per
+        (shape, lane) and are overwritten by the next replay of the same (or, a lane's pool being shared, any) shape of
+        that lane, so consume them first.  Runs on the current stream."""
         dims = tuple(im.shape[2:])
-        if dims not in self._graph_seen:
-            self._graph_seen.add(dims)
-            return _run_tile(self, im, raw=True)
-        if dims not in self._graphs:
+        key = (dims, lane)
+        eng = self.engine
+        if key not in self._graph_seen:
+            self._graph_seen.add(key)
+            eng.lane = lane
+            try:
+                return _run_tile(self, im, raw=True)
+            finally:
+                eng.lane = 0
+        if key not in self._graphs:
             static_in = torch.empty(tuple(im.shape), dtype=torch.float32, device=self.device)
             static_in.copy_(im)
-            if self._graph_pool is None:
-                self._graph_pool = torch.cuda.graph_pool_handle()
+            if lane not in self._graph_pool:
+                self._graph_pool[lane] = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self._graph_pool):
-                outs = _run_tile(self, static_in, raw=True)
-            self._graphs[dims] = (g, static_in, outs)
-        g, static_in, outs = self._graphs[dims]
+            eng.lane = lane
+            try:
+                with torch.cuda.graph(g, pool=self._graph_pool[lane]):
+                    outs = _run_tile(self, static_in, raw=True)
+            finally:
+                eng.lane = 0
+            self._graphs[key] = (g, static_in, outs)
+        g, static_in, outs = self._graphs[key]
         static_in.copy_(im)
         g.replay()
         return outs
+
+    def has_graph(self, dims, lane=0):
+        return (tuple(dims), lane) in self._graphs
 
     @property
     def engine(self):
@@ -448,19 +473,45 @@ def tiled_inference(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 1
     ranges = tiling_ranges(shape, stride, win_size)
     cnt = count_volume(shape, ranges, eng.device)
     acc_buf, keys, sel = None, None, None
-    for rng in ranges:
+    nl = session.lanes if graphs else 1
+    main = torch.cuda.current_stream(eng.device)
+    streams = session.lane_streams(nl) if nl > 1 else []
+    consumed = [None] * nl
+    start = torch.cuda.Event()
+    start.record(main)
+    for idx, rng in enumerate(ranges):
         (x0, x1), (y0, y1), (z0, z1) = rng
         im = full_im[:, :, x0:x1, y0:y1, z0:z1]
-        maps_buf, names, label, x_cl = session.graph_tile(im) if graphs else _run_tile(session, im, raw=True)
+        k = idx % nl
+        dims = (x1 - x0, y1 - y0, z1 - z0)
+        if nl > 1 and session.has_graph(dims, k):
+            st = streams[k]
+            # the lane waits for the stitch that consumed its previous outputs (first use: for the caller's stream as it
+            # stood at the start), NOT for the other lane's tile: that is the overlap
+            st.wait_event(consumed[k] if consumed[k] is not None else start)
+            with torch.cuda.stream(st):
+                maps_buf, names, label, x_cl = session.graph_tile(im, lane=k)
+                done = torch.cuda.Event()
+                done.record(st)
+            main.wait_event(done)
+        elif graphs:
+            if nl > 1:
+                torch.cuda.synchronize(eng.device)             # eager / capture passes run alone (warm-up only)
+            maps_buf, names, label, x_cl = session.graph_tile(im, lane=k)
+        else:
+            maps_buf, names, label, x_cl = _run_tile(session, im, raw=True)
         if acc_buf is None:
-            keys = [k for k in STITCH_KEYS if k in names or (k == "label" and label is not None)]
-            sel = torch.tensor([names.index(k) if k != "label" else -1 for k in keys], dtype=torch.int32,
+            keys = [k_ for k_ in STITCH_KEYS if k_ in names or (k_ == "label" and label is not None)]
+            sel = torch.tensor([names.index(k_) if k_ != "label" else -1 for k_ in keys], dtype=torch.int32,
                                device=eng.device)
             acc_buf = torch.zeros((len(keys),) + shape, dtype=torch.float32, device=eng.device)
         tv = (x1 - x0) * (y1 - y0) * (z1 - z0)
         L.check(lib.bfm_stitch_accumulate_multi(L.ptr(maps_buf), tv, L.ptr(sel), len(keys), L.ptr(label), L.ptr(x_cl),
                                                 x1 - x0, y1 - y0, z1 - z0, L.ptr(acc_buf), shape[0], shape[1],
                                                 shape[2], x0, y0, z0, L.stream_ptr()), "stitch_multi")
+        if nl > 1:
+            consumed[k] = torch.cuda.Event()
+            consumed[k].record(main)
     n = shape[0] * shape[1] * shape[2]
     L.check(lib.bfm_divide_by_count_multi(L.ptr(acc_buf), L.ptr(cnt), n, len(keys), L.stream_ptr()), "divide_by_count")
     acc = OrderedDict((k, acc_buf[j]) for j, k in enumerate(keys))
@@ -482,8 +533,9 @@ def prepare_tile_graphs(full_im, session, stride=[80, 80, 80], win_size=[160, 16
         done.add(dims)
         (x0, x1), (y0, y1), (z0, z1) = rng
         im = full_im[:, :, x0:x1, y0:y1, z0:z1].to(device=session.device, dtype=torch.float32)
-        while dims not in session._graphs:
-            session.graph_tile(im)
+        for lane in range(session.lanes):
+            while not session.has_graph(dims, lane):
+                session.graph_tile(im, lane=lane)
     torch.cuda.synchronize(session.device)
     return sorted(done)
 
@@ -507,18 +559,46 @@ class HipStitchOps:
         self.session = session
         self.lib = L.load()
         self._sel = {}
+        self._lane_after = {}
 
     def _identity(self, k, dev):
         if (k, dev) not in self._sel:
             self._sel[(k, dev)] = torch.arange(k, dtype=torch.int32, device=dev)
         return self._sel[(k, dev)]
 
-    def run_tile(self, im, out=None):
-        """Masked, float typed [K][n] rows of one tile (written into ``out`` when given: the send buffer)."""
-        if self.session.use_graphs:
-            maps_buf, names, label, x_cl = self.session.graph_tile(im)
+    def run_tile(self, im, out=None, lane=None, after=None):
+        """Masked, float typed [K][n] rows of one tile (written into ``out`` when given: the send buffer).
+        lane / after: replay the tile's graph and pack on that lane's stream once event ``after`` (recorded on the
+        caller's stream) has passed; the third return value is then the event to wait for before reading the rows."""
+        sess = self.session
+        dims = tuple(im.shape[2:])
+        on_lane = (lane is not None and sess.use_graphs and sess.lanes > 1 and sess.has_graph(dims, lane))
+        if on_lane:
+            st = sess.lane_streams(sess.lanes)[lane]
+            if after is not None:
+                st.wait_event(after)
+            if lane in self._lane_after:                       # an eager / capture pass of this lane ran on the caller's
+                st.wait_event(self._lane_after.pop(lane))      # stream: its buffers share the lane's graph pool
+            with torch.cuda.stream(st):
+                keys, rows = self._tile_rows(sess.graph_tile(im, lane=lane), out)
+                done = torch.cuda.Event()
+                done.record(st)
+            return keys, rows, done
+        if sess.use_graphs:
+            if lane is not None and sess.lanes > 1:
+                torch.cuda.synchronize(sess.device)            # eager / capture passes run alone (warm-up only)
+            outs = sess.graph_tile(im, lane=lane or 0)
         else:
-            maps_buf, names, label, x_cl = _run_tile(self.session, im, raw=True)
+            outs = _run_tile(sess, im, raw=True)
+        keys, rows = self._tile_rows(outs, out)
+        if lane is not None and sess.use_graphs and sess.lanes > 1:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(sess.device))
+            self._lane_after[lane] = ev
+        return (keys, rows, None) if lane is not None else (keys, rows)
+
+    def _tile_rows(self, outs, out):
+        maps_buf, names, label, x_cl = outs
         keys = [k for k in STITCH_KEYS if k in names or (k == "label" and label is not None)]
         skey = (tuple(names), label is not None)
         if skey not in self._sel:
@@ -613,6 +693,12 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
     keys = None
     works, gathered = [], []
     mine = tiles_of[rank]
+    lanes = session.lanes if (direct and session is not None and session.use_graphs and dev.type == "cuda") else 1
+    start = None
+    if lanes > 1:
+        start = torch.cuda.Event()
+        start.record(torch.cuda.current_stream(dev))           # send buffers are free, the input is in place
+    nrun = 0
     for kk in range(nrounds):
         sbuf = _buf("send%d" % kk, round_numel[kk])
         todo = [i for i in mine if round_of[i] == kk]
@@ -620,7 +706,14 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
             (x0, x1), (y0, y1), (z0, z1) = ranges[i]
             im = full_im[:, :, x0:x1, y0:y1, z0:z1]
             n = tile_cost(ranges[i]) * nkeys
-            if direct:
+            if direct and lanes > 1:
+                # consecutive tiles of this rank alternate between the lanes' streams; the gather of a round waits for
+                # that round's tiles only
+                keys, _, done = ops.run_tile(im, out=sbuf[off_of[i]:off_of[i] + n], lane=nrun % lanes, after=start)
+                nrun += 1
+                if done is not None:
+                    torch.cuda.current_stream(dev).wait_event(done)
+            elif direct:
                 keys, _ = ops.run_tile(im, out=sbuf[off_of[i]:off_of[i] + n])
             else:
                 keys, rows = ops.run_tile(im)

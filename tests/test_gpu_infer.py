@@ -71,7 +71,7 @@ def test_mfma_fragment_layout_exact_integers():
               "backbone.encoders.0.basic_module.SingleConv1.conv.weight": w}
         eng = UNetEngine.__new__(UNetEngine)
         eng.lib = L.load(); eng.device = dev; eng.num_groups = 8; eng.passes = 3; eng.eps = 1e-5; eng.slope = 0.01
-        eng._up_cache = {}; eng._ws = None; eng._plan_cache = {}; eng._tuned = set(); eng.force_direct = False
+        eng._up_cache = {}; eng._ws_lanes = None; eng._plan_cache = {}; eng._tuned = set(); eng.force_direct = False
         ly = eng._make_layer(sd, "backbone.encoders.0.basic_module.SingleConv1", cin, cout)
         cfgp = eng._plan(cin, cout, dims)
         eng._pack(ly, True, cfgp[6])
@@ -239,12 +239,16 @@ def test_tiled_graph_replay_equals_eager_bit_for_bit():
     full2 = torch.flip(full, dims=[2]) * 0.5 + 0.1
     eager = [TU.tiled_inference(v, s, [stride] * 3, [win] * 3, graphs=False)[0] for v in (full, full2)]
     eager = [{k: t.clone() for k, t in e.items()} for e in eager]
+    assert s.lanes >= 2                                              # consecutive tiles overlap on two streams
     shapes = TU.prepare_tile_graphs(full, s, [stride] * 3, [win] * 3)
-    assert len(s._graphs) == len(shapes) >= 1
-    for v, ref in zip((full, full2), eager):
-        acc, _, _ = TU.tiled_inference(v, s, [stride] * 3, [win] * 3, graphs=True)
-        for k in ref:
-            assert torch.equal(acc[k], ref[k]), k
+    assert len(s._graphs) == len(shapes) * s.lanes >= 2
+    for lanes in (s.lanes, 1, 3):                                    # 3: graphs of the third lane are captured lazily
+        s.lanes = lanes
+        for rep in range(3 if lanes == 3 else 1):
+            for v, ref in zip((full, full2), eager):
+                acc, _, _ = TU.tiled_inference(v, s, [stride] * 3, [win] * 3, graphs=True)
+                for k in ref:
+                    assert torch.equal(acc[k], ref[k]), (k, lanes, rep)
 
 
 def test_distributed_path_one_rank_rccl_equals_single_gpu_path():
@@ -268,10 +272,11 @@ def test_distributed_path_one_rank_rccl_equals_single_gpu_path():
     try:
         for graphs in (False, True):
             s.use_graphs = graphs
-            acc, _, cnt = TU.tiled_inference_distributed(full, s, [stride] * 3, [win] * 3)
-            assert list(acc.keys()) == list(ref.keys())
-            for k in ref:
-                assert torch.equal(acc[k], ref[k]), (k, graphs)
+            for rep in range(3 if graphs else 1):                    # third pass: every tile replays on its lane's stream
+                acc, _, cnt = TU.tiled_inference_distributed(full, s, [stride] * 3, [win] * 3)
+                assert list(acc.keys()) == list(ref.keys())
+                for k in ref:
+                    assert torch.equal(acc[k], ref[k]), (k, graphs, rep)
     finally:
         s.use_graphs = False
         dist.destroy_process_group()
@@ -437,7 +442,7 @@ def test_split_k_deep_layer_vs_oracle():
     eng = UNetEngine.__new__(UNetEngine)
     from brainfm_amd import _lib as L
     eng.lib = L.load(); eng.device = dev; eng.num_groups = 8; eng.passes = 3; eng.eps = 1e-5; eng.slope = 0.01
-    eng._up_cache = {}; eng._ws = None; eng._plan_cache = {}; eng._tuned = set(); eng.force_direct = False
+    eng._up_cache = {}; eng._ws_lanes = None; eng._plan_cache = {}; eng._tuned = set(); eng.force_direct = False
     ly = eng._make_layer(sd, name, cs + cx, cout)
     out = eng.single_conv(ly, skip[0].permute(1, 2, 3, 0).contiguous().to(dev), (5, 4, 5),
                           B=low[0].permute(1, 2, 3, 0).contiguous().to(dev), lo_dims=(2, 2, 2))
