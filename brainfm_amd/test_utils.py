@@ -328,7 +328,9 @@ class InferenceSession:
             g = torch.cuda.CUDAGraph()
             eng.lane = lane
             try:
-                with torch.cuda.graph(g, pool=self._graph_pool[lane]):
+                # thread_local: a collective still in flight on a communication thread (gloo stages through the host,
+                # RCCL's watchdog polls events) must not invalidate this thread's capture
+                with torch.cuda.graph(g, pool=self._graph_pool[lane], capture_error_mode="thread_local"):
                     outs = _run_tile(self, static_in, raw=True)
             finally:
                 eng.lane = 0
@@ -706,6 +708,10 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
             (x0, x1), (y0, y1), (z0, z1) = ranges[i]
             im = full_im[:, :, x0:x1, y0:y1, z0:z1]
             n = tile_cost(ranges[i]) * nkeys
+            if direct and session is not None and session.use_graphs and \
+                    not session.has_graph((x1 - x0, y1 - y0, z1 - z0), nrun % lanes if lanes > 1 else 0):
+                for w in works:                                    # warm-up only: no transfer in flight while a graph
+                    w.wait()                                       # is being captured
             if direct and lanes > 1:
                 # consecutive tiles of this rank alternate between the lanes' streams; the gather of a round waits for
                 # that round's tiles only

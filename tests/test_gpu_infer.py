@@ -282,6 +282,21 @@ def test_distributed_path_one_rank_rccl_equals_single_gpu_path():
         dist.destroy_process_group()
 
 
+def test_distributed_path_two_ranks_share_one_gpu():
+    """world_size 2 through the real HIP multi-GPU path: two gloo ranks share this GPU (RCCL refuses two ranks on one
+    device; the data path -- sharding, lanes, graph replay, pack, one asynchronous gather per round, accumulation in the
+    reference's tile order -- is backend independent).  Runs in child processes: this process already owns a group."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "two_rank_worker.py")], capture_output=True, text=True,
+                       timeout=600)
+    if not r.stdout.strip().endswith("OK"):
+        err = [ln for ln in r.stderr.splitlines() if "socket.cpp" not in ln]
+        raise AssertionError("two-rank run failed:\n%s\n%s" % (r.stdout[-1500:], "\n".join(err[-40:])))
+
+
 @pytest.mark.parametrize("passes,tol", [(3, TOL_NET), (1, 5e-2)])
 def test_mfma_network_vs_oracle(passes, tol):
     """64-wide 3-level net (all convs but the stem on MFMA), volume with an exact-zero background,
