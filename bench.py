@@ -94,6 +94,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # dry run of the N > 1 path on a one-GPU box: BFM_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # BFM_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks per device); never set for a measurement
+    if os.environ.get("BFM_BENCH_SHARE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("BFM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or args.dist_path
@@ -102,7 +107,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     n = args.size
     torch.manual_seed(1)                                   # default nn init under seed 1
