@@ -212,7 +212,8 @@ def main():
                        "algorithmic_tflop_per_step": flops_step / 1e12,
                        "end_to_end_tflops": flops_step * args.steps / dt / 1e12, "mfma_passes": args.passes,
                        "submission": "hipGraph replay per tile shape" if sess.use_graphs else "eager",
-                       "parallelism": "tiles sharded over %d rank(s), gather to rank 0" % world},
+                       "parallelism": "tiles sharded over %d rank(s), gather to rank 0" % world,
+                       "tiles_in_flight_per_gpu": sess.lanes if sess.use_graphs else 1},
             "roofline": {"bound": "mfma", "kernel": "conv_mfma* (the %d conv launches of one step, all variants)" % int(k_n),
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "kernel_ms_per_step": k_ms / max(world, 1), "avg_launch_us": k_ms * 1e3 / max(k_n, 1),
