@@ -214,9 +214,21 @@ class BaseGen(torch.utils.data.Dataset):
     # -------------------------------------------------------------- targets (Generator/utils.py:296-477)
     def _crop(self, vol, grid, dtype=torch.float32):
         [_, _, _, x1, y1, z1, x2, y2, z2] = grid
-        a = _vol(vol).get_fdata()[x1:x2, y1:y2, z1:z2]
-        return torch.squeeze(torch.tensor(a.astype(float if dtype == torch.float32 else int), dtype=dtype,
-                                          device=self.device))
+        v = _vol(vol)
+        # Crop first and convert the crop straight to the target type.  The reference goes array -> float64 (whole
+        # volume, get_fdata) -> crop -> float / int -> tensor(dtype): for float32, float64 and integer sources that chain
+        # rounds once, exactly like the direct conversion, so the values are the same; it cost 30 ms x 17 crops per item.
+        if isinstance(v, ArrayVolume):
+            src = v._d[x1:x2, y1:y2, z1:z2]
+        elif hasattr(v, "dataobj"):
+            src = np.asarray(v.dataobj[x1:x2, y1:y2, z1:z2])
+        else:
+            src = v.get_fdata()[x1:x2, y1:y2, z1:z2]
+        np_t = np.float32 if dtype == torch.float32 else np.int64
+        if not (np.issubdtype(src.dtype, np.floating) or np.issubdtype(src.dtype, np.integer)):
+            src = src.astype(np.float64)
+        arr = np.ascontiguousarray(src, dtype=np_t)
+        return torch.squeeze(torch.from_numpy(arr).to(device=self.device, dtype=dtype))
 
     def read_and_deform(self, vol, deform_dict, default_max=False, mean=0., scale=1.):
         """read_and_deform, Generator/utils.py:296-322."""

@@ -218,3 +218,18 @@ def test_generator_feeds_training_steps_and_loss_decreases():
         totals.append(tot)
     print("totals", [round(t, 4) for t in totals])
     assert totals[-1] < totals[0]
+
+
+def test_two_ranks_training_step_equals_averaged_gradients():
+    """DDP semantics at world_size 2 on the real kernels: two gloo ranks share this GPU, each trains on its own sample,
+    gradients are averaged by the flat all-reduce; every rank ends with the same parameters, equal to a single-process
+    step on the hand-averaged gradients (child processes: see tests/two_rank_train_worker.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "two_rank_train_worker.py")], capture_output=True, text=True,
+                       timeout=600)
+    if not r.stdout.strip().endswith("OK"):
+        err = [ln for ln in r.stderr.splitlines() if "socket.cpp" not in ln]
+        raise AssertionError("two-rank training run failed:\n%s\n%s" % (r.stdout[-1500:], "\n".join(err[-40:])))
