@@ -14,7 +14,6 @@ import torch
 from brainfm_amd import backward as BW
 from brainfm_amd import test_utils as TU
 from brainfm_amd import train as TR
-from oracle import unet_ref as O          # random_state_dict only (weights of the reference's shapes)
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 n_samples = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -28,8 +27,8 @@ if world > 1:
     import torch.distributed as dist
     dist.init_process_group("nccl", device_id=dev)
 ga, ta = TU.default_inference_args(f_maps=64, num_levels=6)
-sd = O.random_state_dict(1, 64, 6, seed=1)
-s = TU.InferenceSession(ga, ta, dev, state_dict=sd, passes=3)
+torch.manual_seed(1)                       # default nn init under seed 1, as bench.py
+s = TU.InferenceSession(ga, ta, dev, passes=3)
 tail = s.model.head.tail(s.engine)
 names = ["T1", "T1_grad", "T2", "T2_grad", "FLAIR", "FLAIR_grad", "CT", "CT_grad", "seg_ce", "seg_dice", "distance",
          "bias_field_log", "registration", "registration_grad", "SR", "SR_grad"]

@@ -1,4 +1,6 @@
-import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
 import torch, numpy as np
 from oracle import unet_ref as O
 from brainfm_amd import test_utils as TU, backward as BW

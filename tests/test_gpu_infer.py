@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 TOL_PARITY = 1e-4      # single blocks: max |a-b| / max|b| for fp32-grade paths
 TOL_NET = 1e-3         # whole network: the north-star tolerance.  F.normalize over few channels is
                        # ill-conditioned: torch-CPU fp32 itself sits 2e-4 from an fp64 evaluation of
-                       # the small golden net (scripts/diag_small.py), the HIP path 1.4e-4.
+                       # the small golden net (tests/diag/diag_small.py), the HIP path 1.4e-4.
 
 
 def _dev():
