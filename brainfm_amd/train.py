@@ -66,6 +66,18 @@ def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epoch
     return np.concatenate((warm, sched))
 
 
+def multistep_scheduler(base_value, lr_drops, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0.0, gamma=0.1):
+    """utils/misc.py:1251-1262 (the default lr schedule of cfgs/trainer/default_train.yaml).  Kept quirk: the milestones
+    index the array WITHOUT its warm-up part, so every drop lands warmup_epochs later than lr_drops says."""
+    import numpy as np
+    warm_iters = warmup_epochs * niter_per_ep
+    warm = np.linspace(start_warmup_value, base_value, warm_iters) if warmup_epochs > 0 else np.array([])
+    sched = np.ones(epochs * niter_per_ep - warm_iters) * base_value
+    for m in lr_drops:
+        sched[m * niter_per_ep:] *= gamma
+    return np.concatenate((warm, sched))
+
+
 def allreduce_mean_(grads, group=None):
     """DDP's gradient averaging (scripts/train.py:153-158) as ONE flat all-reduce over all parameters: xGMI rings are
     per-link bound, so a single ~100 MB bucket beats many small ones.  In place; no-op without a process group."""

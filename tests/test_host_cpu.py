@@ -353,6 +353,9 @@ def test_loss_scaler_and_cosine_schedule_host_logic():
     assert len(sch) == 8
     assert np.allclose(sch[:4], [0.0, 1 / 3, 2 / 3, 1.0])
     assert np.allclose(sch[4:], 0.5 * (1 + np.cos(np.pi * np.arange(4) / 4)))
+    # utils/misc.py:1251-1262 by hand: 4 epochs x 2 iterations, 1 warm-up epoch, drop at "epoch 1" of the post-warm-up array
+    ms = TR.multistep_scheduler(1.0, [1], 4, 2, warmup_epochs=1, gamma=0.1)
+    assert np.allclose(ms, [0.0, 1.0, 1.0, 1.0, 0.1, 0.1, 0.1, 0.1])
     import pytest
     from brainfm_amd import _lib as L
     with pytest.raises(L.BfmError):
