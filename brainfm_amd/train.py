@@ -143,6 +143,69 @@ class TrainStep:
                 ly.wpacked, ly.kind, ly.skip = None, None, None
         self.tail.desc.head_wmax = float(self.tail.head_w.abs().max().item())
 
+    # ------------------------------------------------------------------ checkpoints (scripts/train.py:205-214)
+    def _ref_shape(self, name, t):
+        if name.startswith("head.") and name.endswith(".weight"):
+            return tuple(t.shape) + (1, 1, 1)                      # nn.Conv3d(C, n, 1) weight
+        return tuple(t.shape)
+
+    def state_dict(self):
+        """The model's state_dict under the reference's names and shapes (CPU copies)."""
+        return OrderedDict((k, v.detach().reshape(self._ref_shape(k, v)).cpu().clone()) for k, v in self.parameters().items())
+
+    def optimizer_state_dict(self, lr=None, weight_decay=None):
+        """torch.optim.AdamW.state_dict() layout for the single parameter group of scripts/train.py:46-53 (parameters in
+        model.named_parameters() order == self.parameters() order)."""
+        names = list(self.parameters().keys())
+        state = {}
+        for i, k in enumerate(names):
+            if k in self.state:
+                m, v = self.state[k]
+                shp = self._ref_shape(k, self.parameters()[k])
+                state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": m.reshape(shp).cpu().clone(),
+                            "exp_avg_sq": v.reshape(shp).cpu().clone()}
+        group = {"lr": self.lr if lr is None else lr, "betas": tuple(self.betas), "eps": self.eps,
+                 "weight_decay": self.wd if weight_decay is None else weight_decay, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(names)))}
+        return {"state": state, "param_groups": [group]}
+
+    def save_checkpoint(self, path, epoch=0, **extra):
+        """torch.save of {'model', 'optimizer', 'epoch', ...}: what utils.save_on_master writes in scripts/train.py, and
+        what brainfm_amd.models.load_checkpoint / the reference's load_checkpoint read back."""
+        ckp = {"model": self.state_dict(), "optimizer": self.optimizer_state_dict(), "epoch": int(epoch),
+               "scaler_scale": self.scaler.scale}
+        ckp.update(extra)
+        torch.save(ckp, path)
+
+    def load_checkpoint(self, path):
+        """Parameters (matched by name suffix, as utils/checkpoint.py:558-571) and AdamW moments back into the engine."""
+        ckp = torch.load(path, map_location="cpu", weights_only=False)
+        key = next((k for k in ckp if "model" in k), None)
+        sd = ckp[key] if key is not None else ckp
+        params = self.parameters()
+        for k, p in params.items():
+            cands = [lk for lk in sd if lk == k or lk.endswith("." + k) or k.endswith("." + lk)]
+            if not cands:
+                raise KeyError("checkpoint has no tensor matching '%s'" % k)
+            src = sd[max(cands, key=len)]
+            if src.numel() != p.numel():
+                raise ValueError("shape mismatch for %s: %s vs %s" % (k, tuple(src.shape), tuple(p.shape)))
+            p.copy_(src.reshape(p.shape).to(device=self.dev, dtype=torch.float32))
+        self._weights_changed()
+        opt = ckp.get("optimizer")
+        if opt and opt.get("state"):
+            names = list(params.keys())
+            self.state = {}
+            for i, st in opt["state"].items():
+                k = names[int(i)]
+                self.state[k] = (st["exp_avg"].reshape(-1).to(device=self.dev, dtype=torch.float32).contiguous(),
+                                 st["exp_avg_sq"].reshape(-1).to(device=self.dev, dtype=torch.float32).contiguous())
+                self.t = int(float(st["step"]))
+        if "scaler_scale" in ckp and self.scaler.enabled:
+            self.scaler.scale = float(ckp["scaler_scale"])
+        return ckp
+
     # ------------------------------------------------------------------ losses
     def _col(self, task, j=0):
         r0, n = self.tail.row_of[task]

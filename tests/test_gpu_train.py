@@ -233,3 +233,38 @@ def test_two_ranks_training_step_equals_averaged_gradients():
     if not r.stdout.strip().endswith("OK"):
         err = [ln for ln in r.stderr.splitlines() if "socket.cpp" not in ln]
         raise AssertionError("two-rank training run failed:\n%s\n%s" % (r.stdout[-1500:], "\n".join(err[-40:])))
+
+
+def test_checkpoint_round_trip_resumes_bit_identically(tmp_path):
+    """save_checkpoint writes the reference's {'model', 'optimizer', 'epoch'} file (reference parameter names and shapes,
+    torch-AdamW state layout); a fresh session that loads it continues exactly like the one that kept running, and
+    torch.optim.AdamW accepts the optimizer part for a module with the same parameter list."""
+    c = load_case()
+    a, xs, target, samples = _build(c)
+    a.step(xs, target, samples)
+    path = str(tmp_path / "brainfm_pretrained.pth")
+    a.save_checkpoint(path, epoch=3)
+    ckp = torch.load(path, map_location="cpu", weights_only=False)
+    assert ckp["epoch"] == 3 and set(ckp["model"].keys()) == set(c["names"])
+    assert tuple(ckp["model"]["head.final_conv_T1.weight"].shape) == (1, c["f_maps"], 1, 1, 1)
+    # torch's own optimiser takes the state (same parameter order and shapes)
+    ps = [torch.nn.Parameter(v.clone()) for v in ckp["model"].values()]
+    opt = torch.optim.AdamW(ps)
+    opt.load_state_dict(ckp["optimizer"])
+    assert float(opt.state[ps[0]]["step"]) == 1.0
+    b, _, _, _ = _build(c)
+    b.load_checkpoint(path)
+    assert b.t == 1
+    la, ta, _ = a.step(xs, target, samples)
+    lb, tb, _ = b.step(xs, target, samples)
+    assert ta == tb
+    pa, pb = a.parameters(), b.parameters()
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+    # the inference loader reads the same file
+    from brainfm_amd import models as M
+    from brainfm_amd import test_utils as TU
+    ga, ta_ = TU.default_inference_args(f_maps=c["f_maps"], num_levels=c["levels"], left_hemis_only=True,
+                                        num_groups=c["groups"])
+    s = TU.InferenceSession(ga, ta_, _dev(), ckp_path=path, passes=3)
+    assert torch.equal(s.engine.enc[0][0].w_raw.cpu(), ckp["model"][s.engine.enc[0][0].name + ".conv.weight"])
