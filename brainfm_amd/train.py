@@ -121,6 +121,7 @@ class TrainStep:
         self.state = {}                                   # name -> (m, v)
         nseg = tail.desc.n_seg
         self._ws = torch.empty(self.lib.bfm_loss_workspace(max(nseg, 1)), dtype=torch.uint8, device=self.dev)
+        self._ws_multi = torch.empty(self.lib.bfm_loss_l1_multi_workspace(), dtype=torch.uint8, device=self.dev)
 
     # ------------------------------------------------------------------ parameters
     def parameters(self):
@@ -228,6 +229,8 @@ class TrainStep:
         ws, wsn = L.ptr(self._ws), self._ws.numel()
         slots = {}
         k = 0
+        dense = []                                        # (slot index, col, target, weight, mask, clamp, l2, coef): one launch
+        keep = []                                         # tensors the deferred launch reads
 
         def slot(name, n=1):
             nonlocal k
@@ -253,8 +256,8 @@ class TrainStep:
                     L.check(lib.bfm_loss_grad_l1(L.ptr(raw), n_out, co, L.ptr(tgt), L.ptr(wt), D, H, W, coef, L.ptr(dRaw),
                                                  slot(name), ws, wsn, st), "loss_grad_l1 " + name)
                 else:
-                    L.check(lib.bfm_loss_l1(L.ptr(raw), n_out, co, L.ptr(tgt), L.ptr(wt), None, nvox, 0.0, 0, coef,
-                                            L.ptr(dRaw), slot(name), ws, wsn, st), "loss_l1 " + name)
+                    slot(name)
+                    dense.append((k - 1, co, tgt, wt, None, 0.0, 0, coef))
             elif name in ("distance", "registration", "registration_grad"):
                 head = "registration" if name.startswith("registration") else "distance"
                 if head not in target or head not in self.tail.row_of:
@@ -270,15 +273,15 @@ class TrainStep:
                                                      L.ptr(dRaw), slot(name), ws, wsn, st), "loss_grad_l1 " + name)
                     else:
                         clampv = self.max_dist if head == "distance" else 0.0
-                        L.check(lib.bfm_loss_l1(L.ptr(raw), n_out, co, L.ptr(tgt[j]), None, None, nvox, clampv, 0,
-                                                coef / nch, L.ptr(dRaw), slot(name), ws, wsn, st), "loss_l1 " + name)
+                        slot(name)
+                        dense.append((k - 1, co, tgt[j], None, None, clampv, 0, coef / nch))
             elif name == "bias_field_log":
                 if "bias_field_log" not in sample or "bias_field_log" not in self.tail.row_of:
                     continue
                 mask = 1.0 - self._t(target["segmentation"], dims).reshape(-1, D, H, W)[0]
                 tgt = self._t(sample["bias_field_log"], dims)
-                L.check(lib.bfm_loss_l1(L.ptr(raw), n_out, self._col("bias_field_log"), L.ptr(tgt), None, L.ptr(mask), nvox,
-                                        0.0, self.bias_l2, coef, L.ptr(dRaw), slot(name), ws, wsn, st), "loss bias_field_log")
+                slot(name)
+                dense.append((k - 1, self._col("bias_field_log"), tgt, None, mask, 0.0, self.bias_l2, coef))
             elif name == "seg_ce":
                 # CE and Dice share the softmax: one launch covers both names
                 r0, ns = self.tail.row_of["segmentation"]
@@ -295,6 +298,26 @@ class TrainStep:
                     P = torch.empty((nvox, ns), dtype=torch.float32, device=self.dev)
                     L.check(lib.bfm_loss_seg(L.ptr(raw), n_out, r0, ns, L.ptr(tgt), L.ptr(self.wce), L.ptr(self.wce), nvox,
                                              0.0, coef, L.ptr(P), L.ptr(dRaw), slot("seg", 1 + 2 * ns), ws, wsn, st), "loss_seg")
+        # every l1 / l2 entry in batches of 32 per launch (one pass over raw each); results go to a staging row and from
+        # there to their slots
+        for b0 in range(0, len(dense), 32):
+            batch = dense[b0:b0 + 32]
+            n = len(batch)
+            cols = (C.c_int32 * n)(*[e[1] for e in batch])
+            l2s = (C.c_int32 * n)(*[e[6] for e in batch])
+            clamps = (C.c_float * n)(*[e[5] for e in batch])
+            coefs = (C.c_float * n)(*[e[7] for e in batch])
+            tg = (C.c_void_p * n)(*[e[2].data_ptr() for e in batch])
+            wt = (C.c_void_p * n)(*[(e[3].data_ptr() if e[3] is not None else None) for e in batch])
+            mk = (C.c_void_p * n)(*[(e[4].data_ptr() if e[4] is not None else None) for e in batch])
+            keep.extend([e[2] for e in batch] + [e[3] for e in batch] + [e[4] for e in batch])
+            stage = torch.empty(n, dtype=torch.float64, device=self.dev)
+            wsm = self._ws_multi
+            L.check(lib.bfm_loss_l1_multi(L.ptr(raw), n_out, nvox, n, cols, l2s, clamps, coefs, tg, wt, mk, L.ptr(dRaw),
+                                          L.ptr(stage), L.ptr(wsm), wsm.numel(), st), "loss_l1_multi")
+            idx = torch.tensor([e[0] for e in batch], dtype=torch.int64, device=self.dev)
+            vals.index_copy_(0, idx, stage)
+        self._keep = keep
         return slots, k
 
     def _finish_losses(self, per_sample, nvox):

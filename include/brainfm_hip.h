@@ -430,6 +430,13 @@ size_t bfm_loss_workspace(int ns);
 int bfm_loss_l1(const float* raw, int n_out, int co, const float* target, const float* weight, const float* mask_mul,
                 int64_t nvox, float clampv, int l2 /* 1: mean squared error (bias_field_log_type 'l2') */, float coef,
                 float* dRaw, double* loss_out, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+/* n <= 32 l1 / l2 entries of one sample in one pass over raw (host arrays of n columns, l2 flags, clamps, coefficients and
+ * device pointers; weights / masks arrays or their elements may be NULL); loss_out [n] (device, fp64 means) */
+size_t bfm_loss_l1_multi_workspace(void);
+int bfm_loss_l1_multi(const float* raw, int n_out, int64_t nvox, int n, const int32_t* cols, const int32_t* l2,
+                      const float* clampv, const float* coef, const float* const* targets, const float* const* weights,
+                      const float* const* masks, float* dRaw, double* loss_out, void* workspace, size_t workspace_bytes,
+                      bfm_stream_t stream);
 int bfm_loss_grad_l1(const float* raw, int n_out, int co, const float* target, const float* weight, int D, int H, int W,
                      float coef, float* dRaw, double* loss_out, void* workspace, size_t workspace_bytes,
                      bfm_stream_t stream);
