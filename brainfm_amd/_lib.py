@@ -91,6 +91,7 @@ SIGNATURES = {
     "bfm_grid_grad3d_linear": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, C.POINTER(_I), _I, _P, _P]),
     "bfm_gn_stats_train": (_I, [_P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P, _Z, _P]),
     "bfm_lrelu_bwd": (_I, [_P, _P, _L, _F, _P, _P]),
+    "bfm_lrelu_bwd_ex": (_I, [_P, _P, _L, _F, _P, _P, _P]),
     "bfm_conv3x3x3_wgrad_workspace": (_Z, [_I, _I, _I, _I, _I]),
     "bfm_conv3x3x3_wgrad": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _P, _P, _Z, _P]),
     "bfm_conv3x3x3_wgrad_ex": (_I, [_P, _I, _P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _P, _P, _I, _I, _P, _P, _Z, _P]),

@@ -116,10 +116,10 @@ def backward_single_conv(eng, t, dY, need_input_grad=True):
     lib = eng.lib
     dY = dY.contiguous()
     dP = torch.empty_like(dY)
-    L.check(lib.bfm_lrelu_bwd(L.ptr(dY), L.ptr(t.out), dY.numel(), eng.slope, L.ptr(dP), st), "lrelu_bwd")
+    bnd = torch.empty(1, dtype=torch.float32, device=dev)         # max |dP|, written by the same kernel
+    L.check(lib.bfm_lrelu_bwd_ex(L.ptr(dY), L.ptr(t.out), dY.numel(), eng.slope, L.ptr(dP), L.ptr(bnd), st), "lrelu_bwd")
     up = eng._upsample_desc(t.lo_dims, t.dims) if t.B is not None else None
     upp = C.byref(up) if up is not None else None
-    bnd = torch.maximum(dP.max(), -dP.min()).reshape(1).to(torch.float32)
     # ---- weight gradient (split-fp16 matrix-core kernel on the wide layers, exact fp32 one elsewhere / on request)
     wsb = lib.bfm_conv3x3x3_wgrad_workspace(ly.cin, ly.cout, D, H, W)
     ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)

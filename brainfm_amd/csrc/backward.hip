@@ -21,14 +21,23 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 // ----------------------------------------------------------------------------- LeakyReLU
 __global__ void lrelu_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y, int64_t n4, float slope,
-                                 float* __restrict__ dP) {
+                                 float* __restrict__ dP, float* __restrict__ absmax) {
     const float4* a = reinterpret_cast<const float4*>(dY);
     const float4* y = reinterpret_cast<const float4*>(Y);
     float4* o = reinterpret_cast<float4*>(dP);
+    float m = 0.f;
     GRID_STRIDE(i, n4) {
         const float4 g = a[i], v = y[i];
-        o[i] = make_float4(v.x > 0.f ? g.x : g.x * slope, v.y > 0.f ? g.y : g.y * slope, v.z > 0.f ? g.z : g.z * slope,
-                           v.w > 0.f ? g.w : g.w * slope);
+        const float4 r = make_float4(v.x > 0.f ? g.x : g.x * slope, v.y > 0.f ? g.y : g.y * slope,
+                                     v.z > 0.f ? g.z : g.z * slope, v.w > 0.f ? g.w : g.w * slope);
+        o[i] = r;
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
+    }
+    if (absmax) {                                         // max |dP| for the kernels that rescale dP (order independent)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+        if ((threadIdx.x & 63) == 0 && m > 0.f)
+            atomicMax(reinterpret_cast<int*>(absmax), __float_as_int(m));    // non-negative floats order like ints
     }
 }
 
@@ -759,14 +768,71 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ in, const float* _
     }
 }
 
+// window-centric form for C % 4 == 0: one thread per (2x2x2 window, channel quad) reads the window once (8 float4), finds
+// the first maximum per channel in scan order and writes the 8 outputs; the element-centric kernel above re-reads the
+// window from every one of its 8 voxels (0.8 TB/s at 128^3).  Odd trailing slices (outside every window) are zero-filled
+// by the threads of the last window along that axis.
+__global__ void maxpool2_bwd4_kernel(const float* __restrict__ in, const float* __restrict__ dOut, int C, int D, int H,
+                                     int W, float* __restrict__ dIn) {
+    const int d = D / 2, h = H / 2, w = W / 2, CQ = C >> 2;
+    const int64_t n = (int64_t)d * h * w * CQ;
+    GRID_STRIDE(i, n) {
+        const int q = (int)(i % CQ);
+        int64_t u = i / CQ;
+        const int ux = (int)(u % w); u /= w;
+        const int uy = (int)(u % h);
+        const int uz = (int)(u / h);
+        float4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int zz = 2 * uz + (k >> 2), yy = 2 * uy + ((k >> 1) & 1), xx = 2 * ux + (k & 1);
+            v[k] = *reinterpret_cast<const float4*>(in + ((int64_t)(zz * H + yy) * W + xx) * C + q * 4);
+        }
+        const float4 g = *reinterpret_cast<const float4*>(dOut + ((int64_t)(uz * h + uy) * w + ux) * C + q * 4);
+        int am[4] = {0, 0, 0, 0};
+        float mx[4] = {v[0].x, v[0].y, v[0].z, v[0].w};
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            const float e[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (e[c] > mx[c]) { mx[c] = e[c]; am[c] = k; }            // strict: the first maximum wins
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int zz = 2 * uz + (k >> 2), yy = 2 * uy + ((k >> 1) & 1), xx = 2 * ux + (k & 1);
+            const float4 o = make_float4(am[0] == k ? g.x : 0.f, am[1] == k ? g.y : 0.f, am[2] == k ? g.z : 0.f,
+                                         am[3] == k ? g.w : 0.f);
+            *reinterpret_cast<float4*>(dIn + ((int64_t)(zz * H + yy) * W + xx) * C + q * 4) = o;
+        }
+        // odd trailing slices
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool lx = (ux == w - 1) && (W & 1), ly = (uy == h - 1) && (H & 1), lz = (uz == d - 1) && (D & 1);
+        const int x1 = lx ? 3 : 2, y1 = ly ? 3 : 2, z1 = lz ? 3 : 2;
+        if (lx || ly || lz)
+            for (int dz = 0; dz < z1; ++dz)
+                for (int dy = 0; dy < y1; ++dy)
+                    for (int dx = 0; dx < x1; ++dx)
+                        if (dz == 2 || dy == 2 || dx == 2)
+                            *reinterpret_cast<float4*>(dIn + ((int64_t)((2 * uz + dz) * H + 2 * uy + dy) * W + 2 * ux + dx) * C + q * 4) = z4;
+    }
+}
+
 int grid_for(int64_t n) { return (int)std::min<int64_t>(4096, bfm_cdiv64(n, 256)); }
 
 }  // namespace
 
-extern "C" int bfm_lrelu_bwd(const float* dY, const float* Y, int64_t n, float slope, float* dP, bfm_stream_t stream) {
-    if (!dY || !Y || !dP || n <= 0 || n % 4) return BFM_E_ARG;
-    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, bfm_s(stream), dY, Y, n / 4, slope, dP);
+extern "C" int bfm_lrelu_bwd_ex(const float* dY, const float* Y, int64_t n, float slope, float* dP, float* absmax,
+                                bfm_stream_t stream) {
+    if (!dY || !Y || !dP || n <= 0) return BFM_E_ARG;
+    if (n % 4) return BFM_E_SHAPE;
+    if (absmax && hipMemsetAsync(absmax, 0, sizeof(float), bfm_s(stream)) != hipSuccess) return BFM_E_LAUNCH;
+    hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, bfm_s(stream), dY, Y, n / 4, slope, dP, absmax);
     return bfm_launch_status();
+}
+
+extern "C" int bfm_lrelu_bwd(const float* dY, const float* Y, int64_t n, float slope, float* dP, bfm_stream_t stream) {
+    return bfm_lrelu_bwd_ex(dY, Y, n, slope, dP, nullptr, stream);
 }
 
 namespace {
@@ -923,6 +989,11 @@ extern "C" int bfm_maxpool2_bwd(const float* in, const float* dOut, int C, int D
                                 bfm_stream_t stream) {
     if (!in || !dOut || !dIn || C <= 0 || D < 2 || H < 2 || W < 2) return BFM_E_ARG;
     const int64_t n = (int64_t)D * H * W * C;
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), in, dOut, C, D, H, W, dIn);
+    if (C % 4 == 0) {
+        const int64_t nq = (int64_t)(D / 2) * (H / 2) * (W / 2) * (C / 4);
+        hipLaunchKernelGGL(maxpool2_bwd4_kernel, dim3(grid_for(nq)), dim3(256), 0, bfm_s(stream), in, dOut, C, D, H, W, dIn);
+    } else {
+        hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), in, dOut, C, D, H, W, dIn);
+    }
     return bfm_launch_status();
 }

@@ -397,6 +397,9 @@ int bfm_reduce_f64(int op, const double* x, const double* y, int64_t n, double* 
  *   gn_bwd       dXn -> dA (skip channels), dB (low-res channels: sum over the replica box), dgamma, dbeta
  *   maxpool2_bwd gradient to the first maximum of each 2x2x2 window (scan order dz,dy,dx), zeros elsewhere */
 int bfm_lrelu_bwd(const float* dY, const float* Y, int64_t n, float slope, float* dP, bfm_stream_t stream);
+/* the same, also writing max |dP| (device float; the split-fp16 weight / data gradient kernels scale dP by it) */
+int bfm_lrelu_bwd_ex(const float* dY, const float* Y, int64_t n, float slope, float* dP, float* absmax,
+                     bfm_stream_t stream);
 size_t bfm_conv3x3x3_wgrad_workspace(int Cin, int Cout, int D, int H, int W);
 int bfm_conv3x3x3_wgrad(const float* dP, int Cout, const float* A, int CA, const float* B, int CB, int D, int H, int W,
                         const bfm_upsample_t* up, const float* scale, const float* shift, float* dW /*[Cout][Cin][27]*/,
