@@ -12,7 +12,9 @@ Parity note: nibabel is absent from this image, so these readers are pinned to t
 headers in tests/test_host_cpu.py), not to nibabel output.
 """
 import gzip
+import os
 import struct
+import zlib
 
 import numpy as np
 
@@ -23,8 +25,61 @@ _MGH_DTYPES = {0: ">u1", 1: ">i4", 3: ">f4", 4: ">i2"}
 _MGH_CODES = {"u1": 0, "i4": 1, "f4": 3, "i2": 4}
 
 
+class _ParallelGzipWriter:
+    """Write-only gzip file built from independent members compressed in a thread pool (zlib releases the GIL): a
+    multi-member stream is plain RFC 1952 gzip, read back by gzip / nibabel / zcat like any other.  Level 1 is
+    nibabel's own default for .nii.gz / .mgz (nibabel.openers.Opener.default_compresslevel); python's gzip.open default
+    (9) took 23 s for one 256^3 float32 map -- 17 stitched maps per volume made writing the output cost 400 s against
+    0.14 s of inference (reference quirk Q5 made worse).  With 8 threads: 0.3 s per map."""
+
+    CHUNK = 4 << 20
+
+    def __init__(self, filename, level=1, threads=None):
+        self._f = open(filename, "wb")
+        self._buf = []
+        self._level = level
+        self._threads = threads or min(16, os.cpu_count() or 1)
+
+    def write(self, data):
+        self._buf.append(bytes(data) if not isinstance(data, (bytes, bytearray, memoryview)) else data)
+        return len(data)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def close(self):
+        if self._f is None:
+            return
+        raw = b"".join(self._buf)
+        self._buf = []
+        view = memoryview(raw)
+        chunks = [view[i:i + self.CHUNK] for i in range(0, len(raw), self.CHUNK)] or [view]
+        level = self._level
+
+        def comp(c):
+            z = zlib.compressobj(level, zlib.DEFLATED, 31)          # wbits 31: gzip container
+            return z.compress(c) + z.flush()
+
+        if len(chunks) > 1 and self._threads > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(self._threads) as ex:
+                parts = list(ex.map(comp, chunks))
+        else:
+            parts = [comp(c) for c in chunks]
+        for p_ in parts:
+            self._f.write(p_)
+        self._f.close()
+        self._f = None
+
+
 def _open(filename, mode="rb"):
     if filename.endswith((".gz", ".mgz")):
+        if "w" in mode:
+            return _ParallelGzipWriter(filename)
         return gzip.open(filename, mode)
     return open(filename, mode)
 
