@@ -245,7 +245,12 @@ def _write_nifti1(volume, aff, filename):
     with _open(filename, "wb") as f:
         f.write(bytes(hdr))
         f.write(b"\x00\x00\x00\x00")                                     # extension flag -> data at byte 352
-        f.write(np.asfortranarray(vol.astype(vol.dtype.newbyteorder("<"))).tobytes(order="F"))
+        if vol.dtype.byteorder == ">":
+            vol = vol.astype(vol.dtype.newbyteorder("<"))
+        # the file holds x fastest: a Fortran-contiguous array goes out as it lies in memory (its transpose is a
+        # C-contiguous view), anything else is transposed once; no .tobytes() copy on top
+        data = vol if vol.flags.f_contiguous else np.asfortranarray(vol)
+        f.write(memoryview(np.ascontiguousarray(data.T)).cast("B"))
 
 
 # ----------------------------------------------------------------------------- MGH / MGZ
@@ -344,3 +349,43 @@ def MRIwrite(volume, aff, filename, dtype=None):
         _write_mgh(volume, aff, filename)
     else:
         _write_nifti1(volume, aff, filename)
+
+
+def write_device_volumes(volumes, aff, directory, ext=".nii", threads=None, names=None):
+    """Write a dict of device (or host) volumes {name: (D,H,W) tensor} as <directory>/<name><ext> -- the tail of
+    scripts/demo_test.py:108-119 (one utils.MRIwrite per output key).  The axis reversal NIfTI wants (x fastest) is done
+    on the device, the copy to the host lands in one pinned staging buffer per map, and the files are written from a
+    thread pool (file writes and zlib release the GIL).  'label'-like integer maps keep their dtype."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(directory, exist_ok=True)
+    items = list(volumes.items())
+    host = []
+    for k, v in items:
+        if isinstance(v, torch.Tensor):
+            t = v
+            if t.dtype == torch.int64:
+                t = t.to(torch.int32)
+            if t.is_cuda:
+                tt = t.permute(*reversed(range(t.dim()))).contiguous()          # (W,H,D) C-order == (D,H,W) F-order
+                pin = torch.empty(tt.shape, dtype=tt.dtype, pin_memory=True)
+                pin.copy_(tt, non_blocking=True)
+                host.append((k, pin, True))
+            else:
+                host.append((k, t.numpy(), False))
+        else:
+            host.append((k, np.asarray(v), False))
+    if any(h[2] for h in host):
+        torch.cuda.synchronize()
+    paths = []
+
+    def one(entry):
+        k, a, rev = entry
+        arr = a.numpy().T if rev else a                                         # .T of the reversed copy: F-contiguous view
+        path = os.path.join(directory, (names[k] if names else k) + ext)
+        MRIwrite(arr, aff, path)
+        return path
+
+    with ThreadPoolExecutor(threads or min(8, os.cpu_count() or 1)) as ex:
+        paths = list(ex.map(one, host))
+    return paths
