@@ -41,6 +41,9 @@ struct UpParams {
     int bw_shift, bhw_shift;
     int nTy, nTx, nMt, NT, KCB;
     int nvox_lds, plane_stride;
+    int kc_per_split;                // K chunks per blockIdx.y slab (a multiple of 3: the weight ring's phase period)
+    float* slab;                     // split-K: [gridDim.y][2d][2h][2w][Cout] partial sums, summed by upfold_reduce
+    int64_t slab_stride;
 };
 
 __device__ __forceinline__ int row_perm(int l) {        // same lane -> row order as conv_mfma (conflict-free b128)
@@ -145,8 +148,10 @@ __global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) dst[f] = wbase[(size_t)sc * (NF * 64) + f * 64];
     };
-    fetch(0, wq[0]);
-    fetch(1, wq[1]);
+    const int kc0 = blockIdx.y * p.kc_per_split;                  // kc0 % 3 == 0: (kc0 * 8) % 3 == 0, the ring starts at set 0
+    const int kc1 = min(p.KCB, kc0 + p.kc_per_split);
+    fetch(kc0 * 8, wq[0]);
+    fetch(kc0 * 8 + 1, wq[1]);
 
     // one K-chunk; PH = (kc*8) % 3 is the ring phase, passed as a compile-time constant so that every register-set
     // index below is static (the chunk loop is unrolled by three: 8 % 3 == 2 advances the phase by two per chunk)
@@ -220,14 +225,15 @@ __global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
             }
         }
     };
-    for (int kc = 0; kc < p.KCB; kc += 3) {
+    for (int kc = kc0; kc < kc1; kc += 3) {
         do_chunk(kc, std::integral_constant<int, 0>{});
-        if (kc + 1 < p.KCB) do_chunk(kc + 1, std::integral_constant<int, 2>{});
-        if (kc + 2 < p.KCB) do_chunk(kc + 2, std::integral_constant<int, 1>{});
+        if (kc + 1 < kc1) do_chunk(kc + 1, std::integral_constant<int, 2>{});
+        if (kc + 2 < kc1) do_chunk(kc + 2, std::integral_constant<int, 1>{});
     }
 
     // epilogue: class (pz,py,px) of low-res voxel (zl,yl,xl) is full-res voxel (2zl+pz, 2yl+py, 2xl+px)
     const int H2 = 2 * p.h, W2 = 2 * p.w;
+    float* const obase = p.slab ? p.slab + (int64_t)blockIdx.y * p.slab_stride : p.out;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
 #pragma unroll
@@ -237,11 +243,23 @@ __global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
             box_coords(p, mb * 32 + row_perm(rr), bd, bh, bw);
             const int zl = z0 + bd, yl = y0 + bh, xl = x0 + bw;
             if (zl >= p.d || yl >= p.h || xl >= p.w) continue;
-            float* orow = p.out + (((int64_t)(2 * zl + pz) * H2 + (2 * yl + py)) * W2 + (2 * xl + px)) * p.Cout +
+            float* orow = obase + (((int64_t)(2 * zl + pz) * H2 + (2 * yl + py)) * W2 + (2 * xl + px)) * p.Cout +
                           nt * 64 + l32;
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) orow[nb * 32] = acc[mb][nb][i] * dq;
         }
+    }
+}
+
+// split-K: out = sum of the slabs in slab order (deterministic)
+__global__ void upfold_reduce(const float4* __restrict__ slab, int nsplit, int64_t n4, float4* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 a = slab[i];
+        for (int k = 1; k < nsplit; ++k) {
+            const float4 b = slab[i + (int64_t)k * n4];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        out[i] = a;
     }
 }
 
@@ -331,9 +349,36 @@ extern "C" int bfm_pack_conv_weights_upfold(const float* w_oidhw, int CA, int CB
     return bfm_launch_status();
 }
 
-extern "C" int bfm_conv3x3x3_upfold(const float* B, int CB, int d, int h, int w, const float* scale_b,
-                                    const float* shift_b, const float* bound, int G, const void* wpacked, int wexp,
-                                    int Cout, int passes, float* out, bfm_stream_t stream) {
+namespace {
+// split K when the low-res level has too few boxes to fill the chip (the small decoder levels: 5^3 .. 20^3 voxels with
+// 512-2048 low-res channels): chunks per split a multiple of 3 (the weight ring's phase period)
+void upfold_split(int CB, int d, int h, int w, int Cout, int& nsplit, int& per) {
+    int BD, BH, BW;
+    choose_box(d, h, w, BD, BH, BW);
+    const int64_t wgs = (int64_t)bfm_cdiv(d, BD) * bfm_cdiv(h, BH) * bfm_cdiv(w, BW) * (Cout / 64);
+    const int KCB = CB / KC;
+    nsplit = 1;
+    per = KCB;
+    if (wgs >= 192 || KCB < 6) return;
+    int want = (int)std::min<int64_t>(KCB / 3, bfm_cdiv64(384, wgs));
+    if (want < 2) return;
+    per = bfm_cdiv(bfm_cdiv(KCB, want), 3) * 3;
+    nsplit = bfm_cdiv(KCB, per);
+    if (nsplit < 2) { nsplit = 1; per = KCB; }
+}
+}  // namespace
+
+extern "C" size_t bfm_conv3x3x3_upfold_workspace(int CB, int d, int h, int w, int Cout) {
+    if (CB <= 0 || d <= 0 || h <= 0 || w <= 0 || Cout <= 0 || CB % KC || Cout % 64) return 0;
+    int nsplit, per;
+    upfold_split(CB, d, h, w, Cout, nsplit, per);
+    return nsplit > 1 ? (size_t)nsplit * 8 * d * h * w * Cout * sizeof(float) : 0;
+}
+
+extern "C" int bfm_conv3x3x3_upfold_ex(const float* B, int CB, int d, int h, int w, const float* scale_b,
+                                       const float* shift_b, const float* bound, int G, const void* wpacked, int wexp,
+                                       int Cout, int passes, float* out, void* workspace, size_t workspace_bytes,
+                                       bfm_stream_t stream) {
     if (!B || CB <= 0 || d <= 0 || h <= 0 || w <= 0 || !scale_b || !shift_b || !bound || G <= 0 || !wpacked || !out)
         return BFM_E_ARG;
     if (CB % KC || Cout % 64 || Cout <= 0) return BFM_E_SHAPE;
@@ -362,8 +407,34 @@ extern "C" int bfm_conv3x3x3_upfold(const float* B, int CB, int d, int h, int w,
     const int npl = passes == 3 ? 2 : 1;
     const size_t smem = (size_t)2 * npl * p.plane_stride + 64;
     if ((int64_t)p.nMt * p.NT > 0x7fffffff) return BFM_E_SHAPE;
-    dim3 grid((unsigned)(p.nMt * p.NT));
+    int nsplit = 1, per = p.KCB;
+    const int64_t nout = (int64_t)8 * d * h * w * Cout;
+    if (workspace) {
+        upfold_split(CB, d, h, w, Cout, nsplit, per);
+        if (nsplit > 1 && (workspace_bytes < (size_t)nsplit * nout * sizeof(float) ||
+                           (reinterpret_cast<uintptr_t>(workspace) & 15))) {
+            nsplit = 1;
+            per = p.KCB;
+        }
+    }
+    p.kc_per_split = per;
+    p.slab = nsplit > 1 ? static_cast<float*>(workspace) : nullptr;
+    p.slab_stride = nout;
+    dim3 grid((unsigned)(p.nMt * p.NT), (unsigned)nsplit);
     if (passes == 3) hipLaunchKernelGGL(conv_upfold<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
     else hipLaunchKernelGGL(conv_upfold<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+    if (nsplit > 1) {
+        const int64_t n4 = nout / 4;
+        const int nb = (int)std::min<int64_t>(4096, bfm_cdiv64(n4, 256));
+        hipLaunchKernelGGL(upfold_reduce, dim3(nb), dim3(256), 0, bfm_s(stream), reinterpret_cast<const float4*>(p.slab), nsplit,
+                           n4, reinterpret_cast<float4*>(out));
+    }
     return bfm_launch_status();
+}
+
+extern "C" int bfm_conv3x3x3_upfold(const float* B, int CB, int d, int h, int w, const float* scale_b,
+                                    const float* shift_b, const float* bound, int G, const void* wpacked, int wexp,
+                                    int Cout, int passes, float* out, bfm_stream_t stream) {
+    return bfm_conv3x3x3_upfold_ex(B, CB, d, h, w, scale_b, shift_b, bound, G, wpacked, wexp, Cout, passes, out, nullptr, 0,
+                                   stream);
 }

@@ -56,7 +56,7 @@ class UNetEngine:
     tape = None                 # training (backward.py): list that single_conv / maxpool append their records to
     prof_reps = 1
     use_upfold = False
-    upfold_min = 4000
+    upfold_min = 250
     fuse_stats = False
 
     def __init__(self, state_dict, in_channels=1, f_maps=64, num_levels=6, num_groups=8, unit_feat=True,
@@ -81,7 +81,7 @@ class UNetEngine:
         self.force_direct = False
         # decoder first convs with an exact 2x upsample: fold the upsample into the weights (conv3d_upfold.hip)
         self.use_upfold = os.environ.get("BFM_UPFOLD", "1") != "0"
-        self.upfold_min = int(os.environ.get("BFM_UPFOLD_MIN", "4000"))   # fewest low-res voxels worth the launch
+        self.upfold_min = int(os.environ.get("BFM_UPFOLD_MIN", "250"))    # fewest low-res voxels worth it (split-K below ~4000)
         # GroupNorm moments from rows the producing conv wrote in its epilogue instead of a pass over the activation
         self.fuse_stats = os.environ.get("BFM_FUSE_STATS", "1") != "0"
         self.prof_reps = 1
@@ -404,7 +404,8 @@ class UNetEngine:
         cfg0 = self._plan(ca, ly.cout, dims, False, True)
         cfg0[7] = 1
         wsc = self.lib.bfm_conv3x3x3_mfma_workspace(ca, ly.cout, D, H, W, cfg0[5])
-        ws = self._gn_stats(ly, A, ca, B, cb, dims, lo_dims, upp, scale, shift, bound, wsc)
+        wsu = self.lib.bfm_conv3x3x3_upfold_workspace(cb, lo_dims[0], lo_dims[1], lo_dims[2], ly.cout)   # split-K slabs
+        ws = self._gn_stats(ly, A, ca, B, cb, dims, lo_dims, upp, scale, shift, bound, max(wsc, wsu))
         out = torch.empty((D, H, W, ly.cout), dtype=torch.float32, device=self.device)
         if "upfold" not in ly.packs:
             nbytes = self.lib.bfm_pack_conv_weights_upfold_bytes(cb, ly.cout, self.passes)
@@ -430,9 +431,10 @@ class UNetEngine:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         for _ in range(reps):
-            L.check(self.lib.bfm_conv3x3x3_upfold(L.ptr(B), cb, lo_dims[0], lo_dims[1], lo_dims[2], L.ptr(sc_b),
-                                                  L.ptr(sh_b), L.ptr(bound), ly.groups, L.ptr(wup), wexp_up, ly.cout,
-                                                  self.passes, L.ptr(out), st), "conv_upfold " + ly.name)
+            L.check(self.lib.bfm_conv3x3x3_upfold_ex(L.ptr(B), cb, lo_dims[0], lo_dims[1], lo_dims[2], L.ptr(sc_b),
+                                                     L.ptr(sh_b), L.ptr(bound), ly.groups, L.ptr(wup), wexp_up, ly.cout,
+                                                     self.passes, L.ptr(out), L.ptr(ws) if wsu else None, ws.numel(), st),
+                    "conv_upfold " + ly.name)
         if ev is not None:
             ev[1].record()
             self.prof.append((ev[0], ev[1], 2.0 * 27 * cb * ly.cout * nv, 4.0 * (lo * cb + nv * ly.cout), reps,

@@ -169,6 +169,12 @@ int bfm_pack_conv_weights_upfold(const float* w_oidhw /*[Cout][CA+CB][27]*/, int
 int bfm_conv3x3x3_upfold(const float* B, int CB, int d, int h, int w, const float* scale_b, const float* shift_b,
                          const float* bound, int G, const void* wpacked, int wexp, int Cout, int passes, float* out,
                          bfm_stream_t stream);
+/* the same with split-K for low-res levels too small to fill the chip (workspace from _workspace(); 0 bytes = not needed):
+ * partial sums per K slab, reduced in slab order */
+size_t bfm_conv3x3x3_upfold_workspace(int CB, int d, int h, int w, int Cout);
+int bfm_conv3x3x3_upfold_ex(const float* B, int CB, int d, int h, int w, const float* scale_b, const float* shift_b,
+                            const float* bound, int G, const void* wpacked, int wexp, int Cout, int passes, float* out,
+                            void* workspace, size_t workspace_bytes, bfm_stream_t stream);
 int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB, int D, int H, int W,
                        const bfm_upsample_t* up, const float* scale, const float* shift, const float* bound,
                        int G, const void* wpacked, int wexp, int Cout, float slope, int passes,

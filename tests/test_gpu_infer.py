@@ -350,6 +350,32 @@ def test_upsample_folded_decoder_conv_equals_generic_path(lo):
     assert e <= 2e-6, e
 
 
+@pytest.mark.parametrize("lo", [(5, 5, 6), (10, 9, 4)])
+def test_upsample_folded_conv_split_k_on_small_levels(lo):
+    """The same equivalence on a deep decoder level (512 up-sampled + 256 skip channels -> 256, a few hundred low-res
+    voxels): too few boxes to fill the chip, so conv_upfold splits K into slabs that upfold_reduce sums in order."""
+    from brainfm_amd import _lib as L
+    sd = O.random_state_dict(1, 64, 4, seed=12)
+    s = _session(sd=sd, f_maps=64, levels=4)
+    eng = s.engine
+    ly = eng.dec[0][0]
+    cb, ca = 512, 256
+    assert (ly.cin, ly.cout) == (cb + ca, 256)
+    assert L.load().bfm_conv3x3x3_upfold_workspace(cb, lo[0], lo[1], lo[2], ly.cout) > 0        # split-K is planned
+    hi = tuple(2 * v for v in lo)
+    g = torch.Generator().manual_seed(4)
+    A = torch.randn(hi + (ca,), generator=g).to(_dev())
+    B = (torch.randn(lo + (cb,), generator=g) * 2 + 0.3).to(_dev())
+    eng.upfold_min = 1
+    eng.use_upfold = False
+    ref = eng.single_conv(ly, A, hi, B=B, lo_dims=lo).clone()
+    eng.use_upfold = True
+    got = eng.single_conv(ly, A, hi, B=B, lo_dims=lo)
+    assert "upfold" in ly.packs
+    e = _relerr(got.cpu().numpy(), ref.cpu().numpy())
+    assert e <= 3e-6, e
+
+
 @pytest.mark.parametrize("ver", [0, 2, 3, 5])
 def test_producer_moment_rows_equal_activation_moments(ver, monkeypatch):
     """The per-tile {sum, sumsq, min, max} rows written by the stem / conv epilogues must be the moments of the
@@ -570,5 +596,7 @@ def test_training_tape_fast_path_equals_generic(f_maps, levels, dims):
     assert set(gg) == set(gf)
     worst = {k: _relerr(gf[k].cpu().numpy(), gg[k].cpu().numpy()) for k in gg}
     print("fast vs generic tape: max rel grad diff %.2e, mask flips %d of %d" % (max(worst.values()), flips, nel))
-    bad = {k: v for k, v in worst.items() if v > 2e-4}
+    # the one-channel stem GroupNorm's dgamma / dbeta cancel to ~1e-3 of their terms (see the fp64 test above)
+    stem = "backbone.encoders.0.basic_module.SingleConv1.groupnorm."
+    bad = {k: v for k, v in worst.items() if v > (2e-3 if k.startswith(stem) else 2e-4)}
     assert not bad, bad
