@@ -100,6 +100,7 @@ SIGNATURES = {
     "bfm_gn_bwd_workspace": (_Z, [_I, _I, _I, _I]),
     "bfm_gn_bwd": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _Z, _P]),
     "bfm_maxpool2_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    "bfm_transpose_mirror_weights": (_I, [_P, _I, _I, _I, _P, _P]),
     "bfm_loss_workspace": (_Z, [_I]),
     "bfm_loss_l1": (_I, [_P, _I, _I, _P, _P, _P, _L, _F, _I, _F, _P, _P, _P, _Z, _P]),
     "bfm_loss_l1_multi_workspace": (_Z, []),

@@ -87,20 +87,29 @@ def train_single_conv(eng, ly, A, dims, B=None, lo_dims=None):
     return out, t
 
 
+def _dgrad_cout(ly):
+    """Output channels of the data-gradient conv: Cin of the layer, padded to 64 where that opens the matrix-core path
+    (level 0: 64 -> 32 at 128^3 took 170 ms on the direct kernel, 2 ms padded to 64 -> 64; the one-channel stem 17 -> 1 ms)."""
+    if ly.cin % 64 and ly.cout % 16 == 0:
+        return (ly.cin + 63) // 64 * 64
+    return ly.cin
+
+
+def refresh_dgrad(ly, dg):
+    """(Re)derive the transposed, tap-mirrored weights of `ly` into its data-gradient layer `dg` (one kernel pass)."""
+    L.check(L.load().bfm_transpose_mirror_weights(L.ptr(ly.w_raw), ly.cout, ly.cin, dg.cout, L.ptr(dg.w_raw),
+                                                  L.stream_ptr()), "transpose_mirror_weights " + ly.name)
+
+
 def _dgrad_layer(eng, ly):
     """The transposed, tap-mirrored weights of `ly` as a layer of their own: conv(dP, W') = d(loss)/d(conv input)."""
     dg = _Layer()
     dg.gamma, dg.beta = None, None
-    w = ly.w_raw.permute(1, 0, 2, 3, 4).flip(2, 3, 4)
-    cout = ly.cin
-    if ly.cin % 64 and ly.cout % 16 == 0:
-        # the matrix-core conv needs Cout % 64 == 0: zero output channels are cheaper than the direct kernel (level 0:
-        # 64 -> 32 at 128^3 took 170 ms direct, 2 ms padded to 64 -> 64; the one-channel stem 17 ms -> 1 ms)
-        cout = (ly.cin + 63) // 64 * 64
-        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, 0, 0, 0, 0, cout - ly.cin))
+    cout = _dgrad_cout(ly)
     dg.name, dg.cin, dg.cout, dg.groups = ly.name + "[dgrad]", ly.cout, cout, 1
-    dg.w_raw = w.contiguous()
+    dg.w_raw = torch.empty((cout, ly.cout, 3, 3, 3), dtype=torch.float32, device=eng.device)
     dg.kind, dg.wpacked, dg.wexp, dg.packs, dg.skip = None, None, 0, {}, None
+    refresh_dgrad(ly, dg)
     return dg
 
 
@@ -136,6 +145,7 @@ def backward_single_conv(eng, t, dY, need_input_grad=True):
     dg = ly.packs.get("dgrad_layer")                             # transposed weights live with their layer
     if dg is None:
         dg = ly.packs["dgrad_layer"] = _dgrad_layer(eng, ly)
+    ly.touch("dgrad_layer")
     ones = torch.ones(ly.cout, dtype=torch.float32, device=dev)
     zeros = torch.zeros(ly.cout, dtype=torch.float32, device=dev)
     dXn = torch.empty((D, H, W, dg.cout), dtype=torch.float32, device=dev)

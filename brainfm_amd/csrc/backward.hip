@@ -997,3 +997,27 @@ extern "C" int bfm_maxpool2_bwd(const float* in, const float* dOut, int C, int D
     }
     return bfm_launch_status();
 }
+
+// dW'[ci][co][26 - t] = w[co][ci][t] for ci < Cin, 0 for Cin <= ci < CinPad: the weights of the data-gradient conv (transposed,
+// tap-mirrored, output channels padded for the matrix-core kernels) in one pass; torch needed permute + flip + pad +
+// contiguous + copy_ (five passes over 264 M parameters every training iteration).
+namespace {
+__global__ void transpose_mirror_kernel(const float* __restrict__ w, int Cout, int Cin, int CinPad, float* __restrict__ out) {
+    const int64_t n = (int64_t)CinPad * Cout * 27;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % 27);
+        const int64_t r = i / 27;
+        const int co = (int)(r % Cout);
+        const int ci = (int)(r / Cout);
+        out[i] = ci < Cin ? w[((int64_t)co * Cin + ci) * 27 + (26 - t)] : 0.f;
+    }
+}
+}  // namespace
+
+extern "C" int bfm_transpose_mirror_weights(const float* w, int Cout, int Cin, int CinPad, float* out, bfm_stream_t stream) {
+    if (!w || !out || Cout <= 0 || Cin <= 0 || CinPad < Cin) return BFM_E_ARG;
+    const int64_t n = (int64_t)CinPad * Cout * 27;
+    const int nb = (int)std::min<int64_t>(8192, bfm_cdiv64(n, 256));
+    hipLaunchKernelGGL(transpose_mirror_kernel, dim3(nb), dim3(256), 0, bfm_s(stream), w, Cout, Cin, CinPad, out);
+    return bfm_launch_status();
+}

@@ -308,6 +308,51 @@ __global__ void pack_upfold(const float* __restrict__ w, int Cin, int CA, int CB
 int ilog2i(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
 
 // low-res box of 128 voxels (powers of two) wasting the fewest rows on the volume's edges
+// The same packing with the 64 (co) x 16 (ci) x 27 block of one (N tile, K chunk) staged through LDS: coalesced reads,
+// every weight read once instead of once per class / folded tap / hi-lo plane that sums it (training re-packs every
+// iteration: 1.5 ms for the 1024 + 512 -> 512 decoder layer with the gather version above).
+constexpr int PKU_ROW = KC * 27 + 1;
+__global__ void __launch_bounds__(256) pack_upfold_tiled(const float* __restrict__ w, int Cin, int CA, int CB, int Cout,
+                                                         int wexp, int npl, uint4* __restrict__ out) {
+    extern __shared__ float pku_lds[];                      // [64][PKU_ROW]
+    const int KCB = CB / KC;
+    const int nf = 2 * npl;
+    const int kc = blockIdx.x % KCB, ntile = blockIdx.x / KCB;
+    const float s = ldexpf(1.0f, wexp);
+    for (int i = threadIdx.x; i < 64 * KC * 27; i += 256) {
+        const int co = i / (KC * 27), r = i - co * (KC * 27);
+        pku_lds[co * PKU_ROW + r] = w[((int64_t)(ntile * 64 + co) * Cin + CA + kc * KC) * 27 + r];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nfrag = 8 * 8 * nf;                            // (class, folded tap, fragment)
+    for (int q = wave; q < nfrag; q += 4) {
+        const int f = q % nf;
+        const int t = (q / nf) & 7;
+        const int cls = q / (nf * 8);
+        const int nb = f / npl, hl = f - nb * npl;
+        const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
+        const int ta = t >> 2, tb = (t >> 1) & 1, tc = t & 1;
+        const int zlo = pz == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2), zhi = pz == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
+        const int ylo = py == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2), yhi = py == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
+        const int xlo = px == 0 ? (tc == 0 ? 0 : 1) : (tc == 0 ? 0 : 2), xhi = px == 0 ? (tc == 0 ? 0 : 2) : (tc == 0 ? 1 : 2);
+        const float* src = pku_lds + (nb * 32 + (lane & 31)) * PKU_ROW + (8 * (lane >> 5)) * 27;
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* wc = src + j * 27;
+            float sum = 0.f;
+            for (int kd = zlo; kd <= zhi; ++kd)
+                for (int kh = ylo; kh <= yhi; ++kh)
+                    for (int kw = xlo; kw <= xhi; ++kw) sum += wc[kd * 9 + kh * 3 + kw];
+            const float x = sum * s;
+            const _Float16 hh = (_Float16)x;
+            v[j] = hl == 0 ? hh : (_Float16)(x - (float)hh);
+        }
+        out[((((int64_t)(ntile * 8 + cls) * KCB + kc) * 8 + t) * nf + f) * 64 + lane] = __builtin_bit_cast(uint4, v);
+    }
+}
+
 void choose_box(int d, int h, int w, int& BD, int& BH, int& BW) {
     static const int opts[][3] = {{2, 4, 16}, {4, 2, 16}, {4, 4, 8}, {2, 8, 8}, {8, 2, 8}, {8, 4, 4}, {4, 8, 4},
                                   {1, 8, 16}, {8, 1, 16}, {2, 2, 32}, {1, 4, 32}, {4, 1, 32}};
@@ -342,10 +387,24 @@ extern "C" int bfm_pack_conv_weights_upfold(const float* w_oidhw, int CA, int CB
     }
     *wexp_host = wexp;
     const int npl = passes == 3 ? 2 : 1;
-    const int64_t n = (int64_t)(Cout / 64) * 8 * (CB / KC) * 8 * 2 * npl * 64;
-    int nb = (int)std::min<int64_t>(4096, bfm_cdiv64(n, 256));
-    hipLaunchKernelGGL(pack_upfold, dim3(nb), dim3(256), 0, bfm_s(stream), w_oidhw, CA + CB, CA, CB, Cout, wexp, npl,
-                       static_cast<uint4*>(wpacked));
+    const int64_t nblk = (int64_t)(Cout / 64) * (CB / KC);
+    const size_t smem = (size_t)64 * PKU_ROW * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_upfold_tiled), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return BFM_E_LAUNCH;
+        attr = true;
+    }
+    if (nblk <= 0x7fffffff) {
+        hipLaunchKernelGGL(pack_upfold_tiled, dim3((unsigned)nblk), dim3(256), smem, bfm_s(stream), w_oidhw, CA + CB, CA, CB,
+                           Cout, wexp, npl, static_cast<uint4*>(wpacked));
+    } else {
+        const int64_t n = nblk * 8 * 8 * 2 * npl * 64;
+        int nb = (int)std::min<int64_t>(4096, bfm_cdiv64(n, 256));
+        hipLaunchKernelGGL(pack_upfold, dim3(nb), dim3(256), 0, bfm_s(stream), w_oidhw, CA + CB, CA, CB, Cout, wexp, npl,
+                           static_cast<uint4*>(wpacked));
+    }
     return bfm_launch_status();
 }
 

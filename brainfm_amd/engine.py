@@ -39,7 +39,15 @@ def nearest_index_map(n_in, n_out):
 
 
 class _Layer:
-    __slots__ = ("name", "cin", "cout", "groups", "gamma", "beta", "kind", "wpacked", "wexp", "w_raw", "packs", "skip")
+    __slots__ = ("name", "cin", "cout", "groups", "gamma", "beta", "kind", "wpacked", "wexp", "w_raw", "packs", "skip",
+                 "used")
+
+    def touch(self, layout):
+        """Remember which packed forms the current pass really launches (autotune trials leave the others behind)."""
+        u = getattr(self, "used", None)
+        if u is None:
+            u = self.used = set()
+        u.add(layout)
 
 
 class UNetEngine:
@@ -138,37 +146,108 @@ class UNetEngine:
     def _mfma_ok(self, ly, ca, cb):
         return (not self.force_direct) and ca % 16 == 0 and cb % 16 == 0 and ly.cout % 64 == 0
 
+    def _make_pack(self, ly, layout, wmax=None):
+        """Create ly.packs[layout] from ly.w_raw (reusing the buffer of `prev` when repacking in place); wmax: max |w|
+        when the caller already has it on the host (saves a device round trip per layer)."""
+        st = L.stream_ptr()
+        prev = ly.packs.get(layout)
+        if layout == "wino":
+            nbytes = self.lib.bfm_pack_conv_weights_wino_bytes(ly.cin, ly.cout, self.passes)
+            buf = prev[0] if prev is not None else torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            wexp = C.c_int(0)
+            wmax = float(ly.w_raw.abs().max().item()) if wmax is None else wmax
+            L.check(self.lib.bfm_pack_conv_weights_wino(L.ptr(ly.w_raw), ly.cin, ly.cout, wmax, self.passes,
+                                                        L.ptr(buf), C.byref(wexp), st), "pack_wino " + ly.name)
+            ly.packs[layout] = (buf, wexp.value)
+        elif layout in ("mfma", "mfma16"):
+            v2 = layout == "mfma16"
+            fn_b = self.lib.bfm_pack_conv_weights_mfma16_bytes if v2 else self.lib.bfm_pack_conv_weights_mfma_bytes
+            fn_p = self.lib.bfm_pack_conv_weights_mfma16 if v2 else self.lib.bfm_pack_conv_weights_mfma
+            buf = prev[0] if prev is not None else torch.empty(fn_b(ly.cin, ly.cout), dtype=torch.uint8, device=self.device)
+            wexp = C.c_int(0)
+            wmax = float(ly.w_raw.abs().max().item()) if wmax is None else wmax
+            L.check(fn_p(L.ptr(ly.w_raw), ly.cin, ly.cout, wmax, L.ptr(buf), C.byref(wexp), st),
+                    "pack_%s %s" % (layout, ly.name))
+            ly.packs[layout] = (buf, wexp.value)
+        elif layout == "direct":
+            buf = prev[0] if prev is not None else torch.empty(27 * ly.cin * ly.cout, dtype=torch.float32, device=self.device)
+            L.check(self.lib.bfm_pack_conv_weights_direct(L.ptr(ly.w_raw), ly.cin, ly.cout, L.ptr(buf), st),
+                    "pack_direct " + ly.name)
+            ly.packs[layout] = (buf, 0)
+        else:
+            raise L.BfmError("unknown weight layout '%s'" % layout)
+
     def _pack(self, ly, mfma, ver=0):
         """Pack (once per layout) and select the weights for this launch: 'direct' [27][Cin][Cout] fp32,
         'mfma' 32x32x16 fragments (plan variants 0/1), 'mfma16' 16x16x32 tap-pair fragments (variant 2),
         'wino' F(2,3)-along-x transformed fragments (variant 3, single-source layers only)."""
         layout = "direct" if not mfma else ("wino" if ver in (3, 4, 5) else ("mfma16" if ver == 2 else "mfma"))
         if layout not in ly.packs:
-            st = L.stream_ptr()
-            if layout == "wino":
-                nbytes = self.lib.bfm_pack_conv_weights_wino_bytes(ly.cin, ly.cout, self.passes)
-                buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-                wexp = C.c_int(0)
-                wmax = float(ly.w_raw.abs().max().item())
-                L.check(self.lib.bfm_pack_conv_weights_wino(L.ptr(ly.w_raw), ly.cin, ly.cout, wmax, self.passes,
-                                                            L.ptr(buf), C.byref(wexp), st), "pack_wino " + ly.name)
-                ly.packs[layout] = (buf, wexp.value)
-            elif mfma:
-                fn_b = self.lib.bfm_pack_conv_weights_mfma16_bytes if ver == 2 else self.lib.bfm_pack_conv_weights_mfma_bytes
-                fn_p = self.lib.bfm_pack_conv_weights_mfma16 if ver == 2 else self.lib.bfm_pack_conv_weights_mfma
-                buf = torch.empty(fn_b(ly.cin, ly.cout), dtype=torch.uint8, device=self.device)
-                wexp = C.c_int(0)
-                wmax = float(ly.w_raw.abs().max().item())
-                L.check(fn_p(L.ptr(ly.w_raw), ly.cin, ly.cout, wmax, L.ptr(buf), C.byref(wexp), st),
-                        "pack_%s %s" % (layout, ly.name))
-                ly.packs[layout] = (buf, wexp.value)
-            else:
-                buf = torch.empty(27 * ly.cin * ly.cout, dtype=torch.float32, device=self.device)
-                L.check(self.lib.bfm_pack_conv_weights_direct(L.ptr(ly.w_raw), ly.cin, ly.cout, L.ptr(buf), st),
-                        "pack_direct " + ly.name)
-                ly.packs[layout] = (buf, 0)
+            self._make_pack(ly, layout)
+        ly.touch(layout)
         ly.wpacked, ly.wexp = ly.packs[layout]
         ly.kind = "mfma" if mfma else "direct"
+
+    def _make_upfold_pack(self, ly, ca, cb, wmax=None):
+        st = L.stream_ptr()
+        prev = ly.packs.get("upfold")
+        nbytes = self.lib.bfm_pack_conv_weights_upfold_bytes(cb, ly.cout, self.passes)
+        buf = prev[0] if prev is not None else torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        wexp = C.c_int(0)
+        wmax = float(ly.w_raw[:, ca:].abs().max().item()) if wmax is None else wmax
+        L.check(self.lib.bfm_pack_conv_weights_upfold(L.ptr(ly.w_raw), ca, cb, ly.cout, wmax, self.passes,
+                                                      L.ptr(buf), C.byref(wexp), st), "pack_upfold " + ly.name)
+        ly.packs["upfold"] = (buf, wexp.value)
+
+    def repack_all(self, refresh=None):
+        """The weights changed in place (training): rebuild, into the same buffers, every packed form a layer launched in
+        the last pass (forward variants, skip half, up-folded form, the transposed data-gradient layer that backward.py
+        hangs on it), so that nothing is packed lazily inside the next pass; forms only the autotune trials used are
+        dropped.  All max |w| come to the host in ONE copy.  `refresh(ly, dg)` re-derives a data-gradient layer's weights."""
+        jobs = []                                          # (layer, layout, max|w| tensor)
+
+        def absmax(t):                                     # one read pass, no |w| copy
+            lo, hi = torch.aminmax(t)
+            return torch.maximum(hi, -lo)
+
+        def visit(ly, wm=None):
+            used = getattr(ly, "used", None) or set()
+            for layout in list(ly.packs.keys()):
+                if layout not in used:
+                    del ly.packs[layout]
+                elif layout == "dgrad_layer":
+                    dg = ly.packs[layout]
+                    if refresh is not None:
+                        refresh(ly, dg)
+                    if wm is None:
+                        wm = absmax(ly.w_raw)
+                    visit(dg, wm)                          # transposing, mirroring and zero rows keep max |w|
+                elif layout == "upfold":
+                    jobs.append((ly, layout, absmax(ly.w_raw[:, ly.skip.cin:])))
+                elif layout == "direct":
+                    jobs.append((ly, layout, None))
+                else:
+                    if wm is None:
+                        wm = absmax(ly.w_raw)
+                    jobs.append((ly, layout, wm))
+            ly.used = set()
+            ly.wpacked, ly.kind = None, None
+            if ly.skip is not None:
+                ly.skip.w_raw.copy_(ly.w_raw[:, :ly.skip.cin])
+                visit(ly.skip)
+
+        for pair in self.enc + self.dec:
+            for ly in pair:
+                visit(ly)
+        mx = [j[2] for j in jobs if j[2] is not None]
+        host = torch.stack(mx).cpu().tolist() if mx else []
+        it = iter(host)
+        for ly, layout, m in jobs:
+            wmax = next(it) if m is not None else None
+            if layout == "upfold":
+                self._make_upfold_pack(ly, ly.skip.cin, ly.cin - ly.skip.cin, wmax)
+            else:
+                self._make_pack(ly, layout, wmax)
 
     # ------------------------------------------------------------------ helpers
     def _upsample_desc(self, lo, hi):
@@ -408,13 +487,8 @@ class UNetEngine:
         ws = self._gn_stats(ly, A, ca, B, cb, dims, lo_dims, upp, scale, shift, bound, max(wsc, wsu))
         out = torch.empty((D, H, W, ly.cout), dtype=torch.float32, device=self.device)
         if "upfold" not in ly.packs:
-            nbytes = self.lib.bfm_pack_conv_weights_upfold_bytes(cb, ly.cout, self.passes)
-            buf = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            wexp = C.c_int(0)
-            wmax = float(ly.w_raw[:, ca:].abs().max().item())
-            L.check(self.lib.bfm_pack_conv_weights_upfold(L.ptr(ly.w_raw), ca, cb, ly.cout, wmax, self.passes,
-                                                          L.ptr(buf), C.byref(wexp), st), "pack_upfold " + ly.name)
-            ly.packs["upfold"] = (buf, wexp.value)
+            self._make_upfold_pack(ly, ca, cb)
+        ly.touch("upfold")
         wup, wexp_up = ly.packs["upfold"]
 
         def _launch_skip(c):

@@ -138,10 +138,9 @@ class TrainStep:
         return p
 
     def _weights_changed(self):
-        for pair in self.eng.enc + self.eng.dec:
-            for ly in pair:
-                ly.packs.clear()
-                ly.wpacked, ly.kind, ly.skip = None, None, None
+        """Right after the optimiser: every packed form a layer holds (forward variants, skip half, up-folded, transposed
+        data-gradient layer) is rebuilt in place, so the next pass packs nothing lazily."""
+        self.eng.repack_all(refresh=BW.refresh_dgrad)
         self.tail.desc.head_wmax = float(self.tail.head_w.abs().max().item())
 
     # ------------------------------------------------------------------ checkpoints (scripts/train.py:205-214)

@@ -423,6 +423,8 @@ int bfm_gn_bwd(const float* dXn, const float* A, int CA, const float* B, int CB,
                const float* mean, const float* rstd, const float* gamma, int G, float* dA, float* dB, float* dgamma,
                float* dbeta, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
 int bfm_maxpool2_bwd(const float* in, const float* dOut, int C, int D, int H, int W, float* dIn, bfm_stream_t stream);
+/* weights of the data-gradient conv: out[ci][co][26-t] = w[co][ci][t], zero rows for Cin <= ci < CinPad */
+int bfm_transpose_mirror_weights(const float* w_oidhw, int Cout, int Cin, int CinPad, float* out, bfm_stream_t stream);
 
 /* ---- losses, task-head backward and optimiser step (the rest of one training iteration) -------------------
  * Replaces, for the supervised heads, Trainer/models/criterion.py:111-124,178-186,215-294 + losses.py:10-74 (loss values
