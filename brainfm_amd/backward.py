@@ -110,6 +110,7 @@ def _dgrad_layer(eng, ly):
     dg.w_raw = torch.empty((cout, ly.cout, 3, 3, 3), dtype=torch.float32, device=eng.device)
     dg.kind, dg.wpacked, dg.wexp, dg.packs, dg.skip = None, None, 0, {}, None
     refresh_dgrad(ly, dg)
+    eng.pack_count += 1
     return dg
 
 

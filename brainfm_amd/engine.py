@@ -60,6 +60,7 @@ class UNetEngine:
     """
     prof = None
     lane = 0
+    pack_count = 0              # packed weight forms created so far (train.py: lazily created ones order the sample lanes)
     _ws_lanes = None
     tape = None                 # training (backward.py): list that single_conv / maxpool append their records to
     prof_reps = 1
@@ -151,6 +152,7 @@ class UNetEngine:
         when the caller already has it on the host (saves a device round trip per layer)."""
         st = L.stream_ptr()
         prev = ly.packs.get(layout)
+        self.pack_count += 1
         if layout == "wino":
             nbytes = self.lib.bfm_pack_conv_weights_wino_bytes(ly.cin, ly.cout, self.passes)
             buf = prev[0] if prev is not None else torch.empty(nbytes, dtype=torch.uint8, device=self.device)
@@ -190,6 +192,7 @@ class UNetEngine:
 
     def _make_upfold_pack(self, ly, ca, cb, wmax=None):
         st = L.stream_ptr()
+        self.pack_count += 1
         prev = ly.packs.get("upfold")
         nbytes = self.lib.bfm_pack_conv_weights_upfold_bytes(cb, ly.cout, self.passes)
         buf = prev[0] if prev is not None else torch.empty(nbytes, dtype=torch.uint8, device=self.device)

@@ -19,6 +19,7 @@ all-reduce.  There is no CPU path: without the extension or a HIP device constru
 """
 import ctypes as C
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -120,8 +121,26 @@ class TrainStep:
         self.t = 0
         self.state = {}                                   # name -> (m, v)
         nseg = tail.desc.n_seg
-        self._ws = torch.empty(self.lib.bfm_loss_workspace(max(nseg, 1)), dtype=torch.uint8, device=self.dev)
-        self._ws_multi = torch.empty(self.lib.bfm_loss_l1_multi_workspace(), dtype=torch.uint8, device=self.dev)
+        self.sample_lanes = max(1, int(os.environ.get("BFM_TRAIN_LANES", "2")))
+        self._lane_streams = []
+        self._lane = 0
+        self._ws_lane = {}
+        self._ws_bytes = (self.lib.bfm_loss_workspace(max(nseg, 1)), self.lib.bfm_loss_l1_multi_workspace())
+
+    @property
+    def _ws(self):
+        return self._lane_ws()[0]
+
+    @property
+    def _ws_multi(self):
+        return self._lane_ws()[1]
+
+    def _lane_ws(self):
+        """Reduction scratch of the loss kernels, one set per sample lane."""
+        w = self._ws_lane.get(self._lane)
+        if w is None:
+            w = self._ws_lane[self._lane] = tuple(torch.empty(b, dtype=torch.uint8, device=self.dev) for b in self._ws_bytes)
+        return w
 
     # ------------------------------------------------------------------ parameters
     def parameters(self):
@@ -343,46 +362,91 @@ class TrainStep:
         return OrderedDict((("loss_" + n), out["loss_" + n]) for n in self.loss_names if ("loss_" + n) in out)
 
     # ------------------------------------------------------------------ forward + backward
+    def _one_sample(self, x, target, sample, scale):
+        """Forward, losses and backward of one augmented sample on the current stream.  Returns (grads, slots, vals)."""
+        eng, tail, lib = self.eng, self.tail, self.lib
+        dims = tuple(x.shape[-3:])
+        nvox = dims[0] * dims[1] * dims[2]
+        st = L.stream_ptr()
+        x_cl = eng.to_cl(x)
+        feats, tape = BW.backbone_forward_train(eng, x_cl, dims)
+        feat_last = feats[-1][0]
+        raw, fn = tail.run_raw(feat_last, dims, want_feat=True)
+        if fn is None:
+            fn = feat_last
+        dRaw = torch.zeros_like(raw)
+        vals = torch.zeros(4 * len(self.loss_names) + 2 * tail.n_out + 8, dtype=torch.float64, device=self.dev)
+        slots, _ = self._sample_losses(raw, dims, target, sample, dRaw, vals, scale)
+        n_out, cf = tail.n_out, tail.c_feat
+        dW = torch.empty((n_out, cf), dtype=torch.float32, device=self.dev)
+        db = torch.empty(n_out, dtype=torch.float32, device=self.dev)
+        dFn = torch.empty((nvox, cf), dtype=torch.float32, device=self.dev)
+        wsb = torch.empty(lib.bfm_head_bwd_workspace(n_out, cf, nvox), dtype=torch.uint8, device=self.dev)
+        L.check(lib.bfm_head_bwd(L.ptr(dRaw), L.ptr(fn), L.ptr(tail.head_w), n_out, cf, nvox, L.ptr(dW), L.ptr(db),
+                                 L.ptr(dFn), L.ptr(wsb), wsb.numel(), st), "head_bwd")
+        if eng.unit_feat:
+            dfeat = torch.empty_like(dFn)
+            L.check(lib.bfm_normalize_bwd(L.ptr(feat_last), L.ptr(dFn), cf, nvox, 1e-12, L.ptr(dfeat), st), "normalize_bwd")
+        else:
+            dfeat = dFn
+        g = BW.backbone_backward(eng, tape, [None] * (len(feats) - 1) + [dfeat.view(dims + (cf,))])
+        for task, (r0, n) in tail.row_of.items():
+            g["head.final_conv_%s.weight" % task] = dW[r0:r0 + n]
+            g["head.final_conv_%s.bias" % task] = db[r0:r0 + n]
+        return g, slots, vals
+
     def loss_and_grads(self, xs, target, samples):
         """xs: list of (1,C,D,H,W) inputs (one per augmented sample); target / samples as the reference's dicts
         (NCDHW tensors).  Returns (loss_dict, total, grads) with grads = d(scale * total)/d(parameter) summed over the
-        samples (scale = the loss scaler's)."""
-        eng, tail, lib = self.eng, self.tail, self.lib
+        samples in sample order (scale = the loss scaler's).
+        With sample_lanes > 1 (default 2, BFM_TRAIN_LANES) consecutive samples run on separate streams from the second
+        iteration on -- the packed weights are all in place by then (apply() rebuilds them eagerly) and the conv variants
+        are tuned -- so that one sample's small kernels and launch tails hide under the other's convolutions, as the two
+        tiles in flight of the inference path do; the gradients are still added on the caller's stream in sample order,
+        so the result is the same bits."""
+        eng = self.eng
         scale = self.scaler.scale
+        n = len(xs)
+        lanes = self.sample_lanes if (n > 1 and self.t >= 1) else 1
+        nvox = None
+        results = []
+        if lanes <= 1:
+            for x, sample in zip(xs, samples):
+                results.append(self._one_sample(x, target, sample, scale) + (None,))
+        else:
+            main = torch.cuda.current_stream(self.dev)
+            while len(self._lane_streams) < lanes:
+                self._lane_streams.append(torch.cuda.Stream(device=self.dev))
+            start = torch.cuda.Event()
+            start.record(main)
+            seen = eng.pack_count
+            for i, (x, sample) in enumerate(zip(xs, samples)):
+                k = i % lanes
+                st = self._lane_streams[k]
+                st.wait_event(start)
+                if eng.pack_count != seen:                 # a packed form was created lazily while issuing an earlier
+                    for r in results:                      # sample (new shape): later samples must see it finished
+                        st.wait_event(r[3])
+                    seen = eng.pack_count
+                eng.lane, self._lane = k, k
+                try:
+                    with torch.cuda.stream(st):
+                        g, slots, vals = self._one_sample(x, target, sample, scale)
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                finally:
+                    eng.lane, self._lane = 0, 0
+                results.append((g, slots, vals, ev))
+            for g, slots, vals, ev in results:
+                main.wait_event(ev)
+                vals.record_stream(main)
+                for t_ in g.values():
+                    t_.record_stream(main)
         grads = None
         per_sample = []
-        nvox = None
-        for x, sample in zip(xs, samples):
-            dims = tuple(x.shape[-3:])
-            nvox = dims[0] * dims[1] * dims[2]
-            st = L.stream_ptr()
-            x_cl = eng.to_cl(x)
-            feats, tape = BW.backbone_forward_train(eng, x_cl, dims)
-            feat_last = feats[-1][0]
-            raw, fn = tail.run_raw(feat_last, dims, want_feat=True)
-            if fn is None:
-                fn = feat_last
-            dRaw = torch.zeros_like(raw)
-            vals = torch.zeros(4 * len(self.loss_names) + 2 * tail.n_out + 8, dtype=torch.float64, device=self.dev)
-            slots, _ = self._sample_losses(raw, dims, target, sample, dRaw, vals, scale)
+        for x, (g, slots, vals, _) in zip(xs, results):
+            nvox = x.shape[-3] * x.shape[-2] * x.shape[-1]
             per_sample.append((slots, vals))
-            # heads
-            n_out, cf = tail.n_out, tail.c_feat
-            dW = torch.empty((n_out, cf), dtype=torch.float32, device=self.dev)
-            db = torch.empty(n_out, dtype=torch.float32, device=self.dev)
-            dFn = torch.empty((nvox, cf), dtype=torch.float32, device=self.dev)
-            wsb = torch.empty(lib.bfm_head_bwd_workspace(n_out, cf, nvox), dtype=torch.uint8, device=self.dev)
-            L.check(lib.bfm_head_bwd(L.ptr(dRaw), L.ptr(fn), L.ptr(tail.head_w), n_out, cf, nvox, L.ptr(dW), L.ptr(db),
-                                     L.ptr(dFn), L.ptr(wsb), wsb.numel(), st), "head_bwd")
-            if eng.unit_feat:
-                dfeat = torch.empty_like(dFn)
-                L.check(lib.bfm_normalize_bwd(L.ptr(feat_last), L.ptr(dFn), cf, nvox, 1e-12, L.ptr(dfeat), st), "normalize_bwd")
-            else:
-                dfeat = dFn
-            g = BW.backbone_backward(eng, tape, [None] * (len(feats) - 1) + [dfeat.view(dims + (cf,))])
-            for task, (r0, n) in tail.row_of.items():
-                g["head.final_conv_%s.weight" % task] = dW[r0:r0 + n]
-                g["head.final_conv_%s.bias" % task] = db[r0:r0 + n]
             if grads is None:
                 grads = g
             else:

@@ -268,3 +268,26 @@ def test_checkpoint_round_trip_resumes_bit_identically(tmp_path):
                                         num_groups=c["groups"])
     s = TU.InferenceSession(ga, ta_, _dev(), ckp_path=path, passes=3)
     assert torch.equal(s.engine.enc[0][0].w_raw.cpu(), ckp["model"][s.engine.enc[0][0].name + ".conv.weight"])
+
+
+def test_sample_lanes_give_the_same_bits_as_serial_samples():
+    """From the second iteration on the augmented samples of an iteration run on two streams (packed weights and tuned
+    variants are in place by then); gradients are still added in sample order on the caller's stream, so losses,
+    gradients and parameters after three iterations equal the strictly serial run bit for bit."""
+    c = load_case()
+    a, xs, target, samples = _build(c)
+    b, _, _, _ = _build(c)
+    assert a.sample_lanes == 2
+    b.sample_lanes = 1
+    xs3, samples3 = xs + [xs[0] * 0.5 + 0.1], samples + [samples[1]]            # three samples: lanes 0, 1, 0
+    for it in range(3):
+        la, ta, ga = a.loss_and_grads(xs3, target, samples3)
+        lb, tb, gb = b.loss_and_grads(xs3, target, samples3)
+        assert ta == tb and la == lb, it
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), (it, k)
+        a.apply(ga)
+        b.apply(gb)
+    pa, pb = a.parameters(), b.parameters()
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
