@@ -34,10 +34,17 @@ __global__ void lrelu_bwd_kernel(const float* __restrict__ dY, const float* __re
         m = fmaxf(fmaxf(m, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
     }
     if (absmax) {                                         // max |dP| for the kernels that rescale dP (order independent)
+        __shared__ float wm[4];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-        if ((threadIdx.x & 63) == 0 && m > 0.f)
-            atomicMax(reinterpret_cast<int*>(absmax), __float_as_int(m));    // non-negative floats order like ints
+        if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            m = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+            // one atomic per block, and only when it can raise the value (non-negative floats order like ints)
+            if (m > 0.f && __float_as_int(m) > *reinterpret_cast<volatile int*>(absmax))
+                atomicMax(reinterpret_cast<int*>(absmax), __float_as_int(m));
+        }
     }
 }
 
