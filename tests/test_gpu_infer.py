@@ -600,3 +600,38 @@ def test_training_tape_fast_path_equals_generic(f_maps, levels, dims):
     stem = "backbone.encoders.0.basic_module.SingleConv1.groupnorm."
     bad = {k: v for k, v in worst.items() if v > (2e-3 if k.startswith(stem) else 2e-4)}
     assert not bad, bad
+
+
+def test_full_size_256_volume_properties():
+    """BASELINE's bench configuration (256^3 ellipsoid volume, full-width net, 27 tiles) through properties that need no
+    oracle at this size: the hipGraph / two-lane replay equals the eager serial submission bit for bit; a second run
+    reproduces the first; labels stay within the LUT's range (LUT values where one tile covers a voxel); voxels outside
+    every tile's mask stay exactly zero;
+    stitched float maps are finite."""
+    import bench
+    from brainfm_amd import test_utils as TU
+    from brainfm_amd.engine import LABELS_FULL
+    ga, ta = TU.default_inference_args(f_maps=64, num_levels=6)
+    torch.manual_seed(1)
+    s = TU.InferenceSession(ga, ta, _dev(), passes=3)
+    full = bench.make_volume(256, _dev())
+    eager, ranges, cnt = TU.tiled_inference(full, s, [80] * 3, [160] * 3, graphs=False)
+    eager = {k: v.clone() for k, v in eager.items()}
+    assert len(ranges) == 27 and int(cnt.max()) == 8
+    TU.prepare_tile_graphs(full, s, [80] * 3, [160] * 3)
+    for rep in range(2):
+        acc, _, _ = TU.tiled_inference(full, s, [80] * 3, [160] * 3, graphs=True)
+        for k in eager:
+            assert torch.equal(acc[k], eager[k]), (k, rep)
+    lab = eager["label"]
+    inside = full[0, 0] != 0
+    # the reference stitches the label map like every other key (sum of the tiles' labels / cnt, quirk kept): where the
+    # overlapping tiles agree it is a LUT value, elsewhere a mean of LUT values
+    assert float(lab.min()) >= min(LABELS_FULL) and float(lab.max()) <= max(LABELS_FULL)
+    once = cnt == 1
+    if bool((once & inside).any()):
+        lut = torch.tensor(sorted(set(LABELS_FULL)), device=_dev(), dtype=torch.float32)
+        assert bool(torch.isin(lab[once & inside], lut).all())
+    for k, v in eager.items():
+        assert bool(torch.isfinite(v).all()), k
+        assert float(v[~inside].abs().max()) == 0.0, k        # masked out in every tile
