@@ -60,6 +60,7 @@ class UNetEngine:
     """
     prof = None
     lane = 0
+    weights_epoch = 0           # bumped when the weights change in place: captured graphs bake in the packing exponents
     pack_count = 0              # packed weight forms created so far (train.py: lazily created ones order the sample lanes)
     _ws_lanes = None
     tape = None                 # training (backward.py): list that single_conv / maxpool append their records to
@@ -208,6 +209,7 @@ class UNetEngine:
         hangs on it), so that nothing is packed lazily inside the next pass; forms only the autotune trials used are
         dropped.  All max |w| come to the host in ONE copy.  `refresh(ly, dg)` re-derives a data-gradient layer's weights."""
         jobs = []                                          # (layer, layout, max|w| tensor)
+        self.weights_epoch += 1
 
         def absmax(t):                                     # one read pass, no |w| copy
             lo, hi = torch.aminmax(t)

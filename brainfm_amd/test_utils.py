@@ -287,6 +287,7 @@ class InferenceSession:
         self._graph_seen = set()
         self._graphs = {}
         self._graph_pool = {}
+        self._graphs_epoch = 0
         # Tiles of one volume are independent until they are stitched: with lanes > 1 consecutive tiles replay their
         # graphs on separate streams (own static buffers, own scratch), so that one tile's small kernels (GroupNorm
         # finalize, split-K reduce, pooling: ~10 % of a step at 8 blocks each) and kernel tails run under the other
@@ -313,6 +314,11 @@ class InferenceSession:
         dims = tuple(im.shape[2:])
         key = (dims, lane)
         eng = self.engine
+        if eng.weights_epoch != self._graphs_epoch:            # trained in between: graphs hold stale packing exponents
+            self._graphs.clear()
+            self._graph_seen.clear()
+            self._graph_pool = {}
+            self._graphs_epoch = eng.weights_epoch
         if key not in self._graph_seen:
             self._graph_seen.add(key)
             eng.lane = lane

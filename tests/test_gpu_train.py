@@ -291,3 +291,33 @@ def test_sample_lanes_give_the_same_bits_as_serial_samples():
     pa, pb = a.parameters(), b.parameters()
     for k in pa:
         assert torch.equal(pa[k], pb[k]), k
+
+
+def test_graph_inference_after_training_sees_the_new_weights():
+    """Captured tile graphs bake in the packing exponents; after an optimiser step the session drops them, so graph
+    replay equals eager inference on the updated weights."""
+    from brainfm_amd import test_utils as TU
+    c = load_case()
+    from conftest import sd_from_npz
+    ga, ta = TU.default_inference_args(f_maps=c["f_maps"], num_levels=c["levels"], left_hemis_only=True, num_groups=c["groups"])
+    s = TU.InferenceSession(ga, ta, _dev(), state_dict=sd_from_npz(c["d"]), passes=3)
+    from brainfm_amd import train as TR
+    step = TR.TrainStep(s.engine, s.model.head.tail(s.engine), c["loss_names"], c["loss_weights"], c["d"]["weights_ce"],
+                        c["all_samples"], lr=0.05)
+    g = torch.Generator().manual_seed(1)
+    vol = torch.rand((1, 1, 24, 20, 28), generator=g).to(_dev())
+    TU.prepare_tile_graphs(vol, s, [8] * 3, [16] * 3)
+    before, _, _ = TU.tiled_inference(vol, s, [8] * 3, [16] * 3, graphs=True)
+    before = {k: v.clone() for k, v in before.items()}
+    d = c["d"]
+    target = {k[7:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("target/")}
+    xs = [torch.from_numpy(d["x0"])]
+    samples = [{"bias_field_log": torch.from_numpy(d["bias_field_log0"]), "high_res_residual": torch.from_numpy(d["high_res_residual0"])}]
+    step.step(xs, target, samples)
+    eager, _, _ = TU.tiled_inference(vol, s, [8] * 3, [16] * 3, graphs=False)
+    eager = {k: v.clone() for k, v in eager.items()}
+    for rep in range(3):
+        got, _, _ = TU.tiled_inference(vol, s, [8] * 3, [16] * 3, graphs=True)
+        for k in eager:
+            assert torch.equal(got[k], eager[k]), (k, rep)
+    assert any(not torch.equal(before[k], eager[k]) for k in eager)
