@@ -1057,20 +1057,21 @@ __global__ void splitk_reduce(const float* __restrict__ ws, int splitk, int64_t 
 constexpr int PK_ROW = KC * 27 + 1;                         // odd row pitch: lanes of a fragment differ in co
 __global__ void __launch_bounds__(256) pack_mfma_tiled(const float* __restrict__ w, int Cin, int Cout, int wexp,
                                                        uint4* __restrict__ out) {
-    extern __shared__ float pk_lds[];                       // [64][PK_ROW]
+    extern __shared__ float pk_lds[];                       // [32][PK_ROW]: one 32-channel column block (55 KB: 2 blocks / CU)
     const int KCN = Cin / KC;
-    const int kc = blockIdx.x % KCN, ntile = blockIdx.x / KCN;
+    const int nb = blockIdx.x & 1;
+    const int kc = (blockIdx.x >> 1) % KCN, ntile = (blockIdx.x >> 1) / KCN;
     const float s = ldexpf(1.0f, wexp);
-    for (int i = threadIdx.x; i < 64 * KC * 27; i += 256) {
+    for (int i = threadIdx.x; i < 32 * KC * 27; i += 256) {
         const int co = i / (KC * 27), r = i - co * (KC * 27);
-        pk_lds[co * PK_ROW + r] = w[((int64_t)(ntile * 64 + co) * Cin + kc * KC) * 27 + r] * s;
+        pk_lds[co * PK_ROW + r] = w[((int64_t)(ntile * 64 + nb * 32 + co) * Cin + kc * KC) * 27 + r] * s;
     }
     __syncthreads();
-    uint4* dst = out + (int64_t)blockIdx.x * (27 * 2 * 2 * 64);
+    uint4* dst = out + (int64_t)(blockIdx.x >> 1) * (27 * 2 * 2 * 64);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int f = wave; f < 27 * 2 * 2; f += 4) {            // fragment index: ((tap * 2 + nb) * 2 + hl)
-        const int hl = f & 1, nb = (f >> 1) & 1, tap = f >> 2;
-        const float* src = pk_lds + (nb * 32 + (lane & 31)) * PK_ROW + ((lane >> 5) * 8) * 27 + tap;
+    for (int q = wave; q < 27 * 2; q += 4) {                // (tap, hl) of this column block
+        const int hl = q & 1, tap = q >> 1;
+        const float* src = pk_lds + (lane & 31) * PK_ROW + ((lane >> 5) * 8) * 27 + tap;
         half8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1078,7 +1079,7 @@ __global__ void __launch_bounds__(256) pack_mfma_tiled(const float* __restrict__
             const _Float16 hh = (_Float16)x;
             v[j] = hl ? (_Float16)(x - (float)hh) : hh;
         }
-        dst[f * 64 + lane] = *reinterpret_cast<uint4*>(&v);
+        dst[((tap * 2 + nb) * 2 + hl) * 64 + lane] = *reinterpret_cast<uint4*>(&v);
     }
 }
 
@@ -1213,8 +1214,8 @@ extern "C" int bfm_pack_conv_weights_mfma(const float* w, int Cin, int Cout, flo
         wexp = wexp > 60 ? 60 : (wexp < -60 ? -60 : wexp);
     }
     *wexp_host = wexp;
-    const int64_t nblk = (int64_t)(Cout / 64) * (Cin / KC);
-    const size_t smem = (size_t)64 * PK_ROW * sizeof(float);
+    const int64_t nblk = (int64_t)(Cout / 64) * (Cin / KC) * 2;
+    const size_t smem = (size_t)32 * PK_ROW * sizeof(float);
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_mfma_tiled), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1226,7 +1227,7 @@ extern "C" int bfm_pack_conv_weights_mfma(const float* w, int Cin, int Cout, flo
         hipLaunchKernelGGL(pack_mfma_tiled, dim3((unsigned)nblk), dim3(256), smem, bfm_s(stream), w, Cin, Cout, wexp,
                            reinterpret_cast<uint4*>(wpacked));
     } else {
-        int64_t n = nblk * 27 * 2 * 2 * 64;
+        int64_t n = (nblk / 2) * 27 * 2 * 2 * 64;
         int nb = (int)std::min<int64_t>(4096, bfm_cdiv64(n, 256));
         hipLaunchKernelGGL(pack_mfma, dim3(nb), dim3(256), 0, bfm_s(stream), w, Cin, Cout, wexp,
                            reinterpret_cast<uint4*>(wpacked));

@@ -1045,24 +1045,25 @@ __global__ void pack_wino(const float* __restrict__ w, int Cin, int Cout, int we
 constexpr int PKW_ROW = KC * 27 + 1;
 __global__ void __launch_bounds__(256) pack_wino_tiled(const float* __restrict__ w, int Cin, int Cout, int wexp, int npl,
                                                        uint4* __restrict__ out) {
-    extern __shared__ float pkw_lds[];                      // [64][PKW_ROW]
+    extern __shared__ float pkw_lds[];                      // [32][PKW_ROW]: one 32-channel column block (2 blocks / CU)
     const int KCN = Cin / KC;
     const int nf = 2 * npl;
-    const int kc = blockIdx.x % KCN, ntile = blockIdx.x / KCN;
+    const int nb = blockIdx.x & 1;
+    const int kc = (blockIdx.x >> 1) % KCN, ntile = (blockIdx.x >> 1) / KCN;
     const float s = ldexpf(1.0f, wexp);
-    for (int i = threadIdx.x; i < 64 * KC * 27; i += 256) {
+    for (int i = threadIdx.x; i < 32 * KC * 27; i += 256) {
         const int co = i / (KC * 27), r = i - co * (KC * 27);
-        pkw_lds[co * PKW_ROW + r] = w[((int64_t)(ntile * 64 + co) * Cin + kc * KC) * 27 + r];
+        pkw_lds[co * PKW_ROW + r] = w[((int64_t)(ntile * 64 + nb * 32 + co) * Cin + kc * KC) * 27 + r];
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nfrag = 4 * 9 * nf;                            // (ps, t, f)
+    const int nfrag = 4 * 9 * npl;                           // (ps, t, hl) of this column block
     for (int q = wave; q < nfrag; q += 4) {
-        const int f = q % nf;
-        const int t = (q / nf) % 9;
-        const int ps = q / (nf * 9);
-        const int nb = f / npl, hl = f - nb * npl;
-        const float* src = pkw_lds + (nb * 32 + (lane & 31)) * PKW_ROW + (8 * (lane >> 5)) * 27 + t * 3;
+        const int hl = q % npl;
+        const int t = (q / npl) % 9;
+        const int ps = q / (npl * 9);
+        const int f = nb * npl + hl;
+        const float* src = pkw_lds + (lane & 31) * PKW_ROW + (8 * (lane >> 5)) * 27 + t * 3;
         half8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1116,8 +1117,8 @@ extern "C" int bfm_pack_conv_weights_wino(const float* w_oidhw, int Cin, int Cou
     }
     *wexp_host = wexp;
     const int npl = passes == 3 ? 2 : 1;
-    const int64_t nblk = (int64_t)(Cout / 64) * (Cin / KC);
-    const size_t smem = (size_t)64 * PKW_ROW * sizeof(float);
+    const int64_t nblk = (int64_t)(Cout / 64) * (Cin / KC) * 2;
+    const size_t smem = (size_t)32 * PKW_ROW * sizeof(float);
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_wino_tiled), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1129,7 +1130,7 @@ extern "C" int bfm_pack_conv_weights_wino(const float* w_oidhw, int Cin, int Cou
         hipLaunchKernelGGL(pack_wino_tiled, dim3((unsigned)nblk), dim3(256), smem, bfm_s(stream), w_oidhw, Cin, Cout, wexp, npl,
                            static_cast<uint4*>(wpacked));
     } else {
-        const int64_t n = nblk * 4 * 9 * 2 * npl * 64;
+        const int64_t n = (nblk / 2) * 4 * 9 * 2 * npl * 64;
         int nb = (int)std::min<int64_t>(4096, bfm_cdiv64(n, 256));
         hipLaunchKernelGGL(pack_wino, dim3(nb), dim3(256), 0, bfm_s(stream), w_oidhw, Cin, Cout, wexp, npl,
                            static_cast<uint4*>(wpacked));
