@@ -38,6 +38,9 @@ def nearest_index_map(n_in, n_out):
     return np.minimum(idx, n_in - 1).astype(np.int32)
 
 
+_TUNE_CHOICES = {}          # (device, passes, shape key) -> conv variant that won UNetEngine._autotune in this process
+
+
 class _Layer:
     __slots__ = ("name", "cin", "cout", "groups", "gamma", "beta", "kind", "wpacked", "wexp", "w_raw", "packs", "skip",
                  "used")
@@ -295,6 +298,13 @@ class UNetEngine:
         cfg = self._plan_cache[key]
         if key in self._tuned or os.environ.get("BFM_CONV_VER") or os.environ.get("BFM_CONV_TUNE", "1") == "0":
             return cfg
+        # one choice per process, device and shape: a second engine (another session, a resumed run) takes the first
+        # one's winner instead of re-timing, so that two sessions in one process compute bit-identical results
+        gkey = (torch.cuda.current_device(), getattr(self, "passes", None), key)
+        if gkey in _TUNE_CHOICES:
+            cfg[6] = _TUNE_CHOICES[gkey]
+            self._tuned.add(key)
+            return cfg
         best, best_ms = cfg[6], None
         # Winograd (3) takes single-source layers only; its wave-specialised form (4, BFM_CONV_VER=4) has not beaten it
         # on any shape measured so far, so it is not timed here
@@ -321,6 +331,7 @@ class UNetEngine:
                 best, best_ms = ver, ms
         cfg[6] = best
         self._tuned.add(key)
+        _TUNE_CHOICES[gkey] = best
         return cfg
 
     def _gn_stats(self, ly, A, ca, B, cb, dims, lo_dims, upp, scale, shift, bound, ws_min):
