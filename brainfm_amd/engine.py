@@ -334,6 +334,24 @@ class UNetEngine:
         _TUNE_CHOICES[gkey] = best
         return cfg
 
+    def conv_choices(self):
+        """{shape key: variant} of every conv shape timed so far in this process on this device (see _autotune)."""
+        dev, ps = torch.cuda.current_device(), getattr(self, "passes", None)
+        return {k[2]: v for k, v in _TUNE_CHOICES.items() if k[0] == dev and k[1] == ps}
+
+    def adopt_conv_choices(self, table):
+        """Take another engine's (another rank's) winners: shapes not timed here yet will use them without timing, and
+        shapes already timed switch over (weights are packed per variant on first use).  Returns True when a shape
+        already in use changed variant -- captured graphs then hold the old kernels and must be dropped."""
+        dev, ps = torch.cuda.current_device(), getattr(self, "passes", None)
+        changed = False
+        for key, ver in table.items():
+            _TUNE_CHOICES[(dev, ps, key)] = ver
+            if key in self._tuned and self._plan_cache[key][6] != ver:
+                self._plan_cache[key][6] = ver
+                changed = True
+        return changed
+
     def _gn_stats(self, ly, A, ca, B, cb, dims, lo_dims, upp, scale, shift, bound, ws_min):
         """GroupNorm scale/shift/bound of cat((A, up(B))).  Uses the producers' moment rows when every source has
         them (and the upsample is an exact 2x, so every low-res voxel weighs 8); otherwise reads the tensors."""

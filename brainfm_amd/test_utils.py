@@ -646,6 +646,40 @@ DIST_ROUNDS = os.environ.get("BFM_DIST_ROUNDS", "1") != "0"
 
 
 @torch.no_grad()
+def agree_on_conv_variants(session, full_im, ranges, group=None):
+    """Every rank launches the same conv variant for the same layer shape.  The variants are timed per process
+    (UNetEngine._autotune) and agree to ~1e-6, not bit for bit, so without this a volume's result would depend on which
+    rank happened to compute which tile.  Rank 0 times the shapes of every distinct tile size of this volume (one eager
+    tile each, once per session) and broadcasts its table; the others adopt it.  Skipped when the variants are pinned
+    (BFM_CONV_VER, BFM_CONV_TUNE=0)."""
+    import os
+    import torch.distributed as dist
+    if os.environ.get("BFM_CONV_VER") or os.environ.get("BFM_CONV_TUNE", "1") == "0":
+        return
+    sizes = sorted({tuple(b - a for a, b in r) for r in ranges})
+    agreed = session.__dict__.setdefault("_agreed_sizes", set())
+    todo = [s_ for s_ in sizes if s_ not in agreed]
+    if not todo:
+        return
+    eng = session.engine
+    src = 0 if group is None else dist.get_global_rank(group, 0)
+    box = [None]
+    if dist.get_rank(group) == 0:
+        for s_ in todo:
+            im = full_im[:, :, :s_[0], :s_[1], :s_[2]]
+            if tuple(im.shape[2:]) == s_:
+                _run_tile(session, im, raw=True)                 # times whatever shapes are new
+        torch.cuda.synchronize(full_im.device)
+        box = [eng.conv_choices()]
+    with torch.cuda.device(full_im.device):                   # RCCL stages the pickled table through the current device
+        dist.broadcast_object_list(box, src=src, group=group)
+    if eng.adopt_conv_choices(box[0]) and session._graphs:
+        session._graphs.clear()
+        session._graph_seen.clear()
+        session._graph_pool = {}
+    agreed.update(todo)
+
+
 def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 160], group=None,
                                 ops=None, rounds=None):
     """Tiles are independent (GroupNorm statistics are per tile), so they shard over ranks with no
@@ -698,6 +732,8 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
             return _exchange_buffer(session, name, numel, dev)     # persistent; padding is never read: no fill
         return torch.zeros(numel, dtype=torch.float32, device=dev)
 
+    if direct and session is not None and dev.type == "cuda":
+        agree_on_conv_variants(session, full_im, ranges, group)
     keys = None
     works, gathered = [], []
     mine = tiles_of[rank]

@@ -1,6 +1,6 @@
 """Helper of tests/test_gpu_infer.py::test_distributed_path_two_ranks_share_one_gpu: two gloo ranks that share cuda:0 run
-the real multi-GPU code path (tile sharding, lanes, graph replay, pack kernels, round-wise asynchronous gathers, ordered
-accumulation on rank 0) and rank 0 compares with the single-process result bit for bit.  Prints OK / FAIL."""
+the real multi-GPU code path (agreement on the conv variants, tile sharding, lanes, graph replay, pack kernels, round-wise
+asynchronous gathers, ordered accumulation on rank 0) and rank 0 compares with the single-process result bit for bit.  Prints OK / FAIL."""
 import os, sys, socket
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -28,6 +28,36 @@ def worker(rank, world, port, q):
             bad = [k for k in ref if not torch.equal(acc[k], ref[k])]
             print("rep", rep, "bad", bad, flush=True)
             ok = ok and not bad
+    # a 64-wide net (MFMA convs, timed variants): rank 1 starts from deliberately different variant choices; the
+    # agreement step (test_utils.agree_on_conv_variants) must bring it onto rank 0's table, and the volume must again
+    # equal the single-process one bit for bit
+    from oracle import unet_ref as O
+    from brainfm_amd import engine as E
+    sd = O.random_state_dict(1, 64, 3, seed=5)
+    ga, ta = TU.default_inference_args(f_maps=64, num_levels=3)
+    s2 = TU.InferenceSession(ga, ta, dev, state_dict=sd, passes=3)
+    g = torch.Generator().manual_seed(21)
+    full2 = torch.rand(1, 1, 48, 40, 56, generator=g).to(dev)
+    ref2 = None
+    if rank == 0:
+        ref2, _, _ = TU.tiled_inference(full2, s2, [16] * 3, [32] * 3, graphs=False)
+        ref2 = {k: v.clone() for k, v in ref2.items()}
+    else:
+        TU._run_tile(s2, full2[:, :, :32, :32, :32], raw=True)            # times the variants here ...
+        mine = s2.engine.conv_choices()
+        s2.engine.adopt_conv_choices({k: (1 if v == 0 else 0) for k, v in mine.items()})   # ... and takes other ones
+    s2.use_graphs = True
+    for rep in range(3):
+        acc, _, _ = TU.tiled_inference_distributed(full2, s2, [16] * 3, [32] * 3)
+        if rank == 0:
+            bad = [k for k in ref2 if not torch.equal(acc[k], ref2[k])]
+            print("wide net rep", rep, "bad", bad, flush=True)
+            ok = ok and not bad
+    tables = [None] * world
+    dist.all_gather_object(tables, s2.engine.conv_choices())
+    if rank == 0:
+        print("conv variants per rank", [{v: list(t.values()).count(v) for v in set(t.values())} for t in tables], flush=True)
+        ok = ok and len(tables[0]) > 0 and all(all(t.get(k) == v for k, v in tables[0].items()) for t in tables[1:])
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
