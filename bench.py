@@ -136,8 +136,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    debug = os.environ.get("BFM_BENCH_DEBUG") == "1"       # per-step times on stderr (adds a device sync per step)
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
+        if debug:
+            torch.cuda.synchronize()
+            print("rank %d step %.1f ms" % (rank, 1e3 * (time.perf_counter() - ts)), file=sys.stderr, flush=True)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()

@@ -527,12 +527,16 @@ def tiled_inference(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 1
 
 
 @torch.no_grad()
-def prepare_tile_graphs(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 160], world=1, rank=0):
+def prepare_tile_graphs(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 160], world=1, rank=0, group=None):
     """Tune + capture the hipGraph of every tile shape this rank will see (first tile of each shape, run twice:
-    eager, then capture + replay).  Optional: tiled_inference does the same lazily on the first volumes."""
+    eager, then capture + replay).  Optional: tiled_inference does the same lazily on the first volumes.  With more
+    than one rank (collective call then) the ranks first agree on the conv variants, so that the graphs captured here
+    are the ones tiled_inference_distributed replays."""
     shape = tuple(full_im.shape[2:])
     ranges = tiling_ranges(shape, stride, win_size)
     owner = assign_tiles(ranges, world)
+    if world > 1:
+        agree_on_conv_variants(session, full_im, ranges, group)
     done = set()
     for i, rng in enumerate(ranges):
         dims = tuple(b - a for a, b in rng)
@@ -654,7 +658,8 @@ def agree_on_conv_variants(session, full_im, ranges, group=None):
     (BFM_CONV_VER, BFM_CONV_TUNE=0)."""
     import os
     import torch.distributed as dist
-    if os.environ.get("BFM_CONV_VER") or os.environ.get("BFM_CONV_TUNE", "1") == "0":
+    if os.environ.get("BFM_CONV_VER") or os.environ.get("BFM_CONV_TUNE", "1") == "0" or \
+            os.environ.get("BFM_DIST_AGREE", "1") == "0":
         return
     sizes = sorted({tuple(b - a for a, b in r) for r in ranges})
     agreed = session.__dict__.setdefault("_agreed_sizes", set())
