@@ -56,10 +56,11 @@ def conv_flops_tile(dims, fm=(64, 128, 256, 512, 1024, 2048)):
 
 def cpu_baseline(state_dict, full, n):
     """The CPU oracle (a port of the reference's PyTorch-CPU path) timed on this host, rank 0 only,
-    on a bounded sample: the first 80^3 tile of the reference tiling (all heads)."""
+    on a bounded sample: one central 128^3 tile of the volume (the size of BASELINE.json's configs[0]), all heads:
+    ~10-15 s of CPU work on the GPU box's host."""
     from oracle import unet_ref as O
     cores = torch.get_num_threads()
-    s = 80 if n >= 160 else max(16, n // 2)
+    s = 128 if n >= 160 else max(16, n // 2)
     tile = full[:, :, n // 2 - s // 2:n // 2 + s // 2, n // 2 - s // 2:n // 2 + s // 2,
                 n // 2 - s // 2:n // 2 + s // 2].cpu().contiguous()
     sd = {k: v.detach().cpu() for k, v in state_dict.items()}

@@ -431,7 +431,7 @@ def tile_cost(rng):
 
 
 TILE_OVERHEAD_VOXELS = 160000      # fixed cost of a tile in voxel units: 80^3 takes 3.0 ms, 160^3 19 ms (t = 4.46 ms/Mvox + 0.71 ms)
-ROOT_SHARE = 0.02                  # rank 0 also receives, accumulates and divides: handicap as a fraction of all voxels
+PEER_SEND_VOXELS = 160000          # a peer's last (smallest) tile still has to travel to rank 0: ~33 MB over one xGMI link
 
 
 def tile_time(rng):
@@ -440,12 +440,13 @@ def tile_time(rng):
 
 
 def assign_tiles(ranges, world_size):
-    """Longest-processing-time-first assignment of tiles to ranks on the modelled tile cost; rank 0 starts with a
-    handicap for the exchange and accumulation it does on top.  Deterministic (every rank computes the same map)."""
+    """Longest-processing-time-first assignment of tiles to ranks on the modelled tile cost.  Rank 0 keeps its own
+    tile outputs where the accumulation runs (nothing of it travels), so ties go to rank 0 -- it takes the largest
+    tile, the one whose 16 maps (262 MB for 160^3) would otherwise be the longest transfer at the end of the step --
+    and every peer starts with a handicap for the exposed transfer of its last tile.  Deterministic (every rank
+    computes the same map)."""
     order = sorted(range(len(ranges)), key=lambda i: (-tile_time(ranges[i]), i))
-    load = [0] * world_size
-    if world_size > 1:
-        load[0] = int(ROOT_SHARE * sum(tile_cost(r) for r in ranges))
+    load = [0] + [PEER_SEND_VOXELS] * (world_size - 1)
     owner = [0] * len(ranges)
     for i in order:
         r = min(range(world_size), key=lambda k: (load[k], k))
@@ -717,12 +718,15 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
         nkeys = len(session.stitch_keys())
     if nkeys is None:
         nkeys = len(STITCH_KEYS)
-    # per rank: its tiles, largest first (ties in reference order); slot[i] = (round, offset in that round's buffer)
+    # per rank: its tiles, largest first (ties in reference order); slot[i] = (round, offset in that round's buffer).
+    # Rank 0's own tiles never travel: they are packed into a private buffer per round, and the round's (padded) size
+    # is set by the peers alone.
     tiles_of = [sorted([i for i in range(len(ranges)) if owner[i] == r], key=lambda i: (-tile_cost(ranges[i]), i))
                 for r in range(world)]
     nrounds = max(len(t) for t in tiles_of) if rounds else 1
     round_of, off_of = {}, {}
-    round_numel = [0] * nrounds
+    round_numel = [1] * nrounds
+    own_numel = [1] * nrounds
     for r in range(world):
         fill = [0] * nrounds
         for k, i in enumerate(tiles_of[r]):
@@ -730,7 +734,10 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
             round_of[i], off_of[i] = kk, fill[kk]
             fill[kk] += tile_cost(ranges[i]) * nkeys
         for kk in range(nrounds):
-            round_numel[kk] = max(round_numel[kk], fill[kk], 1)
+            if r == 0:
+                own_numel[kk] = max(own_numel[kk], fill[kk])
+            else:
+                round_numel[kk] = max(round_numel[kk], fill[kk])
 
     def _buf(name, numel):
         if session is not None and direct:
@@ -740,7 +747,7 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
     if direct and session is not None and dev.type == "cuda":
         agree_on_conv_variants(session, full_im, ranges, group)
     keys = None
-    works, gathered = [], []
+    works, gathered, own, pending = [], [], [], []
     mine = tiles_of[rank]
     lanes = session.lanes if (direct and session is not None and session.use_graphs and dev.type == "cuda") else 1
     start = None
@@ -749,7 +756,11 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
         start.record(torch.cuda.current_stream(dev))           # send buffers are free, the input is in place
     nrun = 0
     for kk in range(nrounds):
-        sbuf = _buf("send%d" % kk, round_numel[kk])
+        sbuf = _buf("send%d" % kk, round_numel[kk])            # on rank 0: the padding the gather asks of its root
+        dst = sbuf
+        if rank == 0:
+            dst = _buf("own%d" % kk, own_numel[kk])
+            own.append(dst)
         todo = [i for i in mine if round_of[i] == kk]
         for i in todo:
             (x0, x1), (y0, y1), (z0, z1) = ranges[i]
@@ -761,18 +772,22 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
                     w.wait()                                       # is being captured
             if direct and lanes > 1:
                 # consecutive tiles of this rank alternate between the lanes' streams; the gather of a round waits for
-                # that round's tiles only
-                keys, _, done = ops.run_tile(im, out=sbuf[off_of[i]:off_of[i] + n], lane=nrun % lanes, after=start)
+                # that round's tiles only -- and on rank 0 for none: its receives are posted at once, whatever it is
+                # still computing itself
+                keys, _, done = ops.run_tile(im, out=dst[off_of[i]:off_of[i] + n], lane=nrun % lanes, after=start)
                 nrun += 1
                 if done is not None:
-                    torch.cuda.current_stream(dev).wait_event(done)
+                    if rank == 0:
+                        pending.append(done)
+                    else:
+                        torch.cuda.current_stream(dev).wait_event(done)
             elif direct:
-                keys, _ = ops.run_tile(im, out=sbuf[off_of[i]:off_of[i] + n])
+                keys, _ = ops.run_tile(im, out=dst[off_of[i]:off_of[i] + n])
             else:
                 keys, rows = ops.run_tile(im)
                 if len(keys) != nkeys:
                     raise RuntimeError("ops.run_tile returned %d maps, expected %d" % (len(keys), nkeys))
-                sbuf[off_of[i]:off_of[i] + n] = rows.reshape(-1)
+                dst[off_of[i]:off_of[i] + n] = rows.reshape(-1)
         g = [_buf("recv%d_%d" % (kk, r), round_numel[kk]) for r in range(world)] if rank == 0 else None
         gathered.append(g)
         works.append(dist.gather(sbuf, g, dst=0, group=group, async_op=True))
@@ -782,10 +797,13 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
         return None, ranges, None
     if keys is None:
         keys = (session.stitch_keys() if session is not None else [k for k in STITCH_KEYS])[:nkeys]
+    for ev in pending:                                        # rank 0's own tiles (lanes)
+        torch.cuda.current_stream(dev).wait_event(ev)
     acc_buf = torch.zeros((nkeys,) + shape, dtype=torch.float32, device=dev)
     for i, rng in enumerate(ranges):                          # reference tile order
         nv = tile_cost(rng)
-        rows = gathered[round_of[i]][owner[i]][off_of[i]:off_of[i] + nv * nkeys].reshape(nkeys, nv)
+        src = own[round_of[i]] if owner[i] == 0 else gathered[round_of[i]][owner[i]]
+        rows = src[off_of[i]:off_of[i] + nv * nkeys].reshape(nkeys, nv)
         if direct:
             ops.add_all(acc_buf, rows, rng, shape)
         else:

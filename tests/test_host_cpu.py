@@ -97,8 +97,10 @@ def test_lpt_assignment_balances_tiles():
         cost = [sum(TU.tile_time(r) for r, o in zip(ranges, owner) if o == k) for k in range(world)]
         # modelled cost (voxels + per-tile overhead) within 15 % of the mean, or bounded by the one 160^3 tile
         assert max(cost) <= max(TU.tile_time(((0, 160),) * 3) + TU.tile_time(((0, 80),) * 3), 1.15 * sum(cost) / world)
-        if world > 1:                                         # rank 0 also gathers and accumulates: never the heaviest
-            assert cost[0] <= max(cost[1:])
+        big = max(range(len(ranges)), key=lambda i: TU.tile_cost(ranges[i]))
+        assert owner[big] == 0                                # the largest tile's maps never travel: rank 0 computes it
+        if world > 1:
+            assert max(cost) <= 1.07 * sum(cost) / world
     assert TU.assign_tiles(ranges, 8) == TU.assign_tiles(ranges, 8)
 
 
