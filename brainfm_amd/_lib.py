@@ -154,6 +154,7 @@ SIGNATURES = {
     "bfm_divide_by_count": (_I, [_P, _P, _L, _P]),
     "bfm_pack_tile_multi": (_I, [_P, _L, _P, _I, _P, _P, _L, _P, _P]),
     "bfm_divide_by_count_multi": (_I, [_P, _P, _L, _I, _P]),
+    "bfm_stitch_gather_multi": (_I, [_P, _I, _I, _P, _I, _I, _I, _P]),
 }
 
 _lib = None

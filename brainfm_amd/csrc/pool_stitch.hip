@@ -180,6 +180,95 @@ __global__ void divide_kernel(float* __restrict__ full, const float* __restrict_
         full[i] = full[i] / cnt[i];
 }
 
+// The whole stitch of the multi-GPU path in one launch (scripts/demo_test.py:108-119): every tile's K masked rows are
+// resident on rank 0 (packed [K][td*th*tw] by pack_multi_kernel, own or received), so each output voxel sums the tiles
+// that cover it IN TABLE ORDER (the reference's tile order: 0 + t_a + t_b + ... is what the sequential `full[range] +=`
+// computes), divides by their number (what the reference's cnt volume holds) and is written once -- no zero fill, no
+// read-modify-write per tile, no separate divide pass.  tiles [T][8] int64: {row pointer, z0, y0, x0, td, th, tw, 0}.
+// One block per (z, y) line: wave 0 compacts the tiles covering the line into LDS (ballot, order kept), then every
+// thread walks that short list.
+struct LineTile { const float* p; int64_t n, off; int x0, x1; };
+
+__global__ void stitch_gather_kernel(const int64_t* __restrict__ tiles, int T, int K, float* __restrict__ full, int D,
+                                     int H, int W) {
+    extern __shared__ unsigned char smem_raw[];
+    LineTile* cand = reinterpret_cast<LineTile*>(smem_raw);
+    __shared__ int ncand_s, vec_s;
+    const int64_t vol = (int64_t)D * H * W;
+    const int lane = threadIdx.x & 63;
+    const bool out_vec = !(W & 3) && !(reinterpret_cast<uintptr_t>(full) & 15);
+    for (int line = blockIdx.x; line < D * H; line += gridDim.x) {
+        const int z = line / H, y = line % H;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            int n = 0, bad = 0;
+            for (int base = 0; base < T; base += 64) {
+                const int t = base + lane;
+                bool ok = false, al = true;
+                LineTile c{nullptr, 0, 0, 0, 0};
+                if (t < T) {
+                    const int64_t* d = tiles + (int64_t)t * 8;
+                    const int z0 = (int)d[1], y0 = (int)d[2], x0 = (int)d[3];
+                    const int td = (int)d[4], th = (int)d[5], tw = (int)d[6];
+                    ok = z >= z0 && z < z0 + td && y >= y0 && y < y0 + th;
+                    c.n = (int64_t)td * th * tw;
+                    c.p = reinterpret_cast<const float*>(d[0]);
+                    c.off = ((int64_t)(z - z0) * th + (y - y0)) * tw - x0;
+                    c.x0 = x0;
+                    c.x1 = x0 + tw;
+                    al = !((x0 | tw) & 3) && !(c.n & 3) && !(d[0] & 15);   // whole 4-voxel groups in or out, 16-B rows
+                }
+                const unsigned long long m = __ballot(ok);
+                if (ok) cand[n + __popcll(m & ((1ull << lane) - 1ull))] = c;
+                n += __popcll(m);
+                bad += __popcll(__ballot(ok && !al));
+            }
+            if (lane == 0) { ncand_s = n; vec_s = (bad == 0 && out_vec) ? 1 : 0; }
+        }
+        __syncthreads();
+        const int nc = ncand_s;
+        if (vec_s) {
+            // items = (4-voxel group, key): a thread's items of one line share the group when W/4 divides the block
+            const int nq = W >> 2;
+            for (int idx = threadIdx.x; idx < nq * K; idx += blockDim.x) {
+                const int x = (idx % nq) << 2, k = idx / nq;
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                int cover = 0;
+                for (int j = 0; j < nc; j += 4) {
+                    float4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {           // loads first; an uncovered slot adds +0 (acc is never -0)
+                        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (j + u < nc && x >= cand[j + u].x0 && x < cand[j + u].x1) {
+                            v[u] = *reinterpret_cast<const float4*>(cand[j + u].p + (int64_t)k * cand[j + u].n +
+                                                                    cand[j + u].off + x);
+                            ++cover;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+                }
+                const float c = (float)cover;
+                acc.x = acc.x / c; acc.y = acc.y / c; acc.z = acc.z / c; acc.w = acc.w / c;
+                *reinterpret_cast<float4*>(full + (int64_t)k * vol + (int64_t)line * W + x) = acc;
+            }
+            continue;
+        }
+        for (int x = threadIdx.x; x < W; x += blockDim.x) {
+            const int64_t o = (int64_t)line * W + x;
+            int cover = 0;
+            for (int j = 0; j < nc; ++j) cover += (x >= cand[j].x0 && x < cand[j].x1) ? 1 : 0;
+            const float c = (float)cover;
+            for (int k = 0; k < K; ++k) {
+                float acc = 0.f;
+                for (int j = 0; j < nc; ++j)
+                    if (x >= cand[j].x0 && x < cand[j].x1) acc += cand[j].p[(int64_t)k * cand[j].n + cand[j].off + x];
+                full[(int64_t)k * vol + o] = acc / c;
+            }
+        }
+    }
+}
+
 inline int grid_for(int64_t n, int tpb = 256, int cap = 4096) {
     int64_t b = bfm_cdiv64(n, tpb);
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -286,5 +375,16 @@ extern "C" int bfm_pack_tile_multi(const float* maps, int64_t map_stride, const 
 extern "C" int bfm_divide_by_count_multi(float* full, const float* cnt, int64_t vol, int K, bfm_stream_t stream) {
     if (!full || !cnt || vol <= 0 || K <= 0) return BFM_E_ARG;
     hipLaunchKernelGGL(divide_multi_kernel, dim3(grid_for(vol)), dim3(256), 0, bfm_s(stream), full, cnt, vol, K);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_stitch_gather_multi(const int64_t* tiles, int T, int K, float* full, int D, int H, int W,
+                                       bfm_stream_t stream) {
+    if (!tiles || !full || T <= 0 || K <= 0 || D <= 0 || H <= 0 || W <= 0) return BFM_E_ARG;
+    if (T > 2048) return BFM_E_SHAPE;                          // candidate list lives in LDS (32 B per tile)
+    const int64_t lines = (int64_t)D * H;
+    const int nb = (int)(lines > 65536 ? 65536 : lines);
+    hipLaunchKernelGGL(stitch_gather_kernel, dim3(nb), dim3(256), (size_t)T * sizeof(LineTile), bfm_s(stream), tiles, T, K,
+                       full, D, H, W);
     return bfm_launch_status();
 }

@@ -631,6 +631,18 @@ class HipStitchOps:
                                                      None, x1 - x0, y1 - y0, z1 - z0, L.ptr(acc_buf), shape[0],
                                                      shape[1], shape[2], x0, y0, z0, L.stream_ptr()), "stitch_multi")
 
+    def gather_all(self, acc_buf, srcs, ranges, shape):
+        """acc_buf [K][D,H,W] = the whole stitch in one launch: srcs[i] = packed rows [K][n_i] of tile i (reference
+        order), every voxel summed over its tiles in that order, divided by their number, written once
+        (bfm_stitch_gather_multi; same bits as add_all per tile on a zeroed volume + finalize_all)."""
+        key = tuple((s_.data_ptr(),) + tuple(a for a, _ in r) + tuple(b - a for a, b in r) for s_, r in zip(srcs, ranges))
+        tab = self._sel.get(("gather", acc_buf.device))
+        if tab is None or tab[0] != key:
+            host = torch.tensor([list(k_) + [0] for k_ in key], dtype=torch.int64)
+            tab = self._sel[("gather", acc_buf.device)] = (key, host.to(acc_buf.device))
+        L.check(self.lib.bfm_stitch_gather_multi(L.ptr(tab[1]), len(ranges), acc_buf.shape[0], L.ptr(acc_buf), shape[0],
+                                                 shape[1], shape[2], L.stream_ptr()), "stitch_gather_multi")
+
     def finalize_all(self, acc_buf, cnt):
         L.check(self.lib.bfm_divide_by_count_multi(L.ptr(acc_buf), L.ptr(cnt), cnt.numel(), acc_buf.shape[0],
                                                    L.stream_ptr()), "divide_multi")
@@ -648,6 +660,7 @@ def _exchange_buffer(session, name, numel, dev):
 
 
 DIST_ROUNDS = os.environ.get("BFM_DIST_ROUNDS", "1") != "0"
+GATHER_STITCH = os.environ.get("BFM_GATHER_STITCH", "1") != "0"     # 0: per-tile accumulate + divide on rank 0
 
 
 @torch.no_grad()
@@ -705,7 +718,11 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
     if rounds is None:
         rounds = DIST_ROUNDS
     if ops is None:
-        ops = HipStitchOps(session)
+        ops = getattr(session, "_stitch_ops", None)               # kept on the session: its device tables are reused
+        if ops is None:
+            ops = HipStitchOps(session)
+            if session is not None:
+                session._stitch_ops = ops
     shape = tuple(full_im.shape[2:])
     ranges = tiling_ranges(shape, stride, win_size)
     owner = assign_tiles(ranges, world)
@@ -799,21 +816,34 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
         keys = (session.stitch_keys() if session is not None else [k for k in STITCH_KEYS])[:nkeys]
     for ev in pending:                                        # rank 0's own tiles (lanes)
         torch.cuda.current_stream(dev).wait_event(ev)
-    acc_buf = torch.zeros((nkeys,) + shape, dtype=torch.float32, device=dev)
+    srcs = []
     for i, rng in enumerate(ranges):                          # reference tile order
         nv = tile_cost(rng)
         src = own[round_of[i]] if owner[i] == 0 else gathered[round_of[i]][owner[i]]
-        rows = src[off_of[i]:off_of[i] + nv * nkeys].reshape(nkeys, nv)
+        srcs.append(src[off_of[i]:off_of[i] + nv * nkeys].reshape(nkeys, nv))
+    cnt = None
+    if session is not None and direct:                        # the count volume depends on the tiling alone
+        ckey = ("cnt", shape, tuple(stride), tuple(win_size), str(dev))
+        cnt = session.__dict__.setdefault("_dist_cnt", {}).get(ckey)
+    if cnt is None:
+        cnt = count_volume(shape, ranges, dev)
+        if session is not None and direct:
+            session._dist_cnt[ckey] = cnt
+    if hasattr(ops, "gather_all") and GATHER_STITCH:
+        acc_buf = torch.empty((nkeys,) + shape, dtype=torch.float32, device=dev)
+        ops.gather_all(acc_buf, srcs, ranges, shape)          # one launch: sum in tile order, / count, write once
+    else:
+        acc_buf = torch.zeros((nkeys,) + shape, dtype=torch.float32, device=dev)
+        for rng, rows in zip(ranges, srcs):
+            if direct:
+                ops.add_all(acc_buf, rows, rng, shape)
+            else:
+                for j in range(nkeys):
+                    ops.add(acc_buf[j], rows[j], rng, shape)
         if direct:
-            ops.add_all(acc_buf, rows, rng, shape)
+            ops.finalize_all(acc_buf, cnt)
         else:
             for j in range(nkeys):
-                ops.add(acc_buf[j], rows[j], rng, shape)
-    cnt = count_volume(shape, ranges, dev)
-    if direct:
-        ops.finalize_all(acc_buf, cnt)
-    else:
-        for j in range(nkeys):
-            ops.finalize(acc_buf[j], cnt)
+                ops.finalize(acc_buf[j], cnt)
     acc = OrderedDict((k, acc_buf[j]) for j, k in enumerate(keys))
     return acc, ranges, cnt

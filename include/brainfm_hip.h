@@ -255,6 +255,12 @@ int bfm_pack_tile_multi(const float* maps, int64_t map_stride, const int32_t* se
                         const float* tile_input, int64_t n, float* out, bfm_stream_t stream);
 /* full [K][vol] /= cnt [vol], one launch */
 int bfm_divide_by_count_multi(float* full, const float* cnt, int64_t vol, int K, bfm_stream_t stream);
+/* The whole stitch in one launch once every tile's packed rows ([K][td*th*tw], bfm_pack_tile_multi) are resident on
+ * one device -- rank 0 of the multi-GPU path, scripts/demo_test.py:108-119: full[k][v] = (0 + sum over the tiles
+ * covering v, in table order) / (their number), each voxel written once.  tiles: device table [T][8] int64 =
+ * {device pointer to the tile's rows, z0, y0, x0, td, th, tw, 0} in the reference's tile order; T <= 2048.
+ * Bit-identical to T x bfm_stitch_accumulate_multi on a zeroed volume + bfm_divide_by_count_multi. */
+int bfm_stitch_gather_multi(const int64_t* tiles, int T, int K, float* full, int D, int H, int W, bfm_stream_t stream);
 
 /* ------------------------------------------------------------ elementwise
  * Per-voxel helpers for the stand-alone processors / post-processor

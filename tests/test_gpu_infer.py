@@ -282,6 +282,36 @@ def test_distributed_path_one_rank_rccl_equals_single_gpu_path():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("shape,win,stride", [((40, 36, 44), 24, 12), ((60, 52, 70), 16, 8), ((33, 20, 17), 20, 10)])
+def test_gather_stitch_equals_per_tile_accumulate_bitwise(shape, win, stride):
+    """bfm_stitch_gather_multi (rank 0's whole stitch in one launch) against the sequential form it replaces:
+    zeroed volume, bfm_stitch_accumulate_multi per tile in the reference's order, bfm_divide_by_count_multi.  Compared
+    as bit patterns; rows carry exact zeros of both signs (masked voxels).  343 tiles in the second case: the
+    per-line candidate list is compacted over several ballots."""
+    from brainfm_amd import test_utils as TU
+    dev = _dev()
+    g = torch.Generator().manual_seed(7)
+    ranges = TU.tiling_ranges(shape, [stride] * 3, [win] * 3)
+    K = 5
+    srcs = []
+    for r in ranges:
+        n = TU.tile_cost(r)
+        rows = torch.randn((K, n), generator=g) * 10.0 ** float(torch.randint(-3, 4, (1,), generator=g))
+        rows[torch.rand((K, n), generator=g) < 0.2] = 0.0
+        rows[torch.rand((K, n), generator=g) < 0.05] = -0.0
+        srcs.append(rows.to(dev))
+    ops = TU.HipStitchOps(None)
+    ref = torch.zeros((K,) + tuple(shape), dtype=torch.float32, device=dev)
+    for r, rows in zip(ranges, srcs):
+        ops.add_all(ref, rows, r, shape)
+    ops.finalize_all(ref, TU.count_volume(shape, ranges, dev))
+    out = torch.full((K,) + tuple(shape), float("nan"), dtype=torch.float32, device=dev)
+    ops.gather_all(out, srcs, ranges, shape)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    assert not torch.isnan(out).any()
+
+
 def test_distributed_path_two_ranks_share_one_gpu():
     """world_size 2 through the real HIP multi-GPU path: two gloo ranks share this GPU (RCCL refuses two ranks on one
     device; the data path -- sharding, lanes, graph replay, pack, one asynchronous gather per round, accumulation in the
