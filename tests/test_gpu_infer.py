@@ -327,6 +327,51 @@ def test_distributed_path_two_ranks_share_one_gpu():
         raise AssertionError("two-rank run failed:\n%s\n%s" % (r.stdout[-1500:], "\n".join(err[-40:])))
 
 
+def test_full_architecture_labels_differ_from_the_fp32_reference_only_at_numerical_ties():
+    """The shipped architecture (64 maps, 6 levels, 9 heads) on one (64, 96, 128) tile.  Floats: within 1e-4 of the
+    torch-CPU fp32 oracle (north-star tolerance: 1e-3).  Labels: two fp32 evaluations of the same network cannot agree
+    on an argmax whose two best classes are closer than fp32 resolves, so the same oracle is also evaluated in float64
+    as the arbiter: (1) every voxel where the HIP label differs from the fp32 oracle's is a tie in float64 (relative
+    gap of the two best probabilities < 1e-5; measured: <= 2.2e-6); (2) against the float64 labels the HIP path flips
+    no more voxels than torch-CPU fp32 does (measured on 786 432 voxels: HIP 8, torch-CPU fp32 13; HIP vs fp32 15).
+    On the smaller nets of this file (and in smoke()) the label maps are identical."""
+    D, H, W = 64, 96, 128
+    sd = O.random_state_dict(1, 64, 6, seed=5)
+    g = torch.Generator().manual_seed(9)
+    zz, yy, xx = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(W), indexing="ij")
+    ell = (((zz - (D - 1) / 2) / (0.45 * D)) ** 2 + ((yy - (H - 1) / 2) / (0.42 * H)) ** 2 +
+           ((xx - (W - 1) / 2) / (0.44 * W)) ** 2) <= 1
+    x = torch.rand(1, 1, D, H, W, generator=g) * ell[None, None]
+    with torch.no_grad():
+        ref = O.forward_all(x, sd, f_maps=64, num_levels=6)
+        ref64 = O.forward_all(x.double(), {k: v.double() for k, v in sd.items()}, f_maps=64, num_levels=6)
+    s = _session(sd=sd, f_maps=64, levels=6, passes=3)
+    out, _ = s.forward_fused(x.to(_dev()))
+    errs = {}
+    for k, v in ref.items():
+        if k == "feat":
+            for i, f in enumerate(v):
+                errs["feat%d" % i] = _relerr(out["feat"][i].cpu().numpy(), f.numpy())
+        elif k != "label":
+            errs[k] = _relerr(out[k].cpu().numpy(), v.numpy())
+    assert max(errs.values()) <= 1e-4, errs
+    lab = out["label"].cpu()
+    top2 = torch.topk(ref64["segmentation"], 2, dim=1).values
+    gap = ((top2[:, 0] - top2[:, 1]) / top2[:, 0])[:, None]
+    differ = lab != ref["label"]
+    n_hip, n_cpu = int((lab != ref64["label"]).sum()), int((ref["label"] != ref64["label"]).sum())
+    print("label differences: HIP vs fp32 oracle %d, HIP vs fp64 %d, fp32 oracle vs fp64 %d of %d voxels; worst float "
+          "error %.2e" % (int(differ.sum()), n_hip, n_cpu, lab.numel(), max(errs.values())))
+    if int(differ.sum()):
+        assert float(gap[differ].max()) < 1e-5, float(gap[differ].max())
+    assert int(differ.sum()) <= 1e-4 * lab.numel()
+    assert n_hip <= 2 * n_cpu + 4, (n_hip, n_cpu)
+    # the softmax itself is as close to the float64 evaluation as torch-CPU fp32 is
+    e_hip = _relerr(out["segmentation"].cpu().numpy(), ref64["segmentation"].numpy())
+    e_cpu = _relerr(ref["segmentation"].numpy(), ref64["segmentation"].numpy())
+    assert e_hip <= max(2 * e_cpu, 2e-5), (e_hip, e_cpu)
+
+
 @pytest.mark.parametrize("passes,tol", [(3, TOL_NET), (1, 5e-2)])
 def test_mfma_network_vs_oracle(passes, tol):
     """64-wide 3-level net (all convs but the stem on MFMA), volume with an exact-zero background,
