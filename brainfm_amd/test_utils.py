@@ -480,9 +480,11 @@ def tiled_inference(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 1
     full_im = full_im.to(device=eng.device, dtype=torch.float32)
     shape = tuple(full_im.shape[2:])
     ranges = tiling_ranges(shape, stride, win_size)
+    nl = session.lanes if graphs else 1
+    if nl > 1 and GATHER_STITCH:
+        return _tiled_inference_lanes(full_im, session, ranges, shape, stride, win_size)
     cnt = count_volume(shape, ranges, eng.device)
     acc_buf, keys, sel = None, None, None
-    nl = session.lanes if graphs else 1
     main = torch.cuda.current_stream(eng.device)
     streams = session.lane_streams(nl) if nl > 1 else []
     consumed = [None] * nl
@@ -525,6 +527,62 @@ def tiled_inference(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 1
     L.check(lib.bfm_divide_by_count_multi(L.ptr(acc_buf), L.ptr(cnt), n, len(keys), L.stream_ptr()), "divide_by_count")
     acc = OrderedDict((k, acc_buf[j]) for j, k in enumerate(keys))
     return acc, ranges, cnt
+
+
+def _cached_count_volume(session, shape, ranges, stride, win_size, dev):
+    """The count volume depends on the tiling alone: kept on the session (callers read it, nobody writes it)."""
+    ckey = ("cnt", tuple(shape), tuple(stride), tuple(win_size), str(dev))
+    cache = session.__dict__.setdefault("_dist_cnt", {})
+    if ckey not in cache:
+        cache[ckey] = count_volume(shape, ranges, dev)
+    return cache[ckey]
+
+
+def _session_stitch_ops(session):
+    ops = getattr(session, "_stitch_ops", None)               # kept on the session: its device tables are reused
+    if ops is None:
+        ops = session._stitch_ops = HipStitchOps(session)
+    return ops
+
+
+@torch.no_grad()
+def _tiled_inference_lanes(full_im, session, ranges, shape, stride, win_size):
+    """tiled_inference with several tiles in flight: the lanes run independently of each other.  Every tile's masked
+    maps are packed ([K][n], bfm_pack_tile_multi) on its lane's stream into its slot of one persistent buffer -- no
+    lane ever waits for another lane's tile, which the per-tile `full[range] +=` on the caller's stream forced through
+    the reference's tile order -- tiles go to the lanes largest first onto the less loaded lane, and one launch
+    (bfm_stitch_gather_multi) then sums every voxel's tiles in the reference's order and divides by their number: the
+    same bits as the sequential form."""
+    dev = full_im.device
+    ops = _session_stitch_ops(session)
+    nl = session.lanes
+    nkeys = len(session.stitch_keys())
+    offs, total = [], 0
+    for r in ranges:
+        offs.append(total)
+        total += tile_cost(r) * nkeys
+    buf = _exchange_buffer(session, "rows", total, dev)
+    order = sorted(range(len(ranges)), key=lambda i: (-tile_time(ranges[i]), i))
+    load = [0] * nl
+    main = torch.cuda.current_stream(dev)
+    start = torch.cuda.Event()
+    start.record(main)                                         # the input is in place, last volume's rows are consumed
+    last, keys = {}, None
+    for i in order:
+        k = min(range(nl), key=lambda j: (load[j], j))
+        load[k] += tile_time(ranges[i])
+        (x0, x1), (y0, y1), (z0, z1) = ranges[i]
+        n = tile_cost(ranges[i]) * nkeys
+        keys, _, done = ops.run_tile(full_im[:, :, x0:x1, y0:y1, z0:z1], out=buf[offs[i]:offs[i] + n], lane=k, after=start)
+        if done is not None:
+            last[k] = done
+    for ev in last.values():
+        main.wait_event(ev)
+    srcs = [buf[offs[i]:offs[i] + tile_cost(r) * nkeys].view(nkeys, tile_cost(r)) for i, r in enumerate(ranges)]
+    acc_buf = torch.empty((nkeys,) + tuple(shape), dtype=torch.float32, device=dev)
+    ops.gather_all(acc_buf, srcs, ranges, shape)
+    cnt = _cached_count_volume(session, shape, ranges, stride, win_size, dev)
+    return OrderedDict((k_, acc_buf[j]) for j, k_ in enumerate(keys)), ranges, cnt
 
 
 @torch.no_grad()
@@ -718,11 +776,7 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
     if rounds is None:
         rounds = DIST_ROUNDS
     if ops is None:
-        ops = getattr(session, "_stitch_ops", None)               # kept on the session: its device tables are reused
-        if ops is None:
-            ops = HipStitchOps(session)
-            if session is not None:
-                session._stitch_ops = ops
+        ops = _session_stitch_ops(session) if session is not None else HipStitchOps(session)
     shape = tuple(full_im.shape[2:])
     ranges = tiling_ranges(shape, stride, win_size)
     owner = assign_tiles(ranges, world)
@@ -821,14 +875,10 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
         nv = tile_cost(rng)
         src = own[round_of[i]] if owner[i] == 0 else gathered[round_of[i]][owner[i]]
         srcs.append(src[off_of[i]:off_of[i] + nv * nkeys].reshape(nkeys, nv))
-    cnt = None
-    if session is not None and direct:                        # the count volume depends on the tiling alone
-        ckey = ("cnt", shape, tuple(stride), tuple(win_size), str(dev))
-        cnt = session.__dict__.setdefault("_dist_cnt", {}).get(ckey)
-    if cnt is None:
+    if session is not None and direct:
+        cnt = _cached_count_volume(session, shape, ranges, stride, win_size, dev)
+    else:
         cnt = count_volume(shape, ranges, dev)
-        if session is not None and direct:
-            session._dist_cnt[ckey] = cnt
     if hasattr(ops, "gather_all") and GATHER_STITCH:
         acc_buf = torch.empty((nkeys,) + shape, dtype=torch.float32, device=dev)
         ops.gather_all(acc_buf, srcs, ranges, shape)          # one launch: sum in tile order, / count, write once
