@@ -825,7 +825,7 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
     if lanes > 1:
         start = torch.cuda.Event()
         start.record(torch.cuda.current_stream(dev))           # send buffers are free, the input is in place
-    nrun = 0
+    lane_load = [0] * lanes                                    # this rank's tiles go to its less loaded lane
     for kk in range(nrounds):
         sbuf = _buf("send%d" % kk, round_numel[kk])            # on rank 0: the padding the gather asks of its root
         dst = sbuf
@@ -837,16 +837,17 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
             (x0, x1), (y0, y1), (z0, z1) = ranges[i]
             im = full_im[:, :, x0:x1, y0:y1, z0:z1]
             n = tile_cost(ranges[i]) * nkeys
+            lane = min(range(lanes), key=lambda j: (lane_load[j], j))
+            lane_load[lane] += tile_time(ranges[i])
             if direct and session is not None and session.use_graphs and \
-                    not session.has_graph((x1 - x0, y1 - y0, z1 - z0), nrun % lanes if lanes > 1 else 0):
+                    not session.has_graph((x1 - x0, y1 - y0, z1 - z0), lane):
                 for w in works:                                    # warm-up only: no transfer in flight while a graph
                     w.wait()                                       # is being captured
             if direct and lanes > 1:
-                # consecutive tiles of this rank alternate between the lanes' streams; the gather of a round waits for
+                # this rank's tiles run on its lanes' streams, independently of each other; the gather of a round waits for
                 # that round's tiles only -- and on rank 0 for none: its receives are posted at once, whatever it is
                 # still computing itself
-                keys, _, done = ops.run_tile(im, out=dst[off_of[i]:off_of[i] + n], lane=nrun % lanes, after=start)
-                nrun += 1
+                keys, _, done = ops.run_tile(im, out=dst[off_of[i]:off_of[i] + n], lane=lane, after=start)
                 if done is not None:
                     if rank == 0:
                         pending.append(done)
