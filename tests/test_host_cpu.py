@@ -176,13 +176,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_distributed_tiling_two_ranks_bitwise_equals_single():
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_tiling_two_ranks_bitwise_equals_single(world):
+    """world 3: the ranks hold different numbers of tiles (padding rounds), rank 0's own tiles stay local."""
     import torch.multiprocessing as mp
     from brainfm_amd import test_utils as TU
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=120)
