@@ -312,16 +312,17 @@ def test_gather_stitch_equals_per_tile_accumulate_bitwise(shape, win, stride):
     assert not torch.isnan(out).any()
 
 
-def test_distributed_path_two_ranks_share_one_gpu():
-    """world_size 2 through the real HIP multi-GPU path: two gloo ranks share this GPU (RCCL refuses two ranks on one
+@pytest.mark.parametrize("world", [2, 4])
+def test_distributed_path_two_ranks_share_one_gpu(world):
+    """world_size 2 and 4 through the real HIP multi-GPU path: the gloo ranks share this GPU (RCCL refuses two ranks on one
     device; the data path -- sharding, lanes, graph replay, pack, one asynchronous gather per round, accumulation in the
     reference's tile order -- is backend independent).  Runs in child processes: this process already owns a group."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, os.path.join(here, "two_rank_worker.py")], capture_output=True, text=True,
-                       timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(here, "two_rank_worker.py"), str(world)], capture_output=True,
+                       text=True, timeout=600)
     if not r.stdout.strip().endswith("OK"):
         err = [ln for ln in r.stderr.splitlines() if "socket.cpp" not in ln]
         raise AssertionError("two-rank run failed:\n%s\n%s" % (r.stdout[-1500:], "\n".join(err[-40:])))

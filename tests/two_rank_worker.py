@@ -42,7 +42,7 @@ def worker(rank, world, port, q):
     if rank == 0:
         ref2, _, _ = TU.tiled_inference(full2, s2, [16] * 3, [32] * 3, graphs=False)
         ref2 = {k: v.clone() for k, v in ref2.items()}
-    else:
+    elif rank == 1:
         TU._run_tile(s2, full2[:, :, :32, :32, :32], raw=True)            # times the variants here ...
         mine = s2.engine.conv_choices()
         s2.engine.adopt_conv_choices({k: (1 if v == 0 else 0) for k, v in mine.items()})   # ... and takes other ones
@@ -67,7 +67,8 @@ if __name__ == "__main__":
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    ps = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
     for p in ps: p.start()
     for p in ps: p.join(300)
     ok = (not q.empty()) and q.get(timeout=5)
