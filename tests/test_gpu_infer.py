@@ -277,7 +277,12 @@ def test_distributed_path_one_rank_rccl_equals_single_gpu_path():
                 assert list(acc.keys()) == list(ref.keys())
                 for k in ref:
                     assert torch.equal(acc[k], ref[k]), (k, graphs, rep)
+        TU.GATHER_STITCH = False                                     # the sequential stitch on rank 0 (BFM_GATHER_STITCH=0)
+        acc, _, _ = TU.tiled_inference_distributed(full, s, [stride] * 3, [win] * 3)
+        for k in ref:
+            assert torch.equal(acc[k], ref[k]), (k, "sequential stitch")
     finally:
+        TU.GATHER_STITCH = True
         s.use_graphs = False
         dist.destroy_process_group()
 
