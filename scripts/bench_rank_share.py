@@ -1,0 +1,70 @@
+"""What each rank of an N-rank run of the 256^3 volume computes, timed alone on ONE GPU (no transfers): its tiles on its
+two lanes in the order tiled_inference_distributed runs them, plus -- on rank 0 -- the one-launch stitch of all 27 tiles.
+A model of the N-GPU step without the exchange: max over ranks.   python scripts/bench_rank_share.py [N=8] [size=256]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import bench  # noqa: E402
+from brainfm_amd import test_utils as TU  # noqa: E402
+
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+dev = torch.device("cuda", 0)
+torch.manual_seed(1)
+ga, ta = TU.default_inference_args(f_maps=64, num_levels=6)
+sess = TU.InferenceSession(ga, ta, dev, passes=3)
+sess.use_graphs = True
+full = bench.make_volume(n, dev)
+stride, win = [80] * 3, [160] * 3
+ranges = TU.tiling_ranges((n, n, n), stride, win)
+TU.prepare_tile_graphs(full, sess, stride, win)
+owner = TU.assign_tiles(ranges, world)
+ops = TU.HipStitchOps(sess)
+nkeys = len(sess.stitch_keys())
+offs, total = [], 0
+for r in ranges:
+    offs.append(total)
+    total += TU.tile_cost(r) * nkeys
+buf = torch.zeros(total, dtype=torch.float32, device=dev)
+srcs = [buf[offs[i]:offs[i] + TU.tile_cost(r) * nkeys].view(nkeys, TU.tile_cost(r)) for i, r in enumerate(ranges)]
+acc = torch.empty((nkeys, n, n, n), dtype=torch.float32, device=dev)
+
+
+def share(rank):
+    mine = sorted([i for i in range(len(ranges)) if owner[i] == rank], key=lambda i: (-TU.tile_cost(ranges[i]), i))
+    main = torch.cuda.current_stream(dev)
+    start = torch.cuda.Event()
+    start.record(main)
+    load, last = [0] * sess.lanes, {}
+    for i in mine:
+        k = min(range(sess.lanes), key=lambda j: (load[j], j))
+        load[k] += TU.tile_time(ranges[i])
+        (x0, x1), (y0, y1), (z0, z1) = ranges[i]
+        n_i = TU.tile_cost(ranges[i]) * nkeys
+        _, _, done = ops.run_tile(full[:, :, x0:x1, y0:y1, z0:z1], out=buf[offs[i]:offs[i] + n_i], lane=k, after=start)
+        if done is not None:
+            last[k] = done
+    for ev in last.values():
+        main.wait_event(ev)
+    if rank == 0:
+        ops.gather_all(acc, srcs, ranges, (n, n, n))
+    return mine
+
+
+worst = 0.0
+for rank in range(world):
+    share(rank)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        mine = share(rank)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / 5
+    worst = max(worst, ms)
+    print("rank %d of %d: tiles %s (x 80^3 units)%s: %.2f ms" % (
+        rank, world, [TU.tile_cost(ranges[i]) // 512000 for i in mine], " + stitch of all tiles" if rank == 0 else "", ms))
+print("modelled %d-GPU step without the exchange: %.2f ms = %.0f Mvoxel/s" % (world, worst, n ** 3 / worst / 1e3))
