@@ -482,7 +482,12 @@ def tiled_inference(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 1
     ranges = tiling_ranges(shape, stride, win_size)
     nl = session.lanes if graphs else 1
     if nl > 1 and GATHER_STITCH:
-        return _tiled_inference_lanes(full_im, session, ranges, shape, stride, win_size)
+        prev = session.use_graphs                              # graphs=True asked for replay whatever the session's default
+        session.use_graphs = True
+        try:
+            return _tiled_inference_lanes(full_im, session, ranges, shape, stride, win_size)
+        finally:
+            session.use_graphs = prev
     cnt = count_volume(shape, ranges, eng.device)
     acc_buf, keys, sel = None, None, None
     main = torch.cuda.current_stream(eng.device)
