@@ -158,13 +158,13 @@ class _HostOps:
         acc /= cnt
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, shape=(40, 36, 44)):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     from brainfm_amd import test_utils as TU
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     torch.manual_seed(0)
-    full = torch.rand(1, 1, 40, 36, 44)
+    full = torch.rand(1, 1, *shape)
     full[:, :, :6] = 0
     acc, ranges, cnt = TU.tiled_inference_distributed(full, None, [12] * 3, [24] * 3, ops=_HostOps())   # round-wise gathers
     acc1, _, _ = TU.tiled_inference_distributed(full, None, [12] * 3, [24] * 3, ops=_HostOps(), rounds=False)
@@ -176,15 +176,16 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_distributed_tiling_two_ranks_bitwise_equals_single(world):
-    """world 3: the ranks hold different numbers of tiles (padding rounds), rank 0's own tiles stay local."""
+@pytest.mark.parametrize("world,shape", [(2, (40, 36, 44)), (3, (40, 36, 44)), (3, (20, 22, 24))])
+def test_distributed_tiling_two_ranks_bitwise_equals_single(world, shape):
+    """world 3: the ranks hold different numbers of tiles (padding rounds), rank 0's own tiles stay local; a volume of
+    a single tile leaves the other ranks without work (bench.py --size 160 --gpus N)."""
     import torch.multiprocessing as mp
     from brainfm_amd import test_utils as TU
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, shape)) for r in range(world)]
     for p in procs:
         p.start()
     res = q.get(timeout=120)
@@ -193,7 +194,7 @@ def test_distributed_tiling_two_ranks_bitwise_equals_single(world):
         assert p.exitcode == 0
     # single-process result with the same ops, reference tile order
     torch.manual_seed(0)
-    full = torch.rand(1, 1, 40, 36, 44)
+    full = torch.rand(1, 1, *shape)
     full[:, :, :6] = 0
     ops = _HostOps()
     shape = tuple(full.shape[2:])
