@@ -5,13 +5,19 @@
         bench.py --gpus N --steps K --warmup W
 
 One step = one pass of the hot path over one synthetic 256^3 volume (27 overlapping tiles, win 160 /
-stride 80, all 9 task heads, fused tail, on-device stitching), input resident in HBM.  N>1 shards the
-tiles of the SAME volume over ranks (strong scaling) and gathers the masked tile outputs to rank 0
-over RCCL.  Prints ONE JSON line on rank 0.
+stride 80, all 9 task heads, fused tail, the deformed atlas per tile, on-device stitching of the 17 keys
+scripts/demo_test.py:107-119 stitches), input resident in HBM.  N>1 shards the tiles of the SAME volume
+over ranks (strong scaling) and gathers the masked tile outputs to rank 0 over RCCL.  Prints ONE JSON line
+on rank 0.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (one child process
+per device, before this process has made any GPU call) and relays rank 0's line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -19,6 +25,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
+
+CONV_KERNELS = ["conv_wino", "conv_upfold", "conv_mfma", "conv_mfma_ws", "conv_mfma16", "conv_wino_ws", "conv_wino8"]
+_VER_NAME = {0: "conv_mfma", 1: "conv_mfma_ws", 2: "conv_mfma16", 3: "conv_wino", 4: "conv_wino_ws", 5: "conv_wino8"}
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_conv_hbm_traffic.json")
 
 
 def make_volume(n, device):
@@ -30,6 +40,17 @@ def make_volume(n, device):
     ell = ((zz / (100 * s)) ** 2 + (yy / (110 * s)) ** 2 + (xx / (90 * s)) ** 2) <= 1
     v = torch.rand((n, n, n), generator=g) * ell
     return v[None, None].to(device)
+
+
+def make_atlas():
+    """Stand-in for files/gca.mgz (utils/test_utils.py:38-43): a smooth 256^3 float volume with the conformed-space
+    vox2ras matrix that file carries ([[-1,0,0,128],[0,0,1,-128],[0,-1,0,128]])."""
+    import numpy as np
+    ax = torch.arange(256, dtype=torch.float32)
+    i, j, k = torch.meshgrid(ax, ax, ax, indexing="ij")
+    vol = 110. + 60. * torch.sin(i / 17.) * torch.cos(j / 23.) + 40. * torch.sin(k / 13. + 0.5)
+    aff = np.array([[-1., 0., 0., 128.], [0., 0., 1., -128.], [0., -1., 0., 128.], [0., 0., 0., 1.]])
+    return vol, aff
 
 
 def conv_flops_tile(dims, fm=(64, 128, 256, 512, 1024, 2048)):
@@ -54,33 +75,130 @@ def conv_flops_tile(dims, fm=(64, 128, 256, 512, 1024, 2048)):
     return total
 
 
-def cpu_baseline(state_dict, full, n):
-    """The CPU oracle (a port of the reference's PyTorch-CPU path) timed on this host, rank 0 only,
-    on a bounded sample: one central 128^3 tile of the volume (the size of BASELINE.json's configs[0]), all heads:
-    ~10-15 s of CPU work on the GPU box's host."""
+def host_cpu_info():
+    """CPU model, sockets, physical cores per socket, hardware threads (lscpu / /proc/cpuinfo)."""
+    info = {"model": None, "sockets": None, "cores_per_socket": None, "threads": os.cpu_count()}
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        for ln in out.splitlines():
+            k, _, v = ln.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "Model name":
+                info["model"] = v
+            elif k == "Socket(s)":
+                info["sockets"] = int(v)
+            elif k == "Core(s) per socket":
+                info["cores_per_socket"] = int(v)
+    except Exception:
+        pass
+    return info
+
+
+def cpu_baseline(state_dict, full, n, ranges, full_protocol=False):
+    """The CPU oracle (oracle/unet_ref.py: a torch-CPU fp32 port of the reference's path) timed on this host, rank 0
+    only, the way BASELINE.md section 4 / SURVEY 8(d) set it: threads = the physical cores of one socket, per tile
+    shape of the reference tiling 1 warm-up + 3 timed runs (median), and the whole volume's time extrapolated from
+    count(shape) x median(shape) and labelled as such.  To keep the default run within minutes the warm-up + 3-run
+    protocol is applied to the two small shapes and the two large ones get one timed run each (caches and thread pool
+    already warm); --cpu-baseline-full runs it on all four."""
+    import numpy as np
     from oracle import unet_ref as O
-    cores = torch.get_num_threads()
-    s = 128 if n >= 160 else max(16, n // 2)
-    tile = full[:, :, n // 2 - s // 2:n // 2 + s // 2, n // 2 - s // 2:n // 2 + s // 2,
-                n // 2 - s // 2:n // 2 + s // 2].cpu().contiguous()
+    info = host_cpu_info()
+    threads = info["cores_per_socket"] or torch.get_num_threads()
+    prev = torch.get_num_threads()
+    torch.set_num_threads(int(threads))
     sd = {k: v.detach().cpu() for k, v in state_dict.items()}
-    t0 = time.time()
-    with torch.no_grad():
-        O.forward_all(tile, sd, f_maps=64, num_levels=6)
-    dt = time.time() - t0
-    return {"value": tile.numel() / dt, "unit": "voxels/s", "cores": cores, "kind": "port",
-            "sample": "one central %d^3 tile of the volume, all 9 heads, oracle/unet_ref.py (torch-CPU fp32), "
-                      "1 run, %.1f s" % (s, dt)}
+    shapes = {}
+    for r in ranges:
+        s = tuple(b - a for a, b in r)
+        if s not in shapes:
+            shapes[s] = [0, r]
+        shapes[s][0] += 1
+    order = sorted(shapes, key=lambda s: s[0] * s[1] * s[2])
+    per_shape, total_s, spent = {}, 0.0, 0.0
+    try:
+        for idx, s in enumerate(order):
+            cnt, r = shapes[s]
+            (x0, x1), (y0, y1), (z0, z1) = r
+            tile = full[:, :, x0:x1, y0:y1, z0:z1].cpu().contiguous()
+            small = idx < 2 or full_protocol or len(order) <= 2
+            runs = []
+            with torch.no_grad():
+                if small:
+                    O.forward_all(tile, sd, f_maps=64, num_levels=6)                    # warm-up
+                for _ in range(3 if small else 1):
+                    t0 = time.perf_counter()
+                    O.forward_all(tile, sd, f_maps=64, num_levels=6)
+                    runs.append(time.perf_counter() - t0)
+            med = float(np.median(runs))
+            spent += sum(runs) * (4.0 / 3.0 if small else 1.0)
+            per_shape["x".join(map(str, s))] = {"tiles": cnt, "median_s": med, "runs": len(runs),
+                                                 "warmup": 1 if small else 0}
+            total_s += cnt * med
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": n ** 3 / total_s, "unit": "voxels/s", "cores": int(threads), "kind": "port",
+            "cpu_model": info["model"], "sockets": info["sockets"], "cores_per_socket": info["cores_per_socket"],
+            "hardware_threads": info["threads"], "per_tile_shape": per_shape,
+            "extrapolated_volume_s": total_s,
+            "sample": "oracle/unet_ref.py (torch-CPU fp32, all 9 heads) on one tile of each shape of the reference "
+                      "tiling (%s), 1 warm-up + 3 timed runs (median) on the small shapes, 1 timed run on the large ones; "
+                      "value = %d^3 voxels / sum(count x median) = EXTRAPOLATED whole-volume time %.1f s, not a timed "
+                      "27-tile run; %.0f s of CPU work on %d threads (physical cores of one socket)"
+                      % (", ".join(per_shape), n, total_s, spent, int(threads))}
+
+
+def launch_ranks(n, argv):
+    """--gpus N without a launcher: one child per device, started before this process makes any GPU call (a process
+    that has initialised the GPU must not be replaced or forked into ranks).  Relays rank 0's JSON line."""
+    share = os.environ.get("BFM_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()                      # counts devices without initialising the GPU
+    if not share and have < n:
+        print("bench.py: --gpus %d but only %d device(s) visible (BFM_BENCH_SHARE_GPU=1 BFM_BENCH_BACKEND=gloo runs "
+              "the N-rank path on one device as a dry run)" % (n, have), file=sys.stderr)
+        sys.exit(2)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if share:
+            env.setdefault("BFM_BENCH_BACKEND", "gloo")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = None
+    for ln in (out or "").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if any(rcs) or line is None:
+        print("bench.py: rank exit codes %s" % rcs, file=sys.stderr)
+        sys.exit(1)
+    print(line, flush=True)
+
+
+def kernel_of(p):
+    tag, cfg = p[5][0], p[5][4]
+    return "conv_upfold" if tag.endswith("up") else _VER_NAME.get(cfg[6], "conv_mfma")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--passes", type=int, default=3, help="3 = fp32-grade split-f16 MFMA (parity mode), 1 = fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="warm-up + 3 runs on all four tile shapes (~3 min)")
+    ap.add_argument("--no-atlas", action="store_true", help="16 stitched keys (without the deformed atlas)")
     ap.add_argument("--layer-table", default=None, help="write the per-layer conv timing table of the instrumented pass here")
     ap.add_argument("--dist-path", action="store_true",
                     help="run the multi-GPU code path (pack, RCCL gather, root accumulation) even with one rank")
@@ -89,16 +207,28 @@ def main():
                     help="back-to-back launches per HIP-event bracket in the instrumented conv pass")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])
+        return
+
     import torch.distributed as dist
     from brainfm_amd import test_utils as TU
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d; the launcher's world size is what runs" % (args.gpus, world),
+              file=sys.stderr)
     # dry run of the N > 1 path on a one-GPU box: BFM_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
     # BFM_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks per device); never set for a measurement
-    if os.environ.get("BFM_BENCH_SHARE_GPU") == "1":
+    share = os.environ.get("BFM_BENCH_SHARE_GPU") == "1"
+    if share:
         local = 0
+    elif torch.cuda.device_count() <= local:
+        print("bench.py: rank %d needs cuda:%d, %d device(s) visible" % (rank, local, torch.cuda.device_count()),
+              file=sys.stderr)
+        sys.exit(2)
     backend = os.environ.get("BFM_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -117,6 +247,8 @@ def main():
     torch.manual_seed(1)                                   # default nn init under seed 1
     ga, ta = TU.default_inference_args(f_maps=64, num_levels=6)
     sess = TU.InferenceSession(ga, ta, dev, passes=args.passes)
+    if not args.no_atlas:
+        sess.set_atlas(*make_atlas())
     full = make_volume(n, dev)
     stride, win = [80] * 3, [160] * 3
     ranges = TU.tiling_ranges((n, n, n), stride, win)
@@ -140,7 +272,7 @@ def main():
     debug = os.environ.get("BFM_BENCH_DEBUG") == "1"       # per-step times on stderr (adds a device sync per step)
     for _ in range(args.steps):
         ts = time.perf_counter()
-        step()
+        acc = step()[0]
         if debug:
             torch.cuda.synchronize()
             print("rank %d step %.1f ms" % (rank, 1e3 * (time.perf_counter() - ts)), file=sys.stderr, flush=True)
@@ -148,12 +280,32 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    n_keys = len(acc) if acc is not None else None
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    # dominant kernel: conv_mfma.  The timed region replays hipGraphs, which HIP events cannot bracket per kernel, so
+    # per-volume latency (volume resident -> all stitched outputs resident on rank 0): the same step with a
+    # device sync (and a barrier) after every volume; median.  `value` above is the pipelined rate of K volumes back to back.
+    lat = []
+    for _ in range(min(args.steps, 10)):
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        lat.append(time.perf_counter() - ts)
+    lat.sort()
+    lat_med = torch.tensor([lat[len(lat) // 2] if lat else 0.0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(lat_med, op=dist.ReduceOp.MAX)
+    lat_med = float(lat_med.item())
+
+    # dominant kernels: the conv family.  The timed region replays hipGraphs, which HIP events cannot bracket per kernel, so
     # the same step is run once more eagerly right after it with every conv launch issued `reps` times back to back
     # inside one HIP event pair on the launch stream (idempotent; back-to-back so the bracket holds kernel time rather
     # than python submission gaps).  Launch duration = bracket / reps.
@@ -168,71 +320,108 @@ def main():
         sess.use_graphs = g
         prof = eng.prof
         eng.prof = None
-    k_ms = sum(p[0].elapsed_time(p[1]) / p[4] for p in prof)
-    k_fl = sum(p[2] for p in prof)
-    k_by = sum(p[3] for p in prof)
+    per = {k: [0.0, 0.0, 0.0, 0.0] for k in CONV_KERNELS}       # ms, flops, bytes, launches
+    for p in prof:
+        e = per[kernel_of(p)]
+        e[0] += p[0].elapsed_time(p[1]) / p[4]
+        e[1] += p[2]
+        e[2] += p[3]
+        e[3] += 1
     if args.layer_table and rank == 0:
         tab = {}
         for p in prof:
-            e = tab.setdefault(p[5], [0, 0.0, 0.0])
+            e = tab.setdefault((kernel_of(p),) + p[5], [0, 0.0, 0.0])
             e[0] += 1
             e[1] += p[0].elapsed_time(p[1]) / p[4]
             e[2] += p[2]
         with open(args.layer_table, "w") as f:
-            f.write("# conv launches of one step grouped by (layer, Cin, Cout, dims, plan[WM,WN,TD,TH,TW,splitk,ver,0])\n")
-            f.write("%-12s %5s %5s %-16s %-28s %5s %10s %8s %7s\n" % ("layer", "cin", "cout", "dims", "plan", "n", "ms_total",
-                                                                  "us_avg", "TF/s"))
+            f.write("# conv launches of one step grouped by (kernel, layer, Cin, Cout, dims, plan[WM,WN,TD,TH,TW,splitk,ver,0])\n")
+            f.write("%-13s %-12s %5s %5s %-16s %-28s %5s %10s %8s %7s\n" % ("kernel", "layer", "cin", "cout", "dims", "plan",
+                                                                        "n", "ms_total", "us_avg", "TF/s"))
             for key, (cnt, ms, fl) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
-                f.write("%-12s %5d %5d %-16s %-28s %5d %10.3f %8.1f %7.1f\n" % (
-                    key[0], key[1], key[2], "x".join(map(str, key[3])), ",".join(map(str, key[4])), cnt, ms,
+                f.write("%-13s %-12s %5d %5d %-16s %-28s %5d %10.3f %8.1f %7.1f\n" % (
+                    key[0], key[1], key[2], key[3], "x".join(map(str, key[4])), ",".join(map(str, key[5])), cnt, ms,
                     ms * 1e3 / cnt, fl / (ms * 1e-3) / 1e12))
-    agg = torch.tensor([k_ms, k_fl, k_by, float(len(prof))], device=dev, dtype=torch.float64)
+    agg = torch.tensor([per[k] for k in CONV_KERNELS], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(agg)
-    k_ms, k_fl, k_by, k_n = [float(v) for v in agg.tolist()]
-    achieved = k_fl / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-    # HBM traffic of the conv kernels: rocprofv3 PMC passes cannot run inside this process; the committed summary of the
-    # same workload (scripts/pmc_traffic.py, FETCH_SIZE x2 + WRITE_SIZE per MI355X_MICROARCH.md) is reported per launch
-    traffic, traffic_note = None, None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_conv_hbm_traffic.json")
-    if os.path.exists(tpath) and args.size == 256:
-        try:
-            tj = json.load(open(tpath))
-            traffic = tj["kernels"]["conv"]["hbm_bytes_per_launch"]
-            traffic_note = "profiles/r01_conv_hbm_traffic.json: " + tj["source"]
-        except Exception:
-            traffic = None
+    per = {k: [float(v) for v in agg[i].tolist()] for i, k in enumerate(CONV_KERNELS)}
+    k_ms = sum(e[0] for e in per.values())
+    k_fl = sum(e[1] for e in per.values())
+    k_by = sum(e[2] for e in per.values())
+    k_n = sum(e[3] for e in per.values())
     peak = 2500.0                                            # dense f16 MFMA, MI355X_MICROARCH.md
+    # HBM traffic per kernel: rocprofv3 PMC passes cannot run inside this process; the committed summary of the same
+    # workload (scripts/pmc_traffic.py: FETCH_SIZE x2 + WRITE_SIZE, separate passes, per MI355X_MICROARCH.md) is used --
+    # and refused when the launch counts it recorded per kernel differ from this run's (a stale file)
+    traffic_tab, traffic_note = {}, None
+    if os.path.exists(TRAFFIC_FILE) and world == 1:
+        try:
+            tj = json.load(open(TRAFFIC_FILE))
+            mine = {k: int(e[3]) for k, e in per.items() if e[3] > 0}
+            theirs = {k: int(v["launches"]) for k, v in tj["kernels"].items() if k in CONV_KERNELS}
+            if mine == theirs:
+                traffic_tab = {k: v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items()}
+                traffic_note = os.path.relpath(TRAFFIC_FILE, ROOT) + ": " + tj["source"]
+            else:
+                traffic_note = ("%s refused: it recorded launches %s, this run has %s -- regenerate it "
+                                "(scripts/pmc_traffic.py)" % (os.path.relpath(TRAFFIC_FILE, ROOT), theirs, mine))
+        except Exception as e:                                # noqa: BLE001
+            traffic_note = "unreadable traffic file: %r" % (e,)
+    kernels = {}
+    for k, (ms, fl, by, cnt) in per.items():
+        if cnt <= 0:
+            continue
+        ach = fl / (ms * 1e-3) / 1e12
+        kernels[k] = {"launches_per_step": int(cnt), "ms_per_step": ms / max(world, 1), "avg_launch_us": ms * 1e3 / cnt,
+                      "achieved": ach, "frac": ach / peak, "share_of_conv_time": ms / k_ms,
+                      "algorithmic_bytes_per_launch": by / cnt, "traffic": traffic_tab.get(k)}
+    dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
     if rank == 0:
         tile_vox = sum(TU.tile_cost(r) for r in ranges)
         flops_step = sum(conv_flops_tile([r[a][1] - r[a][0] for a in range(3)]) for r in ranges)
+        fam = k_fl / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        dk = kernels.get(dominant, {})
         line = {
             "metric": "voxels/sec whole-volume multi-task inference, 256^3 tiled",
             "value": n ** 3 * args.steps / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
             "dtype": "f16x3-split (fp32-grade)" if args.passes == 3 else "f16", "data": "synthetic",
+            "rccl_ranks": world if (use_dist and backend == "nccl") else 0,
+            "backend": backend if use_dist else None,
+            "devices": ["cuda:%d" % (0 if share else r) for r in range(world)],
+            "timing": "value = K volumes back to back between two barrier+synchronize brackets (no sync between volumes, "
+                      "max over ranks); latency_ms_median = one volume at a time, synchronised after each",
+            "latency_ms_median": lat_med * 1e3,
             "config": {"workload": "%d^3 volume, reference tiling win160/stride80 -> %d tiles, UNet3D f64 x6 levels, "
-                                   "9 heads (69 ch), fused tail + on-device stitch" % (n, len(ranges)),
+                                   "9 heads (69 ch), fused tail + deformed atlas + on-device stitch of %s keys"
+                                   % (n, len(ranges), n_keys),
+                       "stitched_keys": n_keys,
                        "tile_voxels_per_step": tile_vox, "tile_voxels_per_s": tile_vox * args.steps / dt,
                        "algorithmic_tflop_per_step": flops_step / 1e12,
                        "end_to_end_tflops": flops_step * args.steps / dt / 1e12, "mfma_passes": args.passes,
                        "submission": "hipGraph replay per tile shape" if sess.use_graphs else "eager",
                        "parallelism": "tiles sharded over %d rank(s), gather to rank 0" % world,
                        "tiles_in_flight_per_gpu": sess.lanes if sess.use_graphs else 1},
-            "roofline": {"bound": "mfma", "kernel": "conv_mfma* (the %d conv launches of one step, all variants)" % int(k_n),
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "kernel_ms_per_step": k_ms / max(world, 1), "avg_launch_us": k_ms * 1e3 / max(k_n, 1),
-                         "traffic": traffic, "traffic_source": traffic_note,
-                         "algorithmic_bytes_per_launch": k_by / max(k_n, 1), "algorithmic_bytes_per_step": k_by,
-                         "note": "achieved = algorithmic conv FLOPs of one step / summed launch durations; durations "
-                                 "from HIP events around %d back-to-back launches of each conv in an instrumented "
-                                 "eager replay of the step right after the timed region; the kernel issues %dx the "
-                                 "algorithmic FLOPs in f16 MFMA" % (args.roofline_reps, args.passes)},
+            "roofline": {"bound": "mfma", "kernel": dominant,
+                         "achieved": dk.get("achieved"), "peak": peak, "unit": "TFLOP/s", "frac": dk.get("frac"),
+                         "traffic": dk.get("traffic"), "traffic_source": traffic_note,
+                         "avg_launch_us": dk.get("avg_launch_us"),
+                         "algorithmic_bytes_per_launch": dk.get("algorithmic_bytes_per_launch"),
+                         "per_kernel": kernels,
+                         "conv_family": {"achieved": fam, "frac": fam / peak, "kernel_ms_per_step": k_ms / max(world, 1),
+                                         "launches_per_step": int(k_n), "algorithmic_bytes_per_step": k_by},
+                         "note": "the dominant kernel (largest share of the step's conv time) is reported at the top level, "
+                                 "every conv kernel under per_kernel, the whole family under conv_family; achieved = "
+                                 "algorithmic conv FLOPs (2*27*Cin*Cout*voxels, also for Winograd / up-folded layers) / "
+                                 "summed launch durations; durations from HIP events around %d back-to-back launches of "
+                                 "each conv in an instrumented eager replay of the step right after the timed region; the "
+                                 "kernels issue up to %dx the algorithmic FLOPs in f16 MFMA" % (args.roofline_reps, args.passes)},
         }
         if not args.no_cpu_baseline and world == 1:
             sd = {k: v for k, v in sess.model.state_dict().items()}
-            line["cpu_baseline"] = cpu_baseline(sd, full, n)
+            line["cpu_baseline"] = cpu_baseline(sd, full, n, ranges, args.cpu_baseline_full)
         else:
             line["cpu_baseline"] = None
         try:                                                  # librccl's version banner sits in the C stdio buffer and

@@ -128,6 +128,7 @@ SIGNATURES = {
     "bfm_interp3d_linear": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _L, _F, _P, _P]),
     "bfm_interp3d_nearest": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _L, _P, _P]),
     "bfm_deformed_atlas": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), _L, _P, _P]),
+    "bfm_deformed_atlas_tile": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(_F), _L, _P, _P]),
     "bfm_zoom_linear": (_I, [_P, _I, _I, _I, _I, C.POINTER(ZoomAxis), _I, _I, _I, _P, _P]),
     "bfm_conv1d_axis": (_I, [_P, _I, _I, _I, _I, _P, _I, _P, _P]),
     "bfm_grid_pull3d_linear": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, C.POINTER(_I), _I, _P, _P]),
@@ -202,5 +203,33 @@ def ptr(t):
 
 
 def stream_ptr():
+    """The current stream of the CURRENT device: every launch goes there, so an entry point that was given a device
+    must make it current first (on_device below) -- pointers of one GPU on another GPU's stream fault."""
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def on_device(pick):
+    """Decorator: run the function with the device ``pick(*args, **kwargs)`` returns made current (torch.cuda.device),
+    so that stream_ptr(), torch.cuda.current_stream() and fresh allocations all belong to the GPU the operands live on
+    even when the caller's current device is another one.  ``pick`` may return a tensor, a torch.device, an int or a
+    'cuda:N' string; CPU / None leaves the current device alone (the callee raises its own 'no CPU fallback' error)."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapped(*a, **k):
+            import torch
+            d = pick(*a, **k)
+            if isinstance(d, torch.Tensor):
+                d = d.device
+            if isinstance(d, int):
+                d = torch.device("cuda", d)
+            if isinstance(d, str):
+                d = torch.device(d)
+            if d is None or d.type != "cuda" or d.index is None or d.index == torch.cuda.current_device():
+                return fn(*a, **k)
+            with torch.cuda.device(d):
+                return fn(*a, **k)
+        return wrapped
+    return deco

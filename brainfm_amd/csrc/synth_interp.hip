@@ -62,13 +62,16 @@ __global__ void interp_linear(const float* __restrict__ X, int nx, int ny, int n
 
 // get_deformed_atlas (utils/test_utils.py:45-57) fused: mask -> affine of 100*reg -> trilinear sample of the atlas
 struct Aff34 { float a[12]; };
+// NZ: the mask operand is a tile's input image and M = (im != 0), the mask scripts/demo_test.py:88-89 builds
+// (1 where the image is non-zero, also where it is negative or NaN) before it calls get_deformed_atlas
+template <bool NZ>
 __global__ void deformed_atlas(const float* __restrict__ mask, const float* __restrict__ rx,
                                const float* __restrict__ ry, const float* __restrict__ rz,
                                const float* __restrict__ X, int nx, int ny, int nz, Aff34 A, int64_t n,
                                float* __restrict__ out) {
     GRID_STRIDE(i, n) {
         float r = 0.f;
-        if (mask[i] > 0.f) {
+        if (NZ ? (mask[i] != 0.f) : (mask[i] > 0.f)) {
             const float xx = 100.f * rx[i], yy = 100.f * ry[i], zz = 100.f * rz[i];
             const float x = ((A.a[0] * xx + A.a[1] * yy) + A.a[2] * zz) + A.a[3];
             const float y = ((A.a[4] * xx + A.a[5] * yy) + A.a[6] * zz) + A.a[7];
@@ -457,8 +460,20 @@ extern "C" int bfm_deformed_atlas(const float* mask, const float* regx, const fl
         return BFM_E_ARG;
     Aff34 A;
     for (int i = 0; i < 12; ++i) A.a[i] = A_host[i];
-    hipLaunchKernelGGL(deformed_atlas, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), mask, regx, regy, regz, atlas, nx,
-                       ny, nz, A, n, out);
+    hipLaunchKernelGGL(deformed_atlas<false>, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), mask, regx, regy, regz,
+                       atlas, nx, ny, nz, A, n, out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_deformed_atlas_tile(const float* tile_in, const float* regx, const float* regy, const float* regz,
+                                       const float* atlas, int nx, int ny, int nz, const float* A_host, int64_t n,
+                                       float* out, bfm_stream_t stream) {
+    if (!tile_in || !regx || !regy || !regz || !atlas || !A_host || !out || nx <= 0 || ny <= 0 || nz <= 0 || n <= 0)
+        return BFM_E_ARG;
+    Aff34 A;
+    for (int i = 0; i < 12; ++i) A.a[i] = A_host[i];
+    hipLaunchKernelGGL(deformed_atlas<true>, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), tile_in, regx, regy, regz,
+                       atlas, nx, ny, nz, A, n, out);
     return bfm_launch_status();
 }
 

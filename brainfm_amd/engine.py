@@ -40,6 +40,72 @@ def nearest_index_map(n_in, n_out):
 
 _TUNE_CHOICES = {}          # (device, passes, shape key) -> conv variant that won UNetEngine._autotune in this process
 
+# The persisted tune table: the variants agree to ~1e-6, not bit for bit, so a choice made by timing would let two
+# processes flip different argmax ties of the same volume.  brainfm_amd/conv_tune_gfx950.json (next to the .so, tracked)
+# holds the winners for the shapes of the BASELINE configurations, keyed by architecture, MFMA passes and layer shape;
+# a shape found there is never timed.  Shapes outside it are timed in-process as before and written back only under
+# BFM_CONV_TUNE_SAVE=1 (scripts/make_tune_table.py).  BFM_CONV_TUNE=0: the planner's static choice, no table;
+# BFM_CONV_TUNE=retune: ignore the table and time everything again.  BFM_CONV_TUNE_FILE: another path.
+TUNE_FILE = os.environ.get("BFM_CONV_TUNE_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                                  "conv_tune_gfx950.json")
+_TUNE_TABLE = None          # {"<arch>/<passes>": {"cin,cout,d,h,w,two,acc": variant}}
+_ARCH = {}
+
+
+def _tune_key_str(key):
+    cin, cout, dims, two, acc = key[:5]
+    return ",".join(str(int(v)) for v in (cin, cout) + tuple(dims) + (two, acc) + tuple(key[5:]))
+
+
+def _arch_of(dev_index):
+    if dev_index not in _ARCH:
+        name = getattr(torch.cuda.get_device_properties(dev_index), "gcnArchName", "") or "gpu"
+        _ARCH[dev_index] = name.split(":")[0]
+    return _ARCH[dev_index]
+
+
+def _tune_table():
+    global _TUNE_TABLE
+    if _TUNE_TABLE is None:
+        _TUNE_TABLE = {}
+        mode = os.environ.get("BFM_CONV_TUNE", "1")
+        if mode not in ("0", "retune") and os.path.exists(TUNE_FILE):
+            import json
+            try:
+                _TUNE_TABLE = json.load(open(TUNE_FILE)).get("choices", {})
+            except Exception as e:                               # a damaged table must not change results silently
+                raise L.BfmError("cannot read the conv tune table %s: %r" % (TUNE_FILE, e))
+    return _TUNE_TABLE
+
+
+def _tune_lookup(dev_index, passes, key):
+    return _tune_table().get("%s/%s" % (_arch_of(dev_index), passes), {}).get(_tune_key_str(key))
+
+
+def _tune_store(dev_index, passes, key, ver):
+    """Remember a timed winner; with BFM_CONV_TUNE_SAVE=1 also merge it into the file (read-merge-rename, so that
+    several ranks saving at once leave a valid table)."""
+    sect = "%s/%s" % (_arch_of(dev_index), passes)
+    _tune_table().setdefault(sect, {})[_tune_key_str(key)] = int(ver)
+    if os.environ.get("BFM_CONV_TUNE_SAVE") == "1":
+        import json
+        disk = {}
+        if os.path.exists(TUNE_FILE) and os.environ.get("BFM_CONV_TUNE", "1") != "retune":
+            try:
+                disk = json.load(open(TUNE_FILE)).get("choices", {})
+            except Exception:
+                disk = {}
+        for sct, tab in _tune_table().items():
+            disk.setdefault(sct, {}).update(tab)
+        doc = {"about": "conv variant per layer shape (0 conv_mfma, 1 conv_mfma_ws, 2 conv_mfma16, 3 conv_wino); key = "
+                        "cin,cout,D,H,W,two_sources,accumulate[,samples]; written by UNetEngine._autotune under "
+                        "BFM_CONV_TUNE_SAVE=1 (scripts/make_tune_table.py)",
+               "choices": {k: dict(sorted(v.items())) for k, v in sorted(disk.items())}}
+        tmp = "%s.%d.tmp" % (TUNE_FILE, os.getpid())
+        with open(tmp, "w") as f:
+            json.dump(doc, f, indent=0, sort_keys=False)
+        os.replace(tmp, TUNE_FILE)
+
 
 class _Layer:
     __slots__ = ("name", "cin", "cout", "groups", "gamma", "beta", "kind", "wpacked", "wexp", "w_raw", "packs", "skip",
@@ -301,6 +367,10 @@ class UNetEngine:
         # one choice per process, device and shape: a second engine (another session, a resumed run) takes the first
         # one's winner instead of re-timing, so that two sessions in one process compute bit-identical results
         gkey = (torch.cuda.current_device(), getattr(self, "passes", None), key)
+        if gkey not in _TUNE_CHOICES:
+            saved = _tune_lookup(gkey[0], gkey[1], key)         # the persisted table: same bits in every process
+            if saved is not None and not (key[3] and saved in (3, 4, 5)):
+                _TUNE_CHOICES[gkey] = int(saved)
         if gkey in _TUNE_CHOICES:
             cfg[6] = _TUNE_CHOICES[gkey]
             self._tuned.add(key)
@@ -332,6 +402,7 @@ class UNetEngine:
         cfg[6] = best
         self._tuned.add(key)
         _TUNE_CHOICES[gkey] = best
+        _tune_store(gkey[0], gkey[1], key, best)
         return cfg
 
     def conv_choices(self):
@@ -708,14 +779,16 @@ class Tail:
                                1 if eng.unit_feat else 0, self.slot_high_res, self.slot_fake, len(self.map_names),
                                float(self.head_w.abs().max().item()) if self.n_out else 0.0)
 
-    def run(self, feat_cl, dims, input_cl=None, want_feat=True, want_seg=True):
+    def run(self, feat_cl, dims, input_cl=None, want_feat=True, want_seg=True, extra_rows=0):
         """Fused tail.  feat_cl: (D,H,W,c_feat) raw last decoder output.
-        Returns (maps: {name: (D,H,W) fp32}, feat_norm (D,H,W,C)|None, seg (D,H,W,n_seg)|None, label (D,H,W) int64|None)."""
+        Returns (maps: {name: (D,H,W) fp32}, feat_norm (D,H,W,C)|None, seg (D,H,W,n_seg)|None, label (D,H,W) int64|None).
+        extra_rows: spare (D,H,W) rows at the end of the map buffer (self.last_buf) for per-tile maps computed after the
+        tail (the deformed atlas), so that the stitcher still packs one buffer."""
         eng = self.eng
         D, H, W = dims
         nvox = D * H * W
         dev = eng.device
-        maps_buf = torch.empty((len(self.map_names), D, H, W), dtype=torch.float32, device=dev)
+        maps_buf = torch.empty((len(self.map_names) + int(extra_rows), D, H, W), dtype=torch.float32, device=dev)
         # pointer table built on the device (no host->device copy: the whole tile pass is hipGraph-capturable)
         ptrs = torch.arange(len(self.map_names), dtype=torch.int64, device=dev) * (nvox * 4) + maps_buf.data_ptr()
         nseg = self.desc.n_seg

@@ -50,6 +50,7 @@ def _new_like_spatial(t, c=1, dtype=torch.float32):
     return buf, buf.permute(3, 0, 1, 2).unsqueeze(0)
 
 
+@L.on_device(lambda op, t, *a, **k: t)
 def _unary(op, t, a=0.0, b=0.0):
     """Elementwise op on a (1,C,D,H,W) float tensor, channel by channel (C is 1..4 here)."""
     lib = L.load()
@@ -61,6 +62,7 @@ def _unary(op, t, a=0.0, b=0.0):
     return view
 
 
+@L.on_device(lambda op, x, *a, **k: x)
 def _binary(op, x, y, a=0.0):
     lib = L.load()
     x, px, xs, c, n = _cl_rows(x)
@@ -72,6 +74,7 @@ def _binary(op, x, y, a=0.0):
     return view
 
 
+@L.on_device(lambda prob, *a, **k: prob)
 def _argmax_lut(prob, lut_list):
     """LUT[argmax(prob, 1, keepdim=True)] -> (1,1,D,H,W) int64 (Trainer/models/__init__.py:347-349)."""
     lib = L.load()
@@ -220,8 +223,9 @@ class UNet3D(nn.Module):
     @torch.no_grad()
     def _feats_cl(self, x, head=None):
         eng = self.engine(head)
-        x_cl = eng.to_cl(x)
-        return eng, x_cl, eng.backbone_cl(x_cl, tuple(x.shape[2:]))
+        with torch.cuda.device(eng.device):                # kernels launch on the CURRENT device's stream (_lib.stream_ptr)
+            x_cl = eng.to_cl(x)
+            return eng, x_cl, eng.backbone_cl(x_cl, tuple(x.shape[2:]))
 
     @torch.no_grad()
     def get_feature(self, x):
@@ -231,7 +235,8 @@ class UNet3D(nn.Module):
             eng, _, feats = self._feats_cl(x[b:b + 1])
             bufs = [f for f, _ in feats]
             if self.is_unit_vector:
-                bufs[-1] = normalize_cl(eng, bufs[-1], feats[-1][1])
+                with torch.cuda.device(eng.device):
+                    bufs[-1] = normalize_cl(eng, bufs[-1], feats[-1][1])
             outs.append([UNetEngine.as_ncdhw(f) for f in bufs])
         if len(outs) == 1:
             return outs[0]
@@ -296,6 +301,7 @@ class TaskHead(nn.Module):
         return out
 
     @torch.no_grad()
+    @L.on_device(lambda self, x, *a, **k: x[self.out_feat_level])
     def forward(self, x, *kwargs):
         """x: list of feature maps; uses x[out_feat_level] as is (already normalised by the backbone)."""
         x = x[self.out_feat_level]
@@ -338,6 +344,7 @@ class MultiInputIndepJoiner(nn.Module):
         self.postfix = postfix
 
     @torch.no_grad()
+    @L.on_device(lambda self, *a, **k: next(self.backbone.parameters()))
     def forward(self, input_list, input_name="input", cond=[]):
         outs = []
         for i, x in enumerate(input_list):
@@ -380,6 +387,7 @@ class MultiInputIndepJoiner(nn.Module):
 class SegProcessor(nn.Module):
     """joiner.py:69-77: softmax over channels."""
 
+    @L.on_device(lambda self, outputs, *a, **k: outputs[0]["segmentation"] if outputs else None)
     def forward(self, outputs, *kwargs):
         lib = L.load()
         for output in outputs:
@@ -445,6 +453,15 @@ def get_processors(gen_args, train_args, tasks, device, exclude_keys=[]):
     return processors
 
 
+def _first_tensor(outputs):
+    for o in outputs or []:
+        for v in o.values():
+            if isinstance(v, torch.Tensor):
+                return v
+    return None
+
+
+@L.on_device(lambda gen_args, train_args, outputs, *a, **k: _first_tensor(outputs))
 def get_postprocessor(gen_args, train_args, outputs, samples, target, feats, tasks):
     """Trainer/models/__init__.py:272-354, same mutation pattern, HIP elementwise kernels underneath."""
     left = gen_args.generator.left_hemis_only
@@ -533,7 +550,9 @@ def build_model(gen_args, train_args, device="cpu"):
 def load_checkpoint(ckp_path, models, model_keys=["model"], to_print=False):
     """utils/checkpoint.py:409-457 reduced to what inference needs: pick the first checkpoint key
     containing 'model', then match parameter names by suffix (:558-571) so DDP 'module.' prefixes load."""
-    ckp = torch.load(ckp_path, map_location="cpu")
+    # reference checkpoints also pickle the submit / generator / trainer Config objects (scripts/train.py:206-214):
+    # they are the user's own training output, loaded the way the reference does (full unpickling)
+    ckp = torch.load(ckp_path, map_location="cpu", weights_only=False)
     for model, mkey in zip(models, model_keys):
         key = next((k for k in ckp if mkey in k), None)
         sd = ckp[key] if key is not None else ckp

@@ -33,7 +33,13 @@ gen_cfg_dir = ""
 train_cfg_dir = ""
 
 STITCH_KEYS = ["T1", "T2", "FLAIR", "CT", "high_res_residual", "high_res", "bias_field", "lp", "lw", "rp", "rw",
-               "fake_cortical", "regx", "regy", "regz", "label"]
+               "fake_cortical", "regx", "regy", "regz", "label", "deformed_atlas"]
+# the 17 keys scripts/demo_test.py:107-119 stitches: every output without 'feat' / 'segmentation' in its name, then
+# 'deformed_atlas' (outs['deformed_atlas'] = None is appended before the stitch loop, :108)
+
+# atlas the tile loop deforms (utils/test_utils.py:38-43 reads it into module globals at import).  A path here (or
+# InferenceSession.set_atlas) switches the 17th key on; the reference's value is 'files/gca.mgz' relative to its tree.
+atlas_path = None
 
 
 # ----------------------------------------------------------------------------- configs without YAML files
@@ -199,6 +205,7 @@ def resample(I, orig_res=[1., 1., 1.], new_res=[1., 1., 1.]):
     return GU.myzoom_torch(I_resize, 1 / factors)
 
 
+@L.on_device(lambda *a, **k: _resolve_device(k.get("device", "cuda")))
 def prepare_image(img_path, win_size=None, zero_crop_first=False, spacing=None, add_bf=False, is_CT=False,
                   is_label=False, rescale=True, hemis_mask=None, im_only=False, device="cuda"):
     """utils/test_utils.py:235-284 with every array operation on the device.  ``img_path`` is a path (needs
@@ -248,12 +255,36 @@ def prepare_image(img_path, win_size=None, zero_crop_first=False, spacing=None, 
 
 
 # ----------------------------------------------------------------------------- deformed atlas
-def get_deformed_atlas(brain_labels, regx, regy, regz, MNI, A):
-    """utils/test_utils.py:45-57 with the atlas volume and its inverse affine passed in (the reference reads
-    files/gca.mgz into module globals at import).  DEF[M] = trilinear(MNI, A @ (100*reg)) for M = labels>0,
-    one fused kernel."""
+MNI = None          # utils/test_utils.py:38-43: the atlas volume and A = inv(its affine), read once by load_atlas()
+A = None
+
+
+def load_atlas(path=None):
+    """MNI, aff2 = MRIread(atlas_path); A = inv(aff2) (utils/test_utils.py:38-43, done at import there).  Sets the
+    module globals get_deformed_atlas falls back to and returns (MNI, A) as host arrays."""
+    global MNI, A, atlas_path
+    if path is not None:
+        atlas_path = path
+    if atlas_path is None:
+        raise ValueError("set brainfm_amd.test_utils.atlas_path (the reference ships files/gca.mgz)")
+    vol, aff2 = _read_volume(atlas_path, False)
+    MNI = np.asarray(vol, dtype=np.float32)
+    A = np.asarray(torch.tensor(np.linalg.inv(aff2), dtype=torch.float32))
+    return MNI, A
+
+
+@L.on_device(lambda brain_labels, regx, *a, **k: regx)
+def get_deformed_atlas(brain_labels, regx, regy, regz, MNI=None, A=None):
+    """utils/test_utils.py:45-57.  The atlas volume and its inverse affine are the module globals MNI / A of the
+    reference (read from files/gca.mgz at import); here they can also be passed in, and default to what load_atlas()
+    read.  DEF[M] = trilinear(MNI, A @ (100*reg)) for M = labels>0, one fused kernel."""
     if regx.device.type != "cuda":
         raise L.BfmError("get_deformed_atlas runs on a HIP device only; there is no CPU fallback in the product path")
+    if MNI is None or A is None:
+        g = globals()
+        if g["MNI"] is None:
+            load_atlas()
+        MNI, A = g["MNI"], g["A"]
     Ah = np.asarray(torch.as_tensor(A).detach().cpu(), dtype=np.float32)[:3, :4].reshape(-1)
     Ac = (C.c_float * 12)(*[float(v) for v in Ah])
     f = lambda t: t.to(device=regx.device, dtype=torch.float32).contiguous()
@@ -294,6 +325,26 @@ class InferenceSession:
         # tile's convolutions.  Stitching stays on the caller's stream in the reference's tile order.
         self.lanes = max(1, int(os.environ.get("BFM_LANES", "2")))
         self._lane_streams = []
+        self.atlas = None                                  # (MNI (X,Y,Z) fp32 on the device, 12 floats of inv(affine))
+        if atlas_path is not None:
+            self.set_atlas(*_read_volume(atlas_path, False))
+
+    def set_atlas(self, MNI, aff):
+        """The atlas volume and its vox2ras affine (utils/test_utils.py:38-43: MNI, aff2 = MRIread(atlas_path);
+        A = inv(aff2), both float32).  From then on every tile of tiled_inference also yields 'deformed_atlas'
+        (scripts/demo_test.py:102-104).  None switches it off."""
+        if MNI is None:
+            self.atlas = None
+        else:
+            A = np.linalg.inv(np.asarray(aff, dtype=np.float64))
+            A32 = np.asarray(torch.tensor(A, dtype=torch.float32))[:3, :4].reshape(-1)
+            vol = torch.as_tensor(np.asarray(MNI)).to(device=self.device, dtype=torch.float32).contiguous()
+            if vol.dim() != 3:
+                raise L.BfmError("atlas must be a 3-D volume, got %s" % (tuple(vol.shape),))
+            self.atlas = (vol, (C.c_float * 12)(*[float(v) for v in A32]))
+        self._graphs.clear()                               # captured tile graphs bake the atlas pointer and matrix in
+        self._graph_seen.clear()
+        self._graph_pool = {}
 
     def lane_streams(self, n):
         while len(self._lane_streams) < n:
@@ -304,8 +355,11 @@ class InferenceSession:
         """The keys tiled inference stitches for this head set, in STITCH_KEYS order."""
         tail = self.model.head.tail(self.engine)
         names = set(tail.map_names)
+        if self.atlas is not None and {"regx", "regy", "regz"} <= names:
+            names.add("deformed_atlas")
         return [k for k in STITCH_KEYS if k in names or (k == "label" and tail.desc.n_seg > 0)]
 
+    @L.on_device(lambda self, *a, **k: self.device)
     def graph_tile(self, im, lane=0):
         """Run one tile through backbone + tail via a captured hipGraph for its shape (one graph, one set of static
         buffers and one scratch area per lane).  Returns what _run_tile(raw=True) returns; the buffers are static per
@@ -354,6 +408,7 @@ class InferenceSession:
         return self.model.backbone.engine(self.model.head)
 
     @torch.no_grad()
+    @L.on_device(lambda self, *a, **k: self.device)
     def forward_fused(self, x, want_feat=True, want_seg=True):
         """One sample (1,C,D,H,W) through backbone + fused tail.  Returns the reference's output dict."""
         eng = self.engine
@@ -469,6 +524,7 @@ def _stitch_tile(lib, acc, keys, maps, label, x_cl, rng, shape):
 
 
 @torch.no_grad()
+@L.on_device(lambda full_im, session, *a, **k: session.device)
 def tiled_inference(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 160], graphs=None):
     """scripts/demo_test.py:66-119 on the device: per tile infer -> mask -> accumulate; then /cnt.
     full_im: (1,1,D,H,W) on the session's device.  Returns ({key: (D,H,W) fp32}, ranges, cnt).
@@ -591,6 +647,7 @@ def _tiled_inference_lanes(full_im, session, ranges, shape, stride, win_size):
 
 
 @torch.no_grad()
+@L.on_device(lambda full_im, session, *a, **k: session.device)
 def prepare_tile_graphs(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 160], world=1, rank=0, group=None):
     """Tune + capture the hipGraph of every tile shape this rank will see (first tile of each shape, run twice:
     eager, then capture + replay).  Optional: tiled_inference does the same lazily on the first volumes.  With more
@@ -622,7 +679,21 @@ def _run_tile(session, im, raw=False):
     x_cl = eng.to_cl(im)
     feats = eng.backbone_cl(x_cl, dims)
     tail = session.model.head.tail(eng)
-    maps, _, _, label = tail.run(feats[-1][0], dims, input_cl=x_cl, want_feat=False, want_seg=False)
+    atlas = getattr(session, "atlas", None)
+    if atlas is not None and not {"regx", "regy", "regz"} <= set(tail.map_names):
+        atlas = None                                           # the reference's loop needs the registration head too
+    maps, _, _, label = tail.run(feats[-1][0], dims, input_cl=x_cl, want_feat=False, want_seg=False,
+                                 extra_rows=1 if atlas is not None else 0)
+    if atlas is not None:
+        # scripts/demo_test.py:102-104: get_deformed_atlas(mask, regx, regy, regz) with mask = (im != 0), from the
+        # unmasked registration maps; the stitcher multiplies by the mask again (DEF is 0 outside it already)
+        vol, A = atlas
+        row = tail.last_buf[len(tail.map_names)]
+        L.check(L.load().bfm_deformed_atlas_tile(L.ptr(x_cl), L.ptr(maps["regx"]), L.ptr(maps["regy"]),
+                                                 L.ptr(maps["regz"]), L.ptr(vol), vol.shape[0], vol.shape[1],
+                                                 vol.shape[2], A, row.numel(), L.ptr(row), L.stream_ptr()),
+                "deformed_atlas_tile")
+        maps["deformed_atlas"] = row
     if raw:
         return tail.last_buf, list(maps.keys()), label, x_cl
     return maps, label, x_cl
@@ -762,6 +833,7 @@ def agree_on_conv_variants(session, full_im, ranges, group=None):
     agreed.update(todo)
 
 
+@L.on_device(lambda full_im, session, *a, **k: session.device if session is not None else None)
 def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 160], group=None,
                                 ops=None, rounds=None):
     """Tiles are independent (GroupNorm statistics are per tile), so they shard over ranks with no

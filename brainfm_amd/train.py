@@ -118,7 +118,11 @@ class TrainStep:
         self.wce = torch.as_tensor(weights_ce).to(device=self.dev, dtype=torch.float32).contiguous()
         self.lr, self.wd, self.betas, self.eps, self.clip = float(lr), float(weight_decay), betas, float(eps), float(clip_max_norm)
         self.scaler = scaler if scaler is not None else LossScaler(enabled=False)
-        self.t = 0
+        self.t = 0                                          # iterations stepped so far
+        self.steps = {}                                     # per-parameter AdamW step counts (a head without an active
+                                                            # loss is not stepped: its .grad is None in the reference)
+        self._touched_heads = set()
+        self._active_rows = set()
         self.state = {}                                   # name -> (m, v)
         nseg = tail.desc.n_seg
         self.sample_lanes = max(1, int(os.environ.get("BFM_TRAIN_LANES", "2")))
@@ -181,7 +185,7 @@ class TrainStep:
             if k in self.state:
                 m, v = self.state[k]
                 shp = self._ref_shape(k, self.parameters()[k])
-                state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": m.reshape(shp).cpu().clone(),
+                state[i] = {"step": torch.tensor(float(self.steps.get(k, self.t))), "exp_avg": m.reshape(shp).cpu().clone(),
                             "exp_avg_sq": v.reshape(shp).cpu().clone()}
         group = {"lr": self.lr if lr is None else lr, "betas": tuple(self.betas), "eps": self.eps,
                  "weight_decay": self.wd if weight_decay is None else weight_decay, "amsgrad": False, "maximize": False,
@@ -220,7 +224,8 @@ class TrainStep:
                 k = names[int(i)]
                 self.state[k] = (st["exp_avg"].reshape(-1).to(device=self.dev, dtype=torch.float32).contiguous(),
                                  st["exp_avg_sq"].reshape(-1).to(device=self.dev, dtype=torch.float32).contiguous())
-                self.t = int(float(st["step"]))
+                self.steps[k] = int(float(st["step"]))
+            self.t = max(self.steps.values()) if self.steps else 0
         if "scaler_scale" in ckp and self.scaler.enabled:
             self.scaler.scale = float(ckp["scaler_scale"])
         return ckp
@@ -249,6 +254,7 @@ class TrainStep:
         k = 0
         dense = []                                        # (slot index, col, target, weight, mask, clamp, l2, coef): one launch
         keep = []                                         # tensors the deferred launch reads
+        active = set()                                    # head rows some loss of this sample differentiates
 
         def slot(name, n=1):
             nonlocal k
@@ -270,6 +276,7 @@ class TrainStep:
                     continue                                          # criterion.py:274-281: shape mismatch -> 0
                 tgt = self._t(tgt, dims)
                 co = self._col(head)
+                active.add(co)
                 if is_grad:
                     L.check(lib.bfm_loss_grad_l1(L.ptr(raw), n_out, co, L.ptr(tgt), L.ptr(wt), D, H, W, coef, L.ptr(dRaw),
                                                  slot(name), ws, wsn, st), "loss_grad_l1 " + name)
@@ -286,6 +293,7 @@ class TrainStep:
                     continue
                 for j in range(nch):
                     co = self._col(head, j)
+                    active.add(co)
                     if name == "registration_grad":
                         L.check(lib.bfm_loss_grad_l1(L.ptr(raw), n_out, co, L.ptr(tgt[j]), None, D, H, W, coef / nch,
                                                      L.ptr(dRaw), slot(name), ws, wsn, st), "loss_grad_l1 " + name)
@@ -299,10 +307,12 @@ class TrainStep:
                 mask = 1.0 - self._t(target["segmentation"], dims).reshape(-1, D, H, W)[0]
                 tgt = self._t(sample["bias_field_log"], dims)
                 slot(name)
+                active.add(self._col("bias_field_log"))
                 dense.append((k - 1, self._col("bias_field_log"), tgt, None, mask, 0.0, self.bias_l2, coef))
             elif name == "seg_ce":
                 # CE and Dice share the softmax: one launch covers both names
                 r0, ns = self.tail.row_of["segmentation"]
+                active.update(range(r0, r0 + ns))
                 tgt = self._t(target["segmentation"], dims).reshape(ns, D, H, W)
                 c_dice = (scale * self.loss_weights.get("loss_seg_dice", 0.0) / self.all_samples
                           if "seg_dice" in self.loss_names else 0.0)
@@ -312,6 +322,7 @@ class TrainStep:
             elif name == "seg_dice":
                 if "seg_ce" not in self.loss_names:
                     r0, ns = self.tail.row_of["segmentation"]
+                    active.update(range(r0, r0 + ns))
                     tgt = self._t(target["segmentation"], dims).reshape(ns, D, H, W)
                     P = torch.empty((nvox, ns), dtype=torch.float32, device=self.dev)
                     L.check(lib.bfm_loss_seg(L.ptr(raw), n_out, r0, ns, L.ptr(tgt), L.ptr(self.wce), L.ptr(self.wce), nvox,
@@ -336,6 +347,7 @@ class TrainStep:
             idx = torch.tensor([e[0] for e in batch], dtype=torch.int64, device=self.dev)
             vals.index_copy_(0, idx, stage)
         self._keep = keep
+        self._active_rows = active
         return slots, k
 
     def _finish_losses(self, per_sample, nvox):
@@ -393,8 +405,13 @@ class TrainStep:
         for task, (r0, n) in tail.row_of.items():
             g["head.final_conv_%s.weight" % task] = dW[r0:r0 + n]
             g["head.final_conv_%s.bias" % task] = db[r0:r0 + n]
+        # heads no loss of this sample reached: the reference leaves their .grad None (the all-zero rows above only keep
+        # the gradient dictionary's layout fixed for the flat all-reduce); loss_and_grads collects who was reached
+        self._touched_heads.update(task for task, (r0, n) in tail.row_of.items()
+                                   if any(r in self._active_rows for r in range(r0, r0 + n)))
         return g, slots, vals
 
+    @L.on_device(lambda self, *a, **k: self.dev)
     def loss_and_grads(self, xs, target, samples):
         """xs: list of (1,C,D,H,W) inputs (one per augmented sample); target / samples as the reference's dicts
         (NCDHW tensors).  Returns (loss_dict, total, grads) with grads = d(scale * total)/d(parameter) summed over the
@@ -407,6 +424,7 @@ class TrainStep:
         eng = self.eng
         scale = self.scaler.scale
         n = len(xs)
+        self._touched_heads = set()
         lanes = self.sample_lanes if (n > 1 and self.t >= 1) else 1
         nvox = None
         results = []
@@ -457,6 +475,7 @@ class TrainStep:
         return loss_dict, total, grads
 
     # ------------------------------------------------------------------ optimiser
+    @L.on_device(lambda self, *a, **k: self.dev)
     def apply(self, grads, lr=None, weight_decay=None):
         """unscale -> per-parameter clip (utils/misc.py:1329-1338) -> AdamW -> scaler.update.  Returns
         (stepped, norms): stepped is False when a non-finite gradient made the scaler skip the step."""
@@ -481,6 +500,7 @@ class TrainStep:
         self.t += 1
         for k, nrm in zip(names, norms):
             p, g = params[k], grads[k]
+            self.steps[k] = self.steps.get(k, 0) + 1        # torch.optim.AdamW keeps one step count per parameter
             coef = inv
             if self.clip > 0:
                 c = self.clip / (nrm + 1e-6)
@@ -493,16 +513,41 @@ class TrainStep:
             if not p.is_contiguous():
                 raise L.BfmError("parameter %s is not contiguous" % k)
             L.check(lib.bfm_adamw_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, self.betas[0], self.betas[1],
-                                       self.eps, wd, self.t, coef, st), "adamw " + k)
+                                       self.eps, wd, self.steps[k], coef, st), "adamw " + k)
         self._weights_changed()
         self.scaler.update(False)
         return True, norms
 
+    @L.on_device(lambda self, *a, **k: self.dev)
     def step(self, xs, target, samples, lr=None, weight_decay=None, group=None):
-        """One full iteration (Trainer/engine.py:96-147).  Returns (loss_dict, total, stepped)."""
+        """One full iteration (Trainer/engine.py:96-147).  Returns (loss_dict, total, stepped).  With more than one rank
+        the loss dictionary is averaged over the ranks first (utils.reduce_dict, engine.py:124-130) and the skip decision
+        is taken on that reduced value, so every rank skips -- or enters the gradient all-reduce -- together."""
+        import torch.distributed as dist
         loss_dict, total, grads = self.loss_and_grads(xs, target, samples)
+        touched = set(self._touched_heads)
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if multi:
+            world = dist.get_world_size(group)
+            tasks = list(self.tail.row_of.keys())
+            keys = list(self.loss_names)                       # fixed layout: a rank may lack a loss another one has
+            # gloo reduces on the host, RCCL on the device
+            rdev = self.dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            t = torch.tensor([loss_dict.get("loss_" + k, 0.0) for k in keys] +
+                             [1.0 if ("loss_" + k) in loss_dict else 0.0 for k in keys] +
+                             [1.0 if task in touched else 0.0 for task in tasks], dtype=torch.float64, device=rdev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            t = t.cpu().tolist()
+            nk = len(keys)
+            loss_dict = OrderedDict(("loss_" + k, t[i] / world) for i, k in enumerate(keys) if t[nk + i] > 0)
+            total = sum(v * self.loss_weights.get(k, 0.0) for k, v in loss_dict.items() if k in self.loss_weights)
+            touched = {task for j, task in enumerate(tasks) if t[2 * nk + j] > 0}     # find_unused_parameters=True
         if not math.isfinite(total):
             return loss_dict, total, False                     # engine.py:129-136: non-finite loss -> skip the iteration
         allreduce_mean_(grads, group)
+        for task in self.tail.row_of:                          # heads nobody's loss reached: no gradient, no step
+            if task not in touched:
+                grads.pop("head.final_conv_%s.weight" % task, None)
+                grads.pop("head.final_conv_%s.bias" % task, None)
         stepped, _ = self.apply(grads, lr, weight_decay)
         return loss_dict, total, stepped

@@ -307,6 +307,11 @@ int bfm_interp3d_nearest(const void* X, int nx, int ny, int nz, int C, const flo
  * A(3x4) applied to 100*(regx,regy,regz); 0 elsewhere. */
 int bfm_deformed_atlas(const float* mask, const float* regx, const float* regy, const float* regz, const float* atlas,
                        int nx, int ny, int nz, const float* A_host, int64_t n, float* out, bfm_stream_t stream);
+/* The same inside the tile loop -- scripts/demo_test.py:88-89,102-104: the mask operand is the tile's input image and
+ * M = (tile_in != 0), i.e. the 0/1 mask the script builds before it calls get_deformed_atlas. */
+int bfm_deformed_atlas_tile(const float* tile_in, const float* regx, const float* regy, const float* regz,
+                            const float* atlas, int nx, int ny, int nz, const float* A_host, int64_t n, float* out,
+                            bfm_stream_t stream);
 /* myzoom_torch -- Generator/utils.py:200-257.  Per-axis tables (floor index, ceil index, weights) are built
  * by the host exactly as the reference builds them (torch.arange in fp32); the three passes are fused. */
 typedef struct { const int32_t* f; const int32_t* c; const float* wf; const float* wc; } bfm_zoom_axis_t;

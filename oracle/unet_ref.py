@@ -237,22 +237,32 @@ def stitch(tile_outputs, ranges, cnt, shape):
 
 
 STITCH_KEYS = ["T1", "T2", "FLAIR", "CT", "high_res_residual", "high_res", "bias_field", "lp", "lw", "rp", "rw",
-               "fake_cortical", "regx", "regy", "regz", "label"]
+               "fake_cortical", "regx", "regy", "regz", "label", "deformed_atlas"]
 
 
-def tiled_inference(full_im, sd, stride, win_size, **net_kw):
+def tiled_inference(full_im, sd, stride, win_size, atlas=None, **net_kw):
     """test_tile restated without disk round trips (scripts/demo_test.py:66-119).
 
     full_im: (1,1,D,H,W).  Returns {key: (D,H,W) fp32} for the 16 non-feat,
-    non-segmentation keys (the deformed atlas is a separate oracle, synth_ref).
+    non-segmentation keys, plus 'deformed_atlas' (:102-104, stitched like the
+    others :108-119) when atlas = (MNI volume, its vox2ras affine) is given
+    (the reference reads both from files/gca.mgz, utils/test_utils.py:38-43).
     """
     shape = tuple(full_im.shape[2:])
     ranges, cnt = tiling_ranges(shape, stride, win_size)
     per_key = {k: [] for k in STITCH_KEYS}
+    if atlas is not None:
+        from . import synth_ref
+        MNI = np.asarray(atlas[0], dtype=np.float32)
+        A = torch.tensor(np.linalg.inv(np.asarray(atlas[1], dtype=np.float64)), dtype=torch.float32).numpy()
     for (x0, x1), (y0, y1), (z0, z1) in ranges:
         im = full_im[:, :, x0:x1, y0:y1, z0:z1]
         outs = forward_all(im, sd, **net_kw)
         m = tile_mask(im)
+        if atlas is not None:
+            sq = lambda t: torch.squeeze(t).numpy()
+            DEF = synth_ref.deformed_atlas(sq(m), sq(outs["regx"]), sq(outs["regy"]), sq(outs["regz"]), MNI, A)
+            outs["deformed_atlas"] = torch.from_numpy(DEF)[None, None]
         for k in STITCH_KEYS:
             if k in outs:
                 per_key[k].append(torch.squeeze(outs[k] * m))

@@ -19,16 +19,18 @@ def last_step(path, counter):
 
 
 def family(name):
-    for k in ("conv_upfold", "conv_wino", "conv_mfma16", "conv_mfma_ws", "conv_mfma", "conv_stem"):
+    """bench.py's kernel names (CONV_KERNELS); longest match first."""
+    for k in ("conv_upfold", "conv_wino_ws", "conv_wino8", "conv_wino", "conv_mfma16", "conv_mfma_ws", "conv_mfma",
+              "conv_stem", "tail_kernel"):
         if k in name:
-            return "conv"
+            return k
     return None
 
 
 fetch = last_step(sys.argv[1], "FETCH_SIZE")
 write = last_step(sys.argv[2], "WRITE_SIZE")
 out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) on bench.py --steps 1 --warmup 1 "
-                 "--no-graphs --roofline-reps 0 --no-cpu-baseline; last step only; FETCH_SIZE x2 (gfx950 correction)",
+                 "--no-graphs --roofline-reps 0 --no-cpu-baseline; last step only; FETCH_SIZE x2 (gfx950 correction); per kernel",
        "kernels": {}}
 for rows, key, mult in ((fetch, "fetch_bytes", 2.0), (write, "write_bytes", 1.0)):
     for r in rows:
@@ -41,6 +43,7 @@ for rows, key, mult in ((fetch, "fetch_bytes", 2.0), (write, "write_bytes", 1.0)
         e["launches_fetch_pass" if key == "fetch_bytes" else "launches_write_pass"] += 1
 for fam, e in out["kernels"].items():
     n = max(e["launches_fetch_pass"], 1)
+    e["launches"] = e["launches_fetch_pass"]            # bench.py refuses this file when its own launch counts differ
     e["hbm_bytes_per_step"] = e["fetch_bytes"] + e["write_bytes"]
     e["hbm_bytes_per_launch"] = e["hbm_bytes_per_step"] / n
 json.dump(out, open(sys.argv[3], "w"), indent=1)

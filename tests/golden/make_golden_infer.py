@@ -152,10 +152,9 @@ def tiled():
     # interval lists / cnt for the BASELINE shapes (scripts/demo_test.py:126 uses stride 80, win 160)
     for n in (160, 200, 256, 512):
         if n == 512:
-            img = torch.zeros(1, 1, n, 8, 8)  # full 512^3 is not needed for the x interval list
+            img = torch.zeros(1, 1, n, 8, 8)  # the x interval list alone (round-1 key, kept)
             lst, cnt = tiling(img, stride=[80, 80, 80], win_size=[160, 160, 160])
             d["ranges_%d_x" % n] = np.array(sorted(set(tuple(r[0]) for _, r in lst)))
-            continue
         img = torch.zeros(1, 1, n, n, n)
         lst, cnt = tiling(img, stride=[80, 80, 80], win_size=[160, 160, 160])
         d["ranges_%d" % n] = np.array([r for _, r in lst])
@@ -172,12 +171,28 @@ def tiled():
     ell = (((zz - D / 2 + .5) / 17.) ** 2 + ((yy - H / 2 + .5) / 15.) ** 2 + ((xx - W / 2 + .5) / 19.) ** 2) <= 1
     full = torch.rand(1, 1, D, H, W) * ell[None, None]
     im_list, cnt = tiling(full, stride=[12, 12, 12], win_size=[24, 24, 24])
+    # the reference's own get_deformed_atlas (utils/test_utils.py:45-57) on a small synthetic atlas: its module
+    # globals MNI / A (:38-43, read from files/gca.mgz at import) are set here the way the module sets them
+    (get_deformed_atlas,) = load_ref_functions(R + "/utils/test_utils.py", ["get_deformed_atlas"])
+    from Generator.utils import fast_3D_interp_torch
+    ai, aj, ak = torch.meshgrid(torch.arange(26.), torch.arange(30.), torch.arange(22.), indexing="ij")
+    atlas = 100. + 60. * torch.sin(ai / 3.1) * torch.cos(aj / 4.3) + 40. * torch.sin(ak / 2.7 + 0.5)   # smooth, like an MRI atlas
+    c, s_ = np.cos(0.3), np.sin(0.3)
+    aff2 = np.array([[-9. * c, 9. * s_, 0., 110.], [0., 0., 8., -95.], [-9. * s_, -9. * c, 0., 120.], [0., 0., 0., 1.]])
+    get_deformed_atlas.__globals__.update(MNI=atlas.to(torch.float32), fast_3D_interp_torch=fast_3D_interp_torch,
+                                          A=torch.tensor(np.linalg.inv(aff2), dtype=torch.float32))
     keys = None
     acc = {}
+    inside = 0
     for im, rng in im_list:
         o = run(gen_args, train_args, model, processors, post, im.clone())
         mask = im.clone()
         mask[im != 0.] = 1.
+        # scripts/demo_test.py:102-104,108: computed per tile from the unmasked registration maps, saved * mask, and
+        # appended to the keys the stitch loop walks
+        o["deformed_atlas"] = get_deformed_atlas(torch.squeeze(mask), torch.squeeze(o["regx"]), torch.squeeze(o["regy"]),
+                                                 torch.squeeze(o["regz"]))
+        inside += int((o["deformed_atlas"] != 0).sum())
         if keys is None:
             keys = [k for k in o if "feat" not in k and "segmentation" not in k]
             acc = {k: torch.zeros_like(torch.squeeze(full)) for k in keys}
@@ -191,6 +206,9 @@ def tiled():
     out["full"] = full.numpy()
     out["cnt"] = cnt.numpy()
     out["ranges"] = np.array([r for _, r in im_list])
+    out["atlas"] = atlas.numpy()
+    out["atlas_aff"] = aff2
+    print("deformed_atlas: %d tile voxels sampled inside the atlas" % inside)
     for k in keys:
         out["stitched/" + k] = (acc[k] / cnt).numpy()
     out["cfg"] = np.array([8, 3, 8, 12, 24])

@@ -61,7 +61,7 @@ def test_no_oracle_import_in_product():
 def test_tiling_matches_reference_golden():
     from brainfm_amd import test_utils as TU
     d = load_npz("tiling_ranges.npz")
-    for n in (160, 200, 256):
+    for n in (160, 200, 256, 512):                              # 512: BASELINE config 4 (216 tiles)
         img = torch.zeros(1, 1, n, n, n)
         lst, cnt = TU.tiling(img, stride=[80] * 3, win_size=[160] * 3)
         assert np.array_equal(np.array([r for _, r in lst]), d["ranges_%d" % n])
@@ -365,3 +365,46 @@ def test_loss_scaler_and_cosine_schedule_host_logic():
     from brainfm_amd import _lib as L
     with pytest.raises(L.BfmError):
         TR.TrainStep(None, None, ["contrastive"], {}, [1.0], 1)
+
+
+def test_volio_reads_the_reference_atlas_file():
+    """SURVEY N3 pinned to the one real volume file on the reference's hot path, files/gca.mgz (utils/test_utils.py:38-43
+    reads it at import: MNI, aff2 = MRIread(atlas_path); A = inv(aff2)).  Expected values: tests/golden/volio_gca.npz, an
+    independent parse of the MGH format definition (make_golden_volio.py; nibabel is absent, so volio stays 'parity
+    unpinned against nibabel').  The file itself never leaves the reference tree: skipped where that is absent."""
+    import gzip
+    import hashlib
+    from brainfm_amd import volio
+    from brainfm_amd import test_utils as TU
+    path = os.path.join(os.environ.get("BRAINFM_REFERENCE", "/root/reference"), "files", "gca.mgz")
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present (GPU box)")
+    d = load_npz("volio_gca.npz")
+    v = volio.load(path)
+    assert tuple(v.shape) == tuple(d["dims"][:3]) == (256, 256, 256)
+    assert np.array_equal(np.asarray(v.affine), d["affine"])
+    # the conformed-space vox2ras every FreeSurfer atlas carries
+    assert np.array_equal(d["affine"], np.array([[-1., 0, 0, 128], [0, 0, 1, -128], [0, -1, 0, 128], [0, 0, 0, 1]]))
+    im, aff = volio.MRIread(path)                                # the reference's reader signature (utils/misc.py:194-208)
+    assert im.shape == (256, 256, 256) and np.array_equal(aff, d["affine"])
+    assert np.array_equal(im[::8, ::8, ::8].astype(np.float32), d["sub8"])
+    assert float(im.astype(np.float64).sum()) == float(d["sum"]) and float(im.max()) == float(d["max"])
+    # byte level: the payload volio decoded, re-encoded big endian x-fastest, is the file's payload
+    be = np.asfortranarray(im.astype(">f4")).tobytes(order="F")
+    assert np.array_equal(np.frombuffer(hashlib.sha256(be).digest(), dtype=np.uint8), d["sha256_be_payload"])
+    assert np.array_equal(np.frombuffer(gzip.open(path, "rb").read(284), dtype=np.uint8), d["header"])
+    # a round trip through volio's own MGZ writer reproduces header fields and voxels
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "copy.mgz")
+        volio.MRIwrite(im.astype(np.float32), aff, out)
+        raw = gzip.open(out, "rb").read()
+        assert raw[:28] == d["header"][:28].tobytes() or raw[:20] == d["header"][:20].tobytes()
+        assert raw[28:90] == d["header"][28:90].tobytes()        # goodRAS, spacing, direction cosines, c_ras
+        im2, aff2 = volio.MRIread(out)
+        assert np.array_equal(im2, im) and np.array_equal(aff2, aff)
+    # what get_deformed_atlas needs from it
+    MNI, A = TU.load_atlas(path)
+    assert MNI.dtype == np.float32 and MNI.shape == (256, 256, 256)
+    assert np.array_equal(A, np.linalg.inv(d["affine"]).astype(np.float32))
+    TU.MNI, TU.A, TU.atlas_path = None, None, None

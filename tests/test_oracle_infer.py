@@ -73,7 +73,7 @@ def test_full_width_blocks():
 
 def test_tiling_ranges_match_reference():
     d = load_npz("tiling_ranges.npz")
-    for n in (160, 200, 256):
+    for n in (160, 200, 256, 512):
         ranges, cnt = O.tiling_ranges((n, n, n), [80] * 3, [160] * 3)
         assert np.array_equal(np.array(ranges), d["ranges_%d" % n])
         assert np.array_equal(np.bincount(cnt.astype(np.int64).ravel(), minlength=9), d["cnt_%d_hist" % n])
@@ -88,9 +88,11 @@ def test_tiled_stitch_toy():
     f_maps, levels, groups, stride, win = [int(v) for v in d["cfg"]]
     sd = sd_from_npz(d)
     full = torch.from_numpy(d["full"])
-    out, ranges, cnt = O.tiled_inference(full, sd, [stride] * 3, [win] * 3, f_maps=f_maps, num_levels=levels,
-                                         num_groups=groups)
+    out, ranges, cnt = O.tiled_inference(full, sd, [stride] * 3, [win] * 3, atlas=(d["atlas"], d["atlas_aff"]),
+                                         f_maps=f_maps, num_levels=levels, num_groups=groups)
     assert np.array_equal(np.array(ranges), d["ranges"])
     assert np.array_equal(cnt, d["cnt"])
-    for k in [k[9:] for k in d if k.startswith("stitched/")]:
+    keys = [k[9:] for k in d if k.startswith("stitched/")]
+    assert len(keys) == 17 and keys[-1] == "deformed_atlas" and list(out.keys()) == keys    # scripts/demo_test.py:107-119
+    for k in keys:
         _close(out[k].numpy(), d["stitched/" + k], 5e-5)

@@ -54,6 +54,23 @@ def worker(rank, world, port, q):
             worst = max(worst, float((v - after[k]).abs().max()))
         print("max |param difference| after one step: %.3e (lr %.1e)" % (worst, c["lr"]), flush=True)
         good = good and worst <= 2e-2 * c["lr"]
+    # a non-finite loss on ONE rank (Trainer/engine.py:124-145 decides on the all-reduced loss): both ranks must skip the
+    # iteration together -- the rank with the finite loss must not wait in the gradient all-reduce for the other one --
+    # and leave the parameters untouched
+    bad_x = xs[rank].clone()
+    if rank == 1:
+        bad_x[0, 0, 0, 0, 0] = float("nan")
+    ld2, tot2, ok2 = step.step([bad_x], target, [samples[rank]])
+    untouched = all(torch.equal(v, after[k]) for k, v in step.parameters().items())
+    print("rank %d: non-finite iteration -> total %r stepped %r parameters untouched %r" % (rank, tot2, ok2, untouched), flush=True)
+    good = good and (not ok2) and untouched and (tot2 != tot2 or abs(tot2) == float("inf"))
+    # ... and the next finite iteration runs again on both
+    ld3, tot3, ok3 = step.step([xs[rank]], target, [samples[rank]])
+    good = good and bool(ok3)
+    after = {k: v.clone() for k, v in step.parameters().items()}
+    flags = [None] * world
+    dist.all_gather_object(flags, bool(good))
+    good = all(flags)
     # every rank must hold the same parameters
     flat = torch.cat([v.reshape(-1) for v in after.values()])
     other = [torch.empty_like(flat) for _ in range(world)]

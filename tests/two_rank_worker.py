@@ -15,11 +15,13 @@ def worker(rank, world, port, q):
     f_maps, levels, groups, stride, win = [int(v) for v in d["cfg"]]
     ga, ta = TU.default_inference_args(f_maps=f_maps, num_levels=levels, num_groups=groups)
     s = TU.InferenceSession(ga, ta, dev, state_dict=sd_from_npz(d), passes=3)
+    s.set_atlas(d["atlas"], d["atlas_aff"])                      # 17 stitched keys, as scripts/demo_test.py:102-119
     full = torch.from_numpy(d["full"]).to(dev)
     ref = None
     if rank == 0:
         ref, _, _ = TU.tiled_inference(full, s, [stride] * 3, [win] * 3, graphs=False)
         ref = {k: v.clone() for k, v in ref.items()}
+        assert len(ref) == 17 and "deformed_atlas" in ref
     s.use_graphs = True
     ok = True
     for rep in range(4):
