@@ -64,11 +64,18 @@ __global__ void interp_linear(const float* __restrict__ X, int nx, int ny, int n
 struct Aff34 { float a[12]; };
 // NZ: the mask operand is a tile's input image and M = (im != 0), the mask scripts/demo_test.py:88-89 builds
 // (1 where the image is non-zero, also where it is negative or NaN) before it calls get_deformed_atlas
+// The atlas texels are read with L1-bypassing loads (global_load_dword sc0 sc1, served by L2).  Measured on MI355X /
+// ROCm 7.2 (gpurun_out/r2_variants*.log): with plain loads this gather returned wrong texels
+// for whole 16-lane groups when the kernel ran inside the tile graphs -- 0.006 % of the voxels of a 256^3 volume with
+// two tiles in flight, none with the sc1 form in 65 volumes -- while the atlas memory itself never changed.
+__device__ __forceinline__ float ld_l2(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <bool NZ>
 __global__ void deformed_atlas(const float* __restrict__ mask, const float* __restrict__ rx,
-                               const float* __restrict__ ry, const float* __restrict__ rz,
-                               const float* __restrict__ X, int nx, int ny, int nz, Aff34 A, int64_t n,
-                               float* __restrict__ out) {
+                               const float* __restrict__ ry, const float* __restrict__ rz, const float* X, int nx,
+                               int ny, int nz, Aff34 A, int64_t n, float* __restrict__ out) {
     GRID_STRIDE(i, n) {
         float r = 0.f;
         if (NZ ? (mask[i] != 0.f) : (mask[i] > 0.f)) {
@@ -84,7 +91,7 @@ __global__ void deformed_atlas(const float* __restrict__ mask, const float* __re
                 const int cx = min(fx + 1, nx - 1), cy = min(fy + 1, ny - 1), cz = min(fz + 1, nz - 1);
                 const float wcx = x - fxf, wcy = y - fyf, wcz = z - fzf;
                 const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
-                auto at = [&](int a, int b, int c) { return X[((int64_t)a * ny + b) * nz + c]; };
+                auto at = [&](int a, int b, int c) { return ld_l2(X + (((int64_t)a * ny + b) * nz + c)); };
                 const float c00 = at(fx, fy, fz) * wfx + at(cx, fy, fz) * wcx;
                 const float c01 = at(fx, fy, cz) * wfx + at(cx, fy, cz) * wcx;
                 const float c10 = at(fx, cy, fz) * wfx + at(cx, cy, fz) * wcx;

@@ -686,7 +686,8 @@ def _run_tile(session, im, raw=False):
                                  extra_rows=1 if atlas is not None else 0)
     if atlas is not None:
         # scripts/demo_test.py:102-104: get_deformed_atlas(mask, regx, regy, regz) with mask = (im != 0), from the
-        # unmasked registration maps; the stitcher multiplies by the mask again (DEF is 0 outside it already)
+        # unmasked registration maps, into the spare row of the tail's map buffer; the stitcher multiplies by the mask
+        # again (DEF is 0 outside it already)
         vol, A = atlas
         row = tail.last_buf[len(tail.map_names)]
         L.check(L.load().bfm_deformed_atlas_tile(L.ptr(x_cl), L.ptr(maps["regx"]), L.ptr(maps["regy"]),
