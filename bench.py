@@ -108,9 +108,9 @@ def cpu_baseline(state_dict, full, n, ranges, full_protocol=False):
     prev = torch.get_num_threads()
     torch.set_num_threads(int(threads))
     sd = {k: v.detach().cpu() for k, v in state_dict.items()}
-    shapes = {}
-    for r in ranges:
-        s = tuple(b - a for a, b in r)
+    shapes = {}                                            # one class per multiset of extents: (160,80,80) stands for its
+    for r in ranges:                                       # three orientations (same arithmetic, same cost)
+        s = tuple(sorted((b - a for a, b in r), reverse=True))
         if s not in shapes:
             shapes[s] = [0, r]
         shapes[s][0] += 1
@@ -141,8 +141,8 @@ def cpu_baseline(state_dict, full, n, ranges, full_protocol=False):
             "cpu_model": info["model"], "sockets": info["sockets"], "cores_per_socket": info["cores_per_socket"],
             "hardware_threads": info["threads"], "per_tile_shape": per_shape,
             "extrapolated_volume_s": total_s,
-            "sample": "oracle/unet_ref.py (torch-CPU fp32, all 9 heads) on one tile of each shape of the reference "
-                      "tiling (%s), 1 warm-up + 3 timed runs (median) on the small shapes, 1 timed run on the large ones; "
+            "sample": "oracle/unet_ref.py (torch-CPU fp32, all 9 heads) on one tile of each shape class of the "
+                      "reference tiling (%s; orientations of a shape share its time), 1 warm-up + 3 timed runs (median) on the small shapes, 1 timed run on the large ones; "
                       "value = %d^3 voxels / sum(count x median) = EXTRAPOLATED whole-volume time %.1f s, not a timed "
                       "27-tile run; %.0f s of CPU work on %d threads (physical cores of one socket)"
                       % (", ".join(per_shape), n, total_s, spent, int(threads))}
