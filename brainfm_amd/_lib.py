@@ -14,7 +14,7 @@ ERR = {0: "BFM_OK", -1: "BFM_E_ARG", -2: "BFM_E_SHAPE", -3: "BFM_E_WORKSPACE", -
 ROLE_PLAIN, ROLE_CT, ROLE_BIAS_LOG, ROLE_SEG, ROLE_DIST, ROLE_SR, ROLE_PATHOL = range(7)
 (EW_EXP, EW_AFFINE, EW_CLAMP, EW_CLAMP_MIN, EW_GAMMA, EW_SIGMOID, EW_DIV, EW_NONZERO, EW_SUB_DIV, EW_GE,
  EW_NAN_TO_NUM) = range(11)
-(EW_ADD, EW_MUL, EW_MUL_EXP, EW_AXPY_CLAMP0, EW_AXPY, EW_DIV2) = range(6)
+(EW_ADD, EW_MUL, EW_MUL_EXP, EW_AXPY_CLAMP0, EW_AXPY, EW_DIV2, EW_ZERO_WHERE_ZERO) = range(7)
 
 
 class BfmError(RuntimeError):
@@ -135,6 +135,7 @@ SIGNATURES = {
     "bfm_deform_grid_workspace": (_Z, [_I, _I, _I]),
     "bfm_deform_grid": (_I, [_P, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_I), _P, _P, _P, _P, _P, _Z, _P]),
     "bfm_label_gauss": (_I, [_P, _P, _P, _P, _L, _I, _P, _P]),
+    "bfm_label_class_stats": (_I, [_P, _P, _L, _P, _P, _P]),
     "bfm_onehot_lut": (_I, [_P, _P, _I, _I, _L, _P, _P]),
     "bfm_perlin3d": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "bfm_radix_hist_f64": (_I, [_P, _L, C.c_uint64, _I, _P, _P]),

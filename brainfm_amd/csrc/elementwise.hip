@@ -45,6 +45,7 @@ __global__ void ew_binary(int op, const float* __restrict__ x, int64_t xs, const
             case BFM_EW_AXPY_CLAMP0: r = p + a * q; r = r < 0.f ? 0.f : r; break;   // add_noise, utils.py:633-638
             case BFM_EW_AXPY: r = p + a * q; break;
             case BFM_EW_DIV2: r = p / q; break;
+            case BFM_EW_ZERO_WHERE_ZERO: r = q == 0.f ? 0.f : p; break;
             default: r = p;
         }
         out[i * os] = r;

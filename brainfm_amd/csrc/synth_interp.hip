@@ -430,6 +430,33 @@ __global__ void label_gauss(const float* __restrict__ G, const float* __restrict
     }
 }
 
+// generate_sample's pathology branch (datasets.py:388-396): cerebral copy + class sums; one fp64 atomic per block and sum
+__global__ void label_class_stats(const float* __restrict__ G, const float* __restrict__ syn, int64_t n,
+                                  float* __restrict__ cerebral, double* __restrict__ stats) {
+    __shared__ double sh[4][4];
+    double a[4] = {0., 0., 0., 0.};
+    GRID_STRIDE(i, n) {
+        float g = G[i];
+        g = g == 77.f ? 2.f : g;
+        const int l = (int)rintf(g);
+        const float v = syn[i];
+        cerebral[i] = l == 0 ? 0.f : v;
+        if (l == 2 || l == 41) { a[0] += (double)v; a[1] += 1.; }
+        else if (l != 0) { a[2] += (double)v; a[3] += 1.; }
+    }
+    for (int k = 0; k < 4; ++k) {
+        double v = a[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if ((threadIdx.x & 63) == 0) sh[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double v = 0.;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += sh[threadIdx.x][w];
+        if (v != 0.) atomicAdd(stats + threadIdx.x, v);
+    }
+}
+
 __global__ void onehot_lut(const int32_t* __restrict__ S, const int32_t* __restrict__ lut, int nlut, int nl, int64_t n,
                            float* __restrict__ out) {
     const int64_t tot = n * nl;
@@ -546,6 +573,14 @@ extern "C" int bfm_label_gauss(const float* G, const float* mus, const float* si
                                int ntab, float* out, bfm_stream_t stream) {
     if (!G || !mus || !sigmas || !randn || !out || n <= 0 || ntab <= 0) return BFM_E_ARG;
     hipLaunchKernelGGL(label_gauss, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), G, mus, sigmas, randn, n, ntab, out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_label_class_stats(const float* G, const float* syn, int64_t n, float* cerebral, double* stats,
+                                     bfm_stream_t stream) {
+    if (!G || !syn || !cerebral || !stats || n <= 0) return BFM_E_ARG;
+    hipLaunchKernelGGL(label_class_stats, dim3(grid_for(n, 256, 1024)), dim3(256), 0, bfm_s(stream), G, syn, n, cerebral,
+                       stats);
     return bfm_launch_status();
 }
 

@@ -124,7 +124,7 @@ class BaseGen(torch.utils.data.Dataset):
         if photo_mode:
             size_F_small[1] = np.round(self.size[1] / spac).astype(int)
         nonlin_std = s.nonlin_std_max * np.random.rand()
-        Fsmall = GU.ew_unary(L.EW_AFFINE, torch.randn([*size_F_small, 3], dtype=torch.float, device=self.device),
+        Fsmall = GU.ew_unary(L.EW_AFFINE, GU.draws.randn([*size_F_small, 3], self.device),
                              float(np.float32(nonlin_std)), 0.0)
         F = GU.myzoom_torch(Fsmall, np.array(self.size) / size_F_small)
         if photo_mode:
@@ -169,11 +169,11 @@ class BaseGen(torch.utils.data.Dataset):
     # -------------------------------------------------------------- contrast / setup (datasets.py:430-493)
     def get_contrast(self, photo_mode):
         """256-entry mean / std tables (host arithmetic on 256 numbers), datasets.py:430-464."""
-        mus = (25 + 200 * torch.rand(256, dtype=torch.float)).numpy()
-        sigmas = (5 + 20 * torch.rand(256, dtype=torch.float)).numpy()
+        mus = (25 + 200 * GU.draws.rand(256)).numpy()
+        sigmas = (5 + 20 * GU.draws.rand(256)).numpy()
         if np.random.rand() < self.synth_args.ct_prob:
             for grp, (a, b) in (("darker", (25, 10)), ("dark", (90, 20)), ("bright", (110, 20)), ("brighter", (150, 50))):
-                v = a + b * torch.rand(1, dtype=torch.float)[0].item()
+                v = a + b * GU.draws.rand(1)[0].item()
                 for l in ct_brightness_group[grp]:
                     mus[l] = v
         if photo_mode or np.random.rand(1) < 0.5:
@@ -334,10 +334,10 @@ class BaseGen(torch.utils.data.Dataset):
         P, Pprob = torch.squeeze(P).to(torch.float32).contiguous(), torch.squeeze(Pprob).to(torch.float32).contiguous()
         I = I.contiguous()
         I_mu = np.float32(GU.tensor_dot(I, P) / GU.tensor_sum(P))
-        pth_mus = 3 * I_mu / 4 + I_mu / 4 * torch.rand(10000, dtype=torch.float).numpy()
+        pth_mus = 3 * I_mu / 4 + I_mu / 4 * GU.draws.rand(10000).numpy()
         pth_mus = pth_mus if pathol_direction else -pth_mus
-        pth_sigmas = I_mu / 4 * torch.rand(10000, dtype=torch.float).numpy()
-        rn = torch.randn(P.shape, dtype=torch.float, device=self.device)
+        pth_sigmas = I_mu / 4 * GU.draws.rand(10000).numpy()
+        rn = GU.draws.randn(P.shape, self.device)
         out = torch.empty_like(I)
         L.check(L.load().bfm_pathology_encode(L.ptr(I), L.ptr(P), L.ptr(Pprob), L.ptr(rn), float(pth_mus[0]),
                                               float(pth_mus[1]), float(pth_sigmas[0]), float(pth_sigmas[1]), I.numel(),
@@ -379,23 +379,64 @@ class BaseGen(torch.utils.data.Dataset):
             sample["bias_field_log"] = fl(aux["BFlog"])[None]
         return sample
 
-    def generate_sample(self, name, G, setups, deform_dict, res, target):
+    def get_pathology_direction(self, input_mode, pathol_direction=None):
+        """datasets.py:414-427: True = T2/FLAIR-like (lesion brighter), False = T1/CT-like."""
+        if pathol_direction is not None:
+            return pathol_direction
+        if input_mode in ("T1", "CT"):
+            return False
+        if input_mode in ("T2", "FLAIR"):
+            return True
+        return random.choice([True, False])
+
+    def generate_sample(self, name, G, setups, deform_dict, res, target, case=None):
+        """datasets.py:355-412."""
         [xx2, yy2, zz2] = deform_dict["grid"][:3]
+        lib = L.load()
         mus, sigmas = self.get_contrast(setups["photo_mode"])
         Gc = self._crop(G, deform_dict["grid"]).contiguous()
-        rn = torch.randn(Gc.shape, dtype=torch.float, device=self.device)
+        rn = GU.draws.randn(Gc.shape, self.device)
         SYN = torch.empty_like(Gc)
-        L.check(L.load().bfm_label_gauss(L.ptr(Gc), L.ptr(mus), L.ptr(sigmas), L.ptr(rn), Gc.numel(), 256, L.ptr(SYN),
-                                         L.stream_ptr()), "label_gauss")
+        L.check(lib.bfm_label_gauss(L.ptr(Gc), L.ptr(mus), L.ptr(sigmas), L.ptr(rn), Gc.numel(), 256, L.ptr(SYN),
+                                    L.stream_ptr()), "label_gauss")
         SYN = GU.fast_3D_interp_torch(SYN, xx2, yy2, zz2)
-        np.random.rand()                                       # mix_synth_prob draw (datasets.py:377; mixing is off: 0.)
-        pathol_direction = None
-        if not ("pathology" in target and isinstance(target["pathology"], torch.Tensor) and
-                float(target["pathology"].sum().item()) > 0):
+        if np.random.rand() < getattr(self.gen_args, "mix_synth_prob", 0.):        # random linear combination, :377-386
+            have = case if case is not None else {}
+            v = GU.draws.rand(4).clone()
+            v[2] = 0 if "T2" not in have else v[2]
+            v[3] = 0 if "FLAIR" not in have else v[3]
+            v /= torch.sum(v)
+            SYN = GU.ew_binary(L.EW_AXPY, GU.ew_unary(L.EW_AFFINE, SYN, float(v[0]), 0.0),
+                               target["T1"][0].to(torch.float32), float(v[1]))
+            if "T2" in have:
+                SYN = GU.ew_binary(L.EW_AXPY, SYN, target["T2"][0].to(torch.float32), float(v[2]))
+            if "FLAIR" in have:
+                SYN = GU.ew_binary(L.EW_AXPY, SYN, target["FLAIR"][0].to(torch.float32), float(v[3]))
+        if "pathology" in target and isinstance(target["pathology"], torch.Tensor) and \
+                float(target["pathology"].sum().item()) > 0:
+            # :388-404.  The reference masks the DEFORMED image with the label crop (SYN_cerebral[Gr == 0] = 0), which
+            # only works when the crop box has the generator's size; like torch, refuse anything else
+            if tuple(Gc.shape) != tuple(SYN.shape):
+                raise IndexError("The shape of the mask %s does not match the shape of the indexed tensor %s"
+                                 % (list(Gc.shape), list(SYN.shape)))
+            SYN = SYN.contiguous()
+            cer = torch.empty_like(SYN)
+            stats = torch.zeros(4, dtype=torch.float64, device=self.device)
+            L.check(lib.bfm_label_class_stats(L.ptr(Gc), L.ptr(SYN), SYN.numel(), L.ptr(cer), L.ptr(stats),
+                                              L.stream_ptr()), "label_class_stats")
+            cer = GU.fast_3D_interp_torch(cer, xx2, yy2, zz2)[None]
+            st = stats.cpu().tolist()
+            wm_mean = st[0] / st[1] if st[1] else float("nan")
+            gm_mean = st[2] / st[3] if st[3] else float("nan")
+            for k in ("pathology", "pathology_prob"):
+                t = target[k]
+                target[k] = GU.ew_binary(L.EW_ZERO_WHERE_ZERO, t.to(torch.float32).contiguous(), cer).to(t.dtype)
+            pathol_direction = self.get_pathology_direction("synth", gm_mean > wm_mean)
+        else:
+            pathol_direction = None
             target["pathology"] = 0.
             target["pathology_prob"] = 0.
-        else:
-            pathol_direction = random.choice([True, False])
+        SYN = GU.ew_unary(L.EW_CLAMP_MIN, SYN, 0.0)
         return target["pathology"], target["pathology_prob"], \
             self.augment_sample(name, SYN, setups, deform_dict, res, target, pathol_direction=pathol_direction)
 
@@ -441,10 +482,11 @@ class BaseGen(torch.utils.data.Dataset):
         if input_mode == "synth":
             self.update_gen_args(self.synth_image_args)
             target["pathology"], target["pathology_prob"], sample = \
-                self.generate_sample(case_name, img, setups, deform_dict, res, target)
+                self.generate_sample(case_name, img, setups, deform_dict, res, target, case)
         else:
             self.update_gen_args(self.real_image_args)
-            sample = self.augment_sample(case_name, img, setups, deform_dict, res, target, input_mode=input_mode)
+            sample = self.augment_sample(case_name, img, setups, deform_dict, res, target,
+                                         pathol_direction=self.get_pathology_direction(input_mode), input_mode=input_mode)
         if setups["flip"] and isinstance(target["pathology"], torch.Tensor):
             target["pathology"] = torch.flip(target["pathology"], [1])
             target["pathology_prob"] = torch.flip(target["pathology_prob"], [1])
@@ -472,10 +514,12 @@ class BrainIDGen(BaseGen):
             if input_mode == "synth":
                 self.update_gen_args(self.synth_image_args)
                 target["pathology"], target["pathology_prob"], sample = \
-                    self.generate_sample(case_name, img, setups, deform_dict, res, target)
+                    self.generate_sample(case_name, img, setups, deform_dict, res, target, case)
             else:
                 self.update_gen_args(self.real_image_args)
-                sample = self.augment_sample(case_name, img, setups, deform_dict, res, target, input_mode=input_mode)
+                sample = self.augment_sample(case_name, img, setups, deform_dict, res, target,
+                                             pathol_direction=self.get_pathology_direction(input_mode),
+                                             input_mode=input_mode)
             samples.append(sample)
         if setups["flip"] and isinstance(target["pathology"], torch.Tensor):
             target["pathology"] = torch.flip(target["pathology"], [1])

@@ -35,6 +35,48 @@ def _require_cuda(t, what):
 
 
 # ----------------------------------------------------------------------------- sampling helpers (host)
+class DeviceDraws:
+    """Where the generator's torch draws come from.  The reference draws them with torch.rand / torch.randn on its
+    device; here the volume-sized normal fields are drawn on the GPU and the small tables on the host (RNG-stream parity
+    across devices is not a goal).  Tests replace ``generator_utils.draws`` with ReplayDraws to feed the reference's own
+    recorded draws through the chain (tests/golden/make_golden_gen.py)."""
+
+    def randn(self, shape, device):
+        return torch.randn(list(shape), dtype=torch.float, device=device)
+
+    def rand(self, n):
+        return torch.rand(n, dtype=torch.float)
+
+
+class ReplayDraws:
+    """Hands out recorded draws [(kind, array)] in call order; a draw of another kind or shape is an error (the mirror
+    left the reference's call sequence)."""
+
+    def __init__(self, seq):
+        self.seq = list(seq)
+        self.pos = 0
+
+    def _next(self, kind, shape):
+        if self.pos >= len(self.seq):
+            raise AssertionError("the chain asked for draw #%d (%s %s) but the reference made only %d"
+                                 % (self.pos, kind, tuple(shape), len(self.seq)))
+        k, arr = self.seq[self.pos]
+        if k != kind or tuple(arr.shape) != tuple(shape):
+            raise AssertionError("draw #%d: the chain asks for %s %s, the reference drew %s %s"
+                                 % (self.pos, kind, tuple(shape), k, tuple(arr.shape)))
+        self.pos += 1
+        return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
+
+    def randn(self, shape, device):
+        return self._next("randn", tuple(shape)).to(device)
+
+    def rand(self, n):
+        return self._next("rand", (int(n),))
+
+
+draws = DeviceDraws()
+
+
 def resolution_sampler(low_res_only=False):
     """Generator/utils.py:34-57 (host RNG only)."""
     r = (np.random.rand() * 0.5) + 0.5 if low_res_only else np.random.rand()
@@ -286,7 +328,7 @@ def add_bias_field(I, aux_dict, cfg, input_mode, setups, size, device, **kwargs)
     if setups["photo_mode"]:
         size_BF_small[1] = np.round(size[1] / setups["spac"]).astype(int)
     amp = float(np.float32(cfg.bf_std_min + (cfg.bf_std_max - cfg.bf_std_min) * np.random.rand(1))[0])
-    BFsmall = ew_unary(L.EW_AFFINE, torch.randn(size_BF_small, dtype=torch.float, device=I.device), amp, 0.0)
+    BFsmall = ew_unary(L.EW_AFFINE, draws.randn(size_BF_small, I.device), amp, 0.0)
     BFlog = myzoom_torch(BFsmall, np.array(size) / size_BF_small)
     I_bf = ew_binary(L.EW_MUL_EXP, I.to(torch.float32), BFlog)
     aux_dict.update({"BFlog": BFlog, "high_res": I_bf})
@@ -315,7 +357,7 @@ def resample_resolution(I, aux_dict, setups, res, size, device, **kwargs):
 def add_noise(I, aux_dict, cfg, device, **kwargs):
     """Generator/utils.py:633-638: I + std * N(0,1), clamped at 0."""
     noise_std = float(np.float32(cfg.noise_std_min + (cfg.noise_std_max - cfg.noise_std_min) * np.random.rand(1))[0])
-    rn = torch.randn(I.shape, dtype=torch.float, device=I.device)
+    rn = draws.randn(I.shape, I.device)
     return ew_binary(L.EW_AXPY_CLAMP0, I.to(torch.float32), rn, noise_std), aux_dict
 
 

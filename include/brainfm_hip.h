@@ -276,7 +276,8 @@ enum {
 };
 enum {
     BFM_EW_ADD = 0, BFM_EW_MUL = 1, BFM_EW_MUL_EXP = 2 /* x*exp(y), add_bias_field utils.py:585-587 */,
-    BFM_EW_AXPY_CLAMP0 = 3 /* max(x+a*y,0), add_noise utils.py:633-638 */, BFM_EW_AXPY = 4, BFM_EW_DIV2 = 5
+    BFM_EW_AXPY_CLAMP0 = 3 /* max(x+a*y,0), add_noise utils.py:633-638 */, BFM_EW_AXPY = 4, BFM_EW_DIV2 = 5,
+    BFM_EW_ZERO_WHERE_ZERO = 6 /* y==0 ? 0 : x, target['pathology'][SYN_cerebral == 0] = 0, datasets.py:398-399 */
 };
 int bfm_ew_unary(int op, const float* in, int64_t in_stride, float* out, int64_t out_stride, int64_t n,
                  float a, float b, bfm_stream_t stream);
@@ -367,6 +368,11 @@ int bfm_deform_grid(const float* F, int sx, int sy, int sz, const float* A_host 
                     void* workspace, size_t workspace_bytes, bfm_stream_t stream);
 /* generate_sample core -- Generator/datasets.py:366-372: mus[round(G)] + sigmas[round(G)]*randn, clamp >= 0
  * (label 77 merged into 2). */
+/* generate_sample's pathology branch -- Generator/datasets.py:388-396: cerebral[i] = (round(G[i]) == 0) ? 0 : syn[i]
+ * (G == 77 counts as 2, :368) and the four sums behind wm_mean / gm_mean: stats[0..3] = sum(syn | label in {2,41}),
+ * count of those, sum(syn | label not in {0,2,41}), count (fp64; stats must be zeroed by the caller). */
+int bfm_label_class_stats(const float* G, const float* syn, int64_t n, float* cerebral, double* stats,
+                          bfm_stream_t stream);
 int bfm_label_gauss(const float* G, const float* mus, const float* sigmas, const float* randn, int64_t n, int ntab,
                     float* out, bfm_stream_t stream);
 /* onehotmatrix[lut[S]] -- Generator/utils.py:408-411: out [n][n_labels]. */

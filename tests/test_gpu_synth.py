@@ -374,3 +374,60 @@ def test_write_device_volumes_round_trip(tmp_path):
             assert np.array_equal(np.asarray(arr).astype(np.float64), v.cpu().numpy().astype(np.float64)), (k, ext)
             if aff2 is not None:
                 assert np.allclose(aff2, aff, atol=1e-5), (k, ext)
+
+
+def _ns(d):
+    if isinstance(d, dict):
+        return Namespace(**{k: _ns(v) for k, v in d.items()})
+    return d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["A", "B", "C"])
+def test_generator_getitem_vs_reference_golden(tag):
+    """SURVEY rows a19-a21 against the reference itself: tests/golden/gen_chain.npz holds what the reference's own
+    BrainIDGen.__getitem__ (A: synthetic input mixed with the real T1, two samples; B: flipped, random Perlin pathology
+    through generate_sample's pathology branch and encode_pathology) and BaseGen.__getitem__ (C: real T1 input, pathology
+    encoded with the T1 direction) returned on in-memory cases, with every torch draw it made.  The device chain replays
+    those draws (generator_utils.ReplayDraws) and follows NumPy's / random's streams by the seed: every target and every
+    sample must come out the same."""
+    import random
+    from brainfm_amd import generator as G
+    from brainfm_amd import generator_utils as GU
+    from test_oracle_gen import load_case, relerr
+    c = load_case(tag)
+    cfg = dict(c["cfg"])
+    cfg["dataset_option"] = "brain_id" if c["cls"] == "BrainIDGen" else "default"
+    ga = _ns(cfg)
+    case = dict(c["case"], name=tag, dataset="MEM")
+    np.random.seed(c["seed"])
+    random.seed(c["seed"])
+    prev = GU.draws
+    GU.draws = GU.ReplayDraws(c["draws"])
+    try:
+        ds = G.build_datasets(ga, DEV, cases=[case])["all"]
+        assert type(ds).__name__ == c["cls"]
+        n, dname, mode, target, samples = ds[0]
+        assert GU.draws.pos == len(c["draws"])                 # the reference's draw sequence, consumed exactly
+    finally:
+        GU.draws = prev
+    if not isinstance(samples, list):
+        samples = [samples]
+    assert mode == c["mode"] and n == 1 and len(samples) == len(c["samples"])
+    for k, ref in c["target"].items():
+        got = target[k]
+        if np.ndim(ref) == 0:
+            assert not isinstance(got, torch.Tensor) and float(got) == float(ref), (k, got, ref)
+            continue
+        got = N(got)
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        if k in ("segmentation", "pathology"):
+            assert np.mean(got != ref) <= 1e-4, (k, float(np.mean(got != ref)))
+        else:
+            assert relerr(got, ref) <= 2e-5, (k, relerr(got, ref))
+    for i, (s, r) in enumerate(zip(samples, c["samples"])):
+        assert sorted(s.keys()) == sorted(r.keys())
+        for k in r:
+            got = N(s[k])
+            assert got.shape == r[k].shape, (i, k)
+            assert relerr(got, r[k]) <= 1e-4, (i, k, relerr(got, r[k]))
