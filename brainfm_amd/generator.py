@@ -399,6 +399,7 @@ class BaseGen(torch.utils.data.Dataset):
         SYN = torch.empty_like(Gc)
         L.check(lib.bfm_label_gauss(L.ptr(Gc), L.ptr(mus), L.ptr(sigmas), L.ptr(rn), Gc.numel(), 256, L.ptr(SYN),
                                     L.stream_ptr()), "label_gauss")
+        SYN0 = SYN                                            # crop space, before the deformation
         SYN = GU.fast_3D_interp_torch(SYN, xx2, yy2, zz2)
         if np.random.rand() < getattr(self.gen_args, "mix_synth_prob", 0.):        # random linear combination, :377-386
             have = case if case is not None else {}
@@ -414,15 +415,17 @@ class BaseGen(torch.utils.data.Dataset):
                 SYN = GU.ew_binary(L.EW_AXPY, SYN, target["FLAIR"][0].to(torch.float32), float(v[3]))
         if "pathology" in target and isinstance(target["pathology"], torch.Tensor) and \
                 float(target["pathology"].sum().item()) > 0:
-            # :388-404.  The reference masks the DEFORMED image with the label crop (SYN_cerebral[Gr == 0] = 0), which
-            # only works when the crop box has the generator's size; like torch, refuse anything else
-            if tuple(Gc.shape) != tuple(SYN.shape):
-                raise IndexError("The shape of the mask %s does not match the shape of the indexed tensor %s"
-                                 % (list(Gc.shape), list(SYN.shape)))
-            SYN = SYN.contiguous()
-            cer = torch.empty_like(SYN)
+            # :388-404.  The reference masks the DEFORMED image with the label crop (SYN_cerebral[Gr == 0] = 0) and deforms
+            # the result a second time; torch accepts that only when the crop box has the generator's size (IndexError
+            # otherwise: the reference cannot draw pathology on a synthetic input from a larger volume).  Same sizes: the
+            # reference's arithmetic, pinned by gen_chain.npz case B.  Otherwise (an extension, not reference behaviour):
+            # the mask and the white / grey matter means are taken in crop space, where labels and image line up, and
+            # deformed once.
+            same = tuple(Gc.shape) == tuple(SYN.shape)
+            src = SYN.contiguous() if same else SYN0.contiguous()
+            cer = torch.empty_like(src)
             stats = torch.zeros(4, dtype=torch.float64, device=self.device)
-            L.check(lib.bfm_label_class_stats(L.ptr(Gc), L.ptr(SYN), SYN.numel(), L.ptr(cer), L.ptr(stats),
+            L.check(lib.bfm_label_class_stats(L.ptr(Gc), L.ptr(src), src.numel(), L.ptr(cer), L.ptr(stats),
                                               L.stream_ptr()), "label_class_stats")
             cer = GU.fast_3D_interp_torch(cer, xx2, yy2, zz2)[None]
             st = stats.cpu().tolist()

@@ -377,6 +377,7 @@ def test_write_device_volumes_round_trip(tmp_path):
 
 
 def _ns(d):
+    from argparse import Namespace
     if isinstance(d, dict):
         return Namespace(**{k: _ns(v) for k, v in d.items()})
     return d
