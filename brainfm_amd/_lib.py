@@ -72,6 +72,12 @@ SIGNATURES = {
     "bfm_conv3x3x3_mfma_rows": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),
     "bfm_conv3x3x3_mfma_ex": (_I, [_P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _P, _I, _P, _I, _I, _F, _I,
                                    C.POINTER(_I), _P, _P, _Z, _P, _P]),
+    "bfm_conv3x3x3_mfma_batch_workspace": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
+    "bfm_conv3x3x3_mfma_batch": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _UP, _P, _P, _P, _I, _P, _I, _I, _F, _I,
+                                      C.POINTER(_I), _P, _P, _Z, _P, _P]),
+    "bfm_gn_stats_batch_workspace": (_Z, [_I, _I, _I, _I, _I, _I, _UP]),
+    "bfm_gn_stats_batch": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _UP, _P, _P, _I, _F, _P, _P, _P, _P, _Z, _P]),
+    "bfm_gn_stats_rows_batch": (_I, [_P, _I, _I, _P, _I, _I, C.c_double, _L, _I, _P, _P, _I, _F, _P, _P, _P, _P]),
     "bfm_conv3x3x3_stem_rows": (_I, [_I, _I, _I]),
     "bfm_conv3x3x3_stem_ex": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P, _P]),
     "bfm_gn_stats_rows_workspace": (_Z, [_I, _I, _I, _I]),

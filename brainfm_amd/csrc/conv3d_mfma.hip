@@ -54,6 +54,13 @@ struct ConvParams {
     int tw_shift, thw_shift;        // >=0 when TW / TH*TW are powers of two
     int64_t split_stride;           // elements between split-K slabs
     int accum;                      // 1: add what `out` already holds (the up-folded low-res half) before LeakyReLU
+    // S > 1: a batch of S same-shape samples (tiles of one volume) in one launch.  A, B, out are [S][...] contiguous
+    // (element strides sA, sB, sO), scale / shift [S][CA+CB], bound [S][G] (GroupNorm statistics stay per sample,
+    // buildingblocks.py:48-60); nMt = S * nMtS M tiles, sample fastest in the block order so that the S workgroups
+    // that need the same weight fragments run side by side and share them in L2.  Every workgroup does exactly what it
+    // does in the per-sample launch (same box, same K order, same split-K): results are bit-identical.
+    int S, nMtS;
+    int64_t sA, sB, sO;
     // optional moment rows of the OUTPUT (one row per M tile, [nMt][Cout]): {sum, sumsq} fp64, {min, max} fp32.  The
     // consumer's GroupNorm reduces these instead of re-reading the activation (gn_stats.hip: bfm_gn_stats_rows).
     double *rsum, *rsq;
@@ -153,17 +160,33 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(const ConvParams p)
         const int xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int mt = bid / p.NT, nt = bid - mt * p.NT;
+    int mt, nt, smp = 0;
+    if (p.S > 1) {                                       // (M tile of a sample, N tile, sample): sample fastest
+        smp = bid % p.S;
+        const int t = bid / p.S;
+        nt = t % p.NT;
+        mt = smp * p.nMtS + t / p.NT;
+    } else {
+        mt = bid / p.NT;
+        nt = bid - mt * p.NT;
+    }
+    const int mtl = mt - smp * p.nMtS;                   // tile index inside its sample
+    const float* const pA = p.A + smp * p.sA;
+    const float* const pB = p.B + smp * p.sB;
+    const float* const pscale = p.scale + smp * (p.CA + p.CB);
+    const float* const pshift = p.shift + smp * (p.CA + p.CB);
+    const float* const pbound = p.bound + smp * p.G;
+    float* const pout = p.out + smp * p.sO;
     const int split = blockIdx.y;
-    const int tx = mt % p.nTx;
-    const int ty = (mt / p.nTx) % p.nTy;
-    const int tz = mt / (p.nTx * p.nTy);
+    const int tx = mtl % p.nTx;
+    const int ty = (mtl / p.nTx) % p.nTy;
+    const int tz = mtl / (p.nTx * p.nTy);
     const int z0 = tz * p.TD, y0 = ty * p.TH, x0 = tx * p.TW;
     const int boxN = p.TD * p.TH * p.TW;
 
     // ---- operand scale from the GroupNorm bound (power of two, exact)
     float bmax = 0.f;
-    for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, p.bound[g]);
+    for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, pbound[g]);
     int aexp = 0;
     if (bmax > 0.f && bmax < INFINITY) {
         int ex;
@@ -241,7 +264,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(const ConvParams p)
                 box_coords(p, q, d, h, w);
                 const int gz = z0 + d, gy = y0 + h, gx = x0 + w;
                 if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
-                const float* orow = p.out + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + ntw * 64 + l32;
+                const float* orow = pout + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + ntw * 64 + l32;
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) acc[mb][nb][i] = orow[nb * 32] * inv_dq;
             }
@@ -279,9 +302,9 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(const ConvParams p)
         const int c0 = kc * KC;
         const bool fromB = c0 >= p.CA;
         if (fromB != off_fromB) { off_fromB = fromB; compute_offsets(fromB); }
-        const float* src = (fromB ? p.B + (c0 - p.CA) : p.A + c0) + q4 * 4;
-        const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + c0 + q4 * 4);
-        const float4 sh4 = *reinterpret_cast<const float4*>(p.shift + c0 + q4 * 4);
+        const float* src = (fromB ? pB + (c0 - p.CA) : pA + c0) + q4 * 4;
+        const float4 sc4 = *reinterpret_cast<const float4*>(pscale + c0 + q4 * 4);
+        const float4 sh4 = *reinterpret_cast<const float4*>(pshift + c0 + q4 * 4);
         const float sc[4] = {sc4.x * a_scale, sc4.y * a_scale, sc4.z * a_scale, sc4.w * a_scale};
         const float sh[4] = {sh4.x * a_scale, sh4.y * a_scale, sh4.z * a_scale, sh4.w * a_scale};
 
@@ -362,7 +385,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(const ConvParams p)
     // ================= epilogue =================
     const bool final_out = p.splitk == 1;
     const bool want_rows = final_out && p.rsum != nullptr;
-    float* obase = p.out + (final_out ? 0 : (int64_t)split * p.split_stride);
+    float* obase = pout + (final_out ? 0 : (int64_t)split * p.split_stride);
     // per-lane partial moments of <= 32 stored values per column in fp32 (then fp64 across lanes, waves and tiles)
     float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
     float mmn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mmx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -440,16 +463,32 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma16(const ConvParams 
         const int xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int mt = bid / p.NT, nt = bid - mt * p.NT;
+    int mt, nt, smp = 0;
+    if (p.S > 1) {                                       // (M tile of a sample, N tile, sample): sample fastest
+        smp = bid % p.S;
+        const int t = bid / p.S;
+        nt = t % p.NT;
+        mt = smp * p.nMtS + t / p.NT;
+    } else {
+        mt = bid / p.NT;
+        nt = bid - mt * p.NT;
+    }
+    const int mtl = mt - smp * p.nMtS;                   // tile index inside its sample
+    const float* const pA = p.A + smp * p.sA;
+    const float* const pB = p.B + smp * p.sB;
+    const float* const pscale = p.scale + smp * (p.CA + p.CB);
+    const float* const pshift = p.shift + smp * (p.CA + p.CB);
+    const float* const pbound = p.bound + smp * p.G;
+    float* const pout = p.out + smp * p.sO;
     const int split = blockIdx.y;
-    const int tx = mt % p.nTx;
-    const int ty = (mt / p.nTx) % p.nTy;
-    const int tz = mt / (p.nTx * p.nTy);
+    const int tx = mtl % p.nTx;
+    const int ty = (mtl / p.nTx) % p.nTy;
+    const int tz = mtl / (p.nTx * p.nTy);
     const int z0 = tz * p.TD, y0 = ty * p.TH, x0 = tx * p.TW;
     const int boxN = p.TD * p.TH * p.TW;
 
     float bmax = 0.f;
-    for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, p.bound[g]);
+    for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, pbound[g]);
     int aexp = 0;
     if (bmax > 0.f && bmax < INFINITY) {
         int ex;
@@ -520,7 +559,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma16(const ConvParams 
                 box_coords(p, q, d, h, w);
                 const int gz = z0 + d, gy = y0 + h, gx = x0 + w;
                 if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
-                const float* orow = p.out + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + ntw * 64 + l16;
+                const float* orow = pout + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + ntw * 64 + l16;
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) acc[rb][cb][i] = orow[cb * 16] * inv_dq;
             }
@@ -556,9 +595,9 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma16(const ConvParams 
         const int c0 = kc * KC;
         const bool fromB = c0 >= p.CA;
         if (fromB != off_fromB) { off_fromB = fromB; compute_offsets(fromB); }
-        const float* src = (fromB ? p.B + (c0 - p.CA) : p.A + c0) + q4 * 4;
-        const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + c0 + q4 * 4);
-        const float4 sh4 = *reinterpret_cast<const float4*>(p.shift + c0 + q4 * 4);
+        const float* src = (fromB ? pB + (c0 - p.CA) : pA + c0) + q4 * 4;
+        const float4 sc4 = *reinterpret_cast<const float4*>(pscale + c0 + q4 * 4);
+        const float4 sh4 = *reinterpret_cast<const float4*>(pshift + c0 + q4 * 4);
         const float sc[4] = {sc4.x * a_scale, sc4.y * a_scale, sc4.z * a_scale, sc4.w * a_scale};
         const float sh[4] = {sh4.x * a_scale, sh4.y * a_scale, sh4.z * a_scale, sh4.w * a_scale};
 
@@ -637,7 +676,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma16(const ConvParams 
 
     const bool final_out = p.splitk == 1;
     const bool want_rows = final_out && p.rsum != nullptr;
-    float* obase = p.out + (final_out ? 0 : (int64_t)split * p.split_stride);
+    float* obase = pout + (final_out ? 0 : (int64_t)split * p.split_stride);
     float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};      // <= 16 values per column per lane in fp32
     float mmn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mmx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
@@ -1302,11 +1341,39 @@ extern "C" int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB
                                  cfg, out, workspace, workspace_bytes, nullptr, stream);
 }
 
+static int conv_mfma_launch(const float* A, int CA, const float* B, int CB, int S, int D, int H, int W,
+                            const bfm_upsample_t* up, const float* scale, const float* shift, const float* bound, int G,
+                            const void* wpacked, int wexp, int Cout, float slope, int passes, const int* cfg, float* out,
+                            void* workspace, size_t workspace_bytes, void* moment_rows, bfm_stream_t stream);
+
 extern "C" int bfm_conv3x3x3_mfma_ex(const float* A, int CA, const float* B, int CB, int D, int H, int W,
                                      const bfm_upsample_t* up, const float* scale, const float* shift,
                                      const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope,
                                      int passes, const int* cfg, float* out, void* workspace, size_t workspace_bytes,
                                      void* moment_rows, bfm_stream_t stream) {
+    return conv_mfma_launch(A, CA, B, CB, 1, D, H, W, up, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, cfg,
+                            out, workspace, workspace_bytes, moment_rows, stream);
+}
+
+extern "C" size_t bfm_conv3x3x3_mfma_batch_workspace(int Cin, int Cout, int S, int D, int H, int W, int splitk) {
+    return (size_t)(S < 1 ? 1 : S) * bfm_conv3x3x3_mfma_workspace(Cin, Cout, D, H, W, splitk);
+}
+
+extern "C" int bfm_conv3x3x3_mfma_batch(const float* A, int CA, const float* B, int CB, int S, int D, int H, int W,
+                                        const bfm_upsample_t* up, const float* scale, const float* shift,
+                                        const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope,
+                                        int passes, const int* cfg, float* out, void* workspace, size_t workspace_bytes,
+                                        void* moment_rows, bfm_stream_t stream) {
+    if (S < 1 || !cfg) return BFM_E_ARG;
+    if (cfg[6] != 0 && cfg[6] != 2) return BFM_E_SHAPE;        // the persistent and Winograd variants take one sample
+    return conv_mfma_launch(A, CA, B, CB, S, D, H, W, up, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, cfg,
+                            out, workspace, workspace_bytes, moment_rows, stream);
+}
+
+static int conv_mfma_launch(const float* A, int CA, const float* B, int CB, int S, int D, int H, int W,
+                            const bfm_upsample_t* up, const float* scale, const float* shift, const float* bound, int G,
+                            const void* wpacked, int wexp, int Cout, float slope, int passes, const int* cfg, float* out,
+                            void* workspace, size_t workspace_bytes, void* moment_rows, bfm_stream_t stream) {
     if (!A || CA <= 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || G <= 0 || !wpacked || !out)
         return BFM_E_ARG;
     if (CB < 0 || (CB > 0 && (!B || !up || !up->mapD || !up->mapH || !up->mapW || up->d <= 0 || up->h <= 0 ||
@@ -1340,7 +1407,9 @@ extern "C" int bfm_conv3x3x3_mfma_ex(const float* A, int CA, const float* B, int
     p.TD = hp.TD; p.TH = hp.TH; p.TW = hp.TW; p.HT = hp.TH + 2; p.WT = hp.TW + 2;
     const int nTz = bfm_cdiv(D, hp.TD);
     p.nTy = bfm_cdiv(H, hp.TH); p.nTx = bfm_cdiv(W, hp.TW);
-    p.nMt = nTz * p.nTy * p.nTx;
+    p.nMtS = nTz * p.nTy * p.nTx;
+    p.S = S;
+    p.nMt = S * p.nMtS;
     p.NT = Cout / (64 * hp.WN);
     p.KCN = Cin / KC;
     p.splitk = hp.splitk < 1 ? 1 : hp.splitk;
@@ -1359,9 +1428,12 @@ extern "C" int bfm_conv3x3x3_mfma_ex(const float* A, int CA, const float* B, int
     if (hp.ver < 0 || hp.ver > 2) return BFM_E_ARG;
     if (p.nvox_lds * 4 > 12 * 64 * hp.WM * hp.WN) return BFM_E_SHAPE;
     const int64_t nvox = (int64_t)D * H * W;
-    p.split_stride = nvox * Cout;
+    p.sA = nvox * CA;
+    p.sB = CB > 0 ? (int64_t)up->d * up->h * up->w * CB : 0;
+    p.sO = nvox * Cout;
+    p.split_stride = (int64_t)S * nvox * Cout;
     if (p.splitk > 1) {
-        if (!workspace || workspace_bytes < (size_t)p.splitk * nvox * Cout * sizeof(float)) return BFM_E_WORKSPACE;
+        if (!workspace || workspace_bytes < (size_t)p.splitk * S * nvox * Cout * sizeof(float)) return BFM_E_WORKSPACE;
         if (reinterpret_cast<uintptr_t>(workspace) & 15) return BFM_E_ARG;
         p.out = static_cast<float*>(workspace);
     } else {
@@ -1399,7 +1471,7 @@ extern "C" int bfm_conv3x3x3_mfma_ex(const float* A, int CA, const float* B, int
     int rc = bfm_launch_status();
     if (rc != BFM_OK) return rc;
     if (p.splitk > 1) {
-        int64_t n4 = nvox * Cout / 4;
+        int64_t n4 = (int64_t)S * nvox * Cout / 4;
         int nb = (int)std::min<int64_t>(2048, bfm_cdiv64(n4, 256));
         hipLaunchKernelGGL(splitk_reduce, dim3(nb), dim3(256), 0, st, static_cast<const float*>(workspace), p.splitk,
                            n4, p.split_stride / 4, slope, p.accum, out);

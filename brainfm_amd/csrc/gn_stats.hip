@@ -71,6 +71,11 @@ __global__ void __launch_bounds__(TPB) gn_partial(const float* __restrict__ X, i
                                                   float* __restrict__ pmax) {
     extern __shared__ double smem_d[];
     const int t = threadIdx.x;
+    {   // blockIdx.y = sample of a batch: tensors [S][nvox][C], partial tables [S][gridDim.x][C]
+        const size_t so = (size_t)blockIdx.y * gridDim.x * C;
+        X += (size_t)blockIdx.y * nvox * C;
+        psum += so; psq += so; pmin += so; pmax += so;
+    }
     const int CV = C / VEC;
     const int64_t v0 = (int64_t)blockIdx.x * vox_per_block;
     const int64_t v1 = min(nvox, v0 + vox_per_block);
@@ -211,6 +216,14 @@ __global__ void __launch_bounds__(TPB) gn_finalize(PartTab ta, PartTab tb, int G
     const int Ctot = ta.C + tb.C;
     const int cpg = Ctot / G;
     const int c_first = g * cpg;
+    if (blockIdx.y) {   // sample of a batch: tables [S][nb][C] inside each plane, outputs [S][Ctot] / [S][G]
+        const size_t oa = (size_t)blockIdx.y * ta.nb * ta.C, ob = (size_t)blockIdx.y * tb.nb * tb.C;
+        ta.psum += oa; ta.psq += oa; ta.pmin += oa; ta.pmax += oa;
+        if (tb.C) { tb.psum += ob; tb.psq += ob; tb.pmin += ob; tb.pmax += ob; }
+        scale += (size_t)blockIdx.y * Ctot; shift += (size_t)blockIdx.y * Ctot; bound += (size_t)blockIdx.y * G;
+        if (mean_out) mean_out += (size_t)blockIdx.y * G;
+        if (rstd_out) rstd_out += (size_t)blockIdx.y * G;
+    }
 
     double* chan_s = smem_d;
     double* chan_q = chan_s + cpg;
@@ -313,24 +326,24 @@ int blocks_for(int64_t nvox, int C, int64_t* vpb) {
     return (int)nb;
 }
 
-Plan make_plan(int CA, int CB, int64_t nvoxA, int64_t nvoxB) {
+Plan make_plan(int CA, int CB, int64_t nvoxA, int64_t nvoxB, int S = 1) {
     Plan p{};
-    p.nbA = blocks_for(nvoxA, CA, &p.vpbA);
+    p.nbA = blocks_for(nvoxA, CA, &p.vpbA);                 // blocks per sample: the same split as the one-sample call
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    p.offA_sum = take((size_t)p.nbA * CA * 8); p.offA_sq = take((size_t)p.nbA * CA * 8);
-    p.offA_mn = take((size_t)p.nbA * CA * 4); p.offA_mx = take((size_t)p.nbA * CA * 4);
+    p.offA_sum = take((size_t)S * p.nbA * CA * 8); p.offA_sq = take((size_t)S * p.nbA * CA * 8);
+    p.offA_mn = take((size_t)S * p.nbA * CA * 4); p.offA_mx = take((size_t)S * p.nbA * CA * 4);
     if (CB > 0) {
         p.nbB = blocks_for(nvoxB, CB, &p.vpbB);
-        p.offB_sum = take((size_t)p.nbB * CB * 8); p.offB_sq = take((size_t)p.nbB * CB * 8);
-        p.offB_mn = take((size_t)p.nbB * CB * 4); p.offB_mx = take((size_t)p.nbB * CB * 4);
+        p.offB_sum = take((size_t)S * p.nbB * CB * 8); p.offB_sq = take((size_t)S * p.nbB * CB * 8);
+        p.offB_mn = take((size_t)S * p.nbB * CB * 4); p.offB_mx = take((size_t)S * p.nbB * CB * 4);
     }
     p.total = off;
     return p;
 }
 
 void launch_partial(const float* X, int C, int64_t nvox, int nb, int64_t vpb, RepView rep, char* ws, size_t o_sum,
-                    size_t o_sq, size_t o_mn, size_t o_mx, hipStream_t st) {
+                    size_t o_sq, size_t o_mn, size_t o_mx, hipStream_t st, int S = 1) {
     double* ps = reinterpret_cast<double*>(ws + o_sum);
     double* pq = reinterpret_cast<double*>(ws + o_sq);
     float* pn = reinterpret_cast<float*>(ws + o_mn);
@@ -339,8 +352,8 @@ void launch_partial(const float* X, int C, int64_t nvox, int nb, int64_t vpb, Re
     int CV = vec4 ? C / 4 : C;
     int RP = CV > TPB ? 0 : TPB / CV;
     size_t smem = (size_t)RP * C * 24;
-    if (vec4) hipLaunchKernelGGL(gn_partial<4>, dim3(nb), dim3(TPB), smem, st, X, C, nvox, vpb, rep, ps, pq, pn, px);
-    else hipLaunchKernelGGL(gn_partial<1>, dim3(nb), dim3(TPB), smem, st, X, C, nvox, vpb, rep, ps, pq, pn, px);
+    if (vec4) hipLaunchKernelGGL(gn_partial<4>, dim3(nb, S), dim3(TPB), smem, st, X, C, nvox, vpb, rep, ps, pq, pn, px);
+    else hipLaunchKernelGGL(gn_partial<1>, dim3(nb, S), dim3(TPB), smem, st, X, C, nvox, vpb, rep, ps, pq, pn, px);
 }
 
 }  // namespace
@@ -351,10 +364,38 @@ extern "C" size_t bfm_gn_stats_workspace(int CA, int CB, int D, int H, int W, co
     return make_plan(CA, CB, nvoxA, nvoxB).total;
 }
 
+static int gn_stats_launch(const float* A, int CA, const float* B, int CB, int S, int D, int H, int W,
+                           const bfm_upsample_t* up, const float* gamma, const float* beta, int G, float eps, float* scale,
+                           float* shift, float* bound, float* mean_out, float* rstd_out, void* workspace,
+                           size_t workspace_bytes, bfm_stream_t stream);
+
 extern "C" int bfm_gn_stats_train(const float* A, int CA, const float* B, int CB, int D, int H, int W,
                                   const bfm_upsample_t* up, const float* gamma, const float* beta, int G, float eps,
                                   float* scale, float* shift, float* bound, float* mean_out, float* rstd_out,
                                   void* workspace, size_t workspace_bytes, bfm_stream_t stream) {
+    return gn_stats_launch(A, CA, B, CB, 1, D, H, W, up, gamma, beta, G, eps, scale, shift, bound, mean_out, rstd_out,
+                           workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t bfm_gn_stats_batch_workspace(int CA, int CB, int S, int D, int H, int W, const bfm_upsample_t* up) {
+    int64_t nvoxA = (int64_t)D * H * W;
+    int64_t nvoxB = (CB > 0 && up) ? (int64_t)up->d * up->h * up->w : 0;
+    return make_plan(CA, CB, nvoxA, nvoxB, S < 1 ? 1 : S).total;
+}
+
+extern "C" int bfm_gn_stats_batch(const float* A, int CA, const float* B, int CB, int S, int D, int H, int W,
+                                  const bfm_upsample_t* up, const float* gamma, const float* beta, int G, float eps,
+                                  float* scale, float* shift, float* bound, void* workspace, size_t workspace_bytes,
+                                  bfm_stream_t stream) {
+    if (S < 1 || S > 65535) return BFM_E_ARG;
+    return gn_stats_launch(A, CA, B, CB, S, D, H, W, up, gamma, beta, G, eps, scale, shift, bound, nullptr, nullptr,
+                           workspace, workspace_bytes, stream);
+}
+
+static int gn_stats_launch(const float* A, int CA, const float* B, int CB, int S, int D, int H, int W,
+                           const bfm_upsample_t* up, const float* gamma, const float* beta, int G, float eps, float* scale,
+                           float* shift, float* bound, float* mean_out, float* rstd_out, void* workspace,
+                           size_t workspace_bytes, bfm_stream_t stream) {
     if (!A || CA <= 0 || D <= 0 || H <= 0 || W <= 0 || !gamma || !beta || !scale || !shift || !bound || !workspace)
         return BFM_E_ARG;
     if (CB < 0 || (CB > 0 && (!B || !up || up->d <= 0 || up->h <= 0 || up->w <= 0 || !up->repD || !up->repH ||
@@ -375,23 +416,23 @@ extern "C" int bfm_gn_stats_train(const float* A, int CA, const float* B, int CB
 
     const int64_t nvoxA = (int64_t)D * H * W;
     const int64_t nvoxB = CB > 0 ? (int64_t)up->d * up->h * up->w : 0;
-    Plan p = make_plan(CA, CB, nvoxA, nvoxB);
+    Plan p = make_plan(CA, CB, nvoxA, nvoxB, S);
     if (workspace_bytes < p.total) return BFM_E_WORKSPACE;
     char* ws = static_cast<char*>(workspace);
     hipStream_t st = bfm_s(stream);
 
     RepView none{D, H, W, nullptr, nullptr, nullptr};
-    launch_partial(A, CA, nvoxA, p.nbA, p.vpbA, none, ws, p.offA_sum, p.offA_sq, p.offA_mn, p.offA_mx, st);
+    launch_partial(A, CA, nvoxA, p.nbA, p.vpbA, none, ws, p.offA_sum, p.offA_sq, p.offA_mn, p.offA_mx, st, S);
     PartTab ta{reinterpret_cast<double*>(ws + p.offA_sum), reinterpret_cast<double*>(ws + p.offA_sq),
                reinterpret_cast<float*>(ws + p.offA_mn), reinterpret_cast<float*>(ws + p.offA_mx), p.nbA, CA, 1.0};
     PartTab tb{nullptr, nullptr, nullptr, nullptr, 0, 0, 1.0};
     if (CB > 0) {
         RepView rep{up->d, up->h, up->w, up->repD, up->repH, up->repW};
-        launch_partial(B, CB, nvoxB, p.nbB, p.vpbB, rep, ws, p.offB_sum, p.offB_sq, p.offB_mn, p.offB_mx, st);
+        launch_partial(B, CB, nvoxB, p.nbB, p.vpbB, rep, ws, p.offB_sum, p.offB_sq, p.offB_mn, p.offB_mx, st, S);
         tb = PartTab{reinterpret_cast<double*>(ws + p.offB_sum), reinterpret_cast<double*>(ws + p.offB_sq),
                      reinterpret_cast<float*>(ws + p.offB_mn), reinterpret_cast<float*>(ws + p.offB_mx), p.nbB, CB, 1.0};
     }
-    hipLaunchKernelGGL(gn_finalize, dim3(G), dim3(TPB), fin_smem, st, ta, tb, G, (double)nvoxA, eps, gamma, beta,
+    hipLaunchKernelGGL(gn_finalize, dim3(G, S), dim3(TPB), fin_smem, st, ta, tb, G, (double)nvoxA, eps, gamma, beta,
                        scale, shift, bound, mean_out, rstd_out);
     return bfm_launch_status();
 }
@@ -474,6 +515,32 @@ extern "C" int bfm_gn_stats_rows_train(const void* rowsA, int nrowsA, int CA, co
     if (CB > 0) tb = rows_source(rowsB, nrowsB, CB, weightB, ws + needA, st);
     hipLaunchKernelGGL(gn_finalize, dim3(G), dim3(TPB), fin_smem, st, ta, tb, G, (double)nvox, eps, gamma, beta, scale,
                        shift, bound, mean_out, rstd_out);
+    return bfm_launch_status();
+}
+
+// S same-shape samples: rowsA / rowsB are the tables of batched producers ([S * nrows][C] per plane), every output [S][..]
+extern "C" int bfm_gn_stats_rows_batch(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB,
+                                       double weightB, int64_t nvox, int S, const float* gamma, const float* beta, int G,
+                                       float eps, float* scale, float* shift, float* bound, bfm_stream_t stream) {
+    if (!rowsA || nrowsA <= 0 || CA <= 0 || nvox <= 0 || S < 1 || S > 65535 || !gamma || !beta || !scale || !shift || !bound)
+        return BFM_E_ARG;
+    if (CB < 0 || (CB > 0 && (!rowsB || nrowsB <= 0 || !(weightB > 0.0)))) return BFM_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(rowsA) & 7) || (CB > 0 && (reinterpret_cast<uintptr_t>(rowsB) & 7))) return BFM_E_ARG;
+    if (nrowsA > RR_MAX || (CB > 0 && nrowsB > RR_MAX)) return BFM_E_SHAPE;     // per-sample tables small enough to finalize directly
+    const int Ctot = CA + CB;
+    if (G <= 0 || Ctot % G != 0) return BFM_E_SHAPE;
+    const int cpg = Ctot / G;
+    const size_t fin_smem = (size_t)cpg * 24 + (size_t)TPB * 24;
+    if (fin_smem > 64 * 1024) return BFM_E_SHAPE;
+    RowsView va = rows_view(rowsA, S * nrowsA, CA);
+    PartTab ta{va.sum, va.sq, va.mn, va.mx, nrowsA, CA, 1.0};
+    PartTab tb{nullptr, nullptr, nullptr, nullptr, 0, 0, 1.0};
+    if (CB > 0) {
+        RowsView vb = rows_view(rowsB, S * nrowsB, CB);
+        tb = PartTab{vb.sum, vb.sq, vb.mn, vb.mx, nrowsB, CB, weightB};
+    }
+    hipLaunchKernelGGL(gn_finalize, dim3(G, S), dim3(TPB), fin_smem, bfm_s(stream), ta, tb, G, (double)nvox, eps, gamma,
+                       beta, scale, shift, bound, (float*)nullptr, (float*)nullptr);
     return bfm_launch_status();
 }
 

@@ -356,7 +356,7 @@ class UNetEngine:
             self._plan_cache[key] = cfg
         return self._plan_cache[key]
 
-    def _autotune(self, ly, key, launch):
+    def _autotune(self, ly, key, launch, vers=None):
         """Pick the fastest conv variant (0 conv_mfma, 1 conv_mfma_ws, 2 conv_mfma16, 3 conv_wino) for this
         (Cin, Cout, dims, two-source) by timing them once on the real operands (HIP events on the launch stream).  All variants compute the same result; the chip is
         power-limited on this kernel, so which one wins is shape dependent (profiles/).  BFM_CONV_VER pins one."""
@@ -369,7 +369,7 @@ class UNetEngine:
         gkey = (torch.cuda.current_device(), getattr(self, "passes", None), key)
         if gkey not in _TUNE_CHOICES:
             saved = _tune_lookup(gkey[0], gkey[1], key)         # the persisted table: same bits in every process
-            if saved is not None and not (key[3] and saved in (3, 4, 5)):
+            if saved is not None and not (key[3] and saved in (3, 4, 5)) and (vers is None or saved in vers):
                 _TUNE_CHOICES[gkey] = int(saved)
         if gkey in _TUNE_CHOICES:
             cfg[6] = _TUNE_CHOICES[gkey]
@@ -378,7 +378,7 @@ class UNetEngine:
         best, best_ms = cfg[6], None
         # Winograd (3) takes single-source layers only; its wave-specialised form (4, BFM_CONV_VER=4) has not beaten it
         # on any shape measured so far, so it is not timed here
-        for ver in ((0, 1, 2) if key[3] else (0, 1, 2, 3)):
+        for ver in (vers if vers is not None else ((0, 1, 2) if key[3] else (0, 1, 2, 3))):
             trial = (C.c_int * 8)(*list(cfg))
             trial[6] = ver
             try:
@@ -632,10 +632,11 @@ class UNetEngine:
         self._record(ly, A, B, dims, lo_dims, scale, shift, bound, out)
         return out
 
-    def maxpool(self, X, dims):
+    def maxpool(self, X, dims, out=None):
         D, H, W = dims
         c = X.shape[-1]
-        out = torch.empty((D // 2, H // 2, W // 2, c), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((D // 2, H // 2, W // 2, c), dtype=torch.float32, device=self.device)
         rows = None
         if self.fuse_stats:
             n = self.lib.bfm_maxpool2_rows(c, D, H, W)
@@ -650,9 +651,168 @@ class UNetEngine:
         return out, (D // 2, H // 2, W // 2)
 
     # ------------------------------------------------------------------ backbone
+    # ------------------------------------------------------------------ the deep levels, batched over samples
+    # Levels >= deep_from (20^3 voxels and fewer on a 160^3 tile) are bound by their weights: 253 M of the 264 M
+    # parameters = 1 GB of packed fragments that every tile re-reads for a few thousand voxels.  Tiles of one shape
+    # therefore go through these levels TOGETHER: one launch per layer over S samples (bfm_conv3x3x3_mfma_batch,
+    # bfm_gn_stats*_batch; GroupNorm statistics stay per sample), the weights are read once per batch.  A single
+    # tile takes the same code with S = 1, so that a tile's result does not depend on what it was batched with.
+    deep_from = int(os.environ.get("BFM_DEEP_FROM", "3"))
+    deep_batch = os.environ.get("BFM_DEEP_BATCH", "1") != "0"
+    DEEP_VERS = (0, 2)                                     # conv_mfma, conv_mfma16: the variants that take a batch
+
+    def has_deep_region(self):
+        if not (self.deep_batch and self.tape is None and not self.force_direct and len(self.fm) > self.deep_from >= 1):
+            return False
+        ok = getattr(self, "_deep_ok", None)
+        if ok is None:                                       # every layer of the region must be a matrix-core layer
+            ndeep = len(self.enc) - 1 - self.deep_from
+            layers = [ly for pair in self.enc[self.deep_from:] + self.dec[:ndeep] for ly in pair]
+            ok = self._deep_ok = all(ly.cin % 16 == 0 and ly.cout % 64 == 0 for ly in layers) and \
+                self.enc[self.deep_from - 1][1].cout % 16 == 0
+        return ok
+
+    def _batch_stats(self, ly, A, ca, B, cb, S, dims, lo_dims, upp, scale, shift, bound):
+        """GroupNorm scale / shift / bound [S][..] of cat((A[s], up(B[s]))) for every sample of a batch."""
+        D, H, W = dims
+        st = L.stream_ptr()
+        ra = getattr(A, "_bfm_rows", None) if self.fuse_stats else None
+        rb = getattr(B, "_bfm_rows", None) if (self.fuse_stats and B is not None) else None
+        exact2 = B is None or tuple(dims) == tuple(2 * v for v in lo_dims)
+        if ra is not None and ra[1] <= 128 and (B is None or (rb is not None and exact2 and rb[1] <= 128)):
+            L.check(self.lib.bfm_gn_stats_rows_batch(L.ptr(ra[0]), ra[1], ca, L.ptr(rb[0]) if rb is not None else None,
+                                                     rb[1] if rb is not None else 0, cb, 8.0, D * H * W, S,
+                                                     L.ptr(ly.gamma), L.ptr(ly.beta), ly.groups, self.eps, L.ptr(scale),
+                                                     L.ptr(shift), L.ptr(bound), st), "gn_stats_rows_batch " + ly.name)
+            return
+        need = self.lib.bfm_gn_stats_batch_workspace(ca, cb, S, D, H, W, upp)
+        ws = self._workspace(need)
+        L.check(self.lib.bfm_gn_stats_batch(L.ptr(A), ca, L.ptr(B), cb, S, D, H, W, upp, L.ptr(ly.gamma), L.ptr(ly.beta),
+                                            ly.groups, self.eps, L.ptr(scale), L.ptr(shift), L.ptr(bound), L.ptr(ws),
+                                            ws.numel(), st), "gn_stats_batch " + ly.name)
+
+    def batch_conv(self, ly, A, dims, B=None, lo_dims=None, stats=None):
+        """SingleConv on a batch: A (S,D,H,W,CA), B (S,d,h,w,CB) or None -> (S,D,H,W,Cout).  `stats`: per-sample
+        (scale, shift, bound) already computed (the first layer of the region takes them from the pooling rows)."""
+        S = A.shape[0]
+        D, H, W = dims
+        ca = A.shape[-1]
+        cb = 0 if B is None else B.shape[-1]
+        assert ca + cb == ly.cin, (ly.name, ca, cb, ly.cin)
+        if not self._mfma_ok(ly, ca, cb):
+            raise L.BfmError("%s: the batched levels need channel counts that are multiples of 16 / 64" % ly.name)
+        up = self._upsample_desc(lo_dims, dims) if B is not None else None
+        upp = C.byref(up) if up is not None else None
+        if stats is None:
+            scale = torch.empty((S, ly.cin), dtype=torch.float32, device=self.device)
+            shift = torch.empty((S, ly.cin), dtype=torch.float32, device=self.device)
+            bound = torch.empty((S, ly.groups), dtype=torch.float32, device=self.device)
+            self._batch_stats(ly, A, ca, B, cb, S, dims, lo_dims, upp, scale, shift, bound)
+        else:
+            scale, shift, bound = stats
+        key = (ly.cin, ly.cout, tuple(dims), B is not None, False, 1)       # trailing 1: a layer of the batched levels
+        if key not in self._plan_cache:
+            cfg = (C.c_int * 8)()
+            L.check(self.lib.bfm_conv3x3x3_mfma_plan(ly.cin, ly.cout, D, H, W, cfg), "mfma_plan")
+            if cfg[6] not in self.DEEP_VERS:
+                cfg[6] = 0
+            self._plan_cache[key] = cfg
+        cfg = self._plan_cache[key]
+        out = torch.empty((S, D, H, W, ly.cout), dtype=torch.float32, device=self.device)
+        st = L.stream_ptr()
+
+        def _launch(c, rows=None, A_=A, B_=B, S_=S, out_=out, sc=scale, sh=shift, bd=bound):
+            self._pack(ly, True, c[6])
+            wsb = self.lib.bfm_conv3x3x3_mfma_batch_workspace(ly.cin, ly.cout, S_, D, H, W, c[5])
+            ws = self._workspace(wsb)
+            L.check(self.lib.bfm_conv3x3x3_mfma_batch(L.ptr(A_), ca, L.ptr(B_) if cb else None, cb, S_, D, H, W,
+                                                      upp if cb else None, L.ptr(sc), L.ptr(sh), L.ptr(bd), ly.groups,
+                                                      L.ptr(ly.wpacked), ly.wexp, ly.cout, self.slope, self.passes, c,
+                                                      L.ptr(out_), L.ptr(ws), ws.numel(),
+                                                      L.ptr(rows[0]) if rows is not None else None, st),
+                    "conv_mfma_batch " + ly.name)
+        if key not in self._tuned:
+            # timed on ONE sample (the choice must not depend on the batch size: a tile's bits may not either)
+            cfg = self._autotune(ly, key, lambda c: _launch(c, None, A[0:1], B[0:1] if B is not None else None, 1, out[0:1],
+                                                            scale[0:1], shift[0:1], bound[0:1]), vers=self.DEEP_VERS)
+        self._pack(ly, True, cfg[6])
+        rows = None
+        if self.fuse_stats:
+            n = self.lib.bfm_conv3x3x3_mfma_rows(ly.cin, ly.cout, D, H, W, cfg)
+            if n > 0:
+                rows = (torch.empty(self.lib.bfm_moment_rows_bytes(S * n, ly.cout), dtype=torch.uint8, device=self.device), n)
+        ev = None
+        reps = 1
+        if self.prof is not None:
+            reps = max(1, int(self.prof_reps))
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        for _ in range(reps):
+            _launch(cfg, rows)
+        if ev is not None:
+            ev[1].record()
+            nv = D * H * W
+            lo = 0 if B is None else lo_dims[0] * lo_dims[1] * lo_dims[2]
+            self.prof.append((ev[0], ev[1], 2.0 * 27 * ly.cin * ly.cout * nv * S,
+                              4.0 * (S * (nv * ca + lo * cb + nv * ly.cout) + 27 * ly.cin * ly.cout), reps,
+                              (ly.name.replace("backbone.", "").replace(".basic_module.SingleConv", ".") + ("x%d" % S),
+                               ly.cin, ly.cout, tuple(dims), tuple(cfg))))
+        if rows is not None:
+            out._bfm_rows = rows
+        return out
+
+    def deep_region(self, tops):
+        """tops: [(x, dims)] = the outputs of encoder level deep_from-1 of S same-shape samples (each (D,H,W,C)).
+        Runs encoder levels >= deep_from and the decoders that end at those levels on the whole batch.  Returns
+        (out (S,d,h,w,C) = the decoder output at level deep_from, its dims, [per-level feature batches, deepest first])."""
+        S = len(tops)
+        df = self.deep_from
+        dims0 = tuple(tops[0][1])
+        assert all(tuple(d) == dims0 for _, d in tops)
+        c0 = tops[0][0].shape[-1]
+        d = tuple(v // 2 for v in dims0)
+        if min(dims0) < 2:
+            raise L.BfmError("volume too small for %d pooling levels" % (len(self.enc) - 1))
+        # level deep_from: pool every sample into its slot of the batch; the first layer's statistics come from the
+        # pooling rows of each sample (the same call as the one-sample path)
+        l1, l2 = self.enc[df]
+        P = torch.empty((S,) + d + (c0,), dtype=torch.float32, device=self.device)
+        scale = torch.empty((S, l1.cin), dtype=torch.float32, device=self.device)
+        shift = torch.empty((S, l1.cin), dtype=torch.float32, device=self.device)
+        bound = torch.empty((S, l1.groups), dtype=torch.float32, device=self.device)
+        for s_, (x, dd) in enumerate(tops):
+            ps, _ = self.maxpool(x, dd, out=P[s_])
+            self._gn_stats(l1, ps, c0, None, 0, d, None, None, scale[s_], shift[s_], bound[s_], 0)
+        x = self.batch_conv(l1, P, d, stats=(scale, shift, bound))
+        x = self.batch_conv(l2, x, d)
+        skips = [(x, d)]
+        for i in range(df + 1, len(self.enc)):
+            l1, l2 = self.enc[i]
+            if min(d) < 2:
+                raise L.BfmError("volume too small for %d pooling levels" % (len(self.enc) - 1))
+            d2 = tuple(v // 2 for v in d)
+            P = torch.empty((S,) + d2 + (x.shape[-1],), dtype=torch.float32, device=self.device)
+            for s_ in range(S):
+                self.maxpool(x[s_], d, out=P[s_])
+            d = d2                                           # (statistics of pooled batches are always recomputed from the
+            x = self.batch_conv(l1, P, d)                    # tensor: the per-sample pooling rows are separate tables)
+            x = self.batch_conv(l2, x, d)
+            skips.insert(0, (x, d))
+        feats = [(x, d)]
+        skips = skips[1:]
+        ndeep = len(self.enc) - 1 - df                      # decoders that end at a level >= deep_from
+        for (l1, l2), (skip, sd_) in zip(self.dec[:ndeep], skips):
+            y = self.batch_conv(l1, skip, sd_, B=x, lo_dims=d)
+            x = self.batch_conv(l2, y, sd_)
+            d = sd_
+            feats.append((x, d))
+        return x, d, feats
+
     def backbone_cl(self, x_cl, dims):
         """x_cl: (D,H,W,Cin).  Returns the decoder feature maps as channels-last buffers,
         deepest first, the last one NOT yet L2-normalised (the tail kernel does that)."""
+        if self.has_deep_region():
+            return self.backbone_batch([x_cl], dims)[0]
         skips = []
         x, d = x_cl, tuple(dims)
         for i, (l1, l2) in enumerate(self.enc):
@@ -671,6 +831,43 @@ class UNetEngine:
             d = sd_
             feats.append((x, d))
         return feats
+
+    def encoder_top(self, x_cl, dims):
+        """Encoder levels < deep_from of one sample: ([(skip, dims)] shallowest first, top = last of them)."""
+        skips = []
+        x, d = x_cl, tuple(dims)
+        for i, (l1, l2) in enumerate(self.enc[:self.deep_from]):
+            if i > 0:
+                if min(d) < 2:
+                    raise L.BfmError("volume %s too small for %d pooling levels" % (dims, len(self.enc) - 1))
+                x, d = self.maxpool(x, d)
+            x = self.single_conv(l1, x, d)
+            x = self.single_conv(l2, x, d)
+            skips.append((x, d))
+        return skips
+
+    def decoder_top(self, skips, x, d):
+        """Decoders that end above the batched levels, one sample: x (d) = this sample's slice of the region's output."""
+        ndeep = len(self.enc) - 1 - self.deep_from
+        feats = []
+        for (l1, l2), (skip, sd_) in zip(self.dec[ndeep:], reversed(skips)):
+            y = self.single_conv(l1, skip, sd_, B=x, lo_dims=d)
+            x = self.single_conv(l2, y, sd_)
+            d = sd_
+            feats.append((x, d))
+        return feats
+
+    def backbone_batch(self, xs, dims):
+        """The backbone of S same-shape samples: encoder levels above the region per sample, the region batched, the
+        remaining decoders per sample.  Returns one feature list per sample (deepest first, like backbone_cl)."""
+        tops = [self.encoder_top(x, dims) for x in xs]
+        out, d, deep_feats = self.deep_region([t[-1] for t in tops])
+        res = []
+        for s_, skips in enumerate(tops):
+            feats = [(f[s_], fd) for f, fd in deep_feats]
+            feats += self.decoder_top(skips, out[s_], d)
+            res.append(feats)
+        return res
 
     @staticmethod
     def as_ncdhw(buf):

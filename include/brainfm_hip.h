@@ -132,6 +132,27 @@ int bfm_conv3x3x3_mfma_ex(const float* A, int CA, const float* B, int CB, int D,
                           int G, const void* wpacked, int wexp, int Cout, float slope, int passes, const int* cfg,
                           float* out, void* workspace, size_t workspace_bytes, void* moment_rows /*or NULL*/,
                           bfm_stream_t stream);
+/* A batch of S same-shape samples (the tiles of one volume that share a shape) through ONE launch: A [S][D,H,W,CA],
+ * B [S][d,h,w,CB], out [S][D,H,W,Cout], scale / shift [S][CA+CB], bound [S][G] -- GroupNorm statistics stay per
+ * sample (buildingblocks.py:48-60).  Every workgroup does what it does in the one-sample launch (same box, K order and
+ * split-K), so the result is bit-identical to S calls of bfm_conv3x3x3_mfma_ex; what changes is that the S workgroups
+ * needing the same packed-weight fragments run side by side and read them from HBM once (the deep levels are bound by
+ * their 1 GB of weights per tile).  Plan variants 0 and 2 only; moment_rows: [S * rows][Cout]. */
+size_t bfm_conv3x3x3_mfma_batch_workspace(int Cin, int Cout, int S, int D, int H, int W, int splitk);
+int bfm_conv3x3x3_mfma_batch(const float* A, int CA, const float* B, int CB, int S, int D, int H, int W,
+                             const bfm_upsample_t* up, const float* scale, const float* shift, const float* bound, int G,
+                             const void* wpacked, int wexp, int Cout, float slope, int passes, const int* cfg, float* out,
+                             void* workspace, size_t workspace_bytes, void* moment_rows, bfm_stream_t stream);
+/* GroupNorm statistics of such a batch: per sample exactly bfm_gn_stats / bfm_gn_stats_rows (same block split, same
+ * summation order), outputs [S][C] / [S][G]. */
+size_t bfm_gn_stats_batch_workspace(int CA, int CB, int S, int D, int H, int W, const bfm_upsample_t* up);
+int bfm_gn_stats_batch(const float* A, int CA, const float* B, int CB, int S, int D, int H, int W,
+                       const bfm_upsample_t* up, const float* gamma, const float* beta, int G, float eps, float* scale,
+                       float* shift, float* bound, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+int bfm_gn_stats_rows_batch(const void* rowsA, int nrowsA_per_sample, int CA, const void* rowsB, int nrowsB_per_sample,
+                            int CB, double weightB, int64_t nvox, int S, const float* gamma, const float* beta, int G,
+                            float eps, float* scale, float* shift, float* bound, bfm_stream_t stream);
+
 int bfm_maxpool2_rows(int C, int D, int H, int W);
 int bfm_maxpool2_ex(const float* in, int C, int D, int H, int W, float* out, void* moment_rows /*or NULL*/,
                     bfm_stream_t stream);

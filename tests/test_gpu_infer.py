@@ -852,3 +852,33 @@ def test_config5_generator_feeds_a_training_iteration_at_160():
         assert set(loss_dict) == {"loss_" + n for n in C5.LOSS_NAMES}, loss_dict.keys()
         assert all(np.isfinite(v) for v in loss_dict.values())
     assert not torch.equal(step.eng.dec[-1][1].w_raw, w0)
+
+
+def test_deep_levels_batched_over_tiles_equal_the_single_tile_path_bit_for_bit():
+    """Levels >= 3 of the shipped architecture run over a batch of same-shape tiles (one launch per layer, weights read
+    once; GroupNorm statistics per sample).  Every workgroup does what it does for a single tile, so: (1) a tile's
+    features are bit-identical whether it runs alone (S = 1) or batched with others, in any position of the batch;
+    (2) the batched path agrees with the per-layer path of round 1 (BFM_DEEP_BATCH=0: other conv variants, up-folded
+    dec1.1) to fp32 rounding."""
+    from brainfm_amd.engine import UNetEngine
+    sd = O.random_state_dict(1, 64, 6, seed=3)
+    eng = UNetEngine(sd, in_channels=1, f_maps=64, num_levels=6, device=_dev())
+    assert eng.has_deep_region()
+    g = torch.Generator().manual_seed(9)
+    for dims in ((64, 64, 96), (32, 64, 32)):
+        xs = [torch.rand(dims + (1,), generator=g).to(_dev()) for _ in range(3)]
+        xs[1][: dims[0] // 2] = 0                                   # a half-empty tile: constant input to GroupNorm
+        single = [eng.backbone_cl(x, dims) for x in xs]
+        batch = eng.backbone_batch(xs, dims)
+        rev = eng.backbone_batch(xs[::-1], dims)[::-1]
+        for s_ in range(3):
+            assert len(single[s_]) == len(batch[s_]) == 6
+            for (a, da), (b, db), (c, dc) in zip(single[s_], batch[s_], rev[s_]):
+                assert da == db == dc and torch.equal(a, b) and torch.equal(a, c), (dims, s_, da)
+        eng.deep_batch = False
+        try:
+            old = eng.backbone_cl(xs[0], dims)
+        finally:
+            eng.deep_batch = True
+        for (a, da), (b, db) in zip(single[0], old):
+            assert da == db and _relerr(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5, (dims, da, _relerr(a.cpu().numpy(), b.cpu().numpy()))
