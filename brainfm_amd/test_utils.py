@@ -360,13 +360,15 @@ class InferenceSession:
         return [k for k in STITCH_KEYS if k in names or (k == "label" and tail.desc.n_seg > 0)]
 
     @L.on_device(lambda self, *a, **k: self.device)
-    def graph_tile(self, im, lane=0):
-        """Run one tile through backbone + tail via a captured hipGraph for its shape (one graph, one set of static
-        buffers and one scratch area per lane).  Returns what _run_tile(raw=True) returns; the buffers are static per
-        (shape, lane) and are overwritten by the next replay of the same (or, a lane's pool being shared, any) shape of
-        that lane, so consume them first.  Runs on the current stream."""
-        dims = tuple(im.shape[2:])
-        key = (dims, lane)
+    def graph_group(self, ims, lane=0):
+        """Run S same-shape tiles (one batch: the deep levels go through one launch per layer for all of them) through
+        backbone + tail via a captured hipGraph for (shape, S) -- one graph, one set of static buffers and one scratch
+        area per lane.  Returns what _run_group returns, one (maps_buf, names, label, x_cl) per tile; the buffers are
+        static per (shape, S, lane) and are overwritten by the next replay on that lane, so consume them first.  Runs on
+        the current stream."""
+        dims = tuple(ims[0].shape[2:])
+        S = len(ims)
+        key = (dims, S, lane)
         eng = self.engine
         if eng.weights_epoch != self._graphs_epoch:            # trained in between: graphs hold stale packing exponents
             self._graphs.clear()
@@ -377,12 +379,13 @@ class InferenceSession:
             self._graph_seen.add(key)
             eng.lane = lane
             try:
-                return _run_tile(self, im, raw=True)
+                return _run_group(self, ims)
             finally:
                 eng.lane = 0
         if key not in self._graphs:
-            static_in = torch.empty(tuple(im.shape), dtype=torch.float32, device=self.device)
-            static_in.copy_(im)
+            static_in = torch.empty((S,) + tuple(ims[0].shape[1:]), dtype=torch.float32, device=self.device)
+            for s_, im in enumerate(ims):
+                static_in[s_:s_ + 1].copy_(im)
             if lane not in self._graph_pool:
                 self._graph_pool[lane] = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
@@ -391,17 +394,22 @@ class InferenceSession:
                 # thread_local: a collective still in flight on a communication thread (gloo stages through the host,
                 # RCCL's watchdog polls events) must not invalidate this thread's capture
                 with torch.cuda.graph(g, pool=self._graph_pool[lane], capture_error_mode="thread_local"):
-                    outs = _run_tile(self, static_in, raw=True)
+                    outs = _run_group(self, [static_in[s_:s_ + 1] for s_ in range(S)])
             finally:
                 eng.lane = 0
             self._graphs[key] = (g, static_in, outs)
         g, static_in, outs = self._graphs[key]
-        static_in.copy_(im)
+        for s_, im in enumerate(ims):
+            static_in[s_:s_ + 1].copy_(im)
         g.replay()
         return outs
 
-    def has_graph(self, dims, lane=0):
-        return (tuple(dims), lane) in self._graphs
+    def graph_tile(self, im, lane=0):
+        """graph_group for a single tile."""
+        return self.graph_group([im], lane=lane)[0]
+
+    def has_graph(self, dims, lane=0, S=1):
+        return (tuple(dims), int(S), lane) in self._graphs
 
     @property
     def engine(self):
@@ -495,18 +503,40 @@ def tile_time(rng):
 
 
 def assign_tiles(ranges, world_size):
-    """Longest-processing-time-first assignment of tiles to ranks on the modelled tile cost.  Rank 0 keeps its own
-    tile outputs where the accumulation runs (nothing of it travels), so ties go to rank 0 -- it takes the largest
-    tile, the one whose 16 maps (262 MB for 160^3) would otherwise be the longest transfer at the end of the step --
-    and every peer starts with a handicap for the exposed transfer of its last tile.  Deterministic (every rank
-    computes the same map)."""
-    order = sorted(range(len(ranges)), key=lambda i: (-tile_time(ranges[i]), i))
+    """Tiles -> ranks.  Tiles of one shape are kept together (they run the deep levels as one batch and read the 1 GB of
+    weights once): every shape group is cut into as few chunks as keep a chunk within one rank's share of the modelled
+    work, and the chunks go to the ranks longest-processing-time-first.  Rank 0 keeps its own tile outputs where the
+    accumulation runs (nothing of it travels), so ties go to rank 0 and every peer starts with a handicap for the
+    exposed transfer of its last tiles.  For the reference tiling of 256^3 the 27 tiles form 8 groups of equal work
+    (1 x 160^3, 3 x 2, 3 x 4, 1 x 8 tiles): one group per rank at 8 ranks.  Deterministic (every rank computes the same
+    map).  Returns the owner of every tile."""
+    n = len(ranges)
+    if world_size <= 1:
+        return [0] * n
+    total = sum(tile_cost(r) for r in ranges)                 # chunk sizes by voxels: what a batch costs (the per-tile
+    target = total / float(world_size)                        # overhead of tile_time mostly disappears inside a batch)
+    by = OrderedDict()
+    for i, r in enumerate(ranges):
+        by.setdefault(tuple(b - a for a, b in r), []).append(i)
+    chunks = []
+    for lst in by.values():
+        work = sum(tile_cost(ranges[i]) for i in lst)
+        nc = min(len(lst), max(1, int(-(-work // (target * 1.0001)))))
+        base, extra = divmod(len(lst), nc)
+        pos = 0
+        for c in range(nc):
+            sz = base + (1 if c < extra else 0)
+            chunks.append(lst[pos:pos + sz])
+            pos += sz
+    cost = lambda ch: sum(tile_time(ranges[i]) for i in ch)
+    chunks.sort(key=lambda ch: (-cost(ch), ch[0]))
     load = [0] + [PEER_SEND_VOXELS] * (world_size - 1)
-    owner = [0] * len(ranges)
-    for i in order:
+    owner = [0] * n
+    for ch in chunks:
         r = min(range(world_size), key=lambda k: (load[k], k))
-        owner[i] = r
-        load[r] += tile_time(ranges[i])
+        for i in ch:
+            owner[i] = r
+        load[r] += cost(ch)
     return owner
 
 
@@ -623,18 +653,18 @@ def _tiled_inference_lanes(full_im, session, ranges, shape, stride, win_size):
         offs.append(total)
         total += tile_cost(r) * nkeys
     buf = _exchange_buffer(session, "rows", total, dev)
-    order = sorted(range(len(ranges)), key=lambda i: (-tile_time(ranges[i]), i))
     load = [0] * nl
     main = torch.cuda.current_stream(dev)
     start = torch.cuda.Event()
     start.record(main)                                         # the input is in place, last volume's rows are consumed
     last, keys = {}, None
-    for i in order:
+    for batch in tile_batches(ranges):                         # same-shape tiles together: the deep levels run batched
         k = min(range(nl), key=lambda j: (load[j], j))
-        load[k] += tile_time(ranges[i])
-        (x0, x1), (y0, y1), (z0, z1) = ranges[i]
-        n = tile_cost(ranges[i]) * nkeys
-        keys, _, done = ops.run_tile(full_im[:, :, x0:x1, y0:y1, z0:z1], out=buf[offs[i]:offs[i] + n], lane=k, after=start)
+        load[k] += sum(tile_time(ranges[i]) for i in batch)
+        ims = [full_im[:, :, ranges[i][0][0]:ranges[i][0][1], ranges[i][1][0]:ranges[i][1][1],
+                       ranges[i][2][0]:ranges[i][2][1]] for i in batch]
+        outs = [buf[offs[i]:offs[i] + tile_cost(ranges[i]) * nkeys] for i in batch]
+        keys, _, done = ops.run_group(ims, outs, lane=k, after=start)
         if done is not None:
             last[k] = done
     for ev in last.values():
@@ -659,25 +689,24 @@ def prepare_tile_graphs(full_im, session, stride=[80, 80, 80], win_size=[160, 16
     if world > 1:
         agree_on_conv_variants(session, full_im, ranges, group)
     done = set()
-    for i, rng in enumerate(ranges):
-        dims = tuple(b - a for a, b in rng)
-        if owner[i] != rank or dims in done:
+    mine = [i for i in range(len(ranges)) if owner[i] == rank]
+    for batch in tile_batches(ranges, mine):
+        dims = tuple(b - a for a, b in ranges[batch[0]])
+        if (dims, len(batch)) in done:
             continue
-        done.add(dims)
-        (x0, x1), (y0, y1), (z0, z1) = rng
-        im = full_im[:, :, x0:x1, y0:y1, z0:z1].to(device=session.device, dtype=torch.float32)
+        done.add((dims, len(batch)))
+        ims = [full_im[:, :, ranges[i][0][0]:ranges[i][0][1], ranges[i][1][0]:ranges[i][1][1],
+                       ranges[i][2][0]:ranges[i][2][1]].to(device=session.device, dtype=torch.float32) for i in batch]
         for lane in range(session.lanes):
-            while not session.has_graph(dims, lane):
-                session.graph_tile(im, lane=lane)
+            while not session.has_graph(dims, lane, len(batch)):
+                session.graph_group(ims, lane=lane)
     torch.cuda.synchronize(session.device)
-    return sorted(done)
+    return sorted(done)                                       # [(tile shape, tiles per batch)]
 
 
-def _run_tile(session, im, raw=False):
+def _tile_tail(session, feats, x_cl, dims, raw):
+    """Fused tail (+ the deformed atlas) of one tile whose backbone features are `feats`."""
     eng = session.engine
-    dims = tuple(im.shape[2:])
-    x_cl = eng.to_cl(im)
-    feats = eng.backbone_cl(x_cl, dims)
     tail = session.model.head.tail(eng)
     atlas = getattr(session, "atlas", None)
     if atlas is not None and not {"regx", "regy", "regz"} <= set(tail.map_names):
@@ -700,6 +729,49 @@ def _run_tile(session, im, raw=False):
     return maps, label, x_cl
 
 
+def _run_tile(session, im, raw=False):
+    eng = session.engine
+    dims = tuple(im.shape[2:])
+    x_cl = eng.to_cl(im)
+    return _tile_tail(session, eng.backbone_cl(x_cl, dims), x_cl, dims, raw)
+
+
+def _run_group(session, ims):
+    """S same-shape tiles: the deep levels of the backbone run once over the batch (engine.backbone_batch; a tile's
+    result is bit-identical to its single-tile pass), the rest per tile.  Returns [_run_tile(raw=True) tuples]."""
+    eng = session.engine
+    if len(ims) == 1 or not eng.has_deep_region():
+        return [_run_tile(session, im, raw=True) for im in ims]
+    dims = tuple(ims[0].shape[2:])
+    x_cls = [eng.to_cl(im) for im in ims]
+    feats = eng.backbone_batch(x_cls, dims)
+    return [_tile_tail(session, f, x_cl, dims, True) for f, x_cl in zip(feats, x_cls)]
+
+
+GROUP_MAX = max(1, int(os.environ.get("BFM_GROUP_MAX", "8")))       # most tiles batched through the deep levels at once
+
+
+def tile_batches(ranges, idxs=None, group_max=None):
+    """The tiles `idxs` (default: all) as batches of same-shape tiles, at most `group_max` per batch, of balanced
+    sizes, reference order kept inside a batch; batches sorted by modelled work, largest first.  For the reference
+    tiling of 256^3 this is 8 batches of equal work (1 x 160^3, 3 x 2, 3 x 4, 1 x 8 tiles)."""
+    gm = GROUP_MAX if group_max is None else max(1, int(group_max))
+    by = OrderedDict()
+    for i in (range(len(ranges)) if idxs is None else idxs):
+        by.setdefault(tuple(b - a for a, b in ranges[i]), []).append(i)
+    out = []
+    for lst in by.values():
+        nb = -(-len(lst) // gm)
+        base, extra = divmod(len(lst), nb)
+        pos = 0
+        for b in range(nb):
+            sz = base + (1 if b < extra else 0)
+            out.append(lst[pos:pos + sz])
+            pos += sz
+    out.sort(key=lambda b: (-sum(tile_time(ranges[i]) for i in b), b[0]))
+    return out
+
+
 class HipStitchOps:
     """Device-side pack / accumulate used by the multi-GPU path (HIP kernels, one launch per tile each)."""
 
@@ -714,13 +786,16 @@ class HipStitchOps:
             self._sel[(k, dev)] = torch.arange(k, dtype=torch.int32, device=dev)
         return self._sel[(k, dev)]
 
-    def run_tile(self, im, out=None, lane=None, after=None):
-        """Masked, float typed [K][n] rows of one tile (written into ``out`` when given: the send buffer).
-        lane / after: replay the tile's graph and pack on that lane's stream once event ``after`` (recorded on the
-        caller's stream) has passed; the third return value is then the event to wait for before reading the rows."""
+    def run_group(self, ims, outs=None, lane=None, after=None):
+        """Masked, float typed [K][n] rows of every tile of a same-shape batch (written into ``outs[i]`` when given: the
+        send buffer / stitch slots).  lane / after: replay the batch's graph and pack on that lane's stream once event
+        ``after`` (recorded on the caller's stream) has passed; the third return value is then the event to wait for
+        before reading the rows.  Returns (keys, [rows per tile], event | None)."""
         sess = self.session
-        dims = tuple(im.shape[2:])
-        on_lane = (lane is not None and sess.use_graphs and sess.lanes > 1 and sess.has_graph(dims, lane))
+        dims = tuple(ims[0].shape[2:])
+        S = len(ims)
+        outs = outs if outs is not None else [None] * S
+        on_lane = (lane is not None and sess.use_graphs and sess.lanes > 1 and sess.has_graph(dims, lane, S))
         if on_lane:
             st = sess.lane_streams(sess.lanes)[lane]
             if after is not None:
@@ -728,22 +803,27 @@ class HipStitchOps:
             if lane in self._lane_after:                       # an eager / capture pass of this lane ran on the caller's
                 st.wait_event(self._lane_after.pop(lane))      # stream: its buffers share the lane's graph pool
             with torch.cuda.stream(st):
-                keys, rows = self._tile_rows(sess.graph_tile(im, lane=lane), out)
+                res = [self._tile_rows(o, out) for o, out in zip(sess.graph_group(ims, lane=lane), outs)]
                 done = torch.cuda.Event()
                 done.record(st)
-            return keys, rows, done
+            return res[0][0], [r[1] for r in res], done
         if sess.use_graphs:
             if lane is not None and sess.lanes > 1:
                 torch.cuda.synchronize(sess.device)            # eager / capture passes run alone (warm-up only)
-            outs = sess.graph_tile(im, lane=lane or 0)
+            tiles = sess.graph_group(ims, lane=lane or 0)
         else:
-            outs = _run_tile(sess, im, raw=True)
-        keys, rows = self._tile_rows(outs, out)
+            tiles = _run_group(sess, ims)
+        res = [self._tile_rows(o, out) for o, out in zip(tiles, outs)]
         if lane is not None and sess.use_graphs and sess.lanes > 1:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(sess.device))
             self._lane_after[lane] = ev
-        return (keys, rows, None) if lane is not None else (keys, rows)
+        return res[0][0], [r[1] for r in res], None
+
+    def run_tile(self, im, out=None, lane=None, after=None):
+        """run_group for one tile: (keys, rows[, event])."""
+        keys, rows, done = self.run_group([im], [out], lane=lane, after=after)
+        return (keys, rows[0], done) if lane is not None else (keys, rows[0])
 
     def _tile_rows(self, outs, out):
         maps_buf, names, label, x_cl = outs
@@ -867,21 +947,22 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
         nkeys = len(session.stitch_keys())
     if nkeys is None:
         nkeys = len(STITCH_KEYS)
-    # per rank: its tiles, largest first (ties in reference order); slot[i] = (round, offset in that round's buffer).
-    # Rank 0's own tiles never travel: they are packed into a private buffer per round, and the round's (padded) size
-    # is set by the peers alone.
-    tiles_of = [sorted([i for i in range(len(ranges)) if owner[i] == r], key=lambda i: (-tile_cost(ranges[i]), i))
-                for r in range(world)]
-    nrounds = max(len(t) for t in tiles_of) if rounds else 1
+    # per rank: its tiles as batches of same-shape tiles (tile_batches: the deep levels of a batch run as one launch per
+    # layer), largest batch first; slot[i] = (round, offset in that round's buffer) with round k = the k-th batch of
+    # every rank.  Rank 0's own tiles never travel: they are packed into a private buffer per round, and the round's
+    # (padded) size is set by the peers alone.
+    batches_of = [tile_batches(ranges, [i for i in range(len(ranges)) if owner[i] == r]) for r in range(world)]
+    nrounds = max([len(b) for b in batches_of] + [1]) if rounds else 1
     round_of, off_of = {}, {}
     round_numel = [1] * nrounds
     own_numel = [1] * nrounds
     for r in range(world):
         fill = [0] * nrounds
-        for k, i in enumerate(tiles_of[r]):
+        for k, batch in enumerate(batches_of[r]):
             kk = k if rounds else 0
-            round_of[i], off_of[i] = kk, fill[kk]
-            fill[kk] += tile_cost(ranges[i]) * nkeys
+            for i in batch:
+                round_of[i], off_of[i] = kk, fill[kk]
+                fill[kk] += tile_cost(ranges[i]) * nkeys
         for kk in range(nrounds):
             if r == 0:
                 own_numel[kk] = max(own_numel[kk], fill[kk])
@@ -897,47 +978,49 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
         agree_on_conv_variants(session, full_im, ranges, group)
     keys = None
     works, gathered, own, pending = [], [], [], []
-    mine = tiles_of[rank]
+    mine = batches_of[rank]
     lanes = session.lanes if (direct and session is not None and session.use_graphs and dev.type == "cuda") else 1
     start = None
     if lanes > 1:
         start = torch.cuda.Event()
         start.record(torch.cuda.current_stream(dev))           # send buffers are free, the input is in place
-    lane_load = [0] * lanes                                    # this rank's tiles go to its less loaded lane
+    lane_load = [0] * lanes                                    # this rank's batches go to its less loaded lane
     for kk in range(nrounds):
         sbuf = _buf("send%d" % kk, round_numel[kk])            # on rank 0: the padding the gather asks of its root
         dst = sbuf
         if rank == 0:
             dst = _buf("own%d" % kk, own_numel[kk])
             own.append(dst)
-        todo = [i for i in mine if round_of[i] == kk]
-        for i in todo:
-            (x0, x1), (y0, y1), (z0, z1) = ranges[i]
-            im = full_im[:, :, x0:x1, y0:y1, z0:z1]
-            n = tile_cost(ranges[i]) * nkeys
+        todo = [b_ for k, b_ in enumerate(mine) if (k if rounds else 0) == kk]
+        for batch in todo:
+            ims = [full_im[:, :, ranges[i][0][0]:ranges[i][0][1], ranges[i][1][0]:ranges[i][1][1],
+                           ranges[i][2][0]:ranges[i][2][1]] for i in batch]
+            outs = [dst[off_of[i]:off_of[i] + tile_cost(ranges[i]) * nkeys] for i in batch]
             lane = min(range(lanes), key=lambda j: (lane_load[j], j))
-            lane_load[lane] += tile_time(ranges[i])
+            lane_load[lane] += sum(tile_time(ranges[i]) for i in batch)
             if direct and session is not None and session.use_graphs and \
-                    not session.has_graph((x1 - x0, y1 - y0, z1 - z0), lane):
+                    not session.has_graph(tuple(ims[0].shape[2:]), lane, len(batch)):
                 for w in works:                                    # warm-up only: no transfer in flight while a graph
                     w.wait()                                       # is being captured
             if direct and lanes > 1:
-                # this rank's tiles run on its lanes' streams, independently of each other; the gather of a round waits for
-                # that round's tiles only -- and on rank 0 for none: its receives are posted at once, whatever it is
+                # this rank's batches run on its lanes' streams, independently of each other; the gather of a round waits
+                # for that round's tiles only -- and on rank 0 for none: its receives are posted at once, whatever it is
                 # still computing itself
-                keys, _, done = ops.run_tile(im, out=dst[off_of[i]:off_of[i] + n], lane=lane, after=start)
+                keys, _, done = ops.run_group(ims, outs, lane=lane, after=start)
                 if done is not None:
                     if rank == 0:
                         pending.append(done)
                     else:
                         torch.cuda.current_stream(dev).wait_event(done)
             elif direct:
-                keys, _ = ops.run_tile(im, out=dst[off_of[i]:off_of[i] + n])
+                keys, _, _ = ops.run_group(ims, outs)
             else:
-                keys, rows = ops.run_tile(im)
-                if len(keys) != nkeys:
-                    raise RuntimeError("ops.run_tile returned %d maps, expected %d" % (len(keys), nkeys))
-                dst[off_of[i]:off_of[i] + n] = rows.reshape(-1)
+                for i, im in zip(batch, ims):
+                    keys, rows = ops.run_tile(im)
+                    if len(keys) != nkeys:
+                        raise RuntimeError("ops.run_tile returned %d maps, expected %d" % (len(keys), nkeys))
+                    n = tile_cost(ranges[i]) * nkeys
+                    dst[off_of[i]:off_of[i] + n] = rows.reshape(-1)
         g = [_buf("recv%d_%d" % (kk, r), round_numel[kk]) for r in range(world)] if rank == 0 else None
         gathered.append(g)
         works.append(dist.gather(sbuf, g, dst=0, group=group, async_op=True))

@@ -94,14 +94,23 @@ def test_lpt_assignment_balances_tiles():
         owner = TU.assign_tiles(ranges, world)
         assert sorted(set(owner)) == list(range(world))
         assert sum(TU.tile_cost(r) for r in ranges) == 32768000
-        cost = [sum(TU.tile_time(r) for r, o in zip(ranges, owner) if o == k) for k in range(world)]
-        # modelled cost (voxels + per-tile overhead) within 15 % of the mean, or bounded by the one 160^3 tile
-        assert max(cost) <= max(TU.tile_time(((0, 160),) * 3) + TU.tile_time(((0, 80),) * 3), 1.15 * sum(cost) / world)
-        big = max(range(len(ranges)), key=lambda i: TU.tile_cost(ranges[i]))
-        assert owner[big] == 0                                # the largest tile's maps never travel: rank 0 computes it
-        if world > 1:
-            assert max(cost) <= 1.07 * sum(cost) / world
+        vox = [sum(TU.tile_cost(r) for r, o in zip(ranges, owner) if o == k) for k in range(world)]
+        assert max(vox) == min(vox) == 32768000 // world     # the 8 shape groups carry 4 096 000 tile voxels each
+        # tiles of one shape stay together as far as the balance allows: at 8 ranks every rank holds ONE shape group
+        # (its deep levels run as one batch, the weights are read once per rank)
+        shapes_of = [{tuple(b - a for a, b in r) for r, o in zip(ranges, owner) if o == k} for k in range(world)]
+        assert all(len(s_) == 8 // world for s_ in shapes_of), shapes_of
     assert TU.assign_tiles(ranges, 8) == TU.assign_tiles(ranges, 8)
+    # batches: same shape, at most BFM_GROUP_MAX tiles, every tile exactly once, largest work first
+    b = TU.tile_batches(ranges)
+    assert sorted(i for x in b for i in x) == list(range(27)) and [len(x) for x in b] == [8, 4, 4, 4, 2, 2, 2, 1]
+    big = TU.tiling_ranges((512,) * 3, [80] * 3, [160] * 3)
+    bb = TU.tile_batches(big)
+    assert sorted(i for x in bb for i in x) == list(range(216)) and max(len(x) for x in bb) <= TU.GROUP_MAX
+    assert all(len({tuple(q - p for p, q in big[i]) for i in x}) == 1 for x in bb)
+    own = TU.assign_tiles(big, 8)
+    cost = [sum(TU.tile_time(r) for r, o in zip(big, own) if o == k) for k in range(8)]
+    assert max(cost) <= 1.25 * sum(cost) / 8, cost
 
 
 def test_default_args_and_process_args():
