@@ -567,7 +567,7 @@ def tiled_inference(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 1
     shape = tuple(full_im.shape[2:])
     ranges = tiling_ranges(shape, stride, win_size)
     nl = session.lanes if graphs else 1
-    if nl > 1 and GATHER_STITCH:
+    if graphs and GATHER_STITCH:                               # batches of same-shape tiles on the lanes' streams
         prev = session.use_graphs                              # graphs=True asked for replay whatever the session's default
         session.use_graphs = True
         try:
@@ -795,7 +795,7 @@ class HipStitchOps:
         dims = tuple(ims[0].shape[2:])
         S = len(ims)
         outs = outs if outs is not None else [None] * S
-        on_lane = (lane is not None and sess.use_graphs and sess.lanes > 1 and sess.has_graph(dims, lane, S))
+        on_lane = (lane is not None and sess.use_graphs and sess.has_graph(dims, lane, S))
         if on_lane:
             st = sess.lane_streams(sess.lanes)[lane]
             if after is not None:
@@ -808,13 +808,13 @@ class HipStitchOps:
                 done.record(st)
             return res[0][0], [r[1] for r in res], done
         if sess.use_graphs:
-            if lane is not None and sess.lanes > 1:
+            if lane is not None:
                 torch.cuda.synchronize(sess.device)            # eager / capture passes run alone (warm-up only)
             tiles = sess.graph_group(ims, lane=lane or 0)
         else:
             tiles = _run_group(sess, ims)
         res = [self._tile_rows(o, out) for o, out in zip(tiles, outs)]
-        if lane is not None and sess.use_graphs and sess.lanes > 1:
+        if lane is not None and sess.use_graphs:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(sess.device))
             self._lane_after[lane] = ev
