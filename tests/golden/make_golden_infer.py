@@ -216,8 +216,68 @@ def tiled():
     print("infer_tiled", len(im_list), "tiles", keys)
 
 
+@torch.no_grad()
+def wide():
+    """The full pipeline of the reference on a 64-wide, 2-level net -- every conv except the stem is a matrix-core layer
+    in the build (Winograd, up-folded decoder conv, split-fp16 MFMA), so this pins THOSE kernels to the reference itself
+    (labels included), not only to the oracle: single-volume outputs (all heads, int64 labels, features) and the tiled
+    flow of scripts/demo_test.py:66-119 with the 17 stitched keys."""
+    tiling, get_deformed_atlas = load_ref_functions(R + "/utils/test_utils.py", ["tiling", "get_deformed_atlas"])
+    from Generator.utils import fast_3D_interp_torch
+    gen_args, train_args, model, processors, post = build(64, 2, seed=13)
+    torch.manual_seed(6)
+    x = torch.rand(1, 1, 24, 20, 28)
+    x[:, :, :, :3] = 0
+    o = run(gen_args, train_args, model, processors, post, x)
+    d = np_sd(model.state_dict())
+    d["x"] = x.numpy()
+    for i, f in enumerate(o["feat"]):
+        d["feat%d" % i] = f.numpy()
+    for k, v in o.items():
+        if k != "feat":
+            d["out/" + k] = v.numpy()
+    d["cfg"] = np.array([64, 2, 8, 12, 24])               # f_maps, num_levels, num_groups, stride, win
+    # tiled flow with the deformed atlas
+    D, H, W = 40, 36, 44
+    zz, yy, xx = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(W), indexing="ij")
+    ell = (((zz - D / 2 + .5) / 17.) ** 2 + ((yy - H / 2 + .5) / 15.) ** 2 + ((xx - W / 2 + .5) / 19.) ** 2) <= 1
+    full = torch.rand(1, 1, D, H, W) * ell[None, None]
+    ai, aj, ak = torch.meshgrid(torch.arange(26.), torch.arange(30.), torch.arange(22.), indexing="ij")
+    atlas = 100. + 60. * torch.sin(ai / 3.1) * torch.cos(aj / 4.3) + 40. * torch.sin(ak / 2.7 + 0.5)
+    c, s_ = np.cos(0.3), np.sin(0.3)
+    aff2 = np.array([[-9. * c, 9. * s_, 0., 110.], [0., 0., 8., -95.], [-9. * s_, -9. * c, 0., 120.], [0., 0., 0., 1.]])
+    get_deformed_atlas.__globals__.update(MNI=atlas.to(torch.float32), fast_3D_interp_torch=fast_3D_interp_torch,
+                                          A=torch.tensor(np.linalg.inv(aff2), dtype=torch.float32))
+    im_list, cnt = tiling(full, stride=[12, 12, 12], win_size=[24, 24, 24])
+    keys, acc = None, {}
+    for im, rng in im_list:
+        o = run(gen_args, train_args, model, processors, post, im.clone())
+        mask = im.clone()
+        mask[im != 0.] = 1.
+        o["deformed_atlas"] = get_deformed_atlas(torch.squeeze(mask), torch.squeeze(o["regx"]), torch.squeeze(o["regy"]),
+                                                 torch.squeeze(o["regz"]))
+        if keys is None:
+            keys = [k for k in o if "feat" not in k and "segmentation" not in k]
+            acc = {k: torch.zeros_like(torch.squeeze(full)) for k in keys}
+        (x0, x1), (y0, y1), (z0, z1) = rng
+        for k in keys:
+            v = torch.squeeze(o[k] * mask)
+            if "label" in k:
+                v = v.to(torch.int)
+            acc[k][x0:x1, y0:y1, z0:z1] += v
+    d["full"] = full.numpy()
+    d["cnt"] = cnt.numpy()
+    d["atlas"] = atlas.numpy()
+    d["atlas_aff"] = aff2
+    for k in keys:
+        d["stitched/" + k] = (acc[k] / cnt).numpy()
+    np.savez_compressed(os.path.join(HERE, "infer_wide.npz"), **d)
+    print("infer_wide", len(im_list), "tiles", keys, os.path.getsize(os.path.join(HERE, "infer_wide.npz")), "bytes")
+
+
 if __name__ == "__main__":
     small()
     layers()
     tiled()
+    wide()
     print("sizes:", {f: os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz")})

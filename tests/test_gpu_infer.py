@@ -882,3 +882,38 @@ def test_deep_levels_batched_over_tiles_equal_the_single_tile_path_bit_for_bit()
             eng.deep_batch = True
         for (a, da), (b, db) in zip(single[0], old):
             assert da == db and _relerr(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5, (dims, da, _relerr(a.cpu().numpy(), b.cpu().numpy()))
+
+
+def test_matrix_core_path_vs_reference_golden_64_wide():
+    """infer_wide.npz: the reference's own outputs for a 64-wide 2-level net.  Every conv of this net except the stem
+    runs on the matrix-core kernels here (Winograd, split-fp16 MFMA, the up-folded decoder conv), so this is the test
+    that pins THOSE kernels -- not only conv_direct, which the 8-wide goldens exercise -- to the reference itself:
+    float outputs within the north-star tolerance, int64 labels bit-identical, and the 17 stitched keys of the tiled
+    flow (eager per tile, and hipGraph replay of batches on two lanes)."""
+    from brainfm_amd import test_utils as TU
+    d = load_npz("infer_wide.npz")
+    f_maps, levels, groups, stride, win = [int(v) for v in d["cfg"]]
+    s = _session(d, f_maps=f_maps, levels=levels)
+    x = torch.from_numpy(d["x"]).to(_dev())
+    out, _ = s.forward_fused(x)
+    kinds = [ly.kind for blk in s.engine.enc + s.engine.dec for ly in blk]
+    assert kinds.count("mfma") >= 4, kinds                       # dec0.1 runs as up-folded + skip layers (kind None)
+    used = {v for k, v in s.engine.conv_choices().items()}
+    for i, f in enumerate(out["feat"]):
+        assert _relerr(f.cpu().numpy(), d["feat%d" % i]) <= TOL_NET, i
+    _cmp_outputs(out, d)                                         # labels: exact equality with the reference's int64 map
+    s.set_atlas(d["atlas"], d["atlas_aff"])
+    full = torch.from_numpy(d["full"]).to(_dev())
+    keys = [k[9:] for k in d if k.startswith("stitched/")]
+    ref_lab = d["stitched/label"]
+    for graphs in (False, True, True, True):
+        acc, _, cnt = TU.tiled_inference(full, s, [stride] * 3, [win] * 3, graphs=graphs)
+        assert list(acc.keys()) == keys and np.array_equal(cnt.cpu().numpy(), d["cnt"])
+        assert np.array_equal(acc["label"].cpu().numpy(), ref_lab), (graphs, int((acc["label"].cpu().numpy() != ref_lab).sum()))
+        for k in keys:
+            a, b = acc[k].cpu().numpy(), d["stitched/" + k]
+            if k == "deformed_atlas":
+                assert (np.abs(a - b) > TOL_NET * np.abs(b).max()).mean() <= 1e-4, (k, graphs)
+            else:
+                assert _relerr(a, b) <= TOL_NET, (k, _relerr(a, b), graphs)
+    print("conv variants used on the 64-wide golden net:", sorted(used))

@@ -96,3 +96,26 @@ def test_tiled_stitch_toy():
     assert len(keys) == 17 and keys[-1] == "deformed_atlas" and list(out.keys()) == keys    # scripts/demo_test.py:107-119
     for k in keys:
         _close(out[k].numpy(), d["stitched/" + k], 5e-5)
+
+
+def test_wide_net_all_outputs_and_tiled_stitch():
+    """The 64-wide 2-level net of infer_wide.npz (the fixture that pins the build's matrix-core kernels to the reference):
+    the oracle reproduces the reference's single-volume outputs, labels included, and the 17 stitched keys."""
+    d = load_npz("infer_wide.npz")
+    f_maps, levels, groups, stride, win = [int(v) for v in d["cfg"]]
+    sd = sd_from_npz(d)
+    out = O.forward_all(torch.from_numpy(d["x"]), sd, f_maps=f_maps, num_levels=levels, num_groups=groups)
+    for i, f in enumerate(out["feat"]):
+        _close(f.numpy(), d["feat%d" % i])
+    for k in [k[4:] for k in d if k.startswith("out/")]:
+        if k == "label":
+            assert np.array_equal(out[k].numpy(), d["out/label"])
+        else:
+            _close(out[k].numpy(), d["out/" + k])
+    st, ranges, cnt = O.tiled_inference(torch.from_numpy(d["full"]), sd, [stride] * 3, [win] * 3,
+                                        atlas=(d["atlas"], d["atlas_aff"]), f_maps=f_maps, num_levels=levels,
+                                        num_groups=groups)
+    keys = [k[9:] for k in d if k.startswith("stitched/")]
+    assert len(keys) == 17 and list(st.keys()) == keys
+    for k in keys:
+        _close(st[k].numpy(), d["stitched/" + k], 5e-5)
