@@ -258,7 +258,7 @@ def main():
     def step():
         if use_dist:
             return TU.tiled_inference_distributed(full, sess, stride, win)
-        return TU.tiled_inference(full, sess, stride, win)
+        return TU.tiled_inference(full, sess, stride, win, batched=True)     # eager (--no-graphs) runs the same batches
 
     # setup (untimed, once per session): tune the conv variants and capture one hipGraph per tile shape
     if sess.use_graphs:

@@ -555,21 +555,25 @@ def _stitch_tile(lib, acc, keys, maps, label, x_cl, rng, shape):
 
 @torch.no_grad()
 @L.on_device(lambda full_im, session, *a, **k: session.device)
-def tiled_inference(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 160], graphs=None):
+def tiled_inference(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 160], graphs=None, batched=None):
     """scripts/demo_test.py:66-119 on the device: per tile infer -> mask -> accumulate; then /cnt.
     full_im: (1,1,D,H,W) on the session's device.  Returns ({key: (D,H,W) fp32}, ranges, cnt).
-    graphs: replay a captured hipGraph per tile shape (default: session.use_graphs); same kernels, same results."""
+    graphs: replay a captured hipGraph per batch of same-shape tiles (default: session.use_graphs); same kernels, same
+    results.  batched (default: = graphs): tiles of one shape go through the deep levels together and the stitch is one
+    launch; False = the reference's loop, tile by tile, `full[range] +=` in its order.  Same bits either way."""
     if graphs is None:
         graphs = session.use_graphs
+    if batched is None:
+        batched = graphs
     lib = L.load()
     eng = session.engine
     full_im = full_im.to(device=eng.device, dtype=torch.float32)
     shape = tuple(full_im.shape[2:])
     ranges = tiling_ranges(shape, stride, win_size)
     nl = session.lanes if graphs else 1
-    if graphs and GATHER_STITCH:                               # batches of same-shape tiles on the lanes' streams
+    if batched and GATHER_STITCH:                              # batches of same-shape tiles on the lanes' streams
         prev = session.use_graphs                              # graphs=True asked for replay whatever the session's default
-        session.use_graphs = True
+        session.use_graphs = bool(graphs)
         try:
             return _tiled_inference_lanes(full_im, session, ranges, shape, stride, win_size)
         finally:

@@ -1,7 +1,7 @@
 """HBM traffic of the conv kernels of one bench step from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate
 passes as MI355X_MICROARCH.md prescribes: the TCC block cannot hold both).  Units: KB per dispatch; on gfx950
 FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled here.  Only the dispatches of the LAST step
-(after the last run of count_add_kernel launches, which open a step) are kept.
+(between the last two step-closing stitch kernels) are kept.
 usage: python scripts/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
 import csv
 import json
@@ -9,13 +9,14 @@ import sys
 
 
 def last_step(path, counter):
+    """Dispatches of the LAST step: after the stitch kernel that closed the step before it (stitch_gather_kernel runs once
+    per volume in the batched flow; the tile-by-tile flow ends a volume with divide_multi_kernel)."""
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    last = max(i for i, r in enumerate(rows) if "count_add_kernel" in r["Kernel_Name"])
-    first = last
-    while first > 0 and "count_add_kernel" in rows[first - 1]["Kernel_Name"]:
-        first -= 1
-    return rows[first:]
+    ends = [i for i, r in enumerate(rows) if "stitch_gather_kernel" in r["Kernel_Name"] or "divide_multi_kernel" in r["Kernel_Name"]]
+    if len(ends) < 2:
+        raise SystemExit("need at least two steps in the trace (found %d step-closing kernels)" % len(ends))
+    return rows[ends[-2] + 1:ends[-1] + 1]
 
 
 def family(name):
