@@ -417,3 +417,19 @@ def test_volio_reads_the_reference_atlas_file():
     assert MNI.dtype == np.float32 and MNI.shape == (256, 256, 256)
     assert np.array_equal(A, np.linalg.inv(d["affine"]).astype(np.float32))
     TU.MNI, TU.A, TU.atlas_path = None, None, None
+
+
+def test_bench_gpus_flag_launches_ranks_or_refuses():
+    """`python bench.py --gpus N` without a launcher must start N ranks itself -- or fail loudly when the box has fewer
+    than N devices -- instead of silently running one rank and printing n_gpus: 1 (round-1 defect).  No GPU here: the
+    refusal path is what can run; the spawn path is exercised on the GPU box (BFM_BENCH_SHARE_GPU=1 dry runs)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BFM_BENCH_SHARE_GPU")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices present: the spawn path would run the benchmark")
+    assert r.returncode == 2, (r.returncode, r.stderr[-400:])
+    assert "--gpus 2 but only" in r.stderr and '"metric"' not in r.stdout
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "launch_ranks(args.gpus" in src and "os.exec" not in src          # children are spawned, nothing is re-executed
