@@ -94,7 +94,7 @@ def host_cpu_info():
     return info
 
 
-def cpu_baseline(state_dict, full, n, ranges, full_protocol=False):
+def cpu_baseline(state_dict, full, n, ranges, full_protocol=False, sess=None):
     """The CPU oracle (oracle/unet_ref.py: a torch-CPU fp32 port of the reference's path) timed on this host, rank 0
     only, the way BASELINE.md section 4 / SURVEY 8(d) set it: threads = the physical cores of one socket, per tile
     shape of the reference tiling 1 warm-up + 3 timed runs (median), and the whole volume's time extrapolated from
@@ -116,6 +116,7 @@ def cpu_baseline(state_dict, full, n, ranges, full_protocol=False):
         shapes[s][0] += 1
     order = sorted(shapes, key=lambda s: s[0] * s[1] * s[2])
     per_shape, total_s, spent = {}, 0.0, 0.0
+    parity = None
     try:
         for idx, s in enumerate(order):
             cnt, r = shapes[s]
@@ -128,8 +129,10 @@ def cpu_baseline(state_dict, full, n, ranges, full_protocol=False):
                     O.forward_all(tile, sd, f_maps=64, num_levels=6)                    # warm-up
                 for _ in range(3 if small else 1):
                     t0 = time.perf_counter()
-                    O.forward_all(tile, sd, f_maps=64, num_levels=6)
+                    ref = O.forward_all(tile, sd, f_maps=64, num_levels=6)
                     runs.append(time.perf_counter() - t0)
+                if idx == 0 and sess is not None:
+                    parity = label_parity(sess, tile, ref, sd)
             med = float(np.median(runs))
             spent += sum(runs) * (4.0 / 3.0 if small else 1.0)
             per_shape["x".join(map(str, s))] = {"tiles": cnt, "median_s": med, "runs": len(runs),
@@ -137,7 +140,7 @@ def cpu_baseline(state_dict, full, n, ranges, full_protocol=False):
             total_s += cnt * med
     finally:
         torch.set_num_threads(prev)
-    return {"value": n ** 3 / total_s, "unit": "voxels/s", "cores": int(threads), "kind": "port",
+    return {"value": n ** 3 / total_s, "unit": "voxels/s", "cores": int(threads), "kind": "port", "label_parity": parity,
             "cpu_model": info["model"], "sockets": info["sockets"], "cores_per_socket": info["cores_per_socket"],
             "hardware_threads": info["threads"], "per_tile_shape": per_shape,
             "extrapolated_volume_s": total_s,
@@ -146,6 +149,35 @@ def cpu_baseline(state_dict, full, n, ranges, full_protocol=False):
                       "value = %d^3 voxels / sum(count x median) = EXTRAPOLATED whole-volume time %.1f s, not a timed "
                       "27-tile run; %.0f s of CPU work on %d threads (physical cores of one socket)"
                       % (", ".join(per_shape), n, total_s, spent, int(threads))}
+
+
+def label_parity(sess, tile, ref, sd):
+    """The HIP path's labels on the tile the CPU baseline just evaluated, against that fp32 oracle result: number of
+    differing voxels, and -- when there are any -- the relative gap of the two best class probabilities at those voxels
+    in a float64 evaluation of the same network (a difference there is a tie fp32 cannot resolve)."""
+    from oracle import unet_ref as O
+    dev = sess.device
+    out, _ = sess.forward_fused(tile.to(dev), want_feat=False, want_seg=False)
+    lab = out["label"].cpu()
+    differ = lab != ref["label"]
+    nd = int(differ.sum())
+    res = {"tile": list(tile.shape[2:]), "n_voxels": int(lab.numel()), "label_flips_vs_fp32_oracle": nd,
+           "max_fp64_gap": None, "oracle_flips_vs_fp64": None, "hip_flips_vs_fp64": None}
+    worst = 0.0
+    for k, v in ref.items():
+        if k in out and k not in ("feat", "label", "segmentation"):
+            a, b = out[k].cpu().double(), v.double()
+            worst = max(worst, float((a - b).abs().max() / max(1e-6, float(b.abs().max()))))
+    res["max_rel_err_float_maps"] = worst
+    if nd:
+        with torch.no_grad():
+            r64 = O.forward_all(tile.double(), {k: v.double() for k, v in sd.items()}, f_maps=64, num_levels=6)
+        top2 = torch.topk(r64["segmentation"], 2, dim=1).values
+        gap = ((top2[:, 0] - top2[:, 1]) / top2[:, 0])[:, None]
+        res["max_fp64_gap"] = float(gap[differ].max())
+        res["oracle_flips_vs_fp64"] = int((ref["label"] != r64["label"]).sum())
+        res["hip_flips_vs_fp64"] = int((lab != r64["label"]).sum())
+    return res
 
 
 def launch_ranks(n, argv):
@@ -421,7 +453,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             sd = {k: v for k, v in sess.model.state_dict().items()}
-            line["cpu_baseline"] = cpu_baseline(sd, full, n, ranges, args.cpu_baseline_full)
+            line["cpu_baseline"] = cpu_baseline(sd, full, n, ranges, args.cpu_baseline_full, sess)
+            line["label_parity"] = line["cpu_baseline"].pop("label_parity")
         else:
             line["cpu_baseline"] = None
         try:                                                  # librccl's version banner sits in the C stdio buffer and
