@@ -65,7 +65,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 // head GEMM runs as three v_mfma_f32_32x32x16_f16 passes on hi/lo halves (a_lo*w_hi + a_hi*w_lo + a_hi*w_hi, fp32
 // accumulate: ~2^-22 relative per product, the same scheme as conv_mfma) -- 5x fewer matrix-core cycles than the
 // fp32 MFMA chain, which is kept for unnormalised features whose range is unknown.
-template <bool SPLIT>
+// NS > 0: the segmentation head has exactly NS channels and the heads fill NNB 32-wide column blocks -- compile-time
+// bounds for the softmax / argmax and MFMA loops of the shipped head sets (56 and 18 classes); NS = 0: runtime bounds
+// (any head set; every s < n_seg test is then a scalar branch).
+template <bool SPLIT, int NS = 0, int NNB = 0>
 __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int wexp) {
     extern __shared__ float smem[];                 // [WPB][64][ld] logits, then the per-head tables
     int* s_role = reinterpret_cast<int*>(smem + WPB * 64 * ld);        // [OMAX]
@@ -79,7 +82,7 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l32 = lane & 31, lh = lane >> 5;
     const int half = C >> 1;                        // channels per lane (K of the MFMA chain per half)
-    const int nnb = (NO + 31) >> 5;                 // 32-wide output column blocks
+    const int nnb = NNB > 0 ? NNB : (NO + 31) >> 5; // 32-wide output column blocks
 
     // ---- head weights as B fragments.  fp32 chain: B[k = lh][n = l32] of step kk, block nb = W[nb*32+l32][lh*half+kk];
     // split: k-step ks (16 wide), lane slot 8*lh + j  <->  channel lh*half + 8*ks + j  (the same channel order as A)
@@ -254,32 +257,33 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
         }
 
         if (p.d.n_seg > 0) {
-            const int ns = p.d.n_seg;
+            const int ns = NS > 0 ? NS : p.d.n_seg;
             float* sl = row + p.d.seg_first;
             if (live && ns <= 64) {
                 // the whole logit row in registers: one batch of LDS reads, then max / exp / sum / argmax without
                 // a load in any dependence chain (padded entries are -inf -> exp 0, never the maximum)
-                float sv[64];
+                constexpr int LIM = NS > 0 ? NS : 64;              // compile-time class count: no padded entries, no branches
+                float sv[LIM];
 #pragma unroll
-                for (int s = 0; s < 64; ++s) sv[s] = s < ns ? sl[s] : -INFINITY;
+                for (int s = 0; s < LIM; ++s) sv[s] = (NS > 0 || s < ns) ? sl[s] : -INFINITY;
                 float m = -INFINITY;
 #pragma unroll
-                for (int s = 0; s < 64; ++s) m = fmaxf(m, sv[s]);
+                for (int s = 0; s < LIM; ++s) m = fmaxf(m, sv[s]);
                 float sum = 0.f;
 #pragma unroll
-                for (int s = 0; s < 64; ++s) { sv[s] = fast_exp(sv[s] - m); sum += sv[s]; }
+                for (int s = 0; s < LIM; ++s) { sv[s] = fast_exp(sv[s] - m); sum += sv[s]; }
                 const float rs = 1.f / sum;
                 float bp = -1.f;
                 int best = 0;
 #pragma unroll
-                for (int s = 0; s < 64; ++s) {
+                for (int s = 0; s < LIM; ++s) {
                     sv[s] = sv[s] * rs;
                     if (sv[s] > bp) { bp = sv[s]; best = s; }    // first maximum wins (torch.argmax)
                 }
                 if (p.seg_prob) {
 #pragma unroll
-                    for (int s = 0; s < 64; ++s)
-                        if (s < ns) sl[s] = sv[s];
+                    for (int s = 0; s < LIM; ++s)
+                        if (NS > 0 || s < ns) sl[s] = sv[s];
                 }
                 if (p.label) p.label[v] = (int64_t)s_lut[best];
             } else if (live) {
@@ -340,6 +344,10 @@ extern "C" int bfm_tail_heads(const float* feat, const float* input, int64_t nvo
     if (smem > 64 * 1024 &&
         (hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<true>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<true, 56, 3>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<true, 18, 1>),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
          hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<false>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess))
         return BFM_E_LAUNCH;
@@ -352,9 +360,14 @@ extern "C" int bfm_tail_heads(const float* feat, const float* input, int64_t nvo
         wexp = 14 - ex;
         wexp = wexp > 60 ? 60 : (wexp < -60 ? -60 : wexp);
     }
-    if (split)
-        hipLaunchKernelGGL(tail_kernel<true>, dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, wexp);
+    const int nnb = (desc->n_out + 31) >> 5;
+    if (split && desc->n_seg == 56 && nnb == 3)                // the shipped head set (69 outputs, 56 classes)
+        hipLaunchKernelGGL((tail_kernel<true, 56, 3>), dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, wexp);
+    else if (split && desc->n_seg == 18 && nnb == 1)           // left-hemisphere head set (18 classes, 27 outputs)
+        hipLaunchKernelGGL((tail_kernel<true, 18, 1>), dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, wexp);
+    else if (split)
+        hipLaunchKernelGGL((tail_kernel<true>), dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, wexp);
     else
-        hipLaunchKernelGGL(tail_kernel<false>, dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, 0);
+        hipLaunchKernelGGL((tail_kernel<false>), dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, 0);
     return bfm_launch_status();
 }
