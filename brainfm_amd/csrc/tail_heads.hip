@@ -127,6 +127,26 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
     float* slab = smem + wave * 64 * ld;            // this wave's [64][ld] logits
     float* row = slab + lane * ld;
 
+    // wave-uniform tables of the first PMAX non-segmentation outputs: head row, role, destination map (scalar registers)
+    constexpr int PMAX = 16;
+    int po[PMAX], prole[PMAX];
+    float* pptr[PMAX];
+#pragma unroll
+    for (int j = 0; j < PMAX; ++j) {
+        int o = 0, role = BFM_ROLE_PLAIN;
+        unsigned long long u = 0;
+        if (j < nplain) {
+            o = s_plain[j];
+            role = s_role[o];
+            const int slot = s_slot[o];
+            if (slot >= 0) u = reinterpret_cast<unsigned long long>(s_map[slot]);
+        }
+        po[j] = __builtin_amdgcn_readfirstlane(o);
+        prole[j] = __builtin_amdgcn_readfirstlane(role);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        pptr[j] = reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+    }
+
     const int64_t nchunks = (p.nvox + 63) >> 6;
     for (int64_t cix = (int64_t)blockIdx.x * WPB + wave; cix < nchunks; cix += (int64_t)gridDim.x * WPB) {
         const int64_t v0 = cix << 6;
@@ -229,11 +249,10 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
         const bool live = lane < nv;
         const int64_t v = v0 + lane;
         float dist[4] = {0.f, 0.f, 0.f, 0.f};
-        // ---- processors + post-processor per role (segmentation rows are handled below)
-        for (int j = 0; j < nplain; ++j) {
-            const int o = s_plain[j];
-            const int role = s_role[o];
-            const int slot = s_slot[o];
+        // ---- processors + post-processor per role (segmentation rows are handled below).  The first PMAX outputs run
+        // from the wave-uniform tables hoisted out of the chunk loop (scalar registers: the logit reads of all outputs are
+        // independent LDS loads, the stores take a scalar base); any further ones from the LDS tables
+        auto plain_out = [&](int o, int role, float* mp) __attribute__((always_inline)) {
             const float a = row[o];
             float r = a;
             if (role == BFM_ROLE_CT) r = a * 1000.f;
@@ -244,9 +263,17 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
                 const int k = o - p.d.dist_first;
                 if (k == 0) dist[0] = r; else if (k == 1) dist[1] = r; else if (k == 2) dist[2] = r; else dist[3] = r;
             }
-            if (live && slot >= 0) s_map[slot][v] = r;
+            if (live && mp) mp[v] = r;
             if (role == BFM_ROLE_SR && p.d.slot_high_res >= 0 && live && p.input)
                 s_map[p.d.slot_high_res][v] = a + p.input[v];
+        };
+#pragma unroll
+        for (int j = 0; j < PMAX; ++j)
+            if (j < nplain) plain_out(po[j], prole[j], pptr[j]);
+        for (int j = PMAX; j < nplain; ++j) {
+            const int o = s_plain[j];
+            const int slot = s_slot[o];
+            plain_out(o, s_role[o], slot >= 0 ? s_map[slot] : nullptr);
         }
 
         if (p.d.n_dist > 0 && p.d.slot_fake_cortical >= 0 && live) {
