@@ -530,13 +530,19 @@ def assign_tiles(ranges, world_size):
             pos += sz
     cost = lambda ch: sum(tile_time(ranges[i]) for i in ch)
     chunks.sort(key=lambda ch: (-cost(ch), ch[0]))
-    load = [0] + [PEER_SEND_VOXELS] * (world_size - 1)
-    owner = [0] * n
+    load = [0] * world_size
+    bins = [[] for _ in range(world_size)]
     for ch in chunks:
         r = min(range(world_size), key=lambda k: (load[k], k))
-        for i in ch:
-            owner[i] = r
+        bins[r].extend(ch)
         load[r] += cost(ch)
+    # rank 0 also receives and stitches: it takes the lightest share (at 8 ranks of 256^3 the single 160^3 tile, whose
+    # small-kernel chain is the shortest); the others keep the LPT order
+    order = sorted(range(world_size), key=lambda k: (load[k] == 0, load[k], k))     # ... the lightest non-empty one
+    owner = [0] * n
+    for rank, k in enumerate(order):
+        for i in bins[k]:
+            owner[i] = rank
     return owner
 
 
@@ -694,7 +700,7 @@ def prepare_tile_graphs(full_im, session, stride=[80, 80, 80], win_size=[160, 16
         agree_on_conv_variants(session, full_im, ranges, group)
     done = set()
     mine = [i for i in range(len(ranges)) if owner[i] == rank]
-    for batch in tile_batches(ranges, mine):
+    for batch in tile_batches(ranges, mine, min_batches=session.lanes if world > 1 else 1):
         dims = tuple(b - a for a, b in ranges[batch[0]])
         if (dims, len(batch)) in done:
             continue
@@ -757,10 +763,13 @@ def _run_group(session, ims):
 GROUP_MAX = max(1, int(os.environ.get("BFM_GROUP_MAX", "8")))       # most tiles batched through the deep levels at once
 
 
-def tile_batches(ranges, idxs=None, group_max=None):
+def tile_batches(ranges, idxs=None, group_max=None, min_batches=1):
     """The tiles `idxs` (default: all) as batches of same-shape tiles, at most `group_max` per batch, of balanced
     sizes, reference order kept inside a batch; batches sorted by modelled work, largest first.  For the reference
-    tiling of 256^3 this is 8 batches of equal work (1 x 160^3, 3 x 2, 3 x 4, 1 x 8 tiles)."""
+    tiling of 256^3 this is 8 batches of equal work (1 x 160^3, 3 x 2, 3 x 4, 1 x 8 tiles).  min_batches: when there
+    would be fewer batches than that (a rank of an 8-GPU run owns ONE shape group but has two lanes), the batches with
+    the most tiles are halved until there are enough, so that every lane has work and one half's small kernels run
+    under the other half's convolutions."""
     gm = GROUP_MAX if group_max is None else max(1, int(group_max))
     by = OrderedDict()
     for i in (range(len(ranges)) if idxs is None else idxs):
@@ -774,6 +783,12 @@ def tile_batches(ranges, idxs=None, group_max=None):
             sz = base + (1 if b < extra else 0)
             out.append(lst[pos:pos + sz])
             pos += sz
+    while 0 < len(out) < min_batches:
+        j = max(range(len(out)), key=lambda k: (len(out[k]), -k))
+        if len(out[j]) < 2:
+            break
+        h = (len(out[j]) + 1) // 2
+        out[j:j + 1] = [out[j][:h], out[j][h:]]
     out.sort(key=lambda b: (-sum(tile_time(ranges[i]) for i in b), b[0]))
     return out
 
@@ -957,7 +972,9 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
     # layer), largest batch first; slot[i] = (round, offset in that round's buffer) with round k = the k-th batch of
     # every rank.  Rank 0's own tiles never travel: they are packed into a private buffer per round, and the round's
     # (padded) size is set by the peers alone.
-    batches_of = [tile_batches(ranges, [i for i in range(len(ranges)) if owner[i] == r]) for r in range(world)]
+    nlanes = session.lanes if (session is not None and getattr(session, "use_graphs", False)) else 1
+    batches_of = [tile_batches(ranges, [i for i in range(len(ranges)) if owner[i] == r], min_batches=nlanes)
+                  for r in range(world)]
     nrounds = max([len(b) for b in batches_of] + [1]) if rounds else 1
     round_of, off_of = {}, {}
     round_numel = [1] * nrounds

@@ -1,5 +1,6 @@
-"""What each rank of an N-rank run of the 256^3 volume computes, timed alone on ONE GPU (no transfers): its tiles on its
-two lanes in the order tiled_inference_distributed runs them, plus -- on rank 0 -- the one-launch stitch of all 27 tiles.
+"""What each rank of an N-rank run of the 256^3 volume computes, timed alone on ONE GPU (no transfers): its batches of
+same-shape tiles on its two lanes in the order tiled_inference_distributed runs them, plus -- on rank 0 -- the one-launch
+stitch of all 27 tiles.
 A model of the N-GPU step without the exchange: max over ranks.   python scripts/bench_rank_share.py [N=8] [size=256]"""
 import os
 import sys
@@ -19,8 +20,9 @@ sess.use_graphs = True
 full = bench.make_volume(n, dev)
 stride, win = [80] * 3, [160] * 3
 ranges = TU.tiling_ranges((n, n, n), stride, win)
-TU.prepare_tile_graphs(full, sess, stride, win)
 owner = TU.assign_tiles(ranges, world)
+batches_of = [TU.tile_batches(ranges, [i for i in range(len(ranges)) if owner[i] == r_], min_batches=sess.lanes)
+              for r_ in range(world)]
 ops = TU.HipStitchOps(sess)
 nkeys = len(sess.stitch_keys())
 offs, total = [], 0
@@ -33,30 +35,31 @@ acc = torch.empty((nkeys, n, n, n), dtype=torch.float32, device=dev)
 
 
 def share(rank):
-    mine = sorted([i for i in range(len(ranges)) if owner[i] == rank], key=lambda i: (-TU.tile_cost(ranges[i]), i))
     main = torch.cuda.current_stream(dev)
     start = torch.cuda.Event()
     start.record(main)
     load, last = [0] * sess.lanes, {}
-    for i in mine:
+    for batch in batches_of[rank]:
         k = min(range(sess.lanes), key=lambda j: (load[j], j))
-        load[k] += TU.tile_time(ranges[i])
-        (x0, x1), (y0, y1), (z0, z1) = ranges[i]
-        n_i = TU.tile_cost(ranges[i]) * nkeys
-        _, _, done = ops.run_tile(full[:, :, x0:x1, y0:y1, z0:z1], out=buf[offs[i]:offs[i] + n_i], lane=k, after=start)
+        load[k] += sum(TU.tile_time(ranges[i]) for i in batch)
+        ims = [full[:, :, ranges[i][0][0]:ranges[i][0][1], ranges[i][1][0]:ranges[i][1][1], ranges[i][2][0]:ranges[i][2][1]]
+               for i in batch]
+        outs = [buf[offs[i]:offs[i] + TU.tile_cost(ranges[i]) * nkeys] for i in batch]
+        _, _, done = ops.run_group(ims, outs, lane=k, after=start)
         if done is not None:
             last[k] = done
     for ev in last.values():
         main.wait_event(ev)
     if rank == 0:
         ops.gather_all(acc, srcs, ranges, (n, n, n))
-    return mine
+    return [i for b_ in batches_of[rank] for i in b_]
 
 
 worst = 0.0
 for rank in range(world):
-    share(rank)
-    torch.cuda.synchronize()
+    for _ in range(3):                                      # eager pass, capture, first replay of this rank's batch graphs
+        share(rank)
+        torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(5):
@@ -65,6 +68,7 @@ for rank in range(world):
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / 5
     worst = max(worst, ms)
-    print("rank %d of %d: tiles %s (x 80^3 units)%s: %.2f ms" % (
-        rank, world, [TU.tile_cost(ranges[i]) // 512000 for i in mine], " + stitch of all tiles" if rank == 0 else "", ms))
+    print("rank %d of %d: batches %s (tiles x 80^3 units each)%s: %.2f ms" % (
+        rank, world, ["%dx%d" % (len(b_), TU.tile_cost(ranges[b_[0]]) // 512000) for b_ in batches_of[rank]],
+        " + stitch of all tiles" if rank == 0 else "", ms))
 print("modelled %d-GPU step without the exchange: %.2f ms = %.0f Mvoxel/s" % (world, worst, n ** 3 / worst / 1e3))
