@@ -33,7 +33,7 @@ class TailDesc(C.Structure):
                 ("seg_first", C.c_int), ("n_seg", C.c_int), ("seg_lut", C.c_void_p),
                 ("n_dist", C.c_int), ("dist_first", C.c_int), ("max_dist", C.c_float),
                 ("unit_feat", C.c_int), ("slot_high_res", C.c_int), ("slot_fake_cortical", C.c_int),
-                ("n_maps", C.c_int), ("head_wmax", C.c_float)]
+                ("n_maps", C.c_int), ("head_wmax", C.c_float), ("skip_zero_input", C.c_int)]
 
 
 class ZoomAxis(C.Structure):
@@ -93,6 +93,8 @@ SIGNATURES = {
     "bfm_bspline3_resample_axis": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P]),
     "bfm_conv3x3x3_wino_rows": (_I, [_I, _I, _I, _I]),
     "bfm_conv3x3x3_wino_ex": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _P]),
+    "bfm_conv3x3x3_wino_box": (_I, [_I, _I, _I, _I, _P]),
+    "bfm_conv3x3x3_wino_masked": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _P]),
     "bfm_maxpool2_rows": (_I, [_I, _I, _I, _I]),
     "bfm_maxpool2_ex": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "bfm_grid_push3d_linear": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, C.POINTER(_I), _I, _P, _P]),

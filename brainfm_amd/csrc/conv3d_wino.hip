@@ -48,6 +48,7 @@ struct WinoParams {
     double *rsum, *rsq;              // optional output-moment rows [nMt][Cout] (see conv3d_mfma.hip), 4-wave kernel only
     float *rmn, *rmx;
     int ws_buf_bytes;                // persistent kernel: bytes per LDS buffer
+    const float* mask_img;           // optional (D,H,W) image: a box none of whose voxels is non-zero there is not computed
 };
 
 __device__ __forceinline__ int row_perm(int l) {        // as conv_mfma: each 16-lane b128 group reads 16 consecutive positions
@@ -120,6 +121,20 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
     const int ty = (mt / p.nTx) % p.nTy;
     const int tz = mt / (p.nTx * p.nTy);
     const int z0 = tz * p.TD, y0 = ty * p.TH, x0 = tx * p.TW;
+
+    if (p.mask_img) {
+        // The caller multiplies this layer's consumers by (image != 0) (the tile loop, scripts/demo_test.py:88-100, and this
+        // is the last convolution before the per-voxel heads): outputs of a box whose image voxels are all zero are never
+        // looked at, so the box is not computed.  Uniform exit before the first barrier of the main loop.
+        bool nz = false;
+        const int thw = p.TH * p.TW;
+        for (int q = tid; q < p.TD * thw; q += NTHR) {
+            const int d = q / thw, r = q - d * thw, h = r / p.TW, w = r - h * p.TW;
+            const int gz = z0 + d, gy = y0 + h, gx = x0 + w;
+            if (gz < p.D && gy < p.H && gx < p.W) nz = nz || p.mask_img[((int64_t)gz * p.H + gy) * p.W + gx] != 0.f;
+        }
+        if (!__syncthreads_or(nz ? 1 : 0)) return;
+    }
 
     float bmax = 0.f;
     for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, p.bound[g]);
@@ -1145,6 +1160,13 @@ extern "C" int bfm_conv3x3x3_wino_rows(int D, int H, int W, int passes) {
     return bfm_cdiv(D, TD) * bfm_cdiv(H, TH) * bfm_cdiv(W, TW);
 }
 
+extern "C" int bfm_conv3x3x3_wino_box(int D, int H, int W, int passes, int* box) {
+    int TD, TH, TW;
+    if (!box || D <= 0 || H <= 0 || W <= 0 || !choose_box(D, H, W, passes == 3 ? 2 : 1, TD, TH, TW)) return BFM_E_ARG;
+    box[0] = TD; box[1] = TH; box[2] = TW;
+    return BFM_OK;
+}
+
 extern "C" int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W, const float* scale,
                                      const float* shift, const float* bound, int G, const void* wpacked, int wexp,
                                      int Cout, float slope, int passes, int flags, float* out, void* moment_rows,
@@ -1157,10 +1179,30 @@ extern "C" int bfm_conv3x3x3_wino(const float* A, int CA, int D, int H, int W, c
                                  nullptr, stream);
 }
 
+static int wino_launch(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
+                       const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes, int flags,
+                       float* out, void* moment_rows, const float* mask_img, bfm_stream_t stream);
+
 extern "C" int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W, const float* scale,
                                      const float* shift, const float* bound, int G, const void* wpacked, int wexp,
                                      int Cout, float slope, int passes, int flags, float* out, void* moment_rows,
                                      bfm_stream_t stream) {
+    return wino_launch(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out, moment_rows,
+                       nullptr, stream);
+}
+
+extern "C" int bfm_conv3x3x3_wino_masked(const float* A, int CA, int D, int H, int W, const float* scale,
+                                         const float* shift, const float* bound, int G, const void* wpacked, int wexp,
+                                         int Cout, float slope, int passes, int flags, float* out,
+                                         const float* mask_image, bfm_stream_t stream) {
+    if (!mask_image || (flags & 6)) return BFM_E_ARG;          // the 4-wave kernel only; no moment rows (boxes are left out)
+    return wino_launch(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out, nullptr,
+                       mask_image, stream);
+}
+
+static int wino_launch(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
+                       const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes, int flags,
+                       float* out, void* moment_rows, const float* mask_img, bfm_stream_t stream) {
     const int accumulate = flags & 1;
     const bool persistent = (flags & 2) != 0;
     const bool eight = (flags & 4) != 0;
@@ -1179,6 +1221,7 @@ extern "C" int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W
     p.scale = scale; p.shift = shift; p.bound = bound; p.G = G;
     p.wp = static_cast<const uint4*>(wpacked);
     p.wexp = wexp; p.Cout = Cout; p.slope = slope; p.out = out; p.accum = accumulate ? 1 : 0;
+    p.mask_img = mask_img;
     if (!choose_box(D, H, W, npl, p.TD, p.TH, p.TW)) return BFM_E_SHAPE;
     p.HT = p.TH + 2; p.PW = p.TW / 2;
     p.pw_shift = ilog2i(p.PW); p.thp_shift = ilog2i(p.TH * p.PW);

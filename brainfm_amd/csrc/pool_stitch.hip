@@ -99,9 +99,11 @@ __global__ void stitch_kernel(const float* __restrict__ tile, const int64_t* __r
         int64_t t = i / tw;
         int y = (int)(t % th);
         int z = (int)(t / th);
-        float m = (tin == nullptr || tin[i] != 0.f) ? 1.f : 0.f;
-        // labels: (int64 * float mask) -> float, saved, re-read as int, summed into a float volume
-        float v = tile_label ? (float)(int)((float)tile_label[i] * m) : tile[i] * m;
+        const bool m = tin == nullptr || tin[i] != 0.f;
+        // v * mask with mask in {0, 1}, as a select: what lies outside the mask may never have been computed (the tile
+        // loop's last layers skip it) and must not leak a NaN through 0 * NaN; +0 where the reference has +-0 -- both
+        // vanish in `full (+0) += v`.  labels: (int64 * float mask) -> float, saved, re-read as int, summed as float
+        float v = !m ? 0.f : (tile_label ? (float)(int)(float)tile_label[i] : tile[i]);
         full[((int64_t)(z0 + z) * H + (y0 + y)) * W + (x0 + x)] += v;
     }
 }
@@ -124,10 +126,10 @@ __global__ void stitch_multi_kernel(const float* __restrict__ maps, int64_t map_
             for (int k = 0; k < K; ++k) full[(int64_t)k * vol + o] += maps[(int64_t)sel[k] * map_stride + i];
             continue;
         }
-        const float m = tin[i] != 0.f ? 1.f : 0.f;
+        const bool m = tin[i] != 0.f;
         for (int k = 0; k < K; ++k) {
             const int r = sel[k];
-            const float v = r < 0 ? (float)(int)((float)label[i] * m) : maps[(int64_t)r * map_stride + i] * m;
+            const float v = !m ? 0.f : (r < 0 ? (float)(int)(float)label[i] : maps[(int64_t)r * map_stride + i]);
             full[(int64_t)k * vol + o] += v;
         }
     }
@@ -138,10 +140,10 @@ __global__ void pack_multi_kernel(const float* __restrict__ maps, int64_t map_st
                                   int K, const int64_t* __restrict__ label, const float* __restrict__ tin, int64_t n,
                                   float* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float m = tin[i] != 0.f ? 1.f : 0.f;
+        const bool m = tin[i] != 0.f;                  // select, not multiply: see stitch_kernel
         for (int k = 0; k < K; ++k) {
             const int r = sel[k];
-            out[(int64_t)k * n + i] = r < 0 ? (float)(int)((float)label[i] * m) : maps[(int64_t)r * map_stride + i] * m;
+            out[(int64_t)k * n + i] = !m ? 0.f : (r < 0 ? (float)(int)(float)label[i] : maps[(int64_t)r * map_stride + i]);
         }
     }
 }
@@ -157,8 +159,8 @@ __global__ void divide_multi_kernel(float* __restrict__ full, const float* __res
 __global__ void mask_kernel(const float* __restrict__ tile, const int64_t* __restrict__ tile_label,
                             const float* __restrict__ tin, int64_t n, float* __restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float m = tin[i] != 0.f ? 1.f : 0.f;
-        out[i] = tile_label ? (float)(int)((float)tile_label[i] * m) : tile[i] * m;
+        const bool m = tin[i] != 0.f;
+        out[i] = !m ? 0.f : (tile_label ? (float)(int)(float)tile_label[i] : tile[i]);
     }
 }
 

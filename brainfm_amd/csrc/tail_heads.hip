@@ -151,6 +151,12 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
     for (int64_t cix = (int64_t)blockIdx.x * WPB + wave; cix < nchunks; cix += (int64_t)gridDim.x * WPB) {
         const int64_t v0 = cix << 6;
         const int nv = (int)min<int64_t>(64, p.nvox - v0);
+        if (p.d.skip_zero_input && p.input) {
+            // the caller keeps this chunk's outputs only where the input image is non-zero (the tile loop's mask,
+            // scripts/demo_test.py:88-100): nothing of a chunk of 64 zero voxels is looked at
+            const float iv = lane < nv ? p.input[v0 + lane] : 0.f;
+            if (!__any(iv != 0.f)) continue;
+        }
 #pragma unroll 1
         for (int mb = 0; mb < 2; ++mb) {
             const int r = mb * 32 + l32;            // this lane's voxel row inside the chunk

@@ -459,13 +459,23 @@ class UNetEngine:
             self.tape.append(dict(ly=ly, A=A, B=B, dims=tuple(dims), lo_dims=tuple(lo_dims) if lo_dims is not None else None,
                                   scale=scale, shift=shift, bound=bound, mean=mean, rstd=rstd, out=out))
 
-    def _conv_launch(self, ly, A, ca, B, cb, dims, upp, scale, shift, bound, groups, cfg, out, ws, rows=None, slope=None):
+    def _conv_launch(self, ly, A, ca, B, cb, dims, upp, scale, shift, bound, groups, cfg, out, ws, rows=None, slope=None,
+                     mask_img=None):
         """One launch of the planned variant of GN-apply + conv + LeakyReLU (cfg[6]: 0/1/2 conv_mfma family,
-        3 Winograd; cfg[7] bit 0: accumulate onto `out`)."""
+        3 Winograd; cfg[7] bit 0: accumulate onto `out`).  mask_img (variant 3 only): the tile's input image; boxes of
+        output voxels where it is all zero are left uncomputed (bfm_conv3x3x3_wino_masked)."""
         D, H, W = dims
         st = L.stream_ptr()
         slope = self.slope if slope is None else float(slope)
         self._pack(ly, True, cfg[6])
+        if mask_img is not None:
+            if cfg[6] != 3 or cb or rows is not None:
+                raise L.BfmError("a masked launch is the one-source 4-wave Winograd kernel without moment rows")
+            L.check(self.lib.bfm_conv3x3x3_wino_masked(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
+                                                       groups, L.ptr(ly.wpacked), ly.wexp, ly.cout, slope, self.passes,
+                                                       cfg[7] & 1, L.ptr(out), L.ptr(mask_img), st),
+                    "conv_wino(masked) " + ly.name)
+            return
         if cfg[6] in (3, 4, 5):
             if cb:
                 raise L.BfmError("the Winograd variant takes one source")
@@ -495,9 +505,11 @@ class UNetEngine:
         return (buf, n)
 
     # ------------------------------------------------------------------ one SingleConv
-    def single_conv(self, ly, A, dims, B=None, lo_dims=None):
+    def single_conv(self, ly, A, dims, B=None, lo_dims=None, mask_img=None):
         """GroupNorm -> Conv3d(3,p=1) -> LeakyReLU on cat((A, nearest_up(B))).
-        A: (D,H,W,CA) fp32, B: (d,h,w,CB) fp32 or None.  Returns (D,H,W,Cout)."""
+        A: (D,H,W,CA) fp32, B: (d,h,w,CB) fp32 or None.  Returns (D,H,W,Cout).
+        mask_img: (D,H,W) image; the caller promises to look at the output only where it is non-zero (the tile loop's
+        last convolution, see backbone_cl).  Honoured when the layer runs the 4-wave Winograd kernel, ignored otherwise."""
         D, H, W = dims
         ca = A.shape[-1]
         cb = 0 if B is None else B.shape[-1]
@@ -527,7 +539,9 @@ class UNetEngine:
         if mfma:
             ev = None
             reps = 1
-            rows = self._rows_for(ly.cin, ly.cout, dims, cfg)
+            if mask_img is not None and not (cfg[6] == 3 and B is None and self.tape is None):
+                mask_img = None
+            rows = self._rows_for(ly.cin, ly.cout, dims, cfg) if mask_img is None else None
             if self.prof is not None:
                 # instrumented pass (bench.py): the launch is issued prof_reps times back to back inside one HIP
                 # event pair (the result is idempotent), so the bracket holds kernel time, not host submission gaps
@@ -535,12 +549,15 @@ class UNetEngine:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
             for _ in range(reps):
-                self._conv_launch(ly, A, ca, B, cb, dims, upp, scale, shift, bound, ly.groups, cfg, out, ws, rows)
+                self._conv_launch(ly, A, ca, B, cb, dims, upp, scale, shift, bound, ly.groups, cfg, out, ws, rows,
+                                  mask_img=mask_img)
             if rows is not None:
                 out._bfm_rows = rows
             if ev is not None:
                 ev[1].record()
                 nv = D * H * W
+                if mask_img is not None:                    # only the boxes the kernel computes count as work
+                    nv = self.masked_voxels(mask_img, dims)
                 lo = 0 if B is None else lo_dims[0] * lo_dims[1] * lo_dims[2]
                 self.prof.append((ev[0], ev[1], 2.0 * 27 * ly.cin * ly.cout * nv,
                                   4.0 * (nv * ca + lo * cb + nv * ly.cout + 27 * ly.cin * ly.cout), reps,
@@ -564,6 +581,19 @@ class UNetEngine:
                                                   st), "conv_direct " + ly.name)
         self._record(ly, A, B, dims, lo_dims, scale, shift, bound, out)
         return out
+
+    def masked_voxels(self, mask_img, dims):
+        """Output voxels bfm_conv3x3x3_wino_masked computes for this image: those of the kernel's boxes that hold a
+        non-zero voxel (host-side count for the instrumented pass; synchronises)."""
+        D, H, W = dims
+        box = (C.c_int * 3)()
+        L.check(self.lib.bfm_conv3x3x3_wino_box(D, H, W, self.passes, box), "wino_box")
+        td, th, tw = box[0], box[1], box[2]
+        m = (mask_img.reshape(D, H, W) != 0)
+        m = torch.nn.functional.pad(m, (0, -W % tw, 0, -H % th, 0, -D % td))
+        m = m.reshape(m.shape[0] // td, td, m.shape[1] // th, th, m.shape[2] // tw, tw)
+        self.last_mask_fraction = float(m.any(dim=5).any(dim=3).any(dim=1).float().mean().item())
+        return int(round(self.last_mask_fraction * m.numel()))
 
     def _skip_layer(self, ly, ca):
         """The skip-channel half of a decoder's first conv as a layer of its own (weights w[:, :ca])."""
@@ -660,6 +690,9 @@ class UNetEngine:
     deep_from = int(os.environ.get("BFM_DEEP_FROM", "3"))
     deep_batch = os.environ.get("BFM_DEEP_BATCH", "1") != "0"
     DEEP_VERS = (0, 2)                                     # conv_mfma, conv_mfma16: the variants that take a batch
+    # The tile loop multiplies every output of a tile by (tile input != 0) (scripts/demo_test.py:88-100): the last
+    # convolution and the per-voxel heads leave out the voxels that product discards (BFM_MASK_SKIP=0: compute them all).
+    mask_skip = os.environ.get("BFM_MASK_SKIP", "1") != "0"
 
     def has_deep_region(self):
         if not (self.deep_batch and self.tape is None and not self.force_direct and len(self.fm) > self.deep_from >= 1):
@@ -808,11 +841,16 @@ class UNetEngine:
             feats.append((x, d))
         return x, d, feats
 
-    def backbone_cl(self, x_cl, dims):
+    def backbone_cl(self, x_cl, dims, mask_last=False):
         """x_cl: (D,H,W,Cin).  Returns the decoder feature maps as channels-last buffers,
-        deepest first, the last one NOT yet L2-normalised (the tail kernel does that)."""
+        deepest first, the last one NOT yet L2-normalised (the tail kernel does that).
+        mask_last: the caller keeps, of everything computed from the LAST feature map, only the voxels where the
+        (one-channel) input is non-zero -- the tile loop, scripts/demo_test.py:88-100.  The last convolution then leaves
+        out the boxes of voxels whose input is all zero (its own GroupNorm statistics come from the previous layer's
+        full output, so nothing that is kept changes); that map holds unwritten memory there."""
         if self.has_deep_region():
-            return self.backbone_batch([x_cl], dims)[0]
+            return self.backbone_batch([x_cl], dims, mask_last=mask_last)[0]
+        mask_img = x_cl if (mask_last and self.mask_skip and x_cl.shape[-1] == 1) else None
         skips = []
         x, d = x_cl, tuple(dims)
         for i, (l1, l2) in enumerate(self.enc):
@@ -825,9 +863,9 @@ class UNetEngine:
             skips.insert(0, (x, d))
         skips = skips[1:]
         feats = [(x, d)]
-        for (l1, l2), (skip, sd_) in zip(self.dec, skips):
+        for k, ((l1, l2), (skip, sd_)) in enumerate(zip(self.dec, skips)):
             y = self.single_conv(l1, skip, sd_, B=x, lo_dims=d)
-            x = self.single_conv(l2, y, sd_)
+            x = self.single_conv(l2, y, sd_, mask_img=mask_img if k == len(self.dec) - 1 else None)
             d = sd_
             feats.append((x, d))
         return feats
@@ -846,26 +884,30 @@ class UNetEngine:
             skips.append((x, d))
         return skips
 
-    def decoder_top(self, skips, x, d):
-        """Decoders that end above the batched levels, one sample: x (d) = this sample's slice of the region's output."""
+    def decoder_top(self, skips, x, d, mask_img=None):
+        """Decoders that end above the batched levels, one sample: x (d) = this sample's slice of the region's output.
+        mask_img: see backbone_cl(mask_last) -- applies to the last decoder's second convolution."""
         ndeep = len(self.enc) - 1 - self.deep_from
         feats = []
-        for (l1, l2), (skip, sd_) in zip(self.dec[ndeep:], reversed(skips)):
+        nd = len(self.dec) - ndeep
+        for k, ((l1, l2), (skip, sd_)) in enumerate(zip(self.dec[ndeep:], reversed(skips))):
             y = self.single_conv(l1, skip, sd_, B=x, lo_dims=d)
-            x = self.single_conv(l2, y, sd_)
+            x = self.single_conv(l2, y, sd_, mask_img=mask_img if k == nd - 1 else None)
             d = sd_
             feats.append((x, d))
         return feats
 
-    def backbone_batch(self, xs, dims):
+    def backbone_batch(self, xs, dims, mask_last=False):
         """The backbone of S same-shape samples: encoder levels above the region per sample, the region batched, the
-        remaining decoders per sample.  Returns one feature list per sample (deepest first, like backbone_cl)."""
+        remaining decoders per sample.  Returns one feature list per sample (deepest first, like backbone_cl).
+        mask_last: as in backbone_cl."""
         tops = [self.encoder_top(x, dims) for x in xs]
         out, d, deep_feats = self.deep_region([t[-1] for t in tops])
         res = []
         for s_, skips in enumerate(tops):
             feats = [(f[s_], fd) for f, fd in deep_feats]
-            feats += self.decoder_top(skips, out[s_], d)
+            mask_img = xs[s_] if (mask_last and self.mask_skip and xs[s_].shape[-1] == 1) else None
+            feats += self.decoder_top(skips, out[s_], d, mask_img=mask_img)
             res.append(feats)
         return res
 
@@ -974,10 +1016,12 @@ class Tail:
                                self.roles.data_ptr(), self.out_slot.data_ptr(), seg[0], seg[1],
                                self.seg_lut.data_ptr(), dist[1], dist[0], float(max_surf_distance),
                                1 if eng.unit_feat else 0, self.slot_high_res, self.slot_fake, len(self.map_names),
-                               float(self.head_w.abs().max().item()) if self.n_out else 0.0)
+                               float(self.head_w.abs().max().item()) if self.n_out else 0.0, 0)
+        self.desc_skip = None
 
-    def run(self, feat_cl, dims, input_cl=None, want_feat=True, want_seg=True, extra_rows=0):
+    def run(self, feat_cl, dims, input_cl=None, want_feat=True, want_seg=True, extra_rows=0, skip_zero_input=False):
         """Fused tail.  feat_cl: (D,H,W,c_feat) raw last decoder output.
+        skip_zero_input: runs of 64 voxels whose input_cl is all zero are left unwritten (the tile loop discards them).
         Returns (maps: {name: (D,H,W) fp32}, feat_norm (D,H,W,C)|None, seg (D,H,W,n_seg)|None, label (D,H,W) int64|None).
         extra_rows: spare (D,H,W) rows at the end of the map buffer (self.last_buf) for per-tile maps computed after the
         tail (the deformed atlas), so that the stitcher still packs one buffer."""
@@ -992,7 +1036,13 @@ class Tail:
         feat_norm = torch.empty_like(feat_cl) if want_feat else None
         seg = torch.empty((D, H, W, nseg), dtype=torch.float32, device=dev) if (want_seg and nseg) else None
         label = torch.empty((D, H, W), dtype=torch.int64, device=dev) if nseg else None
-        L.check(eng.lib.bfm_tail_heads(L.ptr(feat_cl), L.ptr(input_cl), nvox, C.byref(self.desc), L.ptr(feat_norm),
+        desc = self.desc
+        if skip_zero_input and input_cl is not None and not want_feat and not want_seg:
+            if self.desc_skip is None:
+                self.desc_skip = L.TailDesc.from_buffer_copy(self.desc)
+                self.desc_skip.skip_zero_input = 1
+            desc = self.desc_skip
+        L.check(eng.lib.bfm_tail_heads(L.ptr(feat_cl), L.ptr(input_cl), nvox, C.byref(desc), L.ptr(feat_norm),
                                        L.ptr(ptrs), L.ptr(seg), L.ptr(label), None, L.stream_ptr()), "tail_heads")
         maps = OrderedDict((n, maps_buf[i]) for i, n in enumerate(self.map_names))
         self.last_buf = maps_buf                      # [n_maps][D,H,W]: the stitcher consumes all rows in one launch

@@ -721,8 +721,10 @@ def _tile_tail(session, feats, x_cl, dims, raw):
     atlas = getattr(session, "atlas", None)
     if atlas is not None and not {"regx", "regy", "regz"} <= set(tail.map_names):
         atlas = None                                           # the reference's loop needs the registration head too
+    # every consumer of a tile's maps (stitch / pack kernels, the atlas gather) keeps them only where the tile's input is
+    # non-zero: the heads of the other voxels are not evaluated (engine.mask_skip; rows hold unwritten memory there)
     maps, _, _, label = tail.run(feats[-1][0], dims, input_cl=x_cl, want_feat=False, want_seg=False,
-                                 extra_rows=1 if atlas is not None else 0)
+                                 extra_rows=1 if atlas is not None else 0, skip_zero_input=eng.mask_skip)
     if atlas is not None:
         # scripts/demo_test.py:102-104: get_deformed_atlas(mask, regx, regy, regz) with mask = (im != 0), from the
         # unmasked registration maps, into the spare row of the tail's map buffer; the stitcher multiplies by the mask
@@ -743,7 +745,7 @@ def _run_tile(session, im, raw=False):
     eng = session.engine
     dims = tuple(im.shape[2:])
     x_cl = eng.to_cl(im)
-    return _tile_tail(session, eng.backbone_cl(x_cl, dims), x_cl, dims, raw)
+    return _tile_tail(session, eng.backbone_cl(x_cl, dims, mask_last=True), x_cl, dims, raw)
 
 
 def _run_group(session, ims):
@@ -756,7 +758,7 @@ def _run_group(session, ims):
         return [_run_tile(session, im, raw=True) for im in ims]
     dims = tuple(ims[0].shape[2:])
     x_cls = [eng.to_cl(im) for im in ims]
-    feats = eng.backbone_batch(x_cls, dims)
+    feats = eng.backbone_batch(x_cls, dims, mask_last=True)
     return [_tile_tail(session, f, x_cl, dims, True) for f, x_cl in zip(feats, x_cls)]
 
 

@@ -117,7 +117,16 @@ int bfm_conv3x3x3_wino(const float* A, int CA, int D, int H, int W, const float*
 int bfm_conv3x3x3_wino_rows(int D, int H, int W, int passes);   /* moment rows of the 4-wave kernel (0: cannot run) */
 int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                           const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
-                          int flags, float* out, void* moment_rows /*or NULL; 4-wave kernel only*/, bfm_stream_t stream);
+                          int flags, float* out, void* moment_rows /*or NULL;
+ 4-wave kernel only*/, bfm_stream_t stream);
+
+/* The last convolution of a tile inside the tile loop (scripts/demo_test.py:88-100 keeps `v * (tile_input != 0)` of every
+ * output): a box of output voxels whose tile-input voxels are all zero feeds nothing that survives the mask, so it is not
+ * computed (`out` keeps whatever it held there).  mask_image = the tile's input (D,H,W).  The 4-wave kernel, no moment rows. */
+int bfm_conv3x3x3_wino_box(int D, int H, int W, int passes, int* box /* [3]: the (d,h,w) box of output voxels per workgroup */);
+int bfm_conv3x3x3_wino_masked(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
+                              const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
+                              int flags, float* out, const float* mask_image, bfm_stream_t stream);
 
 /* Output-moment rows.  A producer (conv3x3x3_mfma_ex / conv3x3x3_stem_ex) can write, next to its output, one row
  * per tile of per-channel {sum, sumsq} (fp64) and {min, max} (fp32) of the values it stored: buffer of
@@ -241,6 +250,9 @@ typedef struct {
     int n_maps;                 /* length of the `maps` pointer array (every out_slot / slot_* is < n_maps) */
     float head_wmax;            /* max |head_w| (host knows it): > 0 with unit_feat selects the split-f16 matrix-core
                                    path (fp32-grade, like conv3x3x3_mfma); 0 keeps the exact fp32 MFMA chain */
+    int skip_zero_input;        /* 1: a run of 64 voxels whose `input` is all zero is not evaluated (its maps / label stay
+                                   unwritten).  For the tile loop only, which keeps outputs where the tile's input is
+                                   non-zero (scripts/demo_test.py:88-100); evaluate_image always passes 0 */
 } bfm_tail_desc_t;
 
 int bfm_tail_heads(const float* feat, const float* input /*[nvox], may be NULL*/, int64_t nvox,

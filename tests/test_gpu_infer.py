@@ -917,3 +917,91 @@ def test_matrix_core_path_vs_reference_golden_64_wide():
             else:
                 assert _relerr(a, b) <= TOL_NET, (k, _relerr(a, b), graphs)
     print("conv variants used on the 64-wide golden net:", sorted(used))
+
+
+@pytest.mark.parametrize("dims", [(16, 16, 64), (13, 22, 37), (24, 8, 48)])
+def test_masked_last_convolution_computes_exactly_the_boxes_that_hold_input(dims):
+    """bfm_conv3x3x3_wino_masked (the tile loop's last convolution): a box of output voxels is computed -- bit for bit what
+    bfm_conv3x3x3_wino_ex stores there -- when the tile's input has a non-zero voxel inside it, and is left untouched
+    otherwise; NaN and negative inputs count as non-zero like `im != 0` does (scripts/demo_test.py:88)."""
+    import ctypes as C
+    from brainfm_amd import _lib as L
+    sd = O.random_state_dict(1, 64, 3, seed=17)
+    s = _session(sd=sd, f_maps=64, levels=3)
+    eng = s.engine
+    ly = eng.dec[-1][1]
+    D, H, W = dims
+    g = torch.Generator().manual_seed(5)
+    A = (torch.randn(dims + (64,), generator=g) * 1.3).to(_dev())
+    img = torch.zeros(dims, dtype=torch.float32)
+    img[D // 3: D // 3 + 3, 2:7, W // 2: W // 2 + 5] = torch.rand(3, 5, 5, generator=g) + 0.1
+    img[D - 1, H - 1, W - 1] = -2.0                                    # a corner box, ragged when dims do not divide
+    img[0, H // 2, 1] = float("nan")
+    img = img.to(_dev())
+    scale = torch.rand(64, device=_dev()) + 0.5
+    shift = torch.randn(64, device=_dev()) * 0.1
+    bound = torch.full((ly.groups,), 8.0, device=_dev())
+    cfg = (C.c_int * 8)()
+    L.check(eng.lib.bfm_conv3x3x3_mfma_plan(64, 64, D, H, W, cfg), "plan")
+    cfg[6], cfg[7] = 3, 0
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=_dev())
+    full = torch.empty(dims + (64,), device=_dev())
+    eng._conv_launch(ly, A, 64, None, 0, dims, None, scale, shift, bound, ly.groups, cfg, full, ws)
+    sentinel = -12345.0
+    part = torch.full(dims + (64,), sentinel, device=_dev())
+    eng._conv_launch(ly, A, 64, None, 0, dims, None, scale, shift, bound, ly.groups, cfg, part, ws, mask_img=img)
+    box = (C.c_int * 3)()
+    L.check(eng.lib.bfm_conv3x3x3_wino_box(D, H, W, eng.passes, box), "box")
+    td, th, tw = box[0], box[1], box[2]
+    nz = (img != 0).cpu().numpy()
+    active = np.zeros(dims, dtype=bool)
+    for z in range(0, D, td):
+        for y in range(0, H, th):
+            for x in range(0, W, tw):
+                if nz[z:z + td, y:y + th, x:x + tw].any():
+                    active[z:z + td, y:y + th, x:x + tw] = True
+    assert 0 < active.sum() < active.size
+    act = torch.from_numpy(active).to(_dev())
+    assert torch.equal(part[act], full[act])
+    assert bool((part[~act] == sentinel).all())
+    assert eng.masked_voxels(img, dims) == int(active.sum())
+
+
+def test_tile_loop_mask_skip_changes_no_stitched_bit():
+    """The tile loop keeps v * (tile input != 0) of every tile output (scripts/demo_test.py:88-100), so the last convolution
+    and the per-voxel heads leave out what that product discards (engine.mask_skip).  With the skipped memory poisoned by
+    NaNs beforehand, all 17 stitched keys are bit-identical to the run that computes every voxel -- eager per tile, and
+    batches replayed from hipGraphs on two lanes -- and stay finite."""
+    from brainfm_amd import test_utils as TU
+    import bench
+    ga, ta = TU.default_inference_args(f_maps=64, num_levels=3)
+    shape, stride, win = (112, 96, 144), [24] * 3, [48] * 3
+    g = torch.Generator().manual_seed(21)
+    zz, yy, xx = np.meshgrid(*[np.linspace(-1, 1, n_) for n_ in shape], indexing="ij")
+    inside = torch.from_numpy((zz / 0.8) ** 2 + (yy / 0.6) ** 2 + (xx / 0.7) ** 2 < 1)
+    vol = (torch.rand(shape, generator=g) + 0.05) * inside
+    vol[40:60, 30:50, 60:90] = 0                                        # a hole inside the head
+    full = vol[None, None].to(_dev())
+    atlas = bench.make_atlas()
+    res = {}
+    for skip in (False, True):
+        torch.manual_seed(4)
+        s = TU.InferenceSession(ga, ta, _dev(), passes=3)
+        s.set_atlas(*atlas)
+        s.engine.mask_skip = skip
+        poison = [torch.full((48 * 48 * 48 * 64,), float("nan"), device=_dev()) for _ in range(6)]
+        poison += [torch.full((48 * 48 * 48 * 24,), float("nan"), device=_dev()) for _ in range(4)]
+        del poison
+        eager, ranges, _ = TU.tiled_inference(full, s, stride, win, graphs=False, batched=False)
+        eager = {k: v.clone() for k, v in eager.items()}
+        TU.prepare_tile_graphs(full, s, stride, win)
+        rep, _, _ = TU.tiled_inference(full, s, stride, win, graphs=True)
+        for k in eager:
+            assert torch.equal(rep[k], eager[k]), (skip, k)
+            assert bool(torch.isfinite(eager[k]).all()), (skip, k)
+        res[skip] = eager
+    assert len(res[True]) >= 16
+    for k in res[False]:
+        assert torch.equal(res[True][k], res[False][k]), k
+    m = full[0, 0] != 0
+    assert float(res[True]["T1"][~m].abs().max()) == 0.0 and float(res[True]["T1"][m].abs().max()) > 0
