@@ -97,8 +97,8 @@ __device__ __forceinline__ void split_store4(const float (&t)[4], unsigned char*
     }
 }
 
-template <int NPASS>
-__global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
+template <int NPASS, bool MASKED>
+__device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
     constexpr int NPL = (NPASS == 3) ? 2 : 1;
     constexpr int NF = 2 * NPL;
     constexpr int BATCH = (NPASS == 3) ? 1 : 3;      // staging items loaded together (register budget: 128 accumulators)
@@ -110,7 +110,15 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
     const int l32 = lane & 31, khalf = lane >> 5;
 
     int bid = blockIdx.x;
-    {
+    if constexpr (MASKED) {
+        // the boxes that hold input cluster in one part of the tile (a corner tile of a head volume: one octant), and one
+        // contiguous eighth per XCD would leave most XCDs idle: runs of 8 boxes go round the XCDs instead
+        const int nfull = (p.nMt * p.NT) & ~63;
+        if (bid < nfull) {
+            const int xcd = bid & 7, idx = bid >> 3;
+            bid = ((idx >> 3) << 6) + (xcd << 3) + (idx & 7);
+        }
+    } else {
         const int nblk = p.nMt * p.NT;
         const int q = nblk >> 3, r = nblk & 7;
         const int xcd = bid & 7, idx = bid >> 3;
@@ -122,7 +130,7 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
     const int tz = mt / (p.nTx * p.nTy);
     const int z0 = tz * p.TD, y0 = ty * p.TH, x0 = tx * p.TW;
 
-    if (p.mask_img) {
+    if constexpr (MASKED) {
         // The caller multiplies this layer's consumers by (image != 0) (the tile loop, scripts/demo_test.py:88-100, and this
         // is the last convolution before the per-voxel heads): outputs of a box whose image voxels are all zero are never
         // looked at, so the box is not computed.  Uniform exit before the first barrier of the main loop.
@@ -459,6 +467,13 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) {
         }
     }
 }
+
+template <int NPASS>
+__global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) { conv_wino_body<NPASS, false>(p); }
+
+// the same kernel for the tile loop's last convolution: boxes whose image voxels (p.mask_img) are all zero return at once
+template <int NPASS>
+__global__ void __launch_bounds__(NTHR, 2) conv_wino_masked(const WinoParams p) { conv_wino_body<NPASS, true>(p); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // Wave-specialised persistent form of conv_wino: 8 waves per workgroup, one workgroup per CU.  Waves 0-3 are the
@@ -1253,6 +1268,10 @@ static int wino_launch(const float* A, int CA, int D, int H, int W, const float*
                             80 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             80 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_masked<3>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_masked<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_done = true;
     }
     if (persistent) {
@@ -1292,6 +1311,11 @@ static int wino_launch(const float* A, int CA, int D, int H, int W, const float*
         }
         if (passes == 3) hipLaunchKernelGGL(conv_wino8<3>, grid, dim3(512), smem8, bfm_s(stream), p);
         else hipLaunchKernelGGL(conv_wino8<1>, grid, dim3(512), smem8, bfm_s(stream), p);
+        return bfm_launch_status();
+    }
+    if (mask_img) {
+        if (passes == 3) hipLaunchKernelGGL(conv_wino_masked<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+        else hipLaunchKernelGGL(conv_wino_masked<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
         return bfm_launch_status();
     }
     if (passes == 3) hipLaunchKernelGGL(conv_wino<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);

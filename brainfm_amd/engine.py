@@ -561,8 +561,8 @@ class UNetEngine:
                 lo = 0 if B is None else lo_dims[0] * lo_dims[1] * lo_dims[2]
                 self.prof.append((ev[0], ev[1], 2.0 * 27 * ly.cin * ly.cout * nv,
                                   4.0 * (nv * ca + lo * cb + nv * ly.cout + 27 * ly.cin * ly.cout), reps,
-                                  (ly.name.replace("backbone.", "").replace(".basic_module.SingleConv", "."), ly.cin,
-                                   ly.cout, tuple(dims), tuple(cfg))))
+                                  (ly.name.replace("backbone.", "").replace(".basic_module.SingleConv", ".")
+                                   + ("[masked]" if mask_img is not None else ""), ly.cin, ly.cout, tuple(dims), tuple(cfg))))
         elif ca == 1 and cb == 0 and ly.cout in (32, 64) and not self.force_direct:
             rows = None
             if self.fuse_stats:
@@ -592,8 +592,11 @@ class UNetEngine:
         m = (mask_img.reshape(D, H, W) != 0)
         m = torch.nn.functional.pad(m, (0, -W % tw, 0, -H % th, 0, -D % td))
         m = m.reshape(m.shape[0] // td, td, m.shape[1] // th, th, m.shape[2] // tw, tw)
-        self.last_mask_fraction = float(m.any(dim=5).any(dim=3).any(dim=1).float().mean().item())
-        return int(round(self.last_mask_fraction * m.numel()))
+        act = m.any(dim=5, keepdim=True).any(dim=3, keepdim=True).any(dim=1, keepdim=True).expand_as(m)
+        act = act.reshape(m.shape[0] * td, m.shape[2] * th, m.shape[4] * tw)[:D, :H, :W]
+        n = int(act.sum().item())
+        self.last_mask_fraction = n / float(D * H * W)
+        return n
 
     def _skip_layer(self, ly, ca):
         """The skip-channel half of a decoder's first conv as a layer of its own (weights w[:, :ca])."""
