@@ -38,12 +38,15 @@ struct UpParams {
     int wexp, Cout;
     float* out;                      // [2d][2h][2w][Cout]
     int BD, BH, BW, HT, WT;          // low-res box and its halo'd extents
-    int bw_shift, bhw_shift;
+    int BHW, BVOX;                   // BH * BW, BD * BH * BW (<= 128; rows past it are padding)
     int nTy, nTx, nMt, NT, KCB;
     int nvox_lds, plane_stride;
     int kc_per_split;                // K chunks per blockIdx.y slab (a multiple of 3: the weight ring's phase period)
-    float* slab;                     // split-K: [gridDim.y][2d][2h][2w][Cout] partial sums, summed by upfold_reduce
+    float* slab;                     // split-K: [sample][gridDim.y][2d][2h][2w][Cout] partial sums, summed by upfold_reduce
     int64_t slab_stride;
+    // batch: blockIdx.z = sample; B, out advance by sB, sO elements per sample, scale / shift by CB, bound by G.  A
+    // sample's workgroups do exactly what they do in a launch of that sample alone.
+    int64_t sB, sO;
 };
 
 __device__ __forceinline__ int row_perm(int l) {        // same lane -> row order as conv_mfma (conflict-free b128)
@@ -56,10 +59,10 @@ __device__ __forceinline__ int row_perm(int l) {        // same lane -> row orde
 }
 
 __device__ __forceinline__ void box_coords(const UpParams& p, int q, int& bd, int& bh, int& bw) {
-    bd = q >> p.bhw_shift;
-    const int rem = q & ((1 << p.bhw_shift) - 1);
-    bh = rem >> p.bw_shift;
-    bw = rem & ((1 << p.bw_shift) - 1);
+    bd = q / p.BHW;
+    const int rem = q - bd * p.BHW;
+    bh = rem / p.BW;
+    bw = rem - bh * p.BW;
 }
 
 template <int NPASS>
@@ -85,9 +88,14 @@ __global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
     const int ty = (mt / p.nTx) % p.nTy;
     const int tz = mt / (p.nTx * p.nTy);
     const int z0 = tz * p.BD, y0 = ty * p.BH, x0 = tx * p.BW;      // low-res box origin
+    const int smp = blockIdx.z;
+    const float* const pB = p.B + smp * p.sB;
+    const float* const pscale = p.scale + smp * p.CB;
+    const float* const pshift = p.shift + smp * p.CB;
+    const float* const pbound = p.bound + smp * p.G;
 
     float bmax = 0.f;
-    for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, p.bound[g]);
+    for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, pbound[g]);
     int aexp = 0;
     if (bmax > 0.f && bmax < INFINITY) {
         int ex;
@@ -104,7 +112,8 @@ __global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         int bd, bh, bw;
-        box_coords(p, mb * 32 + row_perm(l32), bd, bh, bw);
+        const int q = mb * 32 + row_perm(l32);
+        box_coords(p, q < p.BVOX ? q : 0, bd, bh, bw);        // padding rows read row 0 (never stored)
         a_off[mb] = (khalf * NPL) * p.plane_stride + (((bd + pz) * p.HT + (bh + py)) * p.WT + (bw + px)) * 16;
     }
 
@@ -158,9 +167,9 @@ __global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
     auto do_chunk = [&](int kc, auto ph_tag) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_tag)::value;
         const int c0 = kc * KC;
-        const float* src = p.B + c0 + q4 * 4;
-        const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + c0 + q4 * 4);
-        const float4 sh4 = *reinterpret_cast<const float4*>(p.shift + c0 + q4 * 4);
+        const float* src = pB + c0 + q4 * 4;
+        const float4 sc4 = *reinterpret_cast<const float4*>(pscale + c0 + q4 * 4);
+        const float4 sh4 = *reinterpret_cast<const float4*>(pshift + c0 + q4 * 4);
         const float sc[4] = {sc4.x * a_scale, sc4.y * a_scale, sc4.z * a_scale, sc4.w * a_scale};
         const float sh[4] = {sh4.x * a_scale, sh4.y * a_scale, sh4.z * a_scale, sh4.w * a_scale};
         __syncthreads();                                 // previous chunk's readers are done
@@ -233,16 +242,17 @@ __global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
 
     // epilogue: class (pz,py,px) of low-res voxel (zl,yl,xl) is full-res voxel (2zl+pz, 2yl+py, 2xl+px)
     const int H2 = 2 * p.h, W2 = 2 * p.w;
-    float* const obase = p.slab ? p.slab + (int64_t)blockIdx.y * p.slab_stride : p.out;
+    float* const obase = p.slab ? p.slab + ((int64_t)smp * gridDim.y + blockIdx.y) * p.slab_stride : p.out + smp * p.sO;
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int rr = (i >> 2) * 8 + khalf * 4 + (i & 3);
             int bd, bh, bw;
-            box_coords(p, mb * 32 + row_perm(rr), bd, bh, bw);
+            const int q = mb * 32 + row_perm(rr);
+            box_coords(p, q, bd, bh, bw);
             const int zl = z0 + bd, yl = y0 + bh, xl = x0 + bw;
-            if (zl >= p.d || yl >= p.h || xl >= p.w) continue;
+            if (q >= p.BVOX || zl >= p.d || yl >= p.h || xl >= p.w) continue;
             float* orow = obase + (((int64_t)(2 * zl + pz) * H2 + (2 * yl + py)) * W2 + (2 * xl + px)) * p.Cout +
                           nt * 64 + l32;
 #pragma unroll
@@ -253,6 +263,8 @@ __global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
 
 // split-K: out = sum of the slabs in slab order (deterministic)
 __global__ void upfold_reduce(const float4* __restrict__ slab, int nsplit, int64_t n4, float4* __restrict__ out) {
+    slab += (int64_t)blockIdx.y * nsplit * n4;                  // blockIdx.y = sample
+    out += (int64_t)blockIdx.y * n4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 a = slab[i];
         for (int k = 1; k < nsplit; ++k) {
@@ -305,8 +317,6 @@ __global__ void pack_upfold(const float* __restrict__ w, int Cin, int CA, int CB
     }
 }
 
-int ilog2i(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
-
 // low-res box of 128 voxels (powers of two) wasting the fewest rows on the volume's edges
 // The same packing with the 64 (co) x 16 (ci) x 27 block of one (N tile, K chunk) staged through LDS: coalesced reads,
 // every weight read once instead of once per class / folded tap / hi-lo plane that sums it (training re-packs every
@@ -354,14 +364,17 @@ __global__ void __launch_bounds__(256) pack_upfold_tiled(const float* __restrict
 }
 
 void choose_box(int d, int h, int w, int& BD, int& BH, int& BW) {
+    // the last three: 125 / 100 of the 128 rows used, for the small decoder levels (5, 10, 20 voxels per axis), where
+    // the power-of-two boxes waste up to three quarters of their rows on the edges; ties keep the earlier entries
     static const int opts[][3] = {{2, 4, 16}, {4, 2, 16}, {4, 4, 8}, {2, 8, 8}, {8, 2, 8}, {8, 4, 4}, {4, 8, 4},
-                                  {1, 8, 16}, {8, 1, 16}, {2, 2, 32}, {1, 4, 32}, {4, 1, 32}};
+                                  {1, 8, 16}, {8, 1, 16}, {2, 2, 32}, {1, 4, 32}, {4, 1, 32},
+                                  {5, 5, 5}, {2, 5, 10}, {5, 2, 10}};
     int64_t best = -1;
     for (auto& o : opts) {
         if ((o[0] + 2) * (o[1] + 2) * (o[2] + 2) * 4 > 4 * NTHR) continue;
         int64_t cost = (int64_t)bfm_cdiv(d, o[0]) * bfm_cdiv(h, o[1]) * bfm_cdiv(w, o[2]);
         // tie-break towards long x-runs (coalesced staging, conflict-free A reads)
-        cost = cost * 64 - o[2];
+        cost = cost * 64 - (o[2] > 32 ? 32 : o[2]);
         if (best < 0 || cost < best) { best = cost; BD = o[0]; BH = o[1]; BW = o[2]; }
     }
 }
@@ -434,10 +447,36 @@ extern "C" size_t bfm_conv3x3x3_upfold_workspace(int CB, int d, int h, int w, in
     return nsplit > 1 ? (size_t)nsplit * 8 * d * h * w * Cout * sizeof(float) : 0;
 }
 
+static int upfold_launch(const float* B, int CB, int S, int d, int h, int w, const float* scale_b, const float* shift_b,
+                         const float* bound, int G, const void* wpacked, int wexp, int Cout, int passes, float* out,
+                         void* workspace, size_t workspace_bytes, bool strict, bfm_stream_t stream);
+
 extern "C" int bfm_conv3x3x3_upfold_ex(const float* B, int CB, int d, int h, int w, const float* scale_b,
                                        const float* shift_b, const float* bound, int G, const void* wpacked, int wexp,
                                        int Cout, int passes, float* out, void* workspace, size_t workspace_bytes,
                                        bfm_stream_t stream) {
+    return upfold_launch(B, CB, 1, d, h, w, scale_b, shift_b, bound, G, wpacked, wexp, Cout, passes, out, workspace,
+                         workspace_bytes, false, stream);
+}
+
+extern "C" size_t bfm_conv3x3x3_upfold_batch_workspace(int CB, int S, int d, int h, int w, int Cout) {
+    return S > 0 ? (size_t)S * bfm_conv3x3x3_upfold_workspace(CB, d, h, w, Cout) : 0;
+}
+
+extern "C" int bfm_conv3x3x3_upfold_batch(const float* B, int CB, int S, int d, int h, int w, const float* scale_b,
+                                          const float* shift_b, const float* bound, int G, const void* wpacked, int wexp,
+                                          int Cout, int passes, float* out, void* workspace, size_t workspace_bytes,
+                                          bfm_stream_t stream) {
+    if (S <= 0 || S > 65535) return BFM_E_ARG;
+    return upfold_launch(B, CB, S, d, h, w, scale_b, shift_b, bound, G, wpacked, wexp, Cout, passes, out, workspace,
+                         workspace_bytes, true, stream);
+}
+
+// strict (the batch entry point): the split-K plan is a function of the per-sample shape alone, so a workspace too small
+// for it is an error instead of a silent fall-back to one slab -- a sample's bits must not depend on the batch it is in
+static int upfold_launch(const float* B, int CB, int S, int d, int h, int w, const float* scale_b, const float* shift_b,
+                         const float* bound, int G, const void* wpacked, int wexp, int Cout, int passes, float* out,
+                         void* workspace, size_t workspace_bytes, bool strict, bfm_stream_t stream) {
     if (!B || CB <= 0 || d <= 0 || h <= 0 || w <= 0 || !scale_b || !shift_b || !bound || G <= 0 || !wpacked || !out)
         return BFM_E_ARG;
     if (CB % KC || Cout % 64 || Cout <= 0) return BFM_E_SHAPE;
@@ -454,7 +493,7 @@ extern "C" int bfm_conv3x3x3_upfold_ex(const float* B, int CB, int d, int h, int
     p.wexp = wexp; p.Cout = Cout; p.out = out;
     choose_box(d, h, w, p.BD, p.BH, p.BW);
     p.HT = p.BH + 2; p.WT = p.BW + 2;
-    p.bw_shift = ilog2i(p.BW); p.bhw_shift = ilog2i(p.BH * p.BW);
+    p.BHW = p.BH * p.BW; p.BVOX = p.BD * p.BHW;
     const int nTz = bfm_cdiv(d, p.BD);
     p.nTy = bfm_cdiv(h, p.BH); p.nTx = bfm_cdiv(w, p.BW);
     p.nMt = nTz * p.nTy * p.nTx;
@@ -468,10 +507,13 @@ extern "C" int bfm_conv3x3x3_upfold_ex(const float* B, int CB, int d, int h, int
     if ((int64_t)p.nMt * p.NT > 0x7fffffff) return BFM_E_SHAPE;
     int nsplit = 1, per = p.KCB;
     const int64_t nout = (int64_t)8 * d * h * w * Cout;
-    if (workspace) {
+    p.sB = (int64_t)d * h * w * CB;
+    p.sO = nout;
+    if (workspace || strict) {
         upfold_split(CB, d, h, w, Cout, nsplit, per);
-        if (nsplit > 1 && (workspace_bytes < (size_t)nsplit * nout * sizeof(float) ||
+        if (nsplit > 1 && (!workspace || workspace_bytes < (size_t)S * nsplit * nout * sizeof(float) ||
                            (reinterpret_cast<uintptr_t>(workspace) & 15))) {
+            if (strict) return BFM_E_ARG;
             nsplit = 1;
             per = p.KCB;
         }
@@ -479,13 +521,13 @@ extern "C" int bfm_conv3x3x3_upfold_ex(const float* B, int CB, int d, int h, int
     p.kc_per_split = per;
     p.slab = nsplit > 1 ? static_cast<float*>(workspace) : nullptr;
     p.slab_stride = nout;
-    dim3 grid((unsigned)(p.nMt * p.NT), (unsigned)nsplit);
+    dim3 grid((unsigned)(p.nMt * p.NT), (unsigned)nsplit, (unsigned)S);
     if (passes == 3) hipLaunchKernelGGL(conv_upfold<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
     else hipLaunchKernelGGL(conv_upfold<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
     if (nsplit > 1) {
         const int64_t n4 = nout / 4;
         const int nb = (int)std::min<int64_t>(4096, bfm_cdiv64(n4, 256));
-        hipLaunchKernelGGL(upfold_reduce, dim3(nb), dim3(256), 0, bfm_s(stream), reinterpret_cast<const float4*>(p.slab), nsplit,
+        hipLaunchKernelGGL(upfold_reduce, dim3(nb, S), dim3(256), 0, bfm_s(stream), reinterpret_cast<const float4*>(p.slab), nsplit,
                            n4, reinterpret_cast<float4*>(out));
     }
     return bfm_launch_status();

@@ -693,6 +693,8 @@ class UNetEngine:
     deep_from = int(os.environ.get("BFM_DEEP_FROM", "3"))
     deep_batch = os.environ.get("BFM_DEEP_BATCH", "1") != "0"
     DEEP_VERS = (0, 2)                                     # conv_mfma, conv_mfma16: the variants that take a batch
+    deep_upfold = os.environ.get("BFM_DEEP_UPFOLD", "1") != "0"          # fold exact 2x upsamples inside the region too
+    deep_upfold_min = int(os.environ.get("BFM_DEEP_UPFOLD_MIN", "100"))  # fewest low-res voxels per sample worth it
     # The tile loop multiplies every output of a tile by (tile input != 0) (scripts/demo_test.py:88-100): the last
     # convolution and the per-voxel heads leave out the voxels that product discards (BFM_MASK_SKIP=0: compute them all).
     mask_skip = os.environ.get("BFM_MASK_SKIP", "1") != "0"
@@ -746,6 +748,9 @@ class UNetEngine:
             self._batch_stats(ly, A, ca, B, cb, S, dims, lo_dims, upp, scale, shift, bound)
         else:
             scale, shift, bound = stats
+        if (B is not None and self.use_upfold and self.deep_upfold and tuple(dims) == tuple(2 * v for v in lo_dims)
+                and lo_dims[0] * lo_dims[1] * lo_dims[2] >= self.deep_upfold_min):
+            return self._batch_conv_upfold(ly, A, dims, B, lo_dims, scale, shift, bound)
         key = (ly.cin, ly.cout, tuple(dims), B is not None, False, 1)       # trailing 1: a layer of the batched levels
         if key not in self._plan_cache:
             cfg = (C.c_int * 8)()
@@ -793,6 +798,82 @@ class UNetEngine:
                               4.0 * (S * (nv * ca + lo * cb + nv * ly.cout) + 27 * ly.cin * ly.cout), reps,
                               (ly.name.replace("backbone.", "").replace(".basic_module.SingleConv", ".") + ("x%d" % S),
                                ly.cin, ly.cout, tuple(dims), tuple(cfg))))
+        if rows is not None:
+            out._bfm_rows = rows
+        return out
+
+    def _batch_conv_upfold(self, ly, A, dims, B, lo_dims, scale, shift, bound):
+        """A decoder's first conv on a batch, with the exact 2x upsample folded into the weights (as _single_conv_upfold
+        does per tile): the low-res channels through bfm_conv3x3x3_upfold_batch (8 folded taps instead of 27), the skip
+        channels through bfm_conv3x3x3_mfma_batch accumulating onto that.  Which path a layer takes depends on its
+        shapes alone, never on S: a tile's bits do not depend on what it is batched with."""
+        S = A.shape[0]
+        D, H, W = dims
+        ca, cb = A.shape[-1], B.shape[-1]
+        st = L.stream_ptr()
+        sk = self._skip_layer(ly, ca)
+        if "upfold" not in ly.packs:
+            self._make_upfold_pack(ly, ca, cb)
+        ly.touch("upfold")
+        wup, wexp_up = ly.packs["upfold"]
+        # the two halves' GroupNorm affine as contiguous [S][C] tables (the kernels step by their own channel count)
+        sc_a, sh_a = scale[:, :ca].contiguous(), shift[:, :ca].contiguous()
+        sc_b, sh_b = scale[:, ca:].contiguous(), shift[:, ca:].contiguous()
+        out = torch.empty((S, D, H, W, ly.cout), dtype=torch.float32, device=self.device)
+        key = (ca, ly.cout, tuple(dims), False, True, 1)
+        if key not in self._plan_cache:
+            cfg = (C.c_int * 8)()
+            L.check(self.lib.bfm_conv3x3x3_mfma_plan(ca, ly.cout, D, H, W, cfg), "mfma_plan")
+            if cfg[6] not in self.DEEP_VERS:
+                cfg[6] = 0
+            cfg[7] = 1
+            self._plan_cache[key] = cfg
+        cfg = self._plan_cache[key]
+
+        def _launch_skip(c, rows=None, A_=A, S_=S, out_=out, sc=sc_a, sh=sh_a, bd=bound):
+            self._pack(sk, True, c[6])
+            ws = self._workspace(self.lib.bfm_conv3x3x3_mfma_batch_workspace(ca, ly.cout, S_, D, H, W, c[5]))
+            L.check(self.lib.bfm_conv3x3x3_mfma_batch(L.ptr(A_), ca, None, 0, S_, D, H, W, None, L.ptr(sc), L.ptr(sh),
+                                                      L.ptr(bd), ly.groups, L.ptr(sk.wpacked), sk.wexp, ly.cout,
+                                                      self.slope, self.passes, c, L.ptr(out_), L.ptr(ws), ws.numel(),
+                                                      L.ptr(rows[0]) if rows is not None else None, st),
+                    "conv_mfma_batch " + sk.name)
+        if key not in self._tuned:                              # on one sample; trials accumulate onto garbage
+            cfg = self._autotune(sk, key, lambda c: _launch_skip(c, None, A[0:1], 1, out[0:1], sc_a[0:1], sh_a[0:1],
+                                                                 bound[0:1]), vers=self.DEEP_VERS)
+        self._pack(sk, True, cfg[6])
+        nv = D * H * W
+        lo = lo_dims[0] * lo_dims[1] * lo_dims[2]
+        tag = ly.name.replace("backbone.", "").replace(".basic_module.SingleConv", ".")
+        reps = max(1, int(self.prof_reps)) if self.prof is not None else 1
+        ev = None
+        if self.prof is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        wsu = self.lib.bfm_conv3x3x3_upfold_batch_workspace(cb, S, lo_dims[0], lo_dims[1], lo_dims[2], ly.cout)
+        for _ in range(reps):
+            ws = self._workspace(wsu)
+            L.check(self.lib.bfm_conv3x3x3_upfold_batch(L.ptr(B), cb, S, lo_dims[0], lo_dims[1], lo_dims[2], L.ptr(sc_b),
+                                                        L.ptr(sh_b), L.ptr(bound), ly.groups, L.ptr(wup), wexp_up,
+                                                        ly.cout, self.passes, L.ptr(out), L.ptr(ws) if wsu else None,
+                                                        ws.numel() if wsu else 0, st), "conv_upfold_batch " + ly.name)
+        if ev is not None:
+            ev[1].record()
+            self.prof.append((ev[0], ev[1], 2.0 * 27 * cb * ly.cout * nv * S, 4.0 * (S * (lo * cb + nv * ly.cout)), reps,
+                              (tag + "x%dup" % S, cb, ly.cout, tuple(dims), (0,) * 8)))
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        rows = None
+        if self.fuse_stats:
+            n = self.lib.bfm_conv3x3x3_mfma_rows(ca, ly.cout, D, H, W, cfg)
+            if n > 0:
+                rows = (torch.empty(self.lib.bfm_moment_rows_bytes(S * n, ly.cout), dtype=torch.uint8, device=self.device), n)
+        for _ in range(reps):
+            _launch_skip(cfg, rows)
+        if ev is not None:
+            ev[1].record()
+            self.prof.append((ev[0], ev[1], 2.0 * 27 * ca * ly.cout * nv * S, 4.0 * S * (nv * ca + 2 * nv * ly.cout), reps,
+                              (tag + "x%dsk" % S, ca, ly.cout, tuple(dims), tuple(cfg))))
         if rows is not None:
             out._bfm_rows = rows
         return out

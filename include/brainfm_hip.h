@@ -205,6 +205,14 @@ size_t bfm_conv3x3x3_upfold_workspace(int CB, int d, int h, int w, int Cout);
 int bfm_conv3x3x3_upfold_ex(const float* B, int CB, int d, int h, int w, const float* scale_b, const float* shift_b,
                             const float* bound, int G, const void* wpacked, int wexp, int Cout, int passes, float* out,
                             void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+/* S same-shape samples in one launch (the batched deep levels): B [S][d][h][w][CB], scale_b / shift_b [S][CB] (contiguous
+ * per sample), bound [S][G], out [S][2d][2h][2w][Cout].  A sample's result is bit-identical to its S = 1 launch: the
+ * split-K plan depends on the per-sample shape alone, and a workspace smaller than _batch_workspace() is an error. */
+size_t bfm_conv3x3x3_upfold_batch_workspace(int CB, int S, int d, int h, int w, int Cout);
+int bfm_conv3x3x3_upfold_batch(const float* B, int CB, int S, int d, int h, int w, const float* scale_b,
+                               const float* shift_b, const float* bound, int G, const void* wpacked, int wexp, int Cout,
+                               int passes, float* out, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+
 int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB, int D, int H, int W,
                        const bfm_upsample_t* up, const float* scale, const float* shift, const float* bound,
                        int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
