@@ -858,14 +858,14 @@ def test_deep_levels_batched_over_tiles_equal_the_single_tile_path_bit_for_bit()
     """Levels >= 3 of the shipped architecture run over a batch of same-shape tiles (one launch per layer, weights read
     once; GroupNorm statistics per sample).  Every workgroup does what it does for a single tile, so: (1) a tile's
     features are bit-identical whether it runs alone (S = 1) or batched with others, in any position of the batch;
-    (2) the batched path agrees with the per-layer path of round 1 (BFM_DEEP_BATCH=0: other conv variants, up-folded
-    dec1.1) to fp32 rounding."""
+    (2) the batched path (generic gather, or the batched up-folded kernel where a level has >= 100 voxels) agrees with
+    the per-layer path of round 1 (BFM_DEEP_BATCH=0: other conv variants) to fp32 rounding."""
     from brainfm_amd.engine import UNetEngine
     sd = O.random_state_dict(1, 64, 6, seed=3)
     eng = UNetEngine(sd, in_channels=1, f_maps=64, num_levels=6, device=_dev())
     assert eng.has_deep_region()
     g = torch.Generator().manual_seed(9)
-    for dims in ((64, 64, 96), (32, 64, 32)):
+    for dims in ((64, 64, 96), (32, 64, 32), (96, 64, 160)):
         xs = [torch.rand(dims + (1,), generator=g).to(_dev()) for _ in range(3)]
         xs[1][: dims[0] // 2] = 0                                   # a half-empty tile: constant input to GroupNorm
         single = [eng.backbone_cl(x, dims) for x in xs]
@@ -882,6 +882,9 @@ def test_deep_levels_batched_over_tiles_equal_the_single_tile_path_bit_for_bit()
             eng.deep_batch = True
         for (a, da), (b, db) in zip(single[0], old):
             assert da == db and _relerr(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5, (dims, da, _relerr(a.cpu().numpy(), b.cpu().numpy()))
+    # the last shape has 6x4x10 = 240 voxels at level 4: decoder 1's first conv went through the batched up-folded kernel
+    # (5x5x5 boxes, split-K), the smaller shapes' through the generic gather
+    assert "upfold" in eng.dec[1][0].packs and "upfold" not in eng.dec[0][0].packs
 
 
 def test_matrix_core_path_vs_reference_golden_64_wide():
