@@ -299,24 +299,38 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
                 float sv[LIM];
 #pragma unroll
                 for (int s = 0; s < LIM; ++s) sv[s] = (NS > 0 || s < ns) ? sl[s] : -INFINITY;
-                float m = -INFINITY;
-#pragma unroll
-                for (int s = 0; s < LIM; ++s) m = fmaxf(m, sv[s]);
-                float sum = 0.f;
-#pragma unroll
-                for (int s = 0; s < LIM; ++s) { sv[s] = fast_exp(sv[s] - m); sum += sv[s]; }
-                const float rs = 1.f / sum;
-                float bp = -1.f;
+                // largest and second largest logit.  The label is argmax over the softmax PROBABILITIES (first maximum,
+                // __init__.py:347-349); when nobody asks for the probabilities and the top logit leads by more than
+                // ARGMAX_GAP, its probability exp2(0) * rs = rs exceeds every other exp2(-gap * log2 e) * rs by >= 160 ulps
+                // (v_exp_f32 is good to 1 ulp, the multiply by rs is monotone), so the 56 exponentials are skipped.  A closer
+                // call anywhere in the wave takes the full softmax for the whole wave.
+                constexpr float ARGMAX_GAP = 1e-5f;
+                float m = -INFINITY, m2 = -INFINITY, chk = 0.f;
                 int best = 0;
 #pragma unroll
                 for (int s = 0; s < LIM; ++s) {
-                    sv[s] = sv[s] * rs;
-                    if (sv[s] > bp) { bp = sv[s]; best = s; }    // first maximum wins (torch.argmax)
+                    const float x = sv[s];
+                    chk += x;                                      // NaN / +inf / mixed infinities end up non-finite here
+                    if (x > m) { m2 = m; m = x; best = s; } else m2 = fmaxf(m2, x);
                 }
-                if (p.seg_prob) {
+                const bool sure = p.seg_prob == nullptr && (m - m2) > ARGMAX_GAP && fabsf(chk) < INFINITY;
+                if (__any(!sure)) {
+                    float sum = 0.f;
 #pragma unroll
-                    for (int s = 0; s < LIM; ++s)
-                        if (NS > 0 || s < ns) sl[s] = sv[s];
+                    for (int s = 0; s < LIM; ++s) { sv[s] = fast_exp(sv[s] - m); sum += sv[s]; }
+                    const float rs = 1.f / sum;
+                    float bp = -1.f;
+                    best = 0;
+#pragma unroll
+                    for (int s = 0; s < LIM; ++s) {
+                        sv[s] = sv[s] * rs;
+                        if (sv[s] > bp) { bp = sv[s]; best = s; }    // first maximum wins (torch.argmax)
+                    }
+                    if (p.seg_prob) {
+#pragma unroll
+                        for (int s = 0; s < LIM; ++s)
+                            if (NS > 0 || s < ns) sl[s] = sv[s];
+                    }
                 }
                 if (p.label) p.label[v] = (int64_t)s_lut[best];
             } else if (live) {
