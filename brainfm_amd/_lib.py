@@ -167,6 +167,10 @@ SIGNATURES = {
     "bfm_pack_tile_multi": (_I, [_P, _L, _P, _I, _P, _P, _L, _P, _P]),
     "bfm_divide_by_count_multi": (_I, [_P, _P, _L, _I, _P]),
     "bfm_stitch_gather_multi": (_I, [_P, _I, _I, _P, _I, _I, _I, _P]),
+    "bfm_tile_mask_blocks": (_I, [_L]),
+    "bfm_tile_mask_index": (_I, [_P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P]),
+    "bfm_pack_tile_compact": (_I, [_P, _L, _P, _I, _P, _P, _L, _P, _L, _P, _P]),
+    "bfm_stitch_gather_compact": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _P]),
 }
 
 _lib = None

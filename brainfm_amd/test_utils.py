@@ -390,6 +390,13 @@ class InferenceSession:
                 self._graph_pool[lane] = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
             eng.lane = lane
+            # no cyclic garbage collection inside the capture: an earlier session (its graphs, their private pools) that
+            # is only reachable through a reference cycle would be torn down by whichever allocation trips the collector,
+            # and destroying a graph while this thread captures aborts the process (seen with two sessions in one test)
+            import gc
+            gc.collect()
+            gc_was_on = gc.isenabled()
+            gc.disable()
             try:
                 # thread_local: a collective still in flight on a communication thread (gloo stages through the host,
                 # RCCL's watchdog polls events) must not invalidate this thread's capture
@@ -397,6 +404,8 @@ class InferenceSession:
                     outs = _run_group(self, [static_in[s_:s_ + 1] for s_ in range(S)])
             finally:
                 eng.lane = 0
+                if gc_was_on:
+                    gc.enable()
             self._graphs[key] = (g, static_in, outs)
         g, static_in, outs = self._graphs[key]
         for s_, im in enumerate(ims):
@@ -667,6 +676,9 @@ def _tiled_inference_lanes(full_im, session, ranges, shape, stride, win_size):
     main = torch.cuda.current_stream(dev)
     start = torch.cuda.Event()
     start.record(main)                                         # the input is in place, last volume's rows are consumed
+    # compact rows (only what the tile mask keeps is packed and read back): every slot keeps its full-size stride here,
+    # so nothing about the volume has to reach the host
+    index = ops.index_volume(full_im, ranges) if COMPACT else None
     last, keys = {}, None
     for batch in tile_batches(ranges):                         # same-shape tiles together: the deep levels run batched
         k = min(range(nl), key=lambda j: (load[j], j))
@@ -674,14 +686,15 @@ def _tiled_inference_lanes(full_im, session, ranges, shape, stride, win_size):
         ims = [full_im[:, :, ranges[i][0][0]:ranges[i][0][1], ranges[i][1][0]:ranges[i][1][1],
                        ranges[i][2][0]:ranges[i][2][1]] for i in batch]
         outs = [buf[offs[i]:offs[i] + tile_cost(ranges[i]) * nkeys] for i in batch]
-        keys, _, done = ops.run_group(ims, outs, lane=k, after=start)
+        keys, _, done = ops.run_group(ims, outs, lane=k, after=start, index=index, tiles_idx=batch,
+                                      strides=[tile_cost(ranges[i]) for i in batch])
         if done is not None:
             last[k] = done
     for ev in last.values():
         main.wait_event(ev)
     srcs = [buf[offs[i]:offs[i] + tile_cost(r) * nkeys].view(nkeys, tile_cost(r)) for i, r in enumerate(ranges)]
     acc_buf = torch.empty((nkeys,) + tuple(shape), dtype=torch.float32, device=dev)
-    ops.gather_all(acc_buf, srcs, ranges, shape)
+    ops.gather_all(acc_buf, srcs, ranges, shape, index=index)
     cnt = _cached_count_volume(session, shape, ranges, stride, win_size, dev)
     return OrderedDict((k_, acc_buf[j]) for j, k_ in enumerate(keys)), ranges, cnt
 
@@ -795,38 +808,97 @@ def tile_batches(ranges, idxs=None, group_max=None, min_batches=1):
     return out
 
 
+COMPACT = os.environ.get("BFM_COMPACT", "1") != "0"    # tiles' rows hold the voxels the tile mask keeps only (0: all of them)
+
+
+class TileIndex:
+    """HipStitchOps.index_volume's result: volume (D,H,W) fp32, pos (int32, all tiles' entries back to back), base[i] /
+    sizes[i] = tile i's slice of pos, nnz_dev / nnz = surviving voxels per tile (device / host or None), ready (event)."""
+
+
 class HipStitchOps:
     """Device-side pack / accumulate used by the multi-GPU path (HIP kernels, one launch per tile each)."""
 
     def __init__(self, session):
-        self.session = session
+        import weakref
+        self._session = weakref.ref(session) if session is not None else None   # the session owns its ops: no cycle
         self.lib = L.load()
         self._sel = {}
         self._lane_after = {}
+
+    @property
+    def session(self):
+        return self._session() if self._session is not None else None
 
     def _identity(self, k, dev):
         if (k, dev) not in self._sel:
             self._sel[(k, dev)] = torch.arange(k, dtype=torch.int32, device=dev)
         return self._sel[(k, dev)]
 
-    def run_group(self, ims, outs=None, lane=None, after=None):
+    def index_volume(self, full_im, ranges, counts=False):
+        """The compact shipping form's index of one volume (bfm_tile_mask_index): for every tile of `ranges`, the column
+        of each of its voxels among the tile's surviving (input != 0) voxels, computed from the volume before any tile
+        runs (three launches on the current stream).  counts=True also brings the tiles' survivor counts to the host
+        (one small copy + a wait for those three kernels): the multi-GPU exchange sizes its buffers with them.
+        Returns None when the volume has more than one channel (the mask is then not a function of one image)."""
+        if full_im.dim() != 5 or full_im.shape[0] != 1 or full_im.shape[1] != 1:
+            return None
+        dev = full_im.device
+        vol = full_im[0, 0]
+        if vol.dtype != torch.float32 or not vol.is_contiguous():
+            vol = vol.to(torch.float32).contiguous()
+        shape = tuple(vol.shape)
+        key = ("index", shape, tuple(tuple(r_) for r in ranges for r_ in r), dev)
+        ent = self._sel.get(key)
+        if ent is None:
+            rows, base, blk = [], 0, 0
+            for r in ranges:
+                dims = [b - a for a, b in r]
+                n = dims[0] * dims[1] * dims[2]
+                rows.append([base, r[0][0], r[1][0], r[2][0], dims[0], dims[1], dims[2], blk])
+                base += n
+                blk += self.lib.bfm_tile_mask_blocks(n)
+            ent = self._sel[key] = dict(
+                tab=torch.tensor(rows, dtype=torch.int64).to(dev), base=[r_[0] for r_ in rows], blocks=blk,
+                pos=torch.empty(base, dtype=torch.int32, device=dev),
+                nnz=torch.empty(len(ranges), dtype=torch.int32, device=dev),
+                ws=torch.empty(blk, dtype=torch.int32, device=dev))
+        L.check(self.lib.bfm_tile_mask_index(L.ptr(vol), shape[0], shape[1], shape[2], L.ptr(ent["tab"]), len(ranges),
+                                             ent["blocks"], L.ptr(ent["pos"]), L.ptr(ent["nnz"]), L.ptr(ent["ws"]),
+                                             L.stream_ptr()), "tile_mask_index")
+        idx = TileIndex()
+        idx.volume, idx.pos, idx.base, idx.nnz_dev = vol, ent["pos"], ent["base"], ent["nnz"]
+        idx.sizes = [tile_cost(r) for r in ranges]
+        idx.ready = torch.cuda.Event()
+        idx.ready.record(torch.cuda.current_stream(dev))
+        idx.nnz = [int(v) for v in ent["nnz"].cpu().tolist()] if counts else None
+        return idx
+
+    def run_group(self, ims, outs=None, lane=None, after=None, index=None, tiles_idx=None, strides=None):
         """Masked, float typed [K][n] rows of every tile of a same-shape batch (written into ``outs[i]`` when given: the
         send buffer / stitch slots).  lane / after: replay the batch's graph and pack on that lane's stream once event
         ``after`` (recorded on the caller's stream) has passed; the third return value is then the event to wait for
-        before reading the rows.  Returns (keys, [rows per tile], event | None)."""
+        before reading the rows.  index / tiles_idx / strides: pack the compact form instead (index_volume; the batch's
+        tile numbers; the row stride of each: [K][stride] with the surviving voxels in the first columns).
+        Returns (keys, [rows per tile], event | None)."""
         sess = self.session
         dims = tuple(ims[0].shape[2:])
         S = len(ims)
         outs = outs if outs is not None else [None] * S
+        cp = [None] * S
+        if index is not None:
+            cp = [(index.pos[index.base[i]:index.base[i] + index.sizes[i]], int(rs)) for i, rs in zip(tiles_idx, strides)]
         on_lane = (lane is not None and sess.use_graphs and sess.has_graph(dims, lane, S))
         if on_lane:
             st = sess.lane_streams(sess.lanes)[lane]
             if after is not None:
                 st.wait_event(after)
+            if index is not None:
+                st.wait_event(index.ready)
             if lane in self._lane_after:                       # an eager / capture pass of this lane ran on the caller's
                 st.wait_event(self._lane_after.pop(lane))      # stream: its buffers share the lane's graph pool
             with torch.cuda.stream(st):
-                res = [self._tile_rows(o, out) for o, out in zip(sess.graph_group(ims, lane=lane), outs)]
+                res = [self._tile_rows(o, out, c) for o, out, c in zip(sess.graph_group(ims, lane=lane), outs, cp)]
                 done = torch.cuda.Event()
                 done.record(st)
             return res[0][0], [r[1] for r in res], done
@@ -836,7 +908,9 @@ class HipStitchOps:
             tiles = sess.graph_group(ims, lane=lane or 0)
         else:
             tiles = _run_group(sess, ims)
-        res = [self._tile_rows(o, out) for o, out in zip(tiles, outs)]
+        if index is not None:
+            torch.cuda.current_stream(sess.device).wait_event(index.ready)
+        res = [self._tile_rows(o, out, c) for o, out, c in zip(tiles, outs, cp)]
         if lane is not None and sess.use_graphs:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(sess.device))
@@ -848,7 +922,7 @@ class HipStitchOps:
         keys, rows, done = self.run_group([im], [out], lane=lane, after=after)
         return (keys, rows[0], done) if lane is not None else (keys, rows[0])
 
-    def _tile_rows(self, outs, out):
+    def _tile_rows(self, outs, out, compact=None):
         maps_buf, names, label, x_cl = outs
         keys = [k for k in STITCH_KEYS if k in names or (k == "label" and label is not None)]
         skey = (tuple(names), label is not None)
@@ -856,6 +930,18 @@ class HipStitchOps:
             self._sel[skey] = torch.tensor([names.index(k) if k != "label" else -1 for k in keys], dtype=torch.int32,
                                            device=x_cl.device)
         n = x_cl.numel()
+        if compact is not None:
+            pos, rs = compact
+            if pos.numel() != n:
+                raise L.BfmError("tile index has %d entries, the tile %d voxels" % (pos.numel(), n))
+            rows = out if out is not None else torch.empty(len(keys) * rs, dtype=torch.float32, device=x_cl.device)
+            if rows.numel() < len(keys) * rs:
+                raise L.BfmError("compact rows need %d floats, the slot has %d" % (len(keys) * rs, rows.numel()))
+            if rs > 0:                                         # rs == 0: an all-zero tile keeps nothing
+                L.check(self.lib.bfm_pack_tile_compact(L.ptr(maps_buf), n, L.ptr(self._sel[skey]), len(keys),
+                                                       L.ptr(label), L.ptr(x_cl), n, L.ptr(pos), rs, L.ptr(rows),
+                                                       L.stream_ptr()), "pack_tile_compact")
+            return keys, rows[:len(keys) * rs].view(len(keys), rs)
         rows = out if out is not None else torch.empty(len(keys) * n, dtype=torch.float32, device=x_cl.device)
         L.check(self.lib.bfm_pack_tile_multi(L.ptr(maps_buf), n, L.ptr(self._sel[skey]), len(keys), L.ptr(label),
                                              L.ptr(x_cl), n, L.ptr(rows), L.stream_ptr()), "pack_tile_multi")
@@ -869,10 +955,24 @@ class HipStitchOps:
                                                      None, x1 - x0, y1 - y0, z1 - z0, L.ptr(acc_buf), shape[0],
                                                      shape[1], shape[2], x0, y0, z0, L.stream_ptr()), "stitch_multi")
 
-    def gather_all(self, acc_buf, srcs, ranges, shape):
+    def gather_all(self, acc_buf, srcs, ranges, shape, index=None):
         """acc_buf [K][D,H,W] = the whole stitch in one launch: srcs[i] = packed rows [K][n_i] of tile i (reference
         order), every voxel summed over its tiles in that order, divided by their number, written once
-        (bfm_stitch_gather_multi; same bits as add_all per tile on a zeroed volume + finalize_all)."""
+        (bfm_stitch_gather_multi; same bits as add_all per tile on a zeroed volume + finalize_all).
+        index: the rows are compact ([K][stride_i], run_group(index=...)) -> bfm_stitch_gather_compact."""
+        if index is not None:
+            key = tuple((s_.data_ptr(), index.pos.data_ptr() + 4 * index.base[i]) + tuple(a for a, _ in r) +
+                        tuple(b - a for a, b in r) + (s_.shape[1] if s_.dim() == 2 else 0,)
+                        for i, (s_, r) in enumerate(zip(srcs, ranges)))
+            tab = self._sel.get(("gatherc", acc_buf.device))
+            if tab is None or tab[0] != key:
+                host = torch.tensor([list(k_) + [0] for k_ in key], dtype=torch.int64)
+                tab = self._sel[("gatherc", acc_buf.device)] = (key, host.to(acc_buf.device))
+            torch.cuda.current_stream(acc_buf.device).wait_event(index.ready)
+            L.check(self.lib.bfm_stitch_gather_compact(L.ptr(tab[1]), len(ranges), acc_buf.shape[0], L.ptr(index.volume),
+                                                       L.ptr(acc_buf), shape[0], shape[1], shape[2], L.stream_ptr()),
+                    "stitch_gather_compact")
+            return
         key = tuple((s_.data_ptr(),) + tuple(a for a, _ in r) + tuple(b - a for a, b in r) for s_, r in zip(srcs, ranges))
         tab = self._sel.get(("gather", acc_buf.device))
         if tab is None or tab[0] != key:
@@ -977,6 +1077,13 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
     nlanes = session.lanes if (session is not None and getattr(session, "use_graphs", False)) else 1
     batches_of = [tile_batches(ranges, [i for i in range(len(ranges)) if owner[i] == r], min_batches=nlanes)
                   for r in range(world)]
+    # compact rows: a tile ships the voxels its mask keeps (known from the volume on every rank before any tile runs:
+    # HipStitchOps.index_volume brings the counts to the host, the same on every rank) -- 1/5 of the bytes on a head in
+    # a 256^3 box
+    index = None
+    if direct and COMPACT and GATHER_STITCH and dev.type == "cuda" and hasattr(ops, "index_volume"):
+        index = ops.index_volume(full_im, ranges, counts=True)
+    width = [index.nnz[i] if index is not None else tile_cost(r) for i, r in enumerate(ranges)]   # columns per row
     nrounds = max([len(b) for b in batches_of] + [1]) if rounds else 1
     round_of, off_of = {}, {}
     round_numel = [1] * nrounds
@@ -987,7 +1094,7 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
             kk = k if rounds else 0
             for i in batch:
                 round_of[i], off_of[i] = kk, fill[kk]
-                fill[kk] += tile_cost(ranges[i]) * nkeys
+                fill[kk] += width[i] * nkeys
         for kk in range(nrounds):
             if r == 0:
                 own_numel[kk] = max(own_numel[kk], fill[kk])
@@ -1020,7 +1127,8 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
         for batch in todo:
             ims = [full_im[:, :, ranges[i][0][0]:ranges[i][0][1], ranges[i][1][0]:ranges[i][1][1],
                            ranges[i][2][0]:ranges[i][2][1]] for i in batch]
-            outs = [dst[off_of[i]:off_of[i] + tile_cost(ranges[i]) * nkeys] for i in batch]
+            outs = [dst[off_of[i]:off_of[i] + width[i] * nkeys] for i in batch]
+            cargs = dict(index=index, tiles_idx=batch, strides=[width[i] for i in batch]) if index is not None else {}
             lane = min(range(lanes), key=lambda j: (lane_load[j], j))
             lane_load[lane] += sum(tile_time(ranges[i]) for i in batch)
             if direct and session is not None and session.use_graphs and \
@@ -1031,14 +1139,14 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
                 # this rank's batches run on its lanes' streams, independently of each other; the gather of a round waits
                 # for that round's tiles only -- and on rank 0 for none: its receives are posted at once, whatever it is
                 # still computing itself
-                keys, _, done = ops.run_group(ims, outs, lane=lane, after=start)
+                keys, _, done = ops.run_group(ims, outs, lane=lane, after=start, **cargs)
                 if done is not None:
                     if rank == 0:
                         pending.append(done)
                     else:
                         torch.cuda.current_stream(dev).wait_event(done)
             elif direct:
-                keys, _, _ = ops.run_group(ims, outs)
+                keys, _, _ = ops.run_group(ims, outs, **cargs)
             else:
                 for i, im in zip(batch, ims):
                     keys, rows = ops.run_tile(im)
@@ -1059,7 +1167,7 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
         torch.cuda.current_stream(dev).wait_event(ev)
     srcs = []
     for i, rng in enumerate(ranges):                          # reference tile order
-        nv = tile_cost(rng)
+        nv = width[i]
         src = own[round_of[i]] if owner[i] == 0 else gathered[round_of[i]][owner[i]]
         srcs.append(src[off_of[i]:off_of[i] + nv * nkeys].reshape(nkeys, nv))
     if session is not None and direct:
@@ -1068,7 +1176,10 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
         cnt = count_volume(shape, ranges, dev)
     if hasattr(ops, "gather_all") and GATHER_STITCH:
         acc_buf = torch.empty((nkeys,) + shape, dtype=torch.float32, device=dev)
-        ops.gather_all(acc_buf, srcs, ranges, shape)          # one launch: sum in tile order, / count, write once
+        if index is not None:
+            ops.gather_all(acc_buf, srcs, ranges, shape, index=index)
+        else:
+            ops.gather_all(acc_buf, srcs, ranges, shape)      # one launch: sum in tile order, / count, write once
     else:
         acc_buf = torch.zeros((nkeys,) + shape, dtype=torch.float32, device=dev)
         for rng, rows in zip(ranges, srcs):

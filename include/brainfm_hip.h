@@ -303,6 +303,27 @@ int bfm_divide_by_count_multi(float* full, const float* cnt, int64_t vol, int K,
  * Bit-identical to T x bfm_stitch_accumulate_multi on a zeroed volume + bfm_divide_by_count_multi. */
 int bfm_stitch_gather_multi(const int64_t* tiles, int T, int K, float* full, int D, int H, int W, bfm_stream_t stream);
 
+/* The compact shipping form of the same flow.  scripts/demo_test.py:88-100 keeps tile_output * (tile input != 0), and a
+ * tile's input is a window of the volume: which voxels of a tile survive is known from the volume alone, on every rank,
+ * before any tile is computed.  A tile's K rows then hold its surviving voxels only, in the tile's raster order:
+ * rows [K][row_stride], voxel i of the tile at column pos[i] = the number of non-zero input voxels before i in the tile.
+ *   bfm_tile_mask_index: pos[] of every tile and nnz[t] = its number of surviving voxels, three launches per volume.
+ *     tiles: device table [T][8] int64 = {offset of the tile's first entry in pos[], z0, y0, x0, td, th, tw, first block},
+ *     first block = sum of bfm_tile_mask_blocks(td*th*tw) over the tiles before it, total_blocks = that sum over all
+ *     tiles; block_ws: total_blocks int32 of scratch.
+ *   bfm_pack_tile_compact: bfm_pack_tile_multi writing the surviving voxels only (row_stride >= the tile's nnz).
+ *   bfm_stitch_gather_compact: bfm_stitch_gather_multi reading such rows; tiles [T][10] int64 = {rows, the tile's pos,
+ *     z0, y0, x0, td, th, tw, row_stride, 0}, volume = the (D,H,W) input the masks come from; T <= 1024.
+ * Results are bit-identical to the dense form (a masked-out voxel adds +0 in every tile). */
+int bfm_tile_mask_blocks(int64_t tile_voxels);
+int bfm_tile_mask_index(const float* volume, int D, int H, int W, const int64_t* tiles, int T, int total_blocks,
+                        int32_t* pos, int32_t* nnz, int32_t* block_ws, bfm_stream_t stream);
+int bfm_pack_tile_compact(const float* maps, int64_t map_stride, const int32_t* sel, int K, const int64_t* tile_label,
+                          const float* tile_input, int64_t n, const int32_t* pos, int64_t row_stride, float* out,
+                          bfm_stream_t stream);
+int bfm_stitch_gather_compact(const int64_t* tiles, int T, int K, const float* volume, float* full, int D, int H, int W,
+                              bfm_stream_t stream);
+
 /* ------------------------------------------------------------ elementwise
  * Per-voxel helpers for the stand-alone processors / post-processor
  * (joiner.py:69-77,149-157; Trainer/models/__init__.py:272-354) and the

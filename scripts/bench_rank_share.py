@@ -38,6 +38,7 @@ def share(rank):
     main = torch.cuda.current_stream(dev)
     start = torch.cuda.Event()
     start.record(main)
+    index = ops.index_volume(full, ranges) if TU.COMPACT else None
     load, last = [0] * sess.lanes, {}
     for batch in batches_of[rank]:
         k = min(range(sess.lanes), key=lambda j: (load[j], j))
@@ -45,13 +46,14 @@ def share(rank):
         ims = [full[:, :, ranges[i][0][0]:ranges[i][0][1], ranges[i][1][0]:ranges[i][1][1], ranges[i][2][0]:ranges[i][2][1]]
                for i in batch]
         outs = [buf[offs[i]:offs[i] + TU.tile_cost(ranges[i]) * nkeys] for i in batch]
-        _, _, done = ops.run_group(ims, outs, lane=k, after=start)
+        _, _, done = ops.run_group(ims, outs, lane=k, after=start, index=index, tiles_idx=batch,
+                                   strides=[TU.tile_cost(ranges[i]) for i in batch])
         if done is not None:
             last[k] = done
     for ev in last.values():
         main.wait_event(ev)
     if rank == 0:
-        ops.gather_all(acc, srcs, ranges, (n, n, n))
+        ops.gather_all(acc, srcs, ranges, (n, n, n), index=index)
     return [i for b_ in batches_of[rank] for i in b_]
 
 

@@ -1008,3 +1008,58 @@ def test_tile_loop_mask_skip_changes_no_stitched_bit():
         assert torch.equal(res[True][k], res[False][k]), k
     m = full[0, 0] != 0
     assert float(res[True]["T1"][~m].abs().max()) == 0.0 and float(res[True]["T1"][m].abs().max()) > 0
+
+
+@pytest.mark.parametrize("shape,win,stride", [((40, 36, 44), 24, 12), ((60, 52, 70), 16, 8), ((33, 20, 17), 20, 10)])
+def test_compact_rows_index_pack_and_stitch_equal_the_dense_form_bitwise(shape, win, stride):
+    """The compact shipping form (bfm_tile_mask_index / bfm_pack_tile_compact / bfm_stitch_gather_compact) against the
+    dense one (bfm_pack_tile_multi / bfm_stitch_gather_multi) on the same tile maps: the index is the exclusive count of
+    non-zero input voxels in tile raster order (numpy cumsum; NaN and negative inputs count, -0.0 does not), the
+    counts reach the host, and the stitched volume is bit-identical -- with the dense stride per slot (single GPU) and
+    with stride = count (what travels between ranks).  Tiles of 1-3 blocks of the index scan, ragged volume, 343 tiles."""
+    from brainfm_amd import test_utils as TU
+    from brainfm_amd import _lib as L
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    vol = torch.rand(shape, generator=g)
+    zz, yy, xx = np.meshgrid(*[np.linspace(-1, 1, n_) for n_ in shape], indexing="ij")
+    vol = vol * torch.from_numpy(((zz / 0.9) ** 2 + (yy / 0.7) ** 2 + (xx / 0.8) ** 2 < 1).astype(np.float32))
+    vol[shape[0] // 2, shape[1] // 2, :5] = torch.tensor([float("nan"), -1.0, -0.0, 0.0, 2.0])
+    full = vol[None, None].to(dev)
+    ranges = TU.tiling_ranges(shape, [stride] * 3, [win] * 3)
+    K, nmaps = 5, 6
+    ops = TU.HipStitchOps(None)
+    idx = ops.index_volume(full, ranges, counts=True)
+    torch.cuda.synchronize()
+    sel = torch.tensor([0, 2, -1, 5, 3], dtype=torch.int32, device=dev)
+    dense, comp_cap, comp_nnz = [], [], []
+    for i, r in enumerate(ranges):
+        tin = full[0, 0, r[0][0]:r[0][1], r[1][0]:r[1][1], r[2][0]:r[2][1]].contiguous()
+        n = tin.numel()
+        m = (tin.cpu().numpy().reshape(-1) != 0)
+        want = np.cumsum(m) - m
+        got = idx.pos[idx.base[i]:idx.base[i] + n].cpu().numpy()
+        assert idx.nnz[i] == int(m.sum()) and np.array_equal(got, want), (i, r)
+        maps = (torch.randn((nmaps, n), generator=g) * 3).to(dev)
+        maps[:, ~torch.from_numpy(m).to(dev)] = float("nan")              # what the skipping kernels leave behind
+        label = torch.randint(0, 2000, (n,), generator=g).to(dev)
+        d = torch.empty(K * n, device=dev)
+        L.check(ops.lib.bfm_pack_tile_multi(L.ptr(maps), n, L.ptr(sel), K, L.ptr(label), L.ptr(tin), n, L.ptr(d),
+                                            L.stream_ptr()), "pack")
+        dense.append(d.view(K, n))
+        for rs, lst in ((n, comp_cap), (idx.nnz[i], comp_nnz)):
+            c = torch.full((K * rs,), float("nan"), device=dev)
+            pos = idx.pos[idx.base[i]:idx.base[i] + n]
+            if rs > 0:
+                L.check(ops.lib.bfm_pack_tile_compact(L.ptr(maps), n, L.ptr(sel), K, L.ptr(label), L.ptr(tin), n,
+                                                      L.ptr(pos), rs, L.ptr(c), L.stream_ptr()), "pack_compact")
+            lst.append(c.view(K, rs))
+        sel_d = dense[-1][:, torch.from_numpy(m).to(dev)]
+        assert torch.equal(comp_nnz[-1].view(torch.int32), sel_d.view(torch.int32))
+    ref = torch.full((K,) + tuple(shape), float("nan"), device=dev)
+    ops.gather_all(ref, dense, ranges, shape)
+    for rows in (comp_cap, comp_nnz):
+        out = torch.full((K,) + tuple(shape), float("nan"), device=dev)
+        ops.gather_all(out, rows, ranges, shape, index=idx)
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
