@@ -699,16 +699,35 @@ class UNetEngine:
     # convolution and the per-voxel heads leave out the voxels that product discards (BFM_MASK_SKIP=0: compute them all).
     mask_skip = os.environ.get("BFM_MASK_SKIP", "1") != "0"
 
+    # A small tile's level deep_from - 1 is small too (80^3: 20^3 voxels of 256 channels -- launches of 60-100 us that
+    # fill a fifth of the chip): the region starts one level higher for tiles whose level there has at most this many
+    # voxels.  A function of the tile shape alone, like everything that decides which kernels a tile runs.
+    deep_vox = int(os.environ.get("BFM_DEEP_VOX", "8000"))
+
+    def _region_ok(self, df):
+        cache = self.__dict__.setdefault("_deep_ok", {})
+        if df not in cache:                                  # every layer of the region must be a matrix-core layer
+            ndeep = len(self.enc) - 1 - df
+            layers = [ly for pair in self.enc[df:] + self.dec[:ndeep] for ly in pair]
+            cache[df] = all(ly.cin % 16 == 0 and ly.cout % 64 == 0 for ly in layers) and \
+                self.enc[df - 1][1].cout % 16 == 0
+        return cache[df]
+
     def has_deep_region(self):
         if not (self.deep_batch and self.tape is None and not self.force_direct and len(self.fm) > self.deep_from >= 1):
             return False
-        ok = getattr(self, "_deep_ok", None)
-        if ok is None:                                       # every layer of the region must be a matrix-core layer
-            ndeep = len(self.enc) - 1 - self.deep_from
-            layers = [ly for pair in self.enc[self.deep_from:] + self.dec[:ndeep] for ly in pair]
-            ok = self._deep_ok = all(ly.cin % 16 == 0 and ly.cout % 64 == 0 for ly in layers) and \
-                self.enc[self.deep_from - 1][1].cout % 16 == 0
-        return ok
+        return self._region_ok(self.deep_from)
+
+    def region_start(self, dims):
+        """First level of the batched region for tiles of this shape: deep_from, or shallower levels (not above 2) while
+        they have at most deep_vox voxels."""
+        df = self.deep_from
+        while df - 1 >= 2:
+            lv = [v >> (df - 1) for v in dims]
+            if min(lv) < 1 or lv[0] * lv[1] * lv[2] > self.deep_vox or not self._region_ok(df - 1):
+                break
+            df -= 1
+        return df
 
     def _batch_stats(self, ly, A, ca, B, cb, S, dims, lo_dims, upp, scale, shift, bound):
         """GroupNorm scale / shift / bound [S][..] of cat((A[s], up(B[s]))) for every sample of a batch."""
@@ -878,12 +897,12 @@ class UNetEngine:
             out._bfm_rows = rows
         return out
 
-    def deep_region(self, tops):
-        """tops: [(x, dims)] = the outputs of encoder level deep_from-1 of S same-shape samples (each (D,H,W,C)).
-        Runs encoder levels >= deep_from and the decoders that end at those levels on the whole batch.  Returns
-        (out (S,d,h,w,C) = the decoder output at level deep_from, its dims, [per-level feature batches, deepest first])."""
+    def deep_region(self, tops, df=None):
+        """tops: [(x, dims)] = the outputs of encoder level df-1 of S same-shape samples (each (D,H,W,C)); df defaults to
+        deep_from.  Runs encoder levels >= df and the decoders that end at those levels on the whole batch.  Returns
+        (out (S,d,h,w,C) = the decoder output at level df, its dims, [per-level feature batches, deepest first])."""
         S = len(tops)
-        df = self.deep_from
+        df = self.deep_from if df is None else df
         dims0 = tuple(tops[0][1])
         assert all(tuple(d) == dims0 for _, d in tops)
         c0 = tops[0][0].shape[-1]
@@ -954,11 +973,11 @@ class UNetEngine:
             feats.append((x, d))
         return feats
 
-    def encoder_top(self, x_cl, dims):
-        """Encoder levels < deep_from of one sample: ([(skip, dims)] shallowest first, top = last of them)."""
+    def encoder_top(self, x_cl, dims, df=None):
+        """Encoder levels < df (default deep_from) of one sample: ([(skip, dims)] shallowest first, top = last of them)."""
         skips = []
         x, d = x_cl, tuple(dims)
-        for i, (l1, l2) in enumerate(self.enc[:self.deep_from]):
+        for i, (l1, l2) in enumerate(self.enc[:self.deep_from if df is None else df]):
             if i > 0:
                 if min(d) < 2:
                     raise L.BfmError("volume %s too small for %d pooling levels" % (dims, len(self.enc) - 1))
@@ -968,10 +987,10 @@ class UNetEngine:
             skips.append((x, d))
         return skips
 
-    def decoder_top(self, skips, x, d, mask_img=None):
+    def decoder_top(self, skips, x, d, mask_img=None, df=None):
         """Decoders that end above the batched levels, one sample: x (d) = this sample's slice of the region's output.
         mask_img: see backbone_cl(mask_last) -- applies to the last decoder's second convolution."""
-        ndeep = len(self.enc) - 1 - self.deep_from
+        ndeep = len(self.enc) - 1 - (self.deep_from if df is None else df)
         feats = []
         nd = len(self.dec) - ndeep
         for k, ((l1, l2), (skip, sd_)) in enumerate(zip(self.dec[ndeep:], reversed(skips))):
@@ -985,13 +1004,14 @@ class UNetEngine:
         """The backbone of S same-shape samples: encoder levels above the region per sample, the region batched, the
         remaining decoders per sample.  Returns one feature list per sample (deepest first, like backbone_cl).
         mask_last: as in backbone_cl."""
-        tops = [self.encoder_top(x, dims) for x in xs]
-        out, d, deep_feats = self.deep_region([t[-1] for t in tops])
+        df = self.region_start(dims)
+        tops = [self.encoder_top(x, dims, df) for x in xs]
+        out, d, deep_feats = self.deep_region([t[-1] for t in tops], df)
         res = []
         for s_, skips in enumerate(tops):
             feats = [(f[s_], fd) for f, fd in deep_feats]
             mask_img = xs[s_] if (mask_last and self.mask_skip and xs[s_].shape[-1] == 1) else None
-            feats += self.decoder_top(skips, out[s_], d, mask_img=mask_img)
+            feats += self.decoder_top(skips, out[s_], d, mask_img=mask_img, df=df)
             res.append(feats)
         return res
 
