@@ -437,36 +437,59 @@ __global__ void stitch_gather_compact_kernel(const int64_t* __restrict__ tiles, 
         }
         __syncthreads();
         const int nc = ncand_s;
+        // background first: most of a head volume is zero input; whole groups of 4 such voxels are written as float4
+        // zeros, one (group, key) item per thread
+        const bool vec = !(W & 3) && !((reinterpret_cast<uintptr_t>(full) | reinterpret_cast<uintptr_t>(vol_in)) & 15);
+        if (vec) {
+            const int nq = W >> 2;
+            const float4 zz = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int it = threadIdx.x; it < nq * K; it += blockDim.x) {
+                const int g = it % nq, k = it / nq;
+                const float4 iv = *reinterpret_cast<const float4*>(vol_in + (int64_t)line * W + 4 * g);
+                if (iv.x == 0.f && iv.y == 0.f && iv.z == 0.f && iv.w == 0.f)
+                    *reinterpret_cast<float4*>(full + (int64_t)k * vol + (int64_t)line * W + 4 * g) = zz;
+            }
+        }
         for (int x = threadIdx.x; x < W; x += blockDim.x) {
             const int64_t o = (int64_t)line * W + x;
             if (vol_in[o] == 0.f) {
-                for (int k = 0; k < K; ++k) full[(int64_t)k * vol + o] = 0.f;
+                bool done = false;
+                if (vec) {
+                    const float4 iv = *reinterpret_cast<const float4*>(vol_in + (o & ~(int64_t)3));
+                    done = iv.x == 0.f && iv.y == 0.f && iv.z == 0.f && iv.w == 0.f;
+                }
+                if (!done)
+                    for (int k = 0; k < K; ++k) full[(int64_t)k * vol + o] = 0.f;
                 continue;
             }
-            // the covering tiles' columns, in table order (up to 8 kept in registers: the reference tilings cover a voxel
-            // at most 8 times; any more are looked up again per key)
-            const float* src[8];
-            int cover = 0;
-            for (int j = 0; j < nc; ++j) {
-                if (x >= cand[j].x0 && x < cand[j].x1) {
-                    if (cover < 8) src[cover] = cand[j].p + cand[j].pos[cand[j].off + x];
-                    ++cover;
+            // the covering tiles' columns, in table order; a line of the reference tilings has at most 12 candidate tiles,
+            // kept in registers through fully unrolled loops (no dynamically indexed private arrays)
+            constexpr int NCMAX = 12;
+            if (nc <= NCMAX) {
+                const float* colp[NCMAX];
+                int64_t crs[NCMAX];
+                int cover = 0;
+#pragma unroll
+                for (int j = 0; j < NCMAX; ++j) {
+                    const bool in = j < nc && x >= cand[j].x0 && x < cand[j].x1;
+                    colp[j] = in ? cand[j].p + cand[j].pos[cand[j].off + x] : nullptr;
+                    crs[j] = in ? cand[j].rs : 0;
+                    cover += in ? 1 : 0;
                 }
-            }
-            const float c = (float)cover;
-            if (cover <= 8) {
-                int64_t rs[8];
-                int q = 0;
-                for (int j = 0; j < nc && q < cover; ++j)
-                    if (x >= cand[j].x0 && x < cand[j].x1) rs[q++] = cand[j].rs;
+                const float c = (float)cover;
                 for (int k = 0; k < K; ++k) {
+                    float v[NCMAX];
+#pragma unroll
+                    for (int j = 0; j < NCMAX; ++j) v[j] = colp[j] ? colp[j][(int64_t)k * crs[j]] : 0.f;
                     float acc = 0.f;
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (u < cover) acc += src[u][(int64_t)k * rs[u]];
+                    for (int j = 0; j < NCMAX; ++j) acc += v[j];          // an absent tile adds +0: acc is never -0
                     full[(int64_t)k * vol + o] = acc / c;
                 }
             } else {
+                int cover = 0;
+                for (int j = 0; j < nc; ++j) cover += (x >= cand[j].x0 && x < cand[j].x1) ? 1 : 0;
+                const float c = (float)cover;
                 for (int k = 0; k < K; ++k) {
                     float acc = 0.f;
                     for (int j = 0; j < nc; ++j)

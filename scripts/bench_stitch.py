@@ -48,3 +48,35 @@ assert torch.equal(per_tile().view(torch.int32), gather().view(torch.int32))
 t0, t1 = timed(per_tile), timed(gather)
 print("%d^3, %d tiles, %d keys: per-tile accumulate + divide %.3f ms; one-launch gather %.3f ms = %.2f TB/s of the "
       "%.2f GB it must move" % (n, len(ranges), K, t0, t1, alg / t1 / 1e9, alg / 1e9))
+
+# the compact form on the bench volume (a head-sized ellipsoid): index, rows [K][count], stitch through the index
+import bench  # noqa: E402
+full = bench.make_volume(n, dev)
+idx = ops.index_volume(full, ranges, counts=True)
+K2 = 17
+dense = [torch.rand((K2, TU.tile_cost(r)), device=dev) for r in ranges]
+comp = []
+for i, (r, d) in enumerate(zip(ranges, dense)):
+    m = full[0, 0, r[0][0]:r[0][1], r[1][0]:r[1][1], r[2][0]:r[2][1]].reshape(-1) != 0
+    d[:, ~m] = 0
+    comp.append(d[:, m].contiguous())
+
+
+def gather_dense():
+    acc = torch.empty((K2,) + shape, dtype=torch.float32, device=dev)
+    ops.gather_all(acc, dense, ranges, shape)
+    return acc
+
+
+def gather_compact():
+    acc = torch.empty((K2,) + shape, dtype=torch.float32, device=dev)
+    ops.gather_all(acc, comp, ranges, shape, index=idx)
+    return acc
+
+
+assert torch.equal(gather_dense().view(torch.int32), gather_compact().view(torch.int32))
+t2, t3 = timed(gather_dense), timed(gather_compact)
+t4 = timed(lambda: ops.index_volume(full, ranges))
+print("bench volume, %d keys: dense gather %.3f ms (%.2f GB of rows); compact gather %.3f ms (%.2f GB of rows); "
+      "index of all tiles %.3f ms" % (K2, t2, sum(d.numel() for d in dense) * 4 / 1e9, t3,
+                                        sum(c.numel() for c in comp) * 4 / 1e9, t4))

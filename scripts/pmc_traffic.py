@@ -9,11 +9,11 @@ import sys
 
 
 def last_step(path, counter):
-    """Dispatches of the LAST step: after the stitch kernel that closed the step before it (stitch_gather_kernel runs once
+    """Dispatches of the LAST step: after the stitch kernel that closed the step before it (stitch_gather[_compact]_kernel runs once
     per volume in the batched flow; the tile-by-tile flow ends a volume with divide_multi_kernel)."""
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    ends = [i for i, r in enumerate(rows) if "stitch_gather_kernel" in r["Kernel_Name"] or "divide_multi_kernel" in r["Kernel_Name"]]
+    ends = [i for i, r in enumerate(rows) if "stitch_gather" in r["Kernel_Name"] or "divide_multi_kernel" in r["Kernel_Name"]]
     if len(ends) < 2:
         raise SystemExit("need at least two steps in the trace (found %d step-closing kernels)" % len(ends))
     return rows[ends[-2] + 1:ends[-1] + 1]
