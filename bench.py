@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-CONV_KERNELS = ["conv_wino", "conv_wino_masked", "conv_upfold", "conv_mfma", "conv_mfma_ws", "conv_mfma16", "conv_wino_ws", "conv_wino8"]
+CONV_KERNELS = ["conv_wino", "conv_wino_masked", "conv_wino_uniform", "conv_upfold", "conv_mfma", "conv_mfma_ws", "conv_mfma16", "conv_wino_ws", "conv_wino8"]
 _VER_NAME = {0: "conv_mfma", 1: "conv_mfma_ws", 2: "conv_mfma16", 3: "conv_wino", 4: "conv_wino_ws", 5: "conv_wino8"}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_conv_hbm_traffic.json")
 
@@ -220,6 +220,8 @@ def kernel_of(p):
     tag, cfg = p[5][0], p[5][4]
     if tag.endswith("[masked]"):
         return "conv_wino_masked"
+    if tag.endswith("[uniform]"):
+        return "conv_wino_uniform"
     return "conv_upfold" if tag.endswith("up") else _VER_NAME.get(cfg[6], "conv_mfma")
 
 
@@ -430,6 +432,21 @@ def main():
                 conv_vox += t.numel()
                 head_vox += t.numel()
         computed_step = flops_step - (tile_vox - conv_vox) * 2.0 * 27 * fm0 * fm0 - (tile_vox - head_vox) * 2.0 * fm0 * n_head
+        # boxes of the two layers that read the first activations where the input is constant around them run a quarter of
+        # their products (engine.uniform_skip)
+        uni2 = uni3 = 0.0
+        if eng.uniform_skip:
+            for r in ranges:
+                t = full[0, 0, r[0][0]:r[0][1], r[1][0]:r[1][1], r[2][0]:r[2][1]].contiguous()
+                for rad in (2, 3):
+                    fl = eng.uniform_flags(t.unsqueeze(-1), tuple(t.shape), rad)
+                    if fl is not None:
+                        v = float(fl.float().mean().item()) * t.numel()
+                        if rad == 2:
+                            uni2 += v
+                        else:
+                            uni3 += v
+            computed_step -= 0.75 * 2.0 * 27 * (uni2 * (fm0 // 2) * fm0 + uni3 * fm0 * fm0)
         fam = k_fl / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         dk = kernels.get(dominant, {})
         line = {
@@ -455,6 +472,8 @@ def main():
                        "tile_mask": {"skip": bool(eng.mask_skip), "tile_voxels_inside_mask_frac": inside / tile_vox,
                                      "last_conv_voxels_computed_frac": conv_vox / tile_vox,
                                      "head_voxels_computed_frac": head_vox / tile_vox,
+                                     "uniform_box_frac_enc0_conv2": uni2 / tile_vox,
+                                     "uniform_box_frac_dec4_conv1_skip": uni3 / tile_vox,
                                      "note": "the tile loop keeps out * (tile input != 0) (scripts/demo_test.py:88-100); "
                                              "the last convolution (4x4x16 boxes) and the heads (runs of 64 voxels) leave "
                                              "out what holds no non-zero input; stitched results are bit-identical "

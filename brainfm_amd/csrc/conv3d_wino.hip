@@ -49,6 +49,7 @@ struct WinoParams {
     float *rmn, *rmx;
     int ws_buf_bytes;                // persistent kernel: bytes per LDS buffer
     const float* mask_img;           // optional (D,H,W) image: a box none of whose voxels is non-zero there is not computed
+    const unsigned char* uni_flags;  // optional [nMt]: 1 = every row of the box sees the same operands (conv_wino_uniform)
 };
 
 __device__ __forceinline__ int row_perm(int l) {        // as conv_mfma: each 16-lane b128 group reads 16 consecutive positions
@@ -97,8 +98,19 @@ __device__ __forceinline__ void split_store4(const float (&t)[4], unsigned char*
     }
 }
 
-template <int NPASS, bool MASKED>
+// MODE 0: every box in full.  1 (conv_wino_masked): boxes without input are not computed.  2 / 3 (conv_wino_rest,
+// conv_wino_uniform; launched as a pair): boxes flagged uniform -- the layer's input is the same vector at every voxel the
+// box reads, because the network's input is constant around it (the background of a head volume) and no zero padding is
+// involved -- are left to MODE 3, which runs the matrix products of ONE 32-row block and copies its accumulators to the
+// other three: every row multiplies the same operands in the same order, so the copies are the bits the full computation
+// produces.  Staging (of the slabs that block reads), output transform, activation, accumulate mode and moment rows are
+// the normal code.  Two kernels rather than a branch: with both loop bodies in one kernel the allocator spilled 54
+// registers and the layer ran 25 % slower than without the shortcut.
+template <int NPASS, int MODE>
 __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
+    constexpr bool MASKED = MODE == 1;
+    constexpr bool UNI = MODE == 3;                      // this kernel computes the flagged boxes (one row block each)
+    constexpr bool BY_FLAG = MODE == 2 || MODE == 3;
     constexpr int NPL = (NPASS == 3) ? 2 : 1;
     constexpr int NF = 2 * NPL;
     constexpr int BATCH = (NPASS == 3) ? 1 : 3;      // staging items loaded together (register budget: 128 accumulators)
@@ -110,7 +122,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
     const int l32 = lane & 31, khalf = lane >> 5;
 
     int bid = blockIdx.x;
-    if constexpr (MASKED) {
+    if constexpr (MASKED || BY_FLAG) {
         // the boxes that hold input cluster in one part of the tile (a corner tile of a head volume: one octant), and one
         // contiguous eighth per XCD would leave most XCDs idle: runs of 8 boxes go round the XCDs instead
         const int nfull = (p.nMt * p.NT) & ~63;
@@ -129,6 +141,10 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
     const int ty = (mt / p.nTx) % p.nTy;
     const int tz = mt / (p.nTx * p.nTy);
     const int z0 = tz * p.TD, y0 = ty * p.TH, x0 = tx * p.TW;
+    if constexpr (BY_FLAG) {                             // wave-uniform exit before any barrier
+        const bool flagged = __builtin_amdgcn_readfirstlane((int)p.uni_flags[mt]) != 0;
+        if (flagged != UNI) return;
+    }
 
     if constexpr (MASKED) {
         // The caller multiplies this layer's consumers by (image != 0) (the tile loop, scripts/demo_test.py:88-100, and this
@@ -191,6 +207,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
             }
             msk[it] = m;
             off0[it] = ((gz * p.H + gy) * p.W + gx) * p.CA;
+            if (UNI && hz > 2) msk[it] = -1;                 // row block 0 (d = 0) reads halo slabs 0..2 only
         }
     }
     const int st_plane = ((q4 >> 1) * NPL) * p.plane_stride + (q4 & 1) * 8;
@@ -216,8 +233,9 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
     fetch(0, wq[0]);
     fetch(1, wq[1]);
 
-    auto do_chunk = [&](int kc, auto par_tag) __attribute__((always_inline)) {
+    auto do_chunk = [&](int kc, auto par_tag, auto mbn_tag) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;
+        constexpr int MBN = decltype(mbn_tag)::value;      // row blocks multiplied: 4, or 1 for a uniform box
         const int c0 = kc * KC;
         const float* src = p.A + c0 + q4 * 4;
         const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + c0 + q4 * 4);
@@ -299,7 +317,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
             fetch(s + 2, wq[(cur + 2) % 3]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
+            for (int mb = 0; mb < MBN; ++mb) {
                 half8 a[NPL];
 #pragma unroll
                 for (int hl = 0; hl < NPL; ++hl)
@@ -317,13 +335,20 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
             }
         }
     };
+    using MbTag = std::integral_constant<int, UNI ? 1 : 4>;
     if constexpr (NSET == 3) {
-        for (int kc = 0; kc < p.KCN; ++kc) do_chunk(kc, std::integral_constant<int, 0>{});
+        for (int kc = 0; kc < p.KCN; ++kc) do_chunk(kc, std::integral_constant<int, 0>{}, MbTag{});
     } else {
         for (int kc = 0; kc < p.KCN; kc += 2) {            // 9 steps per chunk: the parity flips every chunk
-            do_chunk(kc, std::integral_constant<int, 0>{});
-            if (kc + 1 < p.KCN) do_chunk(kc + 1, std::integral_constant<int, 1>{});
+            do_chunk(kc, std::integral_constant<int, 0>{}, MbTag{});
+            if (kc + 1 < p.KCN) do_chunk(kc + 1, std::integral_constant<int, 1>{}, MbTag{});
         }
+    }
+    if constexpr (UNI) {
+#pragma unroll
+        for (int mb = 1; mb < 4; ++mb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = acc[0][nb];
     }
 
     // ================= epilogue: output transform through LDS =================
@@ -469,11 +494,39 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
 }
 
 template <int NPASS>
-__global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) { conv_wino_body<NPASS, false>(p); }
+__global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) { conv_wino_body<NPASS, 0>(p); }
 
 // the same kernel for the tile loop's last convolution: boxes whose image voxels (p.mask_img) are all zero return at once
 template <int NPASS>
-__global__ void __launch_bounds__(NTHR, 2) conv_wino_masked(const WinoParams p) { conv_wino_body<NPASS, true>(p); }
+__global__ void __launch_bounds__(NTHR, 2) conv_wino_masked(const WinoParams p) { conv_wino_body<NPASS, 1>(p); }
+
+// the pair for the layers that read the network's first activations: boxes flagged uniform (bfm_uniform_boxes) run a
+// quarter of the matrix products in conv_wino_uniform, the others as ever in conv_wino_rest
+template <int NPASS>
+__global__ void __launch_bounds__(NTHR, 2) conv_wino_rest(const WinoParams p) { conv_wino_body<NPASS, 2>(p); }
+template <int NPASS>
+__global__ void __launch_bounds__(NTHR, 2) conv_wino_uniform(const WinoParams p) { conv_wino_body<NPASS, 3>(p); }
+
+// flags[box] = 1 when the (D,H,W) image is bitwise constant over the box grown by `radius` voxels and that grown box lies
+// inside the volume (no zero padding within reach).  One workgroup per box, the box grid of the 4-wave kernel.
+__global__ void __launch_bounds__(256) uniform_boxes_kernel(const float* __restrict__ img, int D, int H, int W, int TD, int TH,
+                                                            int TW, int nTy, int nTx, int R, unsigned char* __restrict__ flags) {
+    const int mt = blockIdx.x;
+    const int tx = mt % nTx, ty = (mt / nTx) % nTy, tz = mt / (nTx * nTy);
+    const int z0 = tz * TD - R, y0 = ty * TH - R, x0 = tx * TW - R;
+    const int ed = TD + 2 * R, eh = TH + 2 * R, ew = TW + 2 * R;
+    const bool inside = z0 >= 0 && y0 >= 0 && x0 >= 0 && z0 + ed <= D && y0 + eh <= H && x0 + ew <= W;   // block-uniform
+    int bad = inside ? 0 : 1;
+    if (inside) {
+        const unsigned ref = __float_as_uint(img[((int64_t)z0 * H + y0) * W + x0]);
+        for (int q = threadIdx.x; q < ed * eh * ew; q += 256) {
+            const int w = q % ew, r = q / ew, h = r % eh, d = r / eh;
+            bad |= __float_as_uint(img[((int64_t)(z0 + d) * H + (y0 + h)) * W + (x0 + w)]) != ref ? 1 : 0;
+        }
+    }
+    bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) flags[mt] = bad ? 0 : 1;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Wave-specialised persistent form of conv_wino: 8 waves per workgroup, one workgroup per CU.  Waves 0-3 are the
@@ -1196,7 +1249,28 @@ extern "C" int bfm_conv3x3x3_wino(const float* A, int CA, int D, int H, int W, c
 
 static int wino_launch(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                        const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes, int flags,
-                       float* out, void* moment_rows, const float* mask_img, bfm_stream_t stream);
+                       float* out, void* moment_rows, const float* mask_img, bfm_stream_t stream,
+                       const unsigned char* uni_flags = nullptr);
+
+extern "C" int bfm_uniform_boxes(const float* image, int D, int H, int W, int radius, int passes, unsigned char* flags,
+                                 bfm_stream_t stream) {
+    if (!image || !flags || D <= 0 || H <= 0 || W <= 0 || radius < 0 || radius > 8) return BFM_E_ARG;
+    int TD, TH, TW;
+    if (!choose_box(D, H, W, passes == 3 ? 2 : 1, TD, TH, TW)) return BFM_E_SHAPE;
+    const int nTz = bfm_cdiv(D, TD), nTy = bfm_cdiv(H, TH), nTx = bfm_cdiv(W, TW);
+    hipLaunchKernelGGL(uniform_boxes_kernel, dim3((unsigned)(nTz * nTy * nTx)), dim3(256), 0, bfm_s(stream), image, D, H, W,
+                       TD, TH, TW, nTy, nTx, radius, flags);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_conv3x3x3_wino_uniform(const float* A, int CA, int D, int H, int W, const float* scale,
+                                          const float* shift, const float* bound, int G, const void* wpacked, int wexp,
+                                          int Cout, float slope, int passes, int flags, float* out, void* moment_rows,
+                                          const unsigned char* uniform_flags, bfm_stream_t stream) {
+    if (!uniform_flags || (flags & 6)) return BFM_E_ARG;       // the 4-wave kernel only
+    return wino_launch(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out, moment_rows,
+                       nullptr, stream, uniform_flags);
+}
 
 extern "C" int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W, const float* scale,
                                      const float* shift, const float* bound, int G, const void* wpacked, int wexp,
@@ -1217,7 +1291,8 @@ extern "C" int bfm_conv3x3x3_wino_masked(const float* A, int CA, int D, int H, i
 
 static int wino_launch(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                        const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes, int flags,
-                       float* out, void* moment_rows, const float* mask_img, bfm_stream_t stream) {
+                       float* out, void* moment_rows, const float* mask_img, bfm_stream_t stream,
+                       const unsigned char* uni_flags) {
     const int accumulate = flags & 1;
     const bool persistent = (flags & 2) != 0;
     const bool eight = (flags & 4) != 0;
@@ -1237,6 +1312,7 @@ static int wino_launch(const float* A, int CA, int D, int H, int W, const float*
     p.wp = static_cast<const uint4*>(wpacked);
     p.wexp = wexp; p.Cout = Cout; p.slope = slope; p.out = out; p.accum = accumulate ? 1 : 0;
     p.mask_img = mask_img;
+    p.uni_flags = uni_flags;
     if (!choose_box(D, H, W, npl, p.TD, p.TH, p.TW)) return BFM_E_SHAPE;
     p.HT = p.TH + 2; p.PW = p.TW / 2;
     p.pw_shift = ilog2i(p.PW); p.thp_shift = ilog2i(p.TH * p.PW);
@@ -1271,6 +1347,14 @@ static int wino_launch(const float* A, int CA, int D, int H, int W, const float*
         hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_masked<3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_masked<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_uniform<3>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_uniform<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_rest<3>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_rest<1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_done = true;
     }
@@ -1316,6 +1400,16 @@ static int wino_launch(const float* A, int CA, int D, int H, int W, const float*
     if (mask_img) {
         if (passes == 3) hipLaunchKernelGGL(conv_wino_masked<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
         else hipLaunchKernelGGL(conv_wino_masked<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+        return bfm_launch_status();
+    }
+    if (uni_flags) {                                           // disjoint boxes: the two launches may overlap
+        if (passes == 3) {
+            hipLaunchKernelGGL(conv_wino_rest<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+            hipLaunchKernelGGL(conv_wino_uniform<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+        } else {
+            hipLaunchKernelGGL(conv_wino_rest<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+            hipLaunchKernelGGL(conv_wino_uniform<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+        }
         return bfm_launch_status();
     }
     if (passes == 3) hipLaunchKernelGGL(conv_wino<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);

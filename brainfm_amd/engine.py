@@ -460,10 +460,11 @@ class UNetEngine:
                                   scale=scale, shift=shift, bound=bound, mean=mean, rstd=rstd, out=out))
 
     def _conv_launch(self, ly, A, ca, B, cb, dims, upp, scale, shift, bound, groups, cfg, out, ws, rows=None, slope=None,
-                     mask_img=None):
+                     mask_img=None, uni_flags=None):
         """One launch of the planned variant of GN-apply + conv + LeakyReLU (cfg[6]: 0/1/2 conv_mfma family,
         3 Winograd; cfg[7] bit 0: accumulate onto `out`).  mask_img (variant 3 only): the tile's input image; boxes of
-        output voxels where it is all zero are left uncomputed (bfm_conv3x3x3_wino_masked)."""
+        output voxels where it is all zero are left uncomputed (bfm_conv3x3x3_wino_masked).  uni_flags (variant 3, one
+        source): per-box flags of bfm_uniform_boxes -> bfm_conv3x3x3_wino_uniform."""
         D, H, W = dims
         st = L.stream_ptr()
         slope = self.slope if slope is None else float(slope)
@@ -475,6 +476,12 @@ class UNetEngine:
                                                        groups, L.ptr(ly.wpacked), ly.wexp, ly.cout, slope, self.passes,
                                                        cfg[7] & 1, L.ptr(out), L.ptr(mask_img), st),
                     "conv_wino(masked) " + ly.name)
+            return
+        if uni_flags is not None and cfg[6] == 3 and not cb:
+            L.check(self.lib.bfm_conv3x3x3_wino_uniform(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
+                                                        groups, L.ptr(ly.wpacked), ly.wexp, ly.cout, slope, self.passes,
+                                                        cfg[7] & 1, L.ptr(out), L.ptr(rows[0]) if rows is not None else None,
+                                                        L.ptr(uni_flags), st), "conv_wino(uniform) " + ly.name)
             return
         if cfg[6] in (3, 4, 5):
             if cb:
@@ -505,7 +512,7 @@ class UNetEngine:
         return (buf, n)
 
     # ------------------------------------------------------------------ one SingleConv
-    def single_conv(self, ly, A, dims, B=None, lo_dims=None, mask_img=None):
+    def single_conv(self, ly, A, dims, B=None, lo_dims=None, mask_img=None, uni_flags=None):
         """GroupNorm -> Conv3d(3,p=1) -> LeakyReLU on cat((A, nearest_up(B))).
         A: (D,H,W,CA) fp32, B: (d,h,w,CB) fp32 or None.  Returns (D,H,W,Cout).
         mask_img: (D,H,W) image; the caller promises to look at the output only where it is non-zero (the tile loop's
@@ -523,7 +530,7 @@ class UNetEngine:
         mfma = self._mfma_ok(ly, ca, cb)
         if (mfma and B is not None and self.use_upfold and tuple(dims) == tuple(2 * v for v in lo_dims)
                 and lo_dims[0] * lo_dims[1] * lo_dims[2] >= self.upfold_min):
-            return self._single_conv_upfold(ly, A, dims, B, lo_dims, upp, scale, shift, bound)
+            return self._single_conv_upfold(ly, A, dims, B, lo_dims, upp, scale, shift, bound, uni_flags=uni_flags)
         cfg = None
         wsc = 0
         if mfma:
@@ -541,6 +548,8 @@ class UNetEngine:
             reps = 1
             if mask_img is not None and not (cfg[6] == 3 and B is None and self.tape is None):
                 mask_img = None
+            if uni_flags is not None and not (cfg[6] == 3 and B is None and mask_img is None):
+                uni_flags = None
             rows = self._rows_for(ly.cin, ly.cout, dims, cfg) if mask_img is None else None
             if self.prof is not None:
                 # instrumented pass (bench.py): the launch is issued prof_reps times back to back inside one HIP
@@ -550,7 +559,7 @@ class UNetEngine:
                 ev[0].record()
             for _ in range(reps):
                 self._conv_launch(ly, A, ca, B, cb, dims, upp, scale, shift, bound, ly.groups, cfg, out, ws, rows,
-                                  mask_img=mask_img)
+                                  mask_img=mask_img, uni_flags=uni_flags)
             if rows is not None:
                 out._bfm_rows = rows
             if ev is not None:
@@ -558,11 +567,14 @@ class UNetEngine:
                 nv = D * H * W
                 if mask_img is not None:                    # only the boxes the kernel computes count as work
                     nv = self.masked_voxels(mask_img, dims)
+                if uni_flags is not None:                   # a uniform box runs a quarter of its products
+                    nv = self.uniform_voxels(uni_flags, dims)
                 lo = 0 if B is None else lo_dims[0] * lo_dims[1] * lo_dims[2]
                 self.prof.append((ev[0], ev[1], 2.0 * 27 * ly.cin * ly.cout * nv,
                                   4.0 * (nv * ca + lo * cb + nv * ly.cout + 27 * ly.cin * ly.cout), reps,
                                   (ly.name.replace("backbone.", "").replace(".basic_module.SingleConv", ".")
-                                   + ("[masked]" if mask_img is not None else ""), ly.cin, ly.cout, tuple(dims), tuple(cfg))))
+                                   + ("[masked]" if mask_img is not None else "[uniform]" if uni_flags is not None else ""),
+                                   ly.cin, ly.cout, tuple(dims), tuple(cfg))))
         elif ca == 1 and cb == 0 and ly.cout in (32, 64) and not self.force_direct:
             rows = None
             if self.fuse_stats:
@@ -598,6 +610,27 @@ class UNetEngine:
         self.last_mask_fraction = n / float(D * H * W)
         return n
 
+    def uniform_flags(self, x_cl, dims, radius):
+        """bfm_uniform_boxes of the one-channel image x_cl (D,H,W,1) for the Winograd kernel's box grid of `dims`, or None
+        (switched off, more channels, or no such grid)."""
+        if not self.uniform_skip or x_cl is None or x_cl.shape[-1] != 1 or self.tape is not None:
+            return None
+        D, H, W = dims
+        n = self.lib.bfm_conv3x3x3_wino_rows(D, H, W, self.passes)
+        if n <= 0:
+            return None
+        flags = torch.empty(n, dtype=torch.uint8, device=self.device)
+        L.check(self.lib.bfm_uniform_boxes(L.ptr(x_cl), D, H, W, int(radius), self.passes, L.ptr(flags), L.stream_ptr()),
+                "uniform_boxes")
+        return flags
+
+    def uniform_voxels(self, flags, dims):
+        """Voxels' worth of matrix products a bfm_conv3x3x3_wino_uniform launch runs: boxes not flagged in full, flagged
+        ones a quarter (host-side, for the instrumented pass; synchronises)."""
+        f = float(flags.float().mean().item())
+        self.last_uniform_fraction = f
+        return int(round(dims[0] * dims[1] * dims[2] * (1.0 - 0.75 * f)))
+
     def _skip_layer(self, ly, ca):
         """The skip-channel half of a decoder's first conv as a layer of its own (weights w[:, :ca])."""
         if ly.skip is None:
@@ -609,7 +642,7 @@ class UNetEngine:
             ly.skip = sk
         return ly.skip
 
-    def _single_conv_upfold(self, ly, A, dims, B, lo_dims, upp, scale, shift, bound):
+    def _single_conv_upfold(self, ly, A, dims, B, lo_dims, upp, scale, shift, bound, uni_flags=None):
         """cat((skip, up2x(x))) -> GN -> conv -> LeakyReLU as: GN stats over the virtual concat, the upsampled
         channels through bfm_conv3x3x3_upfold (8 folded taps on the low-res tensor), the skip channels through
         bfm_conv3x3x3_mfma accumulating onto that."""
@@ -654,14 +687,18 @@ class UNetEngine:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         rows = self._rows_for(ca, ly.cout, dims, cfg)
+        if uni_flags is not None and cfg[6] != 3:
+            uni_flags = None
         for _ in range(reps):
-            self._conv_launch(sk, A, ca, None, 0, dims, None, scale, shift, bound, ly.groups, cfg, out, ws, rows)
+            self._conv_launch(sk, A, ca, None, 0, dims, None, scale, shift, bound, ly.groups, cfg, out, ws, rows,
+                              uni_flags=uni_flags)
         if rows is not None:
             out._bfm_rows = rows
         if ev is not None:
             ev[1].record()
-            self.prof.append((ev[0], ev[1], 2.0 * 27 * ca * ly.cout * nv, 4.0 * (nv * ca + 2 * nv * ly.cout), reps,
-                              (tag + "sk", ca, ly.cout, tuple(dims), tuple(cfg))))
+            nve = nv if uni_flags is None else self.uniform_voxels(uni_flags, dims)
+            self.prof.append((ev[0], ev[1], 2.0 * 27 * ca * ly.cout * nve, 4.0 * (nv * ca + 2 * nv * ly.cout), reps,
+                              (tag + ("sk[uniform]" if uni_flags is not None else "sk"), ca, ly.cout, tuple(dims), tuple(cfg))))
         self._record(ly, A, B, dims, lo_dims, scale, shift, bound, out)
         return out
 
@@ -698,6 +735,11 @@ class UNetEngine:
     # The tile loop multiplies every output of a tile by (tile input != 0) (scripts/demo_test.py:88-100): the last
     # convolution and the per-voxel heads leave out the voxels that product discards (BFM_MASK_SKIP=0: compute them all).
     mask_skip = os.environ.get("BFM_MASK_SKIP", "1") != "0"
+    # Where the one-channel input image is constant (a head volume's zero background), the first layers' activations are
+    # one vector per layer; the two full-resolution Winograd layers that read them (encoders.0 conv 2, the skip half of the
+    # last decoder's conv 1) run a quarter of the matrix products in boxes that see nothing else (bfm_uniform_boxes,
+    # bfm_conv3x3x3_wino_uniform; bit-identical).  BFM_UNIFORM_SKIP=0: every box in full.
+    uniform_skip = os.environ.get("BFM_UNIFORM_SKIP", "1") != "0"
 
     # A small tile's level deep_from - 1 is small too (80^3: 20^3 voxels of 256 channels -- launches of 60-100 us that
     # fill a fifth of the chip): the region starts one level higher for tiles whose level there has at most this many
@@ -954,6 +996,7 @@ class UNetEngine:
         if self.has_deep_region():
             return self.backbone_batch([x_cl], dims, mask_last=mask_last)[0]
         mask_img = x_cl if (mask_last and self.mask_skip and x_cl.shape[-1] == 1) else None
+        uf2, uf3 = self.uniform_flags(x_cl, dims, 2), self.uniform_flags(x_cl, dims, 3)
         skips = []
         x, d = x_cl, tuple(dims)
         for i, (l1, l2) in enumerate(self.enc):
@@ -962,12 +1005,13 @@ class UNetEngine:
                     raise L.BfmError("volume %s too small for %d pooling levels" % (dims, len(self.enc) - 1))
                 x, d = self.maxpool(x, d)
             x = self.single_conv(l1, x, d)
-            x = self.single_conv(l2, x, d)
+            x = self.single_conv(l2, x, d, uni_flags=uf2 if i == 0 else None)
             skips.insert(0, (x, d))
         skips = skips[1:]
         feats = [(x, d)]
         for k, ((l1, l2), (skip, sd_)) in enumerate(zip(self.dec, skips)):
-            y = self.single_conv(l1, skip, sd_, B=x, lo_dims=d)
+            last = k == len(self.dec) - 1 and len(self.dec) == len(self.enc) - 1      # ends at full resolution
+            y = self.single_conv(l1, skip, sd_, B=x, lo_dims=d, uni_flags=uf3 if last else None)
             x = self.single_conv(l2, y, sd_, mask_img=mask_img if k == len(self.dec) - 1 else None)
             d = sd_
             feats.append((x, d))
@@ -983,18 +1027,19 @@ class UNetEngine:
                     raise L.BfmError("volume %s too small for %d pooling levels" % (dims, len(self.enc) - 1))
                 x, d = self.maxpool(x, d)
             x = self.single_conv(l1, x, d)
-            x = self.single_conv(l2, x, d)
+            x = self.single_conv(l2, x, d, uni_flags=self.uniform_flags(x_cl, dims, 2) if i == 0 else None)
             skips.append((x, d))
         return skips
 
-    def decoder_top(self, skips, x, d, mask_img=None, df=None):
+    def decoder_top(self, skips, x, d, mask_img=None, df=None, image=None):
         """Decoders that end above the batched levels, one sample: x (d) = this sample's slice of the region's output.
         mask_img: see backbone_cl(mask_last) -- applies to the last decoder's second convolution."""
         ndeep = len(self.enc) - 1 - (self.deep_from if df is None else df)
         feats = []
         nd = len(self.dec) - ndeep
         for k, ((l1, l2), (skip, sd_)) in enumerate(zip(self.dec[ndeep:], reversed(skips))):
-            y = self.single_conv(l1, skip, sd_, B=x, lo_dims=d)
+            uf = self.uniform_flags(image, sd_, 3) if (k == nd - 1 and image is not None) else None
+            y = self.single_conv(l1, skip, sd_, B=x, lo_dims=d, uni_flags=uf)
             x = self.single_conv(l2, y, sd_, mask_img=mask_img if k == nd - 1 else None)
             d = sd_
             feats.append((x, d))
@@ -1011,7 +1056,7 @@ class UNetEngine:
         for s_, skips in enumerate(tops):
             feats = [(f[s_], fd) for f, fd in deep_feats]
             mask_img = xs[s_] if (mask_last and self.mask_skip and xs[s_].shape[-1] == 1) else None
-            feats += self.decoder_top(skips, out[s_], d, mask_img=mask_img, df=df)
+            feats += self.decoder_top(skips, out[s_], d, mask_img=mask_img, df=df, image=xs[s_])
             res.append(feats)
         return res
 

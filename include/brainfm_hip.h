@@ -123,6 +123,21 @@ int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W, const flo
 /* The last convolution of a tile inside the tile loop (scripts/demo_test.py:88-100 keeps `v * (tile_input != 0)` of every
  * output): a box of output voxels whose tile-input voxels are all zero feeds nothing that survives the mask, so it is not
  * computed (`out` keeps whatever it held there).  mask_image = the tile's input (D,H,W).  The 4-wave kernel, no moment rows. */
+/* Boxes whose rows all multiply the same operands.  Where the network's one-channel input image is bitwise constant
+ * (the zero background of a skull-stripped head, utils/test_utils.py:235-284 min-max normalises it to exact zeros) every
+ * activation of the first layers is the same vector at every voxel, away from the zero padding: stem output where the image
+ * is constant within 1 voxel, encoders.0 second conv within 2, and so on.  bfm_uniform_boxes flags the boxes of the 4-wave
+ * Winograd kernel's grid over which `image` is constant within `radius` voxels with the grown box inside the volume;
+ * bfm_conv3x3x3_wino_uniform is bfm_conv3x3x3_wino_ex that, in a flagged box, runs the matrix products of one 32-row block
+ * and copies its accumulators to the other three -- bit-identical results (same operands, same order, in every row), a
+ * quarter of the products.  The caller passes radius = (number of 3x3x3 convolutions between the image and this layer's
+ * OUTPUT), e.g. 2 for encoders.0's second conv, 3 for the skip half of the last decoder's first conv. */
+int bfm_uniform_boxes(const float* image, int D, int H, int W, int radius, int passes, unsigned char* flags /*[wino_rows]*/,
+                      bfm_stream_t stream);
+int bfm_conv3x3x3_wino_uniform(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
+                               const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
+                               int flags, float* out, void* moment_rows, const unsigned char* uniform_flags,
+                               bfm_stream_t stream);
 int bfm_conv3x3x3_wino_box(int D, int H, int W, int passes, int* box /* [3]: the (d,h,w) box of output voxels per workgroup */);
 int bfm_conv3x3x3_wino_masked(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                               const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,

@@ -21,7 +21,7 @@ def last_step(path, counter):
 
 def family(name):
     """bench.py's kernel names (CONV_KERNELS); longest match first."""
-    for k in ("conv_upfold", "conv_wino_masked", "conv_wino_ws", "conv_wino8", "conv_wino", "conv_mfma16", "conv_mfma_ws", "conv_mfma",
+    for k in ("conv_upfold", "conv_wino_masked", "conv_wino_uniform", "conv_wino_ws", "conv_wino8", "conv_wino", "conv_mfma16", "conv_mfma_ws", "conv_mfma",
               "conv_stem", "tail_kernel"):
         if k in name:
             return k
@@ -35,13 +35,17 @@ out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two pa
        "kernels": {}}
 for rows, key, mult in ((fetch, "fetch_bytes", 2.0), (write, "write_bytes", 1.0)):
     for r in rows:
-        fam = family(r["Kernel_Name"])
+        # conv_wino_rest + conv_wino_uniform are the two halves of ONE bfm_conv3x3x3_wino_uniform launch (disjoint boxes):
+        # bench.py counts the pair once, as conv_wino_uniform
+        rest = "conv_wino_rest" in r["Kernel_Name"]
+        fam = "conv_wino_uniform" if rest else family(r["Kernel_Name"])
         if fam is None:
             continue
         e = out["kernels"].setdefault(fam, {"launches_fetch_pass": 0, "launches_write_pass": 0, "fetch_bytes": 0.0,
                                             "write_bytes": 0.0})
         e[key] += float(r["Counter_Value"]) * 1024.0 * mult
-        e["launches_fetch_pass" if key == "fetch_bytes" else "launches_write_pass"] += 1
+        if not rest:
+            e["launches_fetch_pass" if key == "fetch_bytes" else "launches_write_pass"] += 1
 for fam, e in out["kernels"].items():
     n = max(e["launches_fetch_pass"], 1)
     e["launches"] = e["launches_fetch_pass"]            # bench.py refuses this file when its own launch counts differ

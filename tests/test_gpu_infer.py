@@ -1063,3 +1063,56 @@ def test_compact_rows_index_pack_and_stitch_equal_the_dense_form_bitwise(shape, 
         ops.gather_all(out, rows, ranges, shape, index=idx)
         torch.cuda.synchronize()
         assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+
+
+def test_uniform_background_boxes_change_no_bit():
+    """Where the one-channel input is constant (the zero background of a head volume) the first layers' activations are one
+    vector per layer, and the two full-resolution Winograd layers that read them run a quarter of the matrix products in
+    the boxes that see nothing else (engine.uniform_skip: bfm_uniform_boxes + bfm_conv3x3x3_wino_uniform).  Every decoder
+    feature map, the tail's maps and the labels are bit-identical to the run with every box in full; the flags are the
+    boxes whose grown neighbourhood is constant and inside the volume (numpy restatement); and some boxes are flagged."""
+    from brainfm_amd import test_utils as TU
+    import ctypes as C
+    from brainfm_amd import _lib as L
+    ga, ta = TU.default_inference_args(f_maps=64, num_levels=3)
+    dims = (48, 64, 96)
+    g = torch.Generator().manual_seed(3)
+    zz, yy, xx = np.meshgrid(*[np.linspace(-1, 1, n_) for n_ in dims], indexing="ij")
+    inside = torch.from_numpy((zz / 0.45) ** 2 + (yy / 0.4) ** 2 + ((xx + 0.3) / 0.35) ** 2 < 1)
+    vol = (torch.rand(dims, generator=g) + 0.05) * inside
+    x = vol[None, None].to(_dev())
+    outs = {}
+    for skip in (True, False):
+        torch.manual_seed(4)
+        s = TU.InferenceSession(ga, ta, _dev(), passes=3)
+        s.engine.uniform_skip = skip
+        out, _ = s.forward_fused(x)
+        outs[skip] = out
+        if skip:
+            eng = s.engine
+            box = (C.c_int * 3)()
+            L.check(eng.lib.bfm_conv3x3x3_wino_box(dims[0], dims[1], dims[2], eng.passes, box), "box")
+            img = vol.numpy()
+            for rad in (2, 3):
+                fl = eng.uniform_flags(x[0, 0].unsqueeze(-1).contiguous(), dims, rad).cpu().numpy()
+                want = []
+                for z in range(0, dims[0], box[0]):
+                    for y in range(0, dims[1], box[1]):
+                        for xx_ in range(0, dims[2], box[2]):
+                            lo = (z - rad, y - rad, xx_ - rad)
+                            hi = (z + box[0] + rad, y + box[1] + rad, xx_ + box[2] + rad)
+                            ok = min(lo) >= 0 and all(h <= d for h, d in zip(hi, dims))
+                            if ok:
+                                blk = img[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+                                ok = bool((blk.view(np.uint32) == blk.view(np.uint32).flat[0]).all())
+                            want.append(1 if ok else 0)
+                assert np.array_equal(fl, np.array(want, dtype=np.uint8)), rad
+                assert 0 < fl.sum() < fl.size, (rad, int(fl.sum()))
+            kinds = s.engine.conv_choices()
+            assert 3 in set(kinds.values())                       # the Winograd variant ran: the flags were used
+    for k in outs[True]:
+        if k == "feat":
+            for a, b in zip(outs[True][k], outs[False][k]):
+                assert torch.equal(a, b)
+        else:
+            assert torch.equal(outs[True][k], outs[False][k]), k
