@@ -441,12 +441,13 @@ def main():
                 for rad in (2, 3):
                     fl = eng.uniform_flags(t.unsqueeze(-1), tuple(t.shape), rad)
                     if fl is not None:
-                        v = float(fl.float().mean().item()) * t.numel()
+                        nb = eng.lib.bfm_conv3x3x3_wino_rows(t.shape[0], t.shape[1], t.shape[2], eng.passes)
+                        v = max(int(fl[:nb].sum().item()) - 1, 0) / float(nb) * t.numel()   # all flagged boxes but one
                         if rad == 2:
                             uni2 += v
                         else:
                             uni3 += v
-            computed_step -= 0.75 * 2.0 * 27 * (uni2 * (fm0 // 2) * fm0 + uni3 * fm0 * fm0)
+            computed_step -= 2.0 * 27 * (uni2 * (fm0 // 2) * fm0 + uni3 * fm0 * fm0)
         fam = k_fl / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         dk = kernels.get(dominant, {})
         line = {

@@ -50,6 +50,8 @@ struct WinoParams {
     int ws_buf_bytes;                // persistent kernel: bytes per LDS buffer
     const float* mask_img;           // optional (D,H,W) image: a box none of whose voxels is non-zero there is not computed
     const unsigned char* uni_flags;  // optional [nMt]: 1 = every row of the box sees the same operands (conv_wino_uniform)
+    const int* uni_first;            // index of the first flagged box (>= nMt: none): the one conv_wino_rest computes
+    float* uni_acc;                  // [NT][NTHR][32]: that box's accumulators of row block 0, for all the other flagged boxes
 };
 
 __device__ __forceinline__ int row_perm(int l) {        // as conv_mfma: each 16-lane b128 group reads 16 consecutive positions
@@ -101,11 +103,12 @@ __device__ __forceinline__ void split_store4(const float (&t)[4], unsigned char*
 // MODE 0: every box in full.  1 (conv_wino_masked): boxes without input are not computed.  2 / 3 (conv_wino_rest,
 // conv_wino_uniform; launched as a pair): boxes flagged uniform -- the layer's input is the same vector at every voxel the
 // box reads, because the network's input is constant around it (the background of a head volume) and no zero padding is
-// involved -- are left to MODE 3, which runs the matrix products of ONE 32-row block and copies its accumulators to the
-// other three: every row multiplies the same operands in the same order, so the copies are the bits the full computation
-// produces.  Staging (of the slabs that block reads), output transform, activation, accumulate mode and moment rows are
-// the normal code.  Two kernels rather than a branch: with both loop bodies in one kernel the allocator spilled 54
-// registers and the layer ran 25 % slower than without the shortcut.
+// involved.  Every row of every such box multiplies the same operands in the same order, so all of them end the main loop
+// with the same accumulators: conv_wino_rest computes the unflagged boxes and ONE flagged box (the first), whose row
+// block 0 accumulators it also leaves in uni_acc; conv_wino_uniform then gives every other flagged box those
+// accumulators -- the bits its own main loop would have produced -- and runs the normal epilogue (output transform,
+// accumulate mode, activation, moment rows) on them: no staging, no weights, no matrix products.  Two kernels rather
+// than a branch: a second loop body in one kernel made the allocator spill 54 registers and the layer 25 % slower.
 template <int NPASS, int MODE>
 __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
     constexpr bool MASKED = MODE == 1;
@@ -141,9 +144,11 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
     const int ty = (mt / p.nTx) % p.nTy;
     const int tz = mt / (p.nTx * p.nTy);
     const int z0 = tz * p.TD, y0 = ty * p.TH, x0 = tx * p.TW;
-    if constexpr (BY_FLAG) {                             // wave-uniform exit before any barrier
+    bool rep = false;                                    // conv_wino_rest: this is the flagged box it computes
+    if constexpr (BY_FLAG) {                             // wave-uniform exits before any barrier
         const bool flagged = __builtin_amdgcn_readfirstlane((int)p.uni_flags[mt]) != 0;
-        if (flagged != UNI) return;
+        rep = flagged && mt == __builtin_amdgcn_readfirstlane(*p.uni_first);
+        if (UNI ? (!flagged || rep) : (flagged && !rep)) return;
     }
 
     if constexpr (MASKED) {
@@ -207,7 +212,6 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
             }
             msk[it] = m;
             off0[it] = ((gz * p.H + gy) * p.W + gx) * p.CA;
-            if (UNI && hz > 2) msk[it] = -1;                 // row block 0 (d = 0) reads halo slabs 0..2 only
         }
     }
     const int st_plane = ((q4 >> 1) * NPL) * p.plane_stride + (q4 & 1) * 8;
@@ -335,20 +339,38 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
             }
         }
     };
-    using MbTag = std::integral_constant<int, UNI ? 1 : 4>;
-    if constexpr (NSET == 3) {
-        for (int kc = 0; kc < p.KCN; ++kc) do_chunk(kc, std::integral_constant<int, 0>{}, MbTag{});
-    } else {
-        for (int kc = 0; kc < p.KCN; kc += 2) {            // 9 steps per chunk: the parity flips every chunk
-            do_chunk(kc, std::integral_constant<int, 0>{}, MbTag{});
-            if (kc + 1 < p.KCN) do_chunk(kc + 1, std::integral_constant<int, 1>{}, MbTag{});
-        }
-    }
     if constexpr (UNI) {
+        const float4* src4 = reinterpret_cast<const float4*>(p.uni_acc + ((size_t)nt * NTHR + tid) * 32);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v4 = src4[nb * 4 + q];
+                acc[0][nb][4 * q] = v4.x; acc[0][nb][4 * q + 1] = v4.y; acc[0][nb][4 * q + 2] = v4.z; acc[0][nb][4 * q + 3] = v4.w;
+            }
 #pragma unroll
         for (int mb = 1; mb < 4; ++mb)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = acc[0][nb];
+    } else {
+        using MbTag = std::integral_constant<int, 4>;
+        if constexpr (NSET == 3) {
+            for (int kc = 0; kc < p.KCN; ++kc) do_chunk(kc, std::integral_constant<int, 0>{}, MbTag{});
+        } else {
+            for (int kc = 0; kc < p.KCN; kc += 2) {        // 9 steps per chunk: the parity flips every chunk
+                do_chunk(kc, std::integral_constant<int, 0>{}, MbTag{});
+                if (kc + 1 < p.KCN) do_chunk(kc + 1, std::integral_constant<int, 1>{}, MbTag{});
+            }
+        }
+        if (MODE == 2 && rep) {                             // the flagged boxes' common accumulators
+            float4* dst4 = reinterpret_cast<float4*>(p.uni_acc + ((size_t)nt * NTHR + tid) * 32);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    dst4[nb * 4 + q] = make_float4(acc[0][nb][4 * q], acc[0][nb][4 * q + 1], acc[0][nb][4 * q + 2],
+                                                   acc[0][nb][4 * q + 3]);
+        }
     }
 
     // ================= epilogue: output transform through LDS =================
@@ -526,6 +548,21 @@ __global__ void __launch_bounds__(256) uniform_boxes_kernel(const float* __restr
     }
     bad = __syncthreads_or(bad);
     if (threadIdx.x == 0) flags[mt] = bad ? 0 : 1;
+}
+
+// index of the first flagged box (n: none); one workgroup
+__global__ void __launch_bounds__(256) uniform_first_kernel(const unsigned char* __restrict__ flags, int n, int* __restrict__ first) {
+    __shared__ int best[256];
+    int b = n;
+    for (int i = threadIdx.x; i < n; i += 256)
+        if (flags[i]) { b = i; break; }                       // ascending per thread: its first hit is its smallest
+    best[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) best[threadIdx.x] = min(best[threadIdx.x], best[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *first = best[0];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1250,26 +1287,42 @@ extern "C" int bfm_conv3x3x3_wino(const float* A, int CA, int D, int H, int W, c
 static int wino_launch(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                        const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes, int flags,
                        float* out, void* moment_rows, const float* mask_img, bfm_stream_t stream,
-                       const unsigned char* uni_flags = nullptr);
+                       const unsigned char* uni_flags = nullptr, float* uni_acc = nullptr);
+
+extern "C" size_t bfm_uniform_boxes_bytes(int D, int H, int W, int passes) {
+    int TD, TH, TW;
+    if (D <= 0 || H <= 0 || W <= 0 || !choose_box(D, H, W, passes == 3 ? 2 : 1, TD, TH, TW)) return 0;
+    const size_t n = (size_t)bfm_cdiv(D, TD) * bfm_cdiv(H, TH) * bfm_cdiv(W, TW);
+    return ((n + 3) & ~(size_t)3) + 4;                         // flags, then the index of the first flagged box
+}
 
 extern "C" int bfm_uniform_boxes(const float* image, int D, int H, int W, int radius, int passes, unsigned char* flags,
                                  bfm_stream_t stream) {
     if (!image || !flags || D <= 0 || H <= 0 || W <= 0 || radius < 0 || radius > 8) return BFM_E_ARG;
+    if (reinterpret_cast<uintptr_t>(flags) & 3) return BFM_E_ARG;
     int TD, TH, TW;
     if (!choose_box(D, H, W, passes == 3 ? 2 : 1, TD, TH, TW)) return BFM_E_SHAPE;
     const int nTz = bfm_cdiv(D, TD), nTy = bfm_cdiv(H, TH), nTx = bfm_cdiv(W, TW);
-    hipLaunchKernelGGL(uniform_boxes_kernel, dim3((unsigned)(nTz * nTy * nTx)), dim3(256), 0, bfm_s(stream), image, D, H, W,
-                       TD, TH, TW, nTy, nTx, radius, flags);
+    const size_t n = (size_t)nTz * nTy * nTx;
+    int* first = reinterpret_cast<int*>(flags + ((n + 3) & ~(size_t)3));
+    hipLaunchKernelGGL(uniform_boxes_kernel, dim3((unsigned)n), dim3(256), 0, bfm_s(stream), image, D, H, W, TD, TH, TW, nTy,
+                       nTx, radius, flags);
+    hipLaunchKernelGGL(uniform_first_kernel, dim3(1), dim3(256), 0, bfm_s(stream), flags, (int)n, first);
     return bfm_launch_status();
+}
+
+extern "C" size_t bfm_conv3x3x3_wino_uniform_scratch(int Cout) {
+    return Cout > 0 && Cout % 64 == 0 ? (size_t)(Cout / 64) * NTHR * 32 * sizeof(float) : 0;
 }
 
 extern "C" int bfm_conv3x3x3_wino_uniform(const float* A, int CA, int D, int H, int W, const float* scale,
                                           const float* shift, const float* bound, int G, const void* wpacked, int wexp,
                                           int Cout, float slope, int passes, int flags, float* out, void* moment_rows,
-                                          const unsigned char* uniform_flags, bfm_stream_t stream) {
-    if (!uniform_flags || (flags & 6)) return BFM_E_ARG;       // the 4-wave kernel only
+                                          const unsigned char* uniform_flags, void* scratch, bfm_stream_t stream) {
+    if (!uniform_flags || !scratch || (flags & 6)) return BFM_E_ARG;       // the 4-wave kernel only
+    if ((reinterpret_cast<uintptr_t>(uniform_flags) & 3) || (reinterpret_cast<uintptr_t>(scratch) & 15)) return BFM_E_ARG;
     return wino_launch(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out, moment_rows,
-                       nullptr, stream, uniform_flags);
+                       nullptr, stream, uniform_flags, static_cast<float*>(scratch));
 }
 
 extern "C" int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W, const float* scale,
@@ -1292,7 +1345,7 @@ extern "C" int bfm_conv3x3x3_wino_masked(const float* A, int CA, int D, int H, i
 static int wino_launch(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                        const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes, int flags,
                        float* out, void* moment_rows, const float* mask_img, bfm_stream_t stream,
-                       const unsigned char* uni_flags) {
+                       const unsigned char* uni_flags, float* uni_acc) {
     const int accumulate = flags & 1;
     const bool persistent = (flags & 2) != 0;
     const bool eight = (flags & 4) != 0;
@@ -1313,12 +1366,14 @@ static int wino_launch(const float* A, int CA, int D, int H, int W, const float*
     p.wexp = wexp; p.Cout = Cout; p.slope = slope; p.out = out; p.accum = accumulate ? 1 : 0;
     p.mask_img = mask_img;
     p.uni_flags = uni_flags;
+    p.uni_acc = uni_acc;
     if (!choose_box(D, H, W, npl, p.TD, p.TH, p.TW)) return BFM_E_SHAPE;
     p.HT = p.TH + 2; p.PW = p.TW / 2;
     p.pw_shift = ilog2i(p.PW); p.thp_shift = ilog2i(p.TH * p.PW);
     const int nTz = bfm_cdiv(D, p.TD);
     p.nTy = bfm_cdiv(H, p.TH); p.nTx = bfm_cdiv(W, p.TW);
     p.nMt = nTz * p.nTy * p.nTx;
+    p.uni_first = uni_flags ? reinterpret_cast<const int*>(uni_flags + (((size_t)p.nMt + 3) & ~(size_t)3)) : nullptr;
     p.NT = Cout / 64;
     p.KCN = CA / KC;
     p.npos_lds = (p.TD + 2) * p.HT * p.PW;

@@ -478,10 +478,13 @@ class UNetEngine:
                     "conv_wino(masked) " + ly.name)
             return
         if uni_flags is not None and cfg[6] == 3 and not cb:
+            scratch = torch.empty(self.lib.bfm_conv3x3x3_wino_uniform_scratch(ly.cout), dtype=torch.uint8,
+                                  device=self.device)
             L.check(self.lib.bfm_conv3x3x3_wino_uniform(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
                                                         groups, L.ptr(ly.wpacked), ly.wexp, ly.cout, slope, self.passes,
                                                         cfg[7] & 1, L.ptr(out), L.ptr(rows[0]) if rows is not None else None,
-                                                        L.ptr(uni_flags), st), "conv_wino(uniform) " + ly.name)
+                                                        L.ptr(uni_flags), L.ptr(scratch), st),
+                    "conv_wino(uniform) " + ly.name)
             return
         if cfg[6] in (3, 4, 5):
             if cb:
@@ -616,20 +619,21 @@ class UNetEngine:
         if not self.uniform_skip or x_cl is None or x_cl.shape[-1] != 1 or self.tape is not None:
             return None
         D, H, W = dims
-        n = self.lib.bfm_conv3x3x3_wino_rows(D, H, W, self.passes)
+        n = self.lib.bfm_uniform_boxes_bytes(D, H, W, self.passes)
         if n <= 0:
             return None
-        flags = torch.empty(n, dtype=torch.uint8, device=self.device)
+        flags = torch.empty(n, dtype=torch.uint8, device=self.device)     # one byte per box + the first flagged index
         L.check(self.lib.bfm_uniform_boxes(L.ptr(x_cl), D, H, W, int(radius), self.passes, L.ptr(flags), L.stream_ptr()),
                 "uniform_boxes")
         return flags
 
     def uniform_voxels(self, flags, dims):
-        """Voxels' worth of matrix products a bfm_conv3x3x3_wino_uniform launch runs: boxes not flagged in full, flagged
-        ones a quarter (host-side, for the instrumented pass; synchronises)."""
-        f = float(flags.float().mean().item())
-        self.last_uniform_fraction = f
-        return int(round(dims[0] * dims[1] * dims[2] * (1.0 - 0.75 * f)))
+        """Voxels' worth of matrix products a bfm_conv3x3x3_wino_uniform launch runs: the boxes not flagged and one of the
+        flagged ones (host-side, for the instrumented pass; synchronises)."""
+        nb = self.lib.bfm_conv3x3x3_wino_rows(dims[0], dims[1], dims[2], self.passes)
+        k = int(flags[:nb].sum().item())
+        self.last_uniform_fraction = k / float(nb)
+        return int(round(dims[0] * dims[1] * dims[2] * (1.0 - max(k - 1, 0) / float(nb))))
 
     def _skip_layer(self, ly, ca):
         """The skip-channel half of a decoder's first conv as a layer of its own (weights w[:, :ca])."""

@@ -127,16 +127,21 @@ int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W, const flo
  * (the zero background of a skull-stripped head, utils/test_utils.py:235-284 min-max normalises it to exact zeros) every
  * activation of the first layers is the same vector at every voxel, away from the zero padding: stem output where the image
  * is constant within 1 voxel, encoders.0 second conv within 2, and so on.  bfm_uniform_boxes flags the boxes of the 4-wave
- * Winograd kernel's grid over which `image` is constant within `radius` voxels with the grown box inside the volume;
- * bfm_conv3x3x3_wino_uniform is bfm_conv3x3x3_wino_ex that, in a flagged box, runs the matrix products of one 32-row block
- * and copies its accumulators to the other three -- bit-identical results (same operands, same order, in every row), a
- * quarter of the products.  The caller passes radius = (number of 3x3x3 convolutions between the image and this layer's
- * OUTPUT), e.g. 2 for encoders.0's second conv, 3 for the skip half of the last decoder's first conv. */
-int bfm_uniform_boxes(const float* image, int D, int H, int W, int radius, int passes, unsigned char* flags /*[wino_rows]*/,
+ * Winograd kernel's grid over which `image` is constant within `radius` voxels with the grown box inside the volume
+ * (flags: bfm_uniform_boxes_bytes() bytes, 4-byte aligned: one byte per box, then the index of the first flagged box).
+ * bfm_conv3x3x3_wino_uniform is bfm_conv3x3x3_wino_ex that computes the unflagged boxes and ONE flagged box in full, and
+ * gives every other flagged box that box's accumulators (the bits its own main loop would produce: same operands, same
+ * order, in every row of every flagged box) before the normal epilogue -- no staging, weights or matrix products there.
+ * scratch: bfm_conv3x3x3_wino_uniform_scratch(Cout) bytes, 16-byte aligned.  The caller passes radius = (number of 3x3x3
+ * convolutions between the image and this layer's OUTPUT): 2 for encoders.0's second conv, 3 for the skip half of the last
+ * decoder's first conv. */
+size_t bfm_uniform_boxes_bytes(int D, int H, int W, int passes);
+int bfm_uniform_boxes(const float* image, int D, int H, int W, int radius, int passes, unsigned char* flags,
                       bfm_stream_t stream);
+size_t bfm_conv3x3x3_wino_uniform_scratch(int Cout);
 int bfm_conv3x3x3_wino_uniform(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                                const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
-                               int flags, float* out, void* moment_rows, const unsigned char* uniform_flags,
+                               int flags, float* out, void* moment_rows, const unsigned char* uniform_flags, void* scratch,
                                bfm_stream_t stream);
 int bfm_conv3x3x3_wino_box(int D, int H, int W, int passes, int* box /* [3]: the (d,h,w) box of output voxels per workgroup */);
 int bfm_conv3x3x3_wino_masked(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,

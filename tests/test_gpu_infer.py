@@ -1067,8 +1067,8 @@ def test_compact_rows_index_pack_and_stitch_equal_the_dense_form_bitwise(shape, 
 
 def test_uniform_background_boxes_change_no_bit():
     """Where the one-channel input is constant (the zero background of a head volume) the first layers' activations are one
-    vector per layer, and the two full-resolution Winograd layers that read them run a quarter of the matrix products in
-    the boxes that see nothing else (engine.uniform_skip: bfm_uniform_boxes + bfm_conv3x3x3_wino_uniform).  Every decoder
+    vector per layer, and the two full-resolution Winograd layers that read them compute ONE of the boxes that see nothing
+    else and reuse its accumulators in the others (engine.uniform_skip: bfm_uniform_boxes + bfm_conv3x3x3_wino_uniform).  Every decoder
     feature map, the tail's maps and the labels are bit-identical to the run with every box in full; the flags are the
     boxes whose grown neighbourhood is constant and inside the volume (numpy restatement); and some boxes are flagged."""
     from brainfm_amd import test_utils as TU
@@ -1094,7 +1094,10 @@ def test_uniform_background_boxes_change_no_bit():
             L.check(eng.lib.bfm_conv3x3x3_wino_box(dims[0], dims[1], dims[2], eng.passes, box), "box")
             img = vol.numpy()
             for rad in (2, 3):
-                fl = eng.uniform_flags(x[0, 0].unsqueeze(-1).contiguous(), dims, rad).cpu().numpy()
+                raw = eng.uniform_flags(x[0, 0].unsqueeze(-1).contiguous(), dims, rad).cpu().numpy()
+                nb = eng.lib.bfm_conv3x3x3_wino_rows(dims[0], dims[1], dims[2], eng.passes)
+                fl = raw[:nb]
+                first = int(raw[(nb + 3) // 4 * 4:(nb + 3) // 4 * 4 + 4].view(np.int32)[0])
                 want = []
                 for z in range(0, dims[0], box[0]):
                     for y in range(0, dims[1], box[1]):
@@ -1108,6 +1111,7 @@ def test_uniform_background_boxes_change_no_bit():
                             want.append(1 if ok else 0)
                 assert np.array_equal(fl, np.array(want, dtype=np.uint8)), rad
                 assert 0 < fl.sum() < fl.size, (rad, int(fl.sum()))
+                assert first == int(np.flatnonzero(fl)[0])
             kinds = s.engine.conv_choices()
             assert 3 in set(kinds.values())                       # the Winograd variant ran: the flags were used
     for k in outs[True]:
