@@ -97,6 +97,7 @@ SIGNATURES = {
     "bfm_conv3x3x3_wino_ex": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _P]),
     "bfm_conv3x3x3_wino_box": (_I, [_I, _I, _I, _I, _P]),
     "bfm_uniform_boxes": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "bfm_uniform_boxes_level": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "bfm_uniform_boxes_bytes": (_Z, [_I, _I, _I, _I]),
     "bfm_conv3x3x3_wino_uniform_scratch": (_Z, [_I]),
     "bfm_conv3x3x3_wino_uniform": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _P, _P, _P]),

@@ -529,14 +529,16 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino_rest(const WinoParams p) { 
 template <int NPASS>
 __global__ void __launch_bounds__(NTHR, 2) conv_wino_uniform(const WinoParams p) { conv_wino_body<NPASS, 3>(p); }
 
-// flags[box] = 1 when the (D,H,W) image is bitwise constant over the box grown by `radius` voxels and that grown box lies
-// inside the volume (no zero padding within reach).  One workgroup per box, the box grid of the 4-wave kernel.
+// flags[box] = 1 when the (D,H,W) image is bitwise constant over the box -- a box of the layer's grid at pooling level L,
+// i.e. voxels [z0 << L, (z0 + TD) << L) of the image -- grown by `R` image voxels, and that grown region lies inside the
+// volume (no zero padding within reach at any level).  One workgroup per box, the box grid of the 4-wave kernel.
 __global__ void __launch_bounds__(256) uniform_boxes_kernel(const float* __restrict__ img, int D, int H, int W, int TD, int TH,
-                                                            int TW, int nTy, int nTx, int R, unsigned char* __restrict__ flags) {
+                                                            int TW, int nTy, int nTx, int L, int R,
+                                                            unsigned char* __restrict__ flags) {
     const int mt = blockIdx.x;
     const int tx = mt % nTx, ty = (mt / nTx) % nTy, tz = mt / (nTx * nTy);
-    const int z0 = tz * TD - R, y0 = ty * TH - R, x0 = tx * TW - R;
-    const int ed = TD + 2 * R, eh = TH + 2 * R, ew = TW + 2 * R;
+    const int z0 = ((tz * TD) << L) - R, y0 = ((ty * TH) << L) - R, x0 = ((tx * TW) << L) - R;
+    const int ed = (TD << L) + 2 * R, eh = (TH << L) + 2 * R, ew = (TW << L) + 2 * R;
     const bool inside = z0 >= 0 && y0 >= 0 && x0 >= 0 && z0 + ed <= D && y0 + eh <= H && x0 + ew <= W;   // block-uniform
     int bad = inside ? 0 : 1;
     if (inside) {
@@ -1296,19 +1298,25 @@ extern "C" size_t bfm_uniform_boxes_bytes(int D, int H, int W, int passes) {
     return ((n + 3) & ~(size_t)3) + 4;                         // flags, then the index of the first flagged box
 }
 
-extern "C" int bfm_uniform_boxes(const float* image, int D, int H, int W, int radius, int passes, unsigned char* flags,
-                                 bfm_stream_t stream) {
-    if (!image || !flags || D <= 0 || H <= 0 || W <= 0 || radius < 0 || radius > 8) return BFM_E_ARG;
+extern "C" int bfm_uniform_boxes_level(const float* image, int D, int H, int W, int level, int radius, int passes,
+                                       unsigned char* flags, bfm_stream_t stream) {
+    if (!image || !flags || D <= 0 || H <= 0 || W <= 0 || radius < 0 || radius > 64 || level < 0 || level > 4) return BFM_E_ARG;
     if (reinterpret_cast<uintptr_t>(flags) & 3) return BFM_E_ARG;
+    const int d = D >> level, h = H >> level, w = W >> level;          // MaxPool3d(2) floors
     int TD, TH, TW;
-    if (!choose_box(D, H, W, passes == 3 ? 2 : 1, TD, TH, TW)) return BFM_E_SHAPE;
-    const int nTz = bfm_cdiv(D, TD), nTy = bfm_cdiv(H, TH), nTx = bfm_cdiv(W, TW);
+    if (d <= 0 || h <= 0 || w <= 0 || !choose_box(d, h, w, passes == 3 ? 2 : 1, TD, TH, TW)) return BFM_E_SHAPE;
+    const int nTz = bfm_cdiv(d, TD), nTy = bfm_cdiv(h, TH), nTx = bfm_cdiv(w, TW);
     const size_t n = (size_t)nTz * nTy * nTx;
     int* first = reinterpret_cast<int*>(flags + ((n + 3) & ~(size_t)3));
     hipLaunchKernelGGL(uniform_boxes_kernel, dim3((unsigned)n), dim3(256), 0, bfm_s(stream), image, D, H, W, TD, TH, TW, nTy,
-                       nTx, radius, flags);
+                       nTx, level, radius, flags);
     hipLaunchKernelGGL(uniform_first_kernel, dim3(1), dim3(256), 0, bfm_s(stream), flags, (int)n, first);
     return bfm_launch_status();
+}
+
+extern "C" int bfm_uniform_boxes(const float* image, int D, int H, int W, int radius, int passes, unsigned char* flags,
+                                 bfm_stream_t stream) {
+    return bfm_uniform_boxes_level(image, D, H, W, 0, radius, passes, flags, stream);
 }
 
 extern "C" size_t bfm_conv3x3x3_wino_uniform_scratch(int Cout) {

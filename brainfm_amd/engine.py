@@ -613,19 +613,25 @@ class UNetEngine:
         self.last_mask_fraction = n / float(D * H * W)
         return n
 
-    def uniform_flags(self, x_cl, dims, radius):
-        """bfm_uniform_boxes of the one-channel image x_cl (D,H,W,1) for the Winograd kernel's box grid of `dims`, or None
-        (switched off, more channels, or no such grid)."""
+    def uniform_flags(self, x_cl, dims, radius, level=0):
+        """bfm_uniform_boxes_level of the one-channel image x_cl (D,H,W,1), dims = the image's: flags for the Winograd
+        kernel's box grid of the tensor `level` poolings down, or None (switched off, more channels, or no such grid)."""
         if not self.uniform_skip or x_cl is None or x_cl.shape[-1] != 1 or self.tape is not None:
             return None
         D, H, W = dims
-        n = self.lib.bfm_uniform_boxes_bytes(D, H, W, self.passes)
+        n = self.lib.bfm_uniform_boxes_bytes(D >> level, H >> level, W >> level, self.passes)
         if n <= 0:
             return None
         flags = torch.empty(n, dtype=torch.uint8, device=self.device)     # one byte per box + the first flagged index
-        L.check(self.lib.bfm_uniform_boxes(L.ptr(x_cl), D, H, W, int(radius), self.passes, L.ptr(flags), L.stream_ptr()),
-                "uniform_boxes")
+        L.check(self.lib.bfm_uniform_boxes_level(L.ptr(x_cl), D, H, W, int(level), int(radius), self.passes, L.ptr(flags),
+                                                 L.stream_ptr()), "uniform_boxes")
         return flags
+
+    # image-voxel radius within which the input must be constant for the OUTPUT of these layers to be one vector:
+    # (encoder level, conv index) and the skip halves of the decoders that end at levels 0 and 1
+    UNIFORM_RADIUS = {("enc", 0, 1): 2, ("dec", 0): 3}
+    if os.environ.get("BFM_UNIFORM_LEVELS", "0") == "1":   # level 1 too: measured, no gain (DESIGN 3.5)
+        UNIFORM_RADIUS.update({("enc", 1, 0): 4, ("enc", 1, 1): 6, ("dec", 1): 8})
 
     def uniform_voxels(self, flags, dims):
         """Voxels' worth of matrix products a bfm_conv3x3x3_wino_uniform launch runs: the boxes not flagged and one of the
@@ -1000,7 +1006,7 @@ class UNetEngine:
         if self.has_deep_region():
             return self.backbone_batch([x_cl], dims, mask_last=mask_last)[0]
         mask_img = x_cl if (mask_last and self.mask_skip and x_cl.shape[-1] == 1) else None
-        uf2, uf3 = self.uniform_flags(x_cl, dims, 2), self.uniform_flags(x_cl, dims, 3)
+        UR = self.UNIFORM_RADIUS
         skips = []
         x, d = x_cl, tuple(dims)
         for i, (l1, l2) in enumerate(self.enc):
@@ -1008,14 +1014,17 @@ class UNetEngine:
                 if min(d) < 2:
                     raise L.BfmError("volume %s too small for %d pooling levels" % (dims, len(self.enc) - 1))
                 x, d = self.maxpool(x, d)
-            x = self.single_conv(l1, x, d)
-            x = self.single_conv(l2, x, d, uni_flags=uf2 if i == 0 else None)
+            uf1 = self.uniform_flags(x_cl, dims, UR[("enc", i, 0)], i) if ("enc", i, 0) in UR else None
+            x = self.single_conv(l1, x, d, uni_flags=uf1)
+            uf2 = self.uniform_flags(x_cl, dims, UR[("enc", i, 1)], i) if ("enc", i, 1) in UR else None
+            x = self.single_conv(l2, x, d, uni_flags=uf2)
             skips.insert(0, (x, d))
         skips = skips[1:]
         feats = [(x, d)]
         for k, ((l1, l2), (skip, sd_)) in enumerate(zip(self.dec, skips)):
-            last = k == len(self.dec) - 1 and len(self.dec) == len(self.enc) - 1      # ends at full resolution
-            y = self.single_conv(l1, skip, sd_, B=x, lo_dims=d, uni_flags=uf3 if last else None)
+            lvl = len(self.dec) - 1 - k                       # the level this decoder ends at
+            uf = self.uniform_flags(x_cl, dims, UR[("dec", lvl)], lvl) if ("dec", lvl) in UR else None
+            y = self.single_conv(l1, skip, sd_, B=x, lo_dims=d, uni_flags=uf)
             x = self.single_conv(l2, y, sd_, mask_img=mask_img if k == len(self.dec) - 1 else None)
             d = sd_
             feats.append((x, d))
@@ -1030,8 +1039,11 @@ class UNetEngine:
                 if min(d) < 2:
                     raise L.BfmError("volume %s too small for %d pooling levels" % (dims, len(self.enc) - 1))
                 x, d = self.maxpool(x, d)
-            x = self.single_conv(l1, x, d)
-            x = self.single_conv(l2, x, d, uni_flags=self.uniform_flags(x_cl, dims, 2) if i == 0 else None)
+            UR = self.UNIFORM_RADIUS
+            uf1 = self.uniform_flags(x_cl, dims, UR[("enc", i, 0)], i) if ("enc", i, 0) in UR else None
+            x = self.single_conv(l1, x, d, uni_flags=uf1)
+            uf2 = self.uniform_flags(x_cl, dims, UR[("enc", i, 1)], i) if ("enc", i, 1) in UR else None
+            x = self.single_conv(l2, x, d, uni_flags=uf2)
             skips.append((x, d))
         return skips
 
@@ -1042,7 +1054,11 @@ class UNetEngine:
         feats = []
         nd = len(self.dec) - ndeep
         for k, ((l1, l2), (skip, sd_)) in enumerate(zip(self.dec[ndeep:], reversed(skips))):
-            uf = self.uniform_flags(image, sd_, 3) if (k == nd - 1 and image is not None) else None
+            lvl = nd - 1 - k                                  # the level this decoder ends at
+            uf = None
+            if image is not None and ("dec", lvl) in self.UNIFORM_RADIUS:
+                idims = tuple(image.shape[:3])
+                uf = self.uniform_flags(image, idims, self.UNIFORM_RADIUS[("dec", lvl)], lvl)
             y = self.single_conv(l1, skip, sd_, B=x, lo_dims=d, uni_flags=uf)
             x = self.single_conv(l2, y, sd_, mask_img=mask_img if k == nd - 1 else None)
             d = sd_

@@ -138,6 +138,13 @@ int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W, const flo
 size_t bfm_uniform_boxes_bytes(int D, int H, int W, int passes);
 int bfm_uniform_boxes(const float* image, int D, int H, int W, int radius, int passes, unsigned char* flags,
                       bfm_stream_t stream);
+/* the same for a layer `level` MaxPool3d(2) steps down: the box grid is that of the (D >> level, ...) tensor, a box covers
+ * image voxels [z0 << level, (z0 + TD) << level), and radius is in IMAGE voxels: 2 * 2^0 for the two level-0 convolutions
+ * plus 2^level per convolution at the layer's own level up to its output (4, 6, 8 for the three level-1 layers that read the
+ * first activations: encoders.1 conv 1 / conv 2 and the skip half of the second-to-last decoder's conv 1).  flags:
+ * bfm_uniform_boxes_bytes(D >> level, H >> level, W >> level, passes) bytes. */
+int bfm_uniform_boxes_level(const float* image, int D, int H, int W, int level, int radius, int passes, unsigned char* flags,
+                            bfm_stream_t stream);
 size_t bfm_conv3x3x3_wino_uniform_scratch(int Cout);
 int bfm_conv3x3x3_wino_uniform(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                                const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,

@@ -1075,10 +1075,10 @@ def test_uniform_background_boxes_change_no_bit():
     import ctypes as C
     from brainfm_amd import _lib as L
     ga, ta = TU.default_inference_args(f_maps=64, num_levels=3)
-    dims = (48, 64, 96)
+    dims = (48, 64, 128)
     g = torch.Generator().manual_seed(3)
     zz, yy, xx = np.meshgrid(*[np.linspace(-1, 1, n_) for n_ in dims], indexing="ij")
-    inside = torch.from_numpy((zz / 0.45) ** 2 + (yy / 0.4) ** 2 + ((xx + 0.3) / 0.35) ** 2 < 1)
+    inside = torch.from_numpy((zz / 0.45) ** 2 + (yy / 0.4) ** 2 + ((xx + 0.5) / 0.3) ** 2 < 1)
     vol = (torch.rand(dims, generator=g) + 0.05) * inside
     x = vol[None, None].to(_dev())
     outs = {}
@@ -1093,25 +1093,28 @@ def test_uniform_background_boxes_change_no_bit():
             box = (C.c_int * 3)()
             L.check(eng.lib.bfm_conv3x3x3_wino_box(dims[0], dims[1], dims[2], eng.passes, box), "box")
             img = vol.numpy()
-            for rad in (2, 3):
-                raw = eng.uniform_flags(x[0, 0].unsqueeze(-1).contiguous(), dims, rad).cpu().numpy()
-                nb = eng.lib.bfm_conv3x3x3_wino_rows(dims[0], dims[1], dims[2], eng.passes)
+            for lvl, rad in ((0, 2), (0, 3), (1, 4), (1, 6), (1, 8)):
+                ld = tuple(v >> lvl for v in dims)
+                L.check(eng.lib.bfm_conv3x3x3_wino_box(ld[0], ld[1], ld[2], eng.passes, box), "box")
+                raw = eng.uniform_flags(x[0, 0].unsqueeze(-1).contiguous(), dims, rad, lvl).cpu().numpy()
+                nb = eng.lib.bfm_conv3x3x3_wino_rows(ld[0], ld[1], ld[2], eng.passes)
                 fl = raw[:nb]
                 first = int(raw[(nb + 3) // 4 * 4:(nb + 3) // 4 * 4 + 4].view(np.int32)[0])
                 want = []
-                for z in range(0, dims[0], box[0]):
-                    for y in range(0, dims[1], box[1]):
-                        for xx_ in range(0, dims[2], box[2]):
-                            lo = (z - rad, y - rad, xx_ - rad)
-                            hi = (z + box[0] + rad, y + box[1] + rad, xx_ + box[2] + rad)
+                for z in range(0, ld[0], box[0]):
+                    for y in range(0, ld[1], box[1]):
+                        for xx_ in range(0, ld[2], box[2]):
+                            lo = ((z << lvl) - rad, (y << lvl) - rad, (xx_ << lvl) - rad)
+                            hi = (((z + box[0]) << lvl) + rad, ((y + box[1]) << lvl) + rad, ((xx_ + box[2]) << lvl) + rad)
                             ok = min(lo) >= 0 and all(h <= d for h, d in zip(hi, dims))
                             if ok:
                                 blk = img[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
                                 ok = bool((blk.view(np.uint32) == blk.view(np.uint32).flat[0]).all())
                             want.append(1 if ok else 0)
-                assert np.array_equal(fl, np.array(want, dtype=np.uint8)), rad
-                assert 0 < fl.sum() < fl.size, (rad, int(fl.sum()))
-                assert first == int(np.flatnonzero(fl)[0])
+                assert np.array_equal(fl, np.array(want, dtype=np.uint8)), (lvl, rad)
+                if lvl == 0:
+                    assert 0 < fl.sum() < fl.size, (rad, int(fl.sum()))
+                assert first == (int(np.flatnonzero(fl)[0]) if fl.any() else nb)
             kinds = s.engine.conv_choices()
             assert 3 in set(kinds.values())                       # the Winograd variant ran: the flags were used
     for k in outs[True]:
