@@ -442,7 +442,9 @@ def main():
                     fl = eng.uniform_flags(t.unsqueeze(-1), tuple(t.shape), rad)
                     if fl is not None:
                         nb = eng.lib.bfm_conv3x3x3_wino_rows(t.shape[0], t.shape[1], t.shape[2], eng.passes)
-                        v = max(int(fl[:nb].sum().item()) - 1, 0) / float(nb) * t.numel()   # all flagged boxes but one
+                        f = fl[:nb]
+                        reused = int((f != 0).sum().item()) - int(torch.unique(f[f != 0]).numel())
+                        v = max(reused, 0) / float(nb) * t.numel()          # all flagged boxes but one per class
                         if rad == 2:
                             uni2 += v
                         else:

@@ -49,9 +49,9 @@ struct WinoParams {
     float *rmn, *rmx;
     int ws_buf_bytes;                // persistent kernel: bytes per LDS buffer
     const float* mask_img;           // optional (D,H,W) image: a box none of whose voxels is non-zero there is not computed
-    const unsigned char* uni_flags;  // optional [nMt]: 1 = every row of the box sees the same operands (conv_wino_uniform)
-    const int* uni_first;            // index of the first flagged box (>= nMt: none): the one conv_wino_rest computes
-    float* uni_acc;                  // [NT][NTHR][32]: that box's accumulators of row block 0, for all the other flagged boxes
+    const unsigned char* uni_flags;  // optional [nMt]: 0, or 1 + the class of a box whose operands equal its class mates'
+    const int* uni_first;            // [27] first box of each class (>= nMt: none): the ones conv_wino_rest computes
+    float* uni_acc;                  // [27][NT][2][16][NTHR][2]: those boxes' output-transformed sums, for their class mates
 };
 
 __device__ __forceinline__ int row_perm(int l) {        // as conv_mfma: each 16-lane b128 group reads 16 consecutive positions
@@ -101,14 +101,15 @@ __device__ __forceinline__ void split_store4(const float (&t)[4], unsigned char*
 }
 
 // MODE 0: every box in full.  1 (conv_wino_masked): boxes without input are not computed.  2 / 3 (conv_wino_rest,
-// conv_wino_uniform; launched as a pair): boxes flagged uniform -- the layer's input is the same vector at every voxel the
-// box reads, because the network's input is constant around it (the background of a head volume) and no zero padding is
-// involved.  Every row of every such box multiplies the same operands in the same order, so all of them end the main loop
-// with the same accumulators: conv_wino_rest computes the unflagged boxes and ONE flagged box (the first), whose row
-// block 0 accumulators it also leaves in uni_acc; conv_wino_uniform then gives every other flagged box those
-// accumulators -- the bits its own main loop would have produced -- and runs the normal epilogue (output transform,
-// accumulate mode, activation, moment rows) on them: no staging, no weights, no matrix products.  Two kernels rather
-// than a branch: a second loop body in one kernel made the allocator spill 54 registers and the layer 25 % slower.
+// conv_wino_uniform; launched as a pair): boxes flagged uniform -- the network's input is constant over everything the box
+// can see (the background of a head volume), so the layer's input around the box is a function of the distances to the
+// tile's faces alone.  Boxes of one CLASS (per axis: first box, last box, or in between -- 27 classes) then multiply the
+// same operands in the same order, voxel for voxel, and end the main loop with the same accumulators: conv_wino_rest
+// computes the unflagged boxes and the first flagged box of every class, whose output-transformed sums (before accumulate
+// mode and the activation) it also leaves in uni_acc; conv_wino_uniform gives every other flagged box its class's sums --
+// the bits its own main loop and transform would have produced -- in the same thread order, and runs the rest of the
+// epilogue (accumulate mode, activation, store, moment rows) on them: no staging, no weights, no matrix products, no LDS.  Two kernels rather than a branch: a second loop body in one kernel made the
+// allocator spill 54 registers and the layer 25 % slower.
 template <int NPASS, int MODE>
 __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
     constexpr bool MASKED = MODE == 1;
@@ -144,10 +145,12 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
     const int ty = (mt / p.nTx) % p.nTy;
     const int tz = mt / (p.nTx * p.nTy);
     const int z0 = tz * p.TD, y0 = ty * p.TH, x0 = tx * p.TW;
-    bool rep = false;                                    // conv_wino_rest: this is the flagged box it computes
+    bool rep = false;                                    // conv_wino_rest: this is a flagged box it computes
+    int cls = 0;                                         // 1 + class of a flagged box
     if constexpr (BY_FLAG) {                             // wave-uniform exits before any barrier
-        const bool flagged = __builtin_amdgcn_readfirstlane((int)p.uni_flags[mt]) != 0;
-        rep = flagged && mt == __builtin_amdgcn_readfirstlane(*p.uni_first);
+        cls = __builtin_amdgcn_readfirstlane((int)p.uni_flags[mt]);
+        const bool flagged = cls != 0;
+        rep = flagged && mt == __builtin_amdgcn_readfirstlane(p.uni_first[flagged ? cls - 1 : 0]);
         if (UNI ? (!flagged || rep) : (flagged && !rep)) return;
     }
 
@@ -339,20 +342,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
             }
         }
     };
-    if constexpr (UNI) {
-        const float4* src4 = reinterpret_cast<const float4*>(p.uni_acc + ((size_t)nt * NTHR + tid) * 32);
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 v4 = src4[nb * 4 + q];
-                acc[0][nb][4 * q] = v4.x; acc[0][nb][4 * q + 1] = v4.y; acc[0][nb][4 * q + 2] = v4.z; acc[0][nb][4 * q + 3] = v4.w;
-            }
-#pragma unroll
-        for (int mb = 1; mb < 4; ++mb)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = acc[0][nb];
-    } else {
+    if constexpr (!UNI) {
         using MbTag = std::integral_constant<int, 4>;
         if constexpr (NSET == 3) {
             for (int kc = 0; kc < p.KCN; ++kc) do_chunk(kc, std::integral_constant<int, 0>{}, MbTag{});
@@ -362,16 +352,13 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
                 if (kc + 1 < p.KCN) do_chunk(kc + 1, std::integral_constant<int, 1>{}, MbTag{});
             }
         }
-        if (MODE == 2 && rep) {                             // the flagged boxes' common accumulators
-            float4* dst4 = reinterpret_cast<float4*>(p.uni_acc + ((size_t)nt * NTHR + tid) * 32);
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    dst4[nb * 4 + q] = make_float4(acc[0][nb][4 * q], acc[0][nb][4 * q + 1], acc[0][nb][4 * q + 2],
-                                                   acc[0][nb][4 * q + 3]);
-        }
     }
+    // conv_wino_rest leaves, for the first flagged box of a class, the output-transformed sums (before accumulate mode and
+    // the activation) of every thread's 16 pairs in uni_acc [class][nt][nb][it][thread] (y0, y1); conv_wino_uniform reads
+    // them back in the same thread order and goes on from there
+    float2* const ybuf = BY_FLAG && cls ? reinterpret_cast<float2*>(p.uni_acc) +
+                                              ((size_t)(cls - 1) * p.NT + nt) * (2 * 16 * NTHR) + tid
+                                        : nullptr;
 
     // ================= epilogue: output transform through LDS =================
     float* m = reinterpret_cast<float*>(lds);                      // [4 positions][128 accumulator rows][MLD]
@@ -413,12 +400,14 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
                     prev1[it] = o[off_t + (unsigned)p.Cout];
                 }
             }
+            if constexpr (!UNI) {
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb)
+                for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    mw[(mb * 32 + (i >> 2) * 8 + (i & 3)) * MLD] = acc[mb][nb][i];
-            __syncthreads();
+                    for (int i = 0; i < 16; ++i)
+                        mw[(mb * 32 + (i >> 2) * 8 + (i & 3)) * MLD] = acc[mb][nb][i];
+                __syncthreads();
+            }
             const float* mr = m + col;
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
@@ -426,13 +415,20 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
                 const int j_u = qu & ((1 << p.pw_shift) - 1), r_u = qu >> p.pw_shift;
                 const int h_u = r_u & ((1 << th_shift) - 1), d_u = r_u >> th_shift;
                 float* o = ob + (((int64_t)(z0 + d_u) * p.H + (y0 + h_u)) * p.W + x0 + 2 * j_u) * p.Cout;
-                // accumulator row holding pair q: (q & ~31) + row_unperm(q & 31), q & 31 = row0 + 8 (it & 3)
-                const int sub = it & 3;
-                const int qr = (qu & ~31) + (sub == 0 ? un0 : sub == 1 ? row0 + 8 + 12 : sub == 2 ? row0 + 16 - 12 : un3);
-                const float m0 = mr[(0 * 128 + qr) * MLD], m1 = mr[(1 * 128 + qr) * MLD];
-                const float m2 = mr[(2 * 128 + qr) * MLD], m3 = mr[(3 * 128 + qr) * MLD];
-                float y0v = ((m0 + m1) + m2) * dq;
-                float y1v = ((m1 - m2) - m3) * dq;
+                float y0v, y1v;
+                if constexpr (UNI) {
+                    const float2 yy = ybuf[(nb * 16 + it) * NTHR];
+                    y0v = yy.x; y1v = yy.y;
+                } else {
+                    // accumulator row holding pair q: (q & ~31) + row_unperm(q & 31), q & 31 = row0 + 8 (it & 3)
+                    const int sub = it & 3;
+                    const int qr = (qu & ~31) + (sub == 0 ? un0 : sub == 1 ? row0 + 8 + 12 : sub == 2 ? row0 + 16 - 12 : un3);
+                    const float m0 = mr[(0 * 128 + qr) * MLD], m1 = mr[(1 * 128 + qr) * MLD];
+                    const float m2 = mr[(2 * 128 + qr) * MLD], m3 = mr[(3 * 128 + qr) * MLD];
+                    y0v = ((m0 + m1) + m2) * dq;
+                    y1v = ((m1 - m2) - m3) * dq;
+                    if (MODE == 2 && rep) ybuf[(nb * 16 + it) * NTHR] = make_float2(y0v, y1v);
+                }
                 if (p.accum) { y0v = y0v + prev0[it]; y1v = y1v + prev1[it]; }
                 y0v = y0v >= 0.f ? y0v : y0v * p.slope;
                 y1v = y1v >= 0.f ? y1v : y1v * p.slope;
@@ -460,12 +456,14 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
                 }
             }
         }
+        if constexpr (!UNI) {
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb)
+            for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i)                            // accumulator row order (compile-time offsets);
-                mw[(mb * 32 + (i >> 2) * 8 + (i & 3)) * MLD] = acc[mb][nb][i];   // the reader undoes row_perm
-        __syncthreads();
+                for (int i = 0; i < 16; ++i)                        // accumulator row order (compile-time offsets);
+                    mw[(mb * 32 + (i >> 2) * 8 + (i & 3)) * MLD] = acc[mb][nb][i];   // the reader undoes row_perm
+            __syncthreads();
+        }
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int q = row0 + 8 * it;
@@ -473,12 +471,19 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
             pair_coords(p, q, d, h, j);
             const int gz = z0 + d, gy = y0 + h, gx = x0 + 2 * j;
             if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
-            const int qr = (q & ~31) + row_unperm(q & 31);           // accumulator row holding pair q
-            const float m0 = m[(0 * 128 + qr) * MLD + col], m1 = m[(1 * 128 + qr) * MLD + col];
-            const float m2 = m[(2 * 128 + qr) * MLD + col], m3 = m[(3 * 128 + qr) * MLD + col];
             float* o = p.out + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + nt * 64 + nb * 32 + col;
-            float y0v = ((m0 + m1) + m2) * dq;
-            float y1v = ((m1 - m2) - m3) * dq;
+            float y0v, y1v;
+            if constexpr (UNI) {
+                const float2 yy = ybuf[(nb * 16 + it) * NTHR];
+                y0v = yy.x; y1v = yy.y;
+            } else {
+                const int qr = (q & ~31) + row_unperm(q & 31);       // accumulator row holding pair q
+                const float m0 = m[(0 * 128 + qr) * MLD + col], m1 = m[(1 * 128 + qr) * MLD + col];
+                const float m2 = m[(2 * 128 + qr) * MLD + col], m3 = m[(3 * 128 + qr) * MLD + col];
+                y0v = ((m0 + m1) + m2) * dq;
+                y1v = ((m1 - m2) - m3) * dq;
+                if (MODE == 2 && rep) ybuf[(nb * 16 + it) * NTHR] = make_float2(y0v, y1v);
+            }
             if (p.accum) y0v = y0v + prev0[it];
             y0v = y0v >= 0.f ? y0v : y0v * p.slope;
             o[0] = y0v;
@@ -493,7 +498,8 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
         }
         if (p.rsum != nullptr) {
             // moment row of this tile: fold the 8 row groups of every column in fixed order (scratch behind m)
-            double* ls = reinterpret_cast<double*>(lds + 4 * 128 * MLD * sizeof(float));   // [8][32]
+            // (conv_wino_uniform uses no other LDS: its fold sits at offset 0 and the launch asks for 6 KB)
+            double* ls = reinterpret_cast<double*>(lds + (UNI ? 0 : 4 * 128 * MLD * sizeof(float)));   // [8][32]
             double* lq = ls + 256;
             float* lmn = reinterpret_cast<float*>(lq + 256);
             float* lmx = lmn + 256;
@@ -529,42 +535,48 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino_rest(const WinoParams p) { 
 template <int NPASS>
 __global__ void __launch_bounds__(NTHR, 2) conv_wino_uniform(const WinoParams p) { conv_wino_body<NPASS, 3>(p); }
 
-// flags[box] = 1 when the (D,H,W) image is bitwise constant over the box -- a box of the layer's grid at pooling level L,
-// i.e. voxels [z0 << L, (z0 + TD) << L) of the image -- grown by `R` image voxels, and that grown region lies inside the
-// volume (no zero padding within reach at any level).  One workgroup per box, the box grid of the 4-wave kernel.
+// flags[box] = 0, or 1 + class when the (D,H,W) image is bitwise constant over the box -- a box of the layer's grid at
+// pooling level L, i.e. voxels [z0 << L, (z0 + TD) << L) of the image -- grown by `R` image voxels and clipped to the
+// volume.  class = 9 cz + 3 cy + cx with c = 0 for the first box along the axis, 2 for the last (if there is more than
+// one), 1 in between: what the box can see of the tile's faces (zero padding at every level on the way) is the same for
+// all boxes of a class, because a box side is longer than the reach R at its level.  One workgroup per box.
 __global__ void __launch_bounds__(256) uniform_boxes_kernel(const float* __restrict__ img, int D, int H, int W, int TD, int TH,
-                                                            int TW, int nTy, int nTx, int L, int R,
+                                                            int TW, int nTz, int nTy, int nTx, int L, int R,
                                                             unsigned char* __restrict__ flags) {
     const int mt = blockIdx.x;
     const int tx = mt % nTx, ty = (mt / nTx) % nTy, tz = mt / (nTx * nTy);
-    const int z0 = ((tz * TD) << L) - R, y0 = ((ty * TH) << L) - R, x0 = ((tx * TW) << L) - R;
-    const int ed = (TD << L) + 2 * R, eh = (TH << L) + 2 * R, ew = (TW << L) + 2 * R;
-    const bool inside = z0 >= 0 && y0 >= 0 && x0 >= 0 && z0 + ed <= D && y0 + eh <= H && x0 + ew <= W;   // block-uniform
-    int bad = inside ? 0 : 1;
-    if (inside) {
-        const unsigned ref = __float_as_uint(img[((int64_t)z0 * H + y0) * W + x0]);
-        for (int q = threadIdx.x; q < ed * eh * ew; q += 256) {
-            const int w = q % ew, r = q / ew, h = r % eh, d = r / eh;
-            bad |= __float_as_uint(img[((int64_t)(z0 + d) * H + (y0 + h)) * W + (x0 + w)]) != ref ? 1 : 0;
-        }
+    const int z0 = max(((tz * TD) << L) - R, 0), y0 = max(((ty * TH) << L) - R, 0), x0 = max(((tx * TW) << L) - R, 0);
+    const int z1 = min((((tz + 1) * TD) << L) + R, D), y1 = min((((ty + 1) * TH) << L) + R, H);
+    const int x1 = min((((tx + 1) * TW) << L) + R, W);
+    const int ed = z1 - z0, eh = y1 - y0, ew = x1 - x0;
+    int bad = 0;
+    const unsigned ref = __float_as_uint(img[((int64_t)z0 * H + y0) * W + x0]);
+    for (int q = threadIdx.x; q < ed * eh * ew; q += 256) {
+        const int w = q % ew, r = q / ew, h = r % eh, d = r / eh;
+        bad |= __float_as_uint(img[((int64_t)(z0 + d) * H + (y0 + h)) * W + (x0 + w)]) != ref ? 1 : 0;
     }
     bad = __syncthreads_or(bad);
-    if (threadIdx.x == 0) flags[mt] = bad ? 0 : 1;
+    if (threadIdx.x == 0) {
+        const int cz = tz == 0 ? 0 : (tz == nTz - 1 ? 2 : 1), cy = ty == 0 ? 0 : (ty == nTy - 1 ? 2 : 1);
+        const int cx = tx == 0 ? 0 : (tx == nTx - 1 ? 2 : 1);
+        flags[mt] = bad ? 0 : (unsigned char)(1 + 9 * cz + 3 * cy + cx);
+    }
 }
 
-// index of the first flagged box (n: none); one workgroup
+// first[c] = index of the first box of class c (n: none); one workgroup per class
 __global__ void __launch_bounds__(256) uniform_first_kernel(const unsigned char* __restrict__ flags, int n, int* __restrict__ first) {
     __shared__ int best[256];
+    const unsigned char want = (unsigned char)(blockIdx.x + 1);
     int b = n;
     for (int i = threadIdx.x; i < n; i += 256)
-        if (flags[i]) { b = i; break; }                       // ascending per thread: its first hit is its smallest
+        if (flags[i] == want) { b = i; break; }               // ascending per thread: its first hit is its smallest
     best[threadIdx.x] = b;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if (threadIdx.x < o) best[threadIdx.x] = min(best[threadIdx.x], best[threadIdx.x + o]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) *first = best[0];
+    if (threadIdx.x == 0) first[blockIdx.x] = best[0];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1295,7 +1307,7 @@ extern "C" size_t bfm_uniform_boxes_bytes(int D, int H, int W, int passes) {
     int TD, TH, TW;
     if (D <= 0 || H <= 0 || W <= 0 || !choose_box(D, H, W, passes == 3 ? 2 : 1, TD, TH, TW)) return 0;
     const size_t n = (size_t)bfm_cdiv(D, TD) * bfm_cdiv(H, TH) * bfm_cdiv(W, TW);
-    return ((n + 3) & ~(size_t)3) + 4;                         // flags, then the index of the first flagged box
+    return ((n + 3) & ~(size_t)3) + 27 * 4;                    // flags, then the first box of each of the 27 classes
 }
 
 extern "C" int bfm_uniform_boxes_level(const float* image, int D, int H, int W, int level, int radius, int passes,
@@ -1308,9 +1320,11 @@ extern "C" int bfm_uniform_boxes_level(const float* image, int D, int H, int W, 
     const int nTz = bfm_cdiv(d, TD), nTy = bfm_cdiv(h, TH), nTx = bfm_cdiv(w, TW);
     const size_t n = (size_t)nTz * nTy * nTx;
     int* first = reinterpret_cast<int*>(flags + ((n + 3) & ~(size_t)3));
-    hipLaunchKernelGGL(uniform_boxes_kernel, dim3((unsigned)n), dim3(256), 0, bfm_s(stream), image, D, H, W, TD, TH, TW, nTy,
-                       nTx, level, radius, flags);
-    hipLaunchKernelGGL(uniform_first_kernel, dim3(1), dim3(256), 0, bfm_s(stream), flags, (int)n, first);
+    // a class is well defined when a box side outreaches the radius at its level (else a middle box could see a face)
+    if ((TD << level) < radius || (TH << level) < radius || (TW << level) < radius) return BFM_E_SHAPE;
+    hipLaunchKernelGGL(uniform_boxes_kernel, dim3((unsigned)n), dim3(256), 0, bfm_s(stream), image, D, H, W, TD, TH, TW, nTz,
+                       nTy, nTx, level, radius, flags);
+    hipLaunchKernelGGL(uniform_first_kernel, dim3(27), dim3(256), 0, bfm_s(stream), flags, (int)n, first);
     return bfm_launch_status();
 }
 
@@ -1320,7 +1334,7 @@ extern "C" int bfm_uniform_boxes(const float* image, int D, int H, int W, int ra
 }
 
 extern "C" size_t bfm_conv3x3x3_wino_uniform_scratch(int Cout) {
-    return Cout > 0 && Cout % 64 == 0 ? (size_t)(Cout / 64) * NTHR * 32 * sizeof(float) : 0;
+    return Cout > 0 && Cout % 64 == 0 ? (size_t)27 * (Cout / 64) * 2 * 16 * NTHR * 2 * sizeof(float) : 0;
 }
 
 extern "C" int bfm_conv3x3x3_wino_uniform(const float* A, int CA, int D, int H, int W, const float* scale,
@@ -1468,10 +1482,10 @@ static int wino_launch(const float* A, int CA, int D, int H, int W, const float*
     if (uni_flags) {                                           // disjoint boxes: the two launches may overlap
         if (passes == 3) {
             hipLaunchKernelGGL(conv_wino_rest<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
-            hipLaunchKernelGGL(conv_wino_uniform<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+            hipLaunchKernelGGL(conv_wino_uniform<3>, grid, dim3(NTHR), 6144, bfm_s(stream), p);
         } else {
             hipLaunchKernelGGL(conv_wino_rest<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
-            hipLaunchKernelGGL(conv_wino_uniform<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+            hipLaunchKernelGGL(conv_wino_uniform<1>, grid, dim3(NTHR), 6144, bfm_s(stream), p);
         }
         return bfm_launch_status();
     }

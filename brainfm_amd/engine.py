@@ -622,9 +622,12 @@ class UNetEngine:
         n = self.lib.bfm_uniform_boxes_bytes(D >> level, H >> level, W >> level, self.passes)
         if n <= 0:
             return None
-        flags = torch.empty(n, dtype=torch.uint8, device=self.device)     # one byte per box + the first flagged index
-        L.check(self.lib.bfm_uniform_boxes_level(L.ptr(x_cl), D, H, W, int(level), int(radius), self.passes, L.ptr(flags),
-                                                 L.stream_ptr()), "uniform_boxes")
+        flags = torch.empty(n, dtype=torch.uint8, device=self.device)     # one byte per box + the first box of each class
+        rc = self.lib.bfm_uniform_boxes_level(L.ptr(x_cl), D, H, W, int(level), int(radius), self.passes, L.ptr(flags),
+                                              L.stream_ptr())
+        if rc == -2:                                         # BFM_E_SHAPE: a box side shorter than the radius, no classes
+            return None
+        L.check(rc, "uniform_boxes")
         return flags
 
     # image-voxel radius within which the input must be constant for the OUTPUT of these layers to be one vector:
@@ -634,12 +637,14 @@ class UNetEngine:
         UNIFORM_RADIUS.update({("enc", 1, 0): 4, ("enc", 1, 1): 6, ("dec", 1): 8})
 
     def uniform_voxels(self, flags, dims):
-        """Voxels' worth of matrix products a bfm_conv3x3x3_wino_uniform launch runs: the boxes not flagged and one of the
-        flagged ones (host-side, for the instrumented pass; synchronises)."""
+        """Voxels' worth of matrix products a bfm_conv3x3x3_wino_uniform launch runs: the boxes not flagged and one flagged
+        box per class (host-side, for the instrumented pass; synchronises)."""
         nb = self.lib.bfm_conv3x3x3_wino_rows(dims[0], dims[1], dims[2], self.passes)
-        k = int(flags[:nb].sum().item())
+        f = flags[:nb]
+        k = int((f != 0).sum().item())
+        reused = k - int(torch.unique(f[f != 0]).numel())    # all flagged boxes but one per class present
         self.last_uniform_fraction = k / float(nb)
-        return int(round(dims[0] * dims[1] * dims[2] * (1.0 - max(k - 1, 0) / float(nb))))
+        return int(round(dims[0] * dims[1] * dims[2] * (1.0 - max(reused, 0) / float(nb))))
 
     def _skip_layer(self, ly, ca):
         """The skip-channel half of a decoder's first conv as a layer of its own (weights w[:, :ca])."""

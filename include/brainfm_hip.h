@@ -123,16 +123,18 @@ int bfm_conv3x3x3_wino_ex(const float* A, int CA, int D, int H, int W, const flo
 /* The last convolution of a tile inside the tile loop (scripts/demo_test.py:88-100 keeps `v * (tile_input != 0)` of every
  * output): a box of output voxels whose tile-input voxels are all zero feeds nothing that survives the mask, so it is not
  * computed (`out` keeps whatever it held there).  mask_image = the tile's input (D,H,W).  The 4-wave kernel, no moment rows. */
-/* Boxes whose rows all multiply the same operands.  Where the network's one-channel input image is bitwise constant
- * (the zero background of a skull-stripped head, utils/test_utils.py:235-284 min-max normalises it to exact zeros) every
- * activation of the first layers is the same vector at every voxel, away from the zero padding: stem output where the image
- * is constant within 1 voxel, encoders.0 second conv within 2, and so on.  bfm_uniform_boxes flags the boxes of the 4-wave
- * Winograd kernel's grid over which `image` is constant within `radius` voxels with the grown box inside the volume
- * (flags: bfm_uniform_boxes_bytes() bytes, 4-byte aligned: one byte per box, then the index of the first flagged box).
- * bfm_conv3x3x3_wino_uniform is bfm_conv3x3x3_wino_ex that computes the unflagged boxes and ONE flagged box in full, and
- * gives every other flagged box that box's accumulators (the bits its own main loop would produce: same operands, same
- * order, in every row of every flagged box) before the normal epilogue -- no staging, weights or matrix products there.
- * scratch: bfm_conv3x3x3_wino_uniform_scratch(Cout) bytes, 16-byte aligned.  The caller passes radius = (number of 3x3x3
+/* Boxes that multiply the same operands as other boxes.  Where the network's one-channel input image is bitwise constant
+ * (the zero background of a skull-stripped head, utils/test_utils.py:235-284 min-max normalises it to exact zeros) the
+ * activations of the first layers depend on the distances to the tile's faces only (zero padding): stem output where the
+ * image is constant within 1 voxel, encoders.0 second conv within 2, and so on.  bfm_uniform_boxes flags the boxes of the
+ * 4-wave Winograd kernel's grid over which `image` is constant within `radius` voxels (clipped to the volume) with
+ * 1 + class, class = 9 cz + 3 cy + cx, c = 0 / 1 / 2 for the first / a middle / the last box along the axis: all boxes of
+ * a class see the faces the same way (a box side must be >= radius: BFM_E_SHAPE otherwise).  flags:
+ * bfm_uniform_boxes_bytes() bytes, 4-byte aligned: one byte per box, then the first box of each of the 27 classes.
+ * bfm_conv3x3x3_wino_uniform is bfm_conv3x3x3_wino_ex that computes the unflagged boxes and the first flagged box of each
+ * class in full, and gives every other flagged box its class's accumulators (the bits its own main loop would produce: same
+ * operands, same order) before the normal epilogue -- no staging, weights or matrix products there.  scratch:
+ * bfm_conv3x3x3_wino_uniform_scratch(Cout) bytes, 16-byte aligned.  The caller passes radius = (number of 3x3x3
  * convolutions between the image and this layer's OUTPUT): 2 for encoders.0's second conv, 3 for the skip half of the last
  * decoder's first conv. */
 size_t bfm_uniform_boxes_bytes(int D, int H, int W, int passes);

@@ -1067,8 +1067,9 @@ def test_compact_rows_index_pack_and_stitch_equal_the_dense_form_bitwise(shape, 
 
 def test_uniform_background_boxes_change_no_bit():
     """Where the one-channel input is constant (the zero background of a head volume) the first layers' activations are one
-    vector per layer, and the two full-resolution Winograd layers that read them compute ONE of the boxes that see nothing
-    else and reuse its accumulators in the others (engine.uniform_skip: bfm_uniform_boxes + bfm_conv3x3x3_wino_uniform).  Every decoder
+    function of the distances to the tile's faces, and the two full-resolution Winograd layers that read them compute ONE box
+    per class of boxes that see nothing else (first / middle / last box per axis: 27 classes) and reuse its accumulators in
+    its class mates (engine.uniform_skip: bfm_uniform_boxes + bfm_conv3x3x3_wino_uniform).  Every decoder
     feature map, the tail's maps and the labels are bit-identical to the run with every box in full; the flags are the
     boxes whose grown neighbourhood is constant and inside the volume (numpy restatement); and some boxes are flagged."""
     from brainfm_amd import test_utils as TU
@@ -1099,22 +1100,26 @@ def test_uniform_background_boxes_change_no_bit():
                 raw = eng.uniform_flags(x[0, 0].unsqueeze(-1).contiguous(), dims, rad, lvl).cpu().numpy()
                 nb = eng.lib.bfm_conv3x3x3_wino_rows(ld[0], ld[1], ld[2], eng.passes)
                 fl = raw[:nb]
-                first = int(raw[(nb + 3) // 4 * 4:(nb + 3) // 4 * 4 + 4].view(np.int32)[0])
+                first = raw[(nb + 3) // 4 * 4:(nb + 3) // 4 * 4 + 108].view(np.int32)
+                nt = [-(-ld[a] // box[a]) for a in range(3)]
                 want = []
-                for z in range(0, ld[0], box[0]):
-                    for y in range(0, ld[1], box[1]):
-                        for xx_ in range(0, ld[2], box[2]):
-                            lo = ((z << lvl) - rad, (y << lvl) - rad, (xx_ << lvl) - rad)
-                            hi = (((z + box[0]) << lvl) + rad, ((y + box[1]) << lvl) + rad, ((xx_ + box[2]) << lvl) + rad)
-                            ok = min(lo) >= 0 and all(h <= d for h, d in zip(hi, dims))
-                            if ok:
-                                blk = img[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
-                                ok = bool((blk.view(np.uint32) == blk.view(np.uint32).flat[0]).all())
-                            want.append(1 if ok else 0)
-                assert np.array_equal(fl, np.array(want, dtype=np.uint8)), (lvl, rad)
+                for iz in range(nt[0]):
+                    for iy in range(nt[1]):
+                        for ix in range(nt[2]):
+                            z, y, xx_ = iz * box[0], iy * box[1], ix * box[2]
+                            lo = [max((v << lvl) - rad, 0) for v in (z, y, xx_)]
+                            hi = [min(((v + b) << lvl) + rad, d) for v, b, d in zip((z, y, xx_), box, dims)]
+                            blk = img[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+                            ok = bool((blk.view(np.uint32) == blk.view(np.uint32).flat[0]).all())
+                            c = [0 if i == 0 else (2 if i == n - 1 else 1) for i, n in zip((iz, iy, ix), nt)]
+                            want.append(1 + 9 * c[0] + 3 * c[1] + c[2] if ok else 0)
+                want = np.array(want, dtype=np.uint8)
+                assert np.array_equal(fl, want), (lvl, rad)
                 if lvl == 0:
-                    assert 0 < fl.sum() < fl.size, (rad, int(fl.sum()))
-                assert first == (int(np.flatnonzero(fl)[0]) if fl.any() else nb)
+                    assert 0 < (fl != 0).sum() < fl.size and len(np.unique(fl[fl != 0])) > 3, (rad, np.unique(fl))
+                for c in range(27):
+                    hit = np.flatnonzero(fl == c + 1)
+                    assert first[c] == (int(hit[0]) if hit.size else nb), (lvl, rad, c)
             kinds = s.engine.conv_choices()
             assert 3 in set(kinds.values())                       # the Winograd variant ran: the flags were used
     for k in outs[True]:
