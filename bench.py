@@ -434,22 +434,26 @@ def main():
         computed_step = flops_step - (tile_vox - conv_vox) * 2.0 * 27 * fm0 * fm0 - (tile_vox - head_vox) * 2.0 * fm0 * n_head
         # boxes of the two layers that read the first activations where the input is constant around them run a quarter of
         # their products (engine.uniform_skip)
-        uni2 = uni3 = 0.0
+        uni = {}
         if eng.uniform_skip:
+            chans = {("enc", 0, 1): (fm0 // 2, fm0), ("dec", 0): (fm0, fm0), ("enc", 1, 0): (fm0, fm0),
+                     ("enc", 1, 1): (fm0, 2 * fm0), ("dec", 1): (2 * fm0, 2 * fm0)}
             for r in ranges:
                 t = full[0, 0, r[0][0]:r[0][1], r[1][0]:r[1][1], r[2][0]:r[2][1]].contiguous()
-                for rad in (2, 3):
-                    fl = eng.uniform_flags(t.unsqueeze(-1), tuple(t.shape), rad)
-                    if fl is not None:
-                        nb = eng.lib.bfm_conv3x3x3_wino_rows(t.shape[0], t.shape[1], t.shape[2], eng.passes)
-                        f = fl[:nb]
-                        reused = int((f != 0).sum().item()) - int(torch.unique(f[f != 0]).numel())
-                        v = max(reused, 0) / float(nb) * t.numel()          # all flagged boxes but one per class
-                        if rad == 2:
-                            uni2 += v
-                        else:
-                            uni3 += v
-            computed_step -= 2.0 * 27 * (uni2 * (fm0 // 2) * fm0 + uni3 * fm0 * fm0)
+                for key, rad in eng.UNIFORM_RADIUS.items():
+                    lvl = key[1]
+                    fl = eng.uniform_flags(t.unsqueeze(-1), tuple(t.shape), rad, lvl)
+                    if fl is None:
+                        continue
+                    ld = [v >> lvl for v in t.shape]
+                    nb = eng.lib.bfm_conv3x3x3_wino_rows(ld[0], ld[1], ld[2], eng.passes)
+                    f = fl[:nb]
+                    reused = int((f != 0).sum().item()) - int(torch.unique(f[f != 0]).numel())
+                    v = max(reused, 0) / float(nb) * ld[0] * ld[1] * ld[2]    # all flagged boxes but one per class
+                    uni[key] = uni.get(key, 0.0) + v
+                    computed_step -= 2.0 * 27 * chans[key][0] * chans[key][1] * v
+        uni2, uni3 = uni.get(("enc", 0, 1), 0.0), uni.get(("dec", 0), 0.0)
+        uni_l1 = sum(v for k, v in uni.items() if k[1] == 1) / max(sum(1 for k in uni if k[1] == 1), 1)
         fam = k_fl / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         dk = kernels.get(dominant, {})
         line = {
@@ -477,6 +481,7 @@ def main():
                                      "head_voxels_computed_frac": head_vox / tile_vox,
                                      "uniform_box_frac_enc0_conv2": uni2 / tile_vox,
                                      "uniform_box_frac_dec4_conv1_skip": uni3 / tile_vox,
+                                     "uniform_box_frac_level1_layers": uni_l1 / (tile_vox / 8.0),
                                      "note": "the tile loop keeps out * (tile input != 0) (scripts/demo_test.py:88-100); "
                                              "the last convolution (4x4x16 boxes) and the heads (runs of 64 voxels) leave "
                                              "out what holds no non-zero input; stitched results are bit-identical "

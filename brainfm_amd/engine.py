@@ -633,7 +633,7 @@ class UNetEngine:
     # image-voxel radius within which the input must be constant for the OUTPUT of these layers to be one vector:
     # (encoder level, conv index) and the skip halves of the decoders that end at levels 0 and 1
     UNIFORM_RADIUS = {("enc", 0, 1): 2, ("dec", 0): 3}
-    if os.environ.get("BFM_UNIFORM_LEVELS", "0") == "1":   # level 1 too: measured, no gain
+    if os.environ.get("BFM_UNIFORM_LEVELS", "1") != "0":   # one pooling level down too (0: full resolution only)
         UNIFORM_RADIUS.update({("enc", 1, 0): 4, ("enc", 1, 1): 6, ("dec", 1): 8})
 
     def uniform_voxels(self, flags, dims):
