@@ -618,6 +618,13 @@ class UNetEngine:
         kernel's box grid of the tensor `level` poolings down, or None (switched off, more channels, or no such grid)."""
         if not self.uniform_skip or x_cl is None or x_cl.shape[-1] != 1 or self.tape is not None:
             return None
+        # one set of flags per (image, level): the largest radius any layer of the level needs is valid for all of them
+        # (a box constant within 3 voxels is constant within 2) and flags 1 % fewer boxes than each layer's own radius
+        radius = max([radius] + [r for k, r in self.UNIFORM_RADIUS.items() if k[1] == level])
+        ckey = (x_cl.data_ptr(), tuple(dims), int(level), int(radius), torch.cuda.current_stream(self.device).cuda_stream)
+        cache = self.__dict__.setdefault("_uf_cache", {})
+        if ckey in cache:
+            return cache[ckey]
         D, H, W = dims
         n = self.lib.bfm_uniform_boxes_bytes(D >> level, H >> level, W >> level, self.passes)
         if n <= 0:
@@ -626,8 +633,10 @@ class UNetEngine:
         rc = self.lib.bfm_uniform_boxes_level(L.ptr(x_cl), D, H, W, int(level), int(radius), self.passes, L.ptr(flags),
                                               L.stream_ptr())
         if rc == -2:                                         # BFM_E_SHAPE: a box side shorter than the radius, no classes
-            return None
-        L.check(rc, "uniform_boxes")
+            flags = None
+        else:
+            L.check(rc, "uniform_boxes")
+        cache[ckey] = flags
         return flags
 
     # image-voxel radius within which the input must be constant for the OUTPUT of these layers to be one vector:
@@ -1010,6 +1019,7 @@ class UNetEngine:
         full output, so nothing that is kept changes); that map holds unwritten memory there."""
         if self.has_deep_region():
             return self.backbone_batch([x_cl], dims, mask_last=mask_last)[0]
+        self.__dict__["_uf_cache"] = {}                      # flags live for one pass (keyed by the image's address)
         mask_img = x_cl if (mask_last and self.mask_skip and x_cl.shape[-1] == 1) else None
         UR = self.UNIFORM_RADIUS
         skips = []
@@ -1074,6 +1084,7 @@ class UNetEngine:
         """The backbone of S same-shape samples: encoder levels above the region per sample, the region batched, the
         remaining decoders per sample.  Returns one feature list per sample (deepest first, like backbone_cl).
         mask_last: as in backbone_cl."""
+        self.__dict__["_uf_cache"] = {}                      # flags live for one pass (keyed by the image's address)
         df = self.region_start(dims)
         tops = [self.encoder_top(x, dims, df) for x in xs]
         out, d, deep_feats = self.deep_region([t[-1] for t in tops], df)
