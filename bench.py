@@ -238,6 +238,7 @@ def main():
     ap.add_argument("--layer-table", default=None, help="write the per-layer conv timing table of the instrumented pass here")
     ap.add_argument("--dist-path", action="store_true",
                     help="run the multi-GPU code path (pack, RCCL gather, root accumulation) even with one rank")
+    ap.add_argument("--no-dense-check", action="store_true", help="skip the extra steps on a volume without zeros")
     ap.add_argument("--no-graphs", action="store_true", help="submit every kernel from python instead of hipGraph replay")
     ap.add_argument("--roofline-reps", type=int, default=3,
                     help="back-to-back launches per HIP-event bracket in the instrumented conv pass")
@@ -291,10 +292,11 @@ def main():
     eng = sess.engine
     sess.use_graphs = not args.no_graphs
 
-    def step():
+    def step(vol=None):
+        vol = full if vol is None else vol
         if use_dist:
-            return TU.tiled_inference_distributed(full, sess, stride, win)
-        return TU.tiled_inference(full, sess, stride, win, batched=True)     # eager (--no-graphs) runs the same batches
+            return TU.tiled_inference_distributed(vol, sess, stride, win)
+        return TU.tiled_inference(vol, sess, stride, win, batched=True)      # eager (--no-graphs) runs the same batches
 
     # setup (untimed, once per session): tune the conv variants and capture one hipGraph per tile shape
     if sess.use_graphs:
@@ -340,6 +342,31 @@ def main():
     if world > 1:
         dist.all_reduce(lat_med, op=dist.ReduceOp.MAX)
     lat_med = float(lat_med.item())
+
+    # The same build, graphs and step on a volume WITHOUT an exact-zero background (uniform noise everywhere): no box, run or
+    # voxel is left out, every shortcut that depends on the data (engine.mask_skip, uniform_skip, the compact rows) finds
+    # nothing to skip.  Reported next to `value` so that the data-independent rate is on the line too.
+    dense_ms = None
+    if not args.no_dense_check:
+        g = torch.Generator(device="cpu").manual_seed(5)
+        dense = (torch.rand((1, 1, n, n, n), generator=g) + 0.05).to(dev)
+        for _ in range(2):
+            step(dense)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        td = time.perf_counter()
+        nd = max(2, min(args.steps, 5))
+        for _ in range(nd):
+            step(dense)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tdm = torch.tensor([time.perf_counter() - td], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tdm, op=dist.ReduceOp.MAX)
+        dense_ms = float(tdm.item()) / nd * 1e3
+        del dense
 
     # dominant kernels: the conv family.  The timed region replays hipGraphs, which HIP events cannot bracket per kernel, so
     # the same step is run once more eagerly right after it with every conv launch issued `reps` times back to back
@@ -468,6 +495,11 @@ def main():
             "timing": "value = K volumes back to back between two barrier+synchronize brackets (no sync between volumes, "
                       "max over ranks); latency_ms_median = one volume at a time, synchronised after each",
             "latency_ms_median": lat_med * 1e3,
+            "dense_volume": None if dense_ms is None else {
+                "ms_per_step": dense_ms, "value": n ** 3 / dense_ms * 1e3, "unit": "voxels/s",
+                "note": "the same build and graphs on a volume of uniform noise without a zero background: nothing is "
+                        "skipped (config.tile_mask describes what the headline volume, SURVEY config 3's ellipsoid with "
+                        "exact zeros outside, lets the exact shortcuts leave out)"},
             "config": {"workload": "%d^3 volume, reference tiling win160/stride80 -> %d tiles, UNet3D f64 x6 levels, "
                                    "9 heads (69 ch), fused tail + deformed atlas + on-device stitch of %s keys"
                                    % (n, len(ranges), n_keys),
