@@ -809,6 +809,7 @@ def tile_batches(ranges, idxs=None, group_max=None, min_batches=1):
 
 
 COMPACT = os.environ.get("BFM_COMPACT", "1") != "0"    # tiles' rows hold the voxels the tile mask keeps only (0: all of them)
+SKIP_EMPTY = os.environ.get("BFM_SKIP_EMPTY_TILES", "1") != "0"   # multi-GPU path: tiles without any input are not run
 
 
 class TileIndex:
@@ -1075,8 +1076,6 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
     # every rank.  Rank 0's own tiles never travel: they are packed into a private buffer per round, and the round's
     # (padded) size is set by the peers alone.
     nlanes = session.lanes if (session is not None and getattr(session, "use_graphs", False)) else 1
-    batches_of = [tile_batches(ranges, [i for i in range(len(ranges)) if owner[i] == r], min_batches=nlanes)
-                  for r in range(world)]
     # compact rows: a tile ships the voxels its mask keeps (known from the volume on every rank before any tile runs:
     # HipStitchOps.index_volume brings the counts to the host, the same on every rank) -- 1/5 of the bytes on a head in
     # a 256^3 box
@@ -1084,10 +1083,18 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
     if direct and COMPACT and GATHER_STITCH and dev.type == "cuda" and hasattr(ops, "index_volume"):
         index = ops.index_volume(full_im, ranges, counts=True)
     width = [index.nnz[i] if index is not None else tile_cost(r) for i, r in enumerate(ranges)]   # columns per row
+    # a tile whose input is all zero keeps nothing of what it computes (scripts/demo_test.py:88-100) and adds +0 wherever
+    # it is stitched: with the counts on the host it is not run at all (BFM_SKIP_EMPTY_TILES=0: run it)
+    live = [index is None or not SKIP_EMPTY or width[i] > 0 for i in range(len(ranges))]
+    batches_of = [tile_batches(ranges, [i for i in range(len(ranges)) if owner[i] == r and live[i]], min_batches=nlanes)
+                  for r in range(world)]
     nrounds = max([len(b) for b in batches_of] + [1]) if rounds else 1
     round_of, off_of = {}, {}
     round_numel = [1] * nrounds
     own_numel = [1] * nrounds
+    for i in range(len(ranges)):
+        if not live[i]:
+            round_of[i], off_of[i] = 0, 0                      # nothing computed, nothing shipped, nothing read
     for r in range(world):
         fill = [0] * nrounds
         for k, batch in enumerate(batches_of[r]):
