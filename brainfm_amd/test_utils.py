@@ -678,9 +678,15 @@ def _tiled_inference_lanes(full_im, session, ranges, shape, stride, win_size):
     start.record(main)                                         # the input is in place, last volume's rows are consumed
     # compact rows (only what the tile mask keeps is packed and read back): every slot keeps its full-size stride here,
     # so nothing about the volume has to reach the host
-    index = ops.index_volume(full_im, ranges) if COMPACT else None
+    # BFM_SKIP_EMPTY_TILES=all: also bring the tiles' survivor counts to the host (one small copy and a wait per volume)
+    # and do not run a tile without any input at all, as the multi-GPU path does for free
+    skip = COMPACT and os.environ.get("BFM_SKIP_EMPTY_TILES", "1") == "all"
+    index = ops.index_volume(full_im, ranges, counts=skip) if COMPACT else None
+    live = None
+    if skip and index is not None and index.nnz is not None:
+        live = [i for i in range(len(ranges)) if index.nnz[i] > 0]
     last, keys = {}, None
-    for batch in tile_batches(ranges):                         # same-shape tiles together: the deep levels run batched
+    for batch in tile_batches(ranges, live):                   # same-shape tiles together: the deep levels run batched
         k = min(range(nl), key=lambda j: (load[j], j))
         load[k] += sum(tile_time(ranges[i]) for i in batch)
         ims = [full_im[:, :, ranges[i][0][0]:ranges[i][0][1], ranges[i][1][0]:ranges[i][1][1],
@@ -696,6 +702,8 @@ def _tiled_inference_lanes(full_im, session, ranges, shape, stride, win_size):
     acc_buf = torch.empty((nkeys,) + tuple(shape), dtype=torch.float32, device=dev)
     ops.gather_all(acc_buf, srcs, ranges, shape, index=index)
     cnt = _cached_count_volume(session, shape, ranges, stride, win_size, dev)
+    if keys is None:                                           # every tile was empty
+        keys = session.stitch_keys()
     return OrderedDict((k_, acc_buf[j]) for j, k_ in enumerate(keys)), ranges, cnt
 
 

@@ -1129,3 +1129,30 @@ def test_uniform_background_boxes_change_no_bit():
                 assert torch.equal(a, b)
         else:
             assert torch.equal(outs[True][k], outs[False][k]), k
+
+
+def test_tiles_without_input_can_be_left_out(monkeypatch):
+    """A tile whose input is all zero keeps nothing of what it computes (scripts/demo_test.py:88-100).  With
+    BFM_SKIP_EMPTY_TILES=all the single-GPU flow reads the tiles' survivor counts back and does not run such tiles (the
+    multi-GPU path always does: tests/two_rank_worker.py); the stitched volume is the tile loop's, bit for bit, and the
+    skipped tiles' regions are exact zeros."""
+    from brainfm_amd import test_utils as TU
+    ga, ta = TU.default_inference_args(f_maps=64, num_levels=3)
+    g = torch.Generator().manual_seed(6)
+    vol = torch.rand((64, 48, 80), generator=g) + 0.05
+    vol[:, :, 30:] = 0
+    vol[40:, :, :] = 0
+    full = vol[None, None].to(_dev())
+    torch.manual_seed(2)
+    s = TU.InferenceSession(ga, ta, _dev(), passes=3)
+    eager, ranges, _ = TU.tiled_inference(full, s, [16] * 3, [32] * 3, graphs=False)
+    eager = {k: v.clone() for k, v in eager.items()}
+    empty = [r for r in ranges if not bool((full[:, :, r[0][0]:r[0][1], r[1][0]:r[1][1], r[2][0]:r[2][1]] != 0).any())]
+    assert 0 < len(empty) < len(ranges)
+    monkeypatch.setenv("BFM_SKIP_EMPTY_TILES", "all")
+    for rep in range(3):                                               # eager pass, capture, replay of the batch graphs
+        acc, _, _ = TU.tiled_inference(full, s, [16] * 3, [32] * 3, graphs=True)
+        for k in eager:
+            assert torch.equal(acc[k], eager[k]), (k, rep)
+    r = empty[0]
+    assert float(acc["T1"][r[0][0]:r[0][1], r[1][0]:r[1][1], r[2][0]:r[2][1]].abs().max()) == 0.0
