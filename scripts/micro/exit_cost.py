@@ -1,5 +1,6 @@
+"""What a masked Winograd launch costs when only some of its boxes hold input (profiles/r02_sparse_launch_micro.txt)."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ctypes as C
 import torch
 from brainfm_amd import _lib as L, test_utils as TU
