@@ -537,7 +537,10 @@ def main():
                                  "algorithmic conv FLOPs (2*27*Cin*Cout*voxels, also for Winograd / up-folded layers) / "
                                  "summed launch durations; durations from HIP events around %d back-to-back launches of "
                                  "each conv in an instrumented eager replay of the step right after the timed region; the "
-                                 "kernels issue up to %dx the algorithmic FLOPs in f16 MFMA" % (args.roofline_reps, args.passes)},
+                                 "kernels issue up to %dx the algorithmic FLOPs in f16 MFMA; conv_wino_masked / conv_wino_uniform count "
+                                 "the FLOPs of the boxes they evaluate only (config.tile_mask), and conv_wino_uniform is a "
+                                 "pair of kernels per launch: conv_wino_rest (matrix-bound, the unflagged boxes) + a kernel "
+                                 "that streams one box's result to its class mates (HBM-bound)" % (args.roofline_reps, args.passes)},
         }
         if not args.no_cpu_baseline and world == 1:
             sd = {k: v for k, v in sess.model.state_dict().items()}
