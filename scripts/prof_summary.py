@@ -29,6 +29,23 @@ tot = sum(r[2] for r in rows)
 print("# rocprofv3 --kernel-trace summary of %s%s" % (db, (" (last %.0f ms)" % tail_ms) if tail_ms > 0 else ""))
 print("# total kernel time %.3f ms over %g step(s) -> %.3f ms/step; wall span %.3f ms -> %.3f ms/step" %
       (tot, steps, tot / steps, span, span / steps))
+# how much of the wall span has at least one kernel running, and how much has two or more (lanes overlapping)
+ev = []
+for st, en in c.execute("select start, end from kernels" + where):
+    ev.append((st, 1))
+    ev.append((en, -1))
+ev.sort()
+depth, last, busy1, busy2 = 0, None, 0, 0
+for t, d in ev:
+    if last is not None:
+        if depth >= 1:
+            busy1 += t - last
+        if depth >= 2:
+            busy2 += t - last
+    depth += d
+    last = t
+print("# device busy (>= 1 kernel running) %.3f ms/step = %.1f %% of the span; >= 2 kernels running %.3f ms/step" %
+      (busy1 / 1e6 / steps, 100.0 * busy1 / 1e6 / max(span, 1e-9), busy2 / 1e6 / steps))
 print("%-72s %7s %11s %6s %10s %10s %10s" % ("kernel", "calls", "total_ms", "%", "avg_us", "min_us", "max_us"))
 for r in rows:
     name = r[0].replace("(anonymous namespace)::", "")
