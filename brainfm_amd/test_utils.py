@@ -545,9 +545,10 @@ def assign_tiles(ranges, world_size):
         r = min(range(world_size), key=lambda k: (load[k], k))
         bins[r].extend(ch)
         load[r] += cost(ch)
-    # rank 0 also receives and stitches: it takes the lightest share (at 8 ranks of 256^3 the single 160^3 tile, whose
-    # small-kernel chain is the shortest); the others keep the LPT order
-    order = sorted(range(world_size), key=lambda k: (load[k] == 0, load[k], k))     # ... the lightest non-empty one
+    # rank 0 also indexes, receives and stitches (~1 ms at 8 ranks of 256^3): it takes the lightest share that keeps two
+    # lanes busy -- a share of one tile runs on one lane with its small kernels exposed (measured at 8 ranks: the single
+    # 160^3 tile 12.8 ms, two 160x160x80 tiles on two lanes 11.9) --; the others keep the LPT order
+    order = sorted(range(world_size), key=lambda k: (load[k] == 0, len(bins[k]) < 2, load[k], k))
     owner = [0] * n
     for rank, k in enumerate(order):
         for i in bins[k]:
