@@ -1,4 +1,6 @@
-"""Where does the stitched deformed_atlas of the graph / lanes path differ from the eager path? (diagnostic)"""
+"""Where does the stitched deformed_atlas of the graph / lanes path differ from the eager path? (diagnostic)
+The per-slot comparison it falls back to on a mismatch reads the dense packed rows and every voxel of a tile's maps: run it
+with BFM_COMPACT=0 BFM_MASK_SKIP=0 (the compact rows and the skipped voxels came after the hazard it chased)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
