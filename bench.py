@@ -531,7 +531,11 @@ def main():
                          "algorithmic_bytes_per_launch": dk.get("algorithmic_bytes_per_launch"),
                          "per_kernel": kernels,
                          "conv_family": {"achieved": fam, "frac": fam / peak, "kernel_ms_per_step": k_ms / max(world, 1),
-                                         "launches_per_step": int(k_n), "algorithmic_bytes_per_step": k_by},
+                                         "launches_per_step": int(k_n), "algorithmic_bytes_per_step": k_by,
+                                         # the reference's dense work (every voxel of every tile) over the same kernel time:
+                                         # what the rate would read if the boxes the exact shortcuts leave out were counted
+                                         "reference_equivalent_achieved": (flops_step / 1e12) / (k_ms * 1e-3) if k_ms > 0 else None,
+                                         "reference_equivalent_frac": (flops_step / 1e12) / (k_ms * 1e-3) / peak if k_ms > 0 else None},
                          "note": "the dominant kernel (largest share of the step's conv time) is reported at the top level, "
                                  "every conv kernel under per_kernel, the whole family under conv_family; achieved = "
                                  "algorithmic conv FLOPs (2*27*Cin*Cout*voxels, also for Winograd / up-folded layers) / "
