@@ -26,8 +26,8 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-CONV_KERNELS = ["conv_wino", "conv_wino_masked", "conv_wino_uniform", "conv_upfold", "conv_mfma", "conv_mfma_ws", "conv_mfma16", "conv_wino_ws", "conv_wino8"]
-_VER_NAME = {0: "conv_mfma", 1: "conv_mfma_ws", 2: "conv_mfma16", 3: "conv_wino", 4: "conv_wino_ws", 5: "conv_wino8"}
+CONV_KERNELS = ["conv_wino", "conv_wino_masked", "conv_wino_uniform", "conv_upfold", "conv_mfma", "conv_mfma_ws", "conv_mfma16"]
+_VER_NAME = {0: "conv_mfma", 1: "conv_mfma_ws", 2: "conv_mfma16", 3: "conv_wino"}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_conv_hbm_traffic.json")
 
 

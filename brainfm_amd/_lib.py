@@ -27,6 +27,9 @@ class Upsample(C.Structure):
                 ("repD", C.c_void_p), ("repH", C.c_void_p), ("repW", C.c_void_p)]
 
 
+CLASS_STATS_BLOCKS = 1024     # BFM_CLASS_STATS_BLOCKS of include/brainfm_hip.h
+
+
 class TailDesc(C.Structure):
     _fields_ = [("n_out", C.c_int), ("c_feat", C.c_int),
                 ("head_w", C.c_void_p), ("head_b", C.c_void_p), ("roles", C.c_void_p), ("out_slot", C.c_void_p),
@@ -134,6 +137,7 @@ SIGNATURES = {
                                 C.POINTER(_I), _P, _P, _Z, _P]),
     "bfm_maxpool2": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "bfm_tail_heads": (_I, [_P, _P, _L, C.POINTER(TailDesc), _P, _P, _P, _P, _P, _P]),
+    "bfm_tail_heads_rows": (_I, [_P, _P, _L, C.POINTER(TailDesc), _P, _P, _L, _P, _P, _I, _P]),
     "bfm_ew_unary": (_I, [_I, _P, _L, _P, _L, _L, _F, _F, _P]),
     "bfm_ew_binary": (_I, [_I, _P, _L, _P, _L, _P, _L, _L, _F, _P]),
     "bfm_softmax_cl": (_I, [_P, _L, _I, _P, _L, _L, _P]),
@@ -150,7 +154,7 @@ SIGNATURES = {
     "bfm_deform_grid_workspace": (_Z, [_I, _I, _I]),
     "bfm_deform_grid": (_I, [_P, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_I), _P, _P, _P, _P, _P, _Z, _P]),
     "bfm_label_gauss": (_I, [_P, _P, _P, _P, _L, _I, _P, _P]),
-    "bfm_label_class_stats": (_I, [_P, _P, _L, _P, _P, _P]),
+    "bfm_label_class_stats": (_I, [_P, _P, _L, _P, _P, _P, _P]),
     "bfm_onehot_lut": (_I, [_P, _P, _I, _I, _L, _P, _P]),
     "bfm_perlin3d": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "bfm_radix_hist_f64": (_I, [_P, _L, C.c_uint64, _I, _P, _P]),

@@ -47,7 +47,6 @@ struct WinoParams {
     int npos_lds, plane_stride;      // (TD+2)*HT*PW positions; bytes per plane
     double *rsum, *rsq;              // optional output-moment rows [nMt][Cout] (see conv3d_mfma.hip), 4-wave kernel only
     float *rmn, *rmx;
-    int ws_buf_bytes;                // persistent kernel: bytes per LDS buffer
     const float* mask_img;           // optional (D,H,W) image: a box none of whose voxels is non-zero there is not computed
     const unsigned char* uni_flags;  // optional [nMt]: 0, or 1 + the class of a box whose operands equal its class mates'
     const int* uni_first;            // [27] first box of each class (>= nMt: none): the ones conv_wino_rest computes
@@ -559,7 +558,14 @@ __global__ void __launch_bounds__(256) uniform_boxes_kernel(const float* __restr
     if (threadIdx.x == 0) {
         const int cz = tz == 0 ? 0 : (tz == nTz - 1 ? 2 : 1), cy = ty == 0 ? 0 : (ty == nTy - 1 ? 2 : 1);
         const int cx = tx == 0 ? 0 : (tx == nTx - 1 ? 2 : 1);
-        flags[mt] = bad ? 0 : (unsigned char)(1 + 9 * cz + 3 * cy + cx);
+        // a box that is not the last of its axis must not see the far face either: when the last box is a remainder
+        // narrower than the reach, its neighbour's grown region passes the level's extent (d << L image voxels; the
+        // floor of the pooling can only move that face inwards) and the box is no class mate of the true middle boxes
+        const int dl = (D >> L) << L, hl = (H >> L) << L, wl = (W >> L) << L;
+        const bool far = (tz != nTz - 1 && ((((tz + 1) * TD) << L) + R > dl)) ||
+                         (ty != nTy - 1 && ((((ty + 1) * TH) << L) + R > hl)) ||
+                         (tx != nTx - 1 && ((((tx + 1) * TW) << L) + R > wl));
+        flags[mt] = bad || far ? 0 : (unsigned char)(1 + 9 * cz + 3 * cy + cx);
     }
 }
 
@@ -577,567 +583,6 @@ __global__ void __launch_bounds__(256) uniform_first_kernel(const unsigned char*
         __syncthreads();
     }
     if (threadIdx.x == 0) first[blockIdx.x] = best[0];
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Wave-specialised persistent form of conv_wino: 8 waves per workgroup, one workgroup per CU.  Waves 0-3 are the
-// four Winograd positions and only multiply (LDS A reads, weights L2 -> VGPR, MFMA); waves 4-7 only stage: they
-// have no accumulators, so all 20 global loads of a chunk are in flight at once, and they fill buffer (g+1)&1 while
-// the MFMA waves consume buffer g&1.  One workgroup barrier per K-chunk separates the two; on a tile's last chunk
-// the output transform borrows the buffer the MFMA waves just finished with (all 512 threads form y0/y1 and store).
-// In the 4-wave kernel the matrix pipe is busy 39 % of the time (staging latency is exposed: the accumulators leave
-// no registers to batch loads); here staging hides under the other waves' MFMAs.
-template <int NPASS>
-__global__ void __launch_bounds__(512, 1) conv_wino_ws(const WinoParams p) {
-    constexpr int NPL = (NPASS == 3) ? 2 : 1;
-    constexpr int NF = 2 * NPL;
-    constexpr int MAX_IT = 5;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool loader = wave >= 4;
-    const int pos = wave & 3;
-    const int l32 = lane & 31, khalf = lane >> 5;
-    const int buf_bytes = p.ws_buf_bytes;                      // >= 8*NPL*plane_stride and >= the output-transform scratch
-
-    const int nblk = p.nMt * p.NT;
-    const int ntile = (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int G = ntile * p.KCN;
-    auto tile_coords = [&](int k, int& mt, int& nt) __attribute__((always_inline)) {
-        int vb = (int)blockIdx.x + k * (int)gridDim.x;
-        if (vb >= nblk) vb = nblk - 1;
-        const int q = nblk >> 3, r = nblk & 7;
-        const int xcd = vb & 7, idx = vb >> 3;
-        const int b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        mt = b / p.NT;
-        nt = b - mt * p.NT;
-    };
-    auto tile_origin = [&](int mt, int& z0, int& y0, int& x0) __attribute__((always_inline)) {
-        const int tx = mt % p.nTx;
-        const int ty = (mt / p.nTx) % p.nTy;
-        const int tz = mt / (p.nTx * p.nTy);
-        z0 = tz * p.TD; y0 = ty * p.TH; x0 = tx * p.TW;
-    };
-
-    float bmax = 0.f;
-    for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, p.bound[g]);
-    int aexp = 0;
-    if (bmax > 0.f && bmax < INFINITY) {
-        int ex;
-        (void)frexpf(bmax, &ex);
-        aexp = 13 - ex;
-        aexp = aexp > 60 ? 60 : (aexp < -60 ? -60 : aexp);
-    }
-    const float a_scale = ldexpf(1.0f, aexp);
-    const float dq = ldexpf(1.0f, -(aexp + p.wexp));
-
-    // ---------------- loader state
-    const int ltid = tid & 255;
-    const int q4 = ltid & 3;
-    const int n_el = p.npos_lds * 4;
-    const int st_plane = ((q4 >> 1) * NPL) * p.plane_stride + (q4 & 1) * 8;
-    int off0[MAX_IT], msk[MAX_IT];
-    auto set_tile = [&](int k) __attribute__((always_inline)) {
-        int mt, nt, z0, y0, x0;
-        tile_coords(k, mt, nt);
-        tile_origin(mt, z0, y0, x0);
-#pragma unroll
-        for (int it = 0; it < MAX_IT; ++it) {
-            const int e = ltid + it * 256;
-            off0[it] = 0;
-            msk[it] = -1;
-            if (e < n_el) {
-                const int ps = e >> 2;
-                const int j = ps & ((1 << p.pw_shift) - 1);
-                const int r = ps >> p.pw_shift;
-                const int hz = r / p.HT, hy = r - hz * p.HT;
-                const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + 2 * j - 1;
-                int m = 0;
-                if (gz >= 0 && gz < p.D && gy >= 0 && gy < p.H) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        if (gx + i >= 0 && gx + i < p.W) m |= 1 << i;
-                }
-                msk[it] = m;
-                off0[it] = ((gz * p.H + gy) * p.W + gx) * p.CA;
-            }
-        }
-    };
-    int tile_set = -1;
-    struct ItemRegs { float4 v[MAX_IT][4]; int m[MAX_IT]; };
-    // issue the global loads of item g (its tile's offsets are recomputed when the tile changes)
-    auto load_item = [&](int g, ItemRegs& r) __attribute__((always_inline)) {
-        const int tk = g / p.KCN;
-        if (tk != tile_set) { set_tile(tk); tile_set = tk; }
-        const float* src = p.A + (g % p.KCN) * KC + q4 * 4;
-#pragma unroll
-        for (int it = 0; it < MAX_IT; ++it) {
-            r.m[it] = msk[it];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                r.v[it][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (msk[it] >= 0 && (msk[it] & (1 << i)))
-                    r.v[it][i] = *reinterpret_cast<const float4*>(src + off0[it] + i * p.CA);
-            }
-        }
-    };
-    // affine + zero padding + Winograd input transform + hi/lo split + LDS writes of a loaded item
-    auto write_item = [&](int g, const ItemRegs& r, unsigned char* buf) __attribute__((always_inline)) {
-        const int c0 = (g % p.KCN) * KC;
-        const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + c0 + q4 * 4);
-        const float4 sh4 = *reinterpret_cast<const float4*>(p.shift + c0 + q4 * 4);
-        const float sc[4] = {sc4.x * a_scale, sc4.y * a_scale, sc4.z * a_scale, sc4.w * a_scale};
-        const float sh[4] = {sh4.x * a_scale, sh4.y * a_scale, sh4.z * a_scale, sh4.w * a_scale};
-#pragma unroll
-        for (int it = 0; it < MAX_IT; ++it) {
-            if (r.m[it] < 0) continue;
-            float dd[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool ok = r.m[it] & (1 << i);
-                const float y[4] = {r.v[it][i].x, r.v[it][i].y, r.v[it][i].z, r.v[it][i].w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) dd[i][c] = ok ? fmaf(y[c], sc[c], sh[c]) : 0.f;
-            }
-            const int e = ltid + it * 256;
-            unsigned char* dst = buf + st_plane + (e >> 2) * 16;
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                half4 hi, lo;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float t = ps == 0 ? dd[0][c] - dd[2][c]
-                                  : ps == 1 ? dd[1][c] + dd[2][c]
-                                  : ps == 2 ? dd[2][c] - dd[1][c]
-                                            : dd[1][c] - dd[3][c];
-                    const _Float16 hh = (_Float16)t;
-                    hi[c] = hh;
-                    lo[c] = (_Float16)(t - (float)hh);
-                }
-                unsigned char* dp = dst + (ps * 2 * NPL) * p.plane_stride;
-                *reinterpret_cast<half4*>(dp) = hi;
-                if constexpr (NPASS == 3) *reinterpret_cast<half4*>(dp + p.plane_stride) = lo;
-            }
-        }
-    };
-
-    // ---------------- consumer state
-    int a_off[4];
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        int d, h, j;
-        pair_coords(p, mb * 32 + row_perm(l32), d, h, j);
-        a_off[mb] = ((pos * 2 + khalf) * NPL) * p.plane_stride + ((d * p.HT + h) * p.PW + j) * 16;
-    }
-    const int S = p.KCN * 9;
-    const uint4* wcur = p.wp + lane;
-    const uint4* wnxt = p.wp + lane;
-    bool has_next = false;
-    auto set_wbase = [&](int k) __attribute__((always_inline)) {     // tile k current, k+1 next
-        int mt, nt;
-        tile_coords(k, mt, nt);
-        wcur = p.wp + (size_t)(nt * 4 + pos) * S * (NF * 64) + lane;
-        has_next = (k + 1) < ntile;
-        tile_coords(k + 1, mt, nt);
-        wnxt = p.wp + (size_t)(nt * 4 + pos) * S * (NF * 64) + lane;
-    };
-    uint4 wq[3][NF];
-    auto fetch = [&](int sl, uint4 (&dst)[NF]) __attribute__((always_inline)) {   // sl: step within the current tile
-        const uint4* base = wcur;
-        int s2 = sl;
-        if (sl >= S) {
-            if (has_next) { base = wnxt; s2 = sl - S; }
-            else s2 = S - 1;
-        }
-#pragma unroll
-        for (int f = 0; f < NF; ++f) dst[f] = base[(size_t)s2 * (NF * 64) + f * 64];
-    };
-
-    // the read/transform/store half of one output-transform round, executed by all 512 threads
-    auto epilogue_round = [&](int tk, int nb, const float* m) __attribute__((always_inline)) {
-        int mt, nt, z0, y0, x0;
-        tile_coords(tk, mt, nt);
-        tile_origin(mt, z0, y0, x0);
-        const int col = tid & 31, row0 = tid >> 5;                   // 16 row groups
-#pragma unroll 4
-        for (int it = 0; it < 8; ++it) {
-            const int q = row0 + 16 * it;
-            int d, h, j;
-            pair_coords(p, q, d, h, j);
-            const int gz = z0 + d, gy = y0 + h, gx = x0 + 2 * j;
-            if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
-            const float m0 = m[(0 * 128 + q) * MLD + col], m1 = m[(1 * 128 + q) * MLD + col];
-            const float m2 = m[(2 * 128 + q) * MLD + col], m3 = m[(3 * 128 + q) * MLD + col];
-            float* o = p.out + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + nt * 64 + nb * 32 + col;
-            float y0v = ((m0 + m1) + m2) * dq;
-            float y1v = ((m1 - m2) - m3) * dq;
-            if (p.accum) y0v = y0v + o[0];
-            y0v = y0v >= 0.f ? y0v : y0v * p.slope;
-            o[0] = y0v;
-            if (gx + 1 < p.W) {
-                if (p.accum) y1v = y1v + o[p.Cout];
-                y1v = y1v >= 0.f ? y1v : y1v * p.slope;
-                o[p.Cout] = y1v;
-            }
-        }
-    };
-
-    // The two roles run separate loops with the SAME barrier sequence: one barrier after the prologue, one at the end
-    // of every item, and four more (two per 32-column round) on a tile's last chunk.
-    if (loader) {
-        // items are loaded two ahead of the MFMA waves and written one ahead: the global latency of item g+2 hides under
-        // the conversion of item g+1 (two register sets, the loop is unrolled by two so that their roles are static)
-        ItemRegs ra, rb;
-        load_item(0, ra);
-        write_item(0, ra, lds);
-        if (1 < G) load_item(1, ra);
-        __syncthreads();
-        auto iteration = [&](int g, ItemRegs& rcur, ItemRegs& rnxt) __attribute__((always_inline)) {
-            // rcur holds item g+1 (loaded earlier); rnxt receives item g+2
-            if (g + 2 < G) load_item(g + 2, rnxt);
-            if (g + 1 < G) write_item(g + 1, rcur, lds + ((g + 1) & 1) * buf_bytes);
-            if (g % p.KCN == p.KCN - 1) {
-                const float* m = reinterpret_cast<const float*>(lds + (g & 1) * buf_bytes);
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    __syncthreads();
-                    __syncthreads();
-                    epilogue_round(g / p.KCN, nb, m);
-                }
-            }
-            __syncthreads();
-        };
-        for (int g = 0; g < G; g += 2) {
-            iteration(g, ra, rb);
-            if (g + 1 < G) iteration(g + 1, rb, ra);
-        }
-    } else {
-        floatx16 acc[4][2];
-        set_wbase(0);
-        fetch(0, wq[0]);
-        fetch(1, wq[1]);
-        __syncthreads();
-        for (int g = 0; g < G; ++g) {
-            const int kc = g % p.KCN, tk = g / p.KCN;
-            unsigned char* cur = lds + (g & 1) * buf_bytes;
-            if (kc == 0) {
-                if (g > 0) set_wbase(tk);
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
-            }
-            // 36 steps (tap, row block), fully unrolled.  This wave is alone on its SIMD's matrix pipe, so the A fragments
-            // of the next step are read before the current step's MFMAs are issued, and the MFMAs alternate between
-            // the two column blocks so that no MFMA waits for the accumulator written by the one just before it.
-            half8 a_cur[NPL], a_nxt[NPL];
-#pragma unroll
-            for (int hl = 0; hl < NPL; ++hl)
-                a_cur[hl] = *reinterpret_cast<const half8*>(cur + a_off[0] + hl * p.plane_stride);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int curset = t % 3;
-                uint4 bw[NF];
-#pragma unroll
-                for (int f = 0; f < NF; ++f) bw[f] = wq[curset][f];
-                fetch(kc * 9 + t + 2, wq[(curset + 2) % 3]);
-#pragma unroll
-                for (int mb = 0; mb < 4; ++mb) {
-                    const int step = t * 4 + mb + 1;               // the step whose A fragments are fetched now
-                    if (step < 36) {
-                        const int t2 = step >> 2, mb2 = step & 3;
-                        const int kd2 = t2 / 3, kh2 = t2 - kd2 * 3;
-                        const int toff2 = (kd2 * p.HT + kh2) * p.PW * 16;
-#pragma unroll
-                        for (int hl = 0; hl < NPL; ++hl)
-                            a_nxt[hl] = *reinterpret_cast<const half8*>(cur + a_off[mb2] + hl * p.plane_stride + toff2);
-                    }
-                    const half8 bhi0 = __builtin_bit_cast(half8, bw[0]);
-                    const half8 bhi1 = __builtin_bit_cast(half8, bw[NPL]);
-                    if constexpr (NPASS == 3) {
-                        const half8 blo0 = __builtin_bit_cast(half8, bw[1]);
-                        const half8 blo1 = __builtin_bit_cast(half8, bw[NPL + 1]);
-                        acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1], bhi0, acc[mb][0], 0, 0, 0);
-                        acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[1], bhi1, acc[mb][1], 0, 0, 0);
-                        acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], blo0, acc[mb][0], 0, 0, 0);
-                        acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], blo1, acc[mb][1], 0, 0, 0);
-                    }
-                    acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], bhi0, acc[mb][0], 0, 0, 0);
-                    acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur[0], bhi1, acc[mb][1], 0, 0, 0);
-#pragma unroll
-                    for (int hl = 0; hl < NPL; ++hl) a_cur[hl] = a_nxt[hl];
-                }
-            }
-            if (kc == p.KCN - 1) {
-                float* m = reinterpret_cast<float*>(cur);              // [4 positions][128 pairs][MLD]
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    __syncthreads();                                   // A planes / previous round consumed
-#pragma unroll
-                    for (int mb = 0; mb < 4; ++mb)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const int rr = (i >> 2) * 8 + khalf * 4 + (i & 3);
-                            m[(pos * 128 + mb * 32 + row_perm(rr)) * MLD + l32] = acc[mb][nb][i];
-                        }
-                    __syncthreads();
-                    epilogue_round(tk, nb, m);
-                }
-            }
-            __syncthreads();                                           // item g+1 staged, item g consumed
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// 8-wave, software-pipelined form: wave = (position, half of the tile's pair rows), so a wave holds 2x2 accumulator
-// blocks (64 registers) and has room to keep the NEXT chunk's global loads in flight while it multiplies the current
-// one: loads for chunk k+1 are issued before the MFMA loop of chunk k and converted (affine, transform, split, LDS
-// write) after it.  Only that conversion (~a quarter of the MFMA time) stays exposed.  One workgroup per CU.
-template <int NPASS>
-__global__ void __launch_bounds__(512, 1) conv_wino8(const WinoParams p) {
-    constexpr int NPL = (NPASS == 3) ? 2 : 1;
-    constexpr int NF = 2 * NPL;
-    constexpr int MAX_IT = 3;                                      // ceil(5*256 / 512): staging items per thread
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pos = wave & 3, mh = wave >> 2;                      // Winograd position, row half
-    const int l32 = lane & 31, khalf = lane >> 5;
-
-    int bid = blockIdx.x;
-    {
-        const int nblk = p.nMt * p.NT;
-        const int q = nblk >> 3, r = nblk & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int mt = bid / p.NT, nt = bid - mt * p.NT;
-    const int tx = mt % p.nTx;
-    const int ty = (mt / p.nTx) % p.nTy;
-    const int tz = mt / (p.nTx * p.nTy);
-    const int z0 = tz * p.TD, y0 = ty * p.TH, x0 = tx * p.TW;
-
-    float bmax = 0.f;
-    for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, p.bound[g]);
-    int aexp = 0;
-    if (bmax > 0.f && bmax < INFINITY) {
-        int ex;
-        (void)frexpf(bmax, &ex);
-        aexp = 13 - ex;
-        aexp = aexp > 60 ? 60 : (aexp < -60 ? -60 : aexp);
-    }
-    const float a_scale = ldexpf(1.0f, aexp);
-    const float dq = ldexpf(1.0f, -(aexp + p.wexp));
-
-    int a_off[2];
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-        int d, h, j;
-        pair_coords(p, (mh * 2 + mb) * 32 + row_perm(l32), d, h, j);
-        a_off[mb] = ((pos * 2 + khalf) * NPL) * p.plane_stride + ((d * p.HT + h) * p.PW + j) * 16;
-    }
-
-    const int n_el = p.npos_lds * 4;
-    const int q4 = tid & 3;
-    int off0[MAX_IT], msk[MAX_IT];
-#pragma unroll
-    for (int it = 0; it < MAX_IT; ++it) {
-        const int e = tid + it * 512;
-        off0[it] = 0;
-        msk[it] = -1;
-        if (e < n_el) {
-            const int ps = e >> 2;
-            const int j = ps & ((1 << p.pw_shift) - 1);
-            const int r = ps >> p.pw_shift;
-            const int hz = r / p.HT, hy = r - hz * p.HT;
-            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + 2 * j - 1;
-            int m = 0;
-            if (gz >= 0 && gz < p.D && gy >= 0 && gy < p.H) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (gx + i >= 0 && gx + i < p.W) m |= 1 << i;
-            }
-            msk[it] = m;
-            off0[it] = ((gz * p.H + gy) * p.W + gx) * p.CA;
-        }
-    }
-    const int st_plane = ((q4 >> 1) * NPL) * p.plane_stride + (q4 & 1) * 8;
-
-    float4 v[MAX_IT][4];
-    auto load_chunk = [&](int kc) __attribute__((always_inline)) {
-        const float* src = p.A + kc * KC + q4 * 4;
-#pragma unroll
-        for (int it = 0; it < MAX_IT; ++it)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[it][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (msk[it] >= 0 && (msk[it] & (1 << i)))
-                    v[it][i] = *reinterpret_cast<const float4*>(src + off0[it] + i * p.CA);
-            }
-    };
-    auto write_chunk = [&](int kc) __attribute__((always_inline)) {
-        const int c0 = kc * KC;
-        const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + c0 + q4 * 4);
-        const float4 sh4 = *reinterpret_cast<const float4*>(p.shift + c0 + q4 * 4);
-        const float sc[4] = {sc4.x * a_scale, sc4.y * a_scale, sc4.z * a_scale, sc4.w * a_scale};
-        const float sh[4] = {sh4.x * a_scale, sh4.y * a_scale, sh4.z * a_scale, sh4.w * a_scale};
-#pragma unroll
-        for (int it = 0; it < MAX_IT; ++it) {
-            if (msk[it] < 0) continue;
-            float dd[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool ok = msk[it] & (1 << i);
-                const float y[4] = {v[it][i].x, v[it][i].y, v[it][i].z, v[it][i].w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) dd[i][c] = ok ? fmaf(y[c], sc[c], sh[c]) : 0.f;
-            }
-            const int e = tid + it * 512;
-            unsigned char* dst = lds + st_plane + (e >> 2) * 16;
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                half4 hi, lo;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float t = ps == 0 ? dd[0][c] - dd[2][c]
-                                  : ps == 1 ? dd[1][c] + dd[2][c]
-                                  : ps == 2 ? dd[2][c] - dd[1][c]
-                                            : dd[1][c] - dd[3][c];
-                    const _Float16 hh = (_Float16)t;
-                    hi[c] = hh;
-                    lo[c] = (_Float16)(t - (float)hh);
-                }
-                unsigned char* dp = dst + (ps * 2 * NPL) * p.plane_stride;
-                *reinterpret_cast<half4*>(dp) = hi;
-                if constexpr (NPASS == 3) *reinterpret_cast<half4*>(dp + p.plane_stride) = lo;
-            }
-        }
-    };
-
-    floatx16 acc[2][2];
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mb][nb][i] = 0.f;
-
-    const int S = p.KCN * 9;
-    const uint4* wbase = p.wp + (size_t)(nt * 4 + pos) * S * (NF * 64) + lane;
-    uint4 wq[3][NF];
-    auto fetch = [&](int s, uint4 (&dst)[NF]) __attribute__((always_inline)) {
-        const int sc = s < S ? s : S - 1;
-#pragma unroll
-        for (int f = 0; f < NF; ++f) dst[f] = wbase[(size_t)sc * (NF * 64) + f * 64];
-    };
-    fetch(0, wq[0]);
-    fetch(1, wq[1]);
-
-    load_chunk(0);
-    write_chunk(0);
-    __syncthreads();
-    for (int kc = 0; kc < p.KCN; ++kc) {
-        if (kc + 1 < p.KCN) load_chunk(kc + 1);                    // in flight during the MFMA loop below
-        __builtin_amdgcn_sched_barrier(0);                         // ... provided the scheduler does not sink the loads
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int kd = t / 3, kh = t - kd * 3;
-            const int toff = (kd * p.HT + kh) * p.PW * 16;
-            const int cur = t % 3;
-            uint4 bw[NF];
-#pragma unroll
-            for (int f = 0; f < NF; ++f) bw[f] = wq[cur][f];
-            fetch(kc * 9 + t + 2, wq[(cur + 2) % 3]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                half8 a[NPL];
-#pragma unroll
-                for (int hl = 0; hl < NPL; ++hl)
-                    a[hl] = *reinterpret_cast<const half8*>(lds + a_off[mb] + hl * p.plane_stride + toff);
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
-                    const half8 bhi = __builtin_bit_cast(half8, bw[nb * NPL]);
-                    if constexpr (NPASS == 3) {
-                        const half8 blo = __builtin_bit_cast(half8, bw[nb * NPL + 1]);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bhi, acc[mb][nb], 0, 0, 0);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], blo, acc[mb][nb], 0, 0, 0);
-                    }
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bhi, acc[mb][nb], 0, 0, 0);
-                }
-            }
-        }
-        if (kc + 1 < p.KCN) {
-            __syncthreads();                                       // every wave is done reading the planes
-            write_chunk(kc + 1);
-            __syncthreads();
-        }
-    }
-
-    // ================= epilogue: output transform through LDS (all 512 threads) =================
-    float* m = reinterpret_cast<float*>(lds);                      // [4 positions][128 pairs][MLD]
-    const int col = tid & 31, row0 = tid >> 5;                     // 16 row groups
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        __syncthreads();
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rr = (i >> 2) * 8 + khalf * 4 + (i & 3);
-                m[(pos * 128 + (mh * 2 + mb) * 32 + row_perm(rr)) * MLD + l32] = acc[mb][nb][i];
-            }
-        __syncthreads();
-        float fs = 0.f, fq = 0.f, fmn = INFINITY, fmx = -INFINITY;
-#pragma unroll 4
-        for (int it = 0; it < 8; ++it) {
-            const int q = row0 + 16 * it;
-            int d, h, j;
-            pair_coords(p, q, d, h, j);
-            const int gz = z0 + d, gy = y0 + h, gx = x0 + 2 * j;
-            if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
-            const float m0 = m[(0 * 128 + q) * MLD + col], m1 = m[(1 * 128 + q) * MLD + col];
-            const float m2 = m[(2 * 128 + q) * MLD + col], m3 = m[(3 * 128 + q) * MLD + col];
-            float* o = p.out + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + nt * 64 + nb * 32 + col;
-            float y0v = ((m0 + m1) + m2) * dq;
-            float y1v = ((m1 - m2) - m3) * dq;
-            if (p.accum) y0v = y0v + o[0];
-            y0v = y0v >= 0.f ? y0v : y0v * p.slope;
-            o[0] = y0v;
-            fs += y0v; fq = fmaf(y0v, y0v, fq); fmn = fminf(fmn, y0v); fmx = fmaxf(fmx, y0v);
-            if (gx + 1 < p.W) {
-                if (p.accum) y1v = y1v + o[p.Cout];
-                y1v = y1v >= 0.f ? y1v : y1v * p.slope;
-                o[p.Cout] = y1v;
-                fs += y1v; fq = fmaf(y1v, y1v, fq); fmn = fminf(fmn, y1v); fmx = fmaxf(fmx, y1v);
-            }
-        }
-        if (p.rsum != nullptr) {
-            double* ls = reinterpret_cast<double*>(lds + 4 * 128 * MLD * sizeof(float));   // [16][32]
-            double* lq = ls + 512;
-            float* lmn = reinterpret_cast<float*>(lq + 512);
-            float* lmx = lmn + 512;
-            ls[row0 * 32 + col] = (double)fs; lq[row0 * 32 + col] = (double)fq;
-            lmn[row0 * 32 + col] = fmn; lmx[row0 * 32 + col] = fmx;
-            __syncthreads();
-            if (tid < 32) {
-                double SS = 0.0, Q = 0.0;
-                float MN = INFINITY, MX = -INFINITY;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    SS += ls[r * 32 + tid]; Q += lq[r * 32 + tid];
-                    MN = fminf(MN, lmn[r * 32 + tid]); MX = fmaxf(MX, lmx[r * 32 + tid]);
-                }
-                const size_t o = (size_t)mt * p.Cout + nt * 64 + nb * 32 + tid;
-                p.rsum[o] = SS; p.rsq[o] = Q; p.rmn[o] = MN; p.rmx[o] = MX;
-            }
-        }
-    }
 }
 
 // packed[ntile64][pos 4][kc][(kd,kh) 9][nb 2][hl][lane] (uint4 = 8 halfs): lane l holds
@@ -1341,7 +786,7 @@ extern "C" int bfm_conv3x3x3_wino_uniform(const float* A, int CA, int D, int H, 
                                           const float* shift, const float* bound, int G, const void* wpacked, int wexp,
                                           int Cout, float slope, int passes, int flags, float* out, void* moment_rows,
                                           const unsigned char* uniform_flags, void* scratch, bfm_stream_t stream) {
-    if (!uniform_flags || !scratch || (flags & 6)) return BFM_E_ARG;       // the 4-wave kernel only
+    if (!uniform_flags || !scratch || (flags & ~1)) return BFM_E_ARG;
     if ((reinterpret_cast<uintptr_t>(uniform_flags) & 3) || (reinterpret_cast<uintptr_t>(scratch) & 15)) return BFM_E_ARG;
     return wino_launch(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out, moment_rows,
                        nullptr, stream, uniform_flags, static_cast<float*>(scratch));
@@ -1359,7 +804,7 @@ extern "C" int bfm_conv3x3x3_wino_masked(const float* A, int CA, int D, int H, i
                                          const float* shift, const float* bound, int G, const void* wpacked, int wexp,
                                          int Cout, float slope, int passes, int flags, float* out,
                                          const float* mask_image, bfm_stream_t stream) {
-    if (!mask_image || (flags & 6)) return BFM_E_ARG;          // the 4-wave kernel only; no moment rows (boxes are left out)
+    if (!mask_image || (flags & ~1)) return BFM_E_ARG;         // no moment rows (boxes are left out)
     return wino_launch(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out, nullptr,
                        mask_image, stream);
 }
@@ -1369,8 +814,7 @@ static int wino_launch(const float* A, int CA, int D, int H, int W, const float*
                        float* out, void* moment_rows, const float* mask_img, bfm_stream_t stream,
                        const unsigned char* uni_flags, float* uni_acc) {
     const int accumulate = flags & 1;
-    const bool persistent = (flags & 2) != 0;
-    const bool eight = (flags & 4) != 0;
+    if (flags & ~1) return BFM_E_ARG;                           // bit 0 = accumulate; nothing else is defined
     if (!A || CA <= 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || G <= 0 || !wpacked || !out)
         return BFM_E_ARG;
     if (CA % KC || Cout % 64 || Cout <= 0) return BFM_E_SHAPE;
@@ -1404,7 +848,6 @@ static int wino_launch(const float* A, int CA, int D, int H, int W, const float*
     const size_t epi = (size_t)4 * 128 * MLD * sizeof(float) + 6144;    // output-transform scratch + moment-row fold
     if (smem < epi) smem = epi;
     if (moment_rows) {
-        if (persistent) return BFM_E_SHAPE;
         if (reinterpret_cast<uintptr_t>(moment_rows) & 7) return BFM_E_ARG;
         char* rb = static_cast<char*>(moment_rows);
         const size_t n = (size_t)p.nMt * Cout;
@@ -1435,45 +878,7 @@ static int wino_launch(const float* A, int CA, int D, int H, int W, const float*
                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_done = true;
     }
-    if (persistent) {
-        size_t buf = (size_t)8 * npl * p.plane_stride;
-        if (buf < epi) buf = epi;
-        buf = (buf + 255) & ~(size_t)255;
-        p.ws_buf_bytes = (int)buf;
-        const size_t smem2 = 2 * buf;                                  // two buffers
-        if (smem2 > 160 * 1024) return BFM_E_SHAPE;
-        static bool attr2 = false;
-        if (!attr2) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_ws<3>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_ws<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr2 = true;
-        }
-        int nwg = p.nMt * p.NT;
-        if (nwg > 256) nwg = 256;                                     // one 8-wave workgroup per CU
-        if (passes == 3) hipLaunchKernelGGL(conv_wino_ws<3>, dim3(nwg), dim3(512), smem2, bfm_s(stream), p);
-        else hipLaunchKernelGGL(conv_wino_ws<1>, dim3(nwg), dim3(512), smem2, bfm_s(stream), p);
-        return bfm_launch_status();
-    }
     dim3 grid((unsigned)(p.nMt * p.NT));
-    if (eight) {
-        size_t smem8 = (size_t)8 * npl * p.plane_stride;
-        const size_t epi8 = (size_t)4 * 128 * MLD * sizeof(float) + 12288;
-        if (smem8 < epi8) smem8 = epi8;
-        if (smem8 > 160 * 1024) return BFM_E_SHAPE;
-        static bool attr8 = false;
-        if (!attr8) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                160 * 1024);
-            attr8 = true;
-        }
-        if (passes == 3) hipLaunchKernelGGL(conv_wino8<3>, grid, dim3(512), smem8, bfm_s(stream), p);
-        else hipLaunchKernelGGL(conv_wino8<1>, grid, dim3(512), smem8, bfm_s(stream), p);
-        return bfm_launch_status();
-    }
     if (mask_img) {
         if (passes == 3) hipLaunchKernelGGL(conv_wino_masked<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
         else hipLaunchKernelGGL(conv_wino_masked<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);

@@ -430,9 +430,10 @@ __global__ void label_gauss(const float* __restrict__ G, const float* __restrict
     }
 }
 
-// generate_sample's pathology branch (datasets.py:388-396): cerebral copy + class sums; one fp64 atomic per block and sum
+// generate_sample's pathology branch (datasets.py:388-396): cerebral copy + class sums; every block leaves its four
+// partial sums, label_class_fold adds them in block order (no atomics: gm_mean > wm_mean must not depend on the run)
 __global__ void label_class_stats(const float* __restrict__ G, const float* __restrict__ syn, int64_t n,
-                                  float* __restrict__ cerebral, double* __restrict__ stats) {
+                                  float* __restrict__ cerebral, double* __restrict__ partials) {
     __shared__ double sh[4][4];
     double a[4] = {0., 0., 0., 0.};
     GRID_STRIDE(i, n) {
@@ -453,7 +454,15 @@ __global__ void label_class_stats(const float* __restrict__ G, const float* __re
     if (threadIdx.x < 4) {
         double v = 0.;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += sh[threadIdx.x][w];
-        if (v != 0.) atomicAdd(stats + threadIdx.x, v);
+        partials[(size_t)blockIdx.x * 4 + threadIdx.x] = v;
+    }
+}
+
+__global__ void label_class_fold(const double* __restrict__ partials, int nb, double* __restrict__ stats) {
+    if (threadIdx.x < 4) {
+        double v = 0.;
+        for (int b = 0; b < nb; ++b) v += partials[(size_t)b * 4 + threadIdx.x];
+        stats[threadIdx.x] = v;
     }
 }
 
@@ -577,10 +586,11 @@ extern "C" int bfm_label_gauss(const float* G, const float* mus, const float* si
 }
 
 extern "C" int bfm_label_class_stats(const float* G, const float* syn, int64_t n, float* cerebral, double* stats,
-                                     bfm_stream_t stream) {
-    if (!G || !syn || !cerebral || !stats || n <= 0) return BFM_E_ARG;
-    hipLaunchKernelGGL(label_class_stats, dim3(grid_for(n, 256, 1024)), dim3(256), 0, bfm_s(stream), G, syn, n, cerebral,
-                       stats);
+                                     double* partials, bfm_stream_t stream) {
+    if (!G || !syn || !cerebral || !stats || !partials || n <= 0) return BFM_E_ARG;
+    const int nb = grid_for(n, 256, BFM_CLASS_STATS_BLOCKS);
+    hipLaunchKernelGGL(label_class_stats, dim3(nb), dim3(256), 0, bfm_s(stream), G, syn, n, cerebral, partials);
+    hipLaunchKernelGGL(label_class_fold, dim3(1), dim3(64), 0, bfm_s(stream), partials, nb, stats);
     return bfm_launch_status();
 }
 

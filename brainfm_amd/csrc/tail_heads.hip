@@ -37,6 +37,8 @@ struct TailParams {
     bfm_tail_desc_t d;
     float* feat_norm;
     float* const* maps;
+    float* maps_rows;       // maps == NULL: map i is maps_rows + i * row_stride
+    int64_t row_stride;
     float* seg_prob;
     int64_t* label;
     float* raw_out;
@@ -76,7 +78,7 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
     int* s_plain = s_slot + OMAX;                                      // [OMAX] non-segmentation outputs, compacted
     int* s_lut = s_plain + OMAX;                                       // [OMAX]
     float** s_map = reinterpret_cast<float**>(s_lut + OMAX);           // [NMAPS]
-    __shared__ int s_nplain;
+    __shared__ int s_nplain, s_srfirst;
     const int C = p.d.c_feat;
     const int NO = p.d.n_out;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -114,16 +116,20 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
         }
     }
     for (int i = threadIdx.x; i < NO; i += TPBT) { s_role[i] = p.d.roles[i]; s_slot[i] = p.d.out_slot[i]; }
-    for (int i = threadIdx.x; i < p.n_maps; i += TPBT) s_map[i] = p.maps[i];
+    for (int i = threadIdx.x; i < p.n_maps; i += TPBT) s_map[i] = p.maps ? p.maps[i] : p.maps_rows + (int64_t)i * p.row_stride;
     for (int i = threadIdx.x; i < p.d.n_seg; i += TPBT) s_lut[i] = p.d.seg_lut[i];
     if (threadIdx.x == 0) {
-        int n = 0;
-        for (int o = 0; o < NO; ++o)
+        int n = 0, sr = -1;
+        for (int o = 0; o < NO; ++o) {
             if (p.d.roles[o] != BFM_ROLE_SEG) s_plain[n++] = o;
+            if (p.d.roles[o] == BFM_ROLE_SR && sr < 0) sr = o;
+        }
         s_nplain = n;
+        s_srfirst = sr < 0 ? 0 : sr;
     }
     __syncthreads();
     const int nplain = s_nplain;
+    const int sr_first = s_srfirst;                 // rows with BFM_ROLE_SR are one head's channels: contiguous
     float* slab = smem + wave * 64 * ld;            // this wave's [64][ld] logits
     float* row = slab + lane * ld;
 
@@ -270,8 +276,8 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
                 if (k == 0) dist[0] = r; else if (k == 1) dist[1] = r; else if (k == 2) dist[2] = r; else dist[3] = r;
             }
             if (live && mp) mp[v] = r;
-            if (role == BFM_ROLE_SR && p.d.slot_high_res >= 0 && live && p.input)
-                s_map[p.d.slot_high_res][v] = a + p.input[v];
+            if (role == BFM_ROLE_SR && p.d.slot_high_res >= 0 && live && p.input)      // channel c -> slot_high_res + c
+                s_map[min(p.d.slot_high_res + (o - sr_first), p.n_maps - 1)][v] = a + p.input[v];
         };
 #pragma unroll
         for (int j = 0; j < PMAX; ++j)
@@ -364,11 +370,13 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
 
 }  // namespace
 
-extern "C" int bfm_tail_heads(const float* feat, const float* input, int64_t nvox, const bfm_tail_desc_t* desc,
-                              float* feat_norm, float* const* maps, float* seg_prob, int64_t* label,
-                              float* raw_out, bfm_stream_t stream) {
+static int tail_launch(const float* feat, const float* input, int64_t nvox, const bfm_tail_desc_t* desc,
+                       float* feat_norm, float* const* maps_tab, float* maps_rows, int64_t row_stride, float* seg_prob,
+                       int64_t* label, float* raw_out, int skip_zero_input, bfm_stream_t stream) {
     if (!feat || !desc || nvox <= 0 || !desc->head_w || !desc->head_b || !desc->roles || !desc->out_slot)
         return BFM_E_ARG;
+    const bool maps = maps_tab != nullptr || maps_rows != nullptr;
+    if (maps_rows && (row_stride < nvox || (reinterpret_cast<uintptr_t>(maps_rows) & 3))) return BFM_E_ARG;
     if (!maps && !raw_out && !feat_norm) return BFM_E_ARG;
     if (desc->n_out < 0 || desc->n_out > OMAX || (desc->n_out > 0 && !maps && !raw_out)) return BFM_E_SHAPE;
     if (desc->n_seg > 0 && (desc->seg_first < 0 || desc->seg_first + desc->n_seg > desc->n_out)) return BFM_E_SHAPE;
@@ -381,7 +389,9 @@ extern "C" int bfm_tail_heads(const float* feat, const float* input, int64_t nvo
     if (n_maps < 0 || n_maps > NMAPS) return BFM_E_SHAPE;
     for (int o = 0; o < desc->n_out; ++o) (void)o;
     if (maps && (desc->slot_high_res >= n_maps || desc->slot_fake_cortical >= n_maps)) return BFM_E_SHAPE;
-    TailParams p{feat, input, nvox, *desc, feat_norm, maps, seg_prob, label, raw_out, n_maps};
+    TailParams p{feat, input, nvox, *desc, feat_norm, maps_tab, maps_tab ? nullptr : maps_rows, row_stride, seg_prob, label,
+                 raw_out, n_maps};
+    if (skip_zero_input) p.d.skip_zero_input = 1;
     const int ld = (desc->n_out > 0 ? desc->n_out : 1) | 1;        // odd row stride: conflict-free column access
     int64_t nb = bfm_cdiv64(bfm_cdiv64(nvox, 64), WPB);
     if (nb > 256 * 2) nb = 256 * 2;                  // persistent: the weight fragments are loaded once per wave
@@ -417,4 +427,18 @@ extern "C" int bfm_tail_heads(const float* feat, const float* input, int64_t nvo
     else
         hipLaunchKernelGGL((tail_kernel<false>), dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, 0);
     return bfm_launch_status();
+}
+
+extern "C" int bfm_tail_heads(const float* feat, const float* input, int64_t nvox, const bfm_tail_desc_t* desc,
+                              float* feat_norm, float* const* maps, float* seg_prob, int64_t* label,
+                              float* raw_out, bfm_stream_t stream) {
+    return tail_launch(feat, input, nvox, desc, feat_norm, maps, nullptr, 0, seg_prob, label, raw_out, 0, stream);
+}
+
+extern "C" int bfm_tail_heads_rows(const float* feat, const float* input, int64_t nvox, const bfm_tail_desc_t* desc,
+                                   float* feat_norm, float* maps_rows, int64_t row_stride, float* seg_prob,
+                                   int64_t* label, int flags, bfm_stream_t stream) {
+    if (!maps_rows || (flags & ~1)) return BFM_E_ARG;
+    return tail_launch(feat, input, nvox, desc, feat_norm, nullptr, maps_rows, row_stride, seg_prob, label, nullptr,
+                       flags & 1, stream);
 }

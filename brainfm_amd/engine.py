@@ -253,7 +253,7 @@ class UNetEngine:
         """Pack (once per layout) and select the weights for this launch: 'direct' [27][Cin][Cout] fp32,
         'mfma' 32x32x16 fragments (plan variants 0/1), 'mfma16' 16x16x32 tap-pair fragments (variant 2),
         'wino' F(2,3)-along-x transformed fragments (variant 3, single-source layers only)."""
-        layout = "direct" if not mfma else ("wino" if ver in (3, 4, 5) else ("mfma16" if ver == 2 else "mfma"))
+        layout = "direct" if not mfma else ("wino" if ver == 3 else ("mfma16" if ver == 2 else "mfma"))
         if layout not in ly.packs:
             self._make_pack(ly, layout)
         ly.touch(layout)
@@ -351,7 +351,7 @@ class UNetEngine:
         if key not in self._plan_cache:
             cfg = (C.c_int * 8)()
             L.check(self.lib.bfm_conv3x3x3_mfma_plan(cin, cout, dims[0], dims[1], dims[2], cfg), "mfma_plan")
-            if two_src and cfg[6] in (3, 4, 5):                     # BFM_CONV_VER=3/4: Winograd takes one source
+            if two_src and cfg[6] == 3:                             # BFM_CONV_VER=3: Winograd takes one source
                 cfg[6] = 0
             self._plan_cache[key] = cfg
         return self._plan_cache[key]
@@ -369,7 +369,7 @@ class UNetEngine:
         gkey = (torch.cuda.current_device(), getattr(self, "passes", None), key)
         if gkey not in _TUNE_CHOICES:
             saved = _tune_lookup(gkey[0], gkey[1], key)         # the persisted table: same bits in every process
-            if saved is not None and not (key[3] and saved in (3, 4, 5)) and (vers is None or saved in vers):
+            if saved is not None and not (key[3] and saved == 3) and (vers is None or saved in vers):
                 _TUNE_CHOICES[gkey] = int(saved)
         if gkey in _TUNE_CHOICES:
             cfg[6] = _TUNE_CHOICES[gkey]
@@ -486,12 +486,12 @@ class UNetEngine:
                                                         L.ptr(uni_flags), L.ptr(scratch), st),
                     "conv_wino(uniform) " + ly.name)
             return
-        if cfg[6] in (3, 4, 5):
+        if cfg[6] == 3:
             if cb:
                 raise L.BfmError("the Winograd variant takes one source")
             L.check(self.lib.bfm_conv3x3x3_wino_ex(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
                                                    groups, L.ptr(ly.wpacked), ly.wexp, ly.cout, slope, self.passes,
-                                                   (cfg[7] & 1) | (2 if cfg[6] == 4 else 0) | (4 if cfg[6] == 5 else 0), L.ptr(out),
+                                                   (cfg[7] & 1), L.ptr(out),
                                                    L.ptr(rows[0]) if rows is not None else None, st),
                     "conv_wino " + ly.name)
             return
@@ -1133,16 +1133,20 @@ class Tail:
             rows_w.append(w)
             rows_b.append(b)
             for j in range(n):
+                # every channel of a head goes through the head's post-processing: with `losses.uncertainty` set the
+                # regression heads have a second (sigma) channel that the reference's UncertaintyProcessor never splits
+                # off (joiner.py:50-55 looks for 'image' in the output names, none has it), so CT * 1000, exp(bias_field_log)
+                # and residual + input see both channels (Trainer/models/__init__.py:307-352)
                 if task == "CT":
-                    r = L.ROLE_CT if j == 0 else L.ROLE_PLAIN
+                    r = L.ROLE_CT
                 elif task == "bias_field_log":
-                    r = L.ROLE_BIAS_LOG if j == 0 else L.ROLE_PLAIN
+                    r = L.ROLE_BIAS_LOG
                 elif task == "segmentation":
                     r = L.ROLE_SEG
                 elif task == "distance":
                     r = L.ROLE_DIST
                 elif task == "high_res_residual":
-                    r = L.ROLE_SR if j == 0 else L.ROLE_PLAIN
+                    r = L.ROLE_SR
                 elif task == "pathology":
                     r = L.ROLE_PATHOL
                 else:
@@ -1166,15 +1170,13 @@ class Tail:
 
         self.slot_high_res = -1
         self.slot_fake = -1
+        self.channels = OrderedDict()                      # output key -> (first map row, channels): adjacent rows
         for task, (r0, n) in self.row_of.items():
-            if task in ("T1", "T2", "FLAIR", "CT", "pathology"):
-                add(task, r0)
+            if task in ("T1", "T2", "FLAIR", "CT", "pathology", "bias_field_log", "high_res_residual"):
+                key = "bias_field" if task == "bias_field_log" else task
+                self.channels[key] = (add(key, r0), n)
                 for j in range(1, n):
-                    add("%s_sigma" % task, r0 + j)
-            elif task == "bias_field_log":
-                add("bias_field", r0)
-            elif task == "high_res_residual":
-                add("high_res_residual", r0)
+                    add("%s#%d" % (key, j), r0 + j)
             elif task == "distance":
                 for j, nm in enumerate(["lp", "lw", "rp", "rw"][:n]):
                     add(nm, r0 + j)
@@ -1184,10 +1186,15 @@ class Tail:
             elif task == "segmentation":
                 pass
             else:
-                for j in range(n):
-                    add(task if n == 1 else "%s_%d" % (task, j), r0 + j)
+                self.channels[task] = (add(task, r0), n)
+                for j in range(1, n):
+                    add("%s#%d" % (task, j), r0 + j)
         if "high_res_residual" in self.row_of:
-            self.slot_high_res = add("high_res")
+            n = self.row_of["high_res_residual"][1]
+            self.slot_high_res = add("high_res")           # one row per residual channel (slot_high_res + channel)
+            self.channels["high_res"] = (self.slot_high_res, n)
+            for j in range(1, n):
+                add("high_res#%d" % j)
         if "distance" in self.row_of:
             self.slot_fake = add("fake_cortical")
         self.out_slot = torch.tensor(slot_of_row, dtype=torch.int32, device=dev)
@@ -1202,7 +1209,6 @@ class Tail:
                                self.seg_lut.data_ptr(), dist[1], dist[0], float(max_surf_distance),
                                1 if eng.unit_feat else 0, self.slot_high_res, self.slot_fake, len(self.map_names),
                                float(self.head_w.abs().max().item()) if self.n_out else 0.0, 0)
-        self.desc_skip = None
 
     def run(self, feat_cl, dims, input_cl=None, want_feat=True, want_seg=True, extra_rows=0, skip_zero_input=False):
         """Fused tail.  feat_cl: (D,H,W,c_feat) raw last decoder output.
@@ -1215,20 +1221,16 @@ class Tail:
         nvox = D * H * W
         dev = eng.device
         maps_buf = torch.empty((len(self.map_names) + int(extra_rows), D, H, W), dtype=torch.float32, device=dev)
-        # pointer table built on the device (no host->device copy: the whole tile pass is hipGraph-capturable)
-        ptrs = torch.arange(len(self.map_names), dtype=torch.int64, device=dev) * (nvox * 4) + maps_buf.data_ptr()
         nseg = self.desc.n_seg
         feat_norm = torch.empty_like(feat_cl) if want_feat else None
         seg = torch.empty((D, H, W, nseg), dtype=torch.float32, device=dev) if (want_seg and nseg) else None
         label = torch.empty((D, H, W), dtype=torch.int64, device=dev) if nseg else None
-        desc = self.desc
-        if skip_zero_input and input_cl is not None and not want_feat and not want_seg:
-            if self.desc_skip is None:
-                self.desc_skip = L.TailDesc.from_buffer_copy(self.desc)
-                self.desc_skip.skip_zero_input = 1
-            desc = self.desc_skip
-        L.check(eng.lib.bfm_tail_heads(L.ptr(feat_cl), L.ptr(input_cl), nvox, C.byref(desc), L.ptr(feat_norm),
-                                       L.ptr(ptrs), L.ptr(seg), L.ptr(label), None, L.stream_ptr()), "tail_heads")
+        # the maps are the rows of one buffer (no pointer table to build on the device); skipping is a per-call flag, so
+        # the one descriptor -- whose head_wmax the training step refreshes -- serves the tile loop and evaluate_image
+        skip = 1 if (skip_zero_input and input_cl is not None and not want_feat and not want_seg) else 0
+        L.check(eng.lib.bfm_tail_heads_rows(L.ptr(feat_cl), L.ptr(input_cl), nvox, C.byref(self.desc), L.ptr(feat_norm),
+                                            L.ptr(maps_buf), nvox, L.ptr(seg), L.ptr(label), skip, L.stream_ptr()),
+                "tail_heads")
         maps = OrderedDict((n, maps_buf[i]) for i, n in enumerate(self.map_names))
         self.last_buf = maps_buf                      # [n_maps][D,H,W]: the stitcher consumes all rows in one launch
         return maps, feat_norm, seg, label

@@ -402,7 +402,9 @@ class BaseGen(torch.utils.data.Dataset):
         SYN0 = SYN                                            # crop space, before the deformation
         SYN = GU.fast_3D_interp_torch(SYN, xx2, yy2, zz2)
         if np.random.rand() < getattr(self.gen_args, "mix_synth_prob", 0.):        # random linear combination, :377-386
-            have = case if case is not None else {}
+            have = getattr(self, "modalities", None)
+            if have is None:
+                have = case if case is not None else {}
             v = GU.draws.rand(4).clone()
             v[2] = 0 if "T2" not in have else v[2]
             v[3] = 0 if "FLAIR" not in have else v[3]
@@ -424,8 +426,9 @@ class BaseGen(torch.utils.data.Dataset):
             same = tuple(Gc.shape) == tuple(SYN.shape)
             src = SYN.contiguous() if same else SYN0.contiguous()
             cer = torch.empty_like(src)
-            stats = torch.zeros(4, dtype=torch.float64, device=self.device)
-            L.check(lib.bfm_label_class_stats(L.ptr(Gc), L.ptr(src), src.numel(), L.ptr(cer), L.ptr(stats),
+            stats = torch.empty(4, dtype=torch.float64, device=self.device)
+            part = torch.empty(4 * L.CLASS_STATS_BLOCKS, dtype=torch.float64, device=self.device)
+            L.check(lib.bfm_label_class_stats(L.ptr(Gc), L.ptr(src), src.numel(), L.ptr(cer), L.ptr(stats), L.ptr(part),
                                               L.stream_ptr()), "label_class_stats")
             cer = GU.fast_3D_interp_torch(cer, xx2, yy2, zz2)[None]
             st = stats.cpu().tolist()
@@ -451,6 +454,10 @@ class BaseGen(torch.utils.data.Dataset):
 
     def _read_input(self, idx):
         case = self.cases[idx]
+        # Generator/datasets.py:541-557 (get_info): the item's modalities = what exists for this case; generate_sample's
+        # T2 / FLAIR mixing asks this list (:381-387), not the case dictionary it happens to be handed
+        self.modalities = {k: case[k] for k in case if k in ("T1", "T2", "FLAIR", "CT", "Gen", "segmentation",
+                                                              "T1_DM", "T2_DM", "FLAIR_DM", "CT_DM")}
         prob = np.random.rand()
         probs = self.input_prob
         mode = "synth"

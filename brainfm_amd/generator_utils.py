@@ -96,19 +96,32 @@ def resolution_sampler(low_res_only=False):
     return resolution, thickness
 
 
+def _rotation_about(axis, angle):
+    """Right-handed rotation about one coordinate axis: the 2x2 block [[c, -s], [s, c]] on the other two axes taken in
+    cyclic order (x: (y,z), y: (z,x), z: (x,y))."""
+    i, j = (axis + 1) % 3, (axis + 2) % 3
+    R = np.eye(3)
+    c, sn = np.cos(angle), np.sin(angle)
+    R[i, i], R[i, j], R[j, i], R[j, j] = c, -sn, sn, c
+    return R
+
+
+def _shear_along(axis, sh):
+    """Identity whose column `axis` carries the shear coefficients of the other two rows."""
+    S = np.eye(3)
+    for r in range(3):
+        if r != axis:
+            S[r, axis] = sh[r]
+    return S
+
+
 def make_affine_matrix(rot, sh, s):
-    """Generator/utils.py:102-116."""
-    Rx = np.array([[1, 0, 0], [0, np.cos(rot[0]), -np.sin(rot[0])], [0, np.sin(rot[0]), np.cos(rot[0])]])
-    Ry = np.array([[np.cos(rot[1]), 0, np.sin(rot[1])], [0, 1, 0], [-np.sin(rot[1]), 0, np.cos(rot[1])]])
-    Rz = np.array([[np.cos(rot[2]), -np.sin(rot[2]), 0], [np.sin(rot[2]), np.cos(rot[2]), 0], [0, 0, 1]])
-    SHx = np.array([[1, 0, 0], [sh[1], 1, 0], [sh[2], 0, 1]])
-    SHy = np.array([[1, sh[0], 0], [0, 1, 0], [0, sh[2], 1]])
-    SHz = np.array([[1, 0, sh[0]], [0, 1, sh[1]], [0, 0, 1]])
-    A = SHx @ SHy @ SHz @ Rx @ Ry @ Rz
-    A[0, :] = A[0, :] * s[0]
-    A[1, :] = A[1, :] * s[1]
-    A[2, :] = A[2, :] * s[2]
-    return A
+    """Generator/utils.py:102-116: shears (x, y, z) times rotations (x, y, z), rows scaled by s -- the same factors in
+    the same order, so the float64 result is the reference's bit for bit (gen_chain.npz)."""
+    A = np.eye(3)
+    for M in [_shear_along(k, sh) for k in range(3)] + [_rotation_about(k, rot[k]) for k in range(3)]:
+        A = A @ M
+    return A * np.asarray(s, dtype=np.float64).reshape(3, 1)
 
 
 # ----------------------------------------------------------------------------- reductions / elementwise
@@ -245,6 +258,17 @@ def _zoom_tables_dev(n, factor, dev):
     return _ZOOM_CACHE[key]
 
 
+def _zoomed_affine(aff, factor):
+    """vox2ras of a grid resampled by `factor` (Generator/utils.py:252-255): voxel axes shrink by the factor and the
+    first voxel's centre moves by half the change in voxel size along each axis."""
+    old_axes = aff[:-1, :-1]
+    centre_shift = old_axes @ (0.5 - 0.5 / (factor * np.ones(3)))
+    out = aff.copy()
+    out[:-1] = out[:-1] / factor
+    out[:-1, -1] = out[:-1, -1] - centre_shift
+    return out
+
+
 def myzoom_torch(X, factor, aff=None):
     """Generator/utils.py:200-257: separable linear zoom (fused into one kernel)."""
     _require_cuda(X, "myzoom_torch")
@@ -266,10 +290,7 @@ def myzoom_torch(X, factor, aff=None):
                                 L.stream_ptr()), "zoom_linear")
     Y = out[..., 0] if Cc == 1 else out
     if aff is not None:
-        aff_new = aff.copy()
-        aff_new[:-1] = aff_new[:-1] / factor
-        aff_new[:-1, -1] = aff_new[:-1, -1] - aff[:-1, :-1] @ (0.5 - 0.5 / (factor * np.ones(3)))
-        return Y, aff_new
+        return Y, _zoomed_affine(aff, factor)
     return Y
 
 

@@ -16,6 +16,7 @@ state-dict names (so reference checkpoints load unchanged); its torch
 ``forward`` methods are never used.
 """
 import ctypes as C
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -67,10 +68,11 @@ def _binary(op, x, y, a=0.0):
     lib = L.load()
     x, px, xs, c, n = _cl_rows(x)
     y, py, ys, c2, _ = _cl_rows(y)
-    assert c == 1 and c2 == 1
-    buf, view = _new_like_spatial(x, 1)
-    L.check(lib.bfm_ew_binary(op, C.c_void_p(px), xs, C.c_void_p(py), ys, L.ptr(buf), 1, n, float(a),
-                              L.stream_ptr()), "ew_binary")
+    assert c2 == 1 or c2 == c                              # a one-channel y broadcasts over x's channels, as in torch
+    buf, view = _new_like_spatial(x, c)
+    for j in range(c):
+        L.check(lib.bfm_ew_binary(op, C.c_void_p(px + 4 * j), xs, C.c_void_p(py + 4 * (j if c2 == c else 0)), ys,
+                                  C.c_void_p(buf.data_ptr() + 4 * j), c, n, float(a), L.stream_ptr()), "ew_binary")
     return view
 
 
@@ -550,14 +552,30 @@ def build_model(gen_args, train_args, device="cpu"):
 def load_checkpoint(ckp_path, models, model_keys=["model"], to_print=False):
     """utils/checkpoint.py:409-457 reduced to what inference needs: pick the first checkpoint key
     containing 'model', then match parameter names by suffix (:558-571) so DDP 'module.' prefixes load."""
-    # reference checkpoints also pickle the submit / generator / trainer Config objects (scripts/train.py:206-214):
-    # they are the user's own training output, loaded the way the reference does (full unpickling)
-    ckp = torch.load(ckp_path, map_location="cpu", weights_only=False)
+    ckp = read_checkpoint_file(ckp_path)
     for model, mkey in zip(models, model_keys):
         key = next((k for k in ckp if mkey in k), None)
         sd = ckp[key] if key is not None else ckp
         load_state_dict_by_suffix(model, sd)
     return ckp
+
+
+def read_checkpoint_file(path):
+    """torch.load restricted to tensors and plain containers (weights_only=True; argparse.Namespace allow-listed: the
+    argument objects scripts/train.py:206-214 stores beside 'model').  A file that needs more -- the reference pickles
+    its own Config class instances -- is executed-on-load pickle: it is read only when the caller says the file is
+    trusted (BFM_TRUST_CHECKPOINT=1), the way the reference always does."""
+    import argparse
+    import pickle
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            return torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        if os.environ.get("BFM_TRUST_CHECKPOINT", "0") != "1":
+            raise L.BfmError("checkpoint %s holds pickled objects beyond tensors and containers (%s); set "
+                             "BFM_TRUST_CHECKPOINT=1 to unpickle it in full if you trust its source"
+                             % (path, str(e).splitlines()[0])) from e
+        return torch.load(path, map_location="cpu", weights_only=False)
 
 
 def load_state_dict_by_suffix(model, loaded):

@@ -443,15 +443,21 @@ class InferenceSession:
             out["feat"] = [UNetEngine.as_ncdhw(f) for f in bufs]
         order = ["T1", "T2", "FLAIR", "CT", "segmentation", "high_res_residual", "high_res", "bias_field", "lp", "lw",
                  "rp", "rw", "fake_cortical", "regx", "regy", "regz"]
+        def chans(k):
+            # a head with c channels (`losses.uncertainty`: value + sigma) is c adjacent rows of the tail's buffer:
+            # the reference keeps them as one (1,c,D,H,W) tensor (Trainer/models/__init__.py:57-111, joiner.py:50-55)
+            r0, c = tail.channels.get(k, (None, 1))
+            return tail.last_buf[r0:r0 + c][None] if c > 1 else maps[k][None, None]
+
         for k in order:
             if k == "segmentation":
                 if seg is not None:
                     out[k] = seg.permute(3, 0, 1, 2).unsqueeze(0)
             elif k in maps:
-                out[k] = maps[k][None, None]
+                out[k] = chans(k)
         for k, v in maps.items():
-            if k not in out:
-                out[k] = v[None, None]
+            if k not in out and "#" not in k:
+                out[k] = chans(k)
         if label is not None:
             out["label"] = label[None, None]
         return out, x_cl

@@ -26,6 +26,7 @@ import torch
 
 from . import _lib as L
 from . import backward as BW
+from . import models as M
 
 IMAGE_KEYS = ("T1", "T2", "FLAIR", "CT")
 SUPPORTED = set(IMAGE_KEYS) | {k + "_grad" for k in IMAGE_KEYS} | {
@@ -203,7 +204,7 @@ class TrainStep:
 
     def load_checkpoint(self, path):
         """Parameters (matched by name suffix, as utils/checkpoint.py:558-571) and AdamW moments back into the engine."""
-        ckp = torch.load(path, map_location="cpu", weights_only=False)
+        ckp = M.read_checkpoint_file(path)
         key = next((k for k in ckp if "model" in k), None)
         sd = ckp[key] if key is not None else ckp
         params = self.parameters()

@@ -282,7 +282,8 @@ typedef struct {
     int dist_first;
     float max_dist;
     int unit_feat;              /* apply F.normalize before the heads */
-    int slot_high_res;          /* maps slot for residual+input, -1 = none */
+    int slot_high_res;          /* maps slot for residual+input, -1 = none; a residual head with c channels (rows with
+                                   BFM_ROLE_SR, contiguous) writes channel j to slot_high_res + j */
     int slot_fake_cortical;     /* maps slot, -1 = none */
     int n_maps;                 /* length of the `maps` pointer array (every out_slot / slot_* is < n_maps) */
     float head_wmax;            /* max |head_w| (host knows it): > 0 with unit_feat selects the split-f16 matrix-core
@@ -298,6 +299,13 @@ int bfm_tail_heads(const float* feat, const float* input /*[nvox], may be NULL*/
                    float* seg_prob /*[nvox][n_seg] or NULL*/, int64_t* label /*[nvox] or NULL*/,
                    float* raw_out /*[nvox][n_out]: if set, write raw head logits only (TaskHead.forward)*/,
                    bfm_stream_t stream);
+/* The same pass writing its maps into the rows of ONE buffer: map i = maps_rows + i * row_stride (row_stride >= nvox
+ * floats), so a caller that allocates the maps together needs no device-side pointer table (the tile loop inside a
+ * hipGraph: no table-building kernels).  flags bit 0 = skip_zero_input for this call (see bfm_tail_desc_t; the
+ * descriptor itself stays the one evaluate_image uses).  Replaces the same reference lines as bfm_tail_heads. */
+int bfm_tail_heads_rows(const float* feat, const float* input /*[nvox], may be NULL*/, int64_t nvox,
+                        const bfm_tail_desc_t* desc, float* feat_norm /*or NULL*/, float* maps_rows, int64_t row_stride,
+                        float* seg_prob /*or NULL*/, int64_t* label /*or NULL*/, int flags, bfm_stream_t stream);
 
 /* ----------------------------------------------------------------- stitch
  * scripts/demo_test.py:88-119 without the NIfTI round trip:
@@ -461,9 +469,12 @@ int bfm_deform_grid(const float* F, int sx, int sy, int sz, const float* A_host 
  * (label 77 merged into 2). */
 /* generate_sample's pathology branch -- Generator/datasets.py:388-396: cerebral[i] = (round(G[i]) == 0) ? 0 : syn[i]
  * (G == 77 counts as 2, :368) and the four sums behind wm_mean / gm_mean: stats[0..3] = sum(syn | label in {2,41}),
- * count of those, sum(syn | label not in {0,2,41}), count (fp64; stats must be zeroed by the caller). */
-int bfm_label_class_stats(const float* G, const float* syn, int64_t n, float* cerebral, double* stats,
-                          bfm_stream_t stream);
+ * count of those, sum(syn | label not in {0,2,41}), count (fp64, written whole).  partials: workspace of
+ * 4 * BFM_CLASS_STATS_BLOCKS doubles -- the blocks' sums, added in block order, so the result does not depend on the
+ * run (the reference's torch sums are deterministic on CPU; pathol_direction = gm_mean > wm_mean hangs on them). */
+#define BFM_CLASS_STATS_BLOCKS 1024
+int bfm_label_class_stats(const float* G, const float* syn, int64_t n, float* cerebral, double* stats /*[4]*/,
+                          double* partials, bfm_stream_t stream);
 int bfm_label_gauss(const float* G, const float* mus, const float* sigmas, const float* randn, int64_t n, int ntab,
                     float* out, bfm_stream_t stream);
 /* onehotmatrix[lut[S]] -- Generator/utils.py:408-411: out [n][n_labels]. */

@@ -39,17 +39,21 @@ class Draws:
 
 
 def make_affine_matrix(rot, sh, s):
-    """Generator/utils.py:102-116."""
-    Rx = np.array([[1, 0, 0], [0, np.cos(rot[0]), -np.sin(rot[0])], [0, np.sin(rot[0]), np.cos(rot[0])]])
-    Ry = np.array([[np.cos(rot[1]), 0, np.sin(rot[1])], [0, 1, 0], [-np.sin(rot[1]), 0, np.cos(rot[1])]])
-    Rz = np.array([[np.cos(rot[2]), -np.sin(rot[2]), 0], [np.sin(rot[2]), np.cos(rot[2]), 0], [0, 0, 1]])
-    SHx = np.array([[1, 0, 0], [sh[1], 1, 0], [sh[2], 0, 1]])
-    SHy = np.array([[1, sh[0], 0], [0, 1, 0], [0, sh[2], 1]])
-    SHz = np.array([[1, 0, sh[0]], [0, 1, sh[1]], [0, 0, 1]])
-    A = SHx @ SHy @ SHz @ Rx @ Ry @ Rz
-    for r in range(3):
-        A[r, :] = A[r, :] * s[r]
-    return A
+    """Generator/utils.py:102-116, restated: A = SHx SHy SHz Rx Ry Rz, then row r times s[r]."""
+    cx, cy, cz = (np.cos(rot[k]) for k in range(3))
+    sx, sy, sz = (np.sin(rot[k]) for k in range(3))
+    factors = np.zeros((6, 3, 3))
+    factors[:, [0, 1, 2], [0, 1, 2]] = 1.0
+    factors[0, 1, 0], factors[0, 2, 0] = sh[1], sh[2]              # shear carried by column x
+    factors[1, 0, 1], factors[1, 2, 1] = sh[0], sh[2]              # ... column y
+    factors[2, 0, 2], factors[2, 1, 2] = sh[0], sh[1]              # ... column z
+    factors[3, 1:, 1:] = [[cx, -sx], [sx, cx]]
+    factors[4, ::2, ::2] = [[cy, sy], [-sy, cy]]
+    factors[5, :2, :2] = [[cz, -sz], [sz, cz]]
+    A = factors[0]
+    for M in factors[1:]:
+        A = A @ M
+    return np.stack([A[r] * s[r] for r in range(3)])
 
 
 def resolution_sampler(low_res_only=False):

@@ -179,14 +179,19 @@ def processors_and_post(out, x_input, tasks, left_hemis_only=False, max_surf_dis
 
 
 def forward_all(x, sd, tasks=None, in_channels=1, f_maps=64, num_levels=6, num_groups=8, unit_feat=True,
-                left_hemis_only=False, max_surf_distance=3.0):
-    """evaluate_image minus config/checkpoint handling, utils/test_utils.py:289-312."""
+                left_hemis_only=False, max_surf_distance=3.0, uncertainty=False):
+    """evaluate_image minus config/checkpoint handling, utils/test_utils.py:289-312.
+
+    uncertainty: train_args.losses.uncertainty is set (Trainer/models/__init__.py:57-111): the regression heads have
+    two channels.  The reference's UncertaintyProcessor (joiner.py:45-56) splits `name + '_sigma'` off only for output
+    names that contain 'image' -- none of process_args' names does -- so both channels stay in one tensor and go
+    through the post-processor together (pinned by tests/golden/infer_uncert.npz)."""
     if tasks is None:
         tasks = ["T1", "T2", "FLAIR", "CT", "segmentation", "distance", "bias_field", "registration",
                  "super_resolution"]
     feats = get_feature(x, sd, in_channels, f_maps, num_levels, num_groups, unit_feat)
     out = OrderedDict(feat=feats)
-    out.update(task_heads(feats[-1], sd, default_out_channels(left_hemis_only, False, tasks)))
+    out.update(task_heads(feats[-1], sd, default_out_channels(left_hemis_only, uncertainty, tasks)))
     return processors_and_post(out, x, tasks, left_hemis_only, max_surf_distance)
 
 

@@ -474,7 +474,7 @@ def test_upsample_folded_conv_split_k_on_small_levels(lo):
     assert e <= 3e-6, e
 
 
-@pytest.mark.parametrize("ver", [0, 2, 3, 5])
+@pytest.mark.parametrize("ver", [0, 2, 3])
 def test_producer_moment_rows_equal_activation_moments(ver, monkeypatch):
     """The per-tile {sum, sumsq, min, max} rows written by the stem / conv epilogues must be the moments of the
     stored activation (sums to fp32-partial accuracy; min/max exact), and GroupNorm from rows must reproduce GroupNorm from the
@@ -524,7 +524,7 @@ def test_producer_moment_rows_equal_activation_moments(ver, monkeypatch):
     assert _relerr(got.cpu().numpy(), ref.cpu().numpy()) <= 1e-6
 
 
-@pytest.mark.parametrize("wver", [3, 4, 5])
+@pytest.mark.parametrize("wver", [3])
 @pytest.mark.parametrize("dims", [(8, 8, 32), (7, 9, 21), (12, 5, 10)])
 def test_winograd_variant_equals_direct_variant(dims, wver, monkeypatch):
     """conv_wino (F(2,3) along x, 1.5x fewer MFMAs) against conv_mfma on the same operands, including odd widths
@@ -814,16 +814,12 @@ def test_full_size_512_volume_216_tiles_properties():
         assert float(v[~inside].abs().max()) == 0.0, k
     assert float(eager["label"].min()) >= min(LABELS_FULL) and float(eager["label"].max()) <= max(LABELS_FULL)
     assert float(eager["deformed_atlas"].abs().max()) > 0
-    sums = {k: v.double().sum().item() for k, v in eager.items()}
-    ref_label = eager["label"].clone()
-    ref_t1 = eager["T1"].clone()
-    del eager
+    eager = {k: v.clone() for k, v in eager.items()}                # 17 x 512^3 fp32 = 9.1 GB, kept for the comparison
     TU.prepare_tile_graphs(full, s, [80] * 3, [160] * 3)
     for rep in range(2):
         acc, _, _ = TU.tiled_inference(full, s, [80] * 3, [160] * 3, graphs=True)
-        assert torch.equal(acc["label"], ref_label) and torch.equal(acc["T1"], ref_t1), rep
-        for k, v in acc.items():
-            assert v.double().sum().item() == sums[k], (k, rep)      # the other 15 maps through an exact checksum
+        for k in eager:
+            assert torch.equal(acc[k], eager[k]), (k, rep)           # all 17 keys, voxel for voxel
         del acc
 
 
@@ -1065,18 +1061,21 @@ def test_compact_rows_index_pack_and_stitch_equal_the_dense_form_bitwise(shape, 
         assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
 
 
-def test_uniform_background_boxes_change_no_bit():
+@pytest.mark.parametrize("dims", [(48, 64, 128), (50, 66, 130), (45, 70, 150)])
+def test_uniform_background_boxes_change_no_bit(dims):
     """Where the one-channel input is constant (the zero background of a head volume) the first layers' activations are one
     function of the distances to the tile's faces, and the two full-resolution Winograd layers that read them compute ONE box
     per class of boxes that see nothing else (first / middle / last box per axis: 27 classes) and reuse its accumulators in
     its class mates (engine.uniform_skip: bfm_uniform_boxes + bfm_conv3x3x3_wino_uniform).  Every decoder
     feature map, the tail's maps and the labels are bit-identical to the run with every box in full; the flags are the
-    boxes whose grown neighbourhood is constant and inside the volume (numpy restatement); and some boxes are flagged."""
+    boxes whose grown neighbourhood is constant and inside the volume (numpy restatement); and some boxes are flagged.
+    (50, 66, 130) and (45, 70, 150) end every axis -- and, pooled once, the level below -- with a remainder box narrower
+    than the layers' reach: the box before it then sees the far face's zero padding and is no mate of the middle boxes
+    (round 2 flagged it), so it must stay unflagged and the outputs must not move."""
     from brainfm_amd import test_utils as TU
     import ctypes as C
     from brainfm_amd import _lib as L
     ga, ta = TU.default_inference_args(f_maps=64, num_levels=3)
-    dims = (48, 64, 128)
     g = torch.Generator().manual_seed(3)
     zz, yy, xx = np.meshgrid(*[np.linspace(-1, 1, n_) for n_ in dims], indexing="ij")
     inside = torch.from_numpy((zz / 0.45) ** 2 + (yy / 0.4) ** 2 + ((xx + 0.5) / 0.3) ** 2 < 1)
@@ -1113,7 +1112,10 @@ def test_uniform_background_boxes_change_no_bit():
                             blk = img[lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
                             ok = bool((blk.view(np.uint32) == blk.view(np.uint32).flat[0]).all())
                             c = [0 if i == 0 else (2 if i == n - 1 else 1) for i, n in zip((iz, iy, ix), nt)]
-                            want.append(1 + 9 * c[0] + 3 * c[1] + c[2] if ok else 0)
+                            # a box before the last one whose grown far edge passes the level's extent sees that face
+                            far = any(i != n - 1 and (((i + 1) * b) << lvl) + rad > ((d >> lvl) << lvl)
+                                      for i, n, b, d in zip((iz, iy, ix), nt, box, dims))
+                            want.append(1 + 9 * c[0] + 3 * c[1] + c[2] if ok and not far else 0)
                 want = np.array(want, dtype=np.uint8)
                 assert np.array_equal(fl, want), (lvl, rad)
                 if lvl == 0:
@@ -1156,3 +1158,149 @@ def test_tiles_without_input_can_be_left_out(monkeypatch):
             assert torch.equal(acc[k], eager[k]), (k, rep)
     r = empty[0]
     assert float(acc["T1"][r[0][0]:r[0][1], r[1][0]:r[1][1], r[2][0]:r[2][1]].abs().max()) == 0.0
+
+
+def test_uncertainty_head_set_vs_reference_golden():
+    """SURVEY a9's third head set: train_args.losses.uncertainty = 'gaussian' gives T1 / T2 / FLAIR / CT / bias_field_log /
+    high_res_residual a second channel (Trainer/models/__init__.py:57-111) and puts UncertaintyProcessor first
+    (joiner.py:238-241) -- which, looking for 'image' in the output names, never splits anything off, so the reference's
+    dict holds (1,2,D,H,W) tensors whose two channels both went through * 1000 / exp / + input.  Both call surfaces against
+    the reference's own outputs (infer_uncert.npz): the fused path (evaluate_image / forward_fused) and
+    model -> processors -> postprocessor."""
+    from argparse import Namespace
+    from brainfm_amd import test_utils as TU
+    d = load_npz("infer_uncert.npz")
+    f_maps, levels, groups = [int(v) for v in d["cfg"]]
+    ga, ta = TU.default_inference_args(f_maps=f_maps, num_levels=levels, num_groups=groups)
+    ta.losses.uncertainty = "gaussian"
+    s = TU.InferenceSession(ga, ta, _dev(), state_dict=sd_from_npz(d), passes=3)
+    assert ["%s=%d" % kv for kv in s.train_args.out_channels.items()] == list(d["out_channels"])
+    assert list(s.train_args.output_names) == list(d["output_names"])
+    assert list(s.train_args.aux_output_names) == list(d["aux_output_names"])
+    assert [type(p).__name__ for p in s.processors] == list(d["processors"])
+    x = torch.from_numpy(d["x"]).to(_dev())
+    out, _ = s.forward_fused(x)
+    _cmp_outputs(out, d)
+    assert _relerr(out["feat"][-1].cpu().numpy(), d["feat_last"]) <= TOL_NET
+    for k in ("T1", "CT", "bias_field", "high_res"):
+        assert tuple(out[k].shape) == (1, 2) + tuple(x.shape[2:]), (k, tuple(out[k].shape))
+    samples = [{"input": x}]
+    outs, _ = s.model(samples)
+    for p in s.processors:
+        outs = p(outs, samples)
+    outs, _, _ = s.postprocessor(s.gen_args, s.train_args, outs, samples, target=None, feats=None, tasks=s.gen_args.tasks)
+    _cmp_outputs(outs[0], d)
+
+
+def _cpu_threads():
+    import os
+    return max(1, min(64, len(os.sched_getaffinity(0))))
+
+
+def test_config1_feature_extraction_128():
+    """BASELINE config 1 (scripts/demo_get_feature.py:27-31,50-55): evaluate_image(...)['feat'][-1] of one 128^3 volume
+    through the shipped 64 x 6 net -- inputs as SURVEY 8(d) sets them (torch.manual_seed(0); torch.rand(1,1,128,128,128);
+    default nn init under manual_seed(1)) -- against the CPU oracle's feature map on this host.  Tolerance: the north
+    star's 1e-3 relative (measured ~2e-5)."""
+    from brainfm_amd import test_utils as TU
+    ga, ta = TU.default_inference_args(f_maps=64, num_levels=6)
+    torch.manual_seed(1)
+    s = TU.InferenceSession(ga, ta, _dev(), passes=3)
+    sd = {k: v.detach().cpu() for k, v in s.model.state_dict().items()}
+    torch.manual_seed(0)
+    x = torch.rand(1, 1, 128, 128, 128)
+    feat = s.evaluate(x.to(_dev()), feature_only=True)
+    assert tuple(feat.shape) == (1, 64, 128, 128, 128)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(_cpu_threads())
+    try:
+        with torch.no_grad():
+            ref = O.get_feature(x, sd, 1, 64, 6, 8, True)[-1]
+    finally:
+        torch.set_num_threads(prev)
+    got = feat.cpu()
+    err = float((got - ref).abs().max()) / float(ref.abs().max())
+    print("config 1: feat[-1] 128^3 max rel err %.2e" % err)
+    assert err <= 1e-3, err
+    nrm = got.double().pow(2).sum(1).sqrt()
+    assert float((nrm - 1).abs().max()) < 1e-5                      # unit_feat: F.normalize over the 64 channels
+
+
+def test_config2_single_160_volume_all_heads():
+    """BASELINE config 2: one 160^3 volume (seed 0), all 9 heads, as a stand-alone forward (utils/test_utils.py:289-312 ->
+    forward_fused), against the fp32 CPU oracle on this host.  Parity mode: every float output within 1e-3 relative
+    (measured 3e-5), labels equal except where the oracle's own two best probabilities are within 1e-5 of each other
+    (relative), at most 1e-4 of the voxels.  Fast mode (`passes=1`: plain fp16 products, the configuration's "bf16"
+    class): STATED tolerance 5e-2 relative on the float outputs (2^-11 products through 22 layers; measured ~1e-2), and
+    labels are not compared -- with random weights the 56-way softmax is nearly flat."""
+    from brainfm_amd import test_utils as TU
+    ga, ta = TU.default_inference_args(f_maps=64, num_levels=6)
+    torch.manual_seed(1)
+    s = TU.InferenceSession(ga, ta, _dev(), passes=3)
+    sd = {k: v.detach().cpu() for k, v in s.model.state_dict().items()}
+    torch.manual_seed(0)
+    x = torch.rand(1, 1, 160, 160, 160)
+    out, _ = s.forward_fused(x.to(_dev()), want_feat=False, want_seg=False)
+    prev = torch.get_num_threads()
+    torch.set_num_threads(_cpu_threads())
+    try:
+        with torch.no_grad():
+            ref = O.forward_all(x, sd, f_maps=64, num_levels=6)
+    finally:
+        torch.set_num_threads(prev)
+    keys = [k for k in ref if k not in ("feat", "segmentation", "label")]
+    assert len(keys) == 15 and all(k in out for k in keys)
+    errs = {k: float((out[k].cpu() - ref[k]).abs().max()) / max(1e-6, float(ref[k].abs().max())) for k in keys}
+    assert max(errs.values()) <= 1e-3, errs
+    lab = out["label"].cpu()
+    differ = lab != ref["label"]
+    nd = int(differ.sum())
+    top2 = torch.topk(ref["segmentation"], 2, dim=1).values
+    gap = ((top2[:, 0] - top2[:, 1]) / top2[:, 0])[:, None]
+    print("config 2 (parity): worst float err %.2e; %d of %d labels differ, largest oracle top-2 gap there %.2e"
+          % (max(errs.values()), nd, lab.numel(), float(gap[differ].max()) if nd else 0.0))
+    assert nd <= 1e-4 * lab.numel()
+    if nd:
+        assert float(gap[differ].max()) < 1e-5
+    del s, out
+    torch.cuda.empty_cache()
+    ga, ta = TU.default_inference_args(f_maps=64, num_levels=6)
+    s1 = TU.InferenceSession(ga, ta, _dev(), state_dict=sd, passes=1)
+    out1, _ = s1.forward_fused(x.to(_dev()), want_feat=False, want_seg=False)
+    errs1 = {k: float((out1[k].cpu() - ref[k]).abs().max()) / max(1e-6, float(ref[k].abs().max())) for k in keys}
+    print("config 2 (passes=1): worst float err %.2e" % max(errs1.values()))
+    assert max(errs1.values()) <= 5e-2, errs1
+    assert max(errs1.values()) > max(errs.values())                  # it IS the cheaper arithmetic
+
+
+def test_headline_shortcuts_change_no_bit_256(monkeypatch):
+    """The bench volume (256^3 ellipsoid, exact zeros outside), the shipped 64 x 6 net, the reference tiling's 27 tiles,
+    hipGraph replay on two lanes: the data-dependent shortcuts the headline number rests on -- the tile mask's skipped
+    boxes and head runs (scripts/demo_test.py:88-100 discards them), the uniform background boxes, the compact rows -- on
+    (the defaults) against off (BFM_MASK_SKIP=0 BFM_UNIFORM_SKIP=0 BFM_COMPACT=0): all 17 stitched keys torch.equal.
+    BFM_DEEP_UPFOLD / BFM_DEEP_BATCH stay at their defaults in both runs (they select other kernel variants, hence other
+    last bits)."""
+    import bench
+    from brainfm_amd import test_utils as TU
+    full = bench.make_volume(256, _dev())
+    atlas = bench.make_atlas()
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(TU, "COMPACT", on)
+        ga, ta = TU.default_inference_args(f_maps=64, num_levels=6)
+        torch.manual_seed(1)
+        s = TU.InferenceSession(ga, ta, _dev(), passes=3)
+        s.set_atlas(*atlas)
+        s.engine.mask_skip = on
+        s.engine.uniform_skip = on
+        assert s.lanes == 2
+        TU.prepare_tile_graphs(full, s, [80] * 3, [160] * 3)
+        acc, ranges, _ = TU.tiled_inference(full, s, [80] * 3, [160] * 3, graphs=True)
+        assert len(ranges) == 27
+        res[on] = {k: v.clone() for k, v in acc.items()}
+        del s, acc
+        torch.cuda.empty_cache()
+    assert len(res[True]) == 17 and list(res[True]) == list(res[False])
+    for k in res[True]:
+        assert torch.equal(res[True][k], res[False][k]), k
+    assert float(res[True]["T1"].abs().max()) > 0

@@ -321,3 +321,35 @@ def test_graph_inference_after_training_sees_the_new_weights():
         for k in eager:
             assert torch.equal(got[k], eager[k]), (k, rep)
     assert any(not torch.equal(before[k], eager[k]) for k in eager)
+
+
+def test_tile_loop_heads_follow_weights_that_grew_in_training():
+    """The tile loop's head pass (runs of 64 zero-input voxels skipped) scales the head weights into fp16 range by the
+    descriptor's max|w|.  Round 2 kept a private copy of the descriptor for that pass, made before training and never
+    refreshed: head weights that grow a hundredfold then overflow fp16 in the tile loop only.  One
+    descriptor now serves both; the tile loop on a one-tile volume must give forward_fused's maps."""
+    from brainfm_amd import test_utils as TU
+    from brainfm_amd import train as TR
+    from conftest import sd_from_npz
+    c = load_case()
+    ga, ta = TU.default_inference_args(f_maps=c["f_maps"], num_levels=c["levels"], left_hemis_only=True, num_groups=c["groups"])
+    s = TU.InferenceSession(ga, ta, _dev(), state_dict=sd_from_npz(c["d"]), passes=3)
+    step = TR.TrainStep(s.engine, s.model.head.tail(s.engine), c["loss_names"], c["loss_weights"], c["d"]["weights_ce"],
+                        c["all_samples"], lr=0.05)
+    g = torch.Generator().manual_seed(2)
+    vol = (torch.rand((1, 1, 16, 16, 64), generator=g) + 0.05).to(_dev())
+    vol[:, :, :, :, 40:] = 0                                            # runs of zero input: the skipping form is in use
+    TU.tiled_inference(vol, s, [16, 16, 64], [16, 16, 64], graphs=False)     # first tile pass, before the weights move
+    step.tail.head_w.mul_(100.0)
+    step._weights_changed()
+    tiled, ranges, _ = TU.tiled_inference(vol, s, [16, 16, 64], [16, 16, 64], graphs=False)
+    assert len(ranges) == 1
+    fused, _ = s.forward_fused(vol)
+    m = (vol[0, 0] != 0)
+    for k, v in tiled.items():
+        if k not in fused or k == "label":
+            continue
+        want = fused[k].reshape(m.shape) * m
+        assert bool(torch.isfinite(v).all()), k
+        err = float((v - want).abs().max()) / max(1e-6, float(want.abs().max()))
+        assert err <= 1e-4, (k, err)

@@ -119,3 +119,24 @@ def test_wide_net_all_outputs_and_tiled_stitch():
     assert len(keys) == 17 and list(st.keys()) == keys
     for k in keys:
         _close(st[k].numpy(), d["stitched/" + k], 5e-5)
+
+
+def test_uncertainty_head_set():
+    """`losses.uncertainty` (Trainer/models/__init__.py:57-111): two channels per regression head, both kept in one
+    tensor by the reference (its UncertaintyProcessor matches no output name) and post-processed together."""
+    d = load_npz("infer_uncert.npz")
+    f_maps, levels, groups = [int(v) for v in d["cfg"]]
+    assert list(d["processors"]) == ["UncertaintyProcessor", "SegProcessor", "DistProcessor"]
+    out = O.forward_all(torch.from_numpy(d["x"]), sd_from_npz(d), f_maps=f_maps, num_levels=levels, num_groups=groups,
+                        uncertainty=True)
+    keys = [k[4:] for k in d if k.startswith("out/")]
+    assert sorted(keys) == sorted(k for k in out if k != "feat")
+    for k in ("T1", "T2", "FLAIR", "CT", "bias_field", "high_res_residual", "high_res"):
+        assert out[k].shape[1] == 2 and d["out/" + k].shape[1] == 2
+    for k in keys:
+        assert tuple(out[k].shape) == d["out/" + k].shape, k
+        if k == "label":
+            assert np.array_equal(out[k].numpy(), d["out/label"])
+        else:
+            _close(out[k].numpy(), d["out/" + k])
+    _close(out["feat"][-1].numpy(), d["feat_last"])
