@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbrainfm_hip.so")
+# BFM_LIB_PATH: a diagnostic build of the same library (scripts/micro/w2_stamps.sh); never a fallback
+LIB_PATH = os.environ.get("BFM_LIB_PATH") or os.path.join(_HERE, "libbrainfm_hip.so")
 
 ERR = {0: "BFM_OK", -1: "BFM_E_ARG", -2: "BFM_E_SHAPE", -3: "BFM_E_WORKSPACE", -4: "BFM_E_LAUNCH"}
 
@@ -104,7 +105,8 @@ SIGNATURES = {
     "bfm_uniform_boxes_bytes": (_Z, [_I, _I, _I, _I]),
     "bfm_conv3x3x3_wino_uniform_scratch": (_Z, [_I]),
     "bfm_conv3x3x3_wino_uniform": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _P, _P, _P]),
-    "bfm_conv3x3x3_wino_masked": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _P]),
+    "bfm_conv3x3x3_wino_masked_workspace": (_Z, [_I, _I, _I, _I]),
+    "bfm_conv3x3x3_wino_masked": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
     "bfm_maxpool2_rows": (_I, [_I, _I, _I, _I]),
     "bfm_maxpool2_ex": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "bfm_grid_push3d_linear": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, C.POINTER(_I), _I, _P, _P]),

@@ -472,9 +472,11 @@ class UNetEngine:
         if mask_img is not None:
             if cfg[6] != 3 or cb or rows is not None:
                 raise L.BfmError("a masked launch is the one-source 4-wave Winograd kernel without moment rows")
+            nws = self.lib.bfm_conv3x3x3_wino_masked_workspace(D, H, W, self.passes)
+            mws = torch.empty(nws, dtype=torch.uint8, device=self.device)       # box activity, count, list of boxes
             L.check(self.lib.bfm_conv3x3x3_wino_masked(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
                                                        groups, L.ptr(ly.wpacked), ly.wexp, ly.cout, slope, self.passes,
-                                                       cfg[7] & 1, L.ptr(out), L.ptr(mask_img), st),
+                                                       cfg[7] & 1, L.ptr(out), L.ptr(mask_img), L.ptr(mws), nws, st),
                     "conv_wino(masked) " + ly.name)
             return
         if uni_flags is not None and cfg[6] == 3 and not cb:

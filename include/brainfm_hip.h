@@ -153,9 +153,13 @@ int bfm_conv3x3x3_wino_uniform(const float* A, int CA, int D, int H, int W, cons
                                int flags, float* out, void* moment_rows, const unsigned char* uniform_flags, void* scratch,
                                bfm_stream_t stream);
 int bfm_conv3x3x3_wino_box(int D, int H, int W, int passes, int* box /* [3]: the (d,h,w) box of output voxels per workgroup */);
+/* workspace: bfm_conv3x3x3_wino_masked_workspace(D, H, W, passes) bytes (4-byte aligned) for the per-box activity, the
+ * number of boxes that hold input and their list, built on the device ahead of the persistent launch that walks it. */
+size_t bfm_conv3x3x3_wino_masked_workspace(int D, int H, int W, int passes);
 int bfm_conv3x3x3_wino_masked(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                               const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
-                              int flags, float* out, const float* mask_image, bfm_stream_t stream);
+                              int flags, float* out, const float* mask_image, void* workspace, size_t workspace_bytes,
+                              bfm_stream_t stream);
 
 /* Output-moment rows.  A producer (conv3x3x3_mfma_ex / conv3x3x3_stem_ex) can write, next to its output, one row
  * per tile of per-channel {sum, sumsq} (fp64) and {min, max} (fp32) of the values it stored: buffer of
