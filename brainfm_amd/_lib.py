@@ -7,8 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# BFM_LIB_PATH: a diagnostic build of the same library (scripts/micro/w2_stamps.sh); never a fallback
-LIB_PATH = os.environ.get("BFM_LIB_PATH") or os.path.join(_HERE, "libbrainfm_hip.so")
+LIB_PATH = os.path.join(_HERE, "libbrainfm_hip.so")
 
 ERR = {0: "BFM_OK", -1: "BFM_E_ARG", -2: "BFM_E_SHAPE", -3: "BFM_E_WORKSPACE", -4: "BFM_E_LAUNCH"}
 

@@ -18,7 +18,6 @@
 // dequantises, optionally adds what `out` holds (accumulate mode, the skip half of an up-folded decoder conv),
 // applies LeakyReLU and stores 128-byte row segments.  Single-source inputs only (CB == 0), no split-K.
 #include "bfm_common.h"
-#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -52,11 +51,8 @@ struct WinoParams {
     const unsigned char* uni_flags;  // optional [nMt]: 0, or 1 + the class of a box whose operands equal its class mates'
     const int* uni_first;            // [27] first box of each class (>= nMt: none): the ones conv_wino_rest computes
     float* uni_acc;                  // [27][NT][2][16][NTHR][2]: those boxes' output-transformed sums, for their class mates
-    const int* list;                 // conv_wino2, sparse forms: the boxes to compute, ascending (nullptr: all nMt boxes)
+    const int* list;                 // sparse forms: the boxes to compute, ascending
     const int* list_n;               // ... their number, on the device
-    int lds_ring, lds_raw, lds_scsh; // conv_wino2: byte offsets of the weight ring, the moment-fold scratch, the scale/shift table
-    int dbg;                         // conv_wino2, timing experiments only (BFM_W2_DBG, results are wrong when set): 1 no
-                                     // transform arithmetic, 2 no activation loads, 4 no weight DMA, 16 no epilogue, 32 no tap barriers, 64 no start stagger
 };
 
 __device__ __forceinline__ int row_perm(int l) {        // as conv_mfma: each 16-lane b128 group reads 16 consecutive positions
@@ -117,7 +113,6 @@ __device__ __forceinline__ void split_store4(const float (&t)[4], unsigned char*
 // allocator spill 54 registers and the layer 25 % slower.
 template <int NPASS, int MODE>
 __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
-    constexpr bool MASKED = MODE == 1;
     constexpr bool UNI = MODE == 3;                      // this kernel computes the flagged boxes (one row block each)
     constexpr bool BY_FLAG = MODE == 2 || MODE == 3;
     constexpr int NPL = (NPASS == 3) ? 2 : 1;
@@ -125,53 +120,38 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
     constexpr int BATCH = (NPASS == 3) ? 1 : 3;      // staging items loaded together (register budget: 128 accumulators)
     constexpr int NSET = 3;                           // weight register sets: NSET-1 taps ahead
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    // One workgroup per (box, cout tile), XCD-aware bijective remap (neighbouring boxes share halo lines in one L2).  The
+    // sparse forms take their boxes from a list built on the device (wino_mask_list_kernel / uniform_lists_kernel): the
+    // grid still covers every box -- the host does not know the count, and a persistent loop over the list made the
+    // compiler spill 150 registers -- but a workgroup beyond the list reads one cached scalar and ends, where round 2's
+    // workgroups each loaded their box of the mask image (a memory round trip per round of 512 resident workgroups:
+    // conv_wino_rest took 18 ms of a step where its share of the dense launches is 12.5).
+    constexpr bool LIST = MODE != 0;
+    const int nblk = LIST ? p.list_n[0] * p.NT : p.nMt * p.NT;
+    const int bid = blockIdx.x;
+    if (LIST && bid >= nblk) return;                     // workgroup-uniform, before any barrier
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int pos = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = Winograd position 0..3
     const int l32 = lane & 31, khalf = lane >> 5;
-
-    int bid = blockIdx.x;
-    if constexpr (MASKED || BY_FLAG) {
-        // the boxes that hold input cluster in one part of the tile (a corner tile of a head volume: one octant), and one
-        // contiguous eighth per XCD would leave most XCDs idle: runs of 8 boxes go round the XCDs instead
-        const int nfull = (p.nMt * p.NT) & ~63;
-        if (bid < nfull) {
-            const int xcd = bid & 7, idx = bid >> 3;
-            bid = ((idx >> 3) << 6) + (xcd << 3) + (idx & 7);
-        }
-    } else {
-        const int nblk = p.nMt * p.NT;
+    int item;
+    {
         const int q = nblk >> 3, r = nblk & 7;
         const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int mt = bid / p.NT, nt = bid - mt * p.NT;
+    const int mt = LIST ? p.list[item / p.NT] : item / p.NT;
+    const int nt = item % p.NT;
     const int tx = mt % p.nTx;
     const int ty = (mt / p.nTx) % p.nTy;
     const int tz = mt / (p.nTx * p.nTy);
     const int z0 = tz * p.TD, y0 = ty * p.TH, x0 = tx * p.TW;
-    bool rep = false;                                    // conv_wino_rest: this is a flagged box it computes
+    // conv_wino_rest's list: the unflagged boxes and the first flagged box of every class (rep), which leaves its sums for
+    // its class mates; conv_wino_uniform's list: those mates
     int cls = 0;                                         // 1 + class of a flagged box
-    if constexpr (BY_FLAG) {                             // wave-uniform exits before any barrier
-        cls = __builtin_amdgcn_readfirstlane((int)p.uni_flags[mt]);
-        const bool flagged = cls != 0;
-        rep = flagged && mt == __builtin_amdgcn_readfirstlane(p.uni_first[flagged ? cls - 1 : 0]);
-        if (UNI ? (!flagged || rep) : (flagged && !rep)) return;
-    }
-
-    if constexpr (MASKED) {
-        // The caller multiplies this layer's consumers by (image != 0) (the tile loop, scripts/demo_test.py:88-100, and this
-        // is the last convolution before the per-voxel heads): outputs of a box whose image voxels are all zero are never
-        // looked at, so the box is not computed.  Uniform exit before the first barrier of the main loop.
-        bool nz = false;
-        const int thw = p.TH * p.TW;
-        for (int q = tid; q < p.TD * thw; q += NTHR) {
-            const int d = q / thw, r = q - d * thw, h = r / p.TW, w = r - h * p.TW;
-            const int gz = z0 + d, gy = y0 + h, gx = x0 + w;
-            if (gz < p.D && gy < p.H && gx < p.W) nz = nz || p.mask_img[((int64_t)gz * p.H + gy) * p.W + gx] != 0.f;
-        }
-        if (!__syncthreads_or(nz ? 1 : 0)) return;
-    }
+    if constexpr (BY_FLAG) cls = __builtin_amdgcn_readfirstlane((int)p.uni_flags[mt]);
+    const bool rep = MODE == 2 && cls != 0;
 
     float bmax = 0.f;
     for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, p.bound[g]);
@@ -246,7 +226,7 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
     fetch(1, wq[1]);
 
     auto do_chunk = [&](int kc, auto par_tag, auto mbn_tag) __attribute__((always_inline)) {
-        constexpr int PAR = decltype(par_tag)::value;
+        (void)par_tag;
         constexpr int MBN = decltype(mbn_tag)::value;      // row blocks multiplied: 4, or 1 for a uniform box
         const int c0 = kc * KC;
         const float* src = p.A + c0 + q4 * 4;
@@ -540,584 +520,10 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino_rest(const WinoParams p) { 
 template <int NPASS>
 __global__ void __launch_bounds__(NTHR, 2) conv_wino_uniform(const WinoParams p) { conv_wino_body<NPASS, 3>(p); }
 
-// ===============================================================================================================
-// conv_wino2: the same arithmetic (same products, same K order, same output transform) in a form built around what
-// round 2's counters said about conv_wino: its waves spent 34 % of their life parked on loads and barriers and 37 %
-// waiting for the matrix pipe while the vector ALU was busy 32 % of the time -- nothing overlapped.
-//
-//   * persistent: ONE 8-wave workgroup per CU walks a list of (box, cout tile) items, so a launch over a sparse set of
-//     boxes costs its work and nothing per skipped box;
-//   * waves 0-3 only multiply.  Each owns 32 pairs (one d-slice of the box) for ALL FOUR Winograd positions, so the
-//     output transform y0 = m0+m1+m2, y1 = m1-m2-m3 happens in the accumulators' own registers -- no LDS exchange, no
-//     second pass.  Their operand fragments are read one position ahead of the MFMAs that use them, across the tap
-//     barriers too; they issue no vector-memory instruction before the epilogue;
-//   * waves 4-7 only stage, one on every SIMD beside a multiplying wave, so the matrix pipe and the vector ALU of a SIMD
-//     run side by side without any hand interleaving.  They stream the weights of a tap (4 positions x 2 column blocks x
-//     hi/lo = 16 KiB, shared by the four multiplying waves) into a 4-slot LDS ring by LDS-DMA, three taps ahead (with one
-//     tap of lead the L2 round trip of 256 CUs asking for the same 16 KiB at once WAS the tap time); they load the NEXT
-//     K-chunk's activations into registers a whole chunk ahead (20 loads per thread in flight, addresses computed once per
-//     box); and they turn that chunk into transformed, split fp16 values while the current chunk is being multiplied
-//     (taps 4..8; the results wait in registers), so a chunk boundary is one barrier, 36 LDS stores per staging thread and
-//     another barrier.
-// LDS: planes 74 KB + weight ring 64 KB + moment fold 6 KB + scale/shift 1 KB = 145 KB of the CU's 160.
-// Every wave executes the same sequence of s_barrier: 1 (prologue) + per chunk 9 (taps) + 1 (planes free) + per item
-// 1 when moment rows are written.
-// ===============================================================================================================
-constexpr int W2_THR = 512;
-constexpr int W2_MAX_IT = 5;        // transform items per staging thread (npos_lds * 4 <= 5 * 256, as conv_wino)
-constexpr int W2_RING = 4;          // weight ring slots
-constexpr int W2_LEAD = 2;          // taps of lead of the weight stream: step g + W2_LEAD goes into the slot of step g - 2
-
-// One LDS-DMA instruction (global_load_lds_dwordx4: 64 lanes x 16 B -> LDS base + lane * 16) issued from inline
-// assembly, so that the compiler does not know about it.  With the builtin it does, and -- unable to tell which LDS bytes
-// a pending DMA writes -- it puts s_waitcnt vmcnt(0) ahead of every LDS read or write of the issuing wave and ahead of
-// every use of an ordinary load: the staging waves then drained their three taps of lead at every tap.  All waits for
-// these DMAs are the counted ones written out below.
-typedef __attribute__((address_space(3))) unsigned char w2_lds_byte;
-__device__ __forceinline__ void w2_dma16(const void* gsrc, const unsigned char* lds_dst) {
-    const unsigned a = (unsigned)(size_t)(w2_lds_byte*)lds_dst;          // wave-uniform
-    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(a) : "memory", "m0");
-}
-
-__device__ __forceinline__ void w2_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-
-#ifdef BFM_W2_STAMPS
-// diagnostic build only (scripts/micro/w2_stamps.sh): workgroup 0's wave 0 and wave 4 record the shader clock when they
-// arrive at and leave every barrier of their first items
-__device__ unsigned long long w2_stamps[2 * 2048];
-__device__ __forceinline__ void w2_stamp(int role, int& k) {
-    if (blockIdx.x == 0 && (threadIdx.x & 255) == 0 && k < 2048) w2_stamps[role * 2048 + k] = __builtin_amdgcn_s_memtime();
-    ++k;
-}
-#define W2_BARRIER(role, k) do { w2_stamp(role, k); w2_barrier(); w2_stamp(role, k); } while (0)
-#else
-#define W2_BARRIER(role, k) w2_barrier()
-#endif
-
-struct W2Item {                      // one (box, cout tile) of the work list
-    int mt, nt, z0, y0, x0;
-};
-
-__device__ __forceinline__ W2Item w2_item(const WinoParams& p, int idx) {
-    W2Item it;
-    if (p.list != nullptr) {                             // sparse forms: list of boxes, every cout tile of each
-        const int b = idx / p.NT;
-        it.nt = idx - b * p.NT;
-        it.mt = p.list[b];
-    } else {
-        it.mt = idx / p.NT;
-        it.nt = idx - it.mt * p.NT;
-    }
-    const int tx = it.mt % p.nTx;
-    const int ty = (it.mt / p.nTx) % p.nTy;
-    const int tz = it.mt / (p.nTx * p.nTy);
-    it.z0 = tz * p.TD; it.y0 = ty * p.TH; it.x0 = tx * p.TW;
-    return it;
-}
-
-// The epilogue on one wave's 32 pairs x 64 columns, shared by conv_wino2 (values from the accumulators) and
-// conv_wino2_uniform (values another box left in uni_acc): accumulate mode, activation, store, moment partials.
-// y index nb * 16 + i: thread (wave, lane) holds column nb*32 + l32 of rows (i&3) + 8 (i>>2) + 4 khalf of its slice.
-// Executes ONE barrier when p.rsum is set (the caller's other waves must match it).
-// Everything that is loaded (accumulate mode) is loaded before the first store: vector-memory operations retire in
-// order, so a load behind a store -- or a register spilled to scratch -- would wait for every store before it.
-template <bool WRITE_Y>
-__device__ __forceinline__ void w2_store(const WinoParams& p, const W2Item& it, int wave, int l32, int khalf, int tid,
-                                         float (&y0)[32], float (&y1)[32], float2* ybuf, unsigned char* scratch) {
-    const bool interior = it.z0 + p.TD <= p.D && it.y0 + p.TH <= p.H && it.x0 + p.TW <= p.W;      // wave-uniform
-    float fs[2] = {0.f, 0.f}, fq[2] = {0.f, 0.f}, fmn[2] = {INFINITY, INFINITY}, fmx[2] = {-INFINITY, -INFINITY};
-    float* const ob = p.out + it.nt * 64 + l32;
-    // The row -> voxel arithmetic below is a dozen integer operations per row; left alone the compiler hoists its
-    // box-independent part out of the item loop (48 values per thread), spills it, and reloads it from scratch between
-    // the stores -- and a scratch load waits for every store issued before it.  An opaque copy of the lane's k-half keeps
-    // the arithmetic where it is.
-    int kh = khalf;
-    asm volatile("" : "+v"(kh));
-    // row i of this lane -> its pair's first voxel, and whether the pair's voxels exist (bit 0 / bit 1)
-    auto row = [&](int i, unsigned& ok) __attribute__((always_inline)) {
-        const int m = (i & 3) + 8 * (i >> 2) + 4 * kh;
-        int d, h, j;
-        pair_coords(p, wave * 32 + row_perm(m), d, h, j);
-        const int gz = it.z0 + d, gy = it.y0 + h, gx = it.x0 + 2 * j;
-        const bool ok0 = interior || (gz < p.D && gy < p.H && gx < p.W);
-        ok = (ok0 ? 1u : 0u) | ((interior || (ok0 && gx + 1 < p.W)) ? 2u : 0u);
-        return ((gz * p.H + gy) * p.W + gx) * p.Cout;
-    };
-    if (WRITE_Y) {
-#pragma unroll
-        for (int k = 0; k < 32; ++k) ybuf[k * NTHR] = make_float2(y0[k], y1[k]);
-    }
-    if (p.accum) {                                       // y += what `out` holds: all loads ahead of the first store
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            unsigned ok;
-            const float* o = ob + row(i, ok);
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const float a = (ok & 1) ? o[nb * 32] : 0.f, b = (ok & 2) ? o[p.Cout + nb * 32] : 0.f;
-                y0[nb * 16 + i] += a;
-                y1[nb * 16 + i] += b;
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        unsigned ok;
-        float* o = ob + row(i, ok);
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            float a = y0[nb * 16 + i], b = y1[nb * 16 + i];
-            if (ok & 1) {
-                a = a >= 0.f ? a : a * p.slope;
-                o[nb * 32] = a;
-                fs[nb] += a; fq[nb] = fmaf(a, a, fq[nb]); fmn[nb] = fminf(fmn[nb], a); fmx[nb] = fmaxf(fmx[nb], a);
-            }
-            if (ok & 2) {
-                b = b >= 0.f ? b : b * p.slope;
-                o[p.Cout + nb * 32] = b;
-                fs[nb] += b; fq[nb] = fmaf(b, b, fq[nb]); fmn[nb] = fminf(fmn[nb], b); fmx[nb] = fmaxf(fmx[nb], b);
-            }
-        }
-    }
-    if (p.rsum != nullptr) {
-        // moment row of this box: the two k-halves of a column meet by shuffle, the four waves in LDS (fixed order)
-        double* ls = reinterpret_cast<double*>(scratch);          // [4 waves][64 columns]
-        double* lq = ls + 256;
-        float* lmn = reinterpret_cast<float*>(lq + 256);
-        float* lmx = lmn + 256;
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            double sd = (double)fs[nb], qd = (double)fq[nb];
-            sd += __shfl_xor(sd, 32);
-            qd += __shfl_xor(qd, 32);
-            const float mn = fminf(fmn[nb], __shfl_xor(fmn[nb], 32)), mx = fmaxf(fmx[nb], __shfl_xor(fmx[nb], 32));
-            if (khalf == 0) {
-                const int c = wave * 64 + nb * 32 + l32;
-                ls[c] = sd; lq[c] = qd; lmn[c] = mn; lmx[c] = mx;
-            }
-        }
-        w2_barrier();
-        if (tid < 64) {
-            double S = 0.0, Q = 0.0;
-            float MN = INFINITY, MX = -INFINITY;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                S += ls[w * 64 + tid]; Q += lq[w * 64 + tid];
-                MN = fminf(MN, lmn[w * 64 + tid]); MX = fmaxf(MX, lmx[w * 64 + tid]);
-            }
-            const size_t o = (size_t)it.mt * p.Cout + it.nt * 64 + tid;
-            p.rsum[o] = S; p.rsq[o] = Q; p.rmn[o] = MN; p.rmx[o] = MX;
-        }
-    }
-}
-
-// MODE 0: every box.  1: the boxes of p.list (conv_wino_masked's job: boxes that hold input).  2: the boxes of p.list
-// (unflagged boxes and the first flagged box of every class, which also leaves its sums in uni_acc).
-template <int NPASS, int MODE>
-__global__ void __launch_bounds__(W2_THR, 2) conv_wino2(const WinoParams p) {
-    constexpr int NPL = (NPASS == 3) ? 2 : 1;
-    constexpr int NF = 2 * NPL;                          // weight fragments per position and tap = DMA instructions per wave
-    constexpr int SLOT = 4 * NF * 1024;                  // one tap of weights: [pos][nb][hl][lane] x 16 B
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool stager = wave8 >= 4;                      // waves 4-7 stage, waves 0-3 multiply
-    const int wave = wave8 & 3;                          // d-slice of a multiplying wave / position + DMA share of a staging wave
-    unsigned char* const ring = lds + p.lds_ring;
-    unsigned char* const fold = lds + p.lds_raw;         // 6 KB for the moment fold of an item's epilogue
-    float* const scsh = reinterpret_cast<float*>(lds + p.lds_scsh);          // [2][CA]: scale, shift (x 2^aexp)
-
-    // ---- this workgroup's share of the list: the XCD label (block % 8) owns a contiguous eighth, its 32-odd
-    // workgroups walk it side by side (neighbouring boxes share halo lines in that XCD's L2)
-    const int n_items = (p.list_n != nullptr ? p.list_n[0] : p.nMt) * p.NT;
-    const int nwg = gridDim.x;
-    const int nlab = nwg < 8 ? nwg : 8;                  // labels in use (a grid of fewer than 8 workgroups: one each)
-    const int xcd = blockIdx.x % nlab, li = blockIdx.x / nlab;
-    const int per_x = (nwg + nlab - 1 - xcd) / nlab;     // workgroups with this label
-    const int lo = (int)((int64_t)n_items * xcd / nlab), hi = (int)((int64_t)n_items * (xcd + 1) / nlab);
-    int cur_idx = lo + li;
-    if (cur_idx >= hi) return;                           // workgroup-uniform, before any barrier
-    // Every workgroup's items take the same time, so left alone all 256 CUs store their 64 KB of results in the same few
-    // microseconds (and stall on it) and fetch in the same ones: the workgroups of a label start up to 7/8 of an item
-    // apart instead.  s_sleep 127 = 8 128 cycles; the other waves wait at the prologue barrier.
-    if (!(p.dbg & 64)) {
-        const int steps = (li & 7) * (p.KCN > 4 ? 2 : 1);
-        for (int k = 0; k < steps; ++k) __builtin_amdgcn_s_sleep(127);
-    }
-
-    float bmax = 0.f;
-    for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, p.bound[g]);
-    int aexp = 0;
-    if (bmax > 0.f && bmax < INFINITY) {
-        int ex;
-        (void)frexpf(bmax, &ex);
-        aexp = 13 - ex;                                            // |V| <= 2 * bound
-        aexp = aexp > 60 ? 60 : (aexp < -60 ? -60 : aexp);
-    }
-    const float a_scale = ldexpf(1.0f, aexp);
-    const float dq = ldexpf(1.0f, -(aexp + p.wexp));
-    for (int c = tid; c < p.CA; c += W2_THR) {
-        scsh[c] = p.scale[c] * a_scale;
-        scsh[p.CA + c] = p.shift[c] * a_scale;
-    }
-    const int S9 = p.KCN * 9;
-    const int pos_stride = 2 * NPL * p.plane_stride;
-
-    if (stager) {
-        // ===================================== staging waves =====================================
-        int sk = 0; (void)sk;
-        const int ht = tid - 256;                        // 0..255
-        const int q4 = ht & 3;
-        const int n_el = p.npos_lds * 4;
-        int it_dst[W2_MAX_IT], it_c[W2_MAX_IT];          // plane write offset, (hz, hy, j)
-        bool it_ok[W2_MAX_IT];
-#pragma unroll
-        for (int it = 0; it < W2_MAX_IT; ++it) {
-            const int e = ht + it * 256;
-            it_ok[it] = e < n_el;
-            const int ps = it_ok[it] ? (e >> 2) : 0;     // a thread without this item computes item 0 again and drops it
-            const int j = ps & ((1 << p.pw_shift) - 1);
-            const int r = ps >> p.pw_shift;
-            const int hz = r / p.HT, hy = r - hz * p.HT;
-            it_dst[it] = ((q4 >> 1) * NPL) * p.plane_stride + (q4 & 1) * 8 + ps * 16;
-            it_c[it] = hz | (hy << 8) | (j << 16);
-        }
-        // the item whose chunk is being fetched ("pf", one step ahead of the one being multiplied).  A position outside the
-        // volume loads from some valid address and the mask drops the value: every thread issues the same 20 loads (the
-        // DMA counts below rely on it)
-        int msk[W2_MAX_IT];                              // bit i: x position i of the item's run is inside the volume
-        int xbase[W2_MAX_IT];                            // element offset of x position 0 (may lie outside: see msk)
-        auto prepare = [&](const W2Item& w) {
-#pragma unroll
-            for (int it = 0; it < W2_MAX_IT; ++it) {
-                const int hz = it_c[it] & 255, hy = (it_c[it] >> 8) & 255, j = it_c[it] >> 16;
-                const int gz = w.z0 + hz - 1, gy = w.y0 + hy - 1, gx = w.x0 + 2 * j - 1;
-                const bool row_ok = gz >= 0 && gz < p.D && gy >= 0 && gy < p.H;
-                int m = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (row_ok && gx + i >= 0 && gx + i < p.W) m |= 1 << i;
-                msk[it] = m;
-                xbase[it] = ((gz * p.H + gy) * p.W + gx) * p.CA + q4 * 4;
-            }
-        };
-        float4 rawv[W2_MAX_IT][4];                       // the chunk being prepared, as loaded
-        auto issue_raw = [&](int kc) __attribute__((always_inline)) {
-            const float* src = p.A + kc * KC;
-#pragma unroll
-            for (int it = 0; it < W2_MAX_IT; ++it)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int off = (msk[it] >> i) & 1 ? xbase[it] + i * p.CA : q4 * 4;
-                    rawv[it][i] = *reinterpret_cast<const float4*>(src + off);
-                }
-        };
-        // weights of stream step s of cout tile nt: position `wave`'s NF fragments -> a ring slot
-        auto issue_w = [&](int nt, int s, int slot) {
-            const uint4* src = p.wp + ((size_t)(nt * 4 + wave) * S9 + s) * (NF * 64) + lane;
-#pragma unroll
-            for (int f = 0; f < NF; ++f) w2_dma16(src + f * 64, ring + slot * SLOT + (wave * NF + f) * 1024);
-        };
-        // transformed, split values of the chunk being prepared: [item][position] (hi, lo) x 4 channels
-        uint2 trh[W2_MAX_IT][4], trl[W2_MAX_IT][4];
-        auto transform = [&](int it, int kc) __attribute__((always_inline)) {
-            const float4 sc4 = *reinterpret_cast<const float4*>(scsh + kc * KC + q4 * 4);
-            const float4 sh4 = *reinterpret_cast<const float4*>(scsh + p.CA + kc * KC + q4 * 4);
-            const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
-            float dd[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool ok = msk[it] & (1 << i);
-                const float y[4] = {rawv[it][i].x, rawv[it][i].y, rawv[it][i].z, rawv[it][i].w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c) dd[i][c] = ok ? fmaf(y[c], sc[c], sh[c]) : 0.f;     // zero padding after the affine
-            }
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                float t[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    t[c] = ps == 0 ? dd[0][c] - dd[2][c]
-                         : ps == 1 ? dd[1][c] + dd[2][c]
-                         : ps == 2 ? dd[2][c] - dd[1][c]
-                                   : dd[1][c] - dd[3][c];
-                const fp16x2_t h01 = __builtin_amdgcn_cvt_pkrtz(t[0], t[1]);
-                const fp16x2_t h23 = __builtin_amdgcn_cvt_pkrtz(t[2], t[3]);
-                trh[it][ps].x = __builtin_bit_cast(unsigned, h01);
-                trh[it][ps].y = __builtin_bit_cast(unsigned, h23);
-                if constexpr (NPASS == 3) {
-                    const fp16x2_t l01 = __builtin_amdgcn_cvt_pkrtz(t[0] - (float)h01[0], t[1] - (float)h01[1]);
-                    const fp16x2_t l23 = __builtin_amdgcn_cvt_pkrtz(t[2] - (float)h23[0], t[3] - (float)h23[1]);
-                    trl[it][ps].x = __builtin_bit_cast(unsigned, l01);
-                    trl[it][ps].y = __builtin_bit_cast(unsigned, l23);
-                }
-            }
-        };
-        auto write_planes = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int it = 0; it < W2_MAX_IT; ++it) {
-                if (!it_ok[it]) continue;
-#pragma unroll
-                for (int ps = 0; ps < 4; ++ps) {
-                    unsigned char* dp = lds + it_dst[it] + ps * pos_stride;
-                    *reinterpret_cast<uint2*>(dp) = trh[it][ps];
-                    if constexpr (NPASS == 3) *reinterpret_cast<uint2*>(dp + p.plane_stride) = trl[it][ps];
-                }
-            }
-        };
-
-        // ---- prologue: the first item's chunk 0 goes through the same steps without anything to hide behind
-        W2Item cur = w2_item(p, cur_idx);
-        prepare(cur);
-        issue_raw(0);
-#pragma unroll
-        for (int s0 = 0; s0 < W2_LEAD; ++s0) issue_w(cur.nt, s0 < S9 ? s0 : S9 - 1, s0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        W2_BARRIER(1, sk);                                    // [prologue barrier] scale / shift table visible
-#pragma unroll
-        for (int it = 0; it < W2_MAX_IT; ++it) transform(it, 0);
-        write_planes();
-
-        int g = 0;                                       // stream steps multiplied so far (ring slot of a step = g % W2_RING)
-        while (true) {
-            const int next_idx = cur_idx + per_x;        // the label's workgroups stride its eighth side by side
-            const bool has_next = next_idx < hi;
-            W2Item nxt = cur;
-            if (has_next) nxt = w2_item(p, next_idx);
-            for (int kc = 0; kc < p.KCN; ++kc) {
-                const bool last_chunk = kc + 1 == p.KCN;
-                // what this chunk's taps prepare: the item's next chunk, or the next item's first one (the last step of
-                // all reloads its own data so that the counts below stay the same)
-                const int pf_kc = last_chunk ? 0 : kc + 1;
-                if (last_chunk) prepare(nxt);
-                auto tap = [&](auto t_tag) __attribute__((always_inline)) {
-                    constexpr int t = decltype(t_tag)::value;
-                    // This wave's DMAs of step g, issued W2_LEAD taps ago, have landed.  Younger than them at this point:
-                    // the steps behind them, and -- taps 1 .. W2_LEAD-1 -- the chunk's 20 activation loads, issued at tap 0
-                    // AHEAD of step g+W2_LEAD's DMAs (vector-memory operations retire in order: tap W2_LEAD's wait
-                    // retires them).
-                    constexpr int younger = (W2_LEAD - 1) * NF + ((t >= 1 && t < W2_LEAD) ? 4 * W2_MAX_IT : 0);
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger) : "memory");
-                    if (!(p.dbg & 32)) W2_BARRIER(1, sk);     // everyone's landed; the slot of step g-2 is free
-                    // taps 4..8: one item each of the chunk being prepared, AHEAD of this tap's DMAs: whatever the
-                    // compiler waits for before the first use of a loaded register is then at least a tap old
-                    if constexpr (t >= 4 && t - 4 < W2_MAX_IT) { if (!(p.dbg & 1)) transform(t - 4, pf_kc); }
-                    if (t == 0 && !(p.dbg & 2)) issue_raw(pf_kc);
-                    {
-                        // step g+W2_LEAD of the weight stream, into the slot of step g-2 (the multiplying waves passed this
-                        // barrier, so every MFMA fed from that slot has been issued): this item's, or the next item's
-                        // (past the end: a harmless reload)
-                        int s = kc * 9 + t + W2_LEAD, nt2 = cur.nt;
-                        if (s >= S9) { s -= S9; nt2 = nxt.nt; }
-                        if (!(p.dbg & 4)) issue_w(nt2, s, (g + W2_LEAD) % W2_RING);
-                    }
-                    ++g;
-                };
-                tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{});
-                tap(std::integral_constant<int, 2>{}); tap(std::integral_constant<int, 3>{});
-                tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
-                tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{});
-                tap(std::integral_constant<int, 8>{});
-                W2_BARRIER(1, sk);                            // [planes free] the multiplying waves are done with this chunk
-                write_planes();                          // made visible by the next tap 0's barrier
-            }
-            if (p.rsum != nullptr) W2_BARRIER(1, sk);         // [moment fold] matches w2_store's
-            if (!has_next) break;
-            cur = nxt;
-            cur_idx = next_idx;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // drain the run-ahead DMAs before the LDS is released
-        return;
-    }
-
-    // ========================================= multiplying waves =========================================
-    int sk = 0; (void)sk;
-    __builtin_amdgcn_s_setprio(3);                       // the staging wave of this SIMD takes the issue slots this one leaves
-    const int l32 = lane & 31, khalf = lane >> 5;
-    int a_base;                                          // A fragment of this lane's row, position 0, tap (0,0)
-    {
-        int d, h, j;
-        pair_coords(p, wave * 32 + row_perm(l32), d, h, j);
-        a_base = (khalf * NPL) * p.plane_stride + ((d * p.HT + h) * p.PW + j) * 16;
-    }
-    struct Frag { half8 a[NPL]; half8 b[2][NPL]; };
-    auto load = [&](Frag& f, int ps, int toff, const unsigned char* bs) __attribute__((always_inline)) {
-#pragma unroll
-        for (int hl = 0; hl < NPL; ++hl)
-            f.a[hl] = *reinterpret_cast<const half8*>(lds + a_base + ps * pos_stride + hl * p.plane_stride + toff);
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int hl = 0; hl < NPL; ++hl)
-                f.b[nb][hl] = *reinterpret_cast<const half8*>(bs + ((ps * 2 + nb) * NPL + hl) * 1024);
-    };
-    floatx16 acc[4][2];
-    auto mult = [&](const Frag& f, auto ps_tag) __attribute__((always_inline)) {
-        constexpr int ps = decltype(ps_tag)::value;
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            if constexpr (NPASS == 3) {
-                acc[ps][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[1], f.b[nb][0], acc[ps][nb], 0, 0, 0);
-                acc[ps][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[0], f.b[nb][1], acc[ps][nb], 0, 0, 0);
-            }
-            acc[ps][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[0], f.b[nb][0], acc[ps][nb], 0, 0, 0);
-        }
-    };
-    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
-    using P2 = std::integral_constant<int, 2>; using P3 = std::integral_constant<int, 3>;
-
-    W2Item cur = w2_item(p, cur_idx);
-    W2_BARRIER(0, sk);                                        // [prologue barrier]
-    int g = 0;
-    Frag f0, f1, f2;                                     // three operand sets: one being multiplied, two being read
-    // group n = 4 * tap + position of a chunk uses set n % 3 (36 groups per chunk: the pattern repeats every chunk)
-    auto ld = [&](auto n_tag, int toff, const unsigned char* bs) __attribute__((always_inline)) {
-        constexpr int n = decltype(n_tag)::value;
-        if constexpr (n % 3 == 0) load(f0, n & 3, toff, bs);
-        else if constexpr (n % 3 == 1) load(f1, n & 3, toff, bs);
-        else load(f2, n & 3, toff, bs);
-    };
-    auto mu = [&](auto n_tag) __attribute__((always_inline)) {
-        constexpr int n = decltype(n_tag)::value;          // 0..35
-        using PS = std::integral_constant<int, n & 3>;
-        if constexpr (n % 3 == 0) mult(f0, PS{});
-        else if constexpr (n % 3 == 1) mult(f1, PS{});
-        else mult(f2, PS{});
-    };
-    // One operand read behind every MFMA.  A wave issues in order and an MFMA waits at issue for the pipe, so six reads in
-    // a row after six MFMAs leave the pipe idle while they are issued (a SIMD takes a ds_read_b128 every ~28 cycles:
-    // measured, 24 reads alone = 700 cycles per tap), and the tap took MFMA time PLUS read time: 1 500 cycles for 768.
-    auto pair6 = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < 2 * NPL + 2; ++k) {            // reads of one position: NPL (A) + 2 NPL (B)... at most 6
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
-        }
-    };
-    {
-        // an item's first tap multiplies "the previous tap's" positions 2 and 3 like every other tap (one copy of the
-        // chunk's code: the kernel is 60 KB, and code that runs once per item is fetched at a third of the speed the
-        // MFMAs need): their A operands are zeroed at the start of an item, these B operands once (finite)
-        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int hl = 0; hl < NPL; ++hl) { f0.b[nb][hl] = z; f1.b[nb][hl] = z; f2.b[nb][hl] = z; }
-    }
-    while (true) {
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[ps][nb][i] = 0.f;
-        {
-            const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};      // sets 34 % 3 = 1 and 35 % 3 = 2: nothing pending
-#pragma unroll
-            for (int hl = 0; hl < NPL; ++hl) { f1.a[hl] = z; f2.a[hl] = z; }
-        }
-        const int next_idx = cur_idx + per_x;
-        const bool has_next = next_idx < hi;
-        for (int kc = 0; kc < p.KCN; ++kc) {
-            // Per tap: barrier -> read position 0 -> multiply the PREVIOUS tap's position 2 -> read 1 -> multiply the
-            // previous tap's 3 -> read 2 -> multiply 0 -> read 3 -> multiply 1.  Every read is two positions (12 MFMAs,
-            // ~400 cycles) ahead of its MFMAs -- the four waves' bursts of 6 KB each take the LDS ~200 cycles to serve, and
-            // a single multiplying wave per SIMD has nobody to hide that behind -- and all reads of a tap come after its
-            // barrier; the operands a barrier is passed with are in registers.
-            auto tap = [&](auto t_tag) __attribute__((always_inline)) {
-                constexpr int t = decltype(t_tag)::value;
-                constexpr int kd = t / 3, kh = t - kd * 3;
-                constexpr int n0 = 4 * t;
-                constexpr int p2 = (n0 + 34) % 36, p3 = (n0 + 35) % 36;      // the previous tap's positions 2 and 3 (tap 0: the
-                                                                            // previous chunk's tap 8; 36 % 3 == 0: same sets)
-                // this tap's weights are in slot g % W2_RING (and, t == 0, the planes written).  No wait for this wave's own
-                // LDS reads: the slot the staging waves refill behind this barrier is step g-2's, whose reads fed MFMAs
-                // this wave has already issued; the planes are protected by the chunk's last barrier.
-#ifdef BFM_W2_STAMPS
-                w2_stamp(0, sk);
-#endif
-                if (!(p.dbg & 32)) __builtin_amdgcn_s_barrier();
-#ifdef BFM_W2_STAMPS
-                w2_stamp(0, sk);
-#endif
-                const unsigned char* bs = ring + (g % W2_RING) * SLOT + lane * 16;
-                const int toff = (kd * p.HT + kh) * p.PW * 16;
-                ld(std::integral_constant<int, n0>{}, toff, bs);     mu(std::integral_constant<int, p2>{});  pair6();
-                ld(std::integral_constant<int, n0 + 1>{}, toff, bs); mu(std::integral_constant<int, p3>{});  pair6();
-                ld(std::integral_constant<int, n0 + 2>{}, toff, bs); mu(std::integral_constant<int, n0>{});      pair6();
-                ld(std::integral_constant<int, n0 + 3>{}, toff, bs); mu(std::integral_constant<int, n0 + 1>{});  pair6();
-                ++g;
-            };
-            tap(std::integral_constant<int, 0>{}); tap(std::integral_constant<int, 1>{});
-            tap(std::integral_constant<int, 2>{}); tap(std::integral_constant<int, 3>{});
-            tap(std::integral_constant<int, 4>{}); tap(std::integral_constant<int, 5>{});
-            tap(std::integral_constant<int, 6>{}); tap(std::integral_constant<int, 7>{});
-            tap(std::integral_constant<int, 8>{});
-            W2_BARRIER(0, sk);                                // [planes free] tap 8's positions 2 and 3 are in registers
-        }
-        mu(std::integral_constant<int, 34>{});           // the item's last products: tap 8, positions 2 and 3
-        mu(std::integral_constant<int, 35>{});
-
-        // ---- epilogue of the item: output transform in the accumulators' registers
-        float y0[32], y1[32];                            // in the place of the accumulators: 128 registers become 64
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float m0 = acc[0][nb][i], m1 = acc[1][nb][i], m2 = acc[2][nb][i], m3 = acc[3][nb][i];
-                y0[nb * 16 + i] = ((m0 + m1) + m2) * dq;
-                y1[nb * 16 + i] = ((m1 - m2) - m3) * dq;
-            }
-        __builtin_amdgcn_sched_barrier(0);
-        bool rep = false;
-        float2* ybuf = nullptr;
-        if constexpr (MODE == 2) {
-            const int cls = __builtin_amdgcn_readfirstlane((int)p.uni_flags[cur.mt]);
-            rep = cls != 0;                              // a flagged box on this list is its class's first
-            if (rep) ybuf = reinterpret_cast<float2*>(p.uni_acc) + ((size_t)(cls - 1) * p.NT + cur.nt) * (2 * 16 * NTHR) + tid;
-        }
-        if (p.dbg & 16) { if (p.rsum != nullptr) W2_BARRIER(0, sk); }
-        else if (MODE == 2 && rep) w2_store<true>(p, cur, wave, l32, khalf, tid, y0, y1, ybuf, fold);
-        else w2_store<false>(p, cur, wave, l32, khalf, tid, y0, y1, nullptr, fold);
-
-        if (!has_next) break;
-        cur_idx = next_idx;
-        cur = w2_item(p, cur_idx);
-    }
-}
-
-// the flagged boxes that are not their class's first: the class's sums (uni_acc) through the same epilogue
-template <int NPASS>
-__global__ void __launch_bounds__(NTHR, 2) conv_wino2_uniform(const WinoParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l32 = lane & 31, khalf = lane >> 5;
-    const int n_items = p.list_n[0] * p.NT;
-    for (int idx = blockIdx.x; idx < n_items; idx += gridDim.x) {
-        const W2Item it = w2_item(p, idx);
-        const int cls = __builtin_amdgcn_readfirstlane((int)p.uni_flags[it.mt]);
-        const float2* ybuf = reinterpret_cast<const float2*>(p.uni_acc) + ((size_t)(cls - 1) * p.NT + it.nt) * (2 * 16 * NTHR) + tid;
-        float y0[32], y1[32];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) {
-            const float2 yy = ybuf[k * NTHR];
-            y0[k] = yy.x; y1[k] = yy.y;
-        }
-        if (p.rsum != nullptr) __syncthreads();          // the previous item's fold has been read
-        w2_store<false>(p, it, wave, l32, khalf, tid, y0, y1, nullptr, lds);
-    }
-}
-
 // Work lists for the sparse forms: list[] = the boxes with pred(box), ascending; returns their number (thread 0's value
 // is the total).  One workgroup of 1024 threads; `sh` = 17 ints of LDS.
 template <class Pred>
-__device__ __forceinline__ int w2_compact(int nMt, Pred pred, int* __restrict__ list, int* sh) {
+__device__ __forceinline__ int wino_compact(int nMt, Pred pred, int* __restrict__ list, int* sh) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) sh[16] = 0;
     __syncthreads();
@@ -1143,7 +549,7 @@ __device__ __forceinline__ int w2_compact(int nMt, Pred pred, int* __restrict__ 
 }
 
 // act[box] = 1 when a voxel of the box is non-zero in the (D,H,W) image (NaN counts); one wave per box
-__global__ void __launch_bounds__(256) wino2_box_active_kernel(const float* __restrict__ img, int D, int H, int W, int TD,
+__global__ void __launch_bounds__(256) wino_box_active_kernel(const float* __restrict__ img, int D, int H, int W, int TD,
                                                                int TH, int TW, int nTy, int nTx, int nMt,
                                                                unsigned char* __restrict__ act) {
     const int mt = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1161,10 +567,10 @@ __global__ void __launch_bounds__(256) wino2_box_active_kernel(const float* __re
     if (lane == 0) act[mt] = any ? 1 : 0;
 }
 
-__global__ void __launch_bounds__(1024) wino2_mask_list_kernel(const unsigned char* __restrict__ act, int nMt,
+__global__ void __launch_bounds__(1024) wino_mask_list_kernel(const unsigned char* __restrict__ act, int nMt,
                                                                int* __restrict__ list, int* __restrict__ n_out) {
     __shared__ int sh[17];
-    const int n = w2_compact(nMt, [&](int mt) { return act[mt] != 0; }, list, sh);
+    const int n = wino_compact(nMt, [&](int mt) { return act[mt] != 0; }, list, sh);
     if (threadIdx.x == 0) n_out[0] = n;
 }
 
@@ -1204,8 +610,8 @@ __global__ void __launch_bounds__(256) uniform_boxes_kernel(const float* __restr
 }
 
 // first[c] = index of the first box of class c (n: none), and the two work lists of the pair of launches that uses the
-// flags: cnt[0], rest[] = the unflagged boxes and every class's first flagged box (conv_wino2<.., 2>: computed in full);
-// cnt[1], uni[] = the other flagged boxes (conv_wino2_uniform: their class's sums through the epilogue).  One workgroup.
+// flags: cnt[0], rest[] = the unflagged boxes and every class's first flagged box (conv_wino_rest: computed in full);
+// cnt[1], uni[] = the other flagged boxes (conv_wino_uniform: their class's sums through the epilogue).  One workgroup.
 __global__ void __launch_bounds__(1024) uniform_lists_kernel(const unsigned char* __restrict__ flags, int n,
                                                              int* __restrict__ first, int* __restrict__ cnt,
                                                              int* __restrict__ rest, int* __restrict__ uni) {
@@ -1219,10 +625,10 @@ __global__ void __launch_bounds__(1024) uniform_lists_kernel(const unsigned char
     }
     __syncthreads();
     if (threadIdx.x < 27) first[threadIdx.x] = fst[threadIdx.x];
-    const int n0 = w2_compact(n, [&](int mt) { const int f = flags[mt]; return f == 0 || fst[f - 1] == mt; }, rest, sh);
+    const int n0 = wino_compact(n, [&](int mt) { const int f = flags[mt]; return f == 0 || fst[f - 1] == mt; }, rest, sh);
     if (threadIdx.x == 0) cnt[0] = n0;
     __syncthreads();
-    const int n1 = w2_compact(n, [&](int mt) { const int f = flags[mt]; return f != 0 && fst[f - 1] != mt; }, uni, sh);
+    const int n1 = wino_compact(n, [&](int mt) { const int f = flags[mt]; return f != 0 && fst[f - 1] != mt; }, uni, sh);
     if (threadIdx.x == 0) cnt[1] = n1;
 }
 
@@ -1298,16 +704,6 @@ __global__ void __launch_bounds__(256) pack_wino_tiled(const float* __restrict__
 }
 
 int ilog2i(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
-
-// BFM_WINO_V=1: round 2's kernels (conv_wino and its masked / rest / uniform forms), for comparisons
-int wino_version() {
-    static int v = 0;
-    if (v == 0) {
-        const char* e = getenv("BFM_WINO_V");
-        v = (e && e[0] == '1') ? 1 : 2;
-    }
-    return v;
-}
 
 bool choose_box(int D, int H, int W, int npl, int& TD, int& TH, int& TW) {
     static const int opts[][3] = {{4, 4, 16}, {4, 8, 8}, {8, 4, 8}, {8, 8, 4}, {2, 4, 32}, {4, 2, 32}, {2, 8, 16},
@@ -1521,77 +917,6 @@ static int wino_launch(const float* A, int CA, int D, int H, int W, const float*
         p.rmx = reinterpret_cast<float*>(rb + n * 20);
     }
     if ((int64_t)p.nMt * p.NT > 0x7fffffff) return BFM_E_SHAPE;
-    if (wino_version() == 2) {
-        // conv_wino2: planes | weight ring (4 taps) | moment fold | scale/shift table; one workgroup per CU
-        const int nf = 2 * npl;
-        p.lds_ring = 8 * npl * p.plane_stride;
-        p.lds_raw = p.lds_ring + W2_RING * 4 * nf * 1024;
-        p.lds_scsh = p.lds_raw + 6144;
-        const size_t smem2 = (size_t)p.lds_scsh + (size_t)2 * CA * sizeof(float);
-        if (smem2 > 160 * 1024) return BFM_E_SHAPE;
-        static int ncu = 0;
-        if (ncu == 0) {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess ||
-                hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-                return BFM_E_LAUNCH;
-            ncu = v;
-            const void* fns[] = {reinterpret_cast<const void*>(&conv_wino2<3, 0>), reinterpret_cast<const void*>(&conv_wino2<1, 0>),
-                                 reinterpret_cast<const void*>(&conv_wino2<3, 1>), reinterpret_cast<const void*>(&conv_wino2<1, 1>),
-                                 reinterpret_cast<const void*>(&conv_wino2<3, 2>), reinterpret_cast<const void*>(&conv_wino2<1, 2>)};
-            for (const void* f : fns)
-                if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                    return BFM_E_LAUNCH;
-        }
-        const int items = p.nMt * p.NT;
-        {
-            static int dbg = -1;
-            if (dbg < 0) { const char* e = getenv("BFM_W2_DBG"); dbg = e ? atoi(e) : 0; }
-            p.dbg = dbg;
-        }
-        if (mask_img) {
-            if (!mask_ws) return BFM_E_ARG;
-            unsigned char* act = static_cast<unsigned char*>(mask_ws);
-            int* cnt = reinterpret_cast<int*>(act + (((size_t)p.nMt + 3) & ~(size_t)3));
-            hipLaunchKernelGGL(wino2_box_active_kernel, dim3((unsigned)bfm_cdiv(p.nMt, 4)), dim3(256), 0, bfm_s(stream),
-                               mask_img, D, H, W, p.TD, p.TH, p.TW, p.nTy, p.nTx, p.nMt, act);
-            hipLaunchKernelGGL(wino2_mask_list_kernel, dim3(1), dim3(1024), 0, bfm_s(stream), act, p.nMt, cnt + 1, cnt);
-            p.list = cnt + 1; p.list_n = cnt;
-            if (passes == 3) hipLaunchKernelGGL((conv_wino2<3, 1>), dim3(ncu), dim3(W2_THR), smem2, bfm_s(stream), p);
-            else hipLaunchKernelGGL((conv_wino2<1, 1>), dim3(ncu), dim3(W2_THR), smem2, bfm_s(stream), p);
-            return bfm_launch_status();
-        }
-        if (uni_flags) {
-            const int* cnt = p.uni_first + 27;               // uniform_lists_kernel: counts, then the two lists
-            p.list = cnt + 2; p.list_n = cnt;
-            if (passes == 3) hipLaunchKernelGGL((conv_wino2<3, 2>), dim3(ncu), dim3(W2_THR), smem2, bfm_s(stream), p);
-            else hipLaunchKernelGGL((conv_wino2<1, 2>), dim3(ncu), dim3(W2_THR), smem2, bfm_s(stream), p);
-            p.list = cnt + 2 + p.nMt; p.list_n = cnt + 1;     // the other flagged boxes: disjoint, the launches may overlap
-            if (passes == 3) hipLaunchKernelGGL(conv_wino2_uniform<3>, dim3(2 * ncu), dim3(NTHR), 6144, bfm_s(stream), p);
-            else hipLaunchKernelGGL(conv_wino2_uniform<1>, dim3(2 * ncu), dim3(NTHR), 6144, bfm_s(stream), p);
-            return bfm_launch_status();
-        }
-        const int nwg = items < ncu ? items : ncu;
-        if (passes == 3) hipLaunchKernelGGL((conv_wino2<3, 0>), dim3(nwg), dim3(W2_THR), smem2, bfm_s(stream), p);
-        else hipLaunchKernelGGL((conv_wino2<1, 0>), dim3(nwg), dim3(W2_THR), smem2, bfm_s(stream), p);
-#ifdef BFM_W2_STAMPS
-        {
-            static unsigned long long host[2 * 2048];
-            (void)hipDeviceSynchronize();
-            (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(w2_stamps), sizeof(host));
-            const char* f = getenv("BFM_W2_STAMP_FILE");
-            if (f) {
-                FILE* fo = fopen(f, "w");
-                if (fo) {
-                    for (int r = 0; r < 2; ++r)
-                        for (int k = 0; k < 2048; ++k) fprintf(fo, "%d %d %llu\n", r, k, host[r * 2048 + k]);
-                    fclose(fo);
-                }
-            }
-        }
-#endif
-        return bfm_launch_status();
-    }
     if (smem > 80 * 1024) return BFM_E_SHAPE;
     static bool attr_done = false;
     if (!attr_done) {
@@ -1614,19 +939,27 @@ static int wino_launch(const float* A, int CA, int D, int H, int W, const float*
         attr_done = true;
     }
     dim3 grid((unsigned)(p.nMt * p.NT));
+    // the sparse forms take their boxes from a list built on the device; workgroups beyond the list end at once
     if (mask_img) {
+        if (!mask_ws) return BFM_E_ARG;
+        unsigned char* act = static_cast<unsigned char*>(mask_ws);
+        int* cnt = reinterpret_cast<int*>(act + (((size_t)p.nMt + 3) & ~(size_t)3));
+        hipLaunchKernelGGL(wino_box_active_kernel, dim3((unsigned)bfm_cdiv(p.nMt, 4)), dim3(256), 0, bfm_s(stream), mask_img,
+                           D, H, W, p.TD, p.TH, p.TW, p.nTy, p.nTx, p.nMt, act);
+        hipLaunchKernelGGL(wino_mask_list_kernel, dim3(1), dim3(1024), 0, bfm_s(stream), act, p.nMt, cnt + 1, cnt);
+        p.list = cnt + 1; p.list_n = cnt;
         if (passes == 3) hipLaunchKernelGGL(conv_wino_masked<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
         else hipLaunchKernelGGL(conv_wino_masked<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
         return bfm_launch_status();
     }
     if (uni_flags) {                                           // disjoint boxes: the two launches may overlap
-        if (passes == 3) {
-            hipLaunchKernelGGL(conv_wino_rest<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
-            hipLaunchKernelGGL(conv_wino_uniform<3>, grid, dim3(NTHR), 6144, bfm_s(stream), p);
-        } else {
-            hipLaunchKernelGGL(conv_wino_rest<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
-            hipLaunchKernelGGL(conv_wino_uniform<1>, grid, dim3(NTHR), 6144, bfm_s(stream), p);
-        }
+        const int* cnt = p.uni_first + 27;                     // uniform_lists_kernel: the two counts, then the two lists
+        p.list = cnt + 2; p.list_n = cnt;
+        if (passes == 3) hipLaunchKernelGGL(conv_wino_rest<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+        else hipLaunchKernelGGL(conv_wino_rest<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+        p.list = cnt + 2 + p.nMt; p.list_n = cnt + 1;
+        if (passes == 3) hipLaunchKernelGGL(conv_wino_uniform<3>, grid, dim3(NTHR), 6144, bfm_s(stream), p);
+        else hipLaunchKernelGGL(conv_wino_uniform<1>, grid, dim3(NTHR), 6144, bfm_s(stream), p);
         return bfm_launch_status();
     }
     if (passes == 3) hipLaunchKernelGGL(conv_wino<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
