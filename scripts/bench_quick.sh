@@ -6,7 +6,7 @@ timeout -k 10 900 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" 
 python3 - <<PY
 import json
 d = json.loads(open("$out").read().strip().splitlines()[-1])
-print("ms_per_step %.2f  dense %s" % (d["ms_per_step"], d.get("dense_volume", {}).get("ms_per_step")))
+print("ms_per_step %.2f  dense %s" % (d["ms_per_step"], (d.get("dense_volume") or {}).get("ms_per_step")))
 for k, v in d["roofline"]["per_kernel"].items():
     print("  %-20s launches %3d  ms %6.2f  achieved %6.1f" % (k, v["launches_per_step"], v["ms_per_step"], v["achieved"]))
 PY
