@@ -28,7 +28,14 @@ import torch  # noqa: E402
 
 CONV_KERNELS = ["conv_wino", "conv_wino_masked", "conv_wino_uniform", "conv_upfold", "conv_mfma", "conv_mfma_ws", "conv_mfma16"]
 _VER_NAME = {0: "conv_mfma", 1: "conv_mfma_ws", 2: "conv_mfma16", 3: "conv_wino"}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_conv_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_conv_hbm_traffic.json")
+# One body, several launch forms: the Winograd kernel in full, over the boxes the tile mask keeps, and as the rest / uniform
+# pair.  The roofline's top level reports the GROUP with the largest share of the conv time (round 2 picked by kernel
+# name, which put conv_upfold on top while half the time ran in the four names of the Winograd body).
+KERNEL_GROUPS = {"conv_wino (all forms)": ["conv_wino", "conv_wino_masked", "conv_wino_uniform"],
+                 "conv_upfold": ["conv_upfold"],
+                 "conv_mfma family (direct)": ["conv_mfma", "conv_mfma_ws", "conv_mfma16"]}
+CPU_BASELINE_CACHE = os.path.join(ROOT, "gpurun_out", "cpu_baseline_last.json")
 
 
 def make_volume(n, device):
@@ -98,9 +105,8 @@ def cpu_baseline(state_dict, full, n, ranges, full_protocol=False, sess=None):
     """The CPU oracle (oracle/unet_ref.py: a torch-CPU fp32 port of the reference's path) timed on this host, rank 0
     only, the way BASELINE.md section 4 / SURVEY 8(d) set it: threads = the physical cores of one socket, per tile
     shape of the reference tiling 1 warm-up + 3 timed runs (median), and the whole volume's time extrapolated from
-    count(shape) x median(shape) and labelled as such.  To keep the default run within minutes the warm-up + 3-run
-    protocol is applied to the two small shapes and the two large ones get one timed run each (caches and thread pool
-    already warm); --cpu-baseline-full runs it on all four."""
+    count(shape) x median(shape) and labelled as such (~2 min of CPU work on 64 cores).  full_protocol=False
+    (--cpu-baseline-quick): the two large shapes get one timed run each instead."""
     import numpy as np
     from oracle import unet_ref as O
     info = host_cpu_info()
@@ -145,10 +151,13 @@ def cpu_baseline(state_dict, full, n, ranges, full_protocol=False, sess=None):
             "hardware_threads": info["threads"], "per_tile_shape": per_shape,
             "extrapolated_volume_s": total_s,
             "sample": "oracle/unet_ref.py (torch-CPU fp32, all 9 heads) on one tile of each shape class of the "
-                      "reference tiling (%s; orientations of a shape share its time), 1 warm-up + 3 timed runs (median) on the small shapes, 1 timed run on the large ones; "
+                      "reference tiling (%s; orientations of a shape share its time), %s; "
                       "value = %d^3 voxels / sum(count x median) = EXTRAPOLATED whole-volume time %.1f s, not a timed "
                       "27-tile run; %.0f s of CPU work on %d threads (physical cores of one socket)"
-                      % (", ".join(per_shape), n, total_s, spent, int(threads))}
+                      % (", ".join(per_shape),
+                         "1 warm-up + 3 timed runs (median) on every shape (BASELINE.md section 4)" if full_protocol else
+                         "1 warm-up + 3 timed runs (median) on the two small shapes, 1 timed run on the large ones "
+                         "(--cpu-baseline-quick)", n, total_s, spent, int(threads))}
 
 
 def label_parity(sess, tile, ref, sd):
@@ -233,7 +242,9 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--passes", type=int, default=3, help="3 = fp32-grade split-f16 MFMA (parity mode), 1 = fast")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-full", action="store_true", help="warm-up + 3 runs on all four tile shapes (~3 min)")
+    ap.add_argument("--cpu-baseline-quick", action="store_true",
+                    help="1 timed run instead of warm-up + 3 on the two large tile shapes (the default is the full protocol of "
+                         "BASELINE.md section 4 on all four shapes, ~2 min on 64 cores)")
     ap.add_argument("--no-atlas", action="store_true", help="16 stitched keys (without the deformed atlas)")
     ap.add_argument("--layer-table", default=None, help="write the per-layer conv timing table of the instrumented pass here")
     ap.add_argument("--dist-path", action="store_true",
@@ -286,16 +297,26 @@ def main():
     sess = TU.InferenceSession(ga, ta, dev, passes=args.passes)
     if not args.no_atlas:
         sess.set_atlas(*make_atlas())
-    full = make_volume(n, dev)
+    # Only rank 0 holds the volume (the reference reads one file in one process, scripts/demo_test.py:71): the peers get it
+    # by broadcast -- here once for the untimed setup, and inside every timed step (tiled_inference_distributed).
+    full = make_volume(n, dev) if rank == 0 else None
+    if world > 1:
+        if backend == "nccl":
+            assert dist.get_world_size() == world, "RCCL world size %d != WORLD_SIZE %d" % (dist.get_world_size(), world)
+        full = TU.broadcast_volume(full, dev, shape=(n, n, n))
     stride, win = [80] * 3, [160] * 3
     ranges = TU.tiling_ranges((n, n, n), stride, win)
     eng = sess.engine
     sess.use_graphs = not args.no_graphs
 
+    xstats = {}                                            # what the last distributed step's exchange moved
+
     def step(vol=None):
         vol = full if vol is None else vol
         if use_dist:
-            return TU.tiled_inference_distributed(vol, sess, stride, win)
+            xstats.clear()
+            return TU.tiled_inference_distributed(vol if rank == 0 else None, sess, stride, win, shape=(n, n, n),
+                                                  stats=xstats, broadcast=True)
         return TU.tiled_inference(vol, sess, stride, win, batched=True)      # eager (--no-graphs) runs the same batches
 
     # setup (untimed, once per session): tune the conv variants and capture one hipGraph per tile shape
@@ -318,6 +339,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    exposed_ms = None
+    if use_dist and rank == 0 and "ev_own_done" in xstats:
+        exposed_ms = max(0.0, xstats["ev_own_done"].elapsed_time(xstats["ev_gathers_done"]))
+    exchange = None
+    if use_dist:
+        exchange = {k: xstats.get(k) for k in ("world", "rounds", "round_bytes_per_peer", "bytes_sent_per_peer",
+                                               "compact_rows", "broadcast_bytes")}
+        exchange["exchange_exposed_ms"] = exposed_ms
+        exchange["note"] = ("last timed step; broadcast_bytes = the volume, rank 0 to every peer inside the step; "
+                            "bytes_sent_per_peer = the padded rows every peer ships to rank 0 over its rounds; "
+                            "exchange_exposed_ms = on rank 0's stream, from its own tiles being done to the last gather "
+                            "having arrived (what the round-wise gathers did not hide)")
     n_keys = len(acc) if acc is not None else None
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
@@ -348,8 +381,10 @@ def main():
     # nothing to skip.  Reported next to `value` so that the data-independent rate is on the line too.
     dense_ms = None
     if not args.no_dense_check:
-        g = torch.Generator(device="cpu").manual_seed(5)
-        dense = (torch.rand((1, 1, n, n, n), generator=g) + 0.05).to(dev)
+        dense = None
+        if rank == 0:
+            g = torch.Generator(device="cpu").manual_seed(5)
+            dense = (torch.rand((1, 1, n, n, n), generator=g) + 0.05).to(dev)
         for _ in range(2):
             step(dense)
         if use_dist:
@@ -372,48 +407,92 @@ def main():
     # the same step is run once more eagerly right after it with every conv launch issued `reps` times back to back
     # inside one HIP event pair on the launch stream (idempotent; back-to-back so the bracket holds kernel time rather
     # than python submission gaps).  Launch duration = bracket / reps.
-    prof = []
-    if args.roofline_reps > 0:                      # 0: skip (used for rocprofv3 runs that should hold the timed steps only)
+    peak = 2500.0                                            # dense f16 MFMA, MI355X_MICROARCH.md
+
+    def conv_profile(vol, table=None):
+        """Instrumented eager replay of one step on `vol` -> (per-kernel dict, family dict, launches per kernel of this rank)."""
         eng.prof = []
         eng.prof_reps = args.roofline_reps
         g = sess.use_graphs
         sess.use_graphs = False
-        step()
+        step(vol)
         torch.cuda.synchronize()
         sess.use_graphs = g
         prof = eng.prof
         eng.prof = None
-    per = {k: [0.0, 0.0, 0.0, 0.0] for k in CONV_KERNELS}       # ms, flops, bytes, launches
-    for p in prof:
-        e = per[kernel_of(p)]
-        e[0] += p[0].elapsed_time(p[1]) / p[4]
-        e[1] += p[2]
-        e[2] += p[3]
-        e[3] += 1
-    if args.layer_table and rank == 0:
-        tab = {}
+        per = {k: [0.0, 0.0, 0.0, 0.0] for k in CONV_KERNELS}       # ms, flops, bytes, launches
         for p in prof:
-            e = tab.setdefault((kernel_of(p),) + p[5], [0, 0.0, 0.0])
-            e[0] += 1
-            e[1] += p[0].elapsed_time(p[1]) / p[4]
-            e[2] += p[2]
-        with open(args.layer_table, "w") as f:
-            f.write("# conv launches of one step grouped by (kernel, layer, Cin, Cout, dims, plan[WM,WN,TD,TH,TW,splitk,ver,0])\n")
-            f.write("%-13s %-12s %5s %5s %-16s %-28s %5s %10s %8s %7s\n" % ("kernel", "layer", "cin", "cout", "dims", "plan",
-                                                                        "n", "ms_total", "us_avg", "TF/s"))
-            for key, (cnt, ms, fl) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
-                f.write("%-13s %-12s %5d %5d %-16s %-28s %5d %10.3f %8.1f %7.1f\n" % (
-                    key[0], key[1], key[2], key[3], "x".join(map(str, key[4])), ",".join(map(str, key[5])), cnt, ms,
-                    ms * 1e3 / cnt, fl / (ms * 1e-3) / 1e12))
-    agg = torch.tensor([per[k] for k in CONV_KERNELS], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(agg)
-    per = {k: [float(v) for v in agg[i].tolist()] for i, k in enumerate(CONV_KERNELS)}
-    k_ms = sum(e[0] for e in per.values())
-    k_fl = sum(e[1] for e in per.values())
-    k_by = sum(e[2] for e in per.values())
-    k_n = sum(e[3] for e in per.values())
-    peak = 2500.0                                            # dense f16 MFMA, MI355X_MICROARCH.md
+            e = per[kernel_of(p)]
+            e[0] += p[0].elapsed_time(p[1]) / p[4]
+            e[1] += p[2]
+            e[2] += p[3]
+            e[3] += 1
+        if table and rank == 0:
+            tab = {}
+            for p in prof:
+                e = tab.setdefault((kernel_of(p),) + p[5], [0, 0.0, 0.0])
+                e[0] += 1
+                e[1] += p[0].elapsed_time(p[1]) / p[4]
+                e[2] += p[2]
+            with open(table, "w") as f:
+                f.write("# conv launches of one step grouped by (kernel, layer, Cin, Cout, dims, plan[WM,WN,TD,TH,TW,splitk,ver,0])\n")
+                f.write("%-13s %-12s %5s %5s %-16s %-28s %5s %10s %8s %7s\n" % ("kernel", "layer", "cin", "cout", "dims", "plan",
+                                                                            "n", "ms_total", "us_avg", "TF/s"))
+                for key, (cnt, ms, fl) in sorted(tab.items(), key=lambda kv: -kv[1][1]):
+                    f.write("%-13s %-12s %5d %5d %-16s %-28s %5d %10.3f %8.1f %7.1f\n" % (
+                        key[0], key[1], key[2], key[3], "x".join(map(str, key[4])), ",".join(map(str, key[5])), cnt, ms,
+                        ms * 1e3 / cnt, fl / (ms * 1e-3) / 1e12))
+        mine = {k: int(e[3]) for k, e in per.items() if e[3] > 0}
+        mat = torch.tensor([per[k] for k in CONV_KERNELS], device=dev, dtype=torch.float64)
+        if world > 1:
+            # per kernel: FLOPs, bytes and launches summed over the ranks, time = the SLOWEST rank's (what the step waits for)
+            allm = [torch.zeros_like(mat) for _ in range(world)]
+            dist.all_gather(allm, mat)
+            st = torch.stack(allm)
+            mat = st.sum(0)
+            mat[:, 0] = st[:, :, 0].max(0).values
+            rank_ms = [float(v) for v in st[:, :, 0].sum(1).tolist()]
+        else:
+            rank_ms = [float(mat[:, 0].sum())]
+        per = {k: [float(v) for v in mat[i].tolist()] for i, k in enumerate(CONV_KERNELS)}
+        k_ms = max(rank_ms)                                      # conv kernel time of the slowest rank
+        k_fl = sum(e[1] for e in per.values())
+        kernels = {}
+        for k, (ms, fl, by, cnt) in per.items():
+            if cnt <= 0:
+                continue
+            ach = fl / (ms * 1e-3) / 1e12 / max(world, 1)       # per GPU: the ranks' FLOPs over the slowest rank's time
+            kernels[k] = {"launches_per_step": int(cnt), "ms_per_step": ms, "avg_launch_us": ms * 1e3 * max(world, 1) / cnt,
+                          "achieved": ach, "frac": ach / peak, "algorithmic_bytes_per_launch": by / cnt}
+        groups = {}
+        for gname, members in KERNEL_GROUPS.items():
+            ms = sum(per[m][0] for m in members)
+            fl = sum(per[m][1] for m in members)
+            cnt = sum(per[m][3] for m in members)
+            if cnt <= 0:
+                continue
+            ach = fl / (ms * 1e-3) / 1e12 / max(world, 1)
+            groups[gname] = {"kernels": [m for m in members if per[m][3] > 0], "launches_per_step": int(cnt),
+                             "ms_per_step": ms, "achieved": ach, "frac": ach / peak,
+                             "share_of_conv_time": ms / sum(per[m][0] for m in CONV_KERNELS)}
+        fam_ach = k_fl / (k_ms * 1e-3) / 1e12 / max(world, 1) if k_ms > 0 else 0.0
+        family = {"achieved": fam_ach, "frac": fam_ach / peak, "kernel_ms_per_step": k_ms,
+                  "kernel_ms_per_rank": rank_ms if world > 1 else None,
+                  "launches_per_step": int(sum(e[3] for e in per.values())),
+                  "algorithmic_bytes_per_step": sum(e[2] for e in per.values())}
+        return kernels, groups, family, mine
+
+    kernels, groups, family, mine = {}, {}, {}, {}
+    dense_family = None
+    if args.roofline_reps > 0:                      # 0: skip (used for rocprofv3 runs that should hold the timed steps only)
+        kernels, groups, family, mine = conv_profile(None, args.layer_table)
+        if not args.no_dense_check:
+            g = torch.Generator(device="cpu").manual_seed(5)
+            dvol = (torch.rand((1, 1, n, n, n), generator=g) + 0.05).to(dev) if rank == 0 else None
+            _, dgroups, dense_family, _ = conv_profile(dvol)
+            dense_family["per_group"] = {k: {"ms_per_step": v["ms_per_step"], "achieved": v["achieved"], "frac": v["frac"]}
+                                         for k, v in dgroups.items()}
+            del dvol
     # HBM traffic per kernel: rocprofv3 PMC passes cannot run inside this process; the committed summary of the same
     # workload (scripts/pmc_traffic.py: FETCH_SIZE x2 + WRITE_SIZE, separate passes, per MI355X_MICROARCH.md) is used --
     # and refused when the launch counts it recorded per kernel differ from this run's (a stale file)
@@ -421,7 +500,6 @@ def main():
     if os.path.exists(TRAFFIC_FILE) and world == 1:
         try:
             tj = json.load(open(TRAFFIC_FILE))
-            mine = {k: int(e[3]) for k, e in per.items() if e[3] > 0}
             theirs = {k: int(v["launches"]) for k, v in tj["kernels"].items() if k in CONV_KERNELS}
             if mine == theirs:
                 traffic_tab = {k: v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items()}
@@ -431,15 +509,17 @@ def main():
                                 "(scripts/pmc_traffic.py)" % (os.path.relpath(TRAFFIC_FILE, ROOT), theirs, mine))
         except Exception as e:                                # noqa: BLE001
             traffic_note = "unreadable traffic file: %r" % (e,)
-    kernels = {}
-    for k, (ms, fl, by, cnt) in per.items():
-        if cnt <= 0:
-            continue
-        ach = fl / (ms * 1e-3) / 1e12
-        kernels[k] = {"launches_per_step": int(cnt), "ms_per_step": ms / max(world, 1), "avg_launch_us": ms * 1e3 / cnt,
-                      "achieved": ach, "frac": ach / peak, "share_of_conv_time": ms / k_ms,
-                      "algorithmic_bytes_per_launch": by / cnt, "traffic": traffic_tab.get(k)}
-    dominant = max(kernels, key=lambda k: kernels[k]["ms_per_step"]) if kernels else None
+    elif world > 1:
+        traffic_note = "not reported for N > 1: the PMC summary is a one-rank run and the launches per rank differ"
+    for k in kernels:
+        kernels[k]["traffic"] = traffic_tab.get(k)
+    for gname, gv in groups.items():                           # a group's traffic: launch-weighted over its kernels
+        tb = [(kernels[m]["traffic"], kernels[m]["launches_per_step"]) for m in gv["kernels"]]
+        gv["traffic_per_launch"] = (sum(t * c for t, c in tb) / sum(c for _, c in tb)) if tb and all(t is not None for t, _ in tb) else None
+        gv["algorithmic_bytes_per_launch"] = sum(kernels[m]["algorithmic_bytes_per_launch"] * kernels[m]["launches_per_step"]
+                                                 for m in gv["kernels"]) / gv["launches_per_step"]
+        gv["avg_launch_us"] = gv["ms_per_step"] * 1e3 * max(world, 1) / gv["launches_per_step"]
+    dominant = max(groups, key=lambda k: groups[k]["ms_per_step"]) if groups else None
     if rank == 0:
         tile_vox = sum(TU.tile_cost(r) for r in ranges)
         flops_step = sum(conv_flops_tile([r[a][1] - r[a][0] for a in range(3)]) for r in ranges)
@@ -481,8 +561,7 @@ def main():
                     computed_step -= 2.0 * 27 * chans[key][0] * chans[key][1] * v
         uni2, uni3 = uni.get(("enc", 0, 1), 0.0), uni.get(("dec", 0), 0.0)
         uni_l1 = sum(v for k, v in uni.items() if k[1] == 1) / max(sum(1 for k in uni if k[1] == 1), 1)
-        fam = k_fl / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        dk = kernels.get(dominant, {})
+        dk = groups.get(dominant, {})
         line = {
             "metric": "voxels/sec whole-volume multi-task inference, 256^3 tiled",
             "value": n ** 3 * args.steps / dt, "unit": "voxels/s", "n_gpus": world, "steps": args.steps,
@@ -497,9 +576,12 @@ def main():
             "latency_ms_median": lat_med * 1e3,
             "dense_volume": None if dense_ms is None else {
                 "ms_per_step": dense_ms, "value": n ** 3 / dense_ms * 1e3, "unit": "voxels/s",
+                "conv_family": dense_family,
                 "note": "the same build and graphs on a volume of uniform noise without a zero background: nothing is "
                         "skipped (config.tile_mask describes what the headline volume, SURVEY config 3's ellipsoid with "
-                        "exact zeros outside, lets the exact shortcuts leave out)"},
+                        "exact zeros outside, lets the exact shortcuts leave out); conv_family = the instrumented conv "
+                        "pass on this volume: the data-independent fraction of the MFMA peak"},
+            "exchange": exchange,
             "config": {"workload": "%d^3 volume, reference tiling win160/stride80 -> %d tiles, UNet3D f64 x6 levels, "
                                    "9 heads (69 ch), fused tail + deformed atlas + on-device stitch of %s keys"
                                    % (n, len(ranges), n_keys),
@@ -524,34 +606,46 @@ def main():
                        "submission": "hipGraph replay per tile shape" if sess.use_graphs else "eager",
                        "parallelism": "tiles sharded over %d rank(s), gather to rank 0" % world,
                        "tiles_in_flight_per_gpu": sess.lanes if sess.use_graphs else 1},
-            "roofline": {"bound": "mfma", "kernel": dominant,
+            "roofline": {"bound": "mfma", "kernel": dominant, "kernel_members": dk.get("kernels"),
                          "achieved": dk.get("achieved"), "peak": peak, "unit": "TFLOP/s", "frac": dk.get("frac"),
-                         "traffic": dk.get("traffic"), "traffic_source": traffic_note,
+                         "traffic": dk.get("traffic_per_launch"), "traffic_source": traffic_note,
                          "avg_launch_us": dk.get("avg_launch_us"),
                          "algorithmic_bytes_per_launch": dk.get("algorithmic_bytes_per_launch"),
-                         "per_kernel": kernels,
-                         "conv_family": {"achieved": fam, "frac": fam / peak, "kernel_ms_per_step": k_ms / max(world, 1),
-                                         "launches_per_step": int(k_n), "algorithmic_bytes_per_step": k_by,
-                                         # the reference's dense work (every voxel of every tile) over the same kernel time:
-                                         # what the rate would read if the boxes the exact shortcuts leave out were counted
-                                         "reference_equivalent_achieved": (flops_step / 1e12) / (k_ms * 1e-3) if k_ms > 0 else None,
-                                         "reference_equivalent_frac": (flops_step / 1e12) / (k_ms * 1e-3) / peak if k_ms > 0 else None},
-                         "note": "the dominant kernel (largest share of the step's conv time) is reported at the top level, "
-                                 "every conv kernel under per_kernel, the whole family under conv_family; achieved = "
-                                 "algorithmic conv FLOPs (2*27*Cin*Cout*voxels, also for Winograd / up-folded layers) / "
-                                 "summed launch durations; durations from HIP events around %d back-to-back launches of "
-                                 "each conv in an instrumented eager replay of the step right after the timed region; the "
-                                 "kernels issue up to %dx the algorithmic FLOPs in f16 MFMA; conv_wino_masked / conv_wino_uniform count "
-                                 "the FLOPs of the boxes they evaluate only (config.tile_mask), and conv_wino_uniform is a "
-                                 "pair of kernels per launch: conv_wino_rest (matrix-bound, the unflagged boxes) + a kernel "
-                                 "that streams one box's result to its class mates (HBM-bound)" % (args.roofline_reps, args.passes)},
+                         "share_of_conv_time": dk.get("share_of_conv_time"),
+                         "per_group": groups, "per_kernel": kernels, "conv_family": family,
+                         "note": "top level = the GROUP of conv kernels with the largest share of the step's conv time (the "
+                                 "Winograd body runs under three launch names), every group under per_group, every kernel "
+                                 "name under per_kernel, the whole family under conv_family; achieved = algorithmic conv "
+                                 "FLOPs of the boxes a launch evaluates (2*27*Cin*Cout*voxels, also for Winograd / up-folded "
+                                 "layers; config.tile_mask says what the masked / uniform forms leave out) / summed launch "
+                                 "durations; durations from HIP events around %d back-to-back launches of each conv in an "
+                                 "instrumented eager replay of the step right after the timed region; the kernels issue "
+                                 "up to %dx the algorithmic FLOPs in f16 MFMA; conv_wino_uniform is a pair of kernels per "
+                                 "launch: conv_wino_rest (matrix-bound, the unflagged boxes) + a kernel that streams one "
+                                 "box's result to its class mates (HBM-bound); with N > 1 ranks a kernel's time is the "
+                                 "slowest rank's, FLOPs and launches are summed over the ranks" % (args.roofline_reps, args.passes)},
         }
         if not args.no_cpu_baseline and world == 1:
             sd = {k: v for k, v in sess.model.state_dict().items()}
-            line["cpu_baseline"] = cpu_baseline(sd, full, n, ranges, args.cpu_baseline_full, sess)
+            line["cpu_baseline"] = cpu_baseline(sd, full, n, ranges, not args.cpu_baseline_quick, sess)
             line["label_parity"] = line["cpu_baseline"].pop("label_parity")
+            try:                                              # for the N > 1 lines of the same box (rank 0 at N = 1 only)
+                os.makedirs(os.path.dirname(CPU_BASELINE_CACHE), exist_ok=True)
+                json.dump({"size": n, "cpu_baseline": line["cpu_baseline"], "label_parity": line["label_parity"]},
+                          open(CPU_BASELINE_CACHE, "w"))
+            except OSError:
+                pass
         else:
             line["cpu_baseline"] = None
+            if world > 1 and os.path.exists(CPU_BASELINE_CACHE):
+                try:
+                    cj = json.load(open(CPU_BASELINE_CACHE))
+                    if cj.get("size") == n and cj["cpu_baseline"].get("cpu_model") == host_cpu_info()["model"]:
+                        line["cpu_baseline"] = dict(cj["cpu_baseline"], copied_from="the N = 1 run of this box (%s)"
+                                                    % os.path.relpath(CPU_BASELINE_CACHE, ROOT))
+                        line["label_parity"] = cj.get("label_parity")
+                except Exception:                             # noqa: BLE001
+                    pass
         try:                                                  # librccl's version banner sits in the C stdio buffer and
             import ctypes                                     # would otherwise land after the JSON line at exit
             ctypes.CDLL(None).fflush(None)

@@ -1053,9 +1053,36 @@ def agree_on_conv_variants(session, full_im, ranges, group=None):
     agreed.update(todo)
 
 
+def broadcast_volume(full_im, device, group=None, shape=None):
+    """The volume from rank 0 to every rank (the reference loads one file in one process,
+    scripts/demo_test.py:71; the tiles of the other ranks are windows of it).  Rank 0 passes the (1,1,D,H,W) fp32
+    volume; the others pass None and get a fresh tensor.  shape: the spatial shape when every rank knows it already (a
+    5-number header goes first otherwise).  67 MB for 256^3, 537 MB for 512^3: one RCCL broadcast."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    if dist.get_world_size(group) == 1:
+        return full_im
+    if shape is None:
+        hdr = torch.zeros(5, dtype=torch.int64, device=device)
+        if rank == 0:
+            hdr = torch.tensor(list(full_im.shape), dtype=torch.int64, device=device)
+        dist.broadcast(hdr, src=0, group=group)
+        full_shape = tuple(int(v) for v in hdr.tolist())
+    else:
+        full_shape = (1, 1) + tuple(shape)
+    if rank == 0:
+        if tuple(full_im.shape) != full_shape or full_im.dtype != torch.float32:
+            raise L.BfmError("rank 0's volume is %s %s, expected %s float32" % (tuple(full_im.shape), full_im.dtype, full_shape))
+        buf = full_im.contiguous()
+    else:
+        buf = torch.empty(full_shape, dtype=torch.float32, device=device)
+    dist.broadcast(buf, src=0, group=group)
+    return buf
+
+
 @L.on_device(lambda full_im, session, *a, **k: session.device if session is not None else None)
 def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=[160, 160, 160], group=None,
-                                ops=None, rounds=None):
+                                ops=None, rounds=None, shape=None, stats=None, broadcast=False):
     """Tiles are independent (GroupNorm statistics are per tile), so they shard over ranks with no
     data-path collective; gathers to rank 0 carry every rank's masked tile outputs, and rank 0 accumulates them
     in the reference's tile order so the result is bit-identical to the single-GPU path (fp32 += is order
@@ -1064,7 +1091,12 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
     tile of every rank -- leaves in its own asynchronous gather as soon as it is computed, so the transfers ride under
     the next round's kernels and only the last (smallest) round's is exposed; otherwise ONE gather at the end.  With
     27 tiles on 8 GPUs a rank computes ~20 ms and ships ~280 MB: the single gather would add ~1/3 to the step.
-    Every rank holds full_im.  Returns (acc, ranges, cnt) on rank 0, (None, ranges, None) elsewhere.
+    broadcast=True (the same on every rank): only rank 0 holds the volume (the reference reads one file in one process)
+    and sends it to the peers inside this call (broadcast_volume; the peers pass full_im=None and, if they know it, the
+    spatial `shape` -- a 5-number header travels first otherwise).  broadcast=False: every rank passes its own copy.
+    stats: a dict that receives what the exchange moved (bytes per peer and round, and on rank 0 two events that bracket
+    what the gathers left exposed after its own tiles).
+    Returns (acc, ranges, cnt) on rank 0, (None, ranges, None) elsewhere.
     ``ops`` (run_tile/add/finalize) defaults to the HIP kernels; the gloo unit tests inject host ops
     to exercise the sharding / ordering logic without a GPU."""
     import torch.distributed as dist
@@ -1074,6 +1106,15 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
         rounds = DIST_ROUNDS
     if ops is None:
         ops = _session_stitch_ops(session) if session is not None else HipStitchOps(session)
+    if broadcast:
+        if rank != 0 and full_im is not None:
+            raise L.BfmError("broadcast=True: only rank 0 passes the volume")
+        bdev = full_im.device if full_im is not None else (session.device if session is not None else torch.device("cpu"))
+        full_im = broadcast_volume(full_im, bdev, group, shape)
+        if stats is not None:
+            stats["broadcast_bytes"] = int(full_im.numel()) * 4 if world > 1 else 0
+    elif full_im is None:
+        raise L.BfmError("tiled_inference_distributed: this rank has no volume (pass broadcast=True on every rank)")
     shape = tuple(full_im.shape[2:])
     ranges = tiling_ranges(shape, stride, win_size)
     owner = assign_tiles(ranges, world)
@@ -1179,8 +1220,22 @@ def tiled_inference_distributed(full_im, session, stride=[80, 80, 80], win_size=
         g = [_buf("recv%d_%d" % (kk, r), round_numel[kk]) for r in range(world)] if rank == 0 else None
         gathered.append(g)
         works.append(dist.gather(sbuf, g, dst=0, group=group, async_op=True))
+    if stats is not None:
+        stats["world"] = world
+        stats["rounds"] = nrounds
+        stats["round_bytes_per_peer"] = [int(v) * 4 for v in round_numel]
+        stats["bytes_sent_per_peer"] = int(sum(round_numel)) * 4 if world > 1 else 0
+        stats["compact_rows"] = index is not None
+    if rank == 0 and stats is not None and dev.type == "cuda":
+        for ev in pending:                                    # rank 0's own tiles are done ...
+            torch.cuda.current_stream(dev).wait_event(ev)
+        stats["ev_own_done"] = torch.cuda.Event(enable_timing=True)
+        stats["ev_own_done"].record(torch.cuda.current_stream(dev))
     for w in works:
         w.wait()
+    if rank == 0 and stats is not None and dev.type == "cuda":
+        stats["ev_gathers_done"] = torch.cuda.Event(enable_timing=True)      # ... and every peer's rows have arrived
+        stats["ev_gathers_done"].record(torch.cuda.current_stream(dev))
     if rank != 0:
         return None, ranges, None
     if keys is None:

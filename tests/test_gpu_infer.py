@@ -1308,3 +1308,32 @@ def test_headline_shortcuts_change_no_bit_256(monkeypatch):
     for k in res[True]:
         assert torch.equal(res[True][k], res[False][k]), k
     assert float(res[True]["T1"].abs().max()) > 0
+
+
+def test_bench_line_fields_two_ranks_dry_run():
+    """`python bench.py --gpus 2` the way the driver's N > 1 runs see it, as a dry run on this one GPU (gloo ranks sharing
+    cuda:0; timings meaningless): only rank 0 holds the volume and broadcasts it inside the step, the line carries the
+    exchange (bytes per peer and round, what the gathers left exposed), the roofline by group / kernel / family with the
+    slowest rank's kernel time, and the metric, unit and workload BASELINE.json names."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BFM_BENCH_SHARE_GPU="1", BFM_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--size", "200", "--no-dense-check", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=900, env=env, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-800:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["unit"] == "voxels/s" and d["scaling"] == "strong" and d["value"] > 0
+    assert d["metric"].startswith("voxels/sec whole-volume multi-task inference")
+    ex = d["exchange"]
+    assert ex["world"] == 2 and ex["broadcast_bytes"] == 4 * 200 ** 3 and ex["bytes_sent_per_peer"] > 0
+    assert len(ex["round_bytes_per_peer"]) == ex["rounds"] and ex["exchange_exposed_ms"] is not None
+    rf = d["roofline"]
+    assert rf["kernel"] in rf["per_group"] and rf["frac"] == rf["per_group"][rf["kernel"]]["frac"]
+    assert set(rf["per_kernel"]) >= {"conv_wino", "conv_upfold"} and len(rf["conv_family"]["kernel_ms_per_rank"]) == 2
+    assert rf["conv_family"]["kernel_ms_per_step"] == max(rf["conv_family"]["kernel_ms_per_rank"])
+    assert "reference_equivalent_frac" not in rf["conv_family"]

@@ -177,10 +177,22 @@ def _worker(rank, world, port, q, shape=(40, 36, 44)):
     full[:, :, :6] = 0
     acc, ranges, cnt = TU.tiled_inference_distributed(full, None, [12] * 3, [24] * 3, ops=_HostOps())   # round-wise gathers
     acc1, _, _ = TU.tiled_inference_distributed(full, None, [12] * 3, [24] * 3, ops=_HostOps(), rounds=False)
+    # only rank 0 holds the volume (the reference reads one file in one process): it travels by broadcast inside the call,
+    # with the shape known to the peers and with the 5-number header in front of it
+    st = {}
+    acc2, _, _ = TU.tiled_inference_distributed(full if rank == 0 else None, None, [12] * 3, [24] * 3, ops=_HostOps(),
+                                                shape=shape, stats=st, broadcast=True)
+    acc3, _, _ = TU.tiled_inference_distributed(full if rank == 0 else None, None, [12] * 3, [24] * 3, ops=_HostOps(),
+                                                broadcast=True)
+    assert st["world"] == world and st["broadcast_bytes"] == 4 * full.numel() and len(st["round_bytes_per_peer"]) == st["rounds"]
+    assert st["bytes_sent_per_peer"] == sum(st["round_bytes_per_peer"]) > 0
     if rank == 0:
         for k in acc:
             assert torch.equal(acc[k], acc1[k]), k            # one gather at the end gives the same bits
+            assert torch.equal(acc[k], acc2[k]) and torch.equal(acc[k], acc3[k]), k
         q.put({k: v.numpy() for k, v in acc.items()})
+    else:
+        assert acc2 is None and acc3 is None
     dist.barrier()
     dist.destroy_process_group()
 
