@@ -11,6 +11,7 @@
 // Built with -ffp-contract=off: a*b + c*d stays mul, mul, add like the reference's eager torch ops,
 // which is what makes the fp32 results bit-identical to the CPU path.
 #include "bfm_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -72,7 +73,9 @@ __device__ __forceinline__ float ld_l2(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <bool NZ>
+// PLAIN: the texel loads as ordinary global_load_dword -- the form that misbehaved; kept behind BFM_ATLAS_PLAIN_LOADS=1
+// for tests/diag/diag_atlas_repro.py only
+template <bool NZ, bool PLAIN = false>
 __global__ void deformed_atlas(const float* __restrict__ mask, const float* __restrict__ rx,
                                const float* __restrict__ ry, const float* __restrict__ rz, const float* X, int nx,
                                int ny, int nz, Aff34 A, int64_t n, float* __restrict__ out) {
@@ -91,7 +94,10 @@ __global__ void deformed_atlas(const float* __restrict__ mask, const float* __re
                 const int cx = min(fx + 1, nx - 1), cy = min(fy + 1, ny - 1), cz = min(fz + 1, nz - 1);
                 const float wcx = x - fxf, wcy = y - fyf, wcz = z - fzf;
                 const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
-                auto at = [&](int a, int b, int c) { return ld_l2(X + (((int64_t)a * ny + b) * nz + c)); };
+                auto at = [&](int a, int b, int c) {
+                    const float* q = X + (((int64_t)a * ny + b) * nz + c);
+                    return PLAIN ? *q : ld_l2(q);
+                };
                 const float c00 = at(fx, fy, fz) * wfx + at(cx, fy, fz) * wcx;
                 const float c01 = at(fx, fy, cz) * wfx + at(cx, fy, cz) * wcx;
                 const float c10 = at(fx, cy, fz) * wfx + at(cx, cy, fz) * wcx;
@@ -515,8 +521,14 @@ extern "C" int bfm_deformed_atlas_tile(const float* tile_in, const float* regx, 
         return BFM_E_ARG;
     Aff34 A;
     for (int i = 0; i < 12; ++i) A.a[i] = A_host[i];
-    hipLaunchKernelGGL(deformed_atlas<true>, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), tile_in, regx, regy, regz,
-                       atlas, nx, ny, nz, A, n, out);
+    static int plain = -1;                                     // diagnostic switch (tests/diag/diag_atlas_repro.py)
+    if (plain < 0) { const char* e = getenv("BFM_ATLAS_PLAIN_LOADS"); plain = (e && e[0] == '1') ? 1 : 0; }
+    if (plain)
+        hipLaunchKernelGGL((deformed_atlas<true, true>), dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), tile_in, regx, regy,
+                           regz, atlas, nx, ny, nz, A, n, out);
+    else
+        hipLaunchKernelGGL((deformed_atlas<true, false>), dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), tile_in, regx, regy,
+                           regz, atlas, nx, ny, nz, A, n, out);
     return bfm_launch_status();
 }
 

@@ -432,3 +432,54 @@ def test_generator_getitem_vs_reference_golden(tag):
             got = N(s[k])
             assert got.shape == r[k].shape, (i, k)
             assert relerr(got, r[k]) <= 1e-4, (i, k, relerr(got, r[k]))
+
+
+def test_gathers_inside_captured_graphs_on_two_lanes_keep_their_goldens():
+    """The gathers of the library that read texels with plain loads -- fast_3D_interp_torch (bfm_interp3d_linear) and
+    interpol.grid_pull (bfm_grid_pull3d_linear) -- had only ever run on one stream outside any graph, while the atlas
+    gather misbehaved exactly inside two concurrently replaying graphs.  Each is captured in a
+    hipGraph per lane (own coordinate and output buffers, one shared source volume), the two graphs are replayed
+    concurrently on two streams 100 times with a third stream streaming 256 MB beside them, and every replay must give
+    the reference's golden bits (interp: exact; grid_pull: 1e-6)."""
+    from brainfm_amd.generator_utils import fast_3D_interp_torch
+    from brainfm_amd.interpol import grid_pull
+    d = load_npz("synth_interp.npz")
+    X = T(d["X1"])
+    d2 = load_npz("synth_grid_pull.npz")
+    vol, grid = T(d2["vol"]), T(d2["grid"])
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    side = torch.cuda.Stream()
+    big = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=DEV)
+    lanes = []
+    for lane in range(2):
+        ii, jj, kk = T(d["II"]), T(d["JJ"]), T(d["KK"])            # private coordinate buffers per lane
+        gcopy = grid.clone()
+        outs = {}
+
+        def body(ii=ii, jj=jj, kk=kk, gcopy=gcopy, outs=outs):
+            outs["interp"] = fast_3D_interp_torch(X, ii, jj, kk, "linear")
+            outs["pull_zero"] = grid_pull(vol, gcopy, interpolation="linear", bound="zero", extrapolate=False, prefilter=False)
+            outs["pull_dct2"] = grid_pull(vol, gcopy, interpolation="linear", bound="dct2", extrapolate=True, prefilter=False)
+
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(streams[lane]):
+            body()                                                # warm-up (library load, allocations)
+            streams[lane].synchronize()
+            with torch.cuda.graph(g, stream=streams[lane]):
+                body()
+        lanes.append((g, outs))
+    for it in range(100):
+        for _, outs in lanes:
+            for v in outs.values():
+                v.fill_(float("nan"))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            big.mul_(1.0)
+        for lane, (g, _) in enumerate(lanes):
+            with torch.cuda.stream(streams[lane]):
+                g.replay()
+        torch.cuda.synchronize()
+        for lane, (_, outs) in enumerate(lanes):
+            assert np.array_equal(N(outs["interp"]), d["lin1"]), (it, lane)
+            _close(N(outs["pull_zero"]), d2["out_zero_0"], 1e-6)
+            _close(N(outs["pull_dct2"]), d2["out_dct2_1"], 1e-6)
