@@ -23,6 +23,19 @@ inline int grid_for(int64_t n, int tpb = 256, int cap = 8192) {
 #define GRID_STRIDE(i, n) \
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
+// Texel loads of the gathers (data-dependent addresses, lines re-used from the L1 by neighbouring lanes and waves) go past
+// the per-CU vector L1: agent scope = global_load_dword sc1, served by the XCD's L2.  Round 3 cornered what round 2 had
+// only worked around (tests/diag/diag_atlas_repro.py, profiles/r03_atlas_gather_hazard.txt): with
+// ordinary loads such a gather gets wrong texels -- whole 16-lane groups -- whenever a kernel that fills its LDS by LDS-DMA
+// (global_load_lds, every conv kernel here) runs beside it on another stream; an L1 invalidate at kernel start does not
+// help, L1-bypassing loads (agent or system scope) do.  The value type is float or a 4-byte bit pattern.
+__device__ __forceinline__ float ld_tex(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t ld_tex(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ void interp_linear(const float* __restrict__ X, int nx, int ny, int nz, int C,
                               const float* __restrict__ II, const float* __restrict__ JJ,
                               const float* __restrict__ KK, int64_t n, float defv, float* __restrict__ out) {
@@ -50,10 +63,10 @@ __global__ void interp_linear(const float* __restrict__ X, int nx, int ny, int n
         const float* p011 = X + fx * sx + cy * sy + (int64_t)cz * C;
         const float* p111 = X + cx * sx + cy * sy + (int64_t)cz * C;
         for (int c = 0; c < C; ++c) {
-            const float c00 = p000[c] * wfx + p100[c] * wcx;
-            const float c01 = p001[c] * wfx + p101[c] * wcx;
-            const float c10 = p010[c] * wfx + p110[c] * wcx;
-            const float c11 = p011[c] * wfx + p111[c] * wcx;
+            const float c00 = ld_tex(p000 + c) * wfx + ld_tex(p100 + c) * wcx;
+            const float c01 = ld_tex(p001 + c) * wfx + ld_tex(p101 + c) * wcx;
+            const float c10 = ld_tex(p010 + c) * wfx + ld_tex(p110 + c) * wcx;
+            const float c11 = ld_tex(p011 + c) * wfx + ld_tex(p111 + c) * wcx;
             const float c0 = c00 * wfy + c10 * wcy;
             const float c1 = c01 * wfy + c11 * wcy;
             o[c] = c0 * wfz + c1 * wcz;
@@ -65,20 +78,22 @@ __global__ void interp_linear(const float* __restrict__ X, int nx, int ny, int n
 struct Aff34 { float a[12]; };
 // NZ: the mask operand is a tile's input image and M = (im != 0), the mask scripts/demo_test.py:88-89 builds
 // (1 where the image is non-zero, also where it is negative or NaN) before it calls get_deformed_atlas
-// The atlas texels are read with L1-bypassing loads (global_load_dword sc0 sc1, served by L2).  Measured on MI355X /
-// ROCm 7.2 (gpurun_out/r2_variants*.log): with plain loads this gather returned wrong texels
-// for whole 16-lane groups when the kernel ran inside the tile graphs -- 0.006 % of the voxels of a 256^3 volume with
-// two tiles in flight, none with the sc1 form in 65 volumes -- while the atlas memory itself never changed.
+// The atlas texels are read with L1-bypassing loads (ld_tex above explains why; this kernel keeps round 2's system-scope
+// form, global_load_dword sc0 sc1, which 90 volumes of 256^3 and 6 of 512^3 have been checked with; the agent-scope form
+// measured as clean: profiles/r03_atlas_gather_hazard.txt).
 __device__ __forceinline__ float ld_l2(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// PLAIN: the texel loads as ordinary global_load_dword -- the form that misbehaved; kept behind BFM_ATLAS_PLAIN_LOADS=1
-// for tests/diag/diag_atlas_repro.py only
-template <bool NZ, bool PLAIN = false>
+// LOADS (diagnostic forms behind BFM_ATLAS_PLAIN_LOADS, tests/diag/diag_atlas_flow.py): 0 = what ships (sc0 sc1: system
+// scope, served past the non-coherent caches); 1 = ordinary global_load_dword, the form that misbehaved; 2 = ordinary loads
+// behind an agent-scope acquire at the start of the kernel (buffer_inv sc1: this CU's L1 invalidated); 3 = agent-scope
+// loads (sc1: past the L1, served by the XCD's L2)
+template <bool NZ, int LOADS = 0>
 __global__ void deformed_atlas(const float* __restrict__ mask, const float* __restrict__ rx,
                                const float* __restrict__ ry, const float* __restrict__ rz, const float* X, int nx,
                                int ny, int nz, Aff34 A, int64_t n, float* __restrict__ out) {
+    if (LOADS == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     GRID_STRIDE(i, n) {
         float r = 0.f;
         if (NZ ? (mask[i] != 0.f) : (mask[i] > 0.f)) {
@@ -96,7 +111,9 @@ __global__ void deformed_atlas(const float* __restrict__ mask, const float* __re
                 const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
                 auto at = [&](int a, int b, int c) {
                     const float* q = X + (((int64_t)a * ny + b) * nz + c);
-                    return PLAIN ? *q : ld_l2(q);
+                    if (LOADS == 1 || LOADS == 2) return *q;
+                    if (LOADS == 3) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return ld_l2(q);
                 };
                 const float c00 = at(fx, fy, fz) * wfx + at(cx, fy, fz) * wcx;
                 const float c01 = at(fx, fy, cz) * wfx + at(cx, fy, cz) * wcx;
@@ -120,7 +137,7 @@ __global__ void interp_nearest(const uint32_t* __restrict__ X, int nx, int ny, i
         x = min(max(x, 0), nx - 1); y = min(max(y, 0), ny - 1); z = min(max(z, 0), nz - 1);
         const uint32_t* p = X + (((int64_t)x * ny + y) * nz + z) * C;
         uint32_t* o = out + i * C;
-        for (int c = 0; c < C; ++c) o[c] = p[c];
+        for (int c = 0; c < C; ++c) o[c] = ld_tex(p + c);
     }
 }
 
@@ -263,7 +280,7 @@ __global__ void grid_pull3d(const float* __restrict__ inp, int Bi, int C, int nx
                 for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
                     for (int d = 0; d < 2; ++d) {
-                        float val = src[((int64_t)ix[a] * ny + iy[bb]) * nz + iz[d]];
+                        float val = ld_tex(src + ((int64_t)ix[a] * ny + iy[bb]) * nz + iz[d]);
                         val = val * (float)(sx[a] * sy[bb] * sz[d]);
                         val = val * ((ux[a] * uy[bb]) * uz[d]);
                         acc = first ? val : acc + val;
@@ -361,7 +378,7 @@ __global__ void grid_grad3d(const float* __restrict__ inp, int Bi, int C, int nx
                 for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
                     for (int d = 0; d < 2; ++d) {
-                        float val = src[((int64_t)ix[a] * ny + iy[bb]) * nz + iz[d]];
+                        float val = ld_tex(src + ((int64_t)ix[a] * ny + iy[bb]) * nz + iz[d]);
                         val = val * (float)(sx[a] * sy[bb] * sz[d]);
                         ax = fmaf(val, dx[a] * (uy[bb] * uz[d]), ax);
                         ay = fmaf(val, dx[bb] * (ux[a] * uz[d]), ay);
@@ -521,14 +538,15 @@ extern "C" int bfm_deformed_atlas_tile(const float* tile_in, const float* regx, 
         return BFM_E_ARG;
     Aff34 A;
     for (int i = 0; i < 12; ++i) A.a[i] = A_host[i];
-    static int plain = -1;                                     // diagnostic switch (tests/diag/diag_atlas_repro.py)
-    if (plain < 0) { const char* e = getenv("BFM_ATLAS_PLAIN_LOADS"); plain = (e && e[0] == '1') ? 1 : 0; }
-    if (plain)
-        hipLaunchKernelGGL((deformed_atlas<true, true>), dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), tile_in, regx, regy,
-                           regz, atlas, nx, ny, nz, A, n, out);
-    else
-        hipLaunchKernelGGL((deformed_atlas<true, false>), dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), tile_in, regx, regy,
-                           regz, atlas, nx, ny, nz, A, n, out);
+    static int loads = -1;                                     // diagnostic switch (tests/diag/diag_atlas_flow.py)
+    if (loads < 0) { const char* e = getenv("BFM_ATLAS_PLAIN_LOADS"); loads = e ? atoi(e) : 0; }
+#define BFM_ATLAS_LAUNCH(V) hipLaunchKernelGGL((deformed_atlas<true, V>), dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), \
+                                               tile_in, regx, regy, regz, atlas, nx, ny, nz, A, n, out)
+    if (loads == 1) BFM_ATLAS_LAUNCH(1);
+    else if (loads == 2) BFM_ATLAS_LAUNCH(2);
+    else if (loads == 3) BFM_ATLAS_LAUNCH(3);
+    else BFM_ATLAS_LAUNCH(0);
+#undef BFM_ATLAS_LAUNCH
     return bfm_launch_status();
 }
 

@@ -42,6 +42,30 @@ def one(lane, rows, out, atlas):
                                         256, A, n, L.ptr(out), L.stream_ptr()), "atlas")
 
 
+# a co-runner that fills its LDS by LDS-DMA (global_load_lds_dwordx4), the way the conv kernels of the tile flow do
+from brainfm_amd import test_utils as TU
+from brainfm_amd.engine import _Layer
+ga, ta = TU.default_inference_args(f_maps=64, num_levels=6)
+eng = TU.InferenceSession(ga, ta, dev).engine
+cin = cout = 128
+cd = (40, 40, 40)
+cA = torch.randn(*cd, cin, device=dev)
+cscale, cshift, cbound = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1, torch.full((8,), 6.0, device=dev)
+cout_t, cws = torch.empty(*cd, cout, device=dev), torch.empty(1 << 26, dtype=torch.uint8, device=dev)
+ly = _Layer(); ly.name, ly.cin, ly.cout, ly.groups = "corunner", cin, cout, 8
+ly.w_raw = (torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05).contiguous()
+ly.packs, ly.kind, ly.wpacked, ly.wexp, ly.skip = {}, None, None, 0, None
+ccfg = (C.c_int * 8)(); L.check(lib.bfm_conv3x3x3_mfma_plan(cin, cout, cd[0], cd[1], cd[2], ccfg), "plan"); ccfg[6] = 0
+
+
+def conv_beside(k=6):
+    for _ in range(k):
+        eng._conv_launch(ly, cA, cin, None, 0, cd, None, cscale, cshift, cbound, 8, ccfg, cout_t, cws)
+
+
+conv_beside(1)
+torch.cuda.synchronize()
+
 for name, atlas in atlases.items():
     # expected outputs: one serial, synchronised run per lane (with the same loads; a constant atlas has its own check)
     want = []
@@ -54,7 +78,8 @@ for name, atlas in atlases.items():
         if name.startswith("constant"):
             inside = out != 0
             assert bool(((out == 100.0) | ~inside).all()), "serial run already wrong"
-    for mode in ("graph replay, two lanes", "graph replay, two lanes + 1 GB streaming beside", "eager, two lanes"):
+    for mode in ("graph replay, two lanes", "graph replay, two lanes + 1 GB streaming beside", "eager, two lanes",
+                 "graph replay, two lanes + conv_mfma (LDS-DMA) beside", "eager, one lane + conv_mfma (LDS-DMA) beside"):
         bufs, graphs = [], []
         for lane in range(2):
             rows = [torch.empty(n, device=dev) for _ in range(3)]
@@ -76,14 +101,17 @@ for name, atlas in atlases.items():
             if "streaming" in mode:
                 with torch.cuda.stream(side):
                     big.mul_(1.0)
-            for lane in range(2):
+            if "conv_mfma" in mode:
+                with torch.cuda.stream(side):
+                    conv_beside()
+            for lane in range(1 if "one lane" in mode else 2):
                 with torch.cuda.stream(streams[lane]):
                     if graphs:
                         graphs[lane].replay()
                     else:
                         one(lane, bufs[lane][0], bufs[lane][1], atlas)
             torch.cuda.synchronize()
-            for lane in range(2):
+            for lane in range(1 if "one lane" in mode else 2):
                 d = bufs[lane][1] != want[lane]
                 b = int(d.sum())
                 if b and bad < 5:

@@ -439,8 +439,13 @@ def test_gathers_inside_captured_graphs_on_two_lanes_keep_their_goldens():
     interpol.grid_pull (bfm_grid_pull3d_linear) -- had only ever run on one stream outside any graph, while the atlas
     gather misbehaved exactly inside two concurrently replaying graphs.  Each is captured in a
     hipGraph per lane (own coordinate and output buffers, one shared source volume), the two graphs are replayed
-    concurrently on two streams 100 times with a third stream streaming 256 MB beside them, and every replay must give
-    the reference's golden bits (interp: exact; grid_pull: 1e-6)."""
+    concurrently on two streams 100 times with a third stream beside them running a convolution that fills its LDS by
+    LDS-DMA (global_load_lds: round 3 found that THIS is what the atlas gather's ordinary loads went wrong beside,
+    tests/diag/diag_atlas_repro.py), and every replay must give the reference's golden bits (interp: exact; grid_pull:
+    1e-6)."""
+    import ctypes as C
+    from brainfm_amd import _lib as L, test_utils as TU
+    from brainfm_amd.engine import _Layer
     from brainfm_amd.generator_utils import fast_3D_interp_torch
     from brainfm_amd.interpol import grid_pull
     d = load_npz("synth_interp.npz")
@@ -449,7 +454,27 @@ def test_gathers_inside_captured_graphs_on_two_lanes_keep_their_goldens():
     vol, grid = T(d2["vol"]), T(d2["grid"])
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     side = torch.cuda.Stream()
-    big = torch.empty(64 * 1024 * 1024, dtype=torch.float32, device=DEV)
+    ga, ta = TU.default_inference_args(f_maps=64, num_levels=6)
+    eng = TU.InferenceSession(ga, ta, torch.device(DEV)).engine
+    cin = cout = 128
+    cd = (40, 40, 40)
+    cA = torch.randn(*cd, cin, device=DEV)
+    csc, csh, cbd = torch.rand(cin, device=DEV) + 0.5, torch.randn(cin, device=DEV) * 0.1, torch.full((8,), 6.0, device=DEV)
+    cout_t, cws = torch.empty(*cd, cout, device=DEV), torch.empty(1 << 26, dtype=torch.uint8, device=DEV)
+    ly = _Layer()
+    ly.name, ly.cin, ly.cout, ly.groups = "corunner", cin, cout, 8
+    ly.w_raw = (torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05).contiguous()
+    ly.packs, ly.kind, ly.wpacked, ly.wexp, ly.skip = {}, None, None, 0, None
+    ccfg = (C.c_int * 8)()
+    L.check(eng.lib.bfm_conv3x3x3_mfma_plan(cin, cout, cd[0], cd[1], cd[2], ccfg), "plan")
+    ccfg[6] = 0                                                     # conv_mfma: weights through an LDS-DMA ring
+
+    def conv_beside():
+        for _ in range(6):
+            eng._conv_launch(ly, cA, cin, None, 0, cd, None, csc, csh, cbd, 8, ccfg, cout_t, cws)
+
+    conv_beside()
+    torch.cuda.synchronize()
     lanes = []
     for lane in range(2):
         ii, jj, kk = T(d["II"]), T(d["JJ"]), T(d["KK"])            # private coordinate buffers per lane
@@ -474,7 +499,7 @@ def test_gathers_inside_captured_graphs_on_two_lanes_keep_their_goldens():
                 v.fill_(float("nan"))
         torch.cuda.synchronize()
         with torch.cuda.stream(side):
-            big.mul_(1.0)
+            conv_beside()
         for lane, (g, _) in enumerate(lanes):
             with torch.cuda.stream(streams[lane]):
                 g.replay()
