@@ -305,6 +305,97 @@ __device__ __forceinline__ void finalize_group(PartTab ta, PartTab tb, int G, in
     }
 }
 
+// finalize_group on ONE wave, bit for bit: the wave walks the block version's TPB virtual threads 64 at a time (same
+// {channel, part} split, same order of every sum), so the last-arriving block of rows_reduce_finalize runs TPB / 64
+// groups side by side with no workgroup barrier.  lds: this wave's own (cpg + TPB) * 24 bytes.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ void finalize_group_wave(const PartTab& ta, const PartTab& tb, int G, int g,
+                                                    double count_per_channel, float eps, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ scale,
+                                                    float* __restrict__ shift, float* __restrict__ bound,
+                                                    float* __restrict__ mean_out, float* __restrict__ rstd_out, double* lds) {
+    const int lane = threadIdx.x & 63;
+    const int Ctot = ta.C + tb.C;
+    const int cpg = Ctot / G;
+    const int c_first = g * cpg;
+    double* chan_s = lds;
+    double* chan_q = chan_s + cpg;
+    double* red_s = chan_q + cpg;
+    double* red_q = red_s + TPB;
+    float* chan_mn = reinterpret_cast<float*>(red_q + TPB);
+    float* chan_mx = chan_mn + cpg;
+    float* red_mn = chan_mx + cpg;
+    float* red_mx = red_mn + TPB;
+
+    const int cpgP = cpg < TPB ? cpg : TPB;
+    const int P = TPB / cpgP;
+    for (int cb = 0; cb < cpg; cb += cpgP) {
+        for (int vt = lane; vt < P * cpgP; vt += 64) {
+            const int cg = cb + vt % cpgP, part = vt / cpgP;
+            double s = 0.0, q = 0.0; float mn = INFINITY, mx = -INFINITY;
+            if (cg < cpg) {
+                const int c = c_first + cg;
+                const PartTab& T = (c < ta.C) ? ta : tb;
+                const int cc = (c < ta.C) ? c : c - ta.C;
+                for (int b = part; b < T.nb; b += P) {
+                    const size_t i = (size_t)b * T.C + cc;
+                    s += T.psum[i]; q += T.psq[i];
+                    mn = fminf(mn, T.pmin[i]); mx = fmaxf(mx, T.pmax[i]);
+                }
+                s *= T.wgt; q *= T.wgt;
+            }
+            red_s[vt] = s; red_q[vt] = q; red_mn[vt] = mn; red_mx[vt] = mx;
+        }
+        wave_lds_sync();
+        for (int cl = lane; cl < cpgP; cl += 64) {
+            const int cg = cb + cl;
+            if (cg < cpg) {
+                double s = red_s[cl], q = red_q[cl]; float mn = red_mn[cl], mx = red_mx[cl];
+                for (int p = 1; p < P; ++p) {
+                    const int i = p * cpgP + cl;
+                    s += red_s[i]; q += red_q[i];
+                    mn = fminf(mn, red_mn[i]); mx = fmaxf(mx, red_mx[i]);
+                }
+                chan_s[cg] = s; chan_q[cg] = q; chan_mn[cg] = mn; chan_mx[cg] = mx;
+            }
+        }
+        wave_lds_sync();
+    }
+    double S = 0.0, Q = 0.0;
+    for (int c = lane; c < cpg; c += 64) { S += chan_s[c]; Q += chan_q[c]; }
+    S = wave_reduce_sum(S);
+    Q = wave_reduce_sum(Q);
+    S = __shfl(S, 0); Q = __shfl(Q, 0);
+    const double n = count_per_channel * (double)cpg;
+    const double dmean = S / n;
+    double var = Q / n - dmean * dmean;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)dmean;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (lane == 0) {
+        if (mean_out) mean_out[g] = mean;
+        if (rstd_out) rstd_out[g] = rstd;
+    }
+    float bmax = 0.f;
+    for (int cg = lane; cg < cpg; cg += 64) {
+        const int c = c_first + cg;
+        const float sc = rstd * gamma[c];
+        const float sh = -sc * mean + beta[c];
+        scale[c] = sc; shift[c] = sh;
+        const float b0 = fabsf(fmaf(chan_mn[cg], sc, sh));
+        const float b1 = fabsf(fmaf(chan_mx[cg], sc, sh));
+        bmax = fmaxf(bmax, fmaxf(b0, b1));
+    }
+    bmax = wave_reduce_max(bmax);
+    if (lane == 0) bound[g] = bmax;
+    wave_lds_sync();                                    // the scratch is re-used by this wave's next group
+}
+
 __global__ void __launch_bounds__(TPB) gn_finalize(PartTab ta, PartTab tb, int G, double count_per_channel,
                                                    float eps, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, float* __restrict__ scale,
@@ -317,7 +408,7 @@ __global__ void __launch_bounds__(TPB) gn_finalize(PartTab ta, PartTab tb, int G
 
 // rows_reduce of up to two sources and gn_finalize in ONE launch: blocks [0, nbA) fold source A's rows, [nbA, nbA + nbB)
 // source B's (a source with <= RR_MAX rows has no blocks: its table is read as it is), every block takes a ticket when
-// its partials are out, and the block that draws the last one runs the finalize of all G groups -- 2-3 launches of a few
+// its partials are out, and the block that draws the last one runs the finalize of all G groups (one wave per group, finalize_group_wave) -- 2-3 launches of a few
 // microseconds per SingleConv become one (690 of the 2 040 launches of a 256^3 volume were these).  The hand-off is the
 // counter form of the release / acquire protocol (cdna_hip_programming.md, Guideline 16): every storing wave drains its
 // stores, the workgroup meets, lane 0 releases at agent scope, drains again and adds to the ticket with a relaxed agent
@@ -397,10 +488,10 @@ __global__ void __launch_bounds__(TPB) rows_reduce_finalize(RowsSrc ra, RowsSrc 
     }
     __syncthreads();
     if (!is_last) return;
-    for (int g = 0; g < G; ++g) {
-        finalize_group(ta, tb, G, g, 0, count_per_channel, eps, gamma, beta, scale, shift, bound, mean_out, rstd_out, smem_d);
-        __syncthreads();                                 // the group's LDS scratch is re-used by the next one
-    }
+    const int cpg = (ta.C + tb.C) / G;
+    double* mine = smem_d + (size_t)(t >> 6) * (cpg + TPB) * 3;      // (cpg + TPB) * 24 bytes per wave
+    for (int g = t >> 6; g < G; g += TPB / 64)
+        finalize_group_wave(ta, tb, G, g, count_per_channel, eps, gamma, beta, scale, shift, bound, mean_out, rstd_out, mine);
 }
 
 struct Plan {
@@ -609,7 +700,7 @@ extern "C" int bfm_gn_stats_rows_train(const void* rowsA, int nrowsA, int CA, co
     if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 7)) return BFM_E_ARG;
     hipStream_t st = bfm_s(stream);
     char* ws = static_cast<char*>(workspace);
-    if (ticket && needA + needB > 0) {
+    if (ticket && needA + needB > 0 && (size_t)(TPB / 64) * (cpg + TPB) * 24 <= 64 * 1024) {
         // one launch: the blocks that fold the large tables also run the finalize (rows_reduce_finalize)
         auto src = [&](const void* rows, int nrows, int C, double wgt, char* w, RowsSrc& rs, int& nb) {
             RowsView v = rows_view(rows, nrows, C);
@@ -630,7 +721,7 @@ extern "C" int bfm_gn_stats_rows_train(const void* rowsA, int nrowsA, int CA, co
         PartTab ta = src(rowsA, nrowsA, CA, 1.0, ws, ra, nbA);
         PartTab tb{nullptr, nullptr, nullptr, nullptr, 0, 0, 1.0};
         if (CB > 0) tb = src(rowsB, nrowsB, CB, weightB, ws + needA, rb, nbB);
-        const size_t smem = std::max(fin_smem, (size_t)TPB * 24);
+        const size_t smem = (size_t)(TPB / 64) * (cpg + TPB) * 24;      // one finalize scratch per wave (>= the fold's TPB * 24)
         hipLaunchKernelGGL(rows_reduce_finalize, dim3(nbA + nbB), dim3(TPB), smem, st, ra, rb, nbA, nbB, ta, tb, G,
                            (double)nvox, eps, gamma, beta, scale, shift, bound, mean_out, rstd_out, static_cast<int*>(ticket));
         return bfm_launch_status();
