@@ -308,6 +308,15 @@ __device__ __forceinline__ void finalize_group(PartTab ta, PartTab tb, int G, in
 // finalize_group on ONE wave, bit for bit: the wave walks the block version's TPB virtual threads 64 at a time (same
 // {channel, part} split, same order of every sum), so the last-arriving block of rows_reduce_finalize runs TPB / 64
 // groups side by side with no workgroup barrier.  lds: this wave's own (cpg + TPB) * 24 bytes.
+template <typename T>
+__device__ __forceinline__ T ld_agent(const T* p) {          // coherent across the XCDs' L2s without a cache invalidate
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T>
+__device__ __forceinline__ void st_agent(T* p, T v) {        // written through to where every XCD sees it
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -344,8 +353,8 @@ __device__ __forceinline__ void finalize_group_wave(const PartTab& ta, const Par
                 const int cc = (c < ta.C) ? c : c - ta.C;
                 for (int b = part; b < T.nb; b += P) {
                     const size_t i = (size_t)b * T.C + cc;
-                    s += T.psum[i]; q += T.psq[i];
-                    mn = fminf(mn, T.pmin[i]); mx = fmaxf(mx, T.pmax[i]);
+                    s += ld_agent(T.psum + i); q += ld_agent(T.psq + i);
+                    mn = fminf(mn, ld_agent(T.pmin + i)); mx = fmaxf(mx, ld_agent(T.pmax + i));
                 }
                 s *= T.wgt; q *= T.wgt;
             }
@@ -409,11 +418,14 @@ __global__ void __launch_bounds__(TPB) gn_finalize(PartTab ta, PartTab tb, int G
 // rows_reduce of up to two sources and gn_finalize in ONE launch: blocks [0, nbA) fold source A's rows, [nbA, nbA + nbB)
 // source B's (a source with <= RR_MAX rows has no blocks: its table is read as it is), every block takes a ticket when
 // its partials are out, and the block that draws the last one runs the finalize of all G groups (one wave per group, finalize_group_wave) -- 2-3 launches of a few
-// microseconds per SingleConv become one (690 of the 2 040 launches of a 256^3 volume were these).  The hand-off is the
-// counter form of the release / acquire protocol (cdna_hip_programming.md, Guideline 16): every storing wave drains its
-// stores, the workgroup meets, lane 0 releases at agent scope, drains again and adds to the ticket with a relaxed agent
-// atomic; the last arriver acquires at agent scope before any wave of it reads the other blocks' partials.  The order of
-// every sum is what the separate launches had: same bits.  *ticket is zero on entry and is left zero.
+// microseconds per SingleConv become one (690 of the 2 040 launches of a 256^3 volume were these).  The hand-off uses
+// per-access scope instead of fences: an agent-scope release / acquire pair costs an L2 write-back per block and an L2
+// invalidate (eight XCDs, eight L2s) -- measured 36 us at best for this kernel and every neighbouring conv slowed by
+// the lost L2 contents.  So the partials are stored with agent-scope (write-through) stores, every storing wave waits
+// for their acknowledgement (vmcnt(0)), the workgroup meets, lane 0 adds to the ticket with a relaxed agent atomic,
+// and the last arriver reads the partials with agent-scope loads (which do not trust a stale L2 line); no cache-wide
+// operation anywhere.  The order of every sum is what the separate launches had: same bits.  *ticket is zero on
+// entry and is left zero.
 struct RowsSrc {
     const double *rsum, *rsq;
     const float *rmn, *rmx;
@@ -467,24 +479,18 @@ __global__ void __launch_bounds__(TPB) rows_reduce_finalize(RowsSrc ra, RowsSrc 
                     mn = fminf(mn, lmn[i]); mx = fmaxf(mx, lmx[i]);
                 }
                 const size_t o = (size_t)blk * C + col;
-                psum[o] = sv; psq[o] = qv; pmin[o] = mn; pmax[o] = mx;
+                st_agent(psum + o, sv); st_agent(psq + o, qv); st_agent(pmin + o, mn); st_agent(pmax + o, mx);
             }
             __syncthreads();
         }
     }
     // ---- publish, take a ticket
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's stores have left
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through stores are acknowledged
     __syncthreads();
     if (t == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the compiler may drop the fence's own wait: Guideline 16, pitfall 12)
         const int got = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         is_last = got == nbA + nbB - 1;
-        if (is_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // everyone has arrived
-        }
+        if (is_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // everyone has arrived
     }
     __syncthreads();
     if (!is_last) return;
