@@ -205,23 +205,24 @@ __global__ void __launch_bounds__(TPB) rows_reduce(const double* __restrict__ rs
 
 // One block per group.  Dynamic LDS: chan_s[cpg], chan_q[cpg] (double), chan_mn[cpg], chan_mx[cpg] (float),
 // red_s[TPB], red_q[TPB] (double), red_mn[TPB], red_mx[TPB] (float)
-__device__ __forceinline__ void finalize_group(PartTab ta, PartTab tb, int G, int g, int sample, double count_per_channel,
-                                               float eps, const float* __restrict__ gamma,
-                                               const float* __restrict__ beta, float* __restrict__ scale,
-                                               float* __restrict__ shift, float* __restrict__ bound,
-                                               float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                               double* smem_d) {
+__global__ void __launch_bounds__(TPB) gn_finalize(PartTab ta, PartTab tb, int G, double count_per_channel,
+                                                   float eps, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float* __restrict__ scale,
+                                                   float* __restrict__ shift, float* __restrict__ bound,
+                                                   float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    extern __shared__ double smem_d[];
     const int t = threadIdx.x;
+    const int g = blockIdx.x;
     const int Ctot = ta.C + tb.C;
     const int cpg = Ctot / G;
     const int c_first = g * cpg;
-    if (sample) {       // sample of a batch: tables [S][nb][C] inside each plane, outputs [S][Ctot] / [S][G]
-        const size_t oa = (size_t)sample * ta.nb * ta.C, ob = (size_t)sample * tb.nb * tb.C;
+    if (blockIdx.y) {   // sample of a batch: tables [S][nb][C] inside each plane, outputs [S][Ctot] / [S][G]
+        const size_t oa = (size_t)blockIdx.y * ta.nb * ta.C, ob = (size_t)blockIdx.y * tb.nb * tb.C;
         ta.psum += oa; ta.psq += oa; ta.pmin += oa; ta.pmax += oa;
         if (tb.C) { tb.psum += ob; tb.psq += ob; tb.pmin += ob; tb.pmax += ob; }
-        scale += (size_t)sample * Ctot; shift += (size_t)sample * Ctot; bound += (size_t)sample * G;
-        if (mean_out) mean_out += (size_t)sample * G;
-        if (rstd_out) rstd_out += (size_t)sample * G;
+        scale += (size_t)blockIdx.y * Ctot; shift += (size_t)blockIdx.y * Ctot; bound += (size_t)blockIdx.y * G;
+        if (mean_out) mean_out += (size_t)blockIdx.y * G;
+        if (rstd_out) rstd_out += (size_t)blockIdx.y * G;
     }
 
     double* chan_s = smem_d;
@@ -303,201 +304,6 @@ __device__ __forceinline__ void finalize_group(PartTab ta, PartTab tb, int G, in
         for (int i = 0; i < TPB / 64; ++i) b = fmaxf(b, red_mx[i]);
         bound[g] = b;
     }
-}
-
-// finalize_group on ONE wave, bit for bit: the wave walks the block version's TPB virtual threads 64 at a time (same
-// {channel, part} split, same order of every sum), so the last-arriving block of rows_reduce_finalize runs TPB / 64
-// groups side by side with no workgroup barrier.  lds: this wave's own (cpg + TPB) * 24 bytes.
-template <typename T>
-__device__ __forceinline__ T ld_agent(const T* p) {          // coherent across the XCDs' L2s without a cache invalidate
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <typename T>
-__device__ __forceinline__ void st_agent(T* p, T v) {        // written through to where every XCD sees it
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ void finalize_group_wave(const PartTab& ta, const PartTab& tb, int G, int g,
-                                                    double count_per_channel, float eps, const float* __restrict__ gamma,
-                                                    const float* __restrict__ beta, float* __restrict__ scale,
-                                                    float* __restrict__ shift, float* __restrict__ bound,
-                                                    float* __restrict__ mean_out, float* __restrict__ rstd_out, double* lds) {
-    const int lane = threadIdx.x & 63;
-    const int Ctot = ta.C + tb.C;
-    const int cpg = Ctot / G;
-    const int c_first = g * cpg;
-    double* chan_s = lds;
-    double* chan_q = chan_s + cpg;
-    double* red_s = chan_q + cpg;
-    double* red_q = red_s + TPB;
-    float* chan_mn = reinterpret_cast<float*>(red_q + TPB);
-    float* chan_mx = chan_mn + cpg;
-    float* red_mn = chan_mx + cpg;
-    float* red_mx = red_mn + TPB;
-
-    const int cpgP = cpg < TPB ? cpg : TPB;
-    const int P = TPB / cpgP;
-    for (int cb = 0; cb < cpg; cb += cpgP) {
-        for (int vt = lane; vt < P * cpgP; vt += 64) {
-            const int cg = cb + vt % cpgP, part = vt / cpgP;
-            double s = 0.0, q = 0.0; float mn = INFINITY, mx = -INFINITY;
-            if (cg < cpg) {
-                const int c = c_first + cg;
-                const PartTab& T = (c < ta.C) ? ta : tb;
-                const int cc = (c < ta.C) ? c : c - ta.C;
-                for (int b = part; b < T.nb; b += P) {
-                    const size_t i = (size_t)b * T.C + cc;
-                    s += ld_agent(T.psum + i); q += ld_agent(T.psq + i);
-                    mn = fminf(mn, ld_agent(T.pmin + i)); mx = fmaxf(mx, ld_agent(T.pmax + i));
-                }
-                s *= T.wgt; q *= T.wgt;
-            }
-            red_s[vt] = s; red_q[vt] = q; red_mn[vt] = mn; red_mx[vt] = mx;
-        }
-        wave_lds_sync();
-        for (int cl = lane; cl < cpgP; cl += 64) {
-            const int cg = cb + cl;
-            if (cg < cpg) {
-                double s = red_s[cl], q = red_q[cl]; float mn = red_mn[cl], mx = red_mx[cl];
-                for (int p = 1; p < P; ++p) {
-                    const int i = p * cpgP + cl;
-                    s += red_s[i]; q += red_q[i];
-                    mn = fminf(mn, red_mn[i]); mx = fmaxf(mx, red_mx[i]);
-                }
-                chan_s[cg] = s; chan_q[cg] = q; chan_mn[cg] = mn; chan_mx[cg] = mx;
-            }
-        }
-        wave_lds_sync();
-    }
-    double S = 0.0, Q = 0.0;
-    for (int c = lane; c < cpg; c += 64) { S += chan_s[c]; Q += chan_q[c]; }
-    S = wave_reduce_sum(S);
-    Q = wave_reduce_sum(Q);
-    S = __shfl(S, 0); Q = __shfl(Q, 0);
-    const double n = count_per_channel * (double)cpg;
-    const double dmean = S / n;
-    double var = Q / n - dmean * dmean;
-    if (var < 0.0) var = 0.0;
-    const float mean = (float)dmean;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    if (lane == 0) {
-        if (mean_out) mean_out[g] = mean;
-        if (rstd_out) rstd_out[g] = rstd;
-    }
-    float bmax = 0.f;
-    for (int cg = lane; cg < cpg; cg += 64) {
-        const int c = c_first + cg;
-        const float sc = rstd * gamma[c];
-        const float sh = -sc * mean + beta[c];
-        scale[c] = sc; shift[c] = sh;
-        const float b0 = fabsf(fmaf(chan_mn[cg], sc, sh));
-        const float b1 = fabsf(fmaf(chan_mx[cg], sc, sh));
-        bmax = fmaxf(bmax, fmaxf(b0, b1));
-    }
-    bmax = wave_reduce_max(bmax);
-    if (lane == 0) bound[g] = bmax;
-    wave_lds_sync();                                    // the scratch is re-used by this wave's next group
-}
-
-__global__ void __launch_bounds__(TPB) gn_finalize(PartTab ta, PartTab tb, int G, double count_per_channel,
-                                                   float eps, const float* __restrict__ gamma,
-                                                   const float* __restrict__ beta, float* __restrict__ scale,
-                                                   float* __restrict__ shift, float* __restrict__ bound,
-                                                   float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-    extern __shared__ double smem_d[];
-    finalize_group(ta, tb, G, blockIdx.x, blockIdx.y, count_per_channel, eps, gamma, beta, scale, shift, bound, mean_out,
-                   rstd_out, smem_d);
-}
-
-// rows_reduce of up to two sources and gn_finalize in ONE launch: blocks [0, nbA) fold source A's rows, [nbA, nbA + nbB)
-// source B's (a source with <= RR_MAX rows has no blocks: its table is read as it is), every block takes a ticket when
-// its partials are out, and the block that draws the last one runs the finalize of all G groups (one wave per group, finalize_group_wave) -- 2-3 launches of a few
-// microseconds per SingleConv become one (690 of the 2 040 launches of a 256^3 volume were these).  The hand-off uses
-// per-access scope instead of fences: an agent-scope release / acquire pair costs an L2 write-back per block and an L2
-// invalidate (eight XCDs, eight L2s) -- measured 36 us at best for this kernel and every neighbouring conv slowed by
-// the lost L2 contents.  So the partials are stored with agent-scope (write-through) stores, every storing wave waits
-// for their acknowledgement (vmcnt(0)), the workgroup meets, lane 0 adds to the ticket with a relaxed agent atomic,
-// and the last arriver reads the partials with agent-scope loads (which do not trust a stale L2 line); no cache-wide
-// operation anywhere.  The order of every sum is what the separate launches had: same bits.  *ticket is zero on
-// entry and is left zero.
-struct RowsSrc {
-    const double *rsum, *rsq;
-    const float *rmn, *rmx;
-    int nrows, rpb;
-};
-
-__global__ void __launch_bounds__(TPB) rows_reduce_finalize(RowsSrc ra, RowsSrc rb, int nbA, int nbB, PartTab ta, PartTab tb,
-                                                            int G, double count_per_channel, float eps,
-                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ scale, float* __restrict__ shift,
-                                                            float* __restrict__ bound, float* __restrict__ mean_out,
-                                                            float* __restrict__ rstd_out, int* __restrict__ ticket) {
-    extern __shared__ double smem_d[];
-    __shared__ int is_last;
-    const int t = threadIdx.x;
-    {
-        const bool second = (int)blockIdx.x >= nbA;
-        const RowsSrc& rs = second ? rb : ra;
-        const PartTab& pt = second ? tb : ta;
-        const int blk = second ? blockIdx.x - nbA : blockIdx.x;
-        const int C = pt.C;
-        const int r0 = blk * rs.rpb;
-        const int r1 = min(rs.nrows, r0 + rs.rpb);
-        const int CP = C < TPB ? C : TPB;              // columns in flight
-        const int RP = TPB / CP;                        // rows in flight
-        double* ls = smem_d;
-        double* lq = ls + TPB;
-        float* lmn = reinterpret_cast<float*>(lq + TPB);
-        float* lmx = lmn + TPB;
-        double* psum = const_cast<double*>(pt.psum);
-        double* psq = const_cast<double*>(pt.psq);
-        float* pmin = const_cast<float*>(pt.pmin);
-        float* pmax = const_cast<float*>(pt.pmax);
-        for (int cb = 0; cb < C; cb += CP) {
-            const int col = cb + t % CP, part = t / CP;
-            double sv = 0.0, qv = 0.0;
-            float mn = INFINITY, mx = -INFINITY;
-            if (part < RP && col < C) {
-                for (int r = r0 + part; r < r1; r += RP) {
-                    const size_t i = (size_t)r * C + col;
-                    sv += rs.rsum[i]; qv += rs.rsq[i];
-                    mn = fminf(mn, rs.rmn[i]); mx = fmaxf(mx, rs.rmx[i]);
-                }
-            }
-            ls[t] = sv; lq[t] = qv; lmn[t] = mn; lmx[t] = mx;
-            __syncthreads();
-            if (part == 0 && col < C) {
-                for (int pp = 1; pp < RP; ++pp) {
-                    const int i = pp * CP + (t % CP);
-                    sv += ls[i]; qv += lq[i];
-                    mn = fminf(mn, lmn[i]); mx = fmaxf(mx, lmx[i]);
-                }
-                const size_t o = (size_t)blk * C + col;
-                st_agent(psum + o, sv); st_agent(psq + o, qv); st_agent(pmin + o, mn); st_agent(pmax + o, mx);
-            }
-            __syncthreads();
-        }
-    }
-    // ---- publish, take a ticket
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through stores are acknowledged
-    __syncthreads();
-    if (t == 0) {
-        const int got = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = got == nbA + nbB - 1;
-        if (is_last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // everyone has arrived
-    }
-    __syncthreads();
-    if (!is_last) return;
-    const int cpg = (ta.C + tb.C) / G;
-    double* mine = smem_d + (size_t)(t >> 6) * (cpg + TPB) * 3;      // (cpg + TPB) * 24 bytes per wave
-    for (int g = t >> 6; g < G; g += TPB / 64)
-        finalize_group_wave(ta, tb, G, g, count_per_channel, eps, gamma, beta, scale, shift, bound, mean_out, rstd_out, mine);
 }
 
 struct Plan {
@@ -690,10 +496,8 @@ extern "C" size_t bfm_gn_stats_rows_workspace(int nrowsA, int CA, int nrowsB, in
 extern "C" int bfm_gn_stats_rows_train(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB,
                                        double weightB, int64_t nvox, const float* gamma, const float* beta, int G,
                                        float eps, float* scale, float* shift, float* bound, float* mean_out,
-                                       float* rstd_out, void* workspace, size_t workspace_bytes, void* ticket,
-                                       bfm_stream_t stream) {
+                                       float* rstd_out, void* workspace, size_t workspace_bytes, bfm_stream_t stream) {
     if (!rowsA || nrowsA <= 0 || CA <= 0 || nvox <= 0 || !gamma || !beta || !scale || !shift || !bound) return BFM_E_ARG;
-    if (ticket && (reinterpret_cast<uintptr_t>(ticket) & 3)) return BFM_E_ARG;
     if (CB < 0 || (CB > 0 && (!rowsB || nrowsB <= 0 || !(weightB > 0.0)))) return BFM_E_ARG;
     if ((reinterpret_cast<uintptr_t>(rowsA) & 7) || (CB > 0 && (reinterpret_cast<uintptr_t>(rowsB) & 7))) return BFM_E_ARG;
     const int Ctot = CA + CB;
@@ -706,32 +510,6 @@ extern "C" int bfm_gn_stats_rows_train(const void* rowsA, int nrowsA, int CA, co
     if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 7)) return BFM_E_ARG;
     hipStream_t st = bfm_s(stream);
     char* ws = static_cast<char*>(workspace);
-    if (ticket && needA + needB > 0 && (size_t)(TPB / 64) * (cpg + TPB) * 24 <= 64 * 1024) {
-        // one launch: the blocks that fold the large tables also run the finalize (rows_reduce_finalize)
-        auto src = [&](const void* rows, int nrows, int C, double wgt, char* w, RowsSrc& rs, int& nb) {
-            RowsView v = rows_view(rows, nrows, C);
-            if (nrows <= RR_MAX) {
-                rs = RowsSrc{v.sum, v.sq, v.mn, v.mx, nrows, 0};
-                nb = 0;
-                return PartTab{v.sum, v.sq, v.mn, v.mx, nrows, C, wgt};
-            }
-            const int rpb = bfm_cdiv(nrows, RR_MAX);
-            nb = bfm_cdiv(nrows, rpb);
-            rs = RowsSrc{v.sum, v.sq, v.mn, v.mx, nrows, rpb};
-            const size_t n = (size_t)RR_MAX * C;
-            return PartTab{reinterpret_cast<double*>(w), reinterpret_cast<double*>(w + n * 8),
-                           reinterpret_cast<float*>(w + n * 16), reinterpret_cast<float*>(w + n * 20), nb, C, wgt};
-        };
-        RowsSrc ra{}, rb{};
-        int nbA = 0, nbB = 0;
-        PartTab ta = src(rowsA, nrowsA, CA, 1.0, ws, ra, nbA);
-        PartTab tb{nullptr, nullptr, nullptr, nullptr, 0, 0, 1.0};
-        if (CB > 0) tb = src(rowsB, nrowsB, CB, weightB, ws + needA, rb, nbB);
-        const size_t smem = (size_t)(TPB / 64) * (cpg + TPB) * 24;      // one finalize scratch per wave (>= the fold's TPB * 24)
-        hipLaunchKernelGGL(rows_reduce_finalize, dim3(nbA + nbB), dim3(TPB), smem, st, ra, rb, nbA, nbB, ta, tb, G,
-                           (double)nvox, eps, gamma, beta, scale, shift, bound, mean_out, rstd_out, static_cast<int*>(ticket));
-        return bfm_launch_status();
-    }
     PartTab ta = rows_source(rowsA, nrowsA, CA, 1.0, ws, st);
     PartTab tb{nullptr, nullptr, nullptr, nullptr, 0, 0, 1.0};
     if (CB > 0) tb = rows_source(rowsB, nrowsB, CB, weightB, ws + needA, st);
@@ -769,7 +547,7 @@ extern "C" int bfm_gn_stats_rows_batch(const void* rowsA, int nrowsA, int CA, co
 extern "C" int bfm_gn_stats_rows(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB,
                                  double weightB, int64_t nvox, const float* gamma, const float* beta, int G, float eps,
                                  float* scale, float* shift, float* bound, void* workspace, size_t workspace_bytes,
-                                 void* ticket, bfm_stream_t stream) {
+                                 bfm_stream_t stream) {
     return bfm_gn_stats_rows_train(rowsA, nrowsA, CA, rowsB, nrowsB, CB, weightB, nvox, gamma, beta, G, eps, scale, shift,
-                                   bound, nullptr, nullptr, workspace, workspace_bytes, ticket, stream);
+                                   bound, nullptr, nullptr, workspace, workspace_bytes, stream);
 }

@@ -474,59 +474,6 @@ def test_upsample_folded_conv_split_k_on_small_levels(lo):
     assert e <= 3e-6, e
 
 
-@pytest.mark.parametrize("shape", [(300, 64, 0, 0, 8), (1000, 32, 90, 64, 8), (40, 128, 4000, 256, 8), (700, 256, 513, 512, 8),
-                                   (2000, 1, 0, 0, 1)])
-def test_groupnorm_from_rows_one_launch_equals_the_separate_launches(shape):
-    """bfm_gn_stats_rows with a ticket (rows fold + finalize in one launch, the last-arriving block finalizes one
-    group per wave) must give the bits of the ticket-less form (rows_reduce per source, then gn_finalize), and must
-    leave its ticket at zero -- three times over, so a stale ticket would show."""
-    from brainfm_amd import _lib as L
-    lib = L.load()
-    na, ca, nb, cb, G = shape
-    dev = _dev()
-    g = torch.Generator().manual_seed(na + cb)
-
-    def table(n, c):
-        v = torch.randn(n, c, 40, generator=g)
-        buf = torch.empty(n * c * 24, dtype=torch.uint8)
-        k = n * c
-        buf[:k * 8] = v.double().sum(2).contiguous().view(-1).view(torch.uint8)
-        buf[k * 8:k * 16] = (v.double() ** 2).sum(2).contiguous().view(-1).view(torch.uint8)
-        buf[k * 16:k * 20] = v.min(2)[0].contiguous().view(-1).view(torch.uint8)
-        buf[k * 20:k * 24] = v.max(2)[0].contiguous().view(-1).view(torch.uint8)
-        return buf.to(dev)
-
-    A = table(na, ca)
-    B = table(nb, cb) if cb else None
-    C = ca + cb
-    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
-    beta = torch.randn(C, generator=g).to(dev)
-    need = lib.bfm_gn_stats_rows_workspace(na, ca, nb, cb)
-    ws = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
-    ticket = torch.zeros(16, dtype=torch.int32, device=dev)
-    st = L.stream_ptr()
-
-    def run(tk):
-        out = [torch.full((C,), float("nan"), device=dev), torch.full((C,), float("nan"), device=dev),
-               torch.full((G,), float("nan"), device=dev), torch.full((G,), float("nan"), device=dev),
-               torch.full((G,), float("nan"), device=dev)]
-        ws.zero_()
-        L.check(lib.bfm_gn_stats_rows_train(L.ptr(A), na, ca, L.ptr(B) if B is not None else None, nb, cb, 8.0,
-                                            40 * na, L.ptr(gamma), L.ptr(beta), G, 1e-5, L.ptr(out[0]), L.ptr(out[1]),
-                                            L.ptr(out[2]), L.ptr(out[3]), L.ptr(out[4]), L.ptr(ws), need,
-                                            L.ptr(tk) if tk is not None else None, st), "gn_stats_rows")
-        torch.cuda.synchronize()
-        return out
-
-    ref = run(None)
-    assert all(bool(torch.isfinite(o).all()) for o in ref)
-    for _ in range(3):
-        got = run(ticket)
-        for r, o in zip(ref, got):
-            assert torch.equal(r, o)
-        assert int(ticket.abs().sum()) == 0
-
-
 @pytest.mark.parametrize("ver", [0, 2, 3])
 def test_producer_moment_rows_equal_activation_moments(ver, monkeypatch):
     """The per-tile {sum, sumsq, min, max} rows written by the stem / conv epilogues must be the moments of the
