@@ -72,14 +72,14 @@ SIGNATURES = {
     "bfm_conv3x3x3_upfold_workspace": (_Z, [_I, _I, _I, _I, _I]),
     "bfm_conv3x3x3_upfold_ex": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _Z, _P]),
     "bfm_conv3x3x3_upfold_batch_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
-    "bfm_conv3x3x3_upfold_batch": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _Z, _P]),
+    "bfm_conv3x3x3_upfold_batch": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _Z, _I, _P]),
     "bfm_moment_rows_bytes": (_Z, [_I, _I]),
     "bfm_conv3x3x3_mfma_rows": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),
     "bfm_conv3x3x3_mfma_ex": (_I, [_P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _P, _I, _P, _I, _I, _F, _I,
                                    C.POINTER(_I), _P, _P, _Z, _P, _P]),
     "bfm_conv3x3x3_mfma_batch_workspace": (_Z, [_I, _I, _I, _I, _I, _I, _I]),
     "bfm_conv3x3x3_mfma_batch": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _UP, _P, _P, _P, _I, _P, _I, _I, _F, _I,
-                                      C.POINTER(_I), _P, _P, _Z, _P, _P]),
+                                      C.POINTER(_I), _P, _P, _Z, _P, _I, _P]),
     "bfm_gn_stats_batch_workspace": (_Z, [_I, _I, _I, _I, _I, _I, _UP]),
     "bfm_gn_stats_batch": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _UP, _P, _P, _I, _F, _P, _P, _P, _P, _Z, _P]),
     "bfm_gn_stats_rows_batch": (_I, [_P, _I, _I, _P, _I, _I, C.c_double, _L, _I, _P, _P, _I, _F, _P, _P, _P, _P]),

@@ -17,6 +17,7 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libbrainfm_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("BFM_HIPCC_EXTRA", "").split()      # diagnostics builds (e.g. -DBFM_STAMPS), never the shipped one
 
 
 def sources():

@@ -196,7 +196,6 @@ constexpr int X_ROW = 32 * X_CH + 8;
 constexpr int X_PLANE = HHR * X_ROW;
 constexpr int WG3_LDS = (2 * DP_PLANE + 2 * X_PLANE) * 4;  // 108.5 KB
 constexpr int WG3_THREADS = 512;
-constexpr int X_ITEMS = HHR * 9 * 8;                       // (halo row, hx pair, channel quad) = 1728
 
 struct Wg3Params {
     WgParams b;

@@ -34,6 +34,12 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int KC = 16;            // channels per K-chunk
+#ifdef BFM_STAMPS
+__device__ long long g_stamps[4096];
+#define STAMP(i) do { if (stamp_on) g_stamps[stamp_base + (i)] = clock64(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 constexpr int FRAG_U4 = 64;       // one fragment = 64 lanes x uint4
 
 struct ConvParams {
@@ -60,6 +66,7 @@ struct ConvParams {
     // that need the same weight fragments run side by side and share them in L2.  Every workgroup does exactly what it
     // does in the per-sample launch (same box, same K order, same split-K): results are bit-identical.
     int S, nMtS;
+    int saff;                        // elements between two samples' scale / shift rows (CA + CB unless the caller's tables are wider)
     int64_t sA, sB, sO;
     // optional moment rows of the OUTPUT (one row per M tile, [nMt][Cout]): {sum, sumsq} fp64, {min, max} fp32.  The
     // consumer's GroupNorm reduces these instead of re-reading the activation (gn_stats.hip: bfm_gn_stats_rows).
@@ -173,11 +180,16 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(const ConvParams p)
     const int mtl = mt - smp * p.nMtS;                   // tile index inside its sample
     const float* const pA = p.A + smp * p.sA;
     const float* const pB = p.B + smp * p.sB;
-    const float* const pscale = p.scale + smp * (p.CA + p.CB);
-    const float* const pshift = p.shift + smp * (p.CA + p.CB);
+    const float* const pscale = p.scale + smp * p.saff;
+    const float* const pshift = p.shift + smp * p.saff;
     const float* const pbound = p.bound + smp * p.G;
     float* const pout = p.out + smp * p.sO;
     const int split = blockIdx.y;
+#ifdef BFM_STAMPS
+    const bool stamp_on = tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 + 3) && blockIdx.y == gridDim.y / 2;
+    int stamp_base = blockIdx.x == 0 ? 0 : 1024;
+    long long t_wait = 0, t_bar = 0;
+#endif
     const int tx = mtl % p.nTx;
     const int ty = (mtl / p.nTx) % p.nTy;
     const int tz = mtl / (p.nTx * p.nTy);
@@ -308,7 +320,9 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(const ConvParams p)
         const float sc[4] = {sc4.x * a_scale, sc4.y * a_scale, sc4.z * a_scale, sc4.w * a_scale};
         const float sh[4] = {sh4.x * a_scale, sh4.y * a_scale, sh4.z * a_scale, sh4.w * a_scale};
 
+        STAMP((kc - kc_begin) * 8 + 0);
         __syncthreads();                                 // previous chunk's readers are done
+        STAMP((kc - kc_begin) * 8 + 1);
 #pragma unroll
         for (int it0 = 0; it0 < MAX_IT; it0 += 4) {
             float4 v[4];
@@ -337,7 +351,9 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(const ConvParams p)
                 }
             }
         }
+        STAMP((kc - kc_begin) * 8 + 2);
         __syncthreads();
+        STAMP((kc - kc_begin) * 8 + 3);
 
         // ================= 27 taps of MFMA on the staged chunk =================
         // Weights stream through an LDS ring, one (kd,kh) row = 3 taps per slot, filled by LDS-DMA
@@ -347,8 +363,18 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(const ConvParams p)
         const int rbase = (kc - kc_begin) * 9;
         for (int r = 0; r < 9; ++r) {
             const int R = rbase + r;
+#ifdef BFM_STAMPS
+            long long ta = 0, tb = 0, tc = 0;
+            if (stamp_on) ta = clock64();
+#endif
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KPR * (DPF - 1)) : "memory");
+#ifdef BFM_STAMPS
+            if (stamp_on) tb = clock64();
+#endif
             __builtin_amdgcn_s_barrier();
+#ifdef BFM_STAMPS
+            if (stamp_on) { tc = clock64(); t_wait += tb - ta; t_bar += tc - tb; }
+#endif
             issue_row(R + DPF);
             const unsigned char* bs = lds + b_base + ((R % NSLOT) * ROWFR + wn * 12) * 1024 + lane * 16;
             const int kd = r / 3, kh = r - kd * 3;
@@ -381,6 +407,10 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(const ConvParams p)
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // drain the run-ahead DMAs before the LDS is released
+#ifdef BFM_STAMPS
+    if (stamp_on) { g_stamps[stamp_base + 1000] = t_wait; g_stamps[stamp_base + 1001] = t_bar; g_stamps[stamp_base + 1002] = clock64();
+                    g_stamps[stamp_base + 1003] = kc_end - kc_begin; }
+#endif
 
     // ================= epilogue =================
     const bool final_out = p.splitk == 1;
@@ -476,8 +506,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma16(const ConvParams 
     const int mtl = mt - smp * p.nMtS;                   // tile index inside its sample
     const float* const pA = p.A + smp * p.sA;
     const float* const pB = p.B + smp * p.sB;
-    const float* const pscale = p.scale + smp * (p.CA + p.CB);
-    const float* const pshift = p.shift + smp * (p.CA + p.CB);
+    const float* const pscale = p.scale + smp * p.saff;
+    const float* const pshift = p.shift + smp * p.saff;
     const float* const pbound = p.bound + smp * p.G;
     float* const pout = p.out + smp * p.sO;
     const int split = blockIdx.y;
@@ -1218,11 +1248,11 @@ void launch16(const ConvParams& p, int passes, bool wm4, dim3 grid, size_t smem,
 template <int WM, int WN>
 void launch_ws(const ConvParams& p, int passes, dim3 grid, size_t smem, hipStream_t st) {
     if (passes == 3) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_ws<WM, WN, 3>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_ws<WM, WN, 3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_WS);
         hipLaunchKernelGGL((conv_mfma_ws<WM, WN, 3>), grid, dim3(512), smem, st, p);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_ws<WM, WN, 1>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_ws<WM, WN, 1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIMIT_WS);
         hipLaunchKernelGGL((conv_mfma_ws<WM, WN, 1>), grid, dim3(512), smem, st, p);
     }
@@ -1344,7 +1374,7 @@ extern "C" int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB
 static int conv_mfma_launch(const float* A, int CA, const float* B, int CB, int S, int D, int H, int W,
                             const bfm_upsample_t* up, const float* scale, const float* shift, const float* bound, int G,
                             const void* wpacked, int wexp, int Cout, float slope, int passes, const int* cfg, float* out,
-                            void* workspace, size_t workspace_bytes, void* moment_rows, bfm_stream_t stream);
+                            void* workspace, size_t workspace_bytes, void* moment_rows, int affine_stride, bfm_stream_t stream);
 
 extern "C" int bfm_conv3x3x3_mfma_ex(const float* A, int CA, const float* B, int CB, int D, int H, int W,
                                      const bfm_upsample_t* up, const float* scale, const float* shift,
@@ -1352,8 +1382,14 @@ extern "C" int bfm_conv3x3x3_mfma_ex(const float* A, int CA, const float* B, int
                                      int passes, const int* cfg, float* out, void* workspace, size_t workspace_bytes,
                                      void* moment_rows, bfm_stream_t stream) {
     return conv_mfma_launch(A, CA, B, CB, 1, D, H, W, up, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, cfg,
-                            out, workspace, workspace_bytes, moment_rows, stream);
+                            out, workspace, workspace_bytes, moment_rows, 0, stream);
 }
+
+#ifdef BFM_STAMPS
+extern "C" int bfm_debug_stamps(long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(long long) * 4096);
+}
+#endif
 
 extern "C" size_t bfm_conv3x3x3_mfma_batch_workspace(int Cin, int Cout, int S, int D, int H, int W, int splitk) {
     return (size_t)(S < 1 ? 1 : S) * bfm_conv3x3x3_mfma_workspace(Cin, Cout, D, H, W, splitk);
@@ -1363,17 +1399,19 @@ extern "C" int bfm_conv3x3x3_mfma_batch(const float* A, int CA, const float* B, 
                                         const bfm_upsample_t* up, const float* scale, const float* shift,
                                         const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope,
                                         int passes, const int* cfg, float* out, void* workspace, size_t workspace_bytes,
-                                        void* moment_rows, bfm_stream_t stream) {
+                                        void* moment_rows, int affine_stride, bfm_stream_t stream) {
     if (S < 1 || !cfg) return BFM_E_ARG;
+    if (affine_stride != 0 && (affine_stride < CA + CB || (affine_stride & 3))) return BFM_E_ARG;
     if (cfg[6] != 0 && cfg[6] != 2) return BFM_E_SHAPE;        // the persistent and Winograd variants take one sample
     return conv_mfma_launch(A, CA, B, CB, S, D, H, W, up, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, cfg,
-                            out, workspace, workspace_bytes, moment_rows, stream);
+                            out, workspace, workspace_bytes, moment_rows, affine_stride, stream);
 }
 
 static int conv_mfma_launch(const float* A, int CA, const float* B, int CB, int S, int D, int H, int W,
                             const bfm_upsample_t* up, const float* scale, const float* shift, const float* bound, int G,
                             const void* wpacked, int wexp, int Cout, float slope, int passes, const int* cfg, float* out,
-                            void* workspace, size_t workspace_bytes, void* moment_rows, bfm_stream_t stream) {
+                            void* workspace, size_t workspace_bytes, void* moment_rows, int affine_stride,
+                            bfm_stream_t stream) {
     if (!A || CA <= 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || G <= 0 || !wpacked || !out)
         return BFM_E_ARG;
     if (CB < 0 || (CB > 0 && (!B || !up || !up->mapD || !up->mapH || !up->mapW || up->d <= 0 || up->h <= 0 ||
@@ -1409,6 +1447,7 @@ static int conv_mfma_launch(const float* A, int CA, const float* B, int CB, int 
     p.nTy = bfm_cdiv(H, hp.TH); p.nTx = bfm_cdiv(W, hp.TW);
     p.nMtS = nTz * p.nTy * p.nTx;
     p.S = S;
+    p.saff = affine_stride > 0 ? affine_stride : CA + CB;
     p.nMt = S * p.nMtS;
     p.NT = Cout / (64 * hp.WN);
     p.KCN = Cin / KC;

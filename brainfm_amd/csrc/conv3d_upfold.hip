@@ -32,6 +32,7 @@ struct UpParams {
     const float* B;
     int CB, d, h, w;                 // low-res tensor (channels-last)
     const float *scale, *shift;      // GroupNorm affine of the B channels (already offset by CA)
+    int saff;                        // elements between two samples' scale / shift rows
     const float* bound;
     int G;
     const uint4* wp;
@@ -44,7 +45,7 @@ struct UpParams {
     int kc_per_split;                // K chunks per blockIdx.y slab (a multiple of 3: the weight ring's phase period)
     float* slab;                     // split-K: [sample][gridDim.y][2d][2h][2w][Cout] partial sums, summed by upfold_reduce
     int64_t slab_stride;
-    // batch: blockIdx.z = sample; B, out advance by sB, sO elements per sample, scale / shift by CB, bound by G.  A
+    // batch: blockIdx.z = sample; B, out advance by sB, sO elements per sample, scale / shift by saff (CB when the tables are the B half alone), bound by G.  A
     // sample's workgroups do exactly what they do in a launch of that sample alone.
     int64_t sB, sO;
 };
@@ -90,8 +91,8 @@ __global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
     const int z0 = tz * p.BD, y0 = ty * p.BH, x0 = tx * p.BW;      // low-res box origin
     const int smp = blockIdx.z;
     const float* const pB = p.B + smp * p.sB;
-    const float* const pscale = p.scale + smp * p.CB;
-    const float* const pshift = p.shift + smp * p.CB;
+    const float* const pscale = p.scale + smp * p.saff;
+    const float* const pshift = p.shift + smp * p.saff;
     const float* const pbound = p.bound + smp * p.G;
 
     float bmax = 0.f;
@@ -449,14 +450,14 @@ extern "C" size_t bfm_conv3x3x3_upfold_workspace(int CB, int d, int h, int w, in
 
 static int upfold_launch(const float* B, int CB, int S, int d, int h, int w, const float* scale_b, const float* shift_b,
                          const float* bound, int G, const void* wpacked, int wexp, int Cout, int passes, float* out,
-                         void* workspace, size_t workspace_bytes, bool strict, bfm_stream_t stream);
+                         void* workspace, size_t workspace_bytes, bool strict, int affine_stride, bfm_stream_t stream);
 
 extern "C" int bfm_conv3x3x3_upfold_ex(const float* B, int CB, int d, int h, int w, const float* scale_b,
                                        const float* shift_b, const float* bound, int G, const void* wpacked, int wexp,
                                        int Cout, int passes, float* out, void* workspace, size_t workspace_bytes,
                                        bfm_stream_t stream) {
     return upfold_launch(B, CB, 1, d, h, w, scale_b, shift_b, bound, G, wpacked, wexp, Cout, passes, out, workspace,
-                         workspace_bytes, false, stream);
+                         workspace_bytes, false, 0, stream);
 }
 
 extern "C" size_t bfm_conv3x3x3_upfold_batch_workspace(int CB, int S, int d, int h, int w, int Cout) {
@@ -466,17 +467,18 @@ extern "C" size_t bfm_conv3x3x3_upfold_batch_workspace(int CB, int S, int d, int
 extern "C" int bfm_conv3x3x3_upfold_batch(const float* B, int CB, int S, int d, int h, int w, const float* scale_b,
                                           const float* shift_b, const float* bound, int G, const void* wpacked, int wexp,
                                           int Cout, int passes, float* out, void* workspace, size_t workspace_bytes,
-                                          bfm_stream_t stream) {
+                                          int affine_stride, bfm_stream_t stream) {
     if (S <= 0 || S > 65535) return BFM_E_ARG;
+    if (affine_stride != 0 && (affine_stride < CB || (affine_stride & 3))) return BFM_E_ARG;
     return upfold_launch(B, CB, S, d, h, w, scale_b, shift_b, bound, G, wpacked, wexp, Cout, passes, out, workspace,
-                         workspace_bytes, true, stream);
+                         workspace_bytes, true, affine_stride, stream);
 }
 
 // strict (the batch entry point): the split-K plan is a function of the per-sample shape alone, so a workspace too small
 // for it is an error instead of a silent fall-back to one slab -- a sample's bits must not depend on the batch it is in
 static int upfold_launch(const float* B, int CB, int S, int d, int h, int w, const float* scale_b, const float* shift_b,
                          const float* bound, int G, const void* wpacked, int wexp, int Cout, int passes, float* out,
-                         void* workspace, size_t workspace_bytes, bool strict, bfm_stream_t stream) {
+                         void* workspace, size_t workspace_bytes, bool strict, int affine_stride, bfm_stream_t stream) {
     if (!B || CB <= 0 || d <= 0 || h <= 0 || w <= 0 || !scale_b || !shift_b || !bound || G <= 0 || !wpacked || !out)
         return BFM_E_ARG;
     if (CB % KC || Cout % 64 || Cout <= 0) return BFM_E_SHAPE;
@@ -489,6 +491,7 @@ static int upfold_launch(const float* B, int CB, int S, int d, int h, int w, con
     UpParams p{};
     p.B = B; p.CB = CB; p.d = d; p.h = h; p.w = w;
     p.scale = scale_b; p.shift = shift_b; p.bound = bound; p.G = G;
+    p.saff = affine_stride > 0 ? affine_stride : CB;
     p.wp = static_cast<const uint4*>(wpacked);
     p.wexp = wexp; p.Cout = Cout; p.out = out;
     choose_box(d, h, w, p.BD, p.BH, p.BW);

@@ -920,21 +920,21 @@ static int wino_launch(const float* A, int CA, int D, int H, int W, const float*
     if (smem > 80 * 1024) return BFM_E_SHAPE;
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             80 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             80 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_masked<3>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_masked<3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_masked<1>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_masked<1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_uniform<3>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_uniform<3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_uniform<1>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_uniform<1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_rest<3>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_rest<3>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_rest<1>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_rest<1>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         attr_done = true;
     }

@@ -23,6 +23,7 @@ namespace {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8t __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int WPB = 4;       // waves per block (independent)
 constexpr int TPBT = 64 * WPB;
@@ -68,10 +69,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 // accumulate: ~2^-22 relative per product, the same scheme as conv_mfma) -- 5x fewer matrix-core cycles than the
 // fp32 MFMA chain, which is kept for unnormalised features whose range is unknown.
 // NS > 0: the segmentation head has exactly NS channels and the heads fill NNB 32-wide column blocks -- compile-time
-// bounds for the softmax / argmax and MFMA loops of the shipped head sets (56 and 18 classes); NS = 0: runtime bounds
+// bounds for the softmax / argmax and MFMA loops of the shipped head sets (56 and 18 classes), LDC their slab stride;
+// NS = 0: runtime bounds
 // (any head set; every s < n_seg test is then a scalar branch).
-template <bool SPLIT, int NS = 0, int NNB = 0>
-__global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int wexp) {
+template <bool SPLIT, int NS = 0, int NNB = 0, int LDC = 0>
+__global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld_rt, int wexp) {
+    const int ld = LDC > 0 ? LDC : ld_rt;           // compile-time slab stride: LDS offsets become immediates, not registers
     extern __shared__ float smem[];                 // [WPB][64][ld] logits, then the per-head tables
     int* s_role = reinterpret_cast<int*>(smem + WPB * 64 * ld);        // [OMAX]
     int* s_slot = s_role + OMAX;                                       // [OMAX]
@@ -153,97 +156,140 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
         pptr[j] = reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
     }
 
+    // ---- chunk loop, software-pipelined: a chunk's 16 KB of features sit in registers (cur) when its iteration starts --
+    // they were requested before the PREVIOUS chunk's epilogue, whose ~half of the iteration hides the memory round trip
+    // (the epilogue itself touches global memory only with stores: the input value it needs was loaded for the skip test).
+    // A chunk whose input is all zero is never requested; the chunk after a skipped one pays its own latency, as before.
     const int64_t nchunks = (p.nvox + 63) >> 6;
-    for (int64_t cix = (int64_t)blockIdx.x * WPB + wave; cix < nchunks; cix += (int64_t)gridDim.x * WPB) {
-        const int64_t v0 = cix << 6;
-        const int nv = (int)min<int64_t>(64, p.nvox - v0);
-        if (p.d.skip_zero_input && p.input) {
-            // the caller keeps this chunk's outputs only where the input image is non-zero (the tile loop's mask,
-            // scripts/demo_test.py:88-100): nothing of a chunk of 64 zero voxels is looked at
-            const float iv = lane < nv ? p.input[v0 + lane] : 0.f;
-            if (!__any(iv != 0.f)) continue;
-        }
-#pragma unroll 1
+    const int64_t cstride = (int64_t)gridDim.x * WPB;
+    const bool gate = p.d.skip_zero_input && p.input;
+    float cur[2][CMAX / 2];
+    auto request = [&](int64_t c) __attribute__((always_inline)) {
+        const int64_t vb = c << 6;
+        const int nvv = (int)min<int64_t>(64, p.nvox - vb);
+#pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
             const int r = mb * 32 + l32;            // this lane's voxel row inside the chunk
-            const bool rlive = r < nv;
-            float av[CMAX / 2];
-            const float4* src = reinterpret_cast<const float4*>(p.feat + (v0 + (rlive ? r : 0)) * C + lh * half);
+            const bool rl = r < nvv;
+            const float4* src = reinterpret_cast<const float4*>(p.feat + (vb + (rl ? r : 0)) * C + lh * half);
 #pragma unroll
             for (int j = 0; j < CMAX / 8; ++j) {
                 float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (rlive && 4 * j < half) q = src[j];
-                av[4 * j] = q.x; av[4 * j + 1] = q.y; av[4 * j + 2] = q.z; av[4 * j + 3] = q.w;
+                if (4 * j < half) q = src[j];         // a row past the end reads the chunk's first voxel: rows do not mix
+                cur[mb][4 * j] = q.x; cur[mb][4 * j + 1] = q.y; cur[mb][4 * j + 2] = q.z; cur[mb][4 * j + 3] = q.w;
             }
+        }
+    };
+    int64_t cix = (int64_t)blockIdx.x * WPB + wave;
+    bool have = false;                              // cur holds (or is receiving) chunk cix
+    float iv = 0.f;                                 // the input image at this lane's voxel of chunk cix (p.input only)
+    while (cix < nchunks) {
+        const int64_t v0 = cix << 6;
+        const int nv = (int)min<int64_t>(64, p.nvox - v0);
+        if (!have) {
+            if (p.input) iv = lane < nv ? p.input[v0 + lane] : 0.f;
+            // the caller keeps this chunk's outputs only where the input image is non-zero (the tile loop's mask,
+            // scripts/demo_test.py:88-100): nothing of a chunk of 64 zero voxels is looked at
+            if (gate && !__any(iv != 0.f)) { cix += cstride; continue; }
+            request(cix);
+        }
+        const int64_t nxt = cix + cstride;
+        float ivn = 0.f;                            // ... of the next chunk: in flight during the matrix phase
+        if (p.input && nxt < nchunks) {
+            const int64_t vn = nxt << 6;
+            ivn = lane < (int)min<int64_t>(64, p.nvox - vn) ? p.input[vn + lane] : 0.f;
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int r = mb * 32 + l32;
+            const bool rlive = r < nv;
+            float (&av)[CMAX / 2] = cur[mb];
+            float inv = 1.f;
             if (p.d.unit_feat) {
                 float ss = 0.f;
 #pragma unroll
                 for (int c = 0; c < CMAX / 2; ++c) ss = fmaf(av[c], av[c], ss);
                 ss += __shfl_xor(ss, 32);
-                const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);   // F.normalize eps; one division per voxel
-#pragma unroll
-                for (int c = 0; c < CMAX / 2; ++c) av[c] = av[c] * inv;
+                inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);               // F.normalize eps; one division per voxel
             }
             if (p.feat_norm && rlive) {               // optional: normalised features
                 float4* dst = reinterpret_cast<float4*>(p.feat_norm + (v0 + r) * C + lh * half);
 #pragma unroll
                 for (int j = 0; j < CMAX / 8; ++j)
-                    if (4 * j < half) dst[j] = make_float4(av[4 * j], av[4 * j + 1], av[4 * j + 2], av[4 * j + 3]);
+                    if (4 * j < half)
+                        dst[j] = make_float4(av[4 * j] * inv, av[4 * j + 1] * inv, av[4 * j + 2] * inv, av[4 * j + 3] * inv);
             }
             if (NO > 0) {
-                floatx16 acc[3];
-#pragma unroll
-                for (int nb = 0; nb < 3; ++nb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
+                // one 32-column block at a time (16 accumulators live, not 48: the registers carry the next chunk's rows)
                 if constexpr (SPLIT) {
+                    // a = (x * inv) * 2^14 = x * (inv * 2^14) bit for bit; hi by truncation (v_cvt_pkrtz: two values per
+                    // instruction, a - hi exact in fp32), lo likewise -- the split conv3d_wino.hip uses
+                    const float sinv = inv * ascale;
+                    half8t ahi[CMAX / 16], alo[CMAX / 16];
 #pragma unroll
                     for (int ks = 0; ks < CMAX / 16; ++ks) {
-                        if (8 * ks < half) {
-                            half8t ahi, alo;
+                        unsigned hw[4], lw[4];
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const float a = av[8 * ks + j] * ascale;
-                                const _Float16 h = (_Float16)a;
-                                ahi[j] = h;
-                                alo[j] = (_Float16)(a - (float)h);
-                            }
-#pragma unroll
-                            for (int nb = 0; nb < 3; ++nb)
-                                if (nb < nnb) {
-                                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, whi[nb][ks], acc[nb], 0, 0, 0);
-                                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wlo[nb][ks], acc[nb], 0, 0, 0);
-                                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, whi[nb][ks], acc[nb], 0, 0, 0);
-                                }
+                        for (int j = 0; j < 4; ++j) {
+                            const float a0 = av[8 * ks + 2 * j] * sinv, a1 = av[8 * ks + 2 * j + 1] * sinv;
+                            const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(a0, a1);
+                            const fp16x2_t l = __builtin_amdgcn_cvt_pkrtz(a0 - (float)h[0], a1 - (float)h[1]);
+                            hw[j] = __builtin_bit_cast(unsigned, h);
+                            lw[j] = __builtin_bit_cast(unsigned, l);
                         }
+                        ahi[ks] = __builtin_bit_cast(half8t, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+                        alo[ks] = __builtin_bit_cast(half8t, make_uint4(lw[0], lw[1], lw[2], lw[3]));
                     }
 #pragma unroll
-                    for (int nb = 0; nb < 3; ++nb)
+                    for (int nb = 0; nb < 3; ++nb) {
+                        if (nb < nnb) {
+                            floatx16 acc;
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) acc[nb][i] = acc[nb][i] * dq;
+                            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+                            for (int ks = 0; ks < CMAX / 16; ++ks) {
+                                if (8 * ks < half) {
+                                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], whi[nb][ks], acc, 0, 0, 0);
+                                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], wlo[nb][ks], acc, 0, 0, 0);
+                                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], whi[nb][ks], acc, 0, 0, 0);
+                                }
+                            }
+                            const int o = nb * 32 + l32;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) {
+                                const int rr = (i & 3) + 8 * (i >> 2) + 4 * lh;
+                                // acc * dq is exact (a power of two), so the fused form rounds once, as mul + add did
+                                if (o < NO) slab[(mb * 32 + rr) * ld + o] = fmaf(acc[i], dq, bias[nb]);
+                            }
+                        }
+                    }
                 } else {
 #pragma unroll
-                    for (int kk = 0; kk < CMAX / 2; ++kk) {
-                        if (kk < half) {
+                    for (int nb = 0; nb < 3; ++nb) {
+                        if (nb < nnb) {
+                            floatx16 acc;
 #pragma unroll
-                            for (int nb = 0; nb < 3; ++nb)
-                                if (nb < nnb)
-                                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], wfrag[nb][kk], acc[nb], 0, 0, 0);
-                        }
-                    }
-                }
+                            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
-                for (int nb = 0; nb < 3; ++nb) {
-                    if (nb < nnb) {
-                        const int o = nb * 32 + l32;
+                            for (int kk = 0; kk < CMAX / 2; ++kk)
+                                if (kk < half) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk] * inv, wfrag[nb][kk], acc, 0, 0, 0);
+                            const int o = nb * 32 + l32;
 #pragma unroll
-                        for (int i = 0; i < 16; ++i) {
-                            const int rr = (i & 3) + 8 * (i >> 2) + 4 * lh;
-                            if (o < NO) slab[(mb * 32 + rr) * ld + o] = acc[nb][i] + bias[nb];
+                            for (int i = 0; i < 16; ++i) {
+                                const int rr = (i & 3) + 8 * (i >> 2) + 4 * lh;
+                                if (o < NO) slab[(mb * 32 + rr) * ld + o] = acc[i] + bias[nb];
+                            }
                         }
                     }
                 }
             }
+        }
+        // ---- cur is dead: request the next chunk's rows before this chunk's epilogue
+        have = false;
+        int64_t cnext = nxt;
+        if (nxt < nchunks) {
+            if (gate && !__any(ivn != 0.f)) cnext = nxt + cstride;      // nothing of it is looked at
+            else { request(nxt); have = true; }
         }
         wave_lds_sync();
 
@@ -255,6 +301,7 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
                 dst[i] = slab[r * ld + o];
             }
             wave_lds_sync();
+            iv = ivn; cix = cnext;
             continue;
         }
 
@@ -277,7 +324,7 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
             }
             if (live && mp) mp[v] = r;
             if (role == BFM_ROLE_SR && p.d.slot_high_res >= 0 && live && p.input)      // channel c -> slot_high_res + c
-                s_map[min(p.d.slot_high_res + (o - sr_first), p.n_maps - 1)][v] = a + p.input[v];
+                s_map[min(p.d.slot_high_res + (o - sr_first), p.n_maps - 1)][v] = a + iv;
         };
 #pragma unroll
         for (int j = 0; j < PMAX; ++j)
@@ -299,12 +346,9 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
             const int ns = NS > 0 ? NS : p.d.n_seg;
             float* sl = row + p.d.seg_first;
             if (live && ns <= 64) {
-                // the whole logit row in registers: one batch of LDS reads, then max / exp / sum / argmax without
-                // a load in any dependence chain (padded entries are -inf -> exp 0, never the maximum)
+                // one pass over the logit row (independent LDS reads, nothing kept: the registers hold the NEXT chunk's
+                // features by now); padded entries are -inf -> never the maximum
                 constexpr int LIM = NS > 0 ? NS : 64;              // compile-time class count: no padded entries, no branches
-                float sv[LIM];
-#pragma unroll
-                for (int s = 0; s < LIM; ++s) sv[s] = (NS > 0 || s < ns) ? sl[s] : -INFINITY;
                 // largest and second largest logit.  The label is argmax over the softmax PROBABILITIES (first maximum,
                 // __init__.py:347-349); when nobody asks for the probabilities and the top logit leads by more than
                 // ARGMAX_GAP, its probability exp2(0) * rs = rs exceeds every other exp2(-gap * log2 e) * rs by >= 160 ulps
@@ -315,28 +359,27 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
                 int best = 0;
 #pragma unroll
                 for (int s = 0; s < LIM; ++s) {
-                    const float x = sv[s];
+                    const float x = (NS > 0 || s < ns) ? sl[s] : -INFINITY;
                     chk += x;                                      // NaN / +inf / mixed infinities end up non-finite here
                     if (x > m) { m2 = m; m = x; best = s; } else m2 = fmaxf(m2, x);
                 }
                 const bool sure = p.seg_prob == nullptr && (m - m2) > ARGMAX_GAP && fabsf(chk) < INFINITY;
                 if (__any(!sure)) {
+                    // the exponentials go back to the lane's own slab row and are read again for the probabilities
                     float sum = 0.f;
 #pragma unroll
-                    for (int s = 0; s < LIM; ++s) { sv[s] = fast_exp(sv[s] - m); sum += sv[s]; }
+                    for (int s = 0; s < LIM; ++s)
+                        if (NS > 0 || s < ns) { const float e = fast_exp(sl[s] - m); sl[s] = e; sum += e; }
                     const float rs = 1.f / sum;
                     float bp = -1.f;
                     best = 0;
 #pragma unroll
-                    for (int s = 0; s < LIM; ++s) {
-                        sv[s] = sv[s] * rs;
-                        if (sv[s] > bp) { bp = sv[s]; best = s; }    // first maximum wins (torch.argmax)
-                    }
-                    if (p.seg_prob) {
-#pragma unroll
-                        for (int s = 0; s < LIM; ++s)
-                            if (NS > 0 || s < ns) sl[s] = sv[s];
-                    }
+                    for (int s = 0; s < LIM; ++s)
+                        if (NS > 0 || s < ns) {
+                            const float pr = sl[s] * rs;
+                            if (pr > bp) { bp = pr; best = s; }      // first maximum wins (torch.argmax)
+                            if (p.seg_prob) sl[s] = pr;
+                        }
                 }
                 if (p.label) p.label[v] = (int64_t)s_lut[best];
             } else if (live) {
@@ -365,6 +408,8 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
             }
         }
         wave_lds_sync();                                      // slab fully consumed before the next chunk's logits
+        iv = ivn;
+        cix = cnext;
     }
 }
 
@@ -401,9 +446,9 @@ static int tail_launch(const float* feat, const float* input, int64_t nvox, cons
     if (smem > 64 * 1024 &&
         (hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<true>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
-         hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<true, 56, 3>),
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<true, 56, 3, 69>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
-         hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<true, 18, 1>),
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<true, 18, 1, 27>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
          hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<false>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess))
@@ -417,11 +462,10 @@ static int tail_launch(const float* feat, const float* input, int64_t nvox, cons
         wexp = 14 - ex;
         wexp = wexp > 60 ? 60 : (wexp < -60 ? -60 : wexp);
     }
-    const int nnb = (desc->n_out + 31) >> 5;
-    if (split && desc->n_seg == 56 && nnb == 3)                // the shipped head set (69 outputs, 56 classes)
-        hipLaunchKernelGGL((tail_kernel<true, 56, 3>), dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, wexp);
-    else if (split && desc->n_seg == 18 && nnb == 1)           // left-hemisphere head set (18 classes, 27 outputs)
-        hipLaunchKernelGGL((tail_kernel<true, 18, 1>), dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, wexp);
+    if (split && desc->n_seg == 56 && ld == 69)                // the shipped head set (69 outputs, 56 classes)
+        hipLaunchKernelGGL((tail_kernel<true, 56, 3, 69>), dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, wexp);
+    else if (split && desc->n_seg == 18 && ld == 27)           // left-hemisphere head set (18 classes, 27 outputs)
+        hipLaunchKernelGGL((tail_kernel<true, 18, 1, 27>), dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, wexp);
     else if (split)
         hipLaunchKernelGGL((tail_kernel<true>), dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, wexp);
     else

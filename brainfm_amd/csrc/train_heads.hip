@@ -649,7 +649,7 @@ extern "C" int bfm_loss_seg(const float* raw, int n_out, int c0, int ns, const f
                                coef_ce / (float)nvox, coef_dice, n_out, c0, dRaw);
     }
     // loss values are finished on the host from `sums` (CE mean and the Dice sum need wdice): copy them out
-    hipMemcpyAsync(loss_out, sums, (size_t)(1 + 2 * ns) * sizeof(double), hipMemcpyDeviceToDevice, st);
+    (void)hipMemcpyAsync(loss_out, sums, (size_t)(1 + 2 * ns) * sizeof(double), hipMemcpyDeviceToDevice, st);
     return bfm_launch_status();
 }
 

@@ -857,7 +857,7 @@ class UNetEngine:
                                                       upp if cb else None, L.ptr(sc), L.ptr(sh), L.ptr(bd), ly.groups,
                                                       L.ptr(ly.wpacked), ly.wexp, ly.cout, self.slope, self.passes, c,
                                                       L.ptr(out_), L.ptr(ws), ws.numel(),
-                                                      L.ptr(rows[0]) if rows is not None else None, st),
+                                                      L.ptr(rows[0]) if rows is not None else None, 0, st),
                     "conv_mfma_batch " + ly.name)
         if key not in self._tuned:
             # timed on ONE sample (the choice must not depend on the batch size: a tile's bits may not either)
@@ -903,9 +903,10 @@ class UNetEngine:
             self._make_upfold_pack(ly, ca, cb)
         ly.touch("upfold")
         wup, wexp_up = ly.packs["upfold"]
-        # the two halves' GroupNorm affine as contiguous [S][C] tables (the kernels step by their own channel count)
-        sc_a, sh_a = scale[:, :ca].contiguous(), shift[:, :ca].contiguous()
-        sc_b, sh_b = scale[:, ca:].contiguous(), shift[:, ca:].contiguous()
+        # the two halves' GroupNorm affine: column windows of the concat's [S][ca + cb] tables (rows ca + cb apart)
+        sc_a, sh_a = scale[:, :ca], shift[:, :ca]
+        sc_b, sh_b = scale[:, ca:], shift[:, ca:]
+        aff = ca + cb
         out = torch.empty((S, D, H, W, ly.cout), dtype=torch.float32, device=self.device)
         key = (ca, ly.cout, tuple(dims), False, True, 1)
         if key not in self._plan_cache:
@@ -923,7 +924,7 @@ class UNetEngine:
             L.check(self.lib.bfm_conv3x3x3_mfma_batch(L.ptr(A_), ca, None, 0, S_, D, H, W, None, L.ptr(sc), L.ptr(sh),
                                                       L.ptr(bd), ly.groups, L.ptr(sk.wpacked), sk.wexp, ly.cout,
                                                       self.slope, self.passes, c, L.ptr(out_), L.ptr(ws), ws.numel(),
-                                                      L.ptr(rows[0]) if rows is not None else None, st),
+                                                      L.ptr(rows[0]) if rows is not None else None, aff, st),
                     "conv_mfma_batch " + sk.name)
         if key not in self._tuned:                              # on one sample; trials accumulate onto garbage
             cfg = self._autotune(sk, key, lambda c: _launch_skip(c, None, A[0:1], 1, out[0:1], sc_a[0:1], sh_a[0:1],
@@ -943,7 +944,7 @@ class UNetEngine:
             L.check(self.lib.bfm_conv3x3x3_upfold_batch(L.ptr(B), cb, S, lo_dims[0], lo_dims[1], lo_dims[2], L.ptr(sc_b),
                                                         L.ptr(sh_b), L.ptr(bound), ly.groups, L.ptr(wup), wexp_up,
                                                         ly.cout, self.passes, L.ptr(out), L.ptr(ws) if wsu else None,
-                                                        ws.numel() if wsu else 0, st), "conv_upfold_batch " + ly.name)
+                                                        ws.numel() if wsu else 0, aff, st), "conv_upfold_batch " + ly.name)
         if ev is not None:
             ev[1].record()
             self.prof.append((ev[0], ev[1], 2.0 * 27 * cb * ly.cout * nv * S, 4.0 * (S * (lo * cb + nv * ly.cout)), reps,

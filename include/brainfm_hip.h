@@ -179,12 +179,15 @@ int bfm_conv3x3x3_mfma_ex(const float* A, int CA, const float* B, int CB, int D,
  * sample (buildingblocks.py:48-60).  Every workgroup does what it does in the one-sample launch (same box, K order and
  * split-K), so the result is bit-identical to S calls of bfm_conv3x3x3_mfma_ex; what changes is that the S workgroups
  * needing the same packed-weight fragments run side by side and read them from HBM once (the deep levels are bound by
- * their 1 GB of weights per tile).  Plan variants 0 and 2 only; moment_rows: [S * rows][Cout]. */
+ * their 1 GB of weights per tile).  Plan variants 0 and 2 only; moment_rows: [S * rows][Cout].
+ * affine_stride: floats between two samples' scale / shift rows (0 = CA + CB; wider when the caller hands a column
+ * window of a wider [S][C] table, e.g. the skip half of a decoder concat). */
 size_t bfm_conv3x3x3_mfma_batch_workspace(int Cin, int Cout, int S, int D, int H, int W, int splitk);
 int bfm_conv3x3x3_mfma_batch(const float* A, int CA, const float* B, int CB, int S, int D, int H, int W,
                              const bfm_upsample_t* up, const float* scale, const float* shift, const float* bound, int G,
                              const void* wpacked, int wexp, int Cout, float slope, int passes, const int* cfg, float* out,
-                             void* workspace, size_t workspace_bytes, void* moment_rows, bfm_stream_t stream);
+                             void* workspace, size_t workspace_bytes, void* moment_rows, int affine_stride,
+                             bfm_stream_t stream);
 /* GroupNorm statistics of such a batch: per sample exactly bfm_gn_stats / bfm_gn_stats_rows (same block split, same
  * summation order), outputs [S][C] / [S][G]. */
 size_t bfm_gn_stats_batch_workspace(int CA, int CB, int S, int D, int H, int W, const bfm_upsample_t* up);
@@ -238,13 +241,14 @@ size_t bfm_conv3x3x3_upfold_workspace(int CB, int d, int h, int w, int Cout);
 int bfm_conv3x3x3_upfold_ex(const float* B, int CB, int d, int h, int w, const float* scale_b, const float* shift_b,
                             const float* bound, int G, const void* wpacked, int wexp, int Cout, int passes, float* out,
                             void* workspace, size_t workspace_bytes, bfm_stream_t stream);
-/* S same-shape samples in one launch (the batched deep levels): B [S][d][h][w][CB], scale_b / shift_b [S][CB] (contiguous
- * per sample), bound [S][G], out [S][2d][2h][2w][Cout].  A sample's result is bit-identical to its S = 1 launch: the
+/* S same-shape samples in one launch (the batched deep levels): B [S][d][h][w][CB], scale_b / shift_b [S][CB] (rows
+ * affine_stride floats apart, 0 = CB: the upsampled half's window of the concat's [S][CA + CB] table), bound [S][G], out [S][2d][2h][2w][Cout].  A sample's result is bit-identical to its S = 1 launch: the
  * split-K plan depends on the per-sample shape alone, and a workspace smaller than _batch_workspace() is an error. */
 size_t bfm_conv3x3x3_upfold_batch_workspace(int CB, int S, int d, int h, int w, int Cout);
 int bfm_conv3x3x3_upfold_batch(const float* B, int CB, int S, int d, int h, int w, const float* scale_b,
                                const float* shift_b, const float* bound, int G, const void* wpacked, int wexp, int Cout,
-                               int passes, float* out, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+                               int passes, float* out, void* workspace, size_t workspace_bytes, int affine_stride,
+                               bfm_stream_t stream);
 
 int bfm_conv3x3x3_mfma(const float* A, int CA, const float* B, int CB, int D, int H, int W,
                        const bfm_upsample_t* up, const float* scale, const float* shift, const float* bound,
