@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(TPB) conv_direct(const float* __restrict__ A, 
 // arithmetic is ~6 MFMAs per 32 voxels and every store instruction writes two full 128-byte output lines.
 typedef _Float16 half8s __attribute__((ext_vector_type(8)));
 typedef float floatx16s __attribute__((ext_vector_type(16)));
+typedef __fp16 fp16x2s __attribute__((ext_vector_type(2)));
 
 template <int NB>
 __global__ void __launch_bounds__(256, 3) conv_stem_mfma(const float* __restrict__ A, int D, int H, int W,
@@ -116,6 +117,7 @@ __global__ void __launch_bounds__(256, 3) conv_stem_mfma(const float* __restrict
     if (wmax > 0.f && wmax < INFINITY) { int ex; (void)frexpf(wmax, &ex); wexp = 14 - ex; wexp = wexp > 60 ? 60 : (wexp < -60 ? -60 : wexp); }
     const float sa = ldexpf(1.f, aexp), sw = ldexpf(1.f, wexp), dq = ldexpf(1.f, -(aexp + wexp));
     const float sc = scale[0] * sa, sh = shift[0] * sa;
+    const float dqs = dq * slope;
 
     // B fragments: lane holds B[k = 16*ks + 8*kh + j][col = nb*32 + l32], k = tap index (>= 27 -> 0)
     half8s bhi[NB][2], blo[NB][2];
@@ -137,52 +139,90 @@ __global__ void __launch_bounds__(256, 3) conv_stem_mfma(const float* __restrict
     const int64_t gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nw = (int64_t)gridDim.x * 4;
 
-    // gather of one row block: raw input values (the GroupNorm affine is applied later, zero padding stays exact)
-    auto gather = [&](int64_t blk, float (&raw)[16], unsigned& mask) __attribute__((always_inline)) {
-        const int bx = (int)(blk % xb);
-        const int64_t t = blk / xb;
-        const int y = (int)(t % H), z = (int)(t / H);
+    // gather of one row block: raw input values (the GroupNorm affine is applied later, zero padding stays exact).
+    // The kernel is bound by its vector instructions (profiles/r03_hbm_kernels.txt), so everything that does not depend
+    // on the block is computed once per lane: tap q's element offset from the block's own voxel (toff) and the set of
+    // volume faces the tap must stay inside of (need: bit 0/1 z-1/z+1, 2/3 y-1/y+1, 4/5 x-1/x+1, 6 always -- taps >= 27
+    // never load, 7 always -- the lane's own x must be inside the row); per block a tap costs one add, one test, one select.
+    int toff[16];
+    unsigned need[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int k = 16 * (q >> 3) + (q & 7) + (kh ? 8 : 0);
+        const int dz = k / 9 - 1, dy = (k % 9) / 3 - 1, dx = k % 3 - 1;
+        toff[q] = k < 27 ? (dz * H + dy) * W + dx : 0;
+        unsigned n = 0x80u;
+        if (dz < 0) n |= 1u; if (dz > 0) n |= 2u;
+        if (dy < 0) n |= 4u; if (dy > 0) n |= 8u;
+        if (dx < 0) n |= 16u; if (dx > 0) n |= 32u;
+        if (k >= 27) n |= 64u;
+        need[q] = n;
+    }
+    auto gather = [&](int bx, int y, int z, float (&raw)[16], unsigned& mask) __attribute__((always_inline)) {
         const int x = bx * 32 + l32;
+        const int base = (z * H + y) * W + x;                      // the launcher keeps D*H*W below 2^31
+        // faces this voxel's neighbours would cross (bit set = that neighbour does not exist)
+        const unsigned bad = (z == 0 ? 1u : 0u) | (z == D - 1 ? 2u : 0u) | (y == 0 ? 4u : 0u) | (y == H - 1 ? 8u : 0u) |
+                             (x == 0 ? 16u : 0u) | (x >= W - 1 ? 32u : 0u) | 64u | (x >= W ? 0x80u : 0u);
         mask = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            // tap k = 16*(q>>3) + 8*kh + (q&7): both candidates are compile-time constants, kh selects
-            const int k0 = 16 * (q >> 3) + (q & 7), k1 = k0 + 8;
-            const int dz = kh ? (k1 / 9 - 1) : (k0 / 9 - 1);
-            const int dy = kh ? ((k1 % 9) / 3 - 1) : ((k0 % 9) / 3 - 1);
-            const int dx = kh ? (k1 % 3 - 1) : (k0 % 3 - 1);
-            const bool tap = kh ? (k1 < 27) : (k0 < 27);
-            const int zz = z + dz, yy = y + dy, xx = x + dx;
-            const bool inb = tap && (unsigned)zz < (unsigned)D && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-            raw[q] = inb ? A[((int64_t)zz * H + yy) * W + xx] : 0.f;
+            const bool inb = (need[q] & bad) == 0;
+            raw[q] = A[inb ? base + toff[q] : 0];                  // a tap outside reads element 0 and is masked below
             mask |= inb ? (1u << q) : 0u;
         }
     };
 
-    // optional moment rows of the output: one row per wave ([gridDim.x*4][Cout]), see conv3d_mfma.hip
+    // optional moment rows of the output: one row per wave ([gridDim.x*4][Cout]), see conv3d_mfma.hip.  Per block the
+    // <= 16 values a lane stores per column go through fp32 partials (as conv_mfma's epilogue does with <= 32), then fp64.
     double ms[NB], mq[NB];
     float mmn[NB], mmx[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) { ms[nb] = 0.0; mq[nb] = 0.0; mmn[nb] = INFINITY; mmx[nb] = -INFINITY; }
 
+    // block -> (x block, y, z): divided once, then stepped by the (constant) stride in mixed radix
+    const int s_bx = (int)(nw % xb), s_y = (int)((nw / xb) % H), s_z = (int)((nw / xb) / H);
+    int nbx = (int)(gw % xb), ny = (int)((gw / xb) % H), nz = (int)((gw / xb) / H);
+    auto advance = [&]() __attribute__((always_inline)) {
+        nbx += s_bx;
+        int c = nbx >= xb ? 1 : 0;
+        nbx -= c ? xb : 0;
+        ny += s_y + c;
+        c = ny >= H ? 1 : 0;
+        ny -= c ? H : 0;
+        nz += s_z + c;
+    };
     float raw[16];
     unsigned mask = 0;
-    if (gw < nblocks32) gather(gw, raw, mask);
+    if (gw < nblocks32) gather(nbx, ny, nz, raw, mask);
     for (int64_t blk = gw; blk < nblocks32; blk += nw) {
+        const int bx = nbx;
+        const int64_t t = (int64_t)nz * H + ny;
+        advance();
         float nraw[16];
         unsigned nmask = 0;
-        if (blk + nw < nblocks32) gather(blk + nw, nraw, nmask);    // in flight while this block is multiplied / stored
+        if (blk + nw < nblocks32) gather(nbx, ny, nz, nraw, nmask);    // in flight while this block is multiplied / stored
+        // x = hi + lo by truncation, two values per instruction (v_cvt_pkrtz: x - hi is exact in fp32), as conv3d_wino.hip
         half8s ahi[2], alo[2];
+        float v[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float v = (mask >> q) & 1u ? fmaf(raw[q], sc, sh) : 0.f;
-            const _Float16 h = (_Float16)v;
-            ahi[q >> 3][q & 7] = h;
-            alo[q >> 3][q & 7] = (_Float16)(v - (float)h);
+        for (int q = 0; q < 16; ++q) v[q] = (mask >> q) & 1u ? fmaf(raw[q], sc, sh) : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            unsigned hw[4], lw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v0 = v[8 * ks + 2 * j], v1 = v[8 * ks + 2 * j + 1];
+                const fp16x2s h = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+                const fp16x2s l = __builtin_amdgcn_cvt_pkrtz(v0 - (float)h[0], v1 - (float)h[1]);
+                hw[j] = __builtin_bit_cast(unsigned, h);
+                lw[j] = __builtin_bit_cast(unsigned, l);
+            }
+            ahi[ks] = __builtin_bit_cast(half8s, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+            alo[ks] = __builtin_bit_cast(half8s, make_uint4(lw[0], lw[1], lw[2], lw[3]));
         }
-        const int bx = (int)(blk % xb);
-        const int64_t t = blk / xb;
         float* orow = out + (t * W + bx * 32) * Cout;               // t = z*H + y
+        const bool whole = bx * 32 + 32 <= W;                       // wave-uniform: no per-row test on a full block
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             floatx16s acc;
@@ -194,20 +234,25 @@ __global__ void __launch_bounds__(256, 3) conv_stem_mfma(const float* __restrict
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], blo[nb][ks], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], bhi[nb][ks], acc, 0, 0, 0);
             }
+            float fs = 0.f, fq = 0.f;
+            auto emit = [&](bool check) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rr = (i & 3) + 8 * (i >> 2) + 4 * kh;     // C/D row of this register
-                if (bx * 32 + rr < W) {
-                    float r = acc[i] * dq;
-                    r = r >= 0.f ? r : r * slope;
-                    orow[rr * Cout + nb * 32 + l32] = r;
-                    if (rsum) {
-                        const double rd = (double)r;
-                        ms[nb] += rd; mq[nb] += rd * rd;
-                        mmn[nb] = fminf(mmn[nb], r); mmx[nb] = fmaxf(mmx[nb], r);
+                for (int i = 0; i < 16; ++i) {
+                    const int rr = (i & 3) + 8 * (i >> 2) + 4 * kh;     // C/D row of this register
+                    if (!check || bx * 32 + rr < W) {
+                        // LeakyReLU and the dequantisation in one multiply: dq is a power of two, so
+                        // acc * (dq * slope) rounds as (acc * dq) * slope does
+                        const float r = acc[i] * (acc[i] >= 0.f ? dq : dqs);
+                        orow[rr * Cout + nb * 32 + l32] = r;
+                        if (rsum) {
+                            fs += r; fq = fmaf(r, r, fq);
+                            mmn[nb] = fminf(mmn[nb], r); mmx[nb] = fmaxf(mmx[nb], r);
+                        }
                     }
                 }
-            }
+            };
+            if (whole) emit(false); else emit(true);
+            if (rsum) { ms[nb] += (double)fs; mq[nb] += (double)fq; }
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) raw[q] = nraw[q];
@@ -275,6 +320,7 @@ extern "C" int bfm_conv3x3x3_stem_ex(const float* A, int D, int H, int W, const 
                                      float* out, void* moment_rows, bfm_stream_t stream) {
     if (!A || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || !wpacked_direct || !out) return BFM_E_ARG;
     if (Cout != 32 && Cout != 64) return BFM_E_SHAPE;
+    if ((int64_t)D * H * W >= ((int64_t)1 << 31)) return BFM_E_SHAPE;          // the kernel indexes the input with 32 bits
     const int64_t nblk = (int64_t)D * H * ((W + 31) / 32);
     const int64_t nb = stem_grid(D, H, W);
     double *rsum = nullptr, *rsq = nullptr;

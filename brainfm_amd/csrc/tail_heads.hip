@@ -69,12 +69,10 @@ __device__ __forceinline__ void wave_lds_sync() {
 // accumulate: ~2^-22 relative per product, the same scheme as conv_mfma) -- 5x fewer matrix-core cycles than the
 // fp32 MFMA chain, which is kept for unnormalised features whose range is unknown.
 // NS > 0: the segmentation head has exactly NS channels and the heads fill NNB 32-wide column blocks -- compile-time
-// bounds for the softmax / argmax and MFMA loops of the shipped head sets (56 and 18 classes), LDC their slab stride;
-// NS = 0: runtime bounds
+// bounds for the softmax / argmax and MFMA loops of the shipped head sets (56 and 18 classes); NS = 0: runtime bounds
 // (any head set; every s < n_seg test is then a scalar branch).
-template <bool SPLIT, int NS = 0, int NNB = 0, int LDC = 0>
-__global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld_rt, int wexp) {
-    const int ld = LDC > 0 ? LDC : ld_rt;           // compile-time slab stride: LDS offsets become immediates, not registers
+template <bool SPLIT, int NS = 0, int NNB = 0>
+__global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int wexp) {
     extern __shared__ float smem[];                 // [WPB][64][ld] logits, then the per-head tables
     int* s_role = reinterpret_cast<int*>(smem + WPB * 64 * ld);        // [OMAX]
     int* s_slot = s_role + OMAX;                                       // [OMAX]
@@ -156,55 +154,29 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld_rt, 
         pptr[j] = reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
     }
 
-    // ---- chunk loop, software-pipelined: a chunk's 16 KB of features sit in registers (cur) when its iteration starts --
-    // they were requested before the PREVIOUS chunk's epilogue, whose ~half of the iteration hides the memory round trip
-    // (the epilogue itself touches global memory only with stores: the input value it needs was loaded for the skip test).
-    // A chunk whose input is all zero is never requested; the chunk after a skipped one pays its own latency, as before.
     const int64_t nchunks = (p.nvox + 63) >> 6;
-    const int64_t cstride = (int64_t)gridDim.x * WPB;
-    const bool gate = p.d.skip_zero_input && p.input;
-    float cur[2][CMAX / 2];
-    auto request = [&](int64_t c) __attribute__((always_inline)) {
-        const int64_t vb = c << 6;
-        const int nvv = (int)min<int64_t>(64, p.nvox - vb);
-#pragma unroll
+    for (int64_t cix = (int64_t)blockIdx.x * WPB + wave; cix < nchunks; cix += (int64_t)gridDim.x * WPB) {
+        const int64_t v0 = cix << 6;
+        const int nv = (int)min<int64_t>(64, p.nvox - v0);
+        if (p.d.skip_zero_input && p.input) {
+            // the caller keeps this chunk's outputs only where the input image is non-zero (the tile loop's mask,
+            // scripts/demo_test.py:88-100): nothing of a chunk of 64 zero voxels is looked at
+            const float iv = lane < nv ? p.input[v0 + lane] : 0.f;
+            if (!__any(iv != 0.f)) continue;
+        }
+#pragma unroll 1
         for (int mb = 0; mb < 2; ++mb) {
             const int r = mb * 32 + l32;            // this lane's voxel row inside the chunk
-            const bool rl = r < nvv;
-            const float4* src = reinterpret_cast<const float4*>(p.feat + (vb + (rl ? r : 0)) * C + lh * half);
+            const bool rlive = r < nv;
+            float av[CMAX / 2];
+            const float4* src = reinterpret_cast<const float4*>(p.feat + (v0 + (rlive ? r : 0)) * C + lh * half);
 #pragma unroll
             for (int j = 0; j < CMAX / 8; ++j) {
                 float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (4 * j < half) q = src[j];         // a row past the end reads the chunk's first voxel: rows do not mix
-                cur[mb][4 * j] = q.x; cur[mb][4 * j + 1] = q.y; cur[mb][4 * j + 2] = q.z; cur[mb][4 * j + 3] = q.w;
+                if (4 * j < half) q = src[j];       // a row past the end reads the chunk's first voxel: rows do not mix
+                av[4 * j] = q.x; av[4 * j + 1] = q.y; av[4 * j + 2] = q.z; av[4 * j + 3] = q.w;
             }
-        }
-    };
-    int64_t cix = (int64_t)blockIdx.x * WPB + wave;
-    bool have = false;                              // cur holds (or is receiving) chunk cix
-    float iv = 0.f;                                 // the input image at this lane's voxel of chunk cix (p.input only)
-    while (cix < nchunks) {
-        const int64_t v0 = cix << 6;
-        const int nv = (int)min<int64_t>(64, p.nvox - v0);
-        if (!have) {
-            if (p.input) iv = lane < nv ? p.input[v0 + lane] : 0.f;
-            // the caller keeps this chunk's outputs only where the input image is non-zero (the tile loop's mask,
-            // scripts/demo_test.py:88-100): nothing of a chunk of 64 zero voxels is looked at
-            if (gate && !__any(iv != 0.f)) { cix += cstride; continue; }
-            request(cix);
-        }
-        const int64_t nxt = cix + cstride;
-        float ivn = 0.f;                            // ... of the next chunk: in flight during the matrix phase
-        if (p.input && nxt < nchunks) {
-            const int64_t vn = nxt << 6;
-            ivn = lane < (int)min<int64_t>(64, p.nvox - vn) ? p.input[vn + lane] : 0.f;
-        }
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-            const int r = mb * 32 + l32;
-            const bool rlive = r < nv;
-            float (&av)[CMAX / 2] = cur[mb];
-            float inv = 1.f;
+            float inv = 1.f;                        // applied where the row is consumed (one multiply less per channel)
             if (p.d.unit_feat) {
                 float ss = 0.f;
 #pragma unroll
@@ -220,76 +192,63 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld_rt, 
                         dst[j] = make_float4(av[4 * j] * inv, av[4 * j + 1] * inv, av[4 * j + 2] * inv, av[4 * j + 3] * inv);
             }
             if (NO > 0) {
-                // one 32-column block at a time (16 accumulators live, not 48: the registers carry the next chunk's rows)
+                floatx16 acc[3];
+#pragma unroll
+                for (int nb = 0; nb < 3; ++nb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[nb][i] = 0.f;
                 if constexpr (SPLIT) {
-                    // a = (x * inv) * 2^14 = x * (inv * 2^14) bit for bit; hi by truncation (v_cvt_pkrtz: two values per
-                    // instruction, a - hi exact in fp32), lo likewise -- the split conv3d_wino.hip uses
                     const float sinv = inv * ascale;
-                    half8t ahi[CMAX / 16], alo[CMAX / 16];
 #pragma unroll
                     for (int ks = 0; ks < CMAX / 16; ++ks) {
-                        unsigned hw[4], lw[4];
+                        if (8 * ks < half) {
+                            // a = (x * inv) * 2^14 = x * (inv * 2^14) bit for bit; hi by truncation (v_cvt_pkrtz: two
+                            // values per instruction, a - hi exact in fp32), lo likewise -- conv3d_wino.hip's split
+                            unsigned hw[4], lw[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float a0 = av[8 * ks + 2 * j] * sinv, a1 = av[8 * ks + 2 * j + 1] * sinv;
-                            const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(a0, a1);
-                            const fp16x2_t l = __builtin_amdgcn_cvt_pkrtz(a0 - (float)h[0], a1 - (float)h[1]);
-                            hw[j] = __builtin_bit_cast(unsigned, h);
-                            lw[j] = __builtin_bit_cast(unsigned, l);
-                        }
-                        ahi[ks] = __builtin_bit_cast(half8t, make_uint4(hw[0], hw[1], hw[2], hw[3]));
-                        alo[ks] = __builtin_bit_cast(half8t, make_uint4(lw[0], lw[1], lw[2], lw[3]));
-                    }
+                            for (int j = 0; j < 4; ++j) {
+                                const float a0 = av[8 * ks + 2 * j] * sinv, a1 = av[8 * ks + 2 * j + 1] * sinv;
+                                const fp16x2_t h = __builtin_amdgcn_cvt_pkrtz(a0, a1);
+                                const fp16x2_t l = __builtin_amdgcn_cvt_pkrtz(a0 - (float)h[0], a1 - (float)h[1]);
+                                hw[j] = __builtin_bit_cast(unsigned, h);
+                                lw[j] = __builtin_bit_cast(unsigned, l);
+                            }
+                            const half8t ahi = __builtin_bit_cast(half8t, make_uint4(hw[0], hw[1], hw[2], hw[3]));
+                            const half8t alo = __builtin_bit_cast(half8t, make_uint4(lw[0], lw[1], lw[2], lw[3]));
 #pragma unroll
-                    for (int nb = 0; nb < 3; ++nb) {
-                        if (nb < nnb) {
-                            floatx16 acc;
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-                            for (int ks = 0; ks < CMAX / 16; ++ks) {
-                                if (8 * ks < half) {
-                                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo[ks], whi[nb][ks], acc, 0, 0, 0);
-                                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], wlo[nb][ks], acc, 0, 0, 0);
-                                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi[ks], whi[nb][ks], acc, 0, 0, 0);
+                            for (int nb = 0; nb < 3; ++nb)
+                                if (nb < nnb) {
+                                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(alo, whi[nb][ks], acc[nb], 0, 0, 0);
+                                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, wlo[nb][ks], acc[nb], 0, 0, 0);
+                                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ahi, whi[nb][ks], acc[nb], 0, 0, 0);
                                 }
-                            }
-                            const int o = nb * 32 + l32;
-#pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                const int rr = (i & 3) + 8 * (i >> 2) + 4 * lh;
-                                // acc * dq is exact (a power of two), so the fused form rounds once, as mul + add did
-                                if (o < NO) slab[(mb * 32 + rr) * ld + o] = fmaf(acc[i], dq, bias[nb]);
-                            }
                         }
                     }
                 } else {
 #pragma unroll
-                    for (int nb = 0; nb < 3; ++nb) {
-                        if (nb < nnb) {
-                            floatx16 acc;
+                    for (int kk = 0; kk < CMAX / 2; ++kk) {
+                        if (kk < half) {
+                            const float a = av[kk] * inv;
 #pragma unroll
-                            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+                            for (int nb = 0; nb < 3; ++nb)
+                                if (nb < nnb)
+                                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, wfrag[nb][kk], acc[nb], 0, 0, 0);
+                        }
+                    }
+                }
 #pragma unroll
-                            for (int kk = 0; kk < CMAX / 2; ++kk)
-                                if (kk < half) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk] * inv, wfrag[nb][kk], acc, 0, 0, 0);
-                            const int o = nb * 32 + l32;
+                for (int nb = 0; nb < 3; ++nb) {
+                    if (nb < nnb) {
+                        const int o = nb * 32 + l32;
 #pragma unroll
-                            for (int i = 0; i < 16; ++i) {
-                                const int rr = (i & 3) + 8 * (i >> 2) + 4 * lh;
-                                if (o < NO) slab[(mb * 32 + rr) * ld + o] = acc[i] + bias[nb];
-                            }
+                        for (int i = 0; i < 16; ++i) {
+                            const int rr = (i & 3) + 8 * (i >> 2) + 4 * lh;
+                            // split: acc * dq is exact (a power of two), so the fused form rounds once, as mul + add did
+                            if (o < NO) slab[(mb * 32 + rr) * ld + o] = SPLIT ? fmaf(acc[nb][i], dq, bias[nb]) : acc[nb][i] + bias[nb];
                         }
                     }
                 }
             }
-        }
-        // ---- cur is dead: request the next chunk's rows before this chunk's epilogue
-        have = false;
-        int64_t cnext = nxt;
-        if (nxt < nchunks) {
-            if (gate && !__any(ivn != 0.f)) cnext = nxt + cstride;      // nothing of it is looked at
-            else { request(nxt); have = true; }
         }
         wave_lds_sync();
 
@@ -301,7 +260,6 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld_rt, 
                 dst[i] = slab[r * ld + o];
             }
             wave_lds_sync();
-            iv = ivn; cix = cnext;
             continue;
         }
 
@@ -324,7 +282,7 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld_rt, 
             }
             if (live && mp) mp[v] = r;
             if (role == BFM_ROLE_SR && p.d.slot_high_res >= 0 && live && p.input)      // channel c -> slot_high_res + c
-                s_map[min(p.d.slot_high_res + (o - sr_first), p.n_maps - 1)][v] = a + iv;
+                s_map[min(p.d.slot_high_res + (o - sr_first), p.n_maps - 1)][v] = a + p.input[v];
         };
 #pragma unroll
         for (int j = 0; j < PMAX; ++j)
@@ -346,9 +304,12 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld_rt, 
             const int ns = NS > 0 ? NS : p.d.n_seg;
             float* sl = row + p.d.seg_first;
             if (live && ns <= 64) {
-                // one pass over the logit row (independent LDS reads, nothing kept: the registers hold the NEXT chunk's
-                // features by now); padded entries are -inf -> never the maximum
+                // the whole logit row in registers: one batch of LDS reads, then max / exp / sum / argmax without
+                // a load in any dependence chain (padded entries are -inf -> exp 0, never the maximum)
                 constexpr int LIM = NS > 0 ? NS : 64;              // compile-time class count: no padded entries, no branches
+                float sv[LIM];
+#pragma unroll
+                for (int s = 0; s < LIM; ++s) sv[s] = (NS > 0 || s < ns) ? sl[s] : -INFINITY;
                 // largest and second largest logit.  The label is argmax over the softmax PROBABILITIES (first maximum,
                 // __init__.py:347-349); when nobody asks for the probabilities and the top logit leads by more than
                 // ARGMAX_GAP, its probability exp2(0) * rs = rs exceeds every other exp2(-gap * log2 e) * rs by >= 160 ulps
@@ -359,27 +320,28 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld_rt, 
                 int best = 0;
 #pragma unroll
                 for (int s = 0; s < LIM; ++s) {
-                    const float x = (NS > 0 || s < ns) ? sl[s] : -INFINITY;
+                    const float x = sv[s];
                     chk += x;                                      // NaN / +inf / mixed infinities end up non-finite here
                     if (x > m) { m2 = m; m = x; best = s; } else m2 = fmaxf(m2, x);
                 }
                 const bool sure = p.seg_prob == nullptr && (m - m2) > ARGMAX_GAP && fabsf(chk) < INFINITY;
                 if (__any(!sure)) {
-                    // the exponentials go back to the lane's own slab row and are read again for the probabilities
                     float sum = 0.f;
 #pragma unroll
-                    for (int s = 0; s < LIM; ++s)
-                        if (NS > 0 || s < ns) { const float e = fast_exp(sl[s] - m); sl[s] = e; sum += e; }
+                    for (int s = 0; s < LIM; ++s) { sv[s] = fast_exp(sv[s] - m); sum += sv[s]; }
                     const float rs = 1.f / sum;
                     float bp = -1.f;
                     best = 0;
 #pragma unroll
-                    for (int s = 0; s < LIM; ++s)
-                        if (NS > 0 || s < ns) {
-                            const float pr = sl[s] * rs;
-                            if (pr > bp) { bp = pr; best = s; }      // first maximum wins (torch.argmax)
-                            if (p.seg_prob) sl[s] = pr;
-                        }
+                    for (int s = 0; s < LIM; ++s) {
+                        sv[s] = sv[s] * rs;
+                        if (sv[s] > bp) { bp = sv[s]; best = s; }    // first maximum wins (torch.argmax)
+                    }
+                    if (p.seg_prob) {
+#pragma unroll
+                        for (int s = 0; s < LIM; ++s)
+                            if (NS > 0 || s < ns) sl[s] = sv[s];
+                    }
                 }
                 if (p.label) p.label[v] = (int64_t)s_lut[best];
             } else if (live) {
@@ -408,8 +370,6 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld_rt, 
             }
         }
         wave_lds_sync();                                      // slab fully consumed before the next chunk's logits
-        iv = ivn;
-        cix = cnext;
     }
 }
 
@@ -446,9 +406,9 @@ static int tail_launch(const float* feat, const float* input, int64_t nvox, cons
     if (smem > 64 * 1024 &&
         (hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<true>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
-         hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<true, 56, 3, 69>),
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<true, 56, 3>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
-         hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<true, 18, 1, 27>),
+         hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<true, 18, 1>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess ||
          hipFuncSetAttribute(reinterpret_cast<const void*>(&tail_kernel<false>),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess))
@@ -462,10 +422,11 @@ static int tail_launch(const float* feat, const float* input, int64_t nvox, cons
         wexp = 14 - ex;
         wexp = wexp > 60 ? 60 : (wexp < -60 ? -60 : wexp);
     }
-    if (split && desc->n_seg == 56 && ld == 69)                // the shipped head set (69 outputs, 56 classes)
-        hipLaunchKernelGGL((tail_kernel<true, 56, 3, 69>), dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, wexp);
-    else if (split && desc->n_seg == 18 && ld == 27)           // left-hemisphere head set (18 classes, 27 outputs)
-        hipLaunchKernelGGL((tail_kernel<true, 18, 1, 27>), dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, wexp);
+    const int nnb = (desc->n_out + 31) >> 5;
+    if (split && desc->n_seg == 56 && nnb == 3)                // the shipped head set (69 outputs, 56 classes)
+        hipLaunchKernelGGL((tail_kernel<true, 56, 3>), dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, wexp);
+    else if (split && desc->n_seg == 18 && nnb == 1)           // left-hemisphere head set (18 classes, 27 outputs)
+        hipLaunchKernelGGL((tail_kernel<true, 18, 1>), dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, wexp);
     else if (split)
         hipLaunchKernelGGL((tail_kernel<true>), dim3((unsigned)nb), dim3(TPBT), smem, bfm_s(stream), p, ld, wexp);
     else
