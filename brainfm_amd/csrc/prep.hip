@@ -81,7 +81,30 @@ __global__ void mean_lastdim_kernel(const float* __restrict__ in, int64_t n, int
 
 int grid_for(int64_t n) { return (int)std::min<int64_t>(4096, bfm_cdiv64(n, 256)); }
 
+// a tile's window of the volume, copied into the contiguous input of the tile's graph (one wave per x-run)
+__global__ void __launch_bounds__(256) crop3d_kernel(const float* __restrict__ vol, int H, int W, int z0, int y0, int x0,
+                                                     int d, int h, int w, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rows = (int64_t)d * h;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const int z = (int)(r / h), y = (int)(r - (int64_t)z * h);
+        const float* src = vol + ((int64_t)(z0 + z) * H + (y0 + y)) * W + x0;
+        float* dst = out + r * w;
+        for (int x = lane; x < w; x += 64) dst[x] = src[x];
+    }
+}
+
 }  // namespace
+
+extern "C" int bfm_crop3d(const float* vol, int D, int H, int W, int z0, int y0, int x0, int d, int h, int w, float* out,
+                          bfm_stream_t stream) {
+    if (!vol || !out || D <= 0 || H <= 0 || W <= 0 || d <= 0 || h <= 0 || w <= 0) return BFM_E_ARG;
+    if (z0 < 0 || y0 < 0 || x0 < 0 || z0 + d > D || y0 + h > H || x0 + w > W) return BFM_E_SHAPE;
+    const int64_t rows = (int64_t)d * h;
+    hipLaunchKernelGGL(crop3d_kernel, dim3((unsigned)std::min<int64_t>(4096, bfm_cdiv64(rows, 4))), dim3(256), 0, bfm_s(stream),
+                       vol, H, W, z0, y0, x0, d, h, w, out);
+    return bfm_launch_status();
+}
 
 extern "C" int bfm_permute_flip3d(const float* in, int nx, int ny, int nz, const int* perm, const int* flip, float* out,
                                   bfm_stream_t stream) {

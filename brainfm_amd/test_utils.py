@@ -385,7 +385,7 @@ class InferenceSession:
         if key not in self._graphs:
             static_in = torch.empty((S,) + tuple(ims[0].shape[1:]), dtype=torch.float32, device=self.device)
             for s_, im in enumerate(ims):
-                static_in[s_:s_ + 1].copy_(im)
+                self._tile_in(static_in[s_:s_ + 1], im)
             if lane not in self._graph_pool:
                 self._graph_pool[lane] = torch.cuda.graph_pool_handle()
             g = torch.cuda.CUDAGraph()
@@ -409,9 +409,21 @@ class InferenceSession:
             self._graphs[key] = (g, static_in, outs)
         g, static_in, outs = self._graphs[key]
         for s_, im in enumerate(ims):
-            static_in[s_:s_ + 1].copy_(im)
+            self._tile_in(static_in[s_:s_ + 1], im)
         g.replay()
         return outs
+
+    def _tile_in(self, dst, im):
+        """A tile's window of the volume into its graph's contiguous input: bfm_crop3d when `im` is a window of a
+        contiguous fp32 volume (what the tile loops hand over), a tensor copy for anything else."""
+        st = im.stride()
+        d, h, w = im.shape[-3:]
+        if (im.is_cuda and im.dtype == torch.float32 and im.numel() == d * h * w and st[-1] == 1 and st[-2] >= w
+                and st[-3] >= h * st[-2] and st[-3] % st[-2] == 0):
+            L.check(self.engine.lib.bfm_crop3d(L.ptr(im), d, st[-3] // st[-2], st[-2], 0, 0, 0, d, h, w, L.ptr(dst),
+                                               L.stream_ptr()), "crop3d")
+        else:
+            dst.copy_(im)
 
     def graph_tile(self, im, lane=0):
         """graph_group for a single tile."""

@@ -438,6 +438,11 @@ int bfm_grid_push3d_linear(const float* inp, int Bi, int C, int ix, int iy, int 
 int bfm_grid_grad3d_linear(const float* inp, int Bi, int C, int nx, int ny, int nz, const float* grid, int Bg, int ox,
                            int oy, int oz, const int* bound, int extrapolate, float* out, bfm_stream_t stream);
 
+/* The window a tile takes of the volume (scripts/demo_test.py:84-86, `full_im[:, :, x0:x1, y0:y1, z0:z1]`), copied into
+ * a contiguous [d][h][w] buffer: vol [D][H][W] fp32, the window starts at (z0, y0, x0) in that index order. */
+int bfm_crop3d(const float* vol, int D, int H, int W, int z0, int y0, int x0, int d, int h, int w, float* out,
+               bfm_stream_t stream);
+
 /* Pre-processing around the inference path (utils/test_utils.py:235-284 prepare_image).
  * permute_flip3d: align_volume_to_ref's swapaxes + flips (utils/misc.py:1207-1247) in one gather:
  *   out dims = (n[perm[0]], n[perm[1]], n[perm[2]]); out[i0,i1,i2] = in[j], j[perm[a]] = flip[a] ? n[perm[a]]-1-ia : ia.
