@@ -155,15 +155,27 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
     }
 
     const int64_t nchunks = (p.nvox + 63) >> 6;
-    for (int64_t cix = (int64_t)blockIdx.x * WPB + wave; cix < nchunks; cix += (int64_t)gridDim.x * WPB) {
+    const int64_t cstride = (int64_t)gridDim.x * WPB;
+    const bool gate = p.d.skip_zero_input && p.input;
+    // chunks in groups of four: the input values of a group (the skip test, and the SR head's addend) are requested
+    // together, so a run of skipped chunks costs one memory round trip per four instead of one each
+    for (int64_t cbase = (int64_t)blockIdx.x * WPB + wave; cbase < nchunks; cbase += 4 * cstride) {
+      float ivq[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+          const int64_t c = cbase + k * cstride;
+          ivq[k] = (p.input && c < nchunks && (c << 6) + lane < p.nvox) ? p.input[(c << 6) + lane] : 0.f;
+      }
+#pragma unroll 1
+      for (int k = 0; k < 4; ++k) {
+        const int64_t cix = cbase + k * cstride;
+        if (cix >= nchunks) break;
         const int64_t v0 = cix << 6;
         const int nv = (int)min<int64_t>(64, p.nvox - v0);
-        if (p.d.skip_zero_input && p.input) {
-            // the caller keeps this chunk's outputs only where the input image is non-zero (the tile loop's mask,
-            // scripts/demo_test.py:88-100): nothing of a chunk of 64 zero voxels is looked at
-            const float iv = lane < nv ? p.input[v0 + lane] : 0.f;
-            if (!__any(iv != 0.f)) continue;
-        }
+        const float iv = k == 0 ? ivq[0] : (k == 1 ? ivq[1] : (k == 2 ? ivq[2] : ivq[3]));
+        // the caller keeps this chunk's outputs only where the input image is non-zero (the tile loop's mask,
+        // scripts/demo_test.py:88-100): nothing of a chunk of 64 zero voxels is looked at
+        if (gate && !__any(iv != 0.f)) continue;
 #pragma unroll 1
         for (int mb = 0; mb < 2; ++mb) {
             const int r = mb * 32 + l32;            // this lane's voxel row inside the chunk
@@ -282,7 +294,7 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
             }
             if (live && mp) mp[v] = r;
             if (role == BFM_ROLE_SR && p.d.slot_high_res >= 0 && live && p.input)      // channel c -> slot_high_res + c
-                s_map[min(p.d.slot_high_res + (o - sr_first), p.n_maps - 1)][v] = a + p.input[v];
+                s_map[min(p.d.slot_high_res + (o - sr_first), p.n_maps - 1)][v] = a + iv;
         };
 #pragma unroll
         for (int j = 0; j < PMAX; ++j)
@@ -370,6 +382,7 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
             }
         }
         wave_lds_sync();                                      // slab fully consumed before the next chunk's logits
+      }
     }
 }
 
