@@ -86,8 +86,8 @@ SIGNATURES = {
     "bfm_conv3x3x3_stem_rows": (_I, [_I, _I, _I]),
     "bfm_conv3x3x3_stem_ex": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P, _P]),
     "bfm_gn_stats_rows_workspace": (_Z, [_I, _I, _I, _I]),
-    "bfm_gn_stats_rows": (_I, [_P, _I, _I, _P, _I, _I, C.c_double, _L, _P, _P, _I, _F, _P, _P, _P, _P, _Z, _P]),
-    "bfm_gn_stats_rows_train": (_I, [_P, _I, _I, _P, _I, _I, C.c_double, _L, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "bfm_gn_stats_rows": (_I, [_P, _I, _I, _P, _I, _I, C.c_double, _L, _P, _P, _I, _F, _P, _P, _P, _P, _Z, _P, _P]),
+    "bfm_gn_stats_rows_train": (_I, [_P, _I, _I, _P, _I, _I, C.c_double, _L, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
     "bfm_crop3d": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "bfm_permute_flip3d": (_I, [_P, _I, _I, _I, C.POINTER(_I), C.POINTER(_I), _P, _P]),
     "bfm_bbox_nonzero": (_I, [_P, _I, _I, _I, _F, _P, _P]),

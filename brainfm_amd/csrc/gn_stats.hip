@@ -203,6 +203,167 @@ __global__ void __launch_bounds__(TPB) rows_reduce(const double* __restrict__ rs
     }
 }
 
+// From a group's channel totals (LDS: chan_*[cpg]) to its moments and the per-channel affine.  Called by every thread
+// of the workgroup after the barrier that follows the writes of chan_*; red_mx: TPB / 64 floats of scratch.
+__device__ __forceinline__ void group_affine(int g, int cpg, int c_first, double count_per_channel, float eps,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             float* __restrict__ scale, float* __restrict__ shift,
+                                             float* __restrict__ bound, float* __restrict__ mean_out,
+                                             float* __restrict__ rstd_out, const double* chan_s, const double* chan_q,
+                                             const float* chan_mn, const float* chan_mx, float* red_mx) {
+    const int t = threadIdx.x;
+    // group moments: wave 0 folds the channel totals (strided, then an xor butterfly: fixed order)
+    __shared__ float sh_mean, sh_rstd;
+    if (t < 64) {
+        double S = 0.0, Q = 0.0;
+        for (int c = t; c < cpg; c += 64) { S += chan_s[c]; Q += chan_q[c]; }
+        S = wave_reduce_sum(S);
+        Q = wave_reduce_sum(Q);
+        if (t == 0) {
+            double n = count_per_channel * (double)cpg;
+            double mean = S / n;
+            double var = Q / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            sh_mean = (float)mean;
+            sh_rstd = (float)(1.0 / sqrt(var + (double)eps));
+            if (mean_out) mean_out[g] = sh_mean;                   // kept for the backward pass (training)
+            if (rstd_out) rstd_out[g] = sh_rstd;
+        }
+    }
+    __syncthreads();
+    const float mean = sh_mean, rstd = sh_rstd;
+    float bmax = 0.f;
+    for (int cg = t; cg < cpg; cg += TPB) {
+        int c = c_first + cg;
+        float sc = rstd * gamma[c];
+        float sh = -sc * mean + beta[c];
+        scale[c] = sc; shift[c] = sh;
+        float b0 = fabsf(fmaf(chan_mn[cg], sc, sh));
+        float b1 = fabsf(fmaf(chan_mx[cg], sc, sh));
+        bmax = fmaxf(bmax, fmaxf(b0, b1));
+    }
+    bmax = wave_reduce_max(bmax);
+    if ((t & 63) == 0) red_mx[t >> 6] = bmax;
+    __syncthreads();
+    if (t == 0) {
+        float b = 0.f;
+        for (int i = 0; i < TPB / 64; ++i) b = fmaxf(b, red_mx[i]);
+        bound[g] = b;
+    }
+}
+
+// rows_reduce + gn_finalize in ONE launch for tables of more than RR_MAX rows (the full-resolution levels: up to 16 000
+// rows, 229 of these per 256^3 volume).  Grid (G, KS): workgroup (g, k) folds row slice k of BOTH sources for the
+// channels of group g alone -- so what a group's finalize needs afterwards is KS partials per channel, not 128 rows of
+// every channel -- writes them through to memory (agent-scope stores: eight XCDs, eight L2s), waits for the stores'
+// acknowledgement, meets, and takes a ticket of ITS GROUP with a relaxed agent-scope add.  The workgroup that draws a
+// group's last ticket reads the group's KS x cpg partials with agent-scope loads, sums them in slice order, and runs
+// group_affine: a few hundred loads in one round, not the megabyte a single finalizing workgroup had to pull in the
+// first attempt (profiles/r03_gn_one_launch_experiment.txt).  No fence, no cache-wide operation; every sum has a fixed
+// order (rows of a slice: RP interleaved partial sums combined in order; slices in order), so results do not depend
+// on which workgroup arrives last.  tickets[g] are zero on entry and are left zero.
+constexpr int KS = 16;
+
+template <typename T>
+__device__ __forceinline__ T ld_agent(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ void st_agent(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct RowsSrc {
+    const double *rsum, *rsq;
+    const float *rmn, *rmx;
+    int nrows, C;
+    double wgt;
+};
+
+__global__ void __launch_bounds__(TPB) rows_group_finalize(RowsSrc sa, RowsSrc sb, int G, double count_per_channel, float eps,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ scale, float* __restrict__ shift,
+                                                           float* __restrict__ bound, float* __restrict__ mean_out,
+                                                           float* __restrict__ rstd_out, double* __restrict__ psum,
+                                                           double* __restrict__ psq, float* __restrict__ pmn,
+                                                           float* __restrict__ pmx, int* __restrict__ tickets) {
+    extern __shared__ double smem_d[];
+    __shared__ int is_last;
+    const int t = threadIdx.x;
+    const int g = blockIdx.x, k = blockIdx.y;
+    const int Ctot = sa.C + sb.C;
+    const int cpg = Ctot / G;
+    const int c_first = g * cpg;
+    double* chan_s = smem_d;
+    double* chan_q = chan_s + cpg;
+    double* red_s = chan_q + cpg;
+    double* red_q = red_s + TPB;
+    float* chan_mn = reinterpret_cast<float*>(red_q + TPB);
+    float* chan_mx = chan_mn + cpg;
+    float* red_mn = chan_mx + cpg;
+    float* red_mx = red_mn + TPB;
+
+    const int CP = cpg < TPB ? cpg : TPB;           // columns in flight
+    const int RP = TPB / CP;                         // rows in flight
+    const bool active = t < RP * CP;
+    const int cl = t % CP, part = t / CP;
+    for (int cb = 0; cb < cpg; cb += CP) {
+        const int cg = cb + cl;
+        double sv = 0.0, qv = 0.0;
+        float mn = INFINITY, mx = -INFINITY;
+        if (active && cg < cpg) {
+            const int c = c_first + cg;
+            const RowsSrc& S = (c < sa.C) ? sa : sb;
+            const int cc = (c < sa.C) ? c : c - sa.C;
+            const int per = (S.nrows + KS - 1) / KS;
+            const int r0 = k * per, r1 = min(S.nrows, r0 + per);
+            for (int r = r0 + part; r < r1; r += RP) {
+                const size_t i = (size_t)r * S.C + cc;
+                sv += S.rsum[i]; qv += S.rsq[i];
+                mn = fminf(mn, S.rmn[i]); mx = fmaxf(mx, S.rmx[i]);
+            }
+        }
+        red_s[t] = sv; red_q[t] = qv; red_mn[t] = mn; red_mx[t] = mx;
+        __syncthreads();
+        if (active && part == 0 && cg < cpg) {
+            for (int pp = 1; pp < RP; ++pp) {
+                const int i = pp * CP + cl;
+                sv += red_s[i]; qv += red_q[i];
+                mn = fminf(mn, red_mn[i]); mx = fmaxf(mx, red_mx[i]);
+            }
+            const size_t o = ((size_t)g * KS + k) * cpg + cg;
+            st_agent(psum + o, sv); st_agent(psq + o, qv); st_agent(pmn + o, mn); st_agent(pmx + o, mx);
+        }
+        __syncthreads();
+    }
+    // ---- publish, take this group's ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through stores are acknowledged
+    __syncthreads();
+    if (t == 0) {
+        const int got = __hip_atomic_fetch_add(tickets + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = got == KS - 1;
+        if (is_last) __hip_atomic_store(tickets + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all KS have arrived
+    }
+    __syncthreads();
+    if (!is_last) return;
+    // ---- the group's last arriver: channel totals = the KS partials in slice order (all loads of a thread in one round)
+    for (int cg = t; cg < cpg; cg += TPB) {
+        const int c = c_first + cg;
+        const double w = (c < sa.C) ? sa.wgt : sb.wgt;
+        double ps[KS], pq[KS];
+        float pn[KS], px[KS];
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const size_t o = ((size_t)g * KS + kk) * cpg + cg;
+            ps[kk] = ld_agent(psum + o); pq[kk] = ld_agent(psq + o); pn[kk] = ld_agent(pmn + o); px[kk] = ld_agent(pmx + o);
+        }
+        double sv = 0.0, qv = 0.0;
+        float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) { sv += ps[kk]; qv += pq[kk]; mn = fminf(mn, pn[kk]); mx = fmaxf(mx, px[kk]); }
+        chan_s[cg] = sv * w; chan_q[cg] = qv * w; chan_mn[cg] = mn; chan_mx[cg] = mx;
+    }
+    __syncthreads();
+    group_affine(g, cpg, c_first, count_per_channel, eps, gamma, beta, scale, shift, bound, mean_out, rstd_out, chan_s, chan_q,
+                 chan_mn, chan_mx, red_mx);
+}
+
 // One block per group.  Dynamic LDS: chan_s[cpg], chan_q[cpg] (double), chan_mn[cpg], chan_mx[cpg] (float),
 // red_s[TPB], red_q[TPB] (double), red_mn[TPB], red_mx[TPB] (float)
 __global__ void __launch_bounds__(TPB) gn_finalize(PartTab ta, PartTab tb, int G, double count_per_channel,
@@ -266,44 +427,8 @@ __global__ void __launch_bounds__(TPB) gn_finalize(PartTab ta, PartTab tb, int G
         __syncthreads();
     }
 
-    // group moments: wave 0 folds the channel totals (strided, then an xor butterfly: fixed order)
-    __shared__ float sh_mean, sh_rstd;
-    if (t < 64) {
-        double S = 0.0, Q = 0.0;
-        for (int c = t; c < cpg; c += 64) { S += chan_s[c]; Q += chan_q[c]; }
-        S = wave_reduce_sum(S);
-        Q = wave_reduce_sum(Q);
-        if (t == 0) {
-            double n = count_per_channel * (double)cpg;
-            double mean = S / n;
-            double var = Q / n - mean * mean;
-            if (var < 0.0) var = 0.0;
-            sh_mean = (float)mean;
-            sh_rstd = (float)(1.0 / sqrt(var + (double)eps));
-            if (mean_out) mean_out[g] = sh_mean;                   // kept for the backward pass (training)
-            if (rstd_out) rstd_out[g] = sh_rstd;
-        }
-    }
-    __syncthreads();
-    const float mean = sh_mean, rstd = sh_rstd;
-    float bmax = 0.f;
-    for (int cg = t; cg < cpg; cg += TPB) {
-        int c = c_first + cg;
-        float sc = rstd * gamma[c];
-        float sh = -sc * mean + beta[c];
-        scale[c] = sc; shift[c] = sh;
-        float b0 = fabsf(fmaf(chan_mn[cg], sc, sh));
-        float b1 = fabsf(fmaf(chan_mx[cg], sc, sh));
-        bmax = fmaxf(bmax, fmaxf(b0, b1));
-    }
-    bmax = wave_reduce_max(bmax);
-    if ((t & 63) == 0) red_mx[t >> 6] = bmax;
-    __syncthreads();
-    if (t == 0) {
-        float b = 0.f;
-        for (int i = 0; i < TPB / 64; ++i) b = fmaxf(b, red_mx[i]);
-        bound[g] = b;
-    }
+    group_affine(g, cpg, c_first, count_per_channel, eps, gamma, beta, scale, shift, bound, mean_out, rstd_out, chan_s, chan_q,
+                 chan_mn, chan_mx, red_mx);
 }
 
 struct Plan {
@@ -496,7 +621,8 @@ extern "C" size_t bfm_gn_stats_rows_workspace(int nrowsA, int CA, int nrowsB, in
 extern "C" int bfm_gn_stats_rows_train(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB,
                                        double weightB, int64_t nvox, const float* gamma, const float* beta, int G,
                                        float eps, float* scale, float* shift, float* bound, float* mean_out,
-                                       float* rstd_out, void* workspace, size_t workspace_bytes, bfm_stream_t stream) {
+                                       float* rstd_out, void* workspace, size_t workspace_bytes, void* ticket,
+                                       bfm_stream_t stream) {
     if (!rowsA || nrowsA <= 0 || CA <= 0 || nvox <= 0 || !gamma || !beta || !scale || !shift || !bound) return BFM_E_ARG;
     if (CB < 0 || (CB > 0 && (!rowsB || nrowsB <= 0 || !(weightB > 0.0)))) return BFM_E_ARG;
     if ((reinterpret_cast<uintptr_t>(rowsA) & 7) || (CB > 0 && (reinterpret_cast<uintptr_t>(rowsB) & 7))) return BFM_E_ARG;
@@ -510,6 +636,25 @@ extern "C" int bfm_gn_stats_rows_train(const void* rowsA, int nrowsA, int CA, co
     if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 7)) return BFM_E_ARG;
     hipStream_t st = bfm_s(stream);
     char* ws = static_cast<char*>(workspace);
+    if (ticket && (reinterpret_cast<uintptr_t>(ticket) & 3)) return BFM_E_ARG;
+    // one launch (rows_group_finalize) when a table is large, the caller gave G zeroed tickets and the KS x Ctot
+    // partials fit the workspace the two-launch form would have used
+    if (ticket && needA + needB > 0 && G <= BFM_GN_TICKETS && (size_t)KS * Ctot * 24 <= needA + needB &&
+        (size_t)cpg * 24 + (size_t)TPB * 24 <= 64 * 1024) {
+        RowsView va = rows_view(rowsA, nrowsA, CA);
+        RowsSrc sa{va.sum, va.sq, va.mn, va.mx, nrowsA, CA, 1.0};
+        RowsSrc sb{nullptr, nullptr, nullptr, nullptr, 0, 0, 1.0};
+        if (CB > 0) {
+            RowsView vb = rows_view(rowsB, nrowsB, CB);
+            sb = RowsSrc{vb.sum, vb.sq, vb.mn, vb.mx, nrowsB, CB, weightB};
+        }
+        const size_t n = (size_t)KS * Ctot;
+        hipLaunchKernelGGL(rows_group_finalize, dim3(G, KS), dim3(TPB), fin_smem, st, sa, sb, G, (double)nvox, eps, gamma, beta,
+                           scale, shift, bound, mean_out, rstd_out, reinterpret_cast<double*>(ws),
+                           reinterpret_cast<double*>(ws + n * 8), reinterpret_cast<float*>(ws + n * 16),
+                           reinterpret_cast<float*>(ws + n * 20), static_cast<int*>(ticket));
+        return bfm_launch_status();
+    }
     PartTab ta = rows_source(rowsA, nrowsA, CA, 1.0, ws, st);
     PartTab tb{nullptr, nullptr, nullptr, nullptr, 0, 0, 1.0};
     if (CB > 0) tb = rows_source(rowsB, nrowsB, CB, weightB, ws + needA, st);
@@ -547,7 +692,7 @@ extern "C" int bfm_gn_stats_rows_batch(const void* rowsA, int nrowsA, int CA, co
 extern "C" int bfm_gn_stats_rows(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB,
                                  double weightB, int64_t nvox, const float* gamma, const float* beta, int G, float eps,
                                  float* scale, float* shift, float* bound, void* workspace, size_t workspace_bytes,
-                                 bfm_stream_t stream) {
+                                 void* ticket, bfm_stream_t stream) {
     return bfm_gn_stats_rows_train(rowsA, nrowsA, CA, rowsB, nrowsB, CB, weightB, nvox, gamma, beta, G, eps, scale, shift,
-                                   bound, nullptr, nullptr, workspace, workspace_bytes, stream);
+                                   bound, nullptr, nullptr, workspace, workspace_bytes, ticket, stream);
 }

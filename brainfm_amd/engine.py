@@ -155,6 +155,9 @@ class UNetEngine:
         self._ws_lanes = {}
         self._ws_retired = []
         self.lane = 0
+        # arrival counters of the one-launch GroupNorm rows form, made here -- outside any graph capture -- for the lanes a
+        # session may use (zero on first use, left zero by every call)
+        self._gn_tickets = {ln: torch.zeros(16, dtype=torch.int32, device=self.device) for ln in range(4)}
         self._plan_cache = {}
         self._tuned = set()
         self.force_direct = False
@@ -346,6 +349,14 @@ class UNetEngine:
             ws = self._ws_lanes[self.lane] = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=self.device)
         return ws
 
+    def _gn_ticket(self):
+        """The arrival counter of bfm_gn_stats_rows' one-launch form: zero before its first use, left zero by every
+        call; one per lane (the lanes' GroupNorm kernels run concurrently)."""
+        t = self._gn_tickets
+        if self.lane not in t:
+            t[self.lane] = torch.zeros(16, dtype=torch.int32, device=self.device)
+        return t[self.lane]
+
     def _plan(self, cin, cout, dims, two_src=False, accum=False):
         key = (cin, cout, tuple(dims), bool(two_src), bool(accum))
         if key not in self._plan_cache:
@@ -442,7 +453,8 @@ class UNetEngine:
             L.check(self.lib.bfm_gn_stats_rows_train(L.ptr(ra[0]), ra[1], ca, L.ptr(rb[0]) if rb is not None else None,
                                                      rb[1] if rb is not None else 0, cb, 8.0, D * H * W, L.ptr(ly.gamma),
                                                      L.ptr(ly.beta), ly.groups, self.eps, L.ptr(scale), L.ptr(shift),
-                                                     L.ptr(bound), L.ptr(mean), L.ptr(rstd), L.ptr(ws), ws.numel(), st),
+                                                     L.ptr(bound), L.ptr(mean), L.ptr(rstd), L.ptr(ws), ws.numel(),
+                                                     L.ptr(self._gn_ticket()), st),
                     "gn_stats_rows " + ly.name)
             return ws
         wsb = self.lib.bfm_gn_stats_workspace(ca, cb, D, H, W, upp)

@@ -209,14 +209,22 @@ int bfm_conv3x3x3_stem_ex(const float* A, int D, int H, int W, const float* scal
  * a decoder concat, every voxel replicated weightB times by the nearest upsample: 8 for an exact 2x): rowsB.
  * nvox = voxels per channel of the normalised tensor (D*H*W of the full-res grid). */
 size_t bfm_gn_stats_rows_workspace(int nrowsA, int CA, int nrowsB, int CB);
+/* ticket: NULL, or BFM_GN_TICKETS int32 in device memory that are ZERO before the first call and are left zero by every
+ * call (a buffer of its own: nothing else may write it; one per stream that may run these calls concurrently).  With
+ * tickets, a table of more than 128 rows and G <= BFM_GN_TICKETS the whole thing is ONE launch: workgroup (group, row
+ * slice) folds its slice for the group's channels, the last workgroup of a group to finish runs the group's finalize.
+ * Without, it is up to three launches (a fold per large table, then the finalize).  Both forms are deterministic (fixed
+ * summation orders); they differ from each other in the last bits of the fp64 sums. */
+#define BFM_GN_TICKETS 16
 int bfm_gn_stats_rows(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB, double weightB,
                       int64_t nvox, const float* gamma, const float* beta, int G, float eps, float* scale,
-                      float* shift, float* bound, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+                      float* shift, float* bound, void* workspace, size_t workspace_bytes, void* ticket,
+                      bfm_stream_t stream);
 /* the same with the per-group mean / rstd kept for the backward pass (NULL: not wanted) */
 int bfm_gn_stats_rows_train(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB, double weightB,
                             int64_t nvox, const float* gamma, const float* beta, int G, float eps, float* scale,
                             float* shift, float* bound, float* mean_out, float* rstd_out, void* workspace,
-                            size_t workspace_bytes, bfm_stream_t stream);
+                            size_t workspace_bytes, void* ticket, bfm_stream_t stream);
 
 size_t bfm_conv3x3x3_mfma_workspace(int Cin, int Cout, int D, int H, int W, int splitk);
 int bfm_conv3x3x3_mfma_plan(int Cin, int Cout, int D, int H, int W, int* cfg_out /*[8]*/);

@@ -474,6 +474,84 @@ def test_upsample_folded_conv_split_k_on_small_levels(lo):
     assert e <= 3e-6, e
 
 
+@pytest.mark.parametrize("shape", [(300, 64, 0, 0, 8), (1000, 32, 90, 64, 8), (40, 128, 4000, 256, 8), (700, 256, 513, 512, 8),
+                                   (2000, 1, 0, 0, 1)])
+def test_groupnorm_from_rows_one_launch_equals_the_separate_launches(shape):
+    """bfm_gn_stats_rows with tickets (ONE launch: workgroup (group, row slice) folds, the group's last arriver
+    finalizes) against the ticket-less form (rows_reduce per source, then gn_finalize) and against a float64
+    restatement from the same rows: scale / shift / mean / rstd to 1e-6, bound to 1e-5; the one-launch form gives the
+    same bits three times over and leaves its tickets at zero (a stale ticket or an arrival-order dependence would show)."""
+    from brainfm_amd import _lib as L
+    lib = L.load()
+    na, ca, nb, cb, G = shape
+    dev = _dev()
+    g = torch.Generator().manual_seed(na + cb)
+    vals = {}
+
+    def table(name, n, c):
+        v = torch.randn(n, c, 40, generator=g) * 2.0 + 0.3
+        vals[name] = v.double()
+        buf = torch.empty(n * c * 24, dtype=torch.uint8)
+        k = n * c
+        buf[:k * 8] = v.double().sum(2).contiguous().view(-1).view(torch.uint8)
+        buf[k * 8:k * 16] = (v.double() ** 2).sum(2).contiguous().view(-1).view(torch.uint8)
+        buf[k * 16:k * 20] = v.min(2)[0].contiguous().view(-1).view(torch.uint8)
+        buf[k * 20:k * 24] = v.max(2)[0].contiguous().view(-1).view(torch.uint8)
+        return buf.to(dev)
+
+    A = table("a", na, ca)
+    B = table("b", nb, cb) if cb else None
+    C = ca + cb
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    beta = torch.randn(C, generator=g).to(dev)
+    need = lib.bfm_gn_stats_rows_workspace(na, ca, nb, cb)
+    ws = torch.empty(max(need, 8), dtype=torch.uint8, device=dev)
+    ticket = torch.zeros(16, dtype=torch.int32, device=dev)
+    st = L.stream_ptr()
+    nvox = 40 * na                     # the B source's voxels count 8 times: 40 * nb * 8 must equal it for real layers;
+    wB = (40.0 * na) / (40.0 * nb) if cb else 1.0      # here the weight is whatever makes the counts agree
+
+    def run(tk):
+        out = [torch.full((C,), float("nan"), device=dev), torch.full((C,), float("nan"), device=dev),
+               torch.full((G,), float("nan"), device=dev), torch.full((G,), float("nan"), device=dev),
+               torch.full((G,), float("nan"), device=dev)]
+        ws.zero_()
+        L.check(lib.bfm_gn_stats_rows_train(L.ptr(A), na, ca, L.ptr(B) if B is not None else None, nb, cb, wB,
+                                            nvox, L.ptr(gamma), L.ptr(beta), G, 1e-5, L.ptr(out[0]), L.ptr(out[1]),
+                                            L.ptr(out[2]), L.ptr(out[3]), L.ptr(out[4]), L.ptr(ws), need,
+                                            L.ptr(tk) if tk is not None else None, st), "gn_stats_rows")
+        torch.cuda.synchronize()
+        return [o.cpu() for o in out]
+
+    # float64 restatement (buildingblocks.py:48-60 on the virtual concat)
+    s1 = [vals["a"].sum((0, 2))] + ([vals["b"].sum((0, 2)) * wB] if cb else [])
+    s2 = [(vals["a"] ** 2).sum((0, 2))] + ([(vals["b"] ** 2).sum((0, 2)) * wB] if cb else [])
+    mn = torch.cat([vals["a"].amin((0, 2))] + ([vals["b"].amin((0, 2))] if cb else []))
+    mx = torch.cat([vals["a"].amax((0, 2))] + ([vals["b"].amax((0, 2))] if cb else []))
+    s1, s2 = torch.cat(s1).view(G, -1), torch.cat(s2).view(G, -1)
+    n = nvox * (C // G)
+    mean = s1.sum(1) / n
+    rstd = 1.0 / torch.sqrt((s2.sum(1) / n - mean * mean).clamp_min(0) + 1e-5)
+    sc = (rstd[:, None] * gamma.cpu().double().view(G, -1)).view(-1)
+    sh = (-sc.view(G, -1) * mean[:, None]).view(-1) + beta.cpu().double()
+    bd = torch.maximum((mn * sc + sh).abs(), (mx * sc + sh).abs()).view(G, -1).amax(1)
+    want = [sc, sh, bd, mean, rstd]
+
+    ref = run(None)
+    first = run(ticket)
+    for name, w, r, o in zip(("scale", "shift", "bound", "mean", "rstd"), want, ref, first):
+        tol = 1e-5 if name == "bound" else 1e-6
+        scale_ = float(w.abs().max()) + 1e-12
+        assert float((r.double() - w).abs().max()) / scale_ <= tol, ("separate", name)
+        assert float((o.double() - w).abs().max()) / scale_ <= tol, ("one launch", name)
+    assert int(ticket.abs().sum()) == 0
+    for _ in range(2):
+        again = run(ticket)
+        for r, o in zip(first, again):
+            assert torch.equal(r, o)
+        assert int(ticket.abs().sum()) == 0
+
+
 @pytest.mark.parametrize("ver", [0, 2, 3])
 def test_producer_moment_rows_equal_activation_moments(ver, monkeypatch):
     """The per-tile {sum, sumsq, min, max} rows written by the stem / conv epilogues must be the moments of the
