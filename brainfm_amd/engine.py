@@ -158,6 +158,7 @@ class UNetEngine:
         # arrival counters of the one-launch GroupNorm rows form, made here -- outside any graph capture -- for the lanes a
         # session may use (zero on first use, left zero by every call)
         self._gn_tickets = {ln: torch.zeros(16, dtype=torch.int32, device=self.device) for ln in range(4)}
+        self.gn_one_launch = os.environ.get("BFM_GN_ONE_LAUNCH", "1") != "0"
         self._plan_cache = {}
         self._tuned = set()
         self.force_direct = False
@@ -454,7 +455,7 @@ class UNetEngine:
                                                      rb[1] if rb is not None else 0, cb, 8.0, D * H * W, L.ptr(ly.gamma),
                                                      L.ptr(ly.beta), ly.groups, self.eps, L.ptr(scale), L.ptr(shift),
                                                      L.ptr(bound), L.ptr(mean), L.ptr(rstd), L.ptr(ws), ws.numel(),
-                                                     L.ptr(self._gn_ticket()), st),
+                                                     L.ptr(self._gn_ticket()) if self.gn_one_launch else None, st),
                     "gn_stats_rows " + ly.name)
             return ws
         wsb = self.lib.bfm_gn_stats_workspace(ca, cb, D, H, W, upp)
