@@ -1416,3 +1416,19 @@ def test_bench_line_fields_two_ranks_dry_run():
     assert set(rf["per_kernel"]) >= {"conv_wino", "conv_upfold"} and len(rf["conv_family"]["kernel_ms_per_rank"]) == 2
     assert rf["conv_family"]["kernel_ms_per_step"] == max(rf["conv_family"]["kernel_ms_per_rank"])
     assert "reference_equivalent_frac" not in rf["conv_family"]
+
+
+def test_crop3d_is_the_tile_window():
+    """bfm_crop3d (the copy of a tile's window of the volume into its graph's input, scripts/demo_test.py:84-86) against
+    tensor slicing, including a window that touches the far faces; a window outside the volume is refused."""
+    from brainfm_amd import _lib as L
+    lib = L.load()
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    vol = torch.rand(37, 41, 53, generator=g).to(dev)
+    for (z0, y0, x0, d, h, w) in [(0, 0, 0, 37, 41, 53), (5, 7, 11, 16, 20, 33), (21, 1, 0, 16, 40, 53), (36, 40, 52, 1, 1, 1)]:
+        out = torch.full((d, h, w), float("nan"), device=dev)
+        L.check(lib.bfm_crop3d(L.ptr(vol), 37, 41, 53, z0, y0, x0, d, h, w, L.ptr(out), L.stream_ptr()), "crop3d")
+        assert torch.equal(out, vol[z0:z0 + d, y0:y0 + h, x0:x0 + w])
+    out = torch.empty(4, 4, 4, device=dev)
+    assert lib.bfm_crop3d(L.ptr(vol), 37, 41, 53, 35, 0, 0, 4, 4, 4, L.ptr(out), L.stream_ptr()) != 0
