@@ -1,0 +1,499 @@
+// 3x3x3 convolution with a Winograd F(4,3) transform along x: 2x fewer matrix-core FLOPs along x than the direct
+// form (6 products per 4 outputs instead of 12), 1.33x fewer than conv3d_wino.hip's F(2,3).
+//
+//      d = in[x0-1 .. x0+4]                 V = B^T d   (6 values: rows of B^T below)
+//      g = w[.., kw=0..2]                   U = G g     (6 values, packed offline in float64)
+//      m_p = sum over (kd,kh,ci) of V_p * U_p           y = A^T m   (4 outputs x0 .. x0+3)
+//
+//      B^T = [4  0 -5  0 1 0]    G = [ 1/4    0     0  ]    A^T = [1 1  1 1  1 0]
+//            [0 -4 -4  1 1 0]        [-1/6  -1/6  -1/6 ]          [0 1 -1 2 -2 0]
+//            [0  4 -4 -1 1 0]        [-1/6   1/6  -1/6 ]          [0 1  1 4  4 0]
+//            [0 -2 -1  2 1 0]        [ 1/24  1/12  1/6 ]          [0 1 -1 8 -8 1]
+//            [0  2 -1 -2 1 0]        [ 1/24 -1/12  1/6 ]
+//            [0  4  0 -5 0 1]        [ 0     0     1   ]
+//
+// The GEMM is 6 "positions" x (M/4 output quads) x K = 9 (kd,kh) taps x Cin: 13.5 tap-rows per output voxel instead
+// of 18 (F(2,3)) or 27 (direct), and 1.5 transformed values per voxel to split and store instead of 2.  The price is
+// rounding: the transforms amplify fp32 rounding ~9x over F(2,3) (7e-6 of max|y| per layer against 8e-7,
+// scripts/micro/wino_f43_accuracy.py); the products keep the split-fp16 three-pass scheme.
+//
+// Workgroup = 4 waves for one box of 256 output voxels (64 quads = two 32-row blocks per position) x 64 couts.  Six
+// positions do not divide over four SIMDs as waves (a 6-wave workgroup sits 2,2,1,1 on the SIMDs and a second one does
+// not fit beside it: profiles/r03_conv_wino4_experiment.txt), so the twelve (position, row block) units go three to a
+// wave: wave w owns position w entirely (both row blocks) and one row block of position 4 + (w >> 1) -- equal matrix work
+// per wave, 96 accumulator registers, two positions' weights streamed L2 -> VGPR one tap ahead.  The transformed, split
+// halo'd box lives in LDS ([pos][k-half][hi|lo][row][quad][8 ch], 55 KB); epilogue: the six m_p meet in LDS, one thread
+// per (quad, cout) forms y0..y3, dequantises, optionally adds what `out` holds (accumulate mode), applies LeakyReLU and
+// stores.  Single-source inputs only, no split-K, dense boxes only (the sparse forms stay with F(2,3)).
+#include "bfm_common.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int KC = 16;
+constexpr int NPOS = 6;
+constexpr int NTHR = 256;          // four waves: one per SIMD, twice per CU
+constexpr int NRG = NTHR / 32;     // row groups of the epilogue (8)
+constexpr int MLD = 33;            // epilogue LDS row stride in floats (odd: conflict-free)
+
+struct W4Params {
+    const float* A;
+    int CA, D, H, W;
+    const float *scale, *shift, *bound;
+    int G;
+    const uint4* wp;
+    int wexp, Cout;
+    float slope;
+    float* out;
+    int accum;
+    int TD, TH, TW, HT, QW;          // box, halo'd rows per slice, quads per row
+    int qw_shift, thq_shift;         // log2(QW), log2(TH*QW)
+    int nTy, nTx, nMt, NT, KCN;
+    int npos_lds, plane_stride;      // (TD+2)*HT*QW positions; bytes per plane
+    double *rsum, *rsq;              // optional output-moment rows [nMt][Cout] (see conv3d_mfma.hip)
+    float *rmn, *rmx;
+};
+
+__device__ __forceinline__ int row_perm(int l) {        // as conv_mfma: each 16-lane b128 group reads 16 consecutive positions
+    if (l < 4) return l;
+    if (l < 12) return l + 12;
+    if (l < 16) return l - 8;
+    if (l < 20) return l + 8;
+    if (l < 28) return l - 12;
+    return l;
+}
+
+__device__ __forceinline__ int row_unperm(int q) {      // inverse of row_perm
+    if (q < 4) return q;
+    if (q < 8) return q + 8;
+    if (q < 16) return q + 12;
+    if (q < 24) return q - 12;
+    if (q < 28) return q - 8;
+    return q;
+}
+
+__device__ __forceinline__ void quad_coords(const W4Params& p, int q, int& d, int& h, int& j) {
+    d = q >> p.thq_shift;
+    const int rem = q & ((1 << p.thq_shift) - 1);
+    h = rem >> p.qw_shift;
+    j = rem & ((1 << p.qw_shift) - 1);
+}
+
+// x = hi + lo in fp16 for four values, two per instruction (truncation: x - hi is exact in fp32)
+template <bool LO>
+__device__ __forceinline__ void split_store4(const float (&t)[4], unsigned char* dp, int plane_stride) {
+    const fp16x2_t h01 = __builtin_amdgcn_cvt_pkrtz(t[0], t[1]);
+    const fp16x2_t h23 = __builtin_amdgcn_cvt_pkrtz(t[2], t[3]);
+    uint2 hv;
+    hv.x = __builtin_bit_cast(unsigned, h01);
+    hv.y = __builtin_bit_cast(unsigned, h23);
+    *reinterpret_cast<uint2*>(dp) = hv;
+    if constexpr (LO) {
+        const fp16x2_t l01 = __builtin_amdgcn_cvt_pkrtz(t[0] - (float)h01[0], t[1] - (float)h01[1]);
+        const fp16x2_t l23 = __builtin_amdgcn_cvt_pkrtz(t[2] - (float)h23[0], t[3] - (float)h23[1]);
+        uint2 lv;
+        lv.x = __builtin_bit_cast(unsigned, l01);
+        lv.y = __builtin_bit_cast(unsigned, l23);
+        *reinterpret_cast<uint2*>(dp + plane_stride) = lv;
+    }
+}
+
+template <int NPASS>
+__global__ void __launch_bounds__(NTHR, 2) conv_wino4(const W4Params p) {
+    constexpr int NPL = (NPASS == 3) ? 2 : 1;
+    constexpr int NF = 2 * NPL;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave 0..3
+    const int posA = wv;                                           // position owned entirely (units 0, 1 = row blocks 0, 1)
+    const int posB = 4 + (wv >> 1), mbB = wv & 1;                  // unit 2: row block mbB of position posB
+    const int l32 = lane & 31, khalf = lane >> 5;
+    int item;
+    {   // one workgroup per (box, cout tile), XCD-aware bijective remap (neighbouring boxes share halo lines in one L2)
+        const int nblk = p.nMt * p.NT;
+        const int bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = item / p.NT;
+    const int nt = item % p.NT;
+    const int tx = mt % p.nTx;
+    const int ty = (mt / p.nTx) % p.nTy;
+    const int tz = mt / (p.nTx * p.nTy);
+    const int z0 = tz * p.TD, y0 = ty * p.TH, x0 = tx * p.TW;
+
+    float bmax = 0.f;
+    for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, p.bound[g]);
+    int aexp = 0;
+    if (bmax > 0.f && bmax < INFINITY) {
+        int ex;
+        (void)frexpf(bmax, &ex);
+        aexp = 10 - ex;                                            // |V| <= 10 * bound < 16 * 2^ex
+        aexp = aexp > 60 ? 60 : (aexp < -60 ? -60 : aexp);
+    }
+    const float a_scale = ldexpf(1.0f, aexp);
+    const float dq = ldexpf(1.0f, -(aexp + p.wexp));
+
+    // A base offsets of the three units: quad (d,h,j), tap (kd,kh)=(0,0) reads halo row (d, h), quad j
+    int a_off[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int pos = u < 2 ? posA : posB, mb = u < 2 ? u : mbB;
+        int d, h, j;
+        quad_coords(p, mb * 32 + row_perm(l32), d, h, j);
+        a_off[u] = ((pos * 2 + khalf) * NPL) * p.plane_stride + ((d * p.HT + h) * p.QW + j) * 16;
+    }
+
+    // staging items: e = tid + it*NTHR -> (halo row, quad, channel quad); off0 = element offset of voxel
+    // (gz, gy, x0 + 4j - 1) channel 0 (may point outside the row: the mask says which of the 6 x positions exist)
+    constexpr int MAX_IT = 3;
+    const int n_el = p.npos_lds * 4;
+    const int q4 = tid & 3;
+    int off0[MAX_IT];
+    int msk[MAX_IT];                                               // bit i: x position i inside the volume; -1: no item
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        const int e = tid + it * NTHR;
+        off0[it] = 0;
+        msk[it] = -1;
+        if (e < n_el) {
+            const int ps = e >> 2;
+            const int j = ps & ((1 << p.qw_shift) - 1);
+            const int r = ps >> p.qw_shift;
+            const int hz = r / p.HT, hy = r - hz * p.HT;
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + 4 * j - 1;
+            int m = 0;
+            if (gz >= 0 && gz < p.D && gy >= 0 && gy < p.H) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    if (gx + i >= 0 && gx + i < p.W) m |= 1 << i;
+            }
+            msk[it] = m;
+            off0[it] = ((gz * p.H + gy) * p.W + gx) * p.CA;
+        }
+    }
+    const int st_plane = ((q4 >> 1) * NPL) * p.plane_stride + (q4 & 1) * 8;
+
+    floatx16 acc[3][2];
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[u][nb][i] = 0.f;
+
+    // this wave's two weight streams (positions posA, posB): S = KCN*9 steps (chunk-major, (kd,kh)-minor), NF fragments of
+    // 64 x uint4 per step and position; two register sets, one step ahead
+    const int S = p.KCN * 9;
+    const uint4* wbA = p.wp + (size_t)(nt * NPOS + posA) * S * (NF * 64) + lane;
+    const uint4* wbB = p.wp + (size_t)(nt * NPOS + posB) * S * (NF * 64) + lane;
+    uint4 wq[2][2][NF];
+    auto fetch = [&](int s, uint4 (&dst)[2][NF]) __attribute__((always_inline)) {
+        const int sc = s < S ? s : S - 1;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            dst[0][f] = wbA[(size_t)sc * (NF * 64) + f * 64];
+            dst[1][f] = wbB[(size_t)sc * (NF * 64) + f * 64];
+        }
+    };
+    fetch(0, wq[0]);
+
+    auto do_chunk = [&](int kc, auto par_tag) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_tag)::value;      // parity of the chunk's first weight step (9 steps per chunk)
+        const int c0 = kc * KC;
+        const float* src = p.A + c0 + q4 * 4;
+        const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + c0 + q4 * 4);
+        const float4 sh4 = *reinterpret_cast<const float4*>(p.shift + c0 + q4 * 4);
+        const float sc[4] = {sc4.x * a_scale, sc4.y * a_scale, sc4.z * a_scale, sc4.w * a_scale};
+        const float sh[4] = {sh4.x * a_scale, sh4.y * a_scale, sh4.z * a_scale, sh4.w * a_scale};
+        __syncthreads();                                 // previous chunk's readers are done
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it) {
+            if (msk[it] < 0) continue;
+            float4 v[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (msk[it] & (1 << i)) v[i] = *reinterpret_cast<const float4*>(src + off0[it] + i * p.CA);
+            }
+            float dd[6][4];                              // [x position][channel]: affine, zero padding after it
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const bool ok = msk[it] & (1 << i);
+                const float y[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dd[i][c] = ok ? fmaf(y[c], sc[c], sh[c]) : 0.f;
+            }
+            const int e = tid + it * NTHR;
+            unsigned char* dst = lds + st_plane + (e >> 2) * 16;
+            float t[6][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float d0 = dd[0][c], d1 = dd[1][c], d2 = dd[2][c], d3 = dd[3][c], d4 = dd[4][c], d5 = dd[5][c];
+                const float a = fmaf(-4.f, d2, d4);      // d4 - 4 d2
+                const float b = fmaf(-4.f, d1, d3);      // d3 - 4 d1
+                const float cc = d4 - d2;
+                const float ee = 2.f * (d3 - d1);
+                t[0][c] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+                t[1][c] = a + b;
+                t[2][c] = a - b;
+                t[3][c] = cc + ee;
+                t[4][c] = cc - ee;
+                t[5][c] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+            }
+#pragma unroll
+            for (int ps = 0; ps < NPOS; ++ps)
+                split_store4<NPASS == 3>(t[ps], dst + (ps * 2 * NPL) * p.plane_stride, p.plane_stride);
+            __builtin_amdgcn_sched_barrier(0);           // keep the next item's loads from being hoisted (registers)
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int s = kc * 9 + t;
+            const int kd = t / 3, kh = t - kd * 3;
+            const int toff = (kd * p.HT + kh) * p.QW * 16;
+            const int cur = (PAR + t) & 1;
+            fetch(s + 1, wq[cur ^ 1]);                   // pinned here: one tap of L2 latency ahead of its use
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                half8 a[NPL];
+#pragma unroll
+                for (int hl = 0; hl < NPL; ++hl)
+                    a[hl] = *reinterpret_cast<const half8*>(lds + a_off[u] + hl * p.plane_stride + toff);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const half8 bhi = __builtin_bit_cast(half8, wq[cur][u < 2 ? 0 : 1][nb * NPL]);
+                    if constexpr (NPASS == 3) {
+                        const half8 blo = __builtin_bit_cast(half8, wq[cur][u < 2 ? 0 : 1][nb * NPL + 1]);
+                        acc[u][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bhi, acc[u][nb], 0, 0, 0);
+                        acc[u][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], blo, acc[u][nb], 0, 0, 0);
+                    }
+                    acc[u][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bhi, acc[u][nb], 0, 0, 0);
+                }
+            }
+        }
+    };
+    for (int kc = 0; kc < p.KCN; kc += 2) {              // 9 steps per chunk: the parity flips every chunk
+        do_chunk(kc, std::integral_constant<int, 0>{});
+        if (kc + 1 < p.KCN) do_chunk(kc + 1, std::integral_constant<int, 1>{});
+    }
+
+    // ================= epilogue: output transform through LDS =================
+    float* m = reinterpret_cast<float*>(lds);                      // [6 positions][64 accumulator rows][MLD]
+    const int col = tid & 31, rg = tid >> 5;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        __syncthreads();                                           // A planes (or the previous round) fully consumed
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int pos = u < 2 ? posA : posB, mb = u < 2 ? u : mbB;
+            float* mw = m + (pos * 64 + mb * 32 + khalf * 4) * MLD + l32;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)                            // accumulator row order; the reader undoes row_perm
+                mw[((i >> 2) * 8 + (i & 3)) * MLD] = acc[u][nb][i];
+        }
+        __syncthreads();
+        float fs = 0.f, fq = 0.f, fmn = INFINITY, fmx = -INFINITY;   // this thread's column, its 8 quads (<= 32 values)
+#pragma unroll 2
+        for (int q = rg; q < 64; q += NRG) {
+            int d, h, j;
+            quad_coords(p, q, d, h, j);
+            const int gz = z0 + d, gy = y0 + h, gx = x0 + 4 * j;
+            if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
+            const int qr = (q & ~31) + row_unperm(q & 31);           // accumulator row holding quad q
+            const float* mr = m + qr * MLD + col;
+            const float m0 = mr[0 * 64 * MLD], m1 = mr[1 * 64 * MLD], m2 = mr[2 * 64 * MLD];
+            const float m3 = mr[3 * 64 * MLD], m4 = mr[4 * 64 * MLD], m5 = mr[5 * 64 * MLD];
+            const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+            float y[4];
+            y[0] = ((m0 + s1) + s2) * dq;
+            y[1] = fmaf(2.f, d2, d1) * dq;
+            y[2] = fmaf(4.f, s2, s1) * dq;
+            y[3] = (fmaf(8.f, d2, d1) + m5) * dq;
+            float* o = p.out + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + nt * 64 + nb * 32 + col;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (gx + k < p.W) {
+                    float r = y[k];
+                    if (p.accum) r = r + o[(size_t)k * p.Cout];
+                    r = r >= 0.f ? r : r * p.slope;
+                    o[(size_t)k * p.Cout] = r;
+                    fs += r; fq = fmaf(r, r, fq); fmn = fminf(fmn, r); fmx = fmaxf(fmx, r);
+                }
+            }
+        }
+        if (p.rsum != nullptr) {
+            // moment row of this box: fold the 8 row groups of every column in fixed order (scratch behind m)
+            double* ls = reinterpret_cast<double*>(lds + (size_t)NPOS * 64 * MLD * sizeof(float));   // [8][32]
+            double* lq = ls + NRG * 32;
+            float* lmn = reinterpret_cast<float*>(lq + NRG * 32);
+            float* lmx = lmn + NRG * 32;
+            ls[rg * 32 + col] = (double)fs; lq[rg * 32 + col] = (double)fq;
+            lmn[rg * 32 + col] = fmn; lmx[rg * 32 + col] = fmx;
+            __syncthreads();
+            if (tid < 32) {
+                double Ssum = 0.0, Q = 0.0;
+                float MN = INFINITY, MX = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < NRG; ++r) {
+                    Ssum += ls[r * 32 + tid]; Q += lq[r * 32 + tid];
+                    MN = fminf(MN, lmn[r * 32 + tid]); MX = fmaxf(MX, lmx[r * 32 + tid]);
+                }
+                const size_t o = (size_t)mt * p.Cout + nt * 64 + nb * 32 + tid;
+                p.rsum[o] = Ssum; p.rsq[o] = Q; p.rmn[o] = MN; p.rmx[o] = MX;
+            }
+        }
+    }
+}
+
+// packed[ntile64][pos 6][kc][(kd,kh) 9][nb 2][hl][lane] (uint4 = 8 halfs): lane l holds
+// B[k = 8*(l>>5)+j][n = l&31] = U_pos[co = ntile*64 + nb*32 + (l&31)][ci = kc*16 + 8*(l>>5) + j][kd][kh] * 2^wexp, U = G g along kw
+__global__ void pack_wino4(const float* __restrict__ w, int Cin, int Cout, int wexp, int npl, uint4* __restrict__ out) {
+    const int KCN = Cin / KC;
+    const int nf = 2 * npl;
+    const int64_t n = (int64_t)(Cout / 64) * NPOS * KCN * 9 * nf * 64;
+    const double s = ldexp(1.0, wexp);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        int64_t r = i >> 6;
+        const int f = (int)(r % nf); r /= nf;
+        const int t = (int)(r % 9); r /= 9;
+        const int kc = (int)(r % KCN); r /= KCN;
+        const int ps = (int)(r % NPOS); r /= NPOS;
+        const int ntile = (int)r;
+        const int nb = f / npl, hl = f - nb * npl;
+        const int co = ntile * 64 + nb * 32 + (lane & 31);
+        const int ci0 = kc * KC + 8 * (lane >> 5);
+        half8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float* g = w + ((size_t)co * Cin + ci0 + j) * 27 + t * 3;
+            const double g0 = g[0], g1 = g[1], g2 = g[2];
+            const double u = ps == 0 ? g0 / 4.0
+                           : ps == 1 ? -((g0 + g1) + g2) / 6.0
+                           : ps == 2 ? -((g0 - g1) + g2) / 6.0
+                           : ps == 3 ? g0 / 24.0 + g1 / 12.0 + g2 / 6.0
+                           : ps == 4 ? g0 / 24.0 - g1 / 12.0 + g2 / 6.0
+                                     : g2;
+            const float x = (float)(u * s);
+            const _Float16 hh = (_Float16)x;
+            v[j] = hl == 0 ? hh : (_Float16)(x - (float)hh);
+        }
+        out[i] = __builtin_bit_cast(uint4, v);
+    }
+}
+
+int ilog2i(int v) { int r = 0; while ((1 << r) < v) ++r; return r; }
+
+// boxes of exactly 64 quads (two 32-row blocks per position); the cheapest cover of the volume wins
+bool choose_box4(int D, int H, int W, int npl, int& TD, int& TH, int& TW) {
+    static const int opts[][3] = {{4, 4, 16}, {4, 8, 8}, {8, 4, 8}, {8, 8, 4}, {2, 4, 32}, {4, 2, 32}, {2, 8, 16},
+                                  {8, 2, 16}, {16, 4, 4}, {4, 16, 4}};
+    int64_t best = -1;
+    for (auto& o : opts) {
+        const int qw = o[2] / 4;
+        const int64_t npos = (int64_t)(o[0] + 2) * (o[1] + 2) * qw;
+        if (npos * 4 > 3 * NTHR) continue;
+        const int64_t plane = ((npos * 16 + 255) / 256) * 256 + 16;
+        if (2 * NPOS * npl * plane > 62 * 1024) continue;          // two workgroups per CU
+        int64_t cost = (int64_t)bfm_cdiv(D, o[0]) * bfm_cdiv(H, o[1]) * bfm_cdiv(W, o[2]);
+        cost = cost * 64 - o[2];
+        if (best < 0 || cost < best) { best = cost; TD = o[0]; TH = o[1]; TW = o[2]; }
+    }
+    return best >= 0;
+}
+
+}  // namespace
+
+extern "C" size_t bfm_pack_conv_weights_wino4_bytes(int Cin, int Cout, int passes) {
+    if (Cin <= 0 || Cout <= 0 || Cin % KC || Cout % 64) return 0;
+    const int npl = passes == 3 ? 2 : 1;
+    return (size_t)(Cout / 64) * NPOS * (Cin / KC) * 9 * 2 * npl * 64 * sizeof(uint4);
+}
+
+extern "C" int bfm_pack_conv_weights_wino4(const float* w_oidhw, int Cin, int Cout, float wmax_abs_host, int passes,
+                                           void* wpacked, int* wexp_host, bfm_stream_t stream) {
+    if (!w_oidhw || !wpacked || !wexp_host || Cin <= 0 || Cout <= 0) return BFM_E_ARG;
+    if (Cin % KC || Cout % 64 || (passes != 1 && passes != 3)) return BFM_E_SHAPE;
+    int wexp = 0;
+    if (wmax_abs_host > 0.f && wmax_abs_host < INFINITY) {
+        int ex;
+        (void)frexpf(wmax_abs_host, &ex);                        // |U| <= max|g| (the rows of G sum to at most 1)
+        wexp = 14 - ex;
+        wexp = wexp > 60 ? 60 : (wexp < -60 ? -60 : wexp);
+    }
+    *wexp_host = wexp;
+    const int npl = passes == 3 ? 2 : 1;
+    const int64_t n = (int64_t)(Cout / 64) * NPOS * (Cin / KC) * 9 * 2 * npl * 64;
+    const int nb = (int)std::min<int64_t>(8192, bfm_cdiv64(n, 256));
+    hipLaunchKernelGGL(pack_wino4, dim3(nb), dim3(256), 0, bfm_s(stream), w_oidhw, Cin, Cout, wexp, npl,
+                       static_cast<uint4*>(wpacked));
+    return bfm_launch_status();
+}
+
+// rows of the output-moment table the kernel writes for this volume (its own box choice), 0 if it cannot run
+extern "C" int bfm_conv3x3x3_wino4_rows(int D, int H, int W, int passes) {
+    int TD, TH, TW;
+    if (D <= 0 || H <= 0 || W <= 0 || !choose_box4(D, H, W, passes == 3 ? 2 : 1, TD, TH, TW)) return 0;
+    return bfm_cdiv(D, TD) * bfm_cdiv(H, TH) * bfm_cdiv(W, TW);
+}
+
+extern "C" int bfm_conv3x3x3_wino4(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
+                                   const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope,
+                                   int passes, int flags, float* out, void* moment_rows, bfm_stream_t stream) {
+    const int accumulate = flags & 1;
+    if (flags & ~1) return BFM_E_ARG;                           // bit 0 = accumulate; nothing else is defined
+    if (!A || CA <= 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || G <= 0 || !wpacked || !out)
+        return BFM_E_ARG;
+    if (CA % KC || Cout % 64 || Cout <= 0) return BFM_E_SHAPE;
+    if (passes != 1 && passes != 3) return BFM_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(scale) & 15) ||
+        (reinterpret_cast<uintptr_t>(shift) & 15) || (reinterpret_cast<uintptr_t>(wpacked) & 15) ||
+        (reinterpret_cast<uintptr_t>(out) & 15))
+        return BFM_E_ARG;
+    if ((int64_t)D * H * W * CA > 0x7fffffffLL) return BFM_E_SHAPE;       // 32-bit staging offsets
+    const int npl = passes == 3 ? 2 : 1;
+    W4Params p{};
+    p.A = A; p.CA = CA; p.D = D; p.H = H; p.W = W;
+    p.scale = scale; p.shift = shift; p.bound = bound; p.G = G;
+    p.wp = static_cast<const uint4*>(wpacked);
+    p.wexp = wexp; p.Cout = Cout; p.slope = slope; p.out = out; p.accum = accumulate ? 1 : 0;
+    if (!choose_box4(D, H, W, npl, p.TD, p.TH, p.TW)) return BFM_E_SHAPE;
+    p.HT = p.TH + 2; p.QW = p.TW / 4;
+    p.qw_shift = ilog2i(p.QW); p.thq_shift = ilog2i(p.TH * p.QW);
+    const int nTz = bfm_cdiv(D, p.TD);
+    p.nTy = bfm_cdiv(H, p.TH); p.nTx = bfm_cdiv(W, p.TW);
+    p.nMt = nTz * p.nTy * p.nTx;
+    p.NT = Cout / 64;
+    p.KCN = CA / KC;
+    p.npos_lds = (p.TD + 2) * p.HT * p.QW;
+    p.plane_stride = ((p.npos_lds * 16 + 255) / 256) * 256 + 16;
+    size_t smem = (size_t)2 * NPOS * npl * p.plane_stride;
+    const size_t epi = (size_t)NPOS * 64 * MLD * sizeof(float) + (size_t)NRG * 32 * 24;   // output-transform scratch + moment fold
+    if (smem < epi) smem = epi;
+    if (smem > 64 * 1024) return BFM_E_SHAPE;
+    if (moment_rows) {
+        if (reinterpret_cast<uintptr_t>(moment_rows) & 7) return BFM_E_ARG;
+        char* rb = static_cast<char*>(moment_rows);
+        const size_t n = (size_t)p.nMt * Cout;
+        p.rsum = reinterpret_cast<double*>(rb);
+        p.rsq = reinterpret_cast<double*>(rb + n * 8);
+        p.rmn = reinterpret_cast<float*>(rb + n * 16);
+        p.rmx = reinterpret_cast<float*>(rb + n * 20);
+    }
+    if ((int64_t)p.nMt * p.NT > 0x7fffffff) return BFM_E_SHAPE;
+    dim3 grid((unsigned)(p.nMt * p.NT));
+    if (passes == 3) hipLaunchKernelGGL(conv_wino4<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+    else hipLaunchKernelGGL(conv_wino4<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+    return bfm_launch_status();
+}

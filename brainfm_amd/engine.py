@@ -97,7 +97,7 @@ def _tune_store(dev_index, passes, key, ver):
                 disk = {}
         for sct, tab in _tune_table().items():
             disk.setdefault(sct, {}).update(tab)
-        doc = {"about": "conv variant per layer shape (0 conv_mfma, 1 conv_mfma_ws, 2 conv_mfma16, 3 conv_wino); key = "
+        doc = {"about": "conv variant per layer shape (0 conv_mfma, 1 conv_mfma_ws, 2 conv_mfma16, 3 conv_wino, 4 conv_wino4); key = "
                         "cin,cout,D,H,W,two_sources,accumulate[,samples]; written by UNetEngine._autotune under "
                         "BFM_CONV_TUNE_SAVE=1 (scripts/make_tune_table.py)",
                "choices": {k: dict(sorted(v.items())) for k, v in sorted(disk.items())}}
@@ -227,13 +227,15 @@ class UNetEngine:
         st = L.stream_ptr()
         prev = ly.packs.get(layout)
         self.pack_count += 1
-        if layout == "wino":
-            nbytes = self.lib.bfm_pack_conv_weights_wino_bytes(ly.cin, ly.cout, self.passes)
+        if layout in ("wino", "wino4"):
+            fn_b = self.lib.bfm_pack_conv_weights_wino_bytes if layout == "wino" else self.lib.bfm_pack_conv_weights_wino4_bytes
+            fn_p = self.lib.bfm_pack_conv_weights_wino if layout == "wino" else self.lib.bfm_pack_conv_weights_wino4
+            nbytes = fn_b(ly.cin, ly.cout, self.passes)
             buf = prev[0] if prev is not None else torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             wexp = C.c_int(0)
             wmax = float(ly.w_raw.abs().max().item()) if wmax is None else wmax
-            L.check(self.lib.bfm_pack_conv_weights_wino(L.ptr(ly.w_raw), ly.cin, ly.cout, wmax, self.passes,
-                                                        L.ptr(buf), C.byref(wexp), st), "pack_wino " + ly.name)
+            L.check(fn_p(L.ptr(ly.w_raw), ly.cin, ly.cout, wmax, self.passes, L.ptr(buf), C.byref(wexp), st),
+                    "pack_%s %s" % (layout, ly.name))
             ly.packs[layout] = (buf, wexp.value)
         elif layout in ("mfma", "mfma16"):
             v2 = layout == "mfma16"
@@ -256,8 +258,8 @@ class UNetEngine:
     def _pack(self, ly, mfma, ver=0):
         """Pack (once per layout) and select the weights for this launch: 'direct' [27][Cin][Cout] fp32,
         'mfma' 32x32x16 fragments (plan variants 0/1), 'mfma16' 16x16x32 tap-pair fragments (variant 2),
-        'wino' F(2,3)-along-x transformed fragments (variant 3, single-source layers only)."""
-        layout = "direct" if not mfma else ("wino" if ver == 3 else ("mfma16" if ver == 2 else "mfma"))
+        'wino' F(2,3)-along-x transformed fragments (variant 3, single-source layers only), 'wino4' F(4,3) (variant 4)."""
+        layout = "direct" if not mfma else ("wino4" if ver == 4 else "wino" if ver == 3 else ("mfma16" if ver == 2 else "mfma"))
         if layout not in ly.packs:
             self._make_pack(ly, layout)
         ly.touch(layout)
@@ -363,13 +365,13 @@ class UNetEngine:
         if key not in self._plan_cache:
             cfg = (C.c_int * 8)()
             L.check(self.lib.bfm_conv3x3x3_mfma_plan(cin, cout, dims[0], dims[1], dims[2], cfg), "mfma_plan")
-            if two_src and cfg[6] == 3:                             # BFM_CONV_VER=3: Winograd takes one source
+            if two_src and cfg[6] in (3, 4):                        # BFM_CONV_VER=3/4: Winograd takes one source
                 cfg[6] = 0
             self._plan_cache[key] = cfg
         return self._plan_cache[key]
 
     def _autotune(self, ly, key, launch, vers=None):
-        """Pick the fastest conv variant (0 conv_mfma, 1 conv_mfma_ws, 2 conv_mfma16, 3 conv_wino) for this
+        """Pick the fastest conv variant (0 conv_mfma, 1 conv_mfma_ws, 2 conv_mfma16, 3 conv_wino, 4 conv_wino4) for this
         (Cin, Cout, dims, two-source) by timing them once on the real operands (HIP events on the launch stream).  All variants compute the same result; the chip is
         power-limited on this kernel, so which one wins is shape dependent (profiles/).  BFM_CONV_VER pins one."""
         import os
@@ -381,16 +383,16 @@ class UNetEngine:
         gkey = (torch.cuda.current_device(), getattr(self, "passes", None), key)
         if gkey not in _TUNE_CHOICES:
             saved = _tune_lookup(gkey[0], gkey[1], key)         # the persisted table: same bits in every process
-            if saved is not None and not (key[3] and saved == 3) and (vers is None or saved in vers):
+            if saved is not None and not (key[3] and saved in (3, 4)) and (vers is None or saved in vers):
                 _TUNE_CHOICES[gkey] = int(saved)
-        if gkey in _TUNE_CHOICES:
-            cfg[6] = _TUNE_CHOICES[gkey]
+        if gkey in _TUNE_CHOICES and (vers is None or _TUNE_CHOICES[gkey] in vers or (_TUNE_CHOICES[gkey] == 4 and 3 in vers)):
+            c = _TUNE_CHOICES[gkey]
+            cfg[6] = c if (vers is None or c in vers) else 3        # a caller that rules F(4,3) out takes F(2,3)
             self._tuned.add(key)
             return cfg
         best, best_ms = cfg[6], None
-        # Winograd (3) takes single-source layers only; its wave-specialised form (4, BFM_CONV_VER=4) has not beaten it
-        # on any shape measured so far, so it is not timed here
-        for ver in (vers if vers is not None else ((0, 1, 2) if key[3] else (0, 1, 2, 3))):
+        # Winograd (3: F(2,3), 4: F(4,3)) takes single-source layers only
+        for ver in (vers if vers is not None else ((0, 1, 2) if key[3] else (0, 1, 2, 3, 4))):
             trial = (C.c_int * 8)(*list(cfg))
             trial[6] = ver
             try:
@@ -501,6 +503,14 @@ class UNetEngine:
                                                         L.ptr(uni_flags), L.ptr(scratch), st),
                     "conv_wino(uniform) " + ly.name)
             return
+        if cfg[6] == 4:
+            if cb:
+                raise L.BfmError("the Winograd variants take one source")
+            L.check(self.lib.bfm_conv3x3x3_wino4(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound), groups,
+                                                 L.ptr(ly.wpacked), ly.wexp, ly.cout, slope, self.passes, (cfg[7] & 1),
+                                                 L.ptr(out), L.ptr(rows[0]) if rows is not None else None, st),
+                    "conv_wino4 " + ly.name)
+            return
         if cfg[6] == 3:
             if cb:
                 raise L.BfmError("the Winograd variant takes one source")
@@ -516,11 +526,38 @@ class UNetEngine:
                                                ws.numel(), L.ptr(rows[0]) if rows is not None else None, st),
                 "conv_mfma " + ly.name)
 
+    def _needs_f23(self, ly):
+        """Layers that can take the exact shortcuts (the uniform-box pair at levels 0 and 1, the masked last convolution)
+        exist only as F(2,3) kernels, and a layer must compute the same bits with a shortcut on and off: for them a
+        tuned choice of the F(4,3) kernel (variant 4) is replaced by F(2,3) -- by position in the network, never by the
+        state of a switch."""
+        ids = self.__dict__.get("_f23_ids")
+        if ids is None:
+            ids = set()
+            for i, j in ((0, 1), (1, 0), (1, 1)):
+                if i < len(self.enc):
+                    ids.add(id(self.enc[i][j]))
+            for k in (1, 2):
+                if len(self.dec) >= k:
+                    ids.add(id(self.dec[-k][0]))
+            if self.dec:
+                ids.add(id(self.dec[-1][1]))
+            self.__dict__["_f23_ids"] = ids
+        return id(ly) in ids
+
+    def _f23_cfg(self, ly, cfg):
+        if cfg[6] == 4 and (self.tape is not None or self._needs_f23(ly)):      # training keeps F(2,3) everywhere
+            cfg = (C.c_int * 8)(*list(cfg))
+            cfg[6] = 3
+        return cfg
+
     def _rows_for(self, cin, cout, dims, cfg):
         """(buffer, nrows) for the producer's output-moment rows, or None when this plan cannot emit them."""
         if not self.fuse_stats:
             return None
-        if cfg[6] in (3, 5):
+        if cfg[6] == 4:
+            n = self.lib.bfm_conv3x3x3_wino4_rows(dims[0], dims[1], dims[2], self.passes)
+        elif cfg[6] == 3:
             n = self.lib.bfm_conv3x3x3_wino_rows(dims[0], dims[1], dims[2], self.passes)
         else:
             n = self.lib.bfm_conv3x3x3_mfma_rows(cin, cout, dims[0], dims[1], dims[2], cfg)
@@ -559,7 +596,7 @@ class UNetEngine:
         if mfma:
             def _launch(c):
                 self._conv_launch(ly, A, ca, B, cb, dims, upp, scale, shift, bound, ly.groups, c, out, ws)
-            cfg = self._autotune(ly, (ly.cin, ly.cout, tuple(dims), B is not None, False), _launch)
+            cfg = self._f23_cfg(ly, self._autotune(ly, (ly.cin, ly.cout, tuple(dims), B is not None, False), _launch))
         self._pack(ly, mfma, cfg[6] if cfg is not None else 0)
         if mfma:
             ev = None
@@ -703,7 +740,7 @@ class UNetEngine:
 
         def _launch_skip(c):
             self._conv_launch(sk, A, ca, None, 0, dims, None, scale, shift, bound, ly.groups, c, out, ws)
-        cfg = self._autotune(sk, key, _launch_skip)             # trials accumulate onto garbage; overwritten below
+        cfg = self._f23_cfg(ly, self._autotune(sk, key, _launch_skip))   # trials accumulate onto garbage; overwritten below
         self._pack(sk, True, cfg[6])
         sc_b, sh_b = scale[ca:], shift[ca:]
         nv = D * H * W

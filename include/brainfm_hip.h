@@ -226,6 +226,19 @@ int bfm_gn_stats_rows_train(const void* rowsA, int nrowsA, int CA, const void* r
                             float* shift, float* bound, float* mean_out, float* rstd_out, void* workspace,
                             size_t workspace_bytes, void* ticket, bfm_stream_t stream);
 
+/* Winograd F(4,3) along x (conv3d_wino4.hip): the same SingleConv body (buildingblocks.py:31-60) with 13.5 tap-rows
+ * per output voxel instead of F(2,3)'s 18 -- dense boxes, one source, no split-K; rounding ~2x F(2,3)'s per layer
+ * (2e-6 of max|y| against a float64 convolution), so it is a choice of the tune table, never the planner's default.
+ * Weights packed by bfm_pack_conv_weights_wino4 (U = G g in float64); flags bit 0 = accumulate onto `out`;
+ * moment_rows as elsewhere ([bfm_conv3x3x3_wino4_rows()][Cout]). */
+size_t bfm_pack_conv_weights_wino4_bytes(int Cin, int Cout, int passes);
+int bfm_pack_conv_weights_wino4(const float* w_oidhw, int Cin, int Cout, float wmax_abs_host, int passes, void* wpacked,
+                                int* wexp_host, bfm_stream_t stream);
+int bfm_conv3x3x3_wino4_rows(int D, int H, int W, int passes);
+int bfm_conv3x3x3_wino4(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
+                        const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
+                        int flags, float* out, void* moment_rows /*or NULL*/, bfm_stream_t stream);
+
 size_t bfm_conv3x3x3_mfma_workspace(int Cin, int Cout, int D, int H, int W, int splitk);
 int bfm_conv3x3x3_mfma_plan(int Cin, int Cout, int D, int H, int W, int* cfg_out /*[8]*/);
 /* cfg[7] bit 0 ("accumulate"): add what `out` already holds before the LeakyReLU -- used for the skip half of a

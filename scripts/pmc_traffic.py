@@ -21,7 +21,7 @@ def last_step(path, counter):
 
 def family(name):
     """bench.py's kernel names (CONV_KERNELS); longest match first."""
-    for k in ("conv_upfold", "conv_wino_masked", "conv_wino_uniform", "conv_wino", "conv_mfma16", "conv_mfma_ws", "conv_mfma",
+    for k in ("conv_upfold", "conv_wino_masked", "conv_wino_uniform", "conv_wino4", "conv_wino", "conv_mfma16", "conv_mfma_ws", "conv_mfma",
               "conv_stem", "tail_kernel"):
         if k in name:
             return k
