@@ -291,6 +291,16 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino4(const W4Params p) {
     // ================= epilogue: output transform through LDS =================
     float* m = reinterpret_cast<float*>(lds);                      // [6 positions][64 accumulator rows][MLD]
     const int col = tid & 31, rg = tid >> 5;
+    const bool interior = z0 + p.TD <= p.D && y0 + p.TH <= p.H && x0 + p.TW <= p.W;      // wave-uniform
+    unsigned off_t = 0;
+    int un[4] = {0, 0, 0, 0};
+    if (interior) {
+        int d_t, h_t, j_t;
+        quad_coords(p, rg, d_t, h_t, j_t);
+        off_t = (unsigned)(((d_t * p.H + h_t) * p.W + 4 * j_t) * p.Cout + col);
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) un[s2] = row_unperm(rg + 8 * s2);
+    }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         __syncthreads();                                           // A planes (or the previous round) fully consumed
@@ -304,6 +314,48 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino4(const W4Params p) {
         }
         __syncthreads();
         float fs = 0.f, fq = 0.f, fmn = INFINITY, fmx = -INFINITY;   // this thread's column, its 8 quads (<= 32 values)
+        if (interior) {
+            // Interior boxes (all of a 160^3 tile but its last slabs): the thread's quads are q = rg + 8 it, and the bit
+            // fields (d, h, j) of q split into a per-thread part (the three bits of rg, computed once: off_t) and a
+            // wave-uniform part (8 it, on the scalar unit) -- no index arithmetic, no bounds tests per value
+            float* ob = p.out + nt * 64 + nb * 32;
+            float prev[8][4];
+            if (p.accum) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    int d_u, h_u, j_u;
+                    quad_coords(p, 8 * it, d_u, h_u, j_u);
+                    const float* o = ob + (((int64_t)(z0 + d_u) * p.H + (y0 + h_u)) * p.W + x0 + 4 * j_u) * p.Cout;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) prev[it][k] = o[off_t + (unsigned)(k * p.Cout)];
+                }
+            }
+            const float* mc = m + col;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                int d_u, h_u, j_u;
+                quad_coords(p, 8 * it, d_u, h_u, j_u);
+                float* o = ob + (((int64_t)(z0 + d_u) * p.H + (y0 + h_u)) * p.W + x0 + 4 * j_u) * p.Cout;
+                const int qr = 32 * (it >> 2) + un[it & 3];              // accumulator row holding quad rg + 8 it
+                const float* mr = mc + qr * MLD;
+                const float m0 = mr[0 * 64 * MLD], m1 = mr[1 * 64 * MLD], m2 = mr[2 * 64 * MLD];
+                const float m3 = mr[3 * 64 * MLD], m4 = mr[4 * 64 * MLD], m5 = mr[5 * 64 * MLD];
+                const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                float y[4];
+                y[0] = ((m0 + s1) + s2) * dq;
+                y[1] = fmaf(2.f, d2, d1) * dq;
+                y[2] = fmaf(4.f, s2, s1) * dq;
+                y[3] = (fmaf(8.f, d2, d1) + m5) * dq;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float r = y[k];
+                    if (p.accum) r = r + prev[it][k];
+                    r = r >= 0.f ? r : r * p.slope;
+                    o[off_t + (unsigned)(k * p.Cout)] = r;
+                    fs += r; fq = fmaf(r, r, fq); fmn = fminf(fmn, r); fmx = fmaxf(fmx, r);
+                }
+            }
+        } else
 #pragma unroll 2
         for (int q = rg; q < 64; q += NRG) {
             int d, h, j;
