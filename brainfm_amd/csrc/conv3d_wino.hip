@@ -18,6 +18,7 @@
 // dequantises, optionally adds what `out` holds (accumulate mode, the skip half of an up-folded decoder conv),
 // applies LeakyReLU and stores 128-byte row segments.  Single-source inputs only (CB == 0), no split-K.
 #include "bfm_common.h"
+#include "wino_shared.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -723,6 +724,18 @@ bool choose_box(int D, int H, int W, int npl, int& TD, int& TH, int& TW) {
 }
 
 }  // namespace
+
+bool bfm_wino_choose_box(int D, int H, int W, int npl, int& TD, int& TH, int& TW) { return choose_box(D, H, W, npl, TD, TH, TW); }
+
+int bfm_wino_mask_list(const float* mask_img, int D, int H, int W, int TD, int TH, int TW, int nTy, int nTx, int nMt, void* ws,
+                       bfm_stream_t stream) {
+    unsigned char* act = static_cast<unsigned char*>(ws);
+    int* cnt = reinterpret_cast<int*>(act + (((size_t)nMt + 3) & ~(size_t)3));
+    hipLaunchKernelGGL(wino_box_active_kernel, dim3((unsigned)bfm_cdiv(nMt, 4)), dim3(256), 0, bfm_s(stream), mask_img, D, H, W,
+                       TD, TH, TW, nTy, nTx, nMt, act);
+    hipLaunchKernelGGL(wino_mask_list_kernel, dim3(1), dim3(1024), 0, bfm_s(stream), act, nMt, cnt + 1, cnt);
+    return bfm_launch_status();
+}
 
 extern "C" size_t bfm_pack_conv_weights_wino_bytes(int Cin, int Cout, int passes) {
     if (Cin <= 0 || Cout <= 0 || Cin % KC || Cout % 64) return 0;

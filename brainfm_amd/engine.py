@@ -490,19 +490,21 @@ class UNetEngine:
         slope = self.slope if slope is None else float(slope)
         self._pack(ly, True, cfg[6])
         if mask_img is not None:
-            if cfg[6] != 3 or cb or rows is not None:
-                raise L.BfmError("a masked launch is the one-source 4-wave Winograd kernel without moment rows")
+            if cfg[6] not in (3, 4) or cb or rows is not None:
+                raise L.BfmError("a masked launch is a one-source Winograd kernel without moment rows")
             nws = self.lib.bfm_conv3x3x3_wino_masked_workspace(D, H, W, self.passes)
             mws = torch.empty(nws, dtype=torch.uint8, device=self.device)       # box activity, count, list of boxes
-            L.check(self.lib.bfm_conv3x3x3_wino_masked(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
+            fn = self.lib.bfm_conv3x3x3_wino_masked if cfg[6] == 3 else self.lib.bfm_conv3x3x3_wino4_masked
+            L.check(fn(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
                                                        groups, L.ptr(ly.wpacked), ly.wexp, ly.cout, slope, self.passes,
                                                        cfg[7] & 1, L.ptr(out), L.ptr(mask_img), L.ptr(mws), nws, st),
                     "conv_wino(masked) " + ly.name)
             return
-        if uni_flags is not None and cfg[6] == 3 and not cb:
+        if uni_flags is not None and cfg[6] in (3, 4) and not cb:
             scratch = torch.empty(self.lib.bfm_conv3x3x3_wino_uniform_scratch(ly.cout), dtype=torch.uint8,
                                   device=self.device)
-            L.check(self.lib.bfm_conv3x3x3_wino_uniform(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
+            fn = self.lib.bfm_conv3x3x3_wino_uniform if cfg[6] == 3 else self.lib.bfm_conv3x3x3_wino4_uniform
+            L.check(fn(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
                                                         groups, L.ptr(ly.wpacked), ly.wexp, ly.cout, slope, self.passes,
                                                         cfg[7] & 1, L.ptr(out), L.ptr(rows[0]) if rows is not None else None,
                                                         L.ptr(uni_flags), L.ptr(scratch), st),
@@ -531,27 +533,10 @@ class UNetEngine:
                                                ws.numel(), L.ptr(rows[0]) if rows is not None else None, st),
                 "conv_mfma " + ly.name)
 
-    def _needs_f23(self, ly):
-        """Layers that can take the exact shortcuts (the uniform-box pair at levels 0 and 1, the masked last convolution)
-        exist only as F(2,3) kernels, and a layer must compute the same bits with a shortcut on and off: for them a
-        tuned choice of the F(4,3) kernel (variant 4) is replaced by F(2,3) -- by position in the network, never by the
-        state of a switch."""
-        ids = self.__dict__.get("_f23_ids")
-        if ids is None:
-            ids = set()
-            for i, j in ((0, 1), (1, 0), (1, 1)):
-                if i < len(self.enc):
-                    ids.add(id(self.enc[i][j]))
-            for k in (1, 2):
-                if len(self.dec) >= k:
-                    ids.add(id(self.dec[-k][0]))
-            if self.dec:
-                ids.add(id(self.dec[-1][1]))
-            self.__dict__["_f23_ids"] = ids
-        return id(ly) in ids
-
     def _f23_cfg(self, ly, cfg):
-        if cfg[6] == 4 and (self.tape is not None or self._needs_f23(ly)):      # training keeps F(2,3) everywhere
+        """Training keeps F(2,3) where a shape's tuned choice is the F(4,3) kernel (variant 4): its backward pass is
+        verified against the reference at F(2,3)'s rounding."""
+        if cfg[6] == 4 and self.tape is not None:
             cfg = (C.c_int * 8)(*list(cfg))
             cfg[6] = 3
         return cfg
@@ -606,9 +591,9 @@ class UNetEngine:
         if mfma:
             ev = None
             reps = 1
-            if mask_img is not None and not (cfg[6] == 3 and B is None and self.tape is None):
+            if mask_img is not None and not (cfg[6] in (3, 4) and B is None and self.tape is None):
                 mask_img = None
-            if uni_flags is not None and not (cfg[6] == 3 and B is None and mask_img is None):
+            if uni_flags is not None and not (cfg[6] in (3, 4) and B is None and mask_img is None):
                 uni_flags = None
             rows = self._rows_for(ly.cin, ly.cout, dims, cfg) if mask_img is None else None
             if self.prof is not None:
@@ -768,7 +753,7 @@ class UNetEngine:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         rows = self._rows_for(ca, ly.cout, dims, cfg)
-        if uni_flags is not None and cfg[6] != 3:
+        if uni_flags is not None and cfg[6] not in (3, 4):
             uni_flags = None
         for _ in range(reps):
             self._conv_launch(sk, A, ca, None, 0, dims, None, scale, shift, bound, ly.groups, cfg, out, ws, rows,

@@ -552,7 +552,7 @@ def test_groupnorm_from_rows_one_launch_equals_the_separate_launches(shape):
         assert int(ticket.abs().sum()) == 0
 
 
-@pytest.mark.parametrize("ver", [0, 2, 3])
+@pytest.mark.parametrize("ver", [0, 2, 3, 4])
 def test_producer_moment_rows_equal_activation_moments(ver, monkeypatch):
     """The per-tile {sum, sumsq, min, max} rows written by the stem / conv epilogues must be the moments of the
     stored activation (sums to fp32-partial accuracy; min/max exact), and GroupNorm from rows must reproduce GroupNorm from the
@@ -996,8 +996,9 @@ def test_matrix_core_path_vs_reference_golden_64_wide():
     print("conv variants used on the 64-wide golden net:", sorted(used))
 
 
+@pytest.mark.parametrize("ver", [3, 4])
 @pytest.mark.parametrize("dims", [(16, 16, 64), (13, 22, 37), (24, 8, 48)])
-def test_masked_last_convolution_computes_exactly_the_boxes_that_hold_input(dims):
+def test_masked_last_convolution_computes_exactly_the_boxes_that_hold_input(dims, ver):
     """bfm_conv3x3x3_wino_masked (the tile loop's last convolution): a box of output voxels is computed -- bit for bit what
     bfm_conv3x3x3_wino_ex stores there -- when the tile's input has a non-zero voxel inside it, and is left untouched
     otherwise; NaN and negative inputs count as non-zero like `im != 0` does (scripts/demo_test.py:88)."""
@@ -1020,7 +1021,7 @@ def test_masked_last_convolution_computes_exactly_the_boxes_that_hold_input(dims
     bound = torch.full((ly.groups,), 8.0, device=_dev())
     cfg = (C.c_int * 8)()
     L.check(eng.lib.bfm_conv3x3x3_mfma_plan(64, 64, D, H, W, cfg), "plan")
-    cfg[6], cfg[7] = 3, 0
+    cfg[6], cfg[7] = ver, 0                              # 3: F(2,3) (bfm_conv3x3x3_wino_masked), 4: F(4,3) (..._wino4_masked)
     ws = torch.empty(1 << 20, dtype=torch.uint8, device=_dev())
     full = torch.empty(dims + (64,), device=_dev())
     eng._conv_launch(ly, A, 64, None, 0, dims, None, scale, shift, bound, ly.groups, cfg, full, ws)
@@ -1139,8 +1140,9 @@ def test_compact_rows_index_pack_and_stitch_equal_the_dense_form_bitwise(shape, 
         assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
 
 
+@pytest.mark.parametrize("ver", [3, 4])
 @pytest.mark.parametrize("dims", [(48, 64, 128), (50, 66, 130), (45, 70, 150)])
-def test_uniform_background_boxes_change_no_bit(dims):
+def test_uniform_background_boxes_change_no_bit(dims, ver, monkeypatch):
     """Where the one-channel input is constant (the zero background of a head volume) the first layers' activations are one
     function of the distances to the tile's faces, and the two full-resolution Winograd layers that read them compute ONE box
     per class of boxes that see nothing else (first / middle / last box per axis: 27 classes) and reuse its accumulators in
@@ -1153,6 +1155,7 @@ def test_uniform_background_boxes_change_no_bit(dims):
     from brainfm_amd import test_utils as TU
     import ctypes as C
     from brainfm_amd import _lib as L
+    monkeypatch.setenv("BFM_CONV_VER", str(ver))         # 3: the F(2,3) pair, 4: the F(4,3) pair (conv3d_wino4.hip)
     ga, ta = TU.default_inference_args(f_maps=64, num_levels=3)
     g = torch.Generator().manual_seed(3)
     zz, yy, xx = np.meshgrid(*[np.linspace(-1, 1, n_) for n_ in dims], indexing="ij")
@@ -1201,8 +1204,8 @@ def test_uniform_background_boxes_change_no_bit(dims):
                 for c in range(27):
                     hit = np.flatnonzero(fl == c + 1)
                     assert first[c] == (int(hit[0]) if hit.size else nb), (lvl, rad, c)
-            kinds = s.engine.conv_choices()
-            assert 3 in set(kinds.values())                       # the Winograd variant ran: the flags were used
+            kinds = {int(c[6]) for c in s.engine._plan_cache.values()}
+            assert ver in kinds                                   # the Winograd variant ran: the flags were used
     for k in outs[True]:
         if k == "feat":
             for a, b in zip(outs[True][k], outs[False][k]):
