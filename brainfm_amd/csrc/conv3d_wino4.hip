@@ -58,8 +58,6 @@ struct W4Params {
     int npos_lds, plane_stride;      // (TD+2)*HT*QW positions; bytes per plane
     double *rsum, *rsq;              // optional output-moment rows [nMt][Cout] (see conv3d_mfma.hip)
     float *rmn, *rmx;
-    const unsigned char* uni_flags;  // optional [nMt]: 0, or 1 + the class of a box whose operands equal its class mates'
-    float* uni_acc;                  // [27][NT][2][8][NTHR][4]: the class representatives' output-transformed sums
     const int* list;                 // sparse forms: the boxes to compute, ascending
     const int* list_n;               // ... their number, on the device
 };
@@ -108,15 +106,15 @@ __device__ __forceinline__ void split_store4(const float (&t)[4], unsigned char*
     }
 }
 
-// MODE 0: every box in full.  1 (conv_wino4_masked): the boxes of p.list (those that hold input).  2 / 3 (conv_wino4_rest,
-// conv_wino4_uniform; launched as a pair): as conv3d_wino.hip's -- rest computes the unflagged boxes and the first flagged
-// box of every class, whose output-transformed sums (before accumulate mode and the activation) it leaves in uni_acc in
-// the epilogue's own thread order; uniform gives every other flagged box its class's sums and runs the rest of the
-// epilogue on them (no staging, no weights, no matrix products).
+// MODE 0: every box in full.  1 (conv_wino4_masked): the boxes of p.list (those that hold input).
+// There is no uniform-box pair of this kernel, on purpose: conv_wino's pair rests on class mates multiplying the same
+// operands, which needs a layer's NUMERICAL support to be its mathematical one.  F(2,3) has that property (y0 = m0 + m1 + m2
+// touches d0, d1, d2 only); F(4,3) does not -- y0 = m0 + .. + m4 rounds differently when d3, d4 change although they
+// cancel exactly -- so a box at the edge of the constant background would need a reach of 4 voxels along x per layer
+// instead of 1.  Built and measured (tests/diag/diag_wino4_uniform*.py: the pair is exact kernel by kernel, the network
+// is not); the layers that can take that shortcut stay with conv_wino (engine._needs_f23).
 template <int NPASS, int MODE>
 __device__ __forceinline__ void conv_wino4_body(const W4Params& p) {
-    constexpr bool UNI = MODE == 3;
-    constexpr bool BY_FLAG = MODE == 2 || MODE == 3;
     constexpr bool LIST = MODE != 0;
     constexpr int NPL = (NPASS == 3) ? 2 : 1;
     constexpr int NF = 2 * NPL;
@@ -140,9 +138,6 @@ __device__ __forceinline__ void conv_wino4_body(const W4Params& p) {
     }
     const int mt = LIST ? p.list[item / p.NT] : item / p.NT;
     const int nt = item % p.NT;
-    int cls = 0;                                         // 1 + class of a flagged box
-    if constexpr (BY_FLAG) cls = __builtin_amdgcn_readfirstlane((int)p.uni_flags[mt]);
-    const bool rep = MODE == 2 && cls != 0;
     const int tx = mt % p.nTx;
     const int ty = (mt / p.nTx) % p.nTy;
     const int tz = mt / (p.nTx * p.nTy);
@@ -222,7 +217,7 @@ __device__ __forceinline__ void conv_wino4_body(const W4Params& p) {
             dst[1][f] = wbB[(size_t)sc * (NF * 64) + f * 64];
         }
     };
-    if constexpr (!UNI) fetch(0, wq[0]);
+    fetch(0, wq[0]);
 
     auto do_chunk = [&](int kc, auto par_tag) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;      // parity of the chunk's first weight step (9 steps per chunk)
@@ -301,16 +296,10 @@ __device__ __forceinline__ void conv_wino4_body(const W4Params& p) {
             }
         }
     };
-    if constexpr (!UNI) {
-        for (int kc = 0; kc < p.KCN; kc += 2) {          // 9 steps per chunk: the parity flips every chunk
-            do_chunk(kc, std::integral_constant<int, 0>{});
-            if (kc + 1 < p.KCN) do_chunk(kc + 1, std::integral_constant<int, 1>{});
-        }
+    for (int kc = 0; kc < p.KCN; kc += 2) {              // 9 steps per chunk: the parity flips every chunk
+        do_chunk(kc, std::integral_constant<int, 0>{});
+        if (kc + 1 < p.KCN) do_chunk(kc + 1, std::integral_constant<int, 1>{});
     }
-    // y0..y3 of the thread's quad `it` of column block nb: [class][nt][nb][it][thread]
-    float4* const ybuf = BY_FLAG && cls ? reinterpret_cast<float4*>(p.uni_acc) +
-                                              ((size_t)(cls - 1) * p.NT + nt) * (2 * 8 * NTHR) + tid
-                                        : nullptr;
 
     // ================= epilogue: output transform through LDS =================
     float* m = reinterpret_cast<float*>(lds);                      // [6 positions][64 accumulator rows][MLD]
@@ -328,17 +317,15 @@ __device__ __forceinline__ void conv_wino4_body(const W4Params& p) {
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         __syncthreads();                                           // A planes (or the previous round) fully consumed
-        if constexpr (!UNI) {
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int pos = u < 2 ? posA : posB, mb = u < 2 ? u : mbB;
-                float* mw = m + (pos * 64 + mb * 32 + khalf * 4) * MLD + l32;
+        for (int u = 0; u < 3; ++u) {
+            const int pos = u < 2 ? posA : posB, mb = u < 2 ? u : mbB;
+            float* mw = m + (pos * 64 + mb * 32 + khalf * 4) * MLD + l32;
 #pragma unroll
-                for (int i = 0; i < 16; ++i)                        // accumulator row order; the reader undoes row_perm
-                    mw[((i >> 2) * 8 + (i & 3)) * MLD] = acc[u][nb][i];
-            }
-            __syncthreads();
+            for (int i = 0; i < 16; ++i)                            // accumulator row order; the reader undoes row_perm
+                mw[((i >> 2) * 8 + (i & 3)) * MLD] = acc[u][nb][i];
         }
+        __syncthreads();
         float fs = 0.f, fq = 0.f, fmn = INFINITY, fmx = -INFINITY;   // this thread's column, its 8 quads (<= 32 values)
         if (interior) {
             // Interior boxes (all of a 160^3 tile but its last slabs): the thread's quads are q = rg + 8 it, and the bit
@@ -362,22 +349,16 @@ __device__ __forceinline__ void conv_wino4_body(const W4Params& p) {
                 int d_u, h_u, j_u;
                 quad_coords(p, 8 * it, d_u, h_u, j_u);
                 float* o = ob + (((int64_t)(z0 + d_u) * p.H + (y0 + h_u)) * p.W + x0 + 4 * j_u) * p.Cout;
+                const int qr = 32 * (it >> 2) + un[it & 3];              // accumulator row holding quad rg + 8 it
+                const float* mr = mc + qr * MLD;
+                const float m0 = mr[0 * 64 * MLD], m1 = mr[1 * 64 * MLD], m2 = mr[2 * 64 * MLD];
+                const float m3 = mr[3 * 64 * MLD], m4 = mr[4 * 64 * MLD], m5 = mr[5 * 64 * MLD];
+                const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
                 float y[4];
-                if constexpr (UNI) {
-                    const float4 yy = ybuf[(nb * 8 + it) * NTHR];
-                    y[0] = yy.x; y[1] = yy.y; y[2] = yy.z; y[3] = yy.w;
-                } else {
-                    const int qr = 32 * (it >> 2) + un[it & 3];          // accumulator row holding quad rg + 8 it
-                    const float* mr = mc + qr * MLD;
-                    const float m0 = mr[0 * 64 * MLD], m1 = mr[1 * 64 * MLD], m2 = mr[2 * 64 * MLD];
-                    const float m3 = mr[3 * 64 * MLD], m4 = mr[4 * 64 * MLD], m5 = mr[5 * 64 * MLD];
-                    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-                    y[0] = ((m0 + s1) + s2) * dq;
-                    y[1] = fmaf(2.f, d2, d1) * dq;
-                    y[2] = fmaf(4.f, s2, s1) * dq;
-                    y[3] = (fmaf(8.f, d2, d1) + m5) * dq;
-                    if (MODE == 2 && rep) ybuf[(nb * 8 + it) * NTHR] = make_float4(y[0], y[1], y[2], y[3]);
-                }
+                y[0] = ((m0 + s1) + s2) * dq;
+                y[1] = fmaf(2.f, d2, d1) * dq;
+                y[2] = fmaf(4.f, s2, s1) * dq;
+                y[3] = (fmaf(8.f, d2, d1) + m5) * dq;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float r = y[k];
@@ -394,22 +375,16 @@ __device__ __forceinline__ void conv_wino4_body(const W4Params& p) {
             quad_coords(p, q, d, h, j);
             const int gz = z0 + d, gy = y0 + h, gx = x0 + 4 * j;
             if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
+            const int qr = (q & ~31) + row_unperm(q & 31);           // accumulator row holding quad q
+            const float* mr = m + qr * MLD + col;
+            const float m0 = mr[0 * 64 * MLD], m1 = mr[1 * 64 * MLD], m2 = mr[2 * 64 * MLD];
+            const float m3 = mr[3 * 64 * MLD], m4 = mr[4 * 64 * MLD], m5 = mr[5 * 64 * MLD];
+            const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
             float y[4];
-            if constexpr (UNI) {
-                const float4 yy = ybuf[(nb * 8 + (q >> 3)) * NTHR];
-                y[0] = yy.x; y[1] = yy.y; y[2] = yy.z; y[3] = yy.w;
-            } else {
-                const int qr = (q & ~31) + row_unperm(q & 31);       // accumulator row holding quad q
-                const float* mr = m + qr * MLD + col;
-                const float m0 = mr[0 * 64 * MLD], m1 = mr[1 * 64 * MLD], m2 = mr[2 * 64 * MLD];
-                const float m3 = mr[3 * 64 * MLD], m4 = mr[4 * 64 * MLD], m5 = mr[5 * 64 * MLD];
-                const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-                y[0] = ((m0 + s1) + s2) * dq;
-                y[1] = fmaf(2.f, d2, d1) * dq;
-                y[2] = fmaf(4.f, s2, s1) * dq;
-                y[3] = (fmaf(8.f, d2, d1) + m5) * dq;
-                if (MODE == 2 && rep) ybuf[(nb * 8 + (q >> 3)) * NTHR] = make_float4(y[0], y[1], y[2], y[3]);
-            }
+            y[0] = ((m0 + s1) + s2) * dq;
+            y[1] = fmaf(2.f, d2, d1) * dq;
+            y[2] = fmaf(4.f, s2, s1) * dq;
+            y[3] = (fmaf(8.f, d2, d1) + m5) * dq;
             float* o = p.out + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + nt * 64 + nb * 32 + col;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -424,7 +399,7 @@ __device__ __forceinline__ void conv_wino4_body(const W4Params& p) {
         }
         if (p.rsum != nullptr) {
             // moment row of this box: fold the 8 row groups of every column in fixed order (scratch behind m)
-            double* ls = reinterpret_cast<double*>(lds + (UNI ? 0 : (size_t)NPOS * 64 * MLD * sizeof(float)));   // [8][32]
+            double* ls = reinterpret_cast<double*>(lds + (size_t)NPOS * 64 * MLD * sizeof(float));   // [8][32]
             double* lq = ls + NRG * 32;
             float* lmn = reinterpret_cast<float*>(lq + NRG * 32);
             float* lmx = lmn + NRG * 32;
@@ -450,10 +425,6 @@ template <int NPASS>
 __global__ void __launch_bounds__(NTHR, 2) conv_wino4(const W4Params p) { conv_wino4_body<NPASS, 0>(p); }
 template <int NPASS>
 __global__ void __launch_bounds__(NTHR, 2) conv_wino4_masked(const W4Params p) { conv_wino4_body<NPASS, 1>(p); }
-template <int NPASS>
-__global__ void __launch_bounds__(NTHR, 2) conv_wino4_rest(const W4Params p) { conv_wino4_body<NPASS, 2>(p); }
-template <int NPASS>
-__global__ void __launch_bounds__(NTHR, 2) conv_wino4_uniform(const W4Params p) { conv_wino4_body<NPASS, 3>(p); }
 
 // packed[ntile64][pos 6][kc][(kd,kh) 9][nb 2][hl][lane] (uint4 = 8 halfs): lane l holds
 // B[k = 8*(l>>5)+j][n = l&31] = U_pos[co = ntile*64 + nb*32 + (l&31)][ci = kc*16 + 8*(l>>5) + j][kd][kh] * 2^wexp, U = G g along kw
@@ -543,8 +514,7 @@ extern "C" int bfm_conv3x3x3_wino4_rows(int D, int H, int W, int passes) {
 
 static int w4_launch(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift, const float* bound,
                      int G, const void* wpacked, int wexp, int Cout, float slope, int passes, int flags, float* out,
-                     void* moment_rows, const float* mask_img, void* mask_ws, const unsigned char* uni_flags, float* uni_acc,
-                     bfm_stream_t stream) {
+                     void* moment_rows, const float* mask_img, void* mask_ws, bfm_stream_t stream) {
     const int accumulate = flags & 1;
     if (flags & ~1) return BFM_E_ARG;                           // bit 0 = accumulate; nothing else is defined
     if (!A || CA <= 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || G <= 0 || !wpacked || !out)
@@ -562,7 +532,6 @@ static int w4_launch(const float* A, int CA, int D, int H, int W, const float* s
     p.scale = scale; p.shift = shift; p.bound = bound; p.G = G;
     p.wp = static_cast<const uint4*>(wpacked);
     p.wexp = wexp; p.Cout = Cout; p.slope = slope; p.out = out; p.accum = accumulate ? 1 : 0;
-    p.uni_flags = uni_flags; p.uni_acc = uni_acc;
     if (!choose_box4(D, H, W, npl, p.TD, p.TH, p.TW)) return BFM_E_SHAPE;
     p.HT = p.TH + 2; p.QW = p.TW / 4;
     p.qw_shift = ilog2i(p.QW); p.thq_shift = ilog2i(p.TH * p.QW);
@@ -600,18 +569,6 @@ static int w4_launch(const float* A, int CA, int D, int H, int W, const float* s
         else hipLaunchKernelGGL(conv_wino4_masked<1>, grid, dim3(NTHR), smem, st, p);
         return bfm_launch_status();
     }
-    if (uni_flags) {                                           // disjoint boxes: the two launches may overlap
-        // bfm_uniform_boxes' buffer: flags[nMt pad 4] | first[27] | the two counts | rest[nMt] | uni[nMt]
-        const int* cnt = reinterpret_cast<const int*>(uni_flags + (((size_t)p.nMt + 3) & ~(size_t)3)) + 27;
-        p.list = cnt + 2; p.list_n = cnt;
-        if (passes == 3) hipLaunchKernelGGL(conv_wino4_rest<3>, grid, dim3(NTHR), smem, st, p);
-        else hipLaunchKernelGGL(conv_wino4_rest<1>, grid, dim3(NTHR), smem, st, p);
-        p.list = cnt + 2 + p.nMt; p.list_n = cnt + 1;
-        const size_t usm = (size_t)NRG * 32 * 24;              // the moment fold alone
-        if (passes == 3) hipLaunchKernelGGL(conv_wino4_uniform<3>, grid, dim3(NTHR), usm, st, p);
-        else hipLaunchKernelGGL(conv_wino4_uniform<1>, grid, dim3(NTHR), usm, st, p);
-        return bfm_launch_status();
-    }
     if (passes == 3) hipLaunchKernelGGL(conv_wino4<3>, grid, dim3(NTHR), smem, st, p);
     else hipLaunchKernelGGL(conv_wino4<1>, grid, dim3(NTHR), smem, st, p);
     return bfm_launch_status();
@@ -621,7 +578,7 @@ extern "C" int bfm_conv3x3x3_wino4(const float* A, int CA, int D, int H, int W, 
                                    const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope,
                                    int passes, int flags, float* out, void* moment_rows, bfm_stream_t stream) {
     return w4_launch(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out, moment_rows,
-                     nullptr, nullptr, nullptr, nullptr, stream);
+                     nullptr, nullptr, stream);
 }
 
 // the tile loop's last convolution (boxes that hold input only); workspace: bfm_conv3x3x3_wino_masked_workspace() bytes
@@ -634,16 +591,5 @@ extern "C" int bfm_conv3x3x3_wino4_masked(const float* A, int CA, int D, int H, 
         workspace_bytes < bfm_conv3x3x3_wino_masked_workspace(D, H, W, passes))
         return BFM_E_ARG;
     return w4_launch(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out, nullptr,
-                     mask_image, workspace, nullptr, nullptr, stream);
-}
-
-// the uniform-box pair; uniform_flags: bfm_uniform_boxes' buffer, scratch: bfm_conv3x3x3_wino_uniform_scratch(Cout) bytes
-extern "C" int bfm_conv3x3x3_wino4_uniform(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
-                                           const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope,
-                                           int passes, int flags, float* out, void* moment_rows,
-                                           const unsigned char* uniform_flags, void* scratch, bfm_stream_t stream) {
-    if (!uniform_flags || !scratch || (flags & ~1)) return BFM_E_ARG;
-    if ((reinterpret_cast<uintptr_t>(uniform_flags) & 3) || (reinterpret_cast<uintptr_t>(scratch) & 15)) return BFM_E_ARG;
-    return w4_launch(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out, moment_rows,
-                     nullptr, nullptr, uniform_flags, static_cast<float*>(scratch), stream);
+                     mask_image, workspace, stream);
 }

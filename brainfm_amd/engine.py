@@ -500,10 +500,10 @@ class UNetEngine:
                                                        cfg[7] & 1, L.ptr(out), L.ptr(mask_img), L.ptr(mws), nws, st),
                     "conv_wino(masked) " + ly.name)
             return
-        if uni_flags is not None and cfg[6] in (3, 4) and not cb:
+        if uni_flags is not None and cfg[6] == 3 and not cb:
             scratch = torch.empty(self.lib.bfm_conv3x3x3_wino_uniform_scratch(ly.cout), dtype=torch.uint8,
                                   device=self.device)
-            fn = self.lib.bfm_conv3x3x3_wino_uniform if cfg[6] == 3 else self.lib.bfm_conv3x3x3_wino4_uniform
+            fn = self.lib.bfm_conv3x3x3_wino_uniform
             L.check(fn(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
                                                         groups, L.ptr(ly.wpacked), ly.wexp, ly.cout, slope, self.passes,
                                                         cfg[7] & 1, L.ptr(out), L.ptr(rows[0]) if rows is not None else None,
@@ -533,10 +533,28 @@ class UNetEngine:
                                                ws.numel(), L.ptr(rows[0]) if rows is not None else None, st),
                 "conv_mfma " + ly.name)
 
+    def _needs_f23(self, ly):
+        """The layers that can take the uniform-box shortcut (the second conv of encoders.0, both of encoders.1, the skip
+        halves of the last two decoders' first convs) stay with F(2,3): the shortcut rests on class mates multiplying the
+        same operands, F(2,3)'s numerical support is its mathematical one, F(4,3)'s rounding reaches 4 voxels along x
+        (conv3d_wino4.hip) -- and a layer must compute the same bits with the shortcut on and off, so the rule goes by
+        position in the network, never by the state of a switch."""
+        ids = self.__dict__.get("_f23_ids")
+        if ids is None:
+            ids = set()
+            for i, j in ((0, 1), (1, 0), (1, 1)):
+                if i < len(self.enc):
+                    ids.add(id(self.enc[i][j]))
+            for k in (1, 2):
+                if len(self.dec) >= k:
+                    ids.add(id(self.dec[-k][0]))
+            self.__dict__["_f23_ids"] = ids
+        return id(ly) in ids
+
     def _f23_cfg(self, ly, cfg):
-        """Training keeps F(2,3) where a shape's tuned choice is the F(4,3) kernel (variant 4): its backward pass is
-        verified against the reference at F(2,3)'s rounding."""
-        if cfg[6] == 4 and self.tape is not None:
+        """A tuned choice of the F(4,3) kernel (variant 4) becomes F(2,3) for the uniform-box layers and in training (the
+        backward pass is verified against the reference at F(2,3)'s rounding)."""
+        if cfg[6] == 4 and (self.tape is not None or self._needs_f23(ly)):
             cfg = (C.c_int * 8)(*list(cfg))
             cfg[6] = 3
         return cfg
@@ -593,7 +611,7 @@ class UNetEngine:
             reps = 1
             if mask_img is not None and not (cfg[6] in (3, 4) and B is None and self.tape is None):
                 mask_img = None
-            if uni_flags is not None and not (cfg[6] in (3, 4) and B is None and mask_img is None):
+            if uni_flags is not None and not (cfg[6] == 3 and B is None and mask_img is None):
                 uni_flags = None
             rows = self._rows_for(ly.cin, ly.cout, dims, cfg) if mask_img is None else None
             if self.prof is not None:
@@ -753,7 +771,7 @@ class UNetEngine:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         rows = self._rows_for(ca, ly.cout, dims, cfg)
-        if uni_flags is not None and cfg[6] not in (3, 4):
+        if uni_flags is not None and cfg[6] != 3:
             uni_flags = None
         for _ in range(reps):
             self._conv_launch(sk, A, ca, None, 0, dims, None, scale, shift, bound, ly.groups, cfg, out, ws, rows,

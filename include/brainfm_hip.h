@@ -238,17 +238,13 @@ int bfm_conv3x3x3_wino4_rows(int D, int H, int W, int passes);
 int bfm_conv3x3x3_wino4(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                         const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
                         int flags, float* out, void* moment_rows /*or NULL*/, bfm_stream_t stream);
-/* The sparse forms of the same kernel, box for box those of bfm_conv3x3x3_wino_masked / _wino_uniform (same boxes, the same
- * mask workspace, bfm_uniform_boxes buffer and scratch sizes): a layer computes the same bits with a shortcut on and off as
- * long as both launches are of the same variant. */
+/* The masked form of the same kernel, box for box that of bfm_conv3x3x3_wino_masked (same boxes, same workspace).  There
+ * is no uniform-box pair: F(4,3)'s rounding reaches 4 voxels along x where F(2,3)'s numerical support is its
+ * mathematical one (conv3d_wino4.hip), so the layers that take that shortcut stay with bfm_conv3x3x3_wino_uniform. */
 int bfm_conv3x3x3_wino4_masked(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                                const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
                                int flags, float* out, const float* mask_image, void* workspace, size_t workspace_bytes,
                                bfm_stream_t stream);
-int bfm_conv3x3x3_wino4_uniform(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
-                                const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
-                                int flags, float* out, void* moment_rows /*or NULL*/, const unsigned char* uniform_flags,
-                                void* scratch, bfm_stream_t stream);
 
 size_t bfm_conv3x3x3_mfma_workspace(int Cin, int Cout, int D, int H, int W, int splitk);
 int bfm_conv3x3x3_mfma_plan(int Cin, int Cout, int D, int H, int W, int* cfg_out /*[8]*/);
