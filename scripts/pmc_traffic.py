@@ -21,6 +21,8 @@ def last_step(path, counter):
 
 def family(name):
     """bench.py's kernel names (CONV_KERNELS); longest match first."""
+    if "conv_wino4_masked" in name:            # bench.py counts a masked launch as conv_wino_masked whichever variant ran
+        return "conv_wino_masked"
     for k in ("conv_upfold", "conv_wino_masked", "conv_wino_uniform", "conv_wino4", "conv_wino", "conv_mfma16", "conv_mfma_ws", "conv_mfma",
               "conv_stem", "tail_kernel"):
         if k in name:
