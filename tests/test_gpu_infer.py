@@ -1438,3 +1438,50 @@ def test_crop3d_is_the_tile_window():
         assert torch.equal(out, vol[z0:z0 + d, y0:y0 + h, x0:x0 + w])
     out = torch.empty(4, 4, 4, device=dev)
     assert lib.bfm_crop3d(L.ptr(vol), 37, 41, 53, 35, 0, 0, 4, 4, 4, L.ptr(out), L.stream_ptr()) != 0
+
+
+@pytest.mark.parametrize("case", [((8, 8, 16), 16, 64), ((9, 11, 21), 32, 64), ((12, 8, 30), 64, 128), ((5, 13, 7), 16, 64),
+                                  ((17, 6, 35), 48, 192)])
+def test_winograd_f43_kernel_vs_float64_convolution(case):
+    """bfm_conv3x3x3_wino4 (Winograd F(4,3) along x; SingleConv 'gcl' body, buildingblocks.py:31-60) through the C ABI
+    against a float64 convolution of the affine-applied input: plain and accumulate mode, shapes whose extents are no
+    multiples of the 4x4x16 box or of the quad; tolerance 1e-5 of max|y| (measured 1-2.5e-6; F(2,3) sits at 1e-6), and the
+    moment rows it writes are the moments of what it stored."""
+    import torch.nn.functional as F
+    from brainfm_amd import _lib as L
+    lib = L.load()
+    dev = _dev()
+    dims, cin, cout = case
+    g = torch.Generator().manual_seed(cin + dims[2])
+    A = torch.randn(*dims, cin, generator=g).to(dev)
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.05).to(dev).contiguous()
+    scale = (torch.rand(cin, generator=g) + 0.5).to(dev)
+    shift = (torch.randn(cin, generator=g) * 0.1).to(dev)
+    bound = torch.full((8,), float((A.abs().amax((0, 1, 2)) * scale + shift.abs()).max()), device=dev)
+    wp = torch.empty(lib.bfm_pack_conv_weights_wino4_bytes(cin, cout, 3), dtype=torch.uint8, device=dev)
+    wexp = C.c_int(0)
+    L.check(lib.bfm_pack_conv_weights_wino4(L.ptr(w), cin, cout, float(w.abs().max()), 3, L.ptr(wp), C.byref(wexp),
+                                            L.stream_ptr()), "pack_wino4")
+    x64 = (A.double().cpu() * scale.double().cpu() + shift.double().cpu()).permute(3, 0, 1, 2)[None]
+    y64 = F.conv3d(x64, w.double().cpu(), padding=1)[0].permute(1, 2, 3, 0)
+    n = lib.bfm_conv3x3x3_wino4_rows(dims[0], dims[1], dims[2], 3)
+    assert n > 0
+    for base in (None, torch.randn(*dims, cout, generator=g).to(dev)):
+        out = base.clone() if base is not None else torch.full(dims + (cout,), float("nan"), device=dev)
+        rows = torch.zeros(lib.bfm_moment_rows_bytes(n, cout), dtype=torch.uint8, device=dev)
+        L.check(lib.bfm_conv3x3x3_wino4(L.ptr(A), cin, dims[0], dims[1], dims[2], L.ptr(scale), L.ptr(shift), L.ptr(bound), 8,
+                                        L.ptr(wp), wexp.value, cout, 0.01, 3, 1 if base is not None else 0, L.ptr(out),
+                                        L.ptr(rows), L.stream_ptr()), "conv_wino4")
+        torch.cuda.synchronize()
+        want = y64 + (base.double().cpu() if base is not None else 0.0)
+        want = torch.where(want >= 0, want, want * 0.01)
+        assert bool(torch.isfinite(out).all())
+        assert float((out.double().cpu() - want).abs().max() / want.abs().max()) <= 1e-5
+        k = n * cout
+        o2 = out.double().cpu().reshape(-1, cout)
+        rs = rows[:k * 8].view(torch.float64).view(n, cout).sum(0).cpu()
+        rq = rows[k * 8:k * 16].view(torch.float64).view(n, cout).sum(0).cpu()
+        assert float((rs - o2.sum(0)).abs().max()) <= 2e-7 * float(o2.abs().sum(0).max())
+        assert float((rq - (o2 * o2).sum(0)).abs().max()) <= 2e-7 * float((o2 * o2).sum(0).max())
+        assert torch.equal(rows[k * 16:k * 20].view(torch.float32).view(n, cout).min(0)[0].cpu(), out.cpu().reshape(-1, cout).min(0)[0])
+        assert torch.equal(rows[k * 20:k * 24].view(torch.float32).view(n, cout).max(0)[0].cpu(), out.cpu().reshape(-1, cout).max(0)[0])
