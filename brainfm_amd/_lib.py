@@ -47,6 +47,15 @@ class KSet(C.Structure):
     _fields_ = [("k", C.c_void_p * 7), ("coef", C.c_float * 7), ("nk", C.c_int)]
 
 
+GATHER_MAX_JOBS = 12          # BFM_GATHER_MAX_JOBS of include/brainfm_hip.h
+
+
+class GatherJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("out", C.c_void_p), ("mean", C.c_float), ("scale", C.c_float), ("pre", C.c_int),
+                ("default_max", C.c_int), ("post_div", C.c_float), ("clamp", C.c_int), ("clamp_lo", C.c_float),
+                ("clamp_hi", C.c_float), ("sign", C.c_float), ("want_minmax", C.c_int)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -175,6 +184,28 @@ SIGNATURES = {
     "bfm_dopri5_dense_eval": (_I, [_P, _P, _I, C.POINTER(KSet), C.c_double, C.c_double, _P, _L, _P]),
     "bfm_reduce_f32": (_I, [_I, _P, _P, _L, _P, _P, _Z, _P]),
     "bfm_reduce_f64": (_I, [_I, _P, _P, _L, _P, _P, _Z, _P]),
+    "bfm_randn_philox": (_I, [_P, _L, C.c_uint64, C.c_uint64, _F, _P]),
+    "bfm_deform_zoom_workspace": (_Z, []),
+    "bfm_deform_zoom_minmax": (_I, [_P, _I, _I, _I, C.POINTER(ZoomAxis), _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F),
+                                    C.POINTER(_I), _P, _P, _Z, _P]),
+    "bfm_deform_zoom_write": (_I, [_P, _I, _I, _I, C.POINTER(ZoomAxis), _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F),
+                                   C.POINTER(_I), C.POINTER(_F), _P, _P, _P, _P, _P]),
+    "bfm_gather_targets_workspace": (_Z, []),
+    "bfm_gather_targets": (_I, [C.POINTER(GatherJob), _I, _I, _I, _I, C.POINTER(_I), _P, _P, _P, _I, _I, _I, _I, _P, _P,
+                                _Z, _P]),
+    "bfm_minmax_normalise": (_I, [_P, _L, _P, _P]),
+    "bfm_gather_onehot": (_I, [_P, _I, _I, _I, C.POINTER(_I), _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
+    "bfm_percentile_workspace": (_Z, []),
+    "bfm_percentile_f64": (_I, [_P, _L, _L, _I, C.c_double, _P, _P, _Z, _P]),
+    "bfm_shape_workspace": (_Z, []),
+    "bfm_shape_threshold_f64": (_I, [_P, _L, _P, _P, _P, _P, _P, _Z, _P]),
+    "bfm_shape_binarize": (_I, [_P, _I, _L, _P, C.c_double, _P, _P, _P, _Z, _P]),
+    "bfm_pathology_mask": (_I, [_P, _P, _I, _P, _L, _P, _P, _Z, _P]),
+    "bfm_pathology_encode_workspace": (_Z, []),
+    "bfm_pathology_encode_dev": (_I, [_P, _P, _P, _I, _P, C.POINTER(_F), _I, _P, _L, _P, _P, _P, _Z, _P]),
+    "bfm_interp3d_linear_axes": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _F, _P, _P]),
+    "bfm_sample_finalize": (_I, [_P, _P, _I, _I, _I, _P, _I, _P, _P, _P]),
+    "bfm_ew_dev": (_I, [_I, _P, _L, _P, _F, _P, _P]),
     "bfm_stitch_accumulate": (_I, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bfm_stitch_accumulate_multi": (_I, [_P, _L, _P, _I, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
     "bfm_mask_tile": (_I, [_P, _P, _P, _L, _P, _P]),

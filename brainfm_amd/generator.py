@@ -11,8 +11,9 @@ plain arrays: NIfTI/MGZ file I/O is SURVEY 'next' row N3, outside this path, so 
 memory as ``{name, 'Gen': labels, 'T1': vol, ...}`` dicts instead of being globbed from a data root.
 """
 import ctypes as C
+import os
 import random
-from collections import defaultdict
+from collections import OrderedDict, defaultdict
 
 import numpy as np
 import torch
@@ -21,7 +22,7 @@ from . import _lib as L
 from . import generator_utils as GU
 from . import interpol as IP
 from .engine import LABELS_FULL, LABELS_LEFT
-from .shapeid import AdvDiffPDE, generate_shape_3d
+from .shapeid import AdvDiffPDE, generate_shape_3d, generate_shape_3d_dev
 
 n_neutral_labels = 20
 
@@ -45,6 +46,72 @@ def _vol(v):
     return v if hasattr(v, "get_fdata") else ArrayVolume(v)
 
 
+class DeviceVolumes:
+    """Case volumes resident in HBM.  The reference opens every NIfTI file of the case for every item and crops on the
+    host (Generator/utils.py:296-305: nib.load -> get_fdata()[box] -> torch.tensor -> device); a case is ~10 volumes of
+    ~30 MB, so a few hundred cases fit in a fraction of the 288 GB and an item never touches the host copy again: the
+    crop becomes a box inside the resident volume.  Least-recently-used volumes are dropped beyond `budget` bytes
+    (BFM_GEN_CACHE_GB, default 64)."""
+
+    def __init__(self, device, budget=None):
+        self.device = device
+        self.budget = int(float(os.environ.get("BFM_GEN_CACHE_GB", "64")) * 2 ** 30) if budget is None else budget
+        self.items = OrderedDict()                        # (id(source), kind) -> (tensor, source kept alive)
+        self.bytes = 0
+
+    @staticmethod
+    def _host_array(src):
+        if isinstance(src, np.ndarray):
+            arr = src
+        elif hasattr(src, "dataobj"):
+            arr = np.asarray(src.dataobj)
+        else:
+            arr = src.get_fdata()
+        while arr.ndim > 3 and arr.shape[-1] == 1:
+            arr = arr[..., 0]
+        if not (np.issubdtype(arr.dtype, np.floating) or np.issubdtype(arr.dtype, np.integer)):
+            arr = arr.astype(np.float64)
+        return arr
+
+    def get(self, vol, kind="f32"):
+        """The whole volume as float32 (`kind` 'f32': what torch.tensor(get_fdata().astype(float), dtype=torch.float)
+        holds, one rounding from the stored type) or int32 ('i32': .astype(int), truncation)."""
+        src = vol._d if isinstance(vol, ArrayVolume) else vol
+        key = (id(src), kind)
+        hit = self.items.get(key)
+        if hit is not None:
+            self.items.move_to_end(key)
+            return hit[0]
+        arr = self._host_array(src)
+        if kind == "f32":
+            host = np.ascontiguousarray(arr, dtype=np.float32)
+        else:
+            host = np.ascontiguousarray(arr.astype(np.int64) if np.issubdtype(arr.dtype, np.floating) else arr,
+                                        dtype=np.int32)
+        t = torch.from_numpy(host).to(self.device)
+        nbytes = t.numel() * 4
+        while self.items and self.bytes + nbytes > self.budget:
+            _, (old, _) = self.items.popitem(last=False)
+            self.bytes -= old.numel() * 4
+        self.items[key] = (t, src)
+        self.bytes += nbytes
+        return t
+
+
+class DeviceDirection:
+    """pathol_direction decided on the device: gm_mean > wm_mean from bfm_label_class_stats' four sums
+    (datasets.py:392-404), read by bfm_pathology_encode_dev without a host round trip."""
+
+    def __init__(self, stats):
+        self.stats = stats
+
+    def __bool__(self):
+        st = self.stats.cpu().tolist()
+        wm = st[0] / st[1] if st[1] else float("nan")
+        gm = st[2] / st[3] if st[3] else float("nan")
+        return gm > wm
+
+
 class BaseGen(torch.utils.data.Dataset):
     """BaseGen, Generator/datasets.py:24-681."""
 
@@ -63,6 +130,9 @@ class BaseGen(torch.utils.data.Dataset):
         if self.device.type != "cuda":
             raise L.BfmError("the generator runs on a HIP device only; there is no CPU fallback in the product path")
         self.cases = cases or []
+        self.volumes = DeviceVolumes(self.device)
+        self._batch = None                                # pending gather jobs while _targets collects them
+        self._psum = (None, 0.0)                          # (id of target['pathology'], its sum) known to the host
         self.datasets_num = 1
         self.pathology_type = None
         self.hemis_mask = None
@@ -117,7 +187,8 @@ class BaseGen(torch.utils.data.Dataset):
             c2 = ((np.array(shp[0:3]) - 1) / 2).astype(np.float32)
         return scaling_factor_distances, A, c2.astype(np.float32)
 
-    def random_nonlinear_transform(self, photo_mode, spac):
+    def _random_nonlinear_small(self, photo_mode, spac):
+        """The draws of random_nonlinear_transform (datasets.py:209-226): the low-resolution field and its zoom factors."""
         s = self.synth_args
         nonlin_scale = s.nonlin_scale_min + np.random.rand(1) * (s.nonlin_scale_max - s.nonlin_scale_min)
         size_F_small = np.round(nonlin_scale * np.array(self.size)).astype(int).tolist()
@@ -126,7 +197,11 @@ class BaseGen(torch.utils.data.Dataset):
         nonlin_std = s.nonlin_std_max * np.random.rand()
         Fsmall = GU.ew_unary(L.EW_AFFINE, GU.draws.randn([*size_F_small, 3], self.device),
                              float(np.float32(nonlin_std)), 0.0)
-        F = GU.myzoom_torch(Fsmall, np.array(self.size) / size_F_small)
+        return Fsmall, np.array(self.size) / size_F_small
+
+    def random_nonlinear_transform(self, photo_mode, spac):
+        Fsmall, factor = self._random_nonlinear_small(photo_mode, spac)
+        F = GU.myzoom_torch(Fsmall, factor)
         if photo_mode:
             F[:, :, :, 1] = 0
         return F, None
@@ -156,15 +231,56 @@ class BaseGen(torch.utils.data.Dataset):
         x2, y2, z2 = (int(v) for v in hi)
         return xx, yy, zz, x1, y1, z1, x2, y2, z2
 
+    def deform_grid_zoomed(self, shp, A, c2, Fsmall, factor, photo_mode=False):
+        """deform_grid(shp, A, c2, myzoom_torch(Fsmall, factor)) without the detour through HBM: pass 1 evaluates the zoomed
+        field per voxel and leaves only the six extrema (the one read-back the reference has here too, datasets.py:296-301),
+        pass 2 evaluates it again and writes the coordinates already shifted by the crop origin, and F.  Same expressions,
+        same order: the bits of the two-step form.  Returns (F, [xx2, yy2, zz2, x1, y1, z1, x2, y2, z2])."""
+        lib = L.load()
+        sx, sy, sz = self.size
+        dev = self.device
+        Fs = Fsmall.to(torch.float32).contiguous()
+        fnx, fny, fnz = Fs.shape[:3]
+        factor = np.asarray(factor, dtype=np.float64) * np.ones(3)
+        axes = (L.ZoomAxis * 3)()
+        keep = []
+        for a, n in enumerate((fnx, fny, fnz)):
+            t = GU._zoom_tables_dev(n, float(factor[a]), dev)
+            if len(t[0]) != self.size[a]:
+                raise L.BfmError("zoom of the deformation field gives %d voxels along axis %d, not %d"
+                                 % (len(t[0]), a, self.size[a]))
+            keep.append(t)
+            axes[a] = L.ZoomAxis(*[v.data_ptr() for v in t])
+        Ah = (C.c_float * 9)(*[float(v) for v in np.asarray(A, np.float32).reshape(-1)])
+        ch = (C.c_float * 3)(*[float(v) for v in np.asarray(c2, np.float32)])
+        sh = (C.c_int * 3)(*[int(v) for v in shp[:3]])
+        mm = torch.empty(6, dtype=torch.float32, device=dev)
+        ws = GU.workspace(dev, lib.bfm_deform_zoom_workspace())
+        L.check(lib.bfm_deform_zoom_minmax(L.ptr(Fs), fnx, fny, fnz, axes, int(bool(photo_mode)), sx, sy, sz, Ah, ch, sh,
+                                           L.ptr(mm), L.ptr(ws), ws.numel(), L.stream_ptr()), "deform_zoom_minmax")
+        m = mm.cpu().numpy()
+        lo = np.floor(m[:3])
+        hi = 1 + np.ceil(m[3:])
+        loh = (C.c_float * 3)(*[float(v) for v in lo])
+        xx, yy, zz = (torch.empty((sx, sy, sz), dtype=torch.float32, device=dev) for _ in range(3))
+        F = torch.empty((sx, sy, sz, 3), dtype=torch.float32, device=dev)
+        L.check(lib.bfm_deform_zoom_write(L.ptr(Fs), fnx, fny, fnz, axes, int(bool(photo_mode)), sx, sy, sz, Ah, ch, sh, loh,
+                                          L.ptr(xx), L.ptr(yy), L.ptr(zz), L.ptr(F), L.stream_ptr()), "deform_zoom_write")
+        x1, y1, z1 = (int(v) for v in lo)
+        x2, y2, z2 = (int(v) for v in hi)
+        return F, [xx, yy, zz, x1, y1, z1, x2, y2, z2]
+
     def generate_deformation(self, setups, shp):
         scaling_factor_distances, A, c2 = self.random_affine_transform(shp)
         if self.synth_args.nonlinear_transform:
-            F, Fneg = self.random_nonlinear_transform(setups["photo_mode"], setups["spac"])
+            Fsmall, factor = self._random_nonlinear_small(setups["photo_mode"], setups["spac"])
+            F, grid = self.deform_grid_zoomed(shp, A, c2, Fsmall, factor, setups["photo_mode"])
+            Fneg = None
         else:
             F, Fneg = None, None
-        xx2, yy2, zz2, x1, y1, z1, x2, y2, z2 = self.deform_grid(shp, A, c2, F)
+            grid = list(self.deform_grid(shp, A, c2, F))
         return {"scaling_factor_distances": scaling_factor_distances, "A": A, "c2": c2, "F": F, "Fneg": Fneg,
-                "grid": [xx2, yy2, zz2, x1, y1, z1, x2, y2, z2]}
+                "grid": grid, "shape": tuple(int(v) for v in shp[:3])}
 
     # -------------------------------------------------------------- contrast / setup (datasets.py:430-493)
     def get_contrast(self, photo_mode):
@@ -212,90 +328,188 @@ class BaseGen(torch.utils.data.Dataset):
                 "pathol_random_shape": pathol_random_shape, "spac": spac, "flip": flip, "hemis": hemis}
 
     # -------------------------------------------------------------- targets (Generator/utils.py:296-477)
-    def _crop(self, vol, grid, dtype=torch.float32):
+    def _box(self, vol_shape, grid):
+        """The crop the reference reads, `[x1:x2, y1:y2, z1:z2]` clipped like a NumPy slice: (origin, dims)."""
         [_, _, _, x1, y1, z1, x2, y2, z2] = grid
-        v = _vol(vol)
-        # Crop first and convert the crop straight to the target type.  The reference goes array -> float64 (whole
-        # volume, get_fdata) -> crop -> float / int -> tensor(dtype): for float32, float64 and integer sources that chain
-        # rounds once, exactly like the direct conversion, so the values are the same; it cost 30 ms x 17 crops per item.
-        if isinstance(v, ArrayVolume):
-            src = v._d[x1:x2, y1:y2, z1:z2]
-        elif hasattr(v, "dataobj"):
-            src = np.asarray(v.dataobj[x1:x2, y1:y2, z1:z2])
-        else:
-            src = v.get_fdata()[x1:x2, y1:y2, z1:z2]
-        np_t = np.float32 if dtype == torch.float32 else np.int64
-        if not (np.issubdtype(src.dtype, np.floating) or np.issubdtype(src.dtype, np.integer)):
-            src = src.astype(np.float64)
-        arr = np.ascontiguousarray(src, dtype=np_t)
-        return torch.squeeze(torch.from_numpy(arr).to(device=self.device, dtype=dtype))
+        x2, y2, z2 = min(x2, vol_shape[0]), min(y2, vol_shape[1]), min(z2, vol_shape[2])
+        return (x1, y1, z1), (x2 - x1, y2 - y1, z2 - z1)
 
-    def read_and_deform(self, vol, deform_dict, default_max=False, mean=0., scale=1.):
-        """read_and_deform, Generator/utils.py:296-322."""
-        [xx2, yy2, zz2] = deform_dict["grid"][:3]
-        I = torch.nan_to_num(self._crop(vol, deform_dict["grid"]))
+    def _crop(self, vol, grid, dtype=torch.float32, cache=None):
+        """The crop of a case volume as a device tensor (float32 or int32), cut out of the resident copy on the device
+        (round 3: NumPy slice + conversion + upload per crop, 17 crops = 44 ms of host time per item).  `cache`: a dict
+        that keeps the crop for the item (generate_sample crops the label map once per sample in the reference)."""
+        kind = "f32" if dtype == torch.float32 else "i32"
+        full = self.volumes.get(_vol(vol), kind)
+        key = (full.data_ptr(), kind)
+        if cache is not None and key in cache:
+            return cache[key]
+        (x1, y1, z1), (cx, cy, cz) = self._box(full.shape, grid)
+        out = torch.empty((cx, cy, cz), dtype=full.dtype, device=self.device)
+        L.check(L.load().bfm_crop3d(L.ptr(full), full.shape[0], full.shape[1], full.shape[2], x1, y1, z1, cx, cy, cz,
+                                    L.ptr(out), L.stream_ptr()), "crop3d")          # a bit copy of 4-byte elements
+        out = torch.squeeze(out)
+        if dtype not in (torch.float32, torch.int32):
+            out = out.to(dtype)
+        if cache is not None:
+            cache[key] = out
+        return out
+
+    def _job(self, vol, out, pre=1, mean=0., scale=1., default_max=False, post_div=0., clamp=None, sign=0.,
+             want_minmax=False, post=None):
+        """One volume of a bfm_gather_targets launch; `post(scalars, j)` runs after the launch."""
         if mean != 0. or scale != 1.:
-            I = GU.ew_unary(L.EW_SUB_DIV, I, mean, scale)
-        dv = GU.tensor_max(I) if default_max else 0.
-        return GU.fast_3D_interp_torch(I, xx2, yy2, zz2, "linear", dv)
+            pre = 2
+        return {"vol": self.volumes.get(_vol(vol), "f32"), "out": out, "pre": pre, "mean": float(mean),
+                "scale": float(scale), "default_max": bool(default_max), "post_div": float(post_div), "clamp": clamp,
+                "sign": float(sign), "want_minmax": bool(want_minmax), "post": post}
+
+    def _submit(self, jobs, deform_dict, flip):
+        """Queue the jobs while _targets is collecting (one launch for all float targets of the item), else run them."""
+        if self._batch is not None:
+            self._batch.extend(jobs)
+        else:
+            self._run_gather(jobs, deform_dict, flip)
+
+    def _run_gather(self, jobs, deform_dict, flip):
+        lib = L.load()
+        [xx2, yy2, zz2, x1, y1, z1, x2, y2, z2] = deform_dict["grid"]
+        sx, sy, sz = xx2.shape
+        box = (C.c_int * 6)(x1, y1, z1, x2, y2, z2)
+        ws = GU.workspace(self.device, lib.bfm_gather_targets_workspace())
+        by_shape = defaultdict(list)
+        for j in jobs:
+            by_shape[tuple(j["vol"].shape)].append(j)
+        for shape, group in by_shape.items():
+            for c0 in range(0, len(group), L.GATHER_MAX_JOBS):
+                chunk = group[c0:c0 + L.GATHER_MAX_JOBS]
+                arr = (L.GatherJob * len(chunk))()
+                for k, j in enumerate(chunk):
+                    lo, hi = j["clamp"] if j["clamp"] is not None else (0., 0.)
+                    arr[k] = L.GatherJob(j["vol"].data_ptr(), j["out"].data_ptr(), j["mean"], j["scale"], j["pre"],
+                                         int(j["default_max"]), j["post_div"], int(j["clamp"] is not None), float(lo),
+                                         float(hi), j["sign"], int(j["want_minmax"]))
+                scal = torch.empty(3 * L.GATHER_MAX_JOBS, dtype=torch.float64, device=self.device)
+                L.check(lib.bfm_gather_targets(arr, len(chunk), shape[0], shape[1], shape[2], box, L.ptr(xx2), L.ptr(yy2),
+                                               L.ptr(zz2), sx, sy, sz, int(bool(flip)), L.ptr(scal), L.ptr(ws),
+                                               ws.numel(), L.stream_ptr()), "gather_targets")
+                for k, j in enumerate(chunk):
+                    if j["post"] is not None:
+                        j["post"](scal, k)
+
+    def read_and_deform(self, vol, deform_dict, default_max=False, mean=0., scale=1., flip=False):
+        """read_and_deform, Generator/utils.py:296-322 (nan_to_num, (I - mean) / scale, default value = the crop's
+        maximum on request, trilinear sample), straight from the resident volume."""
+        out = torch.empty(tuple(deform_dict["grid"][0].shape), dtype=torch.float32, device=self.device)
+        self._submit([self._job(vol, out, mean=mean, scale=scale, default_max=default_max)], deform_dict, flip)
+        return out
 
     def _flip0(self, t):
-        return torch.flip(t, [0])
+        """torch.flip(t, [0]) of a 3-D fp32 tensor (a mirrored gather)."""
+        tc = t.to(torch.float32).contiguous()
+        out = torch.empty_like(tc)
+        perm = (C.c_int * 3)(0, 1, 2)
+        fl = (C.c_int * 3)(1, 0, 0)
+        L.check(L.load().bfm_permute_flip3d(L.ptr(tc), tc.shape[0], tc.shape[1], tc.shape[2], perm, fl, L.ptr(out),
+                                            L.stream_ptr()), "permute_flip3d")
+        return out
 
     def read_and_deform_image(self, task, vol, setups, deform_dict):
-        I = self.read_and_deform(vol, deform_dict)
-        I = GU.ew_unary(L.EW_SUB_DIV, I, GU.tensor_min(I), 1.0)
-        I = GU.ew_unary(L.EW_DIV, I, GU.tensor_max(I))
-        return {task: (self._flip0(I) if setups["flip"] else I)[None]}
+        """Generator/utils.py:331-345: sample, I -= min, I /= max, flip -- min / max never leave the device."""
+        out = torch.empty(tuple(deform_dict["grid"][0].shape), dtype=torch.float32, device=self.device)
+
+        def normalise(scal, j):
+            L.check(L.load().bfm_minmax_normalise(L.ptr(out), out.numel(),
+                                                  C.c_void_p(scal.data_ptr() + 8 * (L.GATHER_MAX_JOBS + 2 * j)),
+                                                  L.stream_ptr()), "minmax_normalise")
+
+        self._submit([self._job(vol, out, want_minmax=True, post=normalise)], deform_dict, setups["flip"])
+        return {task: out[None]}
 
     def read_and_deform_segmentation(self, vol, setups, deform_dict):
-        [xx2, yy2, zz2] = deform_dict["grid"][:3]
-        S = self._crop(vol, deform_dict["grid"], torch.int32)
-        Sdef = GU.fast_3D_interp_torch(S, xx2, yy2, zz2, "nearest").contiguous()
-        n = Sdef.numel()
-        out = torch.empty(tuple(Sdef.shape) + (self.n_labels,), dtype=torch.float32, device=self.device)
-        L.check(L.load().bfm_onehot_lut(L.ptr(Sdef), L.ptr(self.lut), self.lut.numel(), self.n_labels, n, L.ptr(out),
-                                        L.stream_ptr()), "onehot_lut")
+        """Generator/utils.py:402-425: nearest sample of the label volume, lut, one-hot (+ flip with the left / right
+        channel swap), one kernel."""
+        [xx2, yy2, zz2, x1, y1, z1, x2, y2, z2] = deform_dict["grid"]
+        S = self.volumes.get(_vol(vol), "i32")
+        sx, sy, sz = xx2.shape
+        out = torch.empty((sx, sy, sz, self.n_labels), dtype=torch.float32, device=self.device)
+        box = (C.c_int * 6)(x1, y1, z1, x2, y2, z2)
+        vflip = None
         if setups["flip"]:
-            out = torch.flip(out, [0])[:, :, :, torch.as_tensor(self.vflip, device=self.device)]
+            if getattr(self, "_vflip_dev", None) is None:
+                self._vflip_dev = torch.as_tensor(self.vflip, dtype=torch.int32, device=self.device)
+            vflip = self._vflip_dev
+        L.check(L.load().bfm_gather_onehot(L.ptr(S), S.shape[0], S.shape[1], S.shape[2], box, L.ptr(xx2), L.ptr(yy2),
+                                           L.ptr(zz2), sx, sy, sz, int(bool(setups["flip"])), L.ptr(self.lut),
+                                           self.lut.numel(), self.n_labels, L.ptr(vflip), L.ptr(out), L.stream_ptr()),
+                "gather_onehot")
         return {"segmentation": out.permute([3, 0, 1, 2])}
 
     def read_and_deform_distance(self, vols, setups, deform_dict):
-        maps = [self.read_and_deform(v, deform_dict, default_max=True, mean=128., scale=20) for v in vols]
-        if len(maps) == 4 and setups["flip"]:
-            lp, lw, rp, rw = maps
-            maps = [self._flip0(rp), self._flip0(rw), self._flip0(lp), self._flip0(lw)]
+        """Generator/utils.py:376-400: (I - 128) / 20 sampled with the crop's maximum outside, / scaling factor, clamp;
+        the maps are written straight into the stacked target (left / right swapped under a flip)."""
+        shape = tuple(deform_dict["grid"][0].shape)
+        out = torch.empty((len(vols),) + shape, dtype=torch.float32, device=self.device)
+        order = list(range(len(vols)))
+        if len(vols) == 4 and setups["flip"]:
+            order = [2, 3, 0, 1]                              # (lp, lw, rp, rw) -> (rp, rw, lp, lw)
         m = float(self.gen_args.max_surf_distance)
-        sf = float(deform_dict["scaling_factor_distances"])
-        maps = [GU.ew_unary(L.EW_CLAMP, GU.ew_unary(L.EW_DIV, t, sf), -m, m) for t in maps]
-        return {"distance": torch.stack(maps, dim=0)}
+        sf = float(np.float32(float(deform_dict["scaling_factor_distances"])))
+        jobs = [self._job(vols[src], out[dst], mean=128., scale=20, default_max=True, post_div=sf, clamp=(-m, m))
+                for dst, src in enumerate(order)]
+        self._submit(jobs, deform_dict, setups["flip"])
+        return {"distance": out}
 
     def read_and_deform_registration(self, vols, setups, deform_dict):
-        r = [self.read_and_deform(v, deform_dict, scale=10000) for v in vols]
-        if setups["flip"]:
-            r = [GU.ew_unary(L.EW_AFFINE, self._flip0(r[0]).contiguous(), -1.0, 0.0), self._flip0(r[1]), self._flip0(r[2])]
-        return {"registration": torch.stack(r, dim=0)}
+        """Generator/utils.py:462-473: I / 10000 sampled; under a flip the x map changes sign."""
+        shape = tuple(deform_dict["grid"][0].shape)
+        out = torch.empty((len(vols),) + shape, dtype=torch.float32, device=self.device)
+        jobs = [self._job(v, out[i], scale=10000, sign=(-1. if (setups["flip"] and i == 0) else 0.))
+                for i, v in enumerate(vols)]
+        self._submit(jobs, deform_dict, setups["flip"])
+        return {"registration": out}
 
     def read_and_deform_pathology(self, source, setups, deform_dict, augment, thres):
-        """Generator/utils.py:428-459."""
+        """Generator/utils.py:428-459.  One read-back: sum(P) for the `P.mean() <= pathol_tol` test."""
         shape = tuple(deform_dict["grid"][0].shape)
-        zeros = {"pathology": torch.zeros(shape, device=self.device)[None],
+
+        def zeros():
+            z = {"pathology": torch.zeros(shape, device=self.device)[None],
                  "pathology_prob": torch.zeros(shape, device=self.device)[None]}
+            self._psum = (z["pathology"].data_ptr(), 0.0)
+            return z
+
         if source is None:
-            return zeros
+            return zeros()
+        pmax = None
         if isinstance(source, str) and source == "random_shape":
             percentile = np.random.uniform(self.shape_gen_args.mask_percentile_min,
                                            self.shape_gen_args.mask_percentile_max)
-            _, Pdef = generate_shape_3d(shape, self.shape_gen_args.perlin_res, percentile, self.device)
+            Pdef, pmax = generate_shape_3d_dev(shape, self.shape_gen_args.perlin_res, percentile, self.device)
         else:
-            Pdef = self.read_and_deform(source, deform_dict)
+            pending, self._batch = self._batch, None              # needed now: not part of the collected gather
+            try:
+                Pdef = self.read_and_deform(source, deform_dict)
+            finally:
+                self._batch = pending
         if augment:
             Pdef = GU.augment_pathology(Pdef, self.adv_pde, self.t, self.shape_gen_args, self.device)
-        P = GU.binarize(Pdef, thres)
-        mean = (GU.tensor_sum(P) if P.dtype == torch.float32 else float(P.sum().item())) / P.numel()
-        if mean <= self.shape_gen_args.pathol_tol:
-            return zeros
+            pmax = None
+        P, psum = GU.binarize_dev(Pdef, thres, pmax)
+        total = float(psum.item())
+        if total / P.numel() <= self.shape_gen_args.pathol_tol:
+            return zeros()
+        self._psum = (P.data_ptr(), total)
         return {"pathology": P[None], "pathology_prob": Pdef[None]}
+
+    def _pathology_sum(self, target):
+        """float(target['pathology'].sum()) for the tests of datasets.py:322,387; the host already knows it for the tensor
+        read_and_deform_pathology / generate_sample left there (no kernel, no sync), anything else is summed."""
+        P = target.get("pathology") if hasattr(target, "get") else None
+        if not isinstance(P, torch.Tensor):
+            return 0.0
+        if self._psum[0] == P.data_ptr():
+            return self._psum[1]
+        return float(P.sum().item())
 
     def read_and_deform_target(self, case, task_name, input_mode, setups, deform_dict):
         """datasets.py:592-633."""
@@ -314,8 +528,7 @@ class BaseGen(torch.utils.data.Dataset):
         if task_name in ("T1", "T2", "FLAIR"):
             return self.read_and_deform_image(task_name, v, setups, deform_dict)
         if task_name == "CT":
-            I = self.read_and_deform(v, deform_dict, scale=1000)
-            return {"CT": (self._flip0(I) if setups["flip"] else I)[None]}
+            return {"CT": self.read_and_deform(v, deform_dict, scale=1000, flip=setups["flip"])[None]}
         if task_name == "segmentation":
             return self.read_and_deform_segmentation(v, setups, deform_dict)
         if task_name == "distance":
@@ -323,28 +536,42 @@ class BaseGen(torch.utils.data.Dataset):
         if task_name == "registration":
             return self.read_and_deform_registration(v, setups, deform_dict)
         if task_name == "bias_field":
-            I = self.read_and_deform(v, deform_dict)
-            return {"bias_field": (self._flip0(I) if setups["flip"] else I)[None]}
+            return {"bias_field": self.read_and_deform(v, deform_dict, flip=setups["flip"])[None]}
         return {task_name: 0.}
 
     # -------------------------------------------------------------- samples (datasets.py:306-412,496-518)
     def encode_pathology(self, I, P, Pprob, pathol_direction=None):
+        """datasets.py:496-518.  I_mu = sum(I*P) / sum(P), the mean / spread tables and the direction stay on the device
+        (pathol_direction may be a DeviceDirection); P / Pprob are read in their own dtype (fp64 for Perlin shapes: the
+        sum I + Pprob * (...) is then formed in fp64 and rounded once, as torch's promotion does)."""
+        lib = L.load()
         if pathol_direction is None:
             pathol_direction = random.choice([True, False])
-        P, Pprob = torch.squeeze(P).to(torch.float32).contiguous(), torch.squeeze(Pprob).to(torch.float32).contiguous()
-        I = I.contiguous()
-        I_mu = np.float32(GU.tensor_dot(I, P) / GU.tensor_sum(P))
-        pth_mus = 3 * I_mu / 4 + I_mu / 4 * GU.draws.rand(10000).numpy()
-        pth_mus = pth_mus if pathol_direction else -pth_mus
-        pth_sigmas = I_mu / 4 * GU.draws.rand(10000).numpy()
+        P, Pprob = torch.squeeze(P), torch.squeeze(Pprob)
+        f64 = P.dtype == torch.float64 and Pprob.dtype == torch.float64
+        if not f64:
+            P, Pprob = P.to(torch.float32), Pprob.to(torch.float32)
+        P, Pprob = P.contiguous(), Pprob.contiguous()
+        I = I.to(torch.float32).contiguous()
+        u_mu = GU.draws.rand(10000)
+        u_sig = GU.draws.rand(10000)
+        u4 = (C.c_float * 4)(float(u_mu[0]), float(u_mu[1]), float(u_sig[0]), float(u_sig[1]))
         rn = GU.draws.randn(P.shape, self.device)
         out = torch.empty_like(I)
-        L.check(L.load().bfm_pathology_encode(L.ptr(I), L.ptr(P), L.ptr(Pprob), L.ptr(rn), float(pth_mus[0]),
-                                              float(pth_mus[1]), float(pth_sigmas[0]), float(pth_sigmas[1]), I.numel(),
-                                              L.ptr(out), L.stream_ptr()), "pathology_encode")
+        dotsum = torch.empty(2, dtype=torch.float64, device=self.device)
+        ws = GU.workspace(self.device, lib.bfm_pathology_encode_workspace())
+        if isinstance(pathol_direction, DeviceDirection):
+            direction, stats = -1, pathol_direction.stats
+        else:
+            direction, stats = int(bool(pathol_direction)), None
+        L.check(lib.bfm_pathology_encode_dev(L.ptr(I), L.ptr(P), L.ptr(Pprob), int(f64), L.ptr(rn), u4, direction,
+                                             L.ptr(stats), I.numel(), L.ptr(out), L.ptr(dotsum), L.ptr(ws), ws.numel(),
+                                             L.stream_ptr()), "pathology_encode_dev")
         return out
 
     def augment_sample(self, name, I_def, setups, deform_dict, res, target, pathol_direction=None, input_mode="synth"):
+        """datasets.py:306-352."""
+        lib = L.load()
         sample = {}
         [xx2, yy2, zz2] = deform_dict["grid"][:3]
         if not isinstance(I_def, torch.Tensor):
@@ -352,8 +579,7 @@ class BaseGen(torch.utils.data.Dataset):
             I_def = GU.fast_3D_interp_torch(I_def, xx2, yy2, zz2, "linear")
         if input_mode == "CT":
             I_def = GU.ew_unary(L.EW_CLAMP, I_def, 0., 80.)
-        if "pathology" in target and isinstance(target["pathology"], torch.Tensor) and \
-                float(target["pathology"].sum().item()) > 0:
+        if "pathology" in target and isinstance(target["pathology"], torch.Tensor) and self._pathology_sum(target) > 0:
             I_def = self.encode_pathology(I_def, target["pathology"], target["pathology_prob"], pathol_direction)
         else:
             target["pathology"] = 0.
@@ -368,15 +594,23 @@ class BaseGen(torch.utils.data.Dataset):
             I_def = IP.resize(I_def, shape=list(self.size), anchor="edge", interpolation=3, bound="dct2", prefilter=True)
         else:
             I_def = GU.myzoom_torch(I_def, 1 / aux["factors"]) if "factors" in aux else I_def
-        maxi = GU.tensor_max(I_def)
-        I_final = GU.ew_unary(L.EW_DIV, I_def, maxi)
-        fl = (lambda t: torch.flip(t, [0])) if setups["flip"] else (lambda t: t)
-        if "super_resolution" in self.tasks and "high_res" in aux:
-            hr = GU.ew_unary(L.EW_DIV, aux["high_res"], maxi)
-            sample["high_res_residual"] = fl(GU.ew_binary(L.EW_AXPY, hr, I_final, -1.0))[None]
-        sample["input"] = fl(I_final)[None]
+        # maxi = max(I_def); I_final = I_def / maxi; residual = high_res / maxi - I_final: one reduction, one kernel, the
+        # maximum stays on the device (round 3: a read-back plus four launches)
+        I_def = I_def.to(torch.float32).contiguous()
+        maxi = GU.reduce_dev(1, I_def)
+        flip = bool(setups["flip"])
+        want_res = "super_resolution" in self.tasks and "high_res" in aux
+        hr = aux["high_res"].to(torch.float32).contiguous() if want_res else None
+        I_final = torch.empty_like(I_def)
+        resid = torch.empty_like(I_def) if want_res else None
+        sx, sy, sz = I_def.shape
+        L.check(lib.bfm_sample_finalize(L.ptr(I_def), L.ptr(hr), sx, sy, sz, L.ptr(maxi), int(flip), L.ptr(I_final),
+                                        L.ptr(resid), L.stream_ptr()), "sample_finalize")
+        if want_res:
+            sample["high_res_residual"] = resid[None]
+        sample["input"] = I_final[None]
         if "bias_field" in self.tasks and input_mode != "CT" and "BFlog" in aux:
-            sample["bias_field_log"] = fl(aux["BFlog"])[None]
+            sample["bias_field_log"] = (self._flip0(aux["BFlog"]) if flip else aux["BFlog"])[None]
         return sample
 
     def get_pathology_direction(self, input_mode, pathol_direction=None):
@@ -394,7 +628,7 @@ class BaseGen(torch.utils.data.Dataset):
         [xx2, yy2, zz2] = deform_dict["grid"][:3]
         lib = L.load()
         mus, sigmas = self.get_contrast(setups["photo_mode"])
-        Gc = self._crop(G, deform_dict["grid"]).contiguous()
+        Gc = self._crop(G, deform_dict["grid"], cache=deform_dict.setdefault("_crops", {})).contiguous()
         rn = GU.draws.randn(Gc.shape, self.device)
         SYN = torch.empty_like(Gc)
         L.check(lib.bfm_label_gauss(L.ptr(Gc), L.ptr(mus), L.ptr(sigmas), L.ptr(rn), Gc.numel(), 256, L.ptr(SYN),
@@ -415,8 +649,7 @@ class BaseGen(torch.utils.data.Dataset):
                 SYN = GU.ew_binary(L.EW_AXPY, SYN, target["T2"][0].to(torch.float32), float(v[2]))
             if "FLAIR" in have:
                 SYN = GU.ew_binary(L.EW_AXPY, SYN, target["FLAIR"][0].to(torch.float32), float(v[3]))
-        if "pathology" in target and isinstance(target["pathology"], torch.Tensor) and \
-                float(target["pathology"].sum().item()) > 0:
+        if "pathology" in target and isinstance(target["pathology"], torch.Tensor) and self._pathology_sum(target) > 0:
             # :388-404.  The reference masks the DEFORMED image with the label crop (SYN_cerebral[Gr == 0] = 0) and deforms
             # the result a second time; torch accepts that only when the crop box has the generator's size (IndexError
             # otherwise: the reference cannot draw pathology on a synthetic input from a larger volume).  Same sizes: the
@@ -427,17 +660,24 @@ class BaseGen(torch.utils.data.Dataset):
             src = SYN.contiguous() if same else SYN0.contiguous()
             cer = torch.empty_like(src)
             stats = torch.empty(4, dtype=torch.float64, device=self.device)
-            part = torch.empty(4 * L.CLASS_STATS_BLOCKS, dtype=torch.float64, device=self.device)
+            part = GU.workspace(self.device, 8 * 4 * L.CLASS_STATS_BLOCKS)
             L.check(lib.bfm_label_class_stats(L.ptr(Gc), L.ptr(src), src.numel(), L.ptr(cer), L.ptr(stats), L.ptr(part),
                                               L.stream_ptr()), "label_class_stats")
-            cer = GU.fast_3D_interp_torch(cer, xx2, yy2, zz2)[None]
-            st = stats.cpu().tolist()
-            wm_mean = st[0] / st[1] if st[1] else float("nan")
-            gm_mean = st[2] / st[3] if st[3] else float("nan")
-            for k in ("pathology", "pathology_prob"):
-                t = target[k]
-                target[k] = GU.ew_binary(L.EW_ZERO_WHERE_ZERO, t.to(torch.float32).contiguous(), cer).to(t.dtype)
-            pathol_direction = self.get_pathology_direction("synth", gm_mean > wm_mean)
+            cer = GU.fast_3D_interp_torch(cer, xx2, yy2, zz2)
+            # target['pathology'][SYN_cerebral == 0] = 0 (and _prob), in place and in their own dtype like the reference's
+            # indexed assignment; the masked sum comes back with the same launch pair and is the sample's one read-back
+            P, Pprob = target["pathology"], target["pathology_prob"]
+            if P.dtype != Pprob.dtype or P.dtype not in (torch.float32, torch.float64) or not P.is_contiguous() \
+                    or not Pprob.is_contiguous():
+                dt = torch.float64 if P.dtype == torch.float64 else torch.float32
+                P, Pprob = P.to(dt).contiguous(), Pprob.to(dt).contiguous()
+                target["pathology"], target["pathology_prob"] = P, Pprob
+            psum = torch.empty(1, dtype=torch.float64, device=self.device)
+            ws = GU.workspace(self.device, lib.bfm_shape_workspace())
+            L.check(lib.bfm_pathology_mask(L.ptr(P), L.ptr(Pprob), int(P.dtype == torch.float64), L.ptr(cer), cer.numel(),
+                                           L.ptr(psum), L.ptr(ws), ws.numel(), L.stream_ptr()), "pathology_mask")
+            self._psum = (P.data_ptr(), float(psum.item()))
+            pathol_direction = self.get_pathology_direction("synth", DeviceDirection(stats))
         else:
             pathol_direction = None
             target["pathology"] = 0.
@@ -474,13 +714,24 @@ class BaseGen(torch.utils.data.Dataset):
         return case.get("dataset", "synth"), case.get("name", str(idx)), mode, img, img.affine, res, case
 
     def _targets(self, case, input_mode, setups, deform_dict, default):
+        """datasets.py:592-633,660-668 / 722-730.  The float targets of the item share one coordinate field: their
+        read_and_deform calls are collected and run as ONE gather over the resident volumes (coordinates and weights read
+        and computed once for T1, the distance maps, the registration maps ...)."""
         target = defaultdict(default)
         target["name"] = case.get("name", "")
-        for t in ("T1", "T2", "FLAIR"):
-            target.update(self.read_and_deform_target(case, t, input_mode, setups, deform_dict))
-        for t in self.tasks:
-            if t not in ("T1", "T2", "FLAIR", "surface", "super_resolution", "contrastive", "age"):
+        self._psum = (None, 0.0)
+        self._batch = []
+        try:
+            for t in ("T1", "T2", "FLAIR"):
                 target.update(self.read_and_deform_target(case, t, input_mode, setups, deform_dict))
+            for t in self.tasks:
+                if t not in ("T1", "T2", "FLAIR", "surface", "super_resolution", "contrastive", "age"):
+                    target.update(self.read_and_deform_target(case, t, input_mode, setups, deform_dict))
+            jobs, self._batch = self._batch, None
+            if jobs:
+                self._run_gather(jobs, deform_dict, setups["flip"])
+        finally:
+            self._batch = None
         return target
 
     def __getitem__(self, idx):

@@ -41,8 +41,22 @@ class DeviceDraws:
     across devices is not a goal).  Tests replace ``generator_utils.draws`` with ReplayDraws to feed the reference's own
     recorded draws through the chain (tests/golden/make_golden_gen.py)."""
 
+    def __init__(self):
+        self._seed = None
+        self._offset = 0
+
     def randn(self, shape, device):
-        return torch.randn(list(shape), dtype=torch.float, device=device)
+        """N(0,1) field from bfm_randn_philox: seeded by torch's default generator (torch.manual_seed makes a run
+        repeatable), one counter offset per call."""
+        seed = torch.initial_seed()
+        if seed != self._seed:
+            self._seed, self._offset = seed, 0
+        out = torch.empty(list(shape), dtype=torch.float, device=device)
+        if out.numel():
+            L.check(L.load().bfm_randn_philox(L.ptr(out), out.numel(), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF),
+                                              C.c_uint64(self._offset), 1.0, L.stream_ptr()), "randn_philox")
+        self._offset += 1
+        return out
 
     def rand(self, n):
         return torch.rand(n, dtype=torch.float)
@@ -125,14 +139,32 @@ def make_affine_matrix(rot, sh, s):
 
 
 # ----------------------------------------------------------------------------- reductions / elementwise
-def _reduce(op, x, y=None):
+_WS = {}
+
+
+def workspace(dev, nbytes=1 << 20):
+    """One scratch buffer per device for the reductions' block partials (kernels on one stream run in order, so they can
+    share it; the generator is single-stream)."""
+    key = str(dev)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _WS[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+    return ws
+
+
+def reduce_dev(op, x, y=None):
+    """min (0) / max (1) / sum (2) / sum(x*y) (3) of an fp32 tensor as a 1-element fp64 DEVICE tensor: no host sync."""
     lib = L.load()
     x = x.contiguous()
-    ws = torch.empty(lib.bfm_reduce_workspace(), dtype=torch.uint8, device=x.device)
+    ws = workspace(x.device)
     out = torch.empty(1, dtype=torch.float64, device=x.device)
     L.check(lib.bfm_reduce_f32(op, L.ptr(x), L.ptr(y.contiguous()) if y is not None else None, x.numel(), L.ptr(out),
                                L.ptr(ws), ws.numel(), L.stream_ptr()), "reduce")
-    return float(out.item())
+    return out
+
+
+def _reduce(op, x, y=None):
+    return float(reduce_dev(op, x, y).item())
 
 
 def tensor_min(x): return _reduce(0, x)
@@ -174,6 +206,30 @@ def binarize(p, thres):
     pf = p.to(torch.float32).contiguous()
     t = float(np.float32(thres) * np.float32(tensor_max(pf)))
     return ew_unary(L.EW_GE, pf, t).to(p.dtype)
+
+
+def binarize_dev(p, thres, max_dev=None):
+    """binarize with every scalar on the device: (P, sum(P) as a 1-element fp64 device tensor).  max_dev: max(p) when the
+    producer already has it (generate_shape_3d_dev)."""
+    lib = L.load()
+    f64 = p.dtype == torch.float64
+    pc = p.contiguous() if f64 else p.to(torch.float32).contiguous()
+    if max_dev is None:
+        if f64:
+            max_dev = torch.empty(1, dtype=torch.float64, device=pc.device)
+            ws0 = workspace(pc.device)
+            L.check(lib.bfm_reduce_f64(1, L.ptr(pc), None, pc.numel(), L.ptr(max_dev), L.ptr(ws0), ws0.numel(),
+                                       L.stream_ptr()), "reduce")
+        else:
+            max_dev = reduce_dev(1, pc)
+    P = torch.empty_like(pc)
+    psum = torch.empty(1, dtype=torch.float64, device=pc.device)
+    ws = workspace(pc.device)
+    L.check(lib.bfm_shape_binarize(L.ptr(pc), int(f64), pc.numel(), L.ptr(max_dev), float(thres), L.ptr(P), L.ptr(psum),
+                                   L.ptr(ws), ws.numel(), L.stream_ptr()), "shape_binarize")
+    if not f64 and p.dtype != torch.float32:
+        P = P.to(p.dtype)
+    return P, psum
 
 
 # ----------------------------------------------------------------------------- K10 / K11
@@ -365,12 +421,17 @@ def resample_resolution(I, aux_dict, setups, res, size, device, **kwargs):
     factors = np.array(new_size) / np.array(size)
     delta = (1.0 - factors) / (2.0 * factors)
     v = [np.arange(delta[a], delta[a] + new_size[a] / factors[a], 1 / factors[a])[:new_size[a]] for a in range(3)]
-    II, JJ, KK = np.meshgrid(v[0], v[1], v[2], sparse=False, indexing="ij")
-    dev = I.device
-    II = torch.tensor(II, dtype=torch.float, device=dev)
-    JJ = torch.tensor(JJ, dtype=torch.float, device=dev)
-    KK = torch.tensor(KK, dtype=torch.float, device=dev)
-    I_small = fast_3D_interp_torch(I_blur, II, JJ, KK)
+    # the reference samples at np.meshgrid(v0, v1, v2) converted to float32 (:600-606): the grid is separable, so the
+    # three float32 axis tables are all the kernel needs (same coordinates, same arithmetic as fast_3D_interp_torch)
+    n0, n1, n2 = (len(t) for t in v)
+    tabs = torch.from_numpy(np.concatenate(v).astype(np.float32)).to(I.device)
+    src = I_blur.to(torch.float32).contiguous()
+    I_small = torch.empty((n0, n1, n2), dtype=torch.float32, device=I.device)
+    if I_small.numel():
+        L.check(L.load().bfm_interp3d_linear_axes(L.ptr(src), src.shape[0], src.shape[1], src.shape[2], L.ptr(tabs),
+                                                  C.c_void_p(tabs.data_ptr() + 4 * n0),
+                                                  C.c_void_p(tabs.data_ptr() + 4 * (n0 + n1)), n0, n1, n2, 0.0,
+                                                  L.ptr(I_small), L.stream_ptr()), "interp3d_linear_axes")
     aux_dict.update({"factors": factors})
     return I_small, aux_dict
 

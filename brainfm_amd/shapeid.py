@@ -92,22 +92,27 @@ def kth_smallest_f64(x, k):
     return float(np.array([u], dtype=np.uint64).view(np.float64)[0])
 
 
-def percentile_linear(x, q):
-    """np.percentile(x, q) (method='linear') on a device fp64 tensor: two order statistics + NumPy's lerp."""
+def percentile_dev(x, q):
+    """np.percentile(x, q) (method='linear') of a device fp64 tensor, left on the device: a 3-element fp64 tensor
+    {percentile, x_(k), x_(k+1)}.  Radix select + NumPy's lerp inside libbrainfm_hip.so (bfm_percentile_f64): no
+    histogram ever travels to the host (round 3: 8 histogram read-backs of 256 KB per percentile)."""
+    lib = L.load()
+    x = x.contiguous()
     n = x.numel()
     pos = q / 100.0 * (n - 1)
     lo = int(math.floor(pos))
     hi = min(lo + 1, n - 1)
     t = pos - lo
-    a = kth_smallest_f64(x, lo)
-    b = kth_smallest_f64(x, hi) if hi != lo else a
-    diff = b - a
-    r = a + diff * t
-    if t >= 0.5:                       # numpy.lib._function_base_impl._lerp
-        r = b - diff * (1 - t)
-    if diff == 0:
-        r = a
-    return r
+    out = torch.empty(3, dtype=torch.float64, device=x.device)
+    ws = torch.empty(lib.bfm_percentile_workspace(), dtype=torch.uint8, device=x.device)
+    L.check(lib.bfm_percentile_f64(L.ptr(x), n, lo, int(hi != lo), float(t), L.ptr(out), L.ptr(ws), ws.numel(),
+                                   L.stream_ptr()), "percentile")
+    return out
+
+
+def percentile_linear(x, q):
+    """np.percentile(x, q) as a host float (one read-back)."""
+    return float(percentile_dev(x, q)[0].item())
 
 
 def generate_perlin_noise_3d(shape, res, tileable=(False, False, False), interpolant=interpolant, percentile=None,
@@ -121,13 +126,19 @@ def generate_perlin_noise_3d(shape, res, tileable=(False, False, False), interpo
     return threshold_at_percentile(noise, percentile)
 
 
-def threshold_at_percentile(noise, percentile):
+def threshold_at_percentile(noise, percentile, want_mask=True, want_max=False):
+    """(noise * mask, mask) with mask = noise >= np.percentile(noise, percentile) (perlin3d.py:84-90); the threshold never
+    leaves the device.  want_max: also the 1-element device tensor max(noise * mask) (binarize's operand)."""
     lib = L.load()
-    thr = percentile_linear(noise, percentile)
+    thr = percentile_dev(noise, percentile)
     masked = torch.empty_like(noise)
-    mask = torch.empty_like(noise)
-    L.check(lib.bfm_threshold_mask_f64(L.ptr(noise), noise.numel(), thr, L.ptr(masked), L.ptr(mask), L.stream_ptr()),
-            "threshold_mask")
+    mask = torch.empty_like(noise) if want_mask else None
+    mx = torch.empty(1, dtype=torch.float64, device=noise.device)
+    ws = torch.empty(lib.bfm_shape_workspace(), dtype=torch.uint8, device=noise.device)
+    L.check(lib.bfm_shape_threshold_f64(L.ptr(noise), noise.numel(), L.ptr(thr), L.ptr(masked), L.ptr(mask), L.ptr(mx),
+                                        L.ptr(ws), ws.numel(), L.stream_ptr()), "shape_threshold")
+    if want_max:
+        return masked, mask, mx
     return masked, mask
 
 
@@ -136,6 +147,16 @@ def generate_shape_3d(shape, perlin_res, percentile, device):
     pprob, p = generate_perlin_noise_3d(shape, perlin_res, tileable=(True, False, False), percentile=percentile,
                                         device=device)
     return p, pprob
+
+
+def generate_shape_3d_dev(shape, perlin_res, percentile, device):
+    """generate_shape_3d for the generator: (noise * mask, its maximum as a device scalar); the 0/1 mask, which
+    read_and_deform_pathology drops (Generator/utils.py:438), is not written.  Same np.random draws."""
+    if shape[0] % perlin_res[0] or shape[1] % perlin_res[1] or shape[2] % perlin_res[2]:
+        raise ValueError("shape must be a multiple of res")
+    noise = perlin_from_gradients(shape, perlin_res, perlin_gradients(perlin_res, (True, False, False)), device)
+    masked, _, mx = threshold_at_percentile(noise, percentile, want_mask=False, want_max=True)
+    return masked, mx
 
 
 def stream_3D(Phi_a, Phi_b, Phi_c, batched=False, delta_lst=[1., 1., 1.], multiplier=1.0):

@@ -555,6 +555,95 @@ int bfm_reduce_f32(int op, const float* x, const float* y, int64_t n, double* ou
 int bfm_reduce_f64(int op, const double* x, const double* y, int64_t n, double* out, void* workspace,
                    size_t workspace_bytes, bfm_stream_t stream);
 
+/* ---- the generator item without host round trips (round 4; brainfm_amd/csrc/synth_item.hip) --------------------------
+ * BrainIDGen.__getitem__ (Generator/datasets.py:700-757) re-reads every NIfTI volume of the case and crops it on the
+ * host per item (Generator/utils.py:296-305); here the case's volumes stay resident in HBM, the crop is a box inside
+ * them, scalar operands (min / max / sums / order statistics) stay in device memory between kernels, and short chains
+ * between two reductions are one kernel.  The arithmetic and its order are those of the unfused entry points above. */
+
+/* torch.randn(shape, device) of the generator: Philox4x32-10 counter (element index / 4, offset) under `seed`,
+ * Box-Muller, out = scale * N(0,1).  A different stream from torch's (RNG-stream parity across devices is not a goal
+ * of the reference either); the same (seed, offset) gives the same field on every run and device. */
+int bfm_randn_philox(float* out, int64_t n, uint64_t seed, uint64_t offset, float scale, bfm_stream_t stream);
+
+/* BaseGen.generate_deformation / deform_grid (datasets.py:187-303) with myzoom_torch(Fsmall, size / small)
+ * (utils.py:200-257) folded in: the zoomed field is evaluated per voxel from Fsmall [fnx][fny][fnz][3] and the zoom
+ * tables instead of being written and read back (Fsmall NULL: affine only).  _minmax writes the six extrema of the
+ * clamped coordinates (device, {min x,y,z, max x,y,z}) and nothing else; the host reads them (the reference
+ * synchronises there too, datasets.py:296-301), and _write stores the coordinates minus lo (+ F [n][3] on request).
+ * photo_zero_y: F[..., 1] = 0 (photo mode, datasets.py:243). */
+size_t bfm_deform_zoom_workspace(void);
+int bfm_deform_zoom_minmax(const float* Fsmall, int fnx, int fny, int fnz, const bfm_zoom_axis_t* ax, int photo_zero_y,
+                           int sx, int sy, int sz, const float* A_host, const float* c2_host, const int* shp_host,
+                           float* minmax6, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+int bfm_deform_zoom_write(const float* Fsmall, int fnx, int fny, int fnz, const bfm_zoom_axis_t* ax, int photo_zero_y,
+                          int sx, int sy, int sz, const float* A_host, const float* c2_host, const int* shp_host,
+                          const float* lo_host /*[3]*/, float* xx, float* yy, float* zz, float* F_out /*or NULL*/,
+                          bfm_stream_t stream);
+
+/* read_and_deform and its callers (Generator/utils.py:296-322; _image :331-345, _distance :376-400,
+ * _registration :462-473) for up to BFM_GATHER_MAX_JOBS volumes that share one coordinate field, straight from the
+ * resident full volumes [nx][ny][nz]: box6 = {x1,y1,z1,x2,y2,z2} is the crop the reference takes (upper ends clipped
+ * to the volume like a NumPy slice); validity and corner clamps of fast_3D_interp_torch are evaluated in CROP space.
+ * Per job: texel -> pre (0 none, 1 nan_to_num, 2 nan_to_num then (x - mean) / scale) -> trilinear; invalid
+ * coordinates take 0 or, with default_max, the crop's maximum after `pre` (read_and_deform's default_value_linear);
+ * then r / post_div (0 = off), clamp, r * sign (0 = off), written at the voxel (mirrored along axis 0 with flip0).
+ * want_minmax leaves min / max of the job's output in scalars[BFM_GATHER_MAX_JOBS + 2j (+1)]; scalars[j] holds the
+ * default value of job j.  scalars: 3 * BFM_GATHER_MAX_JOBS doubles (device). */
+#define BFM_GATHER_MAX_JOBS 12
+typedef struct {
+    const float* src; float* out;
+    float mean, scale; int pre; int default_max;
+    float post_div; int clamp; float clamp_lo, clamp_hi; float sign; int want_minmax;
+} bfm_gather_job_t;
+size_t bfm_gather_targets_workspace(void);
+int bfm_gather_targets(const bfm_gather_job_t* jobs, int njobs, int nx, int ny, int nz, const int* box6_host,
+                       const float* II, const float* JJ, const float* KK, int sx, int sy, int sz, int flip0,
+                       double* scalars, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+/* I -= min(I); I /= max(I) (read_and_deform_image, utils.py:340-342) with {min, max} of I in device memory. */
+int bfm_minmax_normalise(float* x, int64_t n, const double* minmax_dev, bfm_stream_t stream);
+/* read_and_deform_segmentation (utils.py:402-425): nearest gather from the resident int32 label volume (crop-space
+ * rounding and clamps), lut, one-hot rows out [sx][sy][sz][n_labels]; flip0: torch.flip(., [0])[..., vflip]. */
+int bfm_gather_onehot(const int32_t* S, int nx, int ny, int nz, const int* box6_host, const float* II, const float* JJ,
+                      const float* KK, int sx, int sy, int sz, int flip0, const int32_t* lut, int nlut, int n_labels,
+                      const int32_t* vflip /*[n_labels] or NULL*/, float* out, bfm_stream_t stream);
+
+/* np.percentile(x, q) (method 'linear', ShapeID/perlin3d.py:84-90) without leaving the device: radix select of the
+ * order statistic k_lo (six passes over 11 / 9-bit digits of the order-preserving key, block histograms in LDS), the
+ * next one where needed, NumPy's _lerp with weight t.  out3 (device) = {percentile, x_(k_lo), x_(k_lo+1)}. */
+size_t bfm_percentile_workspace(void);
+int bfm_percentile_f64(const double* x, int64_t n, int64_t k_lo, int need_next, double t, double* out3, void* workspace,
+                       size_t workspace_bytes, bfm_stream_t stream);
+/* generate_perlin_noise_3d's mask (perlin3d.py:86-90) with the threshold in device memory: masked = x * (x >= thr),
+ * mask (optional) = (x >= thr); max_out = max(masked).  binarize (Generator/utils.py:65-72): P = (p >= thres * max)
+ * in p's dtype, sum_out = sum(P). */
+size_t bfm_shape_workspace(void);
+int bfm_shape_threshold_f64(const double* noise, int64_t n, const double* thr_dev, double* masked, double* mask,
+                            double* max_out, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+int bfm_shape_binarize(const void* p, int is_f64, int64_t n, const double* max_dev, double thres, void* P,
+                       double* sum_out, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+/* generate_sample's pathology branch (datasets.py:398-399): target['pathology'][cer == 0] = 0 and the same for
+ * pathology_prob, in place in their own dtype; sum_out = sum of the masked pathology (the test of :322 / :387). */
+int bfm_pathology_mask(void* P, void* Pprob, int is_f64, const float* cerebral, int64_t n, double* sum_out,
+                       void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+/* encode_pathology (datasets.py:496-518) with I_mu = sum(I*P) / sum(P) kept on the device (dotsum_out[2]); u4 = the
+ * uniform draws behind pth_mus[0], pth_mus[1], pth_sigmas[0], pth_sigmas[1]; direction 1 / 0, or -1 to take
+ * gm_mean > wm_mean from bfm_label_class_stats' sums (datasets.py:392-404) without reading them back. */
+size_t bfm_pathology_encode_workspace(void);
+int bfm_pathology_encode_dev(const float* I, const void* P, const void* Pprob, int is_f64, const float* randn,
+                             const float* u4_host, int direction, const double* class_stats_dev, int64_t n, float* out,
+                             double* dotsum_out, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+/* resample_resolution's sample (utils.py:600-606): fast_3D_interp_torch on meshgrid(ax, ay, az), the grid never
+ * materialised. */
+int bfm_interp3d_linear_axes(const float* X, int nx, int ny, int nz, const float* ax, const float* ay, const float* az,
+                             int ox, int oy, int oz, float default_value, float* out, bfm_stream_t stream);
+/* augment_sample's tail (datasets.py:340-352): input = I / max, residual = high_res / max - input (optional), both
+ * mirrored along axis 0 with flip0; max in device memory. */
+int bfm_sample_finalize(const float* I, const float* high_res, int sx, int sy, int sz, const double* max_dev, int flip0,
+                        float* input_out, float* residual_out, bfm_stream_t stream);
+/* elementwise with the scalar in device memory: op 0: x / s, op 1: x >= a * s ? 1 : 0 (fp32). */
+int bfm_ew_dev(int op, const float* x, int64_t n, const double* scalar_dev, float a, float* out, bfm_stream_t stream);
+
 /* ---- backward pass of the SingleConv block and its neighbours (first correct version) -------------------
  * The reference trains through torch autograd over buildingblocks.py:31-60 (GroupNorm -> Conv3d -> LeakyReLU),
  * :185-186 (MaxPool3d(2)), :265-276,361-363 (nearest upsample + concat).
