@@ -47,6 +47,16 @@ class KSet(C.Structure):
     _fields_ = [("k", C.c_void_p * 7), ("coef", C.c_float * 7), ("nk", C.c_int)]
 
 
+class Dopri5Advect(C.Structure):
+    _fields_ = [("y", C.c_void_p * 2), ("f", C.c_void_p * 2), ("k", C.c_void_p * 5),
+                ("Vx", C.c_void_p), ("Vy", C.c_void_p), ("Vz", C.c_void_p),
+                ("sx", C.c_int), ("sy", C.c_int), ("sz", C.c_int), ("neumann_bc", C.c_int), ("is_f64", C.c_int),
+                ("atol", C.c_double), ("rtol", C.c_double), ("tol_min_dt", C.c_double), ("dt_max", C.c_double),
+                ("safety", C.c_double), ("ifactor", C.c_double), ("dfactor", C.c_double),
+                ("t_out", C.c_void_p), ("nt", C.c_int), ("sol", C.c_void_p), ("state", C.c_void_p),
+                ("workspace", C.c_void_p)]
+
+
 GATHER_MAX_JOBS = 12          # BFM_GATHER_MAX_JOBS of include/brainfm_hip.h
 
 
@@ -184,6 +194,10 @@ SIGNATURES = {
     "bfm_dopri5_dense_eval": (_I, [_P, _P, _I, C.POINTER(KSet), C.c_double, C.c_double, _P, _L, _P]),
     "bfm_reduce_f32": (_I, [_I, _P, _P, _L, _P, _P, _Z, _P]),
     "bfm_reduce_f64": (_I, [_I, _P, _P, _L, _P, _P, _Z, _P]),
+    "bfm_dopri5_advect_state_bytes": (_Z, []),
+    "bfm_dopri5_advect_workspace": (_Z, [_I, _I, _I]),
+    "bfm_dopri5_advect_init": (_I, [C.POINTER(Dopri5Advect), C.c_double, C.c_double, _P]),
+    "bfm_dopri5_advect_steps": (_I, [C.POINTER(Dopri5Advect), _I, _P]),
     "bfm_randn_philox": (_I, [_P, _L, C.c_uint64, C.c_uint64, _F, _P]),
     "bfm_deform_zoom_workspace": (_Z, []),
     "bfm_deform_zoom_minmax": (_I, [_P, _I, _I, _I, C.POINTER(ZoomAxis), _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F),

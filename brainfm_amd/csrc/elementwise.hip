@@ -12,45 +12,66 @@ inline int grid_for(int64_t n, int tpb = 256, int cap = 4096) {
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
+__device__ __forceinline__ float ew_u(int op, float x, float a, float b) {
+    switch (op) {
+        case BFM_EW_EXP: return expf(x);
+        case BFM_EW_AFFINE: return x * a + b;
+        case BFM_EW_CLAMP: return fminf(fmaxf(x, a), b);
+        case BFM_EW_CLAMP_MIN: return x < a ? a : x;
+        case BFM_EW_GAMMA: return a * powf(x / a, b);
+        case BFM_EW_SIGMOID: return 1.f / (1.f + expf(-x));
+        case BFM_EW_DIV: return x / a;
+        case BFM_EW_NONZERO: return x != 0.f ? 1.f : 0.f;
+        case BFM_EW_SUB_DIV: return (x - a) / b;
+        case BFM_EW_GE: return x >= a ? 1.f : 0.f;
+        case BFM_EW_NAN_TO_NUM: return x != x ? 0.f : (x == INFINITY ? 3.402823466e+38f : (x == -INFINITY ? -3.402823466e+38f : x));
+        default: return x;
+    }
+}
+
+__device__ __forceinline__ float ew_b(int op, float p, float q, float a) {
+    float r;
+    switch (op) {
+        case BFM_EW_ADD: return p + q;
+        case BFM_EW_MUL: return p * q;
+        case BFM_EW_MUL_EXP: return p * expf(q);
+        case BFM_EW_AXPY_CLAMP0: r = p + a * q; return r < 0.f ? 0.f : r;   // add_noise, utils.py:633-638
+        case BFM_EW_AXPY: return p + a * q;
+        case BFM_EW_DIV2: return p / q;
+        case BFM_EW_ZERO_WHERE_ZERO: return q == 0.f ? 0.f : p;
+        default: return p;
+    }
+}
+
 __global__ void ew_unary(int op, const float* __restrict__ in, int64_t is, float* __restrict__ out, int64_t os,
                          int64_t n, float a, float b) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float x = in[i * is], r;
-        switch (op) {
-            case BFM_EW_EXP: r = expf(x); break;
-            case BFM_EW_AFFINE: r = x * a + b; break;
-            case BFM_EW_CLAMP: r = fminf(fmaxf(x, a), b); break;
-            case BFM_EW_CLAMP_MIN: r = x < a ? a : x; break;
-            case BFM_EW_GAMMA: r = a * powf(x / a, b); break;
-            case BFM_EW_SIGMOID: r = 1.f / (1.f + expf(-x)); break;
-            case BFM_EW_DIV: r = x / a; break;
-            case BFM_EW_NONZERO: r = x != 0.f ? 1.f : 0.f; break;
-            case BFM_EW_SUB_DIV: r = (x - a) / b; break;
-            case BFM_EW_GE: r = x >= a ? 1.f : 0.f; break;
-            case BFM_EW_NAN_TO_NUM: r = x != x ? 0.f : (x == INFINITY ? 3.402823466e+38f : (x == -INFINITY ? -3.402823466e+38f : x)); break;
-            default: r = x;
-        }
-        out[i * os] = r;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i * os] = ew_u(op, in[i * is], a, b);
+}
+
+// contiguous, 16-byte aligned operands: four elements per lane and access
+__global__ void ew_unary4(int op, const float4* __restrict__ in, float4* __restrict__ out, int64_t n4, float a, float b) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = in[i];
+        out[i] = make_float4(ew_u(op, v.x, a, b), ew_u(op, v.y, a, b), ew_u(op, v.z, a, b), ew_u(op, v.w, a, b));
     }
 }
 
 __global__ void ew_binary(int op, const float* __restrict__ x, int64_t xs, const float* __restrict__ y, int64_t ys,
                           float* __restrict__ out, int64_t os, int64_t n, float a) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float p = x[i * xs], q = y[i * ys], r;
-        switch (op) {
-            case BFM_EW_ADD: r = p + q; break;
-            case BFM_EW_MUL: r = p * q; break;
-            case BFM_EW_MUL_EXP: r = p * expf(q); break;
-            case BFM_EW_AXPY_CLAMP0: r = p + a * q; r = r < 0.f ? 0.f : r; break;   // add_noise, utils.py:633-638
-            case BFM_EW_AXPY: r = p + a * q; break;
-            case BFM_EW_DIV2: r = p / q; break;
-            case BFM_EW_ZERO_WHERE_ZERO: r = q == 0.f ? 0.f : p; break;
-            default: r = p;
-        }
-        out[i * os] = r;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i * os] = ew_b(op, x[i * xs], y[i * ys], a);
+}
+
+__global__ void ew_binary4(int op, const float4* __restrict__ x, const float4* __restrict__ y, float4* __restrict__ out,
+                           int64_t n4, float a) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 p = x[i], q = y[i];
+        out[i] = make_float4(ew_b(op, p.x, q.x, a), ew_b(op, p.y, q.y, a), ew_b(op, p.z, q.z, a), ew_b(op, p.w, q.w, a));
     }
 }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // softmax over the last (channel) axis of a channels-last tensor, one thread per voxel
 __global__ void softmax_cl(const float* __restrict__ x, int64_t xrs, int C, float* __restrict__ y, int64_t yrs,
@@ -115,6 +136,15 @@ extern "C" int bfm_pathology_encode(const float* I, const float* P, const float*
 extern "C" int bfm_ew_unary(int op, const float* in, int64_t in_stride, float* out, int64_t out_stride, int64_t n,
                             float a, float b, bfm_stream_t stream) {
     if (!in || !out || n <= 0 || in_stride <= 0 || out_stride <= 0) return BFM_E_ARG;
+    if (in_stride == 1 && out_stride == 1 && aligned16(in) && aligned16(out) && n >= 1024) {
+        const int64_t n4 = n >> 2;
+        hipLaunchKernelGGL(ew_unary4, dim3(grid_for(n4)), dim3(256), 0, bfm_s(stream), op, (const float4*)in, (float4*)out,
+                           n4, a, b);
+        if (n & 3)
+            hipLaunchKernelGGL(ew_unary, dim3(1), dim3(64), 0, bfm_s(stream), op, in + (n4 << 2), (int64_t)1,
+                               out + (n4 << 2), (int64_t)1, n & 3, a, b);
+        return bfm_launch_status();
+    }
     hipLaunchKernelGGL(ew_unary, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), op, in, in_stride, out, out_stride, n,
                        a, b);
     return bfm_launch_status();
@@ -123,6 +153,15 @@ extern "C" int bfm_ew_unary(int op, const float* in, int64_t in_stride, float* o
 extern "C" int bfm_ew_binary(int op, const float* x, int64_t xs, const float* y, int64_t ys, float* out, int64_t os,
                              int64_t n, float a, bfm_stream_t stream) {
     if (!x || !y || !out || n <= 0 || xs <= 0 || ys < 0 || os <= 0) return BFM_E_ARG;
+    if (xs == 1 && ys == 1 && os == 1 && aligned16(x) && aligned16(y) && aligned16(out) && n >= 1024) {
+        const int64_t n4 = n >> 2;
+        hipLaunchKernelGGL(ew_binary4, dim3(grid_for(n4)), dim3(256), 0, bfm_s(stream), op, (const float4*)x,
+                           (const float4*)y, (float4*)out, n4, a);
+        if (n & 3)
+            hipLaunchKernelGGL(ew_binary, dim3(1), dim3(64), 0, bfm_s(stream), op, x + (n4 << 2), (int64_t)1,
+                               y + (n4 << 2), (int64_t)1, out + (n4 << 2), (int64_t)1, n & 3, a);
+        return bfm_launch_status();
+    }
     hipLaunchKernelGGL(ew_binary, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), op, x, xs, y, ys, out, os, n, a);
     return bfm_launch_status();
 }

@@ -146,47 +146,58 @@ struct ZoomTabs {
     const float *wfx, *wcx, *wfy, *wcy, *wfz, *wcz;
 };
 
-__global__ void zoom_linear(const float* __restrict__ X, int nx, int ny, int nz, int C, ZoomTabs t, int ox, int oy,
-                            int oz, float* __restrict__ out) {
-    const int64_t n = (int64_t)ox * oy * oz * C;
-    GRID_STRIDE(i, n) {
-        const int c = (int)(i % C);
-        int64_t v = i / C;
-        const int k = (int)(v % oz); v /= oz;
-        const int j = (int)(v % oy);
-        const int ii = (int)(v / oy);
-        const int fx = t.fx[ii], cx = t.cx[ii], fy = t.fy[j], cy = t.cy[j], fz = t.fz[k], cz = t.cz[k];
-        const float wfx = t.wfx[ii], wcx = t.wcx[ii], wfy = t.wfy[j], wcy = t.wcy[j], wfz = t.wfz[k], wcz = t.wcz[k];
-        const int64_t sx = (int64_t)ny * nz * C, sy = (int64_t)nz * C;
-        auto at = [&](int a, int b, int d) { return X[a * sx + b * sy + (int64_t)d * C + c]; };
-        // pass order of the reference: x, then y, then z
-        const float a00 = wfx * at(fx, fy, fz) + wcx * at(cx, fy, fz);
-        const float a10 = wfx * at(fx, cy, fz) + wcx * at(cx, cy, fz);
-        const float a01 = wfx * at(fx, fy, cz) + wcx * at(cx, fy, cz);
-        const float a11 = wfx * at(fx, cy, cz) + wcx * at(cx, cy, cz);
-        const float b0 = wfy * a00 + wcy * a10;
-        const float b1 = wfy * a01 + wcy * a11;
-        out[i] = wfz * b0 + wcz * b1;
+// one wave per output (x, y) row, lanes along (z, channel): the row's x / y table entries are wave-uniform and the only
+// divisions left are 32-bit ones by C (round 3: three 64-bit div / mod pairs per element, 59 us for 160^3 x 3)
+__global__ void __launch_bounds__(256) zoom_linear(const float* __restrict__ X, int nx, int ny, int nz, int C, ZoomTabs t,
+                                                   int ox, int oy, int oz, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int rows = ox * oy, rowlen = oz * C;
+    const int64_t sx = (int64_t)ny * nz * C, sy = (int64_t)nz * C;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
+        const int ii = r / oy, j = r - ii * oy;
+        const int fx = t.fx[ii], cx = t.cx[ii], fy = t.fy[j], cy = t.cy[j];
+        const float wfx = t.wfx[ii], wcx = t.wcx[ii], wfy = t.wfy[j], wcy = t.wcy[j];
+        const float* p00 = X + fx * sx + fy * sy;
+        const float* p10 = X + cx * sx + fy * sy;
+        const float* p01 = X + fx * sx + cy * sy;
+        const float* p11 = X + cx * sx + cy * sy;
+        float* o = out + (int64_t)r * rowlen;
+        for (int e = lane; e < rowlen; e += 64) {
+            const int k = C == 1 ? e : e / C, c = C == 1 ? 0 : e - k * C;
+            const int fz = t.fz[k] * C + c, cz = t.cz[k] * C + c;
+            const float wfz = t.wfz[k], wcz = t.wcz[k];
+            // pass order of the reference: x, then y, then z
+            const float a00 = wfx * p00[fz] + wcx * p10[fz];
+            const float a10 = wfx * p01[fz] + wcx * p11[fz];
+            const float a01 = wfx * p00[cz] + wcx * p10[cz];
+            const float a11 = wfx * p01[cz] + wcx * p11[cz];
+            const float b0 = wfy * a00 + wcy * a10;
+            const float b1 = wfy * a01 + wcy * a11;
+            o[e] = wfz * b0 + wcz * b1;
+        }
     }
 }
 
-__global__ void conv1d_axis(const float* __restrict__ in, int nx, int ny, int nz, int axis,
-                            const float* __restrict__ kern, int klen, float* __restrict__ out) {
-    const int64_t n = (int64_t)nx * ny * nz;
+// one wave per (x, y) row, lanes along z (coalesced for every axis); taps in registers-by-value would need a fixed
+// length, so they stay a small table read through the scalar cache
+__global__ void __launch_bounds__(256) conv1d_axis(const float* __restrict__ in, int nx, int ny, int nz, int axis,
+                                                   const float* __restrict__ kern, int klen, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int rows = nx * ny;
     const int half = klen / 2;
     const int64_t stride = axis == 0 ? (int64_t)ny * nz : (axis == 1 ? nz : 1);
     const int len = axis == 0 ? nx : (axis == 1 ? ny : nz);
-    GRID_STRIDE(i, n) {
-        const int z = (int)(i % nz);
-        const int y = (int)((i / nz) % ny);
-        const int x = (int)(i / ((int64_t)ny * nz));
-        const int pos = axis == 0 ? x : (axis == 1 ? y : z);
-        float acc = 0.f;
-        for (int j = 0; j < klen; ++j) {
-            const int q = pos + j - half;
-            if (q >= 0 && q < len) acc = fmaf(kern[j], in[i + (int64_t)(j - half) * stride], acc);
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
+        const int x = r / ny, y = r - x * ny;
+        const int64_t base = (int64_t)r * nz;
+        for (int z = lane; z < nz; z += 64) {
+            const int pos = axis == 0 ? x : (axis == 1 ? y : z);
+            const int j0 = max(0, half - pos), j1 = min(klen, len + half - pos);       // taps inside the volume
+            const float* p = in + base + z + (int64_t)(j0 - half) * stride;
+            float acc = 0.f;
+            for (int j = j0; j < j1; ++j, p += stride) acc = fmaf(kern[j], *p, acc);
+            out[base + z] = acc;
         }
-        out[i] = acc;
     }
 }
 
@@ -432,12 +443,11 @@ __global__ void deform_grid_k(const float* __restrict__ F, int sx, int sy, int s
 }
 
 __global__ void minmax6_final(const float* __restrict__ part, int nb, float* __restrict__ out) {
-    const int k = threadIdx.x;
-    if (k < 6) {
-        float v = part[k];
-        for (int b = 1; b < nb; ++b) v = k < 3 ? fminf(v, part[(size_t)b * 6 + k]) : fmaxf(v, part[(size_t)b * 6 + k]);
-        out[k] = v;
-    }
+    const int k = threadIdx.x >> 6, l = threadIdx.x & 63;                // 6 waves, one per component
+    float v = k < 3 ? INFINITY : -INFINITY;
+    for (int b = l; b < nb; b += 64) v = k < 3 ? fminf(v, part[(size_t)b * 6 + k]) : fmaxf(v, part[(size_t)b * 6 + k]);
+    v = k < 3 ? wave_reduce_min(v) : wave_reduce_max(v);
+    if (l == 0) out[k] = v;
 }
 
 __global__ void label_gauss(const float* __restrict__ G, const float* __restrict__ mus,
@@ -481,12 +491,14 @@ __global__ void label_class_stats(const float* __restrict__ G, const float* __re
     }
 }
 
+// 4 waves, wave k folds quantity k: lane l adds its strided partials, then a fixed xor tree (deterministic; the single
+// thread walking 1024 partials of round 3 took 110 us per call)
 __global__ void label_class_fold(const double* __restrict__ partials, int nb, double* __restrict__ stats) {
-    if (threadIdx.x < 4) {
-        double v = 0.;
-        for (int b = 0; b < nb; ++b) v += partials[(size_t)b * 4 + threadIdx.x];
-        stats[threadIdx.x] = v;
-    }
+    const int k = threadIdx.x >> 6, l = threadIdx.x & 63;
+    double v = 0.;
+    for (int b = l; b < nb; b += 64) v += partials[(size_t)b * 4 + k];
+    v = wave_reduce_sum(v);
+    if (l == 0) stats[k] = v;
 }
 
 __global__ void onehot_lut(const int32_t* __restrict__ S, const int32_t* __restrict__ lut, int nlut, int nl, int64_t n,
@@ -557,8 +569,9 @@ extern "C" int bfm_zoom_linear(const float* X, int nx, int ny, int nz, int C, co
         if (!ax[a].f || !ax[a].c || !ax[a].wf || !ax[a].wc) return BFM_E_ARG;
     ZoomTabs t{ax[0].f, ax[0].c, ax[1].f, ax[1].c, ax[2].f, ax[2].c, ax[0].wf, ax[0].wc, ax[1].wf, ax[1].wc,
                ax[2].wf, ax[2].wc};
-    int64_t n = (int64_t)ox * oy * oz * C;
-    hipLaunchKernelGGL(zoom_linear, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), X, nx, ny, nz, C, t, ox, oy, oz, out);
+    if ((int64_t)ox * oy > INT32_MAX || (int64_t)oz * C > INT32_MAX) return BFM_E_SHAPE;
+    hipLaunchKernelGGL(zoom_linear, dim3(grid_for((int64_t)ox * oy, 4)), dim3(256), 0, bfm_s(stream), X, nx, ny, nz, C, t,
+                       ox, oy, oz, out);
     return bfm_launch_status();
 }
 
@@ -566,8 +579,9 @@ extern "C" int bfm_conv1d_axis(const float* in, int nx, int ny, int nz, int axis
                                float* out, bfm_stream_t stream) {
     if (!in || !kern || !out || nx <= 0 || ny <= 0 || nz <= 0 || axis < 0 || axis > 2 || klen <= 0 || !(klen & 1))
         return BFM_E_ARG;
-    int64_t n = (int64_t)nx * ny * nz;
-    hipLaunchKernelGGL(conv1d_axis, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), in, nx, ny, nz, axis, kern, klen, out);
+    if ((int64_t)nx * ny > INT32_MAX) return BFM_E_SHAPE;
+    hipLaunchKernelGGL(conv1d_axis, dim3(grid_for((int64_t)nx * ny, 4)), dim3(256), 0, bfm_s(stream), in, nx, ny, nz, axis,
+                       kern, klen, out);
     return bfm_launch_status();
 }
 
@@ -603,7 +617,7 @@ extern "C" int bfm_deform_grid(const float* F, int sx, int sy, int sz, const flo
     for (int i = 0; i < 3; ++i) { P.c[i] = c2_host[i]; P.shp[i] = shp_host[i]; }
     hipLaunchKernelGGL(deform_grid_k, dim3(nb), dim3(256), 0, bfm_s(stream), F, sx, sy, sz, P, xx, yy, zz,
                        static_cast<float*>(workspace));
-    hipLaunchKernelGGL(minmax6_final, dim3(1), dim3(64), 0, bfm_s(stream), static_cast<const float*>(workspace), nb,
+    hipLaunchKernelGGL(minmax6_final, dim3(1), dim3(384), 0, bfm_s(stream), static_cast<const float*>(workspace), nb,
                        minmax);
     return bfm_launch_status();
 }
@@ -620,7 +634,7 @@ extern "C" int bfm_label_class_stats(const float* G, const float* syn, int64_t n
     if (!G || !syn || !cerebral || !stats || !partials || n <= 0) return BFM_E_ARG;
     const int nb = grid_for(n, 256, BFM_CLASS_STATS_BLOCKS);
     hipLaunchKernelGGL(label_class_stats, dim3(nb), dim3(256), 0, bfm_s(stream), G, syn, n, cerebral, partials);
-    hipLaunchKernelGGL(label_class_fold, dim3(1), dim3(64), 0, bfm_s(stream), partials, nb, stats);
+    hipLaunchKernelGGL(label_class_fold, dim3(1), dim3(256), 0, bfm_s(stream), partials, nb, stats);
     return bfm_launch_status();
 }
 

@@ -25,37 +25,42 @@ inline int grid_for(int64_t n, int tpb = 256, int cap = 8192) {
 // ------------------------------------------------------------------ Perlin
 __device__ __forceinline__ double fade(double t) { return t * t * t * (t * (t * 6 - 15) + 10); }
 
-__global__ void perlin3d(const double* __restrict__ grad, int sx, int sy, int sz, int rx, int ry, int rz,
-                         double* __restrict__ out) {
-    const int64_t n = (int64_t)sx * sy * sz;
+// one wave per (x, y) row, lanes along z: everything that depends on x and y alone (fractions, fades, cell) is wave-uniform
+__global__ void __launch_bounds__(256) perlin3d(const double* __restrict__ grad, int sx, int sy, int sz, int rx, int ry,
+                                                int rz, double* __restrict__ out) {
     const double dx = (double)rx / (double)sx, dy = (double)ry / (double)sy, dz = (double)rz / (double)sz;
     const int cx = sx / rx, cy = sy / ry, cz = sz / rz;          // d = shape // res
     const int gy = ry + 1, gz = rz + 1;
-    GRID_STRIDE(i, n) {
-        const int z = (int)(i % sz);
-        const int y = (int)((i / sz) % sy);
-        const int x = (int)(i / ((int64_t)sy * sz));
+    const int lane = threadIdx.x & 63;
+    const int rows = sx * sy;
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
+        const int x = r / sy, y = r - x * sy;
         // grid = (mgrid = index*delta) % 1 ; lattice cell = index // d  (NumPy semantics, fp64)
-        const double fx = fmod((double)x * dx, 1.0), fy = fmod((double)y * dy, 1.0), fz = fmod((double)z * dz, 1.0);
-        const int ix = x / cx, iy = y / cy, iz = z / cz;
-        auto G = [&](int a, int b, int c) { return grad + ((int64_t)((ix + a) * gy + (iy + b)) * gz + (iz + c)) * 3; };
-        auto dot = [&](const double* g, double a, double b, double c) { return (a * g[0] + b * g[1]) + c * g[2]; };
-        const double n000 = dot(G(0, 0, 0), fx, fy, fz);
-        const double n100 = dot(G(1, 0, 0), fx - 1, fy, fz);
-        const double n010 = dot(G(0, 1, 0), fx, fy - 1, fz);
-        const double n110 = dot(G(1, 1, 0), fx - 1, fy - 1, fz);
-        const double n001 = dot(G(0, 0, 1), fx, fy, fz - 1);
-        const double n101 = dot(G(1, 0, 1), fx - 1, fy, fz - 1);
-        const double n011 = dot(G(0, 1, 1), fx, fy - 1, fz - 1);
-        const double n111 = dot(G(1, 1, 1), fx - 1, fy - 1, fz - 1);
-        const double t0 = fade(fx), t1 = fade(fy), t2 = fade(fz);
-        const double n00 = n000 * (1 - t0) + t0 * n100;
-        const double n10 = n010 * (1 - t0) + t0 * n110;
-        const double n01 = n001 * (1 - t0) + t0 * n101;
-        const double n11 = n011 * (1 - t0) + t0 * n111;
-        const double n0 = (1 - t1) * n00 + t1 * n10;
-        const double n1 = (1 - t1) * n01 + t1 * n11;
-        out[i] = (1 - t2) * n0 + t2 * n1;
+        const double fx = fmod((double)x * dx, 1.0), fy = fmod((double)y * dy, 1.0);
+        const int ix = x / cx, iy = y / cy;
+        const double t0 = fade(fx), t1 = fade(fy);
+        for (int z = lane; z < sz; z += 64) {
+            const double fz = fmod((double)z * dz, 1.0);
+            const int iz = z / cz;
+            auto G = [&](int a, int b, int c) { return grad + ((int64_t)((ix + a) * gy + (iy + b)) * gz + (iz + c)) * 3; };
+            auto dot = [&](const double* g, double a, double b, double c) { return (a * g[0] + b * g[1]) + c * g[2]; };
+            const double n000 = dot(G(0, 0, 0), fx, fy, fz);
+            const double n100 = dot(G(1, 0, 0), fx - 1, fy, fz);
+            const double n010 = dot(G(0, 1, 0), fx, fy - 1, fz);
+            const double n110 = dot(G(1, 1, 0), fx - 1, fy - 1, fz);
+            const double n001 = dot(G(0, 0, 1), fx, fy, fz - 1);
+            const double n101 = dot(G(1, 0, 1), fx - 1, fy, fz - 1);
+            const double n011 = dot(G(0, 1, 1), fx, fy - 1, fz - 1);
+            const double n111 = dot(G(1, 1, 1), fx - 1, fy - 1, fz - 1);
+            const double t2 = fade(fz);
+            const double n00 = n000 * (1 - t0) + t0 * n100;
+            const double n10 = n010 * (1 - t0) + t0 * n110;
+            const double n01 = n001 * (1 - t0) + t0 * n101;
+            const double n11 = n011 * (1 - t0) + t0 * n111;
+            const double n0 = (1 - t1) * n00 + t1 * n10;
+            const double n1 = (1 - t1) * n01 + t1 * n11;
+            out[(int64_t)r * sz + z] = (1 - t2) * n0 + t2 * n1;
+        }
     }
 }
 
@@ -211,13 +216,34 @@ __global__ void sum_partials(const double* __restrict__ part, int nb, double* __
 
 // generic reductions for the augmentation chain: op 0 min, 1 max, 2 sum(x), 3 sum(x*y)
 template <typename TX>
+__device__ __forceinline__ double red_step(int op, double s, TX x, TX y) {
+    const double v = op == 3 ? (double)(x * y) : (double)x;
+    return op == 0 ? fmin(s, v) : (op == 1 ? fmax(s, v) : s + v);
+}
+
+template <typename TX>
 __global__ void reduce_partial(int op, const TX* __restrict__ x, const TX* __restrict__ y, int64_t n,
                                double* __restrict__ part) {
     double s = op == 0 ? INFINITY : (op == 1 ? -INFINITY : 0.0);
-    GRID_STRIDE(i, n) {
-        const double v = op == 3 ? (double)(x[i] * y[i]) : (double)x[i];
-        s = op == 0 ? fmin(s, v) : (op == 1 ? fmax(s, v) : s + v);
+    constexpr int V = 16 / sizeof(TX);                                  // elements per 16-byte access
+    typedef TX VT __attribute__((ext_vector_type(V)));
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (!y || (reinterpret_cast<uintptr_t>(y) & 15) == 0);
+    int64_t done = 0;
+    if (vec) {
+        const int64_t nv = n / V;
+        const VT* xv = reinterpret_cast<const VT*>(x);
+        const VT* yv = reinterpret_cast<const VT*>(y);
+        GRID_STRIDE(i, nv) {
+            const VT a = xv[i];
+            VT b = a;
+            if (op == 3) b = yv[i];
+#pragma unroll
+            for (int k = 0; k < V; ++k) s = red_step<TX>(op, s, a[k], b[k]);
+        }
+        done = nv * V;
     }
+    for (int64_t i = done + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        s = red_step<TX>(op, s, x[i], op == 3 ? y[i] : x[i]);
     __shared__ double red[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -293,8 +319,9 @@ extern "C" int bfm_perlin3d(const double* grad, int sx, int sy, int sz, int rx, 
                             bfm_stream_t stream) {
     if (!grad || !out || sx <= 0 || sy <= 0 || sz <= 0 || rx <= 0 || ry <= 0 || rz <= 0) return BFM_E_ARG;
     if (sx % rx || sy % ry || sz % rz) return BFM_E_SHAPE;          // "shape must be a multiple of res"
-    int64_t n = (int64_t)sx * sy * sz;
-    hipLaunchKernelGGL(perlin3d, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), grad, sx, sy, sz, rx, ry, rz, out);
+    if ((int64_t)sx * sy > INT32_MAX) return BFM_E_SHAPE;
+    hipLaunchKernelGGL(perlin3d, dim3(grid_for((int64_t)sx * sy, 4)), dim3(256), 0, bfm_s(stream), grad, sx, sy, sz, rx, ry,
+                       rz, out);
     return bfm_launch_status();
 }
 

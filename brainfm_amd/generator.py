@@ -73,22 +73,29 @@ class DeviceVolumes:
             arr = arr.astype(np.float64)
         return arr
 
-    def get(self, vol, kind="f32"):
+    def get(self, vol, kind="f32", mean=0., scale=1.):
         """The whole volume as float32 (`kind` 'f32': what torch.tensor(get_fdata().astype(float), dtype=torch.float)
-        holds, one rounding from the stored type) or int32 ('i32': .astype(int), truncation)."""
+        holds, one rounding from the stored type), as int32 ('i32': .astype(int), truncation), or as read_and_deform
+        prepares it ('prep': nan_to_num, then (I - mean) / scale, Generator/utils.py:303-308 -- elementwise, so applying it
+        to the resident volume once gives every later crop the values the reference computes per item)."""
         src = vol._d if isinstance(vol, ArrayVolume) else vol
-        key = (id(src), kind)
+        key = (id(src), kind, float(mean), float(scale))
         hit = self.items.get(key)
         if hit is not None:
             self.items.move_to_end(key)
             return hit[0]
         arr = self._host_array(src)
-        if kind == "f32":
+        if kind in ("f32", "prep"):
             host = np.ascontiguousarray(arr, dtype=np.float32)
         else:
             host = np.ascontiguousarray(arr.astype(np.int64) if np.issubdtype(arr.dtype, np.floating) else arr,
                                         dtype=np.int32)
         t = torch.from_numpy(host).to(self.device)
+        if kind == "prep":
+            with torch.cuda.device(self.device):
+                t = GU.ew_unary(L.EW_NAN_TO_NUM, t)
+                if mean != 0. or scale != 1.:
+                    t = GU.ew_unary(L.EW_SUB_DIV, t, float(mean), float(scale))
         nbytes = t.numel() * 4
         while self.items and self.bytes + nbytes > self.budget:
             _, (old, _) = self.items.popitem(last=False)
@@ -354,13 +361,12 @@ class BaseGen(torch.utils.data.Dataset):
             cache[key] = out
         return out
 
-    def _job(self, vol, out, pre=1, mean=0., scale=1., default_max=False, post_div=0., clamp=None, sign=0.,
+    def _job(self, vol, out, mean=0., scale=1., default_max=False, post_div=0., clamp=None, sign=0.,
              want_minmax=False, post=None):
-        """One volume of a bfm_gather_targets launch; `post(scalars, j)` runs after the launch."""
-        if mean != 0. or scale != 1.:
-            pre = 2
-        return {"vol": self.volumes.get(_vol(vol), "f32"), "out": out, "pre": pre, "mean": float(mean),
-                "scale": float(scale), "default_max": bool(default_max), "post_div": float(post_div), "clamp": clamp,
+        """One volume of a bfm_gather_targets launch (the resident volume already holds nan_to_num((I - mean) / scale));
+        `post(scalars, j)` runs after the launch."""
+        return {"vol": self.volumes.get(_vol(vol), "prep", mean, scale), "out": out, "pre": 0, "mean": 0.,
+                "scale": 1., "default_max": bool(default_max), "post_div": float(post_div), "clamp": clamp,
                 "sign": float(sign), "want_minmax": bool(want_minmax), "post": post}
 
     def _submit(self, jobs, deform_dict, flip):

@@ -41,21 +41,14 @@ class DeviceDraws:
     across devices is not a goal).  Tests replace ``generator_utils.draws`` with ReplayDraws to feed the reference's own
     recorded draws through the chain (tests/golden/make_golden_gen.py)."""
 
-    def __init__(self):
-        self._seed = None
-        self._offset = 0
-
     def randn(self, shape, device):
-        """N(0,1) field from bfm_randn_philox: seeded by torch's default generator (torch.manual_seed makes a run
-        repeatable), one counter offset per call."""
-        seed = torch.initial_seed()
-        if seed != self._seed:
-            self._seed, self._offset = seed, 0
+        """N(0,1) field from bfm_randn_philox.  Each call takes its 63-bit Philox key from torch's default CPU generator,
+        so torch.manual_seed makes a run repeatable and re-seeding restarts the stream, as with torch.randn."""
+        key = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
         out = torch.empty(list(shape), dtype=torch.float, device=device)
         if out.numel():
-            L.check(L.load().bfm_randn_philox(L.ptr(out), out.numel(), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF),
-                                              C.c_uint64(self._offset), 1.0, L.stream_ptr()), "randn_philox")
-        self._offset += 1
+            L.check(L.load().bfm_randn_philox(L.ptr(out), out.numel(), C.c_uint64(key), C.c_uint64(0), 1.0,
+                                              L.stream_ptr()), "randn_philox")
         return out
 
     def rand(self, n):

@@ -13,6 +13,7 @@ scalar per step; only the solvers and PDE variants the shipped configs use are p
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -285,6 +286,67 @@ class Dopri5Solver:
 
     def integrate(self, t):
         t = [float(v) for v in t]
+        if isinstance(self.func, AdvDiffPDE) and self.y0.dim() == 4 and self.y0.shape[0] == 1 and len(t) >= 2 \
+                and os.environ.get("BFM_ODE_DEVICE", "1") != "0":
+            return self._integrate_device(t)
+        return self._integrate_host(t)
+
+    def _integrate_device(self, t):
+        """The same integration with the controller on the device (bfm_dopri5_advect_*, csrc/synth_ode.hip): the host
+        selects the first step (three read-backs, once), then enqueues steps in chunks and reads one state block per
+        chunk; accept / reject, the clamped next step and the dense outputs never leave the GPU.  Same expressions as
+        the host loop below: same bits up to the last ulp of pow() in the step-size rule."""
+        lib = self.lib
+        func = self.func
+        y0 = self.y0
+        dev = y0.device
+        _, sx, sy, sz = y0.shape
+        n = self.n
+        f0 = func(t[0], y0)
+        dt0 = self._initial_step(t[0], y0, f0)
+        nt = len(t)
+        sol = torch.empty((nt,) + tuple(y0.shape), dtype=y0.dtype, device=dev)
+        sol[0].copy_(y0)
+        ybuf = [y0.clone(), torch.empty_like(y0)]
+        fbuf = [f0, torch.empty_like(f0)]
+        ks = [torch.empty_like(f0) for _ in range(5)]
+        t_out = torch.tensor(t, dtype=torch.float64, device=dev)
+        nstate = lib.bfm_dopri5_advect_state_bytes()
+        state = torch.zeros(nstate, dtype=torch.uint8, device=dev)
+        ws = torch.empty(lib.bfm_dopri5_advect_workspace(sx, sy, sz), dtype=torch.uint8, device=dev)
+        d = L.Dopri5Advect()
+        d.y[0], d.y[1] = ybuf[0].data_ptr(), ybuf[1].data_ptr()
+        d.f[0], d.f[1] = fbuf[0].data_ptr(), fbuf[1].data_ptr()
+        for j in range(5):
+            d.k[j] = ks[j].data_ptr()
+        V = func.V_dict
+        d.Vx, d.Vy, d.Vz = V["Vx"].data_ptr(), V["Vy"].data_ptr(), V["Vz"].data_ptr()
+        d.sx, d.sy, d.sz = sx, sy, sz
+        d.neumann_bc = 1 if func.BC in ("neumann", "cauchy") else 0
+        d.is_f64 = int(self.f64)
+        d.atol, d.rtol = self.atol, self.rtol
+        d.tol_min_dt = 0.2 * self.dt_cfg if 0.1 * self.dt_cfg >= 0.01 else 0.01
+        d.dt_max = 0.1
+        d.safety, d.ifactor, d.dfactor = self.safety, self.ifactor, self.dfactor
+        d.t_out, d.nt, d.sol = t_out.data_ptr(), nt, sol.data_ptr()
+        d.state, d.workspace = state.data_ptr(), ws.data_ptr()
+        L.check(lib.bfm_dopri5_advect_init(C.byref(d), t[0], dt0, L.stream_ptr()), "dopri5_advect_init")
+        # steps needed if every one were as long as allowed; the first chunk covers that, later ones what is left
+        chunk = max(4, min(16, int(math.ceil((t[-1] - t[0]) / d.dt_max)) + 2))
+        while True:
+            L.check(lib.bfm_dopri5_advect_steps(C.byref(d), chunk, L.stream_ptr()), "dopri5_advect_steps")
+            ints = state[40:72].cpu().numpy().view(np.int32)
+            cur, done, next_out, nsteps, naccept, accepted, err = (int(v) for v in ints[:7])
+            if err:
+                raise AssertionError("underflow in dt")
+            if done:
+                break
+            chunk = 8
+        self.nsteps = nsteps
+        func.nfe += 6 * nsteps
+        return sol
+
+    def _integrate_host(self, t):
         y = self.y0
         f = self.func(t[0], y)
         dt = self._initial_step(t[0], y, f)
@@ -322,6 +384,8 @@ class Dopri5Solver:
                     dt_next = 0.1 if dt_next > 0.1 else dt_next
                     interp = (y, y1, ks, dt)
                     y, f, t0s, t1s = y1, f1, t1s, t1s + dt
+                if os.environ.get("BFM_ODE_TRACE"):
+                    print("host", self.nsteps, msr, dt, dt_next, t1s)
                 dt = dt_next
                 self.nsteps += 1
             sol.append(self._dense(interp, t0s, t1s, ti))

@@ -644,6 +644,27 @@ int bfm_sample_finalize(const float* I, const float* high_res, int sx, int sy, i
 /* elementwise with the scalar in device memory: op 0: x / s, op 1: x >= a * s ? 1 : 0 (fp32). */
 int bfm_ew_dev(int op, const float* x, int64_t n, const double* scalar_dev, float a, float* out, bfm_stream_t stream);
 
+/* Dormand-Prince integration of AdvDiffPDE ('adv', div-free V) with the step controller on the device
+ * (ShapeID/DiffEqs/dopri5.py:58-172, rk_common.py:22-61, misc.py:145-170, interp.py:5-65, pde.py:616-640): one kernel per
+ * stage (stage state evaluated at the stencil points from y and the k_j, never stored), error norm, accept / reject with
+ * the reference's forced-accept clamps, next step size and the dense outputs at t_out all computed from / into `state`
+ * (device, bfm_dopri5_advect_state_bytes()).  The host calls _init, copies y0 into y[0] and sol[0], f(t0, y0) into f[0],
+ * then enqueues steps in chunks with _steps and reads the state block back between chunks: its int fields at byte offset
+ * 40 are {cur, done, next_out, nsteps, naccept, accepted, err}; steps enqueued past the end do nothing.  y / sol are in
+ * the state dtype (fp64 or fp32), stages fp32.  workspace: bfm_dopri5_advect_workspace(sx, sy, sz) bytes. */
+typedef struct {
+    void* y[2]; float* f[2]; float* k[5];
+    const float *Vx, *Vy, *Vz;
+    int sx, sy, sz, neumann_bc, is_f64;
+    double atol, rtol, tol_min_dt, dt_max, safety, ifactor, dfactor;
+    const double* t_out /*device [nt]*/; int nt; void* sol /*[nt][n]*/;
+    void* state; void* workspace;
+} bfm_dopri5_advect_t;
+size_t bfm_dopri5_advect_state_bytes(void);
+size_t bfm_dopri5_advect_workspace(int sx, int sy, int sz);
+int bfm_dopri5_advect_init(const bfm_dopri5_advect_t* d, double t0, double dt0, bfm_stream_t stream);
+int bfm_dopri5_advect_steps(const bfm_dopri5_advect_t* d, int nsteps, bfm_stream_t stream);
+
 /* ---- backward pass of the SingleConv block and its neighbours (first correct version) -------------------
  * The reference trains through torch autograd over buildingblocks.py:31-60 (GroupNorm -> Conv3d -> LeakyReLU),
  * :185-186 (MaxPool3d(2)), :265-276,361-363 (nearest upsample + concat).
