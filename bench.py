@@ -189,6 +189,125 @@ def label_parity(sess, tile, ref, sd):
     return res
 
 
+def synthesis_block(dev, items=8):
+    """Hot path B (BASELINE.json north_star: the data-synthesis kernels; SURVEY config 5's generator half) on the bench
+    line: one BrainIDGen.__getitem__ counterpart -- 192^3 Voronoi label case, 4 augmented 160^3 samples, pathology on --
+    timed per item with a device synchronisation after each (median over `items`), and the streaming kernels of that
+    item timed alone at 160^3 inside replayed hipGraphs (20 launches per replay, HIP events around the replay on the
+    launch stream), each against its own algorithmic bytes and the 8 TB/s HBM peak."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import config5_lib as C5
+    from brainfm_amd import _lib as L
+    from brainfm_amd import generator as G
+    from brainfm_amd import generator_utils as GU
+    from brainfm_amd import shapeid as SH
+    N = 160
+    nv = N ** 3
+    st_np, st_t = np.random.get_state(), torch.random.get_rng_state()
+    np.random.seed(100)
+    torch.manual_seed(100)
+    ga = C5.gen_args(N)
+    ds = G.build_datasets(ga, str(dev), cases=[C5.voronoi_case(7)])["all"]
+    for _ in range(2):
+        ds[0]
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(items):
+        t0 = time.perf_counter()
+        ds[0]
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    item = float(np.median(ts))
+    ns = ga.generator.all_samples
+
+    def timed(fn, launches=20, replays=5):
+        fn()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            for _ in range(launches):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(replays):
+            g.replay()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / (launches * replays) * 1e3          # us per launch
+
+    vol = torch.rand(N, N, N, device=dev)
+    src = torch.rand(192, 192, 192, device=dev)
+    ax = torch.arange(N, device=dev, dtype=torch.float32)
+    zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
+    si, sj, sk = (zz * 1.1 + 5 + 0.3 * torch.sin(yy / 9)).contiguous(), (yy * 1.1 + 6).contiguous(), (xx * 1.1 + 4).contiguous()
+    small = torch.rand(6, 6, 6, 3, device=dev)
+    bfs = torch.rand(5, 5, 5, device=dev)
+    kern = {}
+    kern["interp_linear (fast_3D_interp_torch, 192^3 -> 160^3)"] = (timed(lambda: GU.fast_3D_interp_torch(src, si, sj, sk)), nv * 20)
+    kern["zoom_linear (myzoom_torch 6^3x3 -> 160^3x3)"] = (timed(lambda: GU.myzoom_torch(small, N / 6.0)), nv * 12)
+    kern["zoom_linear (bias field 5^3 -> 160^3)"] = (timed(lambda: GU.myzoom_torch(bfs, N / 5.0)), nv * 4)
+    kern["conv1d_axis x3 (gaussian_blur_3d sigma 1.5)"] = (timed(lambda: GU.gaussian_blur_3d(vol, [1.5, 1.5, 1.5], dev)), nv * 24)
+    kern["ew_unary gamma"] = (timed(lambda: GU.ew_unary(L.EW_GAMMA, vol, 300.0, 1.1)), nv * 8)
+    kern["ew_binary mul_exp (bias field)"] = (timed(lambda: GU.ew_binary(L.EW_MUL_EXP, vol, vol)), nv * 12)
+    kern["reduce max (partial + fold)"] = (timed(lambda: GU.reduce_dev(1, vol)), nv * 4)
+    kern["randn_philox"] = (timed(lambda: GU.draws.randn((N, N, N), dev)), nv * 4)
+    np.random.seed(0)
+    grads = SH.perlin_gradients((2, 2, 2), (True, False, False))
+    gdev = torch.from_numpy(np.ascontiguousarray(grads, dtype=np.float64)).to(dev)
+    noise = torch.empty((N, N, N), dtype=torch.float64, device=dev)
+    lib = L.load()
+    kern["perlin3d (fp64 out)"] = (timed(lambda: L.check(lib.bfm_perlin3d(L.ptr(gdev), N, N, N, 2, 2, 2, L.ptr(noise),
+                                                                          L.stream_ptr()), "perlin3d")), nv * 8)
+    kern["percentile_f64 (radix select, 14 launches)"] = (timed(lambda: SH.percentile_dev(noise, 91.0), launches=5), nv * 8 * 7)
+    table = {k: {"us": round(us, 2), "algorithmic_MB": b / 1e6, "TB_per_s": round(b / us / 1e6, 3),
+                 "frac_of_8TBs": round(b / us / 1e6 / 8.0, 4)} for k, (us, b) in kern.items()}
+    # the pathology shape augmentation alone (Generator/utils.py:542-560), longest case nt = max_nt
+    t = torch.from_numpy(np.arange(10) * 0.1)
+    pde = SH.AdvDiffPDE(data_spacing=[1., 1., 1.], perf_pattern="adv", V_type="vector_div_free", V_dict={}, BC="neumann",
+                        dt=0.1, device=dev)
+    _, P0 = SH.generate_shape_3d((N, N, N), [2, 2, 2], 90.0, dev)
+    shp_args = ga.pathology_shape_generator
+    orig_randint = np.random.randint
+    np.random.randint = lambda a, b=None: shp_args.max_nt
+    try:
+        ode = []
+        for r in range(4):
+            np.random.seed(10 + r)
+            pde.nfe = 0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            GU.augment_pathology(P0, pde, t, shp_args, dev)
+            torch.cuda.synchronize()
+            if r:
+                ode.append((time.perf_counter() - t0, (pde.nfe - 2) // 6))
+    finally:
+        np.random.randint = orig_randint
+    ode_ms = float(np.median([o[0] for o in ode])) * 1e3
+    ode_steps = int(np.median([o[1] for o in ode]))
+    ode_bytes = ode_steps * (6 * (8 + 12 + 4) + 4 * 21 + 8) * nv          # per step: y (fp64) + V + k out per stage, the k_j
+    np.random.set_state(st_np)
+    torch.random.set_rng_state(st_t)
+    worst = min(table, key=lambda k: table[k]["frac_of_8TBs"])
+    return {"workload": "BrainIDGen.__getitem__ counterpart: 192^3 Voronoi label case resident in HBM -> deformation, "
+                        "8 float targets + one-hot segmentation + Perlin pathology, %d augmented %d^3 samples" % (ns, N),
+            "item_ms_median": item * 1e3, "item_ms_min": min(ts) * 1e3, "items_per_s": 1.0 / item,
+            "generated_voxels_per_s": ns * nv / item, "samples_per_item": ns,
+            "host_syncs_per_item": 2 + ns, "round3_item_ms": 168.0,
+            "kernels_160": table, "lowest_frac_kernel": worst,
+            "augment_pathology_160": {"ms_median": ode_ms, "steps": ode_steps, "nt": int(shp_args.max_nt),
+                                      "algorithmic_GB": ode_bytes / 1e9,
+                                      "TB_per_s": ode_bytes / ode_ms / 1e9, "frac_of_8TBs": ode_bytes / ode_ms / 1e9 / 8.0,
+                                      "note": "dopri5 over the upwind advection PDE, step controller on the device; per "
+                                              "step and voxel: 6 stages x (fp64 state 8 B + 3 velocities 12 B + k out 4 B) "
+                                              "+ the 21 reads of earlier k_j (4 B) + y1 out 8 B"},
+            "note": "kernel times: 20 launches captured in a hipGraph, replayed 5x inside one HIP event pair on the launch "
+                    "stream; algorithmic bytes per SURVEY 8(d) (coordinates + one touch of the source + output; fp64 "
+                    "where the reference computes in fp64)"}
+
+
 def launch_ranks(n, argv):
     """--gpus N without a launcher: one child per device, started before this process makes any GPU call (a process
     that has initialised the GPU must not be replaced or forked into ranks).  Relays rank 0's JSON line."""
@@ -251,6 +370,7 @@ def main():
                     help="run the multi-GPU code path (pack, RCCL gather, root accumulation) even with one rank")
     ap.add_argument("--no-dense-check", action="store_true", help="skip the extra steps on a volume without zeros")
     ap.add_argument("--no-graphs", action="store_true", help="submit every kernel from python instead of hipGraph replay")
+    ap.add_argument("--no-synthesis", action="store_true", help="skip the synthesis block (hot path B) of the line")
     ap.add_argument("--roofline-reps", type=int, default=3,
                     help="back-to-back launches per HIP-event bracket in the instrumented conv pass")
     args = ap.parse_args()
@@ -625,6 +745,12 @@ def main():
                                  "box's result to its class mates (HBM-bound); with N > 1 ranks a kernel's time is the "
                                  "slowest rank's, FLOPs and launches are summed over the ranks" % (args.roofline_reps, args.passes)},
         }
+        line["synthesis"] = None
+        if not args.no_synthesis and world == 1:
+            try:
+                line["synthesis"] = synthesis_block(dev)
+            except Exception as e:                            # noqa: BLE001 -- never lose the headline line to the extra block
+                line["synthesis"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             sd = {k: v for k, v in sess.model.state_dict().items()}
             line["cpu_baseline"] = cpu_baseline(sd, full, n, ranges, not args.cpu_baseline_quick, sess)

@@ -36,6 +36,42 @@ __device__ __forceinline__ uint32_t ld_tex(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// C == 1: the two z-neighbours of every corner pair come with ONE 8-byte load (sc1 through a buffer descriptor, whose
+// range check covers the read one past a clamped upper corner); same values, same arithmetic, half the L2 requests
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+__global__ void interp_linear1(const float* __restrict__ X, int nx, int ny, int nz, uint32_t vol_bytes,
+                               const float* __restrict__ II, const float* __restrict__ JJ,
+                               const float* __restrict__ KK, int64_t n, float defv, float* __restrict__ out) {
+    const __amdgpu_buffer_rsrc_t R = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X), 0, vol_bytes, 0x00020000);
+    GRID_STRIDE(i, n) {
+        const float x = II[i], y = JJ[i], z = KK[i];
+        const bool ok = (x > 0.f) && (y > 0.f) && (z > 0.f) && (x <= (float)(nx - 1)) && (y <= (float)(ny - 1)) &&
+                        (z <= (float)(nz - 1));
+        if (!ok) { out[i] = defv; continue; }
+        const float fxf = floorf(x), fyf = floorf(y), fzf = floorf(z);
+        const int fx = (int)fxf, fy = (int)fyf, fz = (int)fzf;
+        const int cx = min(fx + 1, nx - 1), cy = min(fy + 1, ny - 1), cz = min(fz + 1, nz - 1);
+        const float wcx = x - fxf, wcy = y - fyf, wcz = z - fzf;
+        const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
+        const int64_t sx = (int64_t)ny * nz, sy = nz;
+        const bool zp = cz != fz;
+        auto pair = [&](int a, int b, float& lo, float& hi) {
+            const v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(R, (uint32_t)((a * sx + b * sy + fz) << 2), 0, 16);
+            lo = __int_as_float(v.x);
+            hi = zp ? __int_as_float(v.y) : lo;
+        };
+        float t000, t001, t100, t101, t010, t011, t110, t111;
+        pair(fx, fy, t000, t001); pair(cx, fy, t100, t101); pair(fx, cy, t010, t011); pair(cx, cy, t110, t111);
+        const float c00 = t000 * wfx + t100 * wcx;
+        const float c01 = t001 * wfx + t101 * wcx;
+        const float c10 = t010 * wfx + t110 * wcx;
+        const float c11 = t011 * wfx + t111 * wcx;
+        const float c0 = c00 * wfy + c10 * wcy;
+        const float c1 = c01 * wfy + c11 * wcy;
+        out[i] = c0 * wfz + c1 * wcz;
+    }
+}
+
 __global__ void interp_linear(const float* __restrict__ X, int nx, int ny, int nz, int C,
                               const float* __restrict__ II, const float* __restrict__ JJ,
                               const float* __restrict__ KK, int64_t n, float defv, float* __restrict__ out) {
@@ -146,10 +182,46 @@ struct ZoomTabs {
     const float *wfx, *wcx, *wfy, *wcy, *wfz, *wcz;
 };
 
-// one wave per output (x, y) row, lanes along (z, channel): the row's x / y table entries are wave-uniform and the only
-// divisions left are 32-bit ones by C (round 3: three 64-bit div / mod pairs per element, 59 us for 160^3 x 3)
+// One wave per output (x, y) row.  The x and y passes of the row depend on the source z only:
+//   B[zs] = wfy * (wfx * X[fx,fy,zs] + wcx * X[cx,fy,zs]) + wcy * (wfx * X[fx,cy,zs] + wcx * X[cx,cy,zs])
+// is formed once per source position in the wave's LDS row, and every output is wfz * B[fz] + wcz * B[cz] -- the
+// reference's pass order (x, y, z) and expressions, so the same bits as the per-output form, with 4 global loads per
+// SOURCE element instead of 8 per OUTPUT element (upsampling 6^3 -> 160^3: 36 -> 12 us for three channels).
+constexpr int ZOOM_ROW = 1024;                                  // source row (nz * C floats) that fits the wave's LDS slot
 __global__ void __launch_bounds__(256) zoom_linear(const float* __restrict__ X, int nx, int ny, int nz, int C, ZoomTabs t,
                                                    int ox, int oy, int oz, float* __restrict__ out) {
+    __shared__ float sB[4][ZOOM_ROW];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rows = ox * oy, rowlen = oz * C, srclen = nz * C;
+    const int64_t sx = (int64_t)ny * nz * C, sy = (int64_t)nz * C;
+    float* B = sB[w];
+    for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
+        const int ii = r / oy, j = r - ii * oy;
+        const int fx = t.fx[ii], cx = t.cx[ii], fy = t.fy[j], cy = t.cy[j];
+        const float wfx = t.wfx[ii], wcx = t.wcx[ii], wfy = t.wfy[j], wcy = t.wcy[j];
+        const float* p00 = X + fx * sx + fy * sy;
+        const float* p10 = X + cx * sx + fy * sy;
+        const float* p01 = X + fx * sx + cy * sy;
+        const float* p11 = X + cx * sx + cy * sy;
+        for (int e = lane; e < srclen; e += 64) {
+            const float a0 = wfx * p00[e] + wcx * p10[e];
+            const float a1 = wfx * p01[e] + wcx * p11[e];
+            B[e] = wfy * a0 + wcy * a1;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): the wave's own LDS writes have landed
+        float* o = out + (int64_t)r * rowlen;
+        for (int e = lane; e < rowlen; e += 64) {
+            const int k = C == 1 ? e : e / C, c = C == 1 ? 0 : e - k * C;
+            o[e] = t.wfz[k] * B[t.fz[k] * C + c] + t.wcz[k] * B[t.cz[k] * C + c];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// the same for source rows longer than the LDS slot: per output element
+__global__ void __launch_bounds__(256) zoom_linear_long(const float* __restrict__ X, int nx, int ny, int nz, int C,
+                                                        ZoomTabs t, int ox, int oy, int oz, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int rows = ox * oy, rowlen = oz * C;
     const int64_t sx = (int64_t)ny * nz * C, sy = (int64_t)nz * C;
@@ -166,7 +238,6 @@ __global__ void __launch_bounds__(256) zoom_linear(const float* __restrict__ X, 
             const int k = C == 1 ? e : e / C, c = C == 1 ? 0 : e - k * C;
             const int fz = t.fz[k] * C + c, cz = t.cz[k] * C + c;
             const float wfz = t.wfz[k], wcz = t.wcz[k];
-            // pass order of the reference: x, then y, then z
             const float a00 = wfx * p00[fz] + wcx * p10[fz];
             const float a10 = wfx * p01[fz] + wcx * p11[fz];
             const float a01 = wfx * p00[cz] + wcx * p10[cz];
@@ -190,13 +261,33 @@ __global__ void __launch_bounds__(256) conv1d_axis(const float* __restrict__ in,
     for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
         const int x = r / ny, y = r - x * ny;
         const int64_t base = (int64_t)r * nz;
-        for (int z = lane; z < nz; z += 64) {
-            const int pos = axis == 0 ? x : (axis == 1 ? y : z);
+        if (axis != 2) {
+            // the tap range is the row's: wave-uniform loop, taps through the scalar cache
+            const int pos = axis == 0 ? x : y;
             const int j0 = max(0, half - pos), j1 = min(klen, len + half - pos);       // taps inside the volume
-            const float* p = in + base + z + (int64_t)(j0 - half) * stride;
-            float acc = 0.f;
-            for (int j = j0; j < j1; ++j, p += stride) acc = fmaf(kern[j], *p, acc);
-            out[base + z] = acc;
+            for (int z = lane; z < nz; z += 64) {
+                const float* p = in + base + z + (int64_t)(j0 - half) * stride;
+                float acc = 0.f;
+                for (int j = j0; j < j1; ++j, p += stride) acc = fmaf(kern[j], *p, acc);
+                out[base + z] = acc;
+            }
+        } else {
+            for (int z0 = 0; z0 < nz; z0 += 64) {
+                const int z = z0 + lane;
+                const bool interior = z0 >= half && z0 + 63 + half < nz;              // all 64 lanes take every tap
+                if (interior) {
+                    const float* p = in + base + z - half;
+                    float acc = 0.f;
+                    for (int j = 0; j < klen; ++j) acc = fmaf(kern[j], p[j], acc);
+                    out[base + z] = acc;
+                } else if (z < nz) {
+                    const int j0 = max(0, half - z), j1 = min(klen, nz + half - z);
+                    const float* p = in + base + z - half;
+                    float acc = 0.f;
+                    for (int j = j0; j < j1; ++j) acc = fmaf(kern[j], p[j], acc);
+                    out[base + z] = acc;
+                }
+            }
         }
     }
 }
@@ -518,8 +609,13 @@ __global__ void onehot_lut(const int32_t* __restrict__ S, const int32_t* __restr
 extern "C" int bfm_interp3d_linear(const float* X, int nx, int ny, int nz, int C, const float* II, const float* JJ,
                                    const float* KK, int64_t n, float default_value, float* out, bfm_stream_t stream) {
     if (!X || !II || !JJ || !KK || !out || nx <= 0 || ny <= 0 || nz <= 0 || C <= 0 || n <= 0) return BFM_E_ARG;
-    hipLaunchKernelGGL(interp_linear, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), X, nx, ny, nz, C, II, JJ, KK, n,
-                       default_value, out);
+    const int64_t vbytes = (int64_t)nx * ny * nz * 4;
+    if (C == 1 && vbytes < ((int64_t)1 << 32))
+        hipLaunchKernelGGL(interp_linear1, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), X, nx, ny, nz, (uint32_t)vbytes,
+                           II, JJ, KK, n, default_value, out);
+    else
+        hipLaunchKernelGGL(interp_linear, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), X, nx, ny, nz, C, II, JJ, KK, n,
+                           default_value, out);
     return bfm_launch_status();
 }
 
@@ -570,8 +666,12 @@ extern "C" int bfm_zoom_linear(const float* X, int nx, int ny, int nz, int C, co
     ZoomTabs t{ax[0].f, ax[0].c, ax[1].f, ax[1].c, ax[2].f, ax[2].c, ax[0].wf, ax[0].wc, ax[1].wf, ax[1].wc,
                ax[2].wf, ax[2].wc};
     if ((int64_t)ox * oy > INT32_MAX || (int64_t)oz * C > INT32_MAX) return BFM_E_SHAPE;
-    hipLaunchKernelGGL(zoom_linear, dim3(grid_for((int64_t)ox * oy, 4)), dim3(256), 0, bfm_s(stream), X, nx, ny, nz, C, t,
-                       ox, oy, oz, out);
+    if ((int64_t)nz * C <= ZOOM_ROW)
+        hipLaunchKernelGGL(zoom_linear, dim3(grid_for((int64_t)ox * oy, 4)), dim3(256), 0, bfm_s(stream), X, nx, ny, nz, C,
+                           t, ox, oy, oz, out);
+    else
+        hipLaunchKernelGGL(zoom_linear_long, dim3(grid_for((int64_t)ox * oy, 4)), dim3(256), 0, bfm_s(stream), X, nx, ny,
+                           nz, C, t, ox, oy, oz, out);
     return bfm_launch_status();
 }
 

@@ -31,6 +31,19 @@ __device__ __forceinline__ int32_t ld_tex(const int32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The two z-neighbours of a trilinear sample sit side by side in memory: ONE 8-byte load, still past the L1 (aux 16 =
+// sc1, agent scope), through a buffer descriptor whose range check makes the one-past-the-end read of a clamped upper
+// corner harmless (it returns 0 and the value is not used).  Halves the L2 requests of the gathers.
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tex_rsrc(const float* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void ld_tex2(__amdgpu_buffer_rsrc_t r, int64_t elem, bool second_distinct, float& a, float& b) {
+    const v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(r, (uint32_t)(elem << 2), 0, 16);
+    a = __int_as_float(v.x);
+    b = second_distinct ? __int_as_float(v.y) : a;
+}
+
 __device__ __forceinline__ float nan_to_num(float x) {
     return x != x ? 0.f : (x == INFINITY ? 3.402823466e+38f : (x == -INFINITY ? -3.402823466e+38f : x));
 }
@@ -215,9 +228,10 @@ __global__ void box_max_fold(GJobs J, const float* __restrict__ part, int nb, do
 
 // out_j[i] = post_j(trilinear(pre_j(src_j)) at the crop-space coordinate (II,JJ,KK)[i]); fast_3D_interp_torch's validity
 // test and corner clamps are taken in CROP space (Generator/utils.py:140-192 on the cropped array)
-__global__ void gather_targets(GJobs J, int ny, int nz, Box B, const float* __restrict__ II,
+__global__ void gather_targets(GJobs J, int ny, int nz, Box B, uint32_t vol_bytes, const float* __restrict__ II,
                                const float* __restrict__ JJ, const float* __restrict__ KK, int64_t n, int sx,
                                int64_t syz, int flip, const double* __restrict__ scal, float* __restrict__ part) {
+    const bool paired = vol_bytes != 0;                           // volumes of 4 GB and more: single loads
     float smin[GJ_MAX], smax[GJ_MAX];
 #pragma unroll
     for (int j = 0; j < GJ_MAX; ++j) { smin[j] = INFINITY; smax[j] = -INFINITY; }
@@ -232,6 +246,7 @@ __global__ void gather_targets(GJobs J, int ny, int nz, Box B, const float* __re
         }
         int64_t o000 = 0, o100 = 0, o010 = 0, o110 = 0, o001 = 0, o101 = 0, o011 = 0, o111 = 0;
         float wcx = 0.f, wcy = 0.f, wcz = 0.f, wfx = 0.f, wfy = 0.f, wfz = 0.f;
+        bool zpair = false;
         if (ok) {
             const float fxf = floorf(x), fyf = floorf(y), fzf = floorf(z);
             const int fx = (int)fxf, fy = (int)fyf, fz = (int)fzf;
@@ -244,6 +259,7 @@ __global__ void gather_targets(GJobs J, int ny, int nz, Box B, const float* __re
             const int64_t az = B.z1 + fz, bz = B.z1 + cz;
             o000 = ax + ay + az; o100 = bx + ay + az; o010 = ax + by + az; o110 = bx + by + az;
             o001 = ax + ay + bz; o101 = bx + ay + bz; o011 = ax + by + bz; o111 = bx + by + bz;
+            zpair = cz != fz;
         }
 #pragma unroll
         for (int j = 0; j < GJ_MAX; ++j) {
@@ -252,10 +268,19 @@ __global__ void gather_targets(GJobs J, int ny, int nz, Box B, const float* __re
             float r;
             if (ok) {
                 const float* X = jb.src;
-                const float c00 = pre_op(ld_tex(X + o000), jb) * wfx + pre_op(ld_tex(X + o100), jb) * wcx;
-                const float c01 = pre_op(ld_tex(X + o001), jb) * wfx + pre_op(ld_tex(X + o101), jb) * wcx;
-                const float c10 = pre_op(ld_tex(X + o010), jb) * wfx + pre_op(ld_tex(X + o110), jb) * wcx;
-                const float c11 = pre_op(ld_tex(X + o011), jb) * wfx + pre_op(ld_tex(X + o111), jb) * wcx;
+                float t000, t001, t100, t101, t010, t011, t110, t111;
+                if (paired) {
+                    const __amdgpu_buffer_rsrc_t R = tex_rsrc(X, vol_bytes);
+                    ld_tex2(R, o000, zpair, t000, t001); ld_tex2(R, o100, zpair, t100, t101);
+                    ld_tex2(R, o010, zpair, t010, t011); ld_tex2(R, o110, zpair, t110, t111);
+                } else {
+                    t000 = ld_tex(X + o000); t001 = ld_tex(X + o001); t100 = ld_tex(X + o100); t101 = ld_tex(X + o101);
+                    t010 = ld_tex(X + o010); t011 = ld_tex(X + o011); t110 = ld_tex(X + o110); t111 = ld_tex(X + o111);
+                }
+                const float c00 = pre_op(t000, jb) * wfx + pre_op(t100, jb) * wcx;
+                const float c01 = pre_op(t001, jb) * wfx + pre_op(t101, jb) * wcx;
+                const float c10 = pre_op(t010, jb) * wfx + pre_op(t110, jb) * wcx;
+                const float c11 = pre_op(t011, jb) * wfx + pre_op(t111, jb) * wcx;
                 const float c0 = c00 * wfy + c10 * wcy;
                 const float c1 = c01 * wfy + c11 * wcy;
                 r = c0 * wfz + c1 * wcz;
@@ -568,7 +593,7 @@ __global__ void pathology_encode_dev(const float* __restrict__ I, const T* __res
 // ------------------------------------------------------------------ separable-coordinate trilinear sample
 __global__ void interp_linear_axes(const float* __restrict__ X, int nx, int ny, int nz, const float* __restrict__ ax,
                                    const float* __restrict__ ay, const float* __restrict__ az, int ox, int oy, int oz,
-                                   float defv, float* __restrict__ out) {
+                                   float defv, uint32_t vol_bytes, float* __restrict__ out) {
     const int64_t n = (int64_t)ox * oy * oz;
     GRID_STRIDE(i, n) {
         const int k = (int)(i % oz);
@@ -584,11 +609,21 @@ __global__ void interp_linear_axes(const float* __restrict__ X, int nx, int ny, 
         const float wcx = x - fxf, wcy = y - fyf, wcz = z - fzf;
         const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
         const int64_t sx = (int64_t)ny * nz, sy = nz;
-        auto at = [&](int a, int b, int c) { return ld_tex(X + a * sx + b * sy + c); };
-        const float c00 = at(fx, fy, fz) * wfx + at(cx, fy, fz) * wcx;
-        const float c01 = at(fx, fy, cz) * wfx + at(cx, fy, cz) * wcx;
-        const float c10 = at(fx, cy, fz) * wfx + at(cx, cy, fz) * wcx;
-        const float c11 = at(fx, cy, cz) * wfx + at(cx, cy, cz) * wcx;
+        float t000, t001, t100, t101, t010, t011, t110, t111;
+        if (vol_bytes) {
+            const __amdgpu_buffer_rsrc_t R = tex_rsrc(X, vol_bytes);
+            const bool zp = cz != fz;
+            ld_tex2(R, fx * sx + fy * sy + fz, zp, t000, t001); ld_tex2(R, cx * sx + fy * sy + fz, zp, t100, t101);
+            ld_tex2(R, fx * sx + cy * sy + fz, zp, t010, t011); ld_tex2(R, cx * sx + cy * sy + fz, zp, t110, t111);
+        } else {
+            auto at = [&](int a, int b, int c) { return ld_tex(X + a * sx + b * sy + c); };
+            t000 = at(fx, fy, fz); t001 = at(fx, fy, cz); t100 = at(cx, fy, fz); t101 = at(cx, fy, cz);
+            t010 = at(fx, cy, fz); t011 = at(fx, cy, cz); t110 = at(cx, cy, fz); t111 = at(cx, cy, cz);
+        }
+        const float c00 = t000 * wfx + t100 * wcx;
+        const float c01 = t001 * wfx + t101 * wcx;
+        const float c10 = t010 * wfx + t110 * wcx;
+        const float c11 = t011 * wfx + t111 * wcx;
         const float c0 = c00 * wfy + c10 * wcy;
         const float c1 = c01 * wfy + c11 * wcy;
         out[i] = c0 * wfz + c1 * wcz;
@@ -735,7 +770,9 @@ extern "C" int bfm_gather_targets(const bfm_gather_job_t* jobs, int njobs, int n
     }
     const int64_t n = (int64_t)sx * sy * sz;
     const int nb = grid_for(n, 256, GT_BLOCKS);
-    hipLaunchKernelGGL(gather_targets, dim3(nb), dim3(256), 0, st, J, ny, nz, B, II, JJ, KK, n, sx, (int64_t)sy * sz,
+    const int64_t vbytes = (int64_t)nx * ny * nz * 4;
+    hipLaunchKernelGGL(gather_targets, dim3(nb), dim3(256), 0, st, J, ny, nz, B,
+                       (uint32_t)(vbytes < ((int64_t)1 << 32) ? vbytes : 0), II, JJ, KK, n, sx, (int64_t)sy * sz,
                        flip0 ? 1 : 0, scalars, part_st);
     if (any_stat) hipLaunchKernelGGL(gather_stat_fold, dim3(njobs), dim3(64), 0, st, J, part_st, nb, scalars);
     return bfm_launch_status();
@@ -869,8 +906,9 @@ extern "C" int bfm_interp3d_linear_axes(const float* X, int nx, int ny, int nz, 
                                         const float* az, int ox, int oy, int oz, float default_value, float* out,
                                         bfm_stream_t stream) {
     if (!X || !ax || !ay || !az || !out || nx <= 0 || ny <= 0 || nz <= 0 || ox <= 0 || oy <= 0 || oz <= 0) return BFM_E_ARG;
+    const int64_t vbytes = (int64_t)nx * ny * nz * 4;
     hipLaunchKernelGGL(interp_linear_axes, dim3(grid_for((int64_t)ox * oy * oz)), dim3(256), 0, bfm_s(stream), X, nx, ny,
-                       nz, ax, ay, az, ox, oy, oz, default_value, out);
+                       nz, ax, ay, az, ox, oy, oz, default_value, (uint32_t)(vbytes < ((int64_t)1 << 32) ? vbytes : 0), out);
     return bfm_launch_status();
 }
 

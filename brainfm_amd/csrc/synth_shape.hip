@@ -36,11 +36,14 @@ __global__ void __launch_bounds__(256) perlin3d(const double* __restrict__ grad,
     for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
         const int x = r / sy, y = r - x * sy;
         // grid = (mgrid = index*delta) % 1 ; lattice cell = index // d  (NumPy semantics, fp64)
-        const double fx = fmod((double)x * dx, 1.0), fy = fmod((double)y * dy, 1.0);
+        // v % 1 for v >= 0 is v - floor(v), exactly (np.mod and fmod agree there); fmod() itself is a long software routine
+        const double vx = (double)x * dx, vy = (double)y * dy;
+        const double fx = vx - floor(vx), fy = vy - floor(vy);
         const int ix = x / cx, iy = y / cy;
         const double t0 = fade(fx), t1 = fade(fy);
         for (int z = lane; z < sz; z += 64) {
-            const double fz = fmod((double)z * dz, 1.0);
+            const double vz = (double)z * dz;
+            const double fz = vz - floor(vz);
             const int iz = z / cz;
             auto G = [&](int a, int b, int c) { return grad + ((int64_t)((ix + a) * gy + (iy + b)) * gz + (iz + c)) * 3; };
             auto dot = [&](const double* g, double a, double b, double c) { return (a * g[0] + b * g[1]) + c * g[2]; };
