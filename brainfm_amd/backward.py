@@ -160,10 +160,8 @@ def backward_single_conv(eng, t, dY, need_input_grad=True):
 
         def _launch(c):
             eng._conv_launch(dg, dP, ly.cout, None, 0, t.dims, None, ones, zeros, bnd, 1, c, dXn, ws2, None, slope=1.0)
-        cfg = eng._autotune(dg, key, _launch, vers=(0, 1, 2) if key[3] else (0, 1, 2, 3))   # F(4,3) is an inference choice
-        if cfg[6] == 4:                                         # the shape was tuned by an inference pass of this process
-            cfg = type(cfg)(*list(cfg))
-            cfg[6] = 3
+        # F(4,3) is an inference choice: _autotune hands back a narrowed COPY (variant 3) when the table says 4
+        cfg = eng._autotune(dg, key, _launch, vers=(0, 1, 2) if key[3] else (0, 1, 2, 3))
         _launch(cfg)
         if dg.cout != ly.cin:
             dXn = dXn[..., :ly.cin].contiguous()

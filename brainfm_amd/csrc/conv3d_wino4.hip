@@ -14,8 +14,10 @@
 //
 // The GEMM is 6 "positions" x (M/4 output quads) x K = 9 (kd,kh) taps x Cin: 13.5 tap-rows per output voxel instead
 // of 18 (F(2,3)) or 27 (direct), and 1.5 transformed values per voxel to split and store instead of 2.  The price is
-// rounding: the transforms amplify fp32 rounding ~9x over F(2,3) (7e-6 of max|y| per layer against 8e-7,
-// scripts/micro/wino_f43_accuracy.py); the products keep the split-fp16 three-pass scheme.
+// rounding: measured through the C ABI against a float64 convolution the kernel sits at 1-2.5e-6 of max|y| per layer,
+// about twice F(2,3)'s 1e-6 (tests/test_gpu_infer.py::test_winograd_f43_kernel_vs_float64_convolution; the 7e-6 of the
+// first NumPy model, scripts/micro/wino_f43_accuracy.py, was pessimistic); the products keep the split-fp16 three-pass
+// scheme.
 //
 // Workgroup = 4 waves for one box of 256 output voxels (64 quads = two 32-row blocks per position) x 64 couts.  Six
 // positions do not divide over four SIMDs as waves (a 6-wave workgroup sits 2,2,1,1 on the SIMDs and a second one does
@@ -24,7 +26,8 @@
 // per wave, 96 accumulator registers, two positions' weights streamed L2 -> VGPR one tap ahead.  The transformed, split
 // halo'd box lives in LDS ([pos][k-half][hi|lo][row][quad][8 ch], 55 KB); epilogue: the six m_p meet in LDS, one thread
 // per (quad, cout) forms y0..y3, dequantises, optionally adds what `out` holds (accumulate mode), applies LeakyReLU and
-// stores.  Single-source inputs only, no split-K, dense boxes only (the sparse forms stay with F(2,3)).
+// stores.  Single-source inputs only, no split-K; the dense form and the masked form over the boxes the tile mask keeps
+// (conv_wino4_masked, the tile loop's last convolution); the uniform-box pair stays with F(2,3) (engine._needs_f23).
 #include "bfm_common.h"
 #include "wino_shared.h"
 #include <cstdlib>

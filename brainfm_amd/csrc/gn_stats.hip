@@ -259,7 +259,7 @@ __device__ __forceinline__ void group_affine(int g, int cpg, int c_first, double
 // acknowledgement, meets, and takes a ticket of ITS GROUP with a relaxed agent-scope add.  The workgroup that draws a
 // group's last ticket reads the group's KS x cpg partials with agent-scope loads, sums them in slice order, and runs
 // group_affine: a few hundred loads in one round, not the megabyte a single finalizing workgroup had to pull in the
-// first attempt (profiles/r03_gn_one_launch_experiment.txt).  No fence, no cache-wide operation; every sum has a fixed
+// first attempt (profiles/r03_gn_one_launch_experiment.txt).  One release / acquire pair per group; every sum has a fixed
 // order (rows of a slice: RP interleaved partial sums combined in order; slices in order), so results do not depend
 // on which workgroup arrives last.  tickets[g] are zero on entry and are left zero.
 constexpr int KS = 16;
@@ -336,12 +336,17 @@ __global__ void __launch_bounds__(TPB) rows_group_finalize(RowsSrc sa, RowsSrc s
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through stores are acknowledged
     __syncthreads();
     if (t == 0) {
-        const int got = __hip_atomic_fetch_add(tickets + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = got == KS - 1;
+        // release: the workgroup's partials (written through and acknowledged above) are ordered before the ticket in the
+        // memory model too, not only by the vmcnt wait; the counter is taken modulo KS so that a ticket left non-zero by
+        // an aborted launch cannot mark the wrong arriver as the last one for ever (it costs that one launch at most,
+        // and the host entry point zeroes the tickets when a launch fails)
+        const int got = __hip_atomic_fetch_add(tickets + g, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (got % KS) == KS - 1;
         if (is_last) __hip_atomic_store(tickets + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all KS have arrived
     }
     __syncthreads();
     if (!is_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // pairs with the other workgroups' release adds
     // ---- the group's last arriver: channel totals = the KS partials in slice order (all loads of a thread in one round)
     for (int cg = t; cg < cpg; cg += TPB) {
         const int c = c_first + cg;
@@ -653,7 +658,9 @@ extern "C" int bfm_gn_stats_rows_train(const void* rowsA, int nrowsA, int CA, co
                            scale, shift, bound, mean_out, rstd_out, reinterpret_cast<double*>(ws),
                            reinterpret_cast<double*>(ws + n * 8), reinterpret_cast<float*>(ws + n * 16),
                            reinterpret_cast<float*>(ws + n * 20), static_cast<int*>(ticket));
-        return bfm_launch_status();
+        const int rc = bfm_launch_status();
+        if (rc != BFM_OK) (void)hipMemsetAsync(ticket, 0, (size_t)G * sizeof(int), st);    // never leave a partial count behind
+        return rc;
     }
     PartTab ta = rows_source(rowsA, nrowsA, CA, 1.0, ws, st);
     PartTab tb{nullptr, nullptr, nullptr, nullptr, 0, 0, 1.0};

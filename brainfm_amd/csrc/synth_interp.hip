@@ -646,14 +646,21 @@ extern "C" int bfm_deformed_atlas_tile(const float* tile_in, const float* regx, 
         return BFM_E_ARG;
     Aff34 A;
     for (int i = 0; i < 12; ++i) A.a[i] = A_host[i];
-    static int loads = -1;                                     // diagnostic switch (tests/diag/diag_atlas_flow.py)
-    if (loads < 0) { const char* e = getenv("BFM_ATLAS_PLAIN_LOADS"); loads = e ? atoi(e) : 0; }
 #define BFM_ATLAS_LAUNCH(V) hipLaunchKernelGGL((deformed_atlas<true, V>), dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), \
                                                tile_in, regx, regy, regz, atlas, nx, ny, nz, A, n, out)
+#ifdef BFM_DIAG
+    // diagnostics build only (BFM_HIPCC_EXTRA=-DBFM_DIAG, tests/diag/diag_atlas_flow.py): the load forms that
+    // profiles/r03_atlas_gather_hazard.txt documents as returning wrong texels beside LDS-DMA kernels.  The shipped
+    // library has no switch: a stray environment variable cannot select them.
+    static int loads = -1;
+    if (loads < 0) { const char* e = getenv("BFM_ATLAS_PLAIN_LOADS"); loads = e ? atoi(e) : 0; }
     if (loads == 1) BFM_ATLAS_LAUNCH(1);
     else if (loads == 2) BFM_ATLAS_LAUNCH(2);
     else if (loads == 3) BFM_ATLAS_LAUNCH(3);
     else BFM_ATLAS_LAUNCH(0);
+#else
+    BFM_ATLAS_LAUNCH(0);
+#endif
 #undef BFM_ATLAS_LAUNCH
     return bfm_launch_status();
 }

@@ -387,14 +387,22 @@ class UNetEngine:
                 _TUNE_CHOICES[gkey] = int(saved)
         if gkey in _TUNE_CHOICES and (vers is None or _TUNE_CHOICES[gkey] in vers or (_TUNE_CHOICES[gkey] == 4 and 3 in vers)):
             c = _TUNE_CHOICES[gkey]
-            cfg[6] = c if (vers is None or c in vers) else 3        # a caller that rules F(4,3) out takes F(2,3)
-            self._tuned.add(key)
-            return cfg
+            if vers is None or c in vers:
+                cfg[6] = c
+                self._tuned.add(key)
+                return cfg
+            # a caller that rules F(4,3) out (training, the uniform-box layers) takes F(2,3) on a COPY: the shared plan
+            # keeps the table's choice, so a later inference forward on this engine runs what a fresh process would
+            narrowed = (C.c_int * 8)(*list(cfg))
+            narrowed[6] = 3
+            return narrowed
         best, best_ms = cfg[6], None
         # Winograd (3: F(2,3), 4: F(4,3)) takes single-source layers only.  F(4,3) rounds ~2x coarser than F(2,3): it is
         # timed only when the committed table is being made (BFM_CONV_TUNE=retune, scripts/make_tune_table.py) -- a shape
         # outside the table never gets it from an in-process timing
         single = (0, 1, 2, 3, 4) if os.environ.get("BFM_CONV_TUNE", "1") == "retune" else (0, 1, 2, 3)
+        if hasattr(self, "enc") and self._needs_f23(ly):
+            single = (0, 1, 2, 3)                               # these layers never run F(4,3): do not let it win their entry
         for ver in (vers if vers is not None else ((0, 1, 2) if key[3] else single)):
             trial = (C.c_int * 8)(*list(cfg))
             trial[6] = ver

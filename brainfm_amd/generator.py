@@ -629,7 +629,7 @@ class BaseGen(torch.utils.data.Dataset):
             return True
         return random.choice([True, False])
 
-    def generate_sample(self, name, G, setups, deform_dict, res, target, case=None):
+    def generate_sample(self, name, G, setups, deform_dict, res, target):
         """datasets.py:355-412."""
         [xx2, yy2, zz2] = deform_dict["grid"][:3]
         lib = L.load()
@@ -642,9 +642,7 @@ class BaseGen(torch.utils.data.Dataset):
         SYN0 = SYN                                            # crop space, before the deformation
         SYN = GU.fast_3D_interp_torch(SYN, xx2, yy2, zz2)
         if np.random.rand() < getattr(self.gen_args, "mix_synth_prob", 0.):        # random linear combination, :377-386
-            have = getattr(self, "modalities", None)
-            if have is None:
-                have = case if case is not None else {}
+            have = getattr(self, "modalities", None) or {}
             v = GU.draws.rand(4).clone()
             v[2] = 0 if "T2" not in have else v[2]
             v[3] = 0 if "FLAIR" not in have else v[3]
@@ -749,7 +747,7 @@ class BaseGen(torch.utils.data.Dataset):
         if input_mode == "synth":
             self.update_gen_args(self.synth_image_args)
             target["pathology"], target["pathology_prob"], sample = \
-                self.generate_sample(case_name, img, setups, deform_dict, res, target, case)
+                self.generate_sample(case_name, img, setups, deform_dict, res, target)
         else:
             self.update_gen_args(self.real_image_args)
             sample = self.augment_sample(case_name, img, setups, deform_dict, res, target,
@@ -781,7 +779,7 @@ class BrainIDGen(BaseGen):
             if input_mode == "synth":
                 self.update_gen_args(self.synth_image_args)
                 target["pathology"], target["pathology_prob"], sample = \
-                    self.generate_sample(case_name, img, setups, deform_dict, res, target, case)
+                    self.generate_sample(case_name, img, setups, deform_dict, res, target)
             else:
                 self.update_gen_args(self.real_image_args)
                 sample = self.augment_sample(case_name, img, setups, deform_dict, res, target,

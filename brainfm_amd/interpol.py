@@ -210,10 +210,18 @@ def _prefilter_scalars(n):
     return z, gain, pole_last, init_scale, final_scale, w
 
 
-def spline_coeff_nd(inp, bound="dct2", order=3, dim=3, inplace=False):
-    """utils/interpol/coeff.py:315-344 for cubic splines with DCT-II ('nearest' / 'dct2') conditions, 3-D volumes."""
+_SPLINE_ORDER = {"nearest": 0, "linear": 1, "quadratic": 2, "cubic": 3, "fourth": 4, "fifth": 5, "sixth": 6, "seventh": 7}
+
+
+def spline_coeff_nd(input, interpolation="linear", bound="dct2", dim=None, inplace=False):
+    """utils/interpol/api.py:386-432 -> coeff.py:315-344 for cubic splines with DCT-II ('nearest' / 'dct2') conditions over
+    the last three dimensions (`dim` None or 3); orders 0 / 1 return the input, as the reference does."""
+    inp = input
     if inp.device.type != "cuda":
         raise L.BfmError("spline_coeff_nd runs on a HIP device only")
+    order = interpolation[0] if isinstance(interpolation, (list, tuple)) else interpolation
+    order = _SPLINE_ORDER.get(order.lower(), None) if isinstance(order, str) else int(order)
+    dim = 3 if dim is None else dim
     if order in (0, 1):
         return inp if inplace else inp.clone()
     if order != 3 or dim != 3:
@@ -297,7 +305,7 @@ def resize(image, factor=None, shape=None, anchor="c", interpolation=1, prefilte
     b = _SPLINE_BOUND.get(b.lower() if isinstance(b, str) else b)
     if b is None:
         raise NotImplementedError("resize: cubic path supports 'nearest'/'dct2' bounds")
-    coeff = spline_coeff_nd(image, bound=b, order=3, dim=3) if prefilter else image.to(torch.float32)
+    coeff = spline_coeff_nd(image, interpolation=3, bound=b, dim=3) if prefilter else image.to(torch.float32)
     lead = coeff.shape[:-3]
     vols = coeff.reshape((-1,) + tuple(coeff.shape[-3:])).contiguous()
     lib = L.load()

@@ -12,8 +12,10 @@ unet3d/model.py) so that ``scripts/demo_test.py`` / ``demo_get_feature.py`` /
   processor(outputs, samples) ; postprocessor(gen_args, train_args, outputs, samples, target, feats, tasks)
 
 The nn.Module tree exists to carry parameters under the reference's
-state-dict names (so reference checkpoints load unchanged); its torch
-``forward`` methods are never used.
+state-dict names; its torch ``forward`` methods are never used.  Reference
+checkpoints -- including the Config objects scripts/train.py pickles beside
+the weights -- load unchanged and without executing anything from the file
+(read_checkpoint_file).
 """
 import ctypes as C
 import os
@@ -560,22 +562,83 @@ def load_checkpoint(ckp_path, models, model_keys=["model"], to_print=False):
     return ckp
 
 
+class InertObject(dict):
+    """What a pickled object of a class this package does not know becomes when a checkpoint is read: a dict that keeps
+    the object's items / state for inspection and runs none of its code (the reference stores its own
+    utils.config.Config instances -- dict subclasses -- under 'gen_args' / 'train_args' / 'submit_args',
+    scripts/train.py:206-214; only 'model' and 'optimizer' are needed here)."""
+
+    def __init__(self, *args, **kwargs):                      # REDUCE / NEWOBJ with whatever arguments: ignored
+        dict.__init__(self)
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            dict.update(self, state)
+        else:
+            dict.__setitem__(self, "__state__", state)
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
+
+
+def _restricted_pickle_module():
+    """A pickle-module stand-in for torch.load whose Unpickler resolves only what tensors, storages, NumPy arrays and
+    plain containers need; every other global -- any class or function of the checkpoint's author -- resolves to
+    InertObject, so nothing from the file is executed."""
+    import builtins
+    import pickle
+    import types
+
+    safe_builtins = {"set", "frozenset", "dict", "list", "tuple", "int", "float", "complex", "bool", "str", "bytes",
+                     "bytearray", "slice", "range", "object"}
+    allowed = {("collections", "OrderedDict"), ("collections", "defaultdict"), ("argparse", "Namespace"),
+               ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
+               ("torch.serialization", "_get_layout"),
+               ("numpy", "dtype"), ("numpy", "ndarray"),
+               ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+               ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+               ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer")}
+
+    class Unpickler(pickle.Unpickler):
+        def find_class(self, module, name):
+            if module == "builtins":
+                return getattr(builtins, name) if name in safe_builtins else InertObject
+            ok = (module, name) in allowed \
+                or (module == "torch._utils" and name.startswith("_rebuild_")) \
+                or (module in ("torch", "torch.storage") and name.endswith("Storage")) \
+                or (module == "torch" and isinstance(getattr(torch, name, None), torch.dtype))
+            if ok:
+                return super().find_class(module, name)
+            return InertObject
+
+    mod = types.ModuleType("brainfm_amd_restricted_pickle")
+    mod.Unpickler = Unpickler
+    mod.load = lambda f, **kw: Unpickler(f, **kw).load()
+    mod.loads = lambda b, **kw: Unpickler(__import__("io").BytesIO(b), **kw).load()
+    mod.UnpicklingError = pickle.UnpicklingError
+    mod.PickleError = pickle.PickleError
+    return mod
+
+
 def read_checkpoint_file(path):
-    """torch.load restricted to tensors and plain containers (weights_only=True; argparse.Namespace allow-listed: the
-    argument objects scripts/train.py:206-214 stores beside 'model').  A file that needs more -- the reference pickles
-    its own Config class instances -- is executed-on-load pickle: it is read only when the caller says the file is
-    trusted (BFM_TRUST_CHECKPOINT=1), the way the reference always does."""
+    """A checkpoint file without running its pickle: first torch.load(weights_only=True) (tensors and plain containers;
+    argparse.Namespace allow-listed); a file that holds more -- the reference's own checkpoints pickle utils.config.Config
+    objects beside 'model' (scripts/train.py:206-214) -- is read again with a restricted Unpickler that turns every
+    unknown class into an inert dict (InertObject): the tensors load, nothing of the file executes, and the reference's
+    modules need not be importable.  BFM_TRUST_CHECKPOINT=1 alone selects a full unpickle (torch.load(weights_only=False),
+    the reference's own way; needs the pickled classes importable)."""
     import argparse
     import pickle
+    if os.environ.get("BFM_TRUST_CHECKPOINT", "0") == "1":
+        return torch.load(path, map_location="cpu", weights_only=False)
     try:
         with torch.serialization.safe_globals([argparse.Namespace]):
             return torch.load(path, map_location="cpu", weights_only=True)
-    except pickle.UnpicklingError as e:
-        if os.environ.get("BFM_TRUST_CHECKPOINT", "0") != "1":
-            raise L.BfmError("checkpoint %s holds pickled objects beyond tensors and containers (%s); set "
-                             "BFM_TRUST_CHECKPOINT=1 to unpickle it in full if you trust its source"
-                             % (path, str(e).splitlines()[0])) from e
-        return torch.load(path, map_location="cpu", weights_only=False)
+    except pickle.UnpicklingError:
+        return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_restricted_pickle_module())
 
 
 def load_state_dict_by_suffix(model, loaded):

@@ -60,9 +60,9 @@ def default_inference_args(f_maps=64, num_levels=6, left_hemis_only=False, size=
 
 
 # ----------------------------------------------------------------------------- tiling (host logic)
-def zero_crop(orig, tol=0, crop_range_lst=None):
+def zero_crop(orig, tol=0, crop_range_lst=None, save_path=None):
     """utils/test_utils.py:60-90.  On the device the bounding box of (orig > tol) comes from one reduction kernel
-    instead of torch.argwhere's coordinate list."""
+    instead of torch.argwhere's coordinate list.  `save_path` is accepted and unused, as in the reference."""
     if crop_range_lst is None and orig.is_cuda and orig.dim() == 3:
         src = orig.to(torch.float32).contiguous()
         box = torch.empty(6, dtype=torch.int32, device=orig.device)
@@ -205,9 +205,9 @@ def resample(I, orig_res=[1., 1., 1.], new_res=[1., 1., 1.]):
     return GU.myzoom_torch(I_resize, 1 / factors)
 
 
-@L.on_device(lambda *a, **k: _resolve_device(k.get("device", "cuda")))
+@L.on_device(lambda *a, **k: _resolve_device(k.get("device", a[10] if len(a) > 10 else "cpu")))
 def prepare_image(img_path, win_size=None, zero_crop_first=False, spacing=None, add_bf=False, is_CT=False,
-                  is_label=False, rescale=True, hemis_mask=None, im_only=False, device="cuda"):
+                  is_label=False, rescale=True, hemis_mask=None, im_only=False, device="cpu"):
     """utils/test_utils.py:235-284 with every array operation on the device.  ``img_path`` is a path (needs
     set_volume_reader) or an in-memory ``(array, affine)`` pair.  Returns what the reference returns:
     final, orig, high_res, bf, aff, crop_start, orig_shp."""

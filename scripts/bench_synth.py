@@ -68,7 +68,7 @@ v5 = vol[None, None].contiguous()
 g160 = (torch.stack([zz, yy, xx], -1) + 0.37)[None].contiguous()
 report("interpol.grid_push linear, 1 ch (atomics)", timeit(lambda: IP.grid_push(v5, g160, [N, N, N], 1, "dct2", True)), nv * 24)
 report("interpol.grid_grad linear, 1 ch", timeit(lambda: IP.grid_grad(v5, g160, 1, "dct2", True)), nv * 28)
-report("bspline3 prefilter, 3 axes (spline_coeff_nd)", timeit(lambda: IP.spline_coeff_nd(vol, "dct2", 3, 3)), nv * 24)
+report("bspline3 prefilter, 3 axes (spline_coeff_nd)", timeit(lambda: IP.spline_coeff_nd(vol, 3, "dct2", 3)), nv * 24)
 low = torch.rand(80, 80, 53, device=dev)
 report("interpol.resize cubic 80x80x53 -> 160^3 (prefilter + 3 passes)",
        timeit(lambda: IP.resize(low, shape=[N, N, N], anchor="edge", interpolation=3, bound="dct2", prefilter=True)), nv * 4 * 2)

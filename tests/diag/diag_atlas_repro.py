@@ -55,7 +55,7 @@ cout_t, cws = torch.empty(*cd, cout, device=dev), torch.empty(1 << 26, dtype=tor
 ly = _Layer(); ly.name, ly.cin, ly.cout, ly.groups = "corunner", cin, cout, 8
 ly.w_raw = (torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05).contiguous()
 ly.packs, ly.kind, ly.wpacked, ly.wexp, ly.skip = {}, None, None, 0, None
-ccfg = (C.c_int * 8)(); L.check(lib.bfm_conv3x3x3_mfma_plan(cin, cout, cd[0], cd[1], cd[2], ccfg), "plan"); ccfg[6] = 0
+ccfg = (C.c_int * 8)(); L.check(lib.bfm_conv3x3x3_mfma_plan(cin, cout, cd[0], cd[1], cd[2], ccfg), "plan"); ccfg[6] = int(os.environ.get("BFM_DIAG_CORUNNER_VER", "0"))   # 0 conv_mfma (LDS-DMA weights), 3 conv_wino (weights L2 -> VGPR)
 
 
 def conv_beside(k=6):

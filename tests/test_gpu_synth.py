@@ -284,7 +284,7 @@ def test_cubic_bspline_resize_vs_reference_golden(name, anchor):
     d = load_npz("interpol_resize.npz")
     x = torch.from_numpy(d[name + "/x"]).to("cuda:0")
     shape = [int(v) for v in d[name + "/shape"]]
-    coeff = IP.spline_coeff_nd(x, bound="dct2", order=3, dim=3)
+    coeff = IP.spline_coeff_nd(x, interpolation=3, bound="dct2", dim=3)
     ref_c = d[name + "/coeff"]
     assert float(np.abs(coeff.cpu().numpy() - ref_c).max()) <= 1e-5 * float(np.abs(ref_c).max())
     y = IP.resize(x, shape=shape, anchor=anchor, interpolation=3, bound="dct2", prefilter=True)
@@ -508,3 +508,80 @@ def test_gathers_inside_captured_graphs_on_two_lanes_keep_their_goldens():
             assert np.array_equal(N(outs["interp"]), d["lin1"]), (it, lane)
             _close(N(outs["pull_zero"]), d2["out_zero_0"], 1e-6)
             _close(N(outs["pull_dct2"]), d2["out_dct2_1"], 1e-6)
+
+
+def test_streaming_kernels_with_l1_reuse_beside_an_lds_dma_corunner_keep_their_bits():
+    """DESIGN.md section 3.3 / VERDICT r3 #6: besides the gathers, three kernels of the tile flow read with ordinary
+    vector loads that re-use L1 lines between neighbouring lanes -- the stem's halo gather (bfm_conv3x3x3_stem_ex),
+    maxpool2 (bfm_maxpool2_ex) and the uniform-box flags (bfm_uniform_boxes_level).  Each runs on two streams at once
+    beside the LDS-DMA co-runner the atlas gather went wrong beside (conv_mfma, variant 0), 40 rounds; every output must
+    equal the kernel's own serial result bit for bit."""
+    import ctypes as C
+    from brainfm_amd import _lib as L, test_utils as TU
+    from brainfm_amd.engine import _Layer
+    dev = torch.device(DEV)
+    ga, ta = TU.default_inference_args(f_maps=64, num_levels=6)
+    eng = TU.InferenceSession(ga, ta, dev).engine
+    lib = eng.lib
+    cin = cout = 128
+    cd = (40, 40, 40)
+    cA = torch.randn(*cd, cin, device=DEV)
+    csc, csh, cbd = torch.rand(cin, device=DEV) + 0.5, torch.randn(cin, device=DEV) * 0.1, torch.full((8,), 6.0, device=DEV)
+    cout_t, cws = torch.empty(*cd, cout, device=DEV), torch.empty(1 << 26, dtype=torch.uint8, device=DEV)
+    ly = _Layer()
+    ly.name, ly.cin, ly.cout, ly.groups = "corunner", cin, cout, 8
+    ly.w_raw = (torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05).contiguous()
+    ly.packs, ly.kind, ly.wpacked, ly.wexp, ly.skip = {}, None, None, 0, None
+    ccfg = (C.c_int * 8)()
+    L.check(lib.bfm_conv3x3x3_mfma_plan(cin, cout, cd[0], cd[1], cd[2], ccfg), "plan")
+    ccfg[6] = 0
+
+    def conv_beside():
+        for _ in range(6):
+            eng._conv_launch(ly, cA, cin, None, 0, cd, None, csc, csh, cbd, 8, ccfg, cout_t, cws)
+
+    g = torch.Generator().manual_seed(3)
+    dims = (96, 80, 112)
+    img = torch.rand(dims, generator=g).to(DEV)
+    img[:20] = 0
+    img[:, :, 90:] = 0
+    x_cl = img.reshape(*dims, 1).contiguous()
+    stem = eng.enc[0][0]
+    eng._pack(stem, False)                                            # the stem kernel reads the direct [27][1][Cout] layout
+    sc1, sh1, bd1 = torch.ones(1, device=DEV), torch.zeros(1, device=DEV), torch.full((1,), 1.0, device=DEV)
+    act = torch.randn(*(48, 40, 56), 64, generator=torch.Generator().manual_seed(4)).to(DEV)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    side = torch.cuda.Stream()
+
+    def run_all(store):
+        # stem: 1 -> 32/64 channels, halo gather of the one-channel image
+        out = torch.empty(*dims, stem.cout, device=DEV)
+        L.check(lib.bfm_conv3x3x3_stem_ex(L.ptr(x_cl), dims[0], dims[1], dims[2], L.ptr(sc1), L.ptr(sh1), L.ptr(bd1),
+                                          L.ptr(stem.wpacked), stem.cout, 0.01, L.ptr(out), None, L.stream_ptr()), "stem")
+        store["stem"] = out
+        pooled = torch.empty(24, 20, 28, 64, device=DEV)
+        L.check(lib.bfm_maxpool2_ex(L.ptr(act), 64, 48, 40, 56, L.ptr(pooled), None, L.stream_ptr()), "maxpool2")
+        store["pool"] = pooled
+        for level in (0, 1):
+            n = lib.bfm_uniform_boxes_bytes(dims[0] >> level, dims[1] >> level, dims[2] >> level, eng.passes)
+            fl = torch.zeros(n, dtype=torch.uint8, device=DEV)
+            L.check(lib.bfm_uniform_boxes_level(L.ptr(x_cl), dims[0], dims[1], dims[2], level, 3, eng.passes, L.ptr(fl),
+                                                L.stream_ptr()), "uniform_boxes")
+            store["flags%d" % level] = fl
+
+    want = {}
+    run_all(want)
+    conv_beside()
+    torch.cuda.synchronize()
+    assert int((want["flags0"] != 0).sum()) > 0                       # the zero slabs give flagged boxes
+    for it in range(40):
+        got = [{}, {}]
+        with torch.cuda.stream(side):
+            conv_beside()
+        for lane in range(2):
+            with torch.cuda.stream(streams[lane]):
+                run_all(got[lane])
+        torch.cuda.synchronize()
+        for lane in range(2):
+            for k, v in want.items():
+                assert torch.equal(got[lane][k], v), (it, lane, k)

@@ -445,3 +445,84 @@ def test_bench_gpus_flag_launches_ranks_or_refuses():
     assert "--gpus 2 but only" in r.stderr and '"metric"' not in r.stdout
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "launch_ranks(args.gpus" in src and "os.exec" not in src          # children are spawned, nothing is re-executed
+
+
+def test_python_boundary_signatures_match_the_reference():
+    """the mirrors keep the reference's Python call surface.  tests/golden/api_signatures.json holds
+    inspect.signature of every boundary callable of the REAL reference (make_golden_signatures.py, build container);
+    each mirror must have the same parameter names in the same order with the same defaults.  A mirror may only add
+    parameters that have defaults, and only those the fixture lists under allowed_extra (recorded deviations)."""
+    import inspect
+    import json
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "api_signatures.json")))
+    assert not d["unresolved_in_reference"], d["unresolved_in_reference"]
+    assert len(d["signatures"]) >= 55
+
+    def resolve(spec):
+        mod, qual = spec.split(":")
+        obj = __import__(mod, fromlist=["_"])
+        for part in qual.split("."):
+            obj = getattr(obj, part)
+        return obj
+
+    problems = []
+    for ref, e in sorted(d["signatures"].items()):
+        fn = resolve(e["mirror"])
+        mine = [[p.name, p.kind.name, None if p.default is inspect.Parameter.empty else
+                 ("<function %s>" % p.default.__name__ if inspect.isfunction(p.default) else repr(p.default))]
+                for p in inspect.signature(fn).parameters.values()]
+        want = e["params"]
+        extra = d["allowed_extra"].get(e["mirror"], {})
+        if mine[:len(want)] != want:
+            problems.append((e["mirror"], "reference %s" % want, "mirror %s" % mine))
+            continue
+        for name, kind, default in mine[len(want):]:
+            if name not in extra or default is None:
+                problems.append((e["mirror"], "extra parameter %s (default %s) is not a recorded deviation" % (name, default)))
+    assert not problems, "\n".join(str(p) for p in problems)
+
+
+def test_reference_format_checkpoints_load_without_running_their_pickle(tmp_path, monkeypatch):
+    """scripts/train.py:206-214 pickles utils.config.Config objects (dict subclasses of the reference's own module)
+    beside 'model' and 'optimizer'.  read_checkpoint_file must return the tensors of such a file (a) without the
+    reference's modules being importable, (b) without BFM_TRUST_CHECKPOINT, and (c) without executing anything the
+    file asks for: a pickled object whose __reduce__ would run code comes back as an inert dict."""
+    import subprocess
+    import sys
+    import torch
+    from brainfm_amd import models as M
+    path = str(tmp_path / "ckp.pth")
+    marker = str(tmp_path / "executed")
+    # written by a child process in which the classes live in a module `utils.config` that this process never has
+    writer = '''
+import sys, types, torch, os
+m = types.ModuleType("utils"); c = types.ModuleType("utils.config"); m.config = c
+sys.modules["utils"] = m; sys.modules["utils.config"] = c
+class AttrDict(dict):
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k); self.__dict__ = self
+class Config(AttrDict):
+    pass
+class Evil:
+    def __reduce__(self):
+        return (os.system, ("touch %s",))
+for k in (AttrDict, Config, Evil):
+    k.__module__ = "utils.config"; setattr(c, k.__name__, k)
+w = torch.arange(12, dtype=torch.float32).reshape(3, 4)
+torch.save({"model": {"module.backbone.w": w, "head.b": torch.ones(2)}, "optimizer": {"state": {0: {"step": torch.tensor(3.)}}},
+            "epoch": 7, "gen_args": Config(a=1, nested=AttrDict(b=[1, 2])), "train_args": Config(lr=0.1), "evil": Evil()}, %r)
+''' % (marker, path)
+    subprocess.check_call([sys.executable, "-c", writer])
+    assert "utils.config" not in sys.modules
+    monkeypatch.delenv("BFM_TRUST_CHECKPOINT", raising=False)
+    ckp = M.read_checkpoint_file(path)
+    assert not os.path.exists(marker), "the checkpoint's pickle was executed"
+    assert torch.equal(ckp["model"]["module.backbone.w"], torch.arange(12, dtype=torch.float32).reshape(3, 4))
+    assert torch.equal(ckp["model"]["head.b"], torch.ones(2)) and ckp["epoch"] == 7
+    assert float(ckp["optimizer"]["state"][0]["step"]) == 3.0
+    assert isinstance(ckp["gen_args"], M.InertObject) and ckp["gen_args"]["a"] == 1 and ckp["gen_args"].nested["b"] == [1, 2]
+    assert isinstance(ckp["evil"], M.InertObject)
+    # a plain tensor checkpoint still takes the weights_only path
+    plain = str(tmp_path / "plain.pth")
+    torch.save({"model": {"w": torch.zeros(2)}}, plain)
+    assert torch.equal(M.read_checkpoint_file(plain)["model"]["w"], torch.zeros(2))
