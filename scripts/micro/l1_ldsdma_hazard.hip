@@ -66,8 +66,8 @@ __global__ void __launch_bounds__(256) corunner(const uint4* __restrict__ w, int
         for (int i = 0; i < 8; ++i) {                        // 8 fragments of 1 KiB per wave and round -> 32 KiB of LDS
             const int f = (blockIdx.x * 131 + r * 32 + wave * 8 + i) % nfrag;
             const uint4* src = w + (size_t)f * 64 + lane;
-            char* dst = lds + (wave * 8 + i) * 1024;
-            if (MODE == 0 || MODE == 4) {
+            char* dst = lds + (MODE == 5 ? 65536 : 0) + (wave * 8 + i) * 1024;   // M = 5: slots ABOVE 64 KiB of LDS
+            if (MODE == 0 || MODE == 4 || MODE == 5) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
             } else {
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) corunner(const uint4* __restrict__ w, int
         if (MODE == 4 && r == rounds - 1) break;             // M = 4: the wave ENDS with its last eight LDS-DMA loads in flight
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        s += reinterpret_cast<const float*>(lds)[(threadIdx.x * 37 + r) & 8191];
+        s += reinterpret_cast<const float*>(lds + (MODE == 5 ? 65536 : 0))[(threadIdx.x * 37 + r) & 8191];
         __syncthreads();
     }
     if (s == 12345.678f) sink[0] = s;                        // keeps the LDS reads alive
@@ -142,18 +142,21 @@ int main() {
     CK(hipDeviceSynchronize());
     hipStream_t s[3];
     for (int i = 0; i < 3; ++i) CK(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
-    const char* cname[5] = {"LDS-DMA (global_load_lds_dwordx4) only", "ordinary loads + ds_write, same bytes", "no co-runner",
-                            "LDS-DMA ring, counted waits, ds_read_b128, MFMA", "LDS-DMA, waves END with DMA in flight"};
+    const char* cname[6] = {"LDS-DMA (global_load_lds_dwordx4) only", "ordinary loads + ds_write, same bytes", "no co-runner",
+                            "LDS-DMA ring, counted waits, ds_read_b128, MFMA", "LDS-DMA, waves END with DMA in flight",
+                            "LDS-DMA into LDS above 64 KiB (96 KiB allocated)"};
     const char* gname[2] = {"ordinary global_load_dword", "agent scope (sc1)"};
     const int rounds = 400;
     printf("# gather 160x160x80 from a 256^3 volume on two streams, co-runner on a third; %d rounds each; wrong texels\n", rounds);
-    for (int cm = 0; cm < 5; ++cm) {
+    CK(hipFuncSetAttribute((const void*)corunner<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+    for (int cm = 0; cm < 6; ++cm) {
         for (int gm = 0; gm < 2; ++gm) {
             CK(hipMemset(bad, 0, 4));
             CK(hipDeviceSynchronize());
             for (int r = 0; r < rounds; ++r) {
                 if (cm == 0) hipLaunchKernelGGL(corunner<0>, dim3(512), dim3(256), 32768, s[2], w, nfrag, 40, sink);
                 if (cm == 1) hipLaunchKernelGGL(corunner<1>, dim3(512), dim3(256), 32768, s[2], w, nfrag, 40, sink);
+                if (cm == 5) hipLaunchKernelGGL(corunner<5>, dim3(512), dim3(256), 98304, s[2], w, nfrag, 40, sink);
                 if (cm == 4) hipLaunchKernelGGL(corunner<4>, dim3(2048), dim3(256), 32768, s[2], w, nfrag, 10, sink);
                 if (cm == 3) hipLaunchKernelGGL(corunner_mfma, dim3(512), dim3(256), 65536, s[2], w, nfrag, 60, sink);
                 for (int l = 0; l < 2; ++l) {
