@@ -182,19 +182,32 @@ struct ZoomTabs {
     const float *wfx, *wcx, *wfy, *wcy, *wfz, *wcz;
 };
 
-// One wave per output (x, y) row.  The x and y passes of the row depend on the source z only:
+// One wave per output (x, y) row, several rows per wave.  The x and y passes of a row depend on the source z only:
 //   B[zs] = wfy * (wfx * X[fx,fy,zs] + wcx * X[cx,fy,zs]) + wcy * (wfx * X[fx,cy,zs] + wcx * X[cx,cy,zs])
 // is formed once per source position in the wave's LDS row, and every output is wfz * B[fz] + wcz * B[cz] -- the
 // reference's pass order (x, y, z) and expressions, so the same bits as the per-output form, with 4 global loads per
-// SOURCE element instead of 8 per OUTPUT element (upsampling 6^3 -> 160^3: 36 -> 12 us for three channels).
+// SOURCE element instead of 8 per OUTPUT element.  The z tables of the row (index pair and weights per output element)
+// are staged in LDS once per workgroup, and a lane writes four consecutive outputs with one 16-byte store: the kernel
+// is a write stream (round 3: 59 us for 6^3 x 3 -> 160^3 x 3; per-output form with wave rows: 36 us).
 constexpr int ZOOM_ROW = 1024;                                  // source row (nz * C floats) that fits the wave's LDS slot
+constexpr int ZOOM_OUT = 2048;                                  // output row (oz * C elements) whose z tables fit LDS
 __global__ void __launch_bounds__(256) zoom_linear(const float* __restrict__ X, int nx, int ny, int nz, int C, ZoomTabs t,
                                                    int ox, int oy, int oz, float* __restrict__ out) {
-    __shared__ float sB[4][ZOOM_ROW];
+    extern __shared__ float zsm[];                                // [4][srclen] B rows, then the four z tables [rowlen]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int rows = ox * oy, rowlen = oz * C, srclen = nz * C;
+    int* sF = reinterpret_cast<int*>(zsm + 4 * srclen);
+    int* sC = sF + rowlen;
+    float* sWf = reinterpret_cast<float*>(sC + rowlen);
+    float* sWc = sWf + rowlen;
     const int64_t sx = (int64_t)ny * nz * C, sy = (int64_t)nz * C;
-    float* B = sB[w];
+    for (int e = threadIdx.x; e < rowlen; e += 256) {
+        const int k = C == 1 ? e : e / C, c = C == 1 ? 0 : e - k * C;
+        sF[e] = t.fz[k] * C + c; sC[e] = t.cz[k] * C + c; sWf[e] = t.wfz[k]; sWc[e] = t.wcz[k];
+    }
+    __syncthreads();
+    float* B = zsm + w * srclen;
+    const bool vec = (rowlen & 3) == 0 && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     for (int r = blockIdx.x * 4 + w; r < rows; r += gridDim.x * 4) {
         const int ii = r / oy, j = r - ii * oy;
         const int fx = t.fx[ii], cx = t.cx[ii], fy = t.fy[j], cy = t.cy[j];
@@ -211,9 +224,17 @@ __global__ void __launch_bounds__(256) zoom_linear(const float* __restrict__ X, 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): the wave's own LDS writes have landed
         float* o = out + (int64_t)r * rowlen;
-        for (int e = lane; e < rowlen; e += 64) {
-            const int k = C == 1 ? e : e / C, c = C == 1 ? 0 : e - k * C;
-            o[e] = t.wfz[k] * B[t.fz[k] * C + c] + t.wcz[k] * B[t.cz[k] * C + c];
+        if (vec) {
+            for (int e = lane * 4; e < rowlen; e += 256) {
+                float4 v;
+                v.x = sWf[e] * B[sF[e]] + sWc[e] * B[sC[e]];
+                v.y = sWf[e + 1] * B[sF[e + 1]] + sWc[e + 1] * B[sC[e + 1]];
+                v.z = sWf[e + 2] * B[sF[e + 2]] + sWc[e + 2] * B[sC[e + 2]];
+                v.w = sWf[e + 3] * B[sF[e + 3]] + sWc[e + 3] * B[sC[e + 3]];
+                *reinterpret_cast<float4*>(o + e) = v;
+            }
+        } else {
+            for (int e = lane; e < rowlen; e += 64) o[e] = sWf[e] * B[sF[e]] + sWc[e] * B[sC[e]];
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -249,8 +270,73 @@ __global__ void __launch_bounds__(256) zoom_linear_long(const float* __restrict_
     }
 }
 
-// one wave per (x, y) row, lanes along z (coalesced for every axis); taps in registers-by-value would need a fixed
-// length, so they stay a small table read through the scalar cache
+// gaussian_blur_3d, one axis: a workgroup stages a [len][64] slab (the whole extent along the filtered axis x 64
+// consecutive z for axes 0 / 1; 64 rows x the whole z extent for axis 2) in LDS and forms every output from it -- each
+// input element leaves HBM / L2 once instead of once per tap (round 3: one global load per tap and output, 34 us per pass
+// at 160^3).  The taps are added in the reference's order (ascending, those outside the volume skipped), with fmaf, as
+// before: the same bits.
+constexpr int C1D_SEG = 32;                                     // outputs along the filtered axis per workgroup (axes 0, 1)
+constexpr int C1D_ROWS = 16;                                    // rows per workgroup (axis 2)
+constexpr int C1D_TAPS = 64;
+constexpr int C1D_NZ = 1024;                                    // longest z row of the axis-2 slab form
+template <int AXIS>
+__global__ void __launch_bounds__(256) conv1d_slab(const float* __restrict__ in, int nx, int ny, int nz,
+                                                   const float* __restrict__ kern, int klen, float* __restrict__ out) {
+    extern __shared__ float slab[];                               // [SEG + klen - 1][65] (axes 0, 1) or [ROWS][nz | 1] (axis 2)
+    __shared__ float taps[C1D_TAPS];
+    const int half = klen / 2;
+    for (int j = threadIdx.x; j < klen; j += 256) taps[j] = kern[j];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (AXIS != 2) {
+        const int len = AXIS == 0 ? nx : ny;
+        const int other = AXIS == 0 ? ny : nx;                    // the axis that is neither filtered nor z
+        const int64_t stride = AXIS == 0 ? (int64_t)ny * nz : nz;
+        const int zchunks = (nz + 63) / 64, segs = (len + C1D_SEG - 1) / C1D_SEG;
+        const int nslab = other * zchunks * segs;
+        for (int sl = blockIdx.x; sl < nslab; sl += gridDim.x) {
+            const int sg = sl % segs, rest = sl / segs;
+            const int o = rest / zchunks, z0 = (rest - o * zchunks) * 64;
+            const int p0 = sg * C1D_SEG, p1 = min(len, p0 + C1D_SEG);
+            const int lo = max(0, p0 - half), hi = min(len, p1 + half);      // rows of the volume the segment's taps touch
+            const int64_t base = (AXIS == 0 ? (int64_t)o * nz : (int64_t)o * ny * nz) + z0;
+            const int z = z0 + lane;
+            __syncthreads();
+            for (int p = lo + w; p < hi; p += 4) slab[(p - lo) * 65 + lane] = z < nz ? in[base + (int64_t)p * stride + lane] : 0.f;
+            __syncthreads();
+            if (z < nz)
+                for (int p = p0 + w; p < p1; p += 4) {
+                    const int j0 = max(0, half - p), j1 = min(klen, len + half - p);
+                    float acc = 0.f;
+                    for (int j = j0; j < j1; ++j) acc = fmaf(taps[j], slab[(p + j - half - lo) * 65 + lane], acc);
+                    out[base + (int64_t)p * stride + lane] = acc;
+                }
+        }
+    } else {
+        const int len = nz, ld = nz | 1;
+        const int rows = nx * ny;
+        const int nslab = (rows + C1D_ROWS - 1) / C1D_ROWS;
+        for (int sl = blockIdx.x; sl < nslab; sl += gridDim.x) {
+            const int r0 = sl * C1D_ROWS, nr = min(C1D_ROWS, rows - r0);
+            const int64_t base = (int64_t)r0 * nz;
+            __syncthreads();
+            for (int e = threadIdx.x; e < nr * len; e += 256) {      // consecutive rows are one contiguous run
+                const int r = e / len, z = e - r * len;
+                slab[r * ld + z] = in[base + e];
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < nr * len; e += 256) {
+                const int r = e / len, z = e - r * len;
+                const int j0 = max(0, half - z), j1 = min(klen, len + half - z);
+                const float* p = slab + r * ld + z - half;
+                float acc = 0.f;
+                for (int j = j0; j < j1; ++j) acc = fmaf(taps[j], p[j], acc);
+                out[base + e] = acc;
+            }
+        }
+    }
+}
+
+// any extent: one wave per (x, y) row, lanes along z, one global load per tap
 __global__ void __launch_bounds__(256) conv1d_axis(const float* __restrict__ in, int nx, int ny, int nz, int axis,
                                                    const float* __restrict__ kern, int klen, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -261,33 +347,13 @@ __global__ void __launch_bounds__(256) conv1d_axis(const float* __restrict__ in,
     for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
         const int x = r / ny, y = r - x * ny;
         const int64_t base = (int64_t)r * nz;
-        if (axis != 2) {
-            // the tap range is the row's: wave-uniform loop, taps through the scalar cache
-            const int pos = axis == 0 ? x : y;
+        for (int z = lane; z < nz; z += 64) {
+            const int pos = axis == 0 ? x : (axis == 1 ? y : z);
             const int j0 = max(0, half - pos), j1 = min(klen, len + half - pos);       // taps inside the volume
-            for (int z = lane; z < nz; z += 64) {
-                const float* p = in + base + z + (int64_t)(j0 - half) * stride;
-                float acc = 0.f;
-                for (int j = j0; j < j1; ++j, p += stride) acc = fmaf(kern[j], *p, acc);
-                out[base + z] = acc;
-            }
-        } else {
-            for (int z0 = 0; z0 < nz; z0 += 64) {
-                const int z = z0 + lane;
-                const bool interior = z0 >= half && z0 + 63 + half < nz;              // all 64 lanes take every tap
-                if (interior) {
-                    const float* p = in + base + z - half;
-                    float acc = 0.f;
-                    for (int j = 0; j < klen; ++j) acc = fmaf(kern[j], p[j], acc);
-                    out[base + z] = acc;
-                } else if (z < nz) {
-                    const int j0 = max(0, half - z), j1 = min(klen, nz + half - z);
-                    const float* p = in + base + z - half;
-                    float acc = 0.f;
-                    for (int j = j0; j < j1; ++j) acc = fmaf(kern[j], p[j], acc);
-                    out[base + z] = acc;
-                }
-            }
+            const float* p = in + base + z + (int64_t)(j0 - half) * stride;
+            float acc = 0.f;
+            for (int j = j0; j < j1; ++j, p += stride) acc = fmaf(kern[j], *p, acc);
+            out[base + z] = acc;
         }
     }
 }
@@ -673,9 +739,10 @@ extern "C" int bfm_zoom_linear(const float* X, int nx, int ny, int nz, int C, co
     ZoomTabs t{ax[0].f, ax[0].c, ax[1].f, ax[1].c, ax[2].f, ax[2].c, ax[0].wf, ax[0].wc, ax[1].wf, ax[1].wc,
                ax[2].wf, ax[2].wc};
     if ((int64_t)ox * oy > INT32_MAX || (int64_t)oz * C > INT32_MAX) return BFM_E_SHAPE;
-    if ((int64_t)nz * C <= ZOOM_ROW)
-        hipLaunchKernelGGL(zoom_linear, dim3(grid_for((int64_t)ox * oy, 4)), dim3(256), 0, bfm_s(stream), X, nx, ny, nz, C,
-                           t, ox, oy, oz, out);
+    if ((int64_t)nz * C <= ZOOM_ROW && (int64_t)oz * C <= ZOOM_OUT)
+        hipLaunchKernelGGL(zoom_linear, dim3(grid_for((int64_t)ox * oy, 8, 4096)), dim3(256),
+                           (size_t)(4 * nz * C + 4 * oz * C) * sizeof(float), bfm_s(stream), X, nx, ny, nz, C, t, ox, oy, oz,
+                           out);
     else
         hipLaunchKernelGGL(zoom_linear_long, dim3(grid_for((int64_t)ox * oy, 4)), dim3(256), 0, bfm_s(stream), X, nx, ny,
                            nz, C, t, ox, oy, oz, out);
@@ -687,6 +754,23 @@ extern "C" int bfm_conv1d_axis(const float* in, int nx, int ny, int nz, int axis
     if (!in || !kern || !out || nx <= 0 || ny <= 0 || nz <= 0 || axis < 0 || axis > 2 || klen <= 0 || !(klen & 1))
         return BFM_E_ARG;
     if ((int64_t)nx * ny > INT32_MAX) return BFM_E_SHAPE;
+    if (klen <= C1D_TAPS && (axis != 2 || nz <= C1D_NZ)) {
+        hipStream_t st = bfm_s(stream);
+        if (axis == 2) {
+            const int nslab = (nx * ny + C1D_ROWS - 1) / C1D_ROWS;
+            const size_t smem = (size_t)C1D_ROWS * (nz | 1) * sizeof(float);
+            hipLaunchKernelGGL(conv1d_slab<2>, dim3(std::min(nslab, 8192)), dim3(256), smem, st, in, nx, ny, nz, kern, klen, out);
+        } else {
+            const int len = axis == 0 ? nx : ny;
+            const int nslab = (axis == 0 ? ny : nx) * ((nz + 63) / 64) * ((len + C1D_SEG - 1) / C1D_SEG);
+            const size_t smem = (size_t)(C1D_SEG + klen - 1) * 65 * sizeof(float);
+            if (axis == 0)
+                hipLaunchKernelGGL(conv1d_slab<0>, dim3(std::min(nslab, 8192)), dim3(256), smem, st, in, nx, ny, nz, kern, klen, out);
+            else
+                hipLaunchKernelGGL(conv1d_slab<1>, dim3(std::min(nslab, 8192)), dim3(256), smem, st, in, nx, ny, nz, kern, klen, out);
+        }
+        return bfm_launch_status();
+    }
     hipLaunchKernelGGL(conv1d_axis, dim3(grid_for((int64_t)nx * ny, 4)), dim3(256), 0, bfm_s(stream), in, nx, ny, nz, axis,
                        kern, klen, out);
     return bfm_launch_status();

@@ -69,10 +69,9 @@ __device__ __forceinline__ void philox4(uint64_t ctr, uint64_t offset, uint64_t 
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
     const float u1 = ((float)(a >> 8) + 0.5f) * 5.9604644775390625e-8f;      // (0, 1)
     const float u2 = ((float)(b >> 8) + 0.5f) * 5.9604644775390625e-8f;
-    const float r = sqrtf(-2.f * logf(u1));
-    float s, c;
-    sincospif(2.f * u2, &s, &c);
-    z0 = r * c; z1 = r * s;
+    // hardware log2 / sqrt / sin / cos (the arguments are in (0, 1): no range reduction needed; v_sin / v_cos take turns)
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));      // -2 ln u = -2 ln2 log2 u
+    z0 = r * __builtin_amdgcn_cosf(u2); z1 = r * __builtin_amdgcn_sinf(u2);
 }
 
 __global__ void randn_philox(float* __restrict__ out, int64_t n, uint64_t seed, uint64_t offset, float scale) {
