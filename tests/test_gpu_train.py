@@ -353,3 +353,31 @@ def test_tile_loop_heads_follow_weights_that_grew_in_training():
         assert bool(torch.isfinite(v).all()), k
         err = float((v - want).abs().max()) / max(1e-6, float(want.abs().max()))
         assert err <= 1e-4, (k, err)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_out,nvox", [(69, 128 * 77 + 5), (96, 4096), (8, 1000), (33, 64)])
+def test_heads_backward_fused_pass_vs_float64(n_out, nvox):
+    """bfm_head_bwd at the shipped feature width (C = 64) takes the one-pass kernel of round 4 -- dFn = dRaw . W, dW = dRaw^T . Fn
+    and db = column sums of dRaw from LDS tiles on the exact-fp32 matrix core -- instead of three passes over dRaw; both
+    paths against float64 (fp32 accumulation over nvox terms: 2e-5 of the largest entry), incl. voxel counts that are not a
+    multiple of the 64-voxel tile and head widths on both sides of the 32-row blocks.  C = 16 keeps the separate kernels."""
+    import ctypes as C
+    from brainfm_amd import _lib as L
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    for cf in (64, 16):
+        g = torch.Generator().manual_seed(n_out * 7 + cf)
+        dRaw = (torch.randn(nvox, n_out, generator=g) * (torch.rand(nvox, 1, generator=g) > 0.3)).to(dev)
+        Fn = torch.randn(nvox, cf, generator=g).to(dev)
+        W = torch.randn(n_out, cf, generator=g).to(dev)
+        dW = torch.full((n_out, cf), float("nan"), device=dev)
+        db = torch.full((n_out,), float("nan"), device=dev)
+        dFn = torch.full((nvox, cf), float("nan"), device=dev)
+        ws = torch.empty(lib.bfm_head_bwd_workspace(n_out, cf, nvox), dtype=torch.uint8, device=dev)
+        L.check(lib.bfm_head_bwd(L.ptr(dRaw), L.ptr(Fn), L.ptr(W), n_out, cf, nvox, L.ptr(dW), L.ptr(db), L.ptr(dFn),
+                                 L.ptr(ws), ws.numel(), L.stream_ptr()), "head_bwd")
+        r64, f64, w64 = dRaw.double(), Fn.double(), W.double()
+        for got, ref, what in ((dFn, r64 @ w64, "dFn"), (dW, r64.t() @ f64, "dW"), (db, r64.sum(0), "db")):
+            err = float((got.double() - ref).abs().max()) / max(1e-6, float(ref.abs().max()))
+            assert err <= 2e-5, (cf, what, err)
