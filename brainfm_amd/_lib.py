@@ -149,6 +149,7 @@ SIGNATURES = {
     "bfm_loss_l1": (_I, [_P, _I, _I, _P, _P, _P, _L, _F, _I, _F, _P, _P, _P, _Z, _P]),
     "bfm_loss_l1_multi_workspace": (_Z, []),
     "bfm_loss_l1_multi": (_I, [_P, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "bfm_loss_grad_l1_multi": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "bfm_loss_grad_l1": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
     "bfm_loss_seg": (_I, [_P, _I, _I, _I, _P, _P, _P, _L, _F, _F, _P, _P, _P, _P, _Z, _P]),
     "bfm_head_bwd_workspace": (_Z, [_I, _I, _L]),

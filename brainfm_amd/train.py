@@ -254,6 +254,7 @@ class TrainStep:
         slots = {}
         k = 0
         dense = []                                        # (slot index, col, target, weight, mask, clamp, l2, coef): one launch
+        grads_l1 = []                                     # (slot index, col, target, weight, coef): the gradient-L1 entries, one launch
         keep = []                                         # tensors the deferred launch reads
         active = set()                                    # head rows some loss of this sample differentiates
 
@@ -279,8 +280,8 @@ class TrainStep:
                 co = self._col(head)
                 active.add(co)
                 if is_grad:
-                    L.check(lib.bfm_loss_grad_l1(L.ptr(raw), n_out, co, L.ptr(tgt), L.ptr(wt), D, H, W, coef, L.ptr(dRaw),
-                                                 slot(name), ws, wsn, st), "loss_grad_l1 " + name)
+                    slot(name)
+                    grads_l1.append((k - 1, co, tgt, wt, coef))
                 else:
                     slot(name)
                     dense.append((k - 1, co, tgt, wt, None, 0.0, 0, coef))
@@ -296,8 +297,8 @@ class TrainStep:
                     co = self._col(head, j)
                     active.add(co)
                     if name == "registration_grad":
-                        L.check(lib.bfm_loss_grad_l1(L.ptr(raw), n_out, co, L.ptr(tgt[j]), None, D, H, W, coef / nch,
-                                                     L.ptr(dRaw), slot(name), ws, wsn, st), "loss_grad_l1 " + name)
+                        slot(name)
+                        grads_l1.append((k - 1, co, tgt[j], None, coef / nch))
                     else:
                         clampv = self.max_dist if head == "distance" else 0.0
                         slot(name)
@@ -345,6 +346,29 @@ class TrainStep:
             wsm = self._ws_multi
             L.check(lib.bfm_loss_l1_multi(L.ptr(raw), n_out, nvox, n, cols, l2s, clamps, coefs, tg, wt, mk, L.ptr(dRaw),
                                           L.ptr(stage), L.ptr(wsm), wsm.numel(), st), "loss_l1_multi")
+            idx = torch.tensor([e[0] for e in batch], dtype=torch.int64, device=self.dev)
+            vals.index_copy_(0, idx, stage)
+        # every gradient-L1 entry in one launch (distinct columns per launch: two entries on one column go to two launches)
+        pending = list(grads_l1)
+        while pending:
+            batch, rest, seen = [], [], set()
+            for e in pending:
+                if e[1] in seen or len(batch) == 32:
+                    rest.append(e)
+                else:
+                    seen.add(e[1])
+                    batch.append(e)
+            pending = rest
+            n = len(batch)
+            cols = (C.c_int32 * n)(*[e[1] for e in batch])
+            coefs = (C.c_float * n)(*[e[4] for e in batch])
+            tg = (C.c_void_p * n)(*[e[2].data_ptr() for e in batch])
+            wt = (C.c_void_p * n)(*[(e[3].data_ptr() if e[3] is not None else None) for e in batch])
+            keep.extend([e[2] for e in batch] + [e[3] for e in batch])
+            stage = torch.empty(n, dtype=torch.float64, device=self.dev)
+            wsm = self._ws_multi
+            L.check(lib.bfm_loss_grad_l1_multi(L.ptr(raw), n_out, n, cols, coefs, tg, wt, D, H, W, L.ptr(dRaw), L.ptr(stage),
+                                               L.ptr(wsm), wsm.numel(), st), "loss_grad_l1_multi")
             idx = torch.tensor([e[0] for e in batch], dtype=torch.int64, device=self.dev)
             vals.index_copy_(0, idx, stage)
         self._keep = keep

@@ -722,6 +722,11 @@ int bfm_loss_l1_multi(const float* raw, int n_out, int64_t nvox, int n, const in
 int bfm_loss_grad_l1(const float* raw, int n_out, int co, const float* target, const float* weight, int D, int H, int W,
                      float coef, float* dRaw, double* loss_out, void* workspace, size_t workspace_bytes,
                      bfm_stream_t stream);
+/* every gradient-L1 entry of a sample in one launch: entry k is bfm_loss_grad_l1 on column cols[k] (distinct columns) with
+ * coef[k], targets[k], weights[k] (or NULL); loss_out[k] as there.  n <= 32; workspace: bfm_loss_l1_multi_workspace(). */
+int bfm_loss_grad_l1_multi(const float* raw, int n_out, int n, const int32_t* cols, const float* coef,
+                           const float* const* targets, const float* const* weights, int D, int H, int W, float* dRaw,
+                           double* loss_out, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
 int bfm_loss_seg(const float* raw, int n_out, int c0, int ns, const float* target, const float* wce, const float* wdice,
                  int64_t nvox, float coef_ce, float coef_dice, float* P, float* dRaw, double* loss_out /*[1+2ns]*/,
                  void* workspace, size_t workspace_bytes, bfm_stream_t stream);
