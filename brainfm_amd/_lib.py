@@ -167,6 +167,7 @@ SIGNATURES = {
     "bfm_tail_heads_rows": (_I, [_P, _P, _L, C.POINTER(TailDesc), _P, _P, _L, _P, _P, _I, _P]),
     "bfm_ew_unary": (_I, [_I, _P, _L, _P, _L, _L, _F, _F, _P]),
     "bfm_ew_binary": (_I, [_I, _P, _L, _P, _L, _P, _L, _L, _F, _P]),
+    "bfm_absmax_f32": (_I, [_P, _L, _L, _L, _P, _P]),
     "bfm_softmax_cl": (_I, [_P, _L, _I, _P, _L, _L, _P]),
     "bfm_argmax_lut_cl": (_I, [_P, _L, _I, _P, _P, _L, _P]),
     "bfm_pathology_encode": (_I, [_P, _P, _P, _P, _F, _F, _F, _F, _L, _P, _P]),

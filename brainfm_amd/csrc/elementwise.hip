@@ -126,7 +126,33 @@ __global__ void pathology_encode(const float* __restrict__ I, const float* __res
     }
 }
 
+// max |x| over `rows` runs of `len` floats, `row_stride` apart (a contiguous tensor: one row), folded into *out with an
+// integer atomicMax on the bit pattern (non-negative floats order like unsigned integers; *out starts at +0): one launch,
+// any order.  NaNs do not take part (fmaxf), as max |w| of finite weights is what the callers want.
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int64_t rows, int64_t len, int64_t row_stride,
+                                                     unsigned* __restrict__ out) {
+    float m = 0.f;
+    const int64_t n = rows * len;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / len;
+        m = fmaxf(m, fabsf(x[r * row_stride + (i - r * len)]));
+    }
+    m = wave_reduce_max(m);
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+
 }  // namespace
+
+extern "C" int bfm_absmax_f32(const float* x, int64_t rows, int64_t len, int64_t row_stride, float* out_zeroed,
+                              bfm_stream_t stream) {
+    if (!x || !out_zeroed || rows <= 0 || len <= 0 || row_stride < len) return BFM_E_ARG;
+    hipLaunchKernelGGL(absmax_kernel, dim3(grid_for(rows * len, 256, 1024)), dim3(256), 0, bfm_s(stream), x, rows, len,
+                       row_stride, reinterpret_cast<unsigned*>(out_zeroed));
+    return bfm_launch_status();
+}
 
 extern "C" int bfm_pathology_encode(const float* I, const float* P, const float* Pprob, const float* randn, float mu0,
                                     float mu1, float s0, float s1, int64_t n, float* out, bfm_stream_t stream) {

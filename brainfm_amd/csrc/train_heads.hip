@@ -147,12 +147,15 @@ __global__ void __launch_bounds__(256) l1_multi_kernel(const float* __restrict__
     }
 }
 
+// one wave per quantity: lane l adds its strided partials in order, then a fixed xor tree (deterministic; one thread
+// walking 1 024 partials of every quantity took 350 us per call)
 __global__ void l1_multi_fold_kernel(const double* __restrict__ part, int nb, int n, double scale, double* __restrict__ out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.x, l = threadIdx.x;
     if (k >= n) return;
     double s_ = 0.0;
-    for (int b = 0; b < nb; ++b) s_ += part[(int64_t)b * L1M_MAX + k];
-    out[k] = s_ * scale;
+    for (int b = l; b < nb; b += 64) s_ += part[(int64_t)b * L1M_MAX + k];
+    s_ = wave_reduce_sum(s_);
+    if (l == 0) out[k] = s_ * scale;
 }
 
 // ----------------------------------------------------------------------------- gradient L1 (GradientLoss 'l1')
@@ -330,11 +333,12 @@ __global__ void __launch_bounds__(256) seg_class_sums_kernel(const float* __rest
 
 // fold the per-block partials: out[0] = CE sum, out[1..ns] = sum p*t, out[1+ns..] = sum (p+t)
 __global__ void seg_fold_kernel(const double* __restrict__ part, int nb, int ns, double* __restrict__ out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int k = blockIdx.x, l = threadIdx.x;                    // one wave per quantity
     if (k >= 1 + 2 * ns) return;
-    double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += part[(int64_t)b * (1 + 2 * ns) + k];
-    out[k] = s;
+    double s_ = 0.0;
+    for (int b = l; b < nb; b += 64) s_ += part[(int64_t)b * (1 + 2 * ns) + k];
+    s_ = wave_reduce_sum(s_);
+    if (l == 0) out[k] = s_;
 }
 
 // pass 2: d(w_ce*CE_mean + w_dice*Dice)/d(logits) through the softmax, added into dRaw
@@ -523,11 +527,12 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ X
     }
 }
 __global__ void colsum_fold_kernel(const double* __restrict__ part, int nb, int n_out, float* __restrict__ out) {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    const int o = blockIdx.x, l = threadIdx.x;                    // one wave per column
     if (o >= n_out) return;
-    double s = 0.0;
-    for (int b = 0; b < nb; ++b) s += part[(int64_t)b * n_out + o];
-    out[o] = (float)s;
+    double s_ = 0.0;
+    for (int b = l; b < nb; b += 64) s_ += part[(int64_t)b * n_out + o];
+    s_ = wave_reduce_sum(s_);
+    if (l == 0) out[o] = (float)s_;
 }
 
 // F.normalize backward: f^ = f / max(|f|, eps);  df = (dF^ - f^ <dF^, f^>) / max(|f|, eps)   (|f| > eps branch)
@@ -668,7 +673,7 @@ extern "C" int bfm_loss_l1_multi(const float* raw, int n_out, int64_t nvox, int 
     hipStream_t st = bfm_s(stream);
     hipLaunchKernelGGL(l1_multi_kernel, dim3(nb), dim3(256), (size_t)2 * tile_vox * ld * sizeof(float), st, raw, n_out, nvox,
                        tile_vox, tab, dRaw, part);
-    hipLaunchKernelGGL(l1_multi_fold_kernel, dim3(1), dim3(64), 0, st, part, nb, n, 1.0 / (double)nvox, loss_out);
+    hipLaunchKernelGGL(l1_multi_fold_kernel, dim3(n), dim3(64), 0, st, part, nb, n, 1.0 / (double)nvox, loss_out);
     return bfm_launch_status();
 }
 
@@ -706,7 +711,7 @@ extern "C" int bfm_loss_grad_l1_multi(const float* raw, int n_out, int n, const 
     double* part = static_cast<double*>(workspace);
     const int nb = grid_for(nvox, RB);
     hipLaunchKernelGGL(grad_l1_multi_kernel, dim3(nb), dim3(256), 0, bfm_s(stream), raw, n_out, tab, D, H, W, dRaw, part);
-    hipLaunchKernelGGL(l1_multi_fold_kernel, dim3(1), dim3(64), 0, bfm_s(stream), part, nb, n, 1.0 / (double)nvox, loss_out);
+    hipLaunchKernelGGL(l1_multi_fold_kernel, dim3(n), dim3(64), 0, bfm_s(stream), part, nb, n, 1.0 / (double)nvox, loss_out);
     return bfm_launch_status();
 }
 
@@ -732,7 +737,7 @@ extern "C" int bfm_loss_seg(const float* raw, int n_out, int c0, int ns, const f
     // blocks past the last voxel chunk still write zeros: the fold below reads all nb rows
     hipLaunchKernelGGL(seg_class_sums_kernel, dim3(nb), dim3(256), 0, st, P, target, ns, nvox, vpb, part);
     double* sums = part + (size_t)RB * (1 + 2 * ns);             // [1 + 2 ns]
-    hipLaunchKernelGGL(seg_fold_kernel, dim3(bfm_cdiv(1 + 2 * ns, 64)), dim3(64), 0, st, part, nb, ns, sums);
+    hipLaunchKernelGGL(seg_fold_kernel, dim3(1 + 2 * ns), dim3(64), 0, st, part, nb, ns, sums);
     if (dRaw) {
         if (tiled)
             hipLaunchKernelGGL(seg_bwd_tile_kernel, dim3(grid_for(nvox, 2048)), dim3(256), tile_bytes, st, P, target, ns, wce, wdice, sums,
@@ -870,7 +875,7 @@ extern "C" int bfm_head_bwd(const float* dRaw, const float* Fn, const float* hea
         hipLaunchKernelGGL(head_bwd_fused_kernel, dim3(nb), dim3(256), smem, st, dRaw, Fn, head_w, n_out, nvox, dFn, wpart, bpart);
         hipLaunchKernelGGL(fold_splits_kernel, dim3(grid_for((int64_t)n_out * C)), dim3(256), 0, st, wpart, nb,
                            (int64_t)n_out * C, dW);
-        hipLaunchKernelGGL(colsum_fold_kernel, dim3(bfm_cdiv(n_out, 64)), dim3(64), 0, st, bpart, nb, n_out, db);
+        hipLaunchKernelGGL(colsum_fold_kernel, dim3(n_out), dim3(64), 0, st, bpart, nb, n_out, db);
         return bfm_launch_status();
     }
     hipLaunchKernelGGL(head_dfeat_kernel, dim3(grid_for(nvox * C)), dim3(256), (size_t)n_out * C * sizeof(float), st, dRaw,
@@ -889,7 +894,7 @@ extern "C" int bfm_head_bwd(const float* dRaw, const float* Fn, const float* hea
     const int64_t vpb = bfm_cdiv64(nvox, nb);
     const int nb2 = (int)bfm_cdiv64(nvox, vpb);
     hipLaunchKernelGGL(colsum_kernel, dim3(nb2), dim3(256), 0, st, dRaw, n_out, nvox, vpb, cpart);
-    hipLaunchKernelGGL(colsum_fold_kernel, dim3(bfm_cdiv(n_out, 64)), dim3(64), 0, st, cpart, nb2, n_out, db);
+    hipLaunchKernelGGL(colsum_fold_kernel, dim3(n_out), dim3(64), 0, st, cpart, nb2, n_out, db);
     return bfm_launch_status();
 }
 

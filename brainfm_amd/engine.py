@@ -286,9 +286,21 @@ class UNetEngine:
         jobs = []                                          # (layer, layout, max|w| tensor)
         self.weights_epoch += 1
 
-        def absmax(t):                                     # one read pass, no |w| copy
-            lo, hi = torch.aminmax(t)
-            return torch.maximum(hi, -lo)
+        slots = torch.zeros(4 * (len(self.enc) + len(self.dec)) * 4 + 16, dtype=torch.float32, device=self.device)
+        nslot = [0]
+
+        def absmax(t):                                     # one launch per tensor into its slot of one vector
+            i = nslot[0]
+            nslot[0] += 1
+            if t.is_contiguous():
+                rows, ln, stride = 1, t.numel(), t.numel()
+            else:                                           # w_raw[:, c0:]: rows of (cin - c0) * 27 floats, cin * 27 apart
+                rows, ln, stride = t.shape[0], t[0].numel(), t.stride(0)
+                if not t[0].is_contiguous():
+                    raise L.BfmError("absmax: unsupported layout")
+            L.check(self.lib.bfm_absmax_f32(L.ptr(t), rows, ln, stride, C.c_void_p(slots.data_ptr() + 4 * i),
+                                            L.stream_ptr()), "absmax")
+            return i
 
         def visit(ly, wm=None):
             used = getattr(ly, "used", None) or set()
@@ -319,11 +331,9 @@ class UNetEngine:
         for pair in self.enc + self.dec:
             for ly in pair:
                 visit(ly)
-        mx = [j[2] for j in jobs if j[2] is not None]
-        host = torch.stack(mx).cpu().tolist() if mx else []
-        it = iter(host)
+        host = slots[:nslot[0]].cpu().tolist() if nslot[0] else []
         for ly, layout, m in jobs:
-            wmax = next(it) if m is not None else None
+            wmax = host[m] if m is not None else None
             if layout == "upfold":
                 self._make_upfold_pack(ly, ly.skip.cin, ly.cin - ly.skip.cin, wmax)
             else:

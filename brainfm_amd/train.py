@@ -165,7 +165,10 @@ class TrainStep:
         """Right after the optimiser: every packed form a layer holds (forward variants, skip half, up-folded, transposed
         data-gradient layer) is rebuilt in place, so the next pass packs nothing lazily."""
         self.eng.repack_all(refresh=BW.refresh_dgrad)
-        self.tail.desc.head_wmax = float(self.tail.head_w.abs().max().item())
+        hw = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        L.check(self.lib.bfm_absmax_f32(L.ptr(self.tail.head_w), 1, self.tail.head_w.numel(), self.tail.head_w.numel(),
+                                        L.ptr(hw), L.stream_ptr()), "absmax head_w")
+        self.tail.desc.head_wmax = float(hw.item())
 
     # ------------------------------------------------------------------ checkpoints (scripts/train.py:205-214)
     def _ref_shape(self, name, t):

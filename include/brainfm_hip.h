@@ -418,6 +418,10 @@ int bfm_ew_unary(int op, const float* in, int64_t in_stride, float* out, int64_t
                  float a, float b, bfm_stream_t stream);
 int bfm_ew_binary(int op, const float* x, int64_t x_stride, const float* y, int64_t y_stride /*0 = broadcast*/,
                   float* out, int64_t out_stride, int64_t n, float a, bfm_stream_t stream);
+/* max |x| over `rows` runs of `len` floats `row_stride` apart, folded into *out_zeroed (device, +0 on entry) by an integer
+ * atomic maximum of the bit pattern: the max |w| the weight packers scale by, one launch per layer without a host round
+ * trip each (training re-packs every layer after AdamW: round 3 used four torch kernels per layer for it). */
+int bfm_absmax_f32(const float* x, int64_t rows, int64_t len, int64_t row_stride, float* out_zeroed, bfm_stream_t stream);
 int bfm_softmax_cl(const float* x, int64_t x_row_stride, int C, float* y, int64_t y_row_stride, int64_t n,
                    bfm_stream_t stream);
 int bfm_argmax_lut_cl(const float* p, int64_t row_stride, int C, const int32_t* lut, int64_t* out, int64_t n,
