@@ -374,13 +374,19 @@ __global__ void seg_bwd_kernel(const float* __restrict__ P, const float* __restr
 // voxels with coalesced row segments, each thread then works on its own voxel's row in LDS (odd stride: no bank
 // conflicts), and the results leave as coalesced rows again.  The per-thread versions above touch memory with a stride of
 // n_out (69) floats per lane: 5.4 + 7.3 ms at 128^3.
+// SUMS: the per-class sums of seg_class_sums_kernel ride along -- thread (j, c) adds p * t and p + t of the tile's voxels
+// j, j + nj, ... from the probabilities it has in LDS (round 4: the separate pass re-read P and the target, 0.95 ms at 128^3)
+template <bool SUMS>
 __global__ void __launch_bounds__(256) seg_fwd_tile_kernel(const float* __restrict__ raw, int n_out, int c0, int ns,
                                                            const float* __restrict__ target, const float* __restrict__ wce,
                                                            int64_t nvox, float* __restrict__ P, double* __restrict__ part) {
     extern __shared__ float tile[];                          // [256][ld]
     __shared__ double red[256];
+    __shared__ double s_pt[SUMS ? 256 : 1], s_ps[SUMS ? 256 : 1];
     const int ld = ns | 1;
     const int t = threadIdx.x;
+    const int nj = 256 / ns, cj = t / ns, cc = t - cj * ns;   // class-sum mapping
+    double sa = 0.0, sb = 0.0;
     double ce = 0.0;
     const int64_t ntile = bfm_cdiv64(nvox, 256);
     for (int64_t tb = blockIdx.x; tb < ntile; tb += gridDim.x) {
@@ -410,9 +416,26 @@ __global__ void __launch_bounds__(256) seg_fwd_tile_kernel(const float* __restri
             const int vl = i / ns, c = i - vl * ns;
             P[vb * ns + i] = tile[vl * ld + c];
         }
+        if (SUMS && cj < nj)
+            for (int vl = cj; vl < nv; vl += nj) {
+                const float p = tile[vl * ld + cc], tc = target[(int64_t)cc * nvox + vb + vl];
+                sa += (double)(p * tc);
+                sb += (double)(p + tc);
+            }
     }
     ce = block_sum(ce, red);
     if (threadIdx.x == 0) part[(int64_t)blockIdx.x * (1 + 2 * ns)] = ce;
+    if (SUMS) {
+        s_pt[t] = sa;
+        s_ps[t] = sb;
+        __syncthreads();
+        if (t < ns) {
+            double a = 0.0, b = 0.0;
+            for (int k = 0; k < nj; ++k) { a += s_pt[k * ns + t]; b += s_ps[k * ns + t]; }
+            part[(int64_t)blockIdx.x * (1 + 2 * ns) + 1 + t] = a;
+            part[(int64_t)blockIdx.x * (1 + 2 * ns) + 1 + ns + t] = b;
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) seg_bwd_tile_kernel(const float* __restrict__ P, const float* __restrict__ target, int ns,
@@ -730,12 +753,14 @@ extern "C" int bfm_loss_seg(const float* raw, int n_out, int c0, int ns, const f
     if (ns > 256 || bfm_cdiv64(nvox, vpb) > nb) return BFM_E_SHAPE;
     const bool tiled = ns <= 61;                                 // 256 rows of (ns | 1) floats + constants within 64 KB
     const size_t tile_bytes = (size_t)(256 * (ns | 1) + 3 * ns) * sizeof(float);
-    if (tiled)
-        hipLaunchKernelGGL(seg_fwd_tile_kernel, dim3(nb), dim3(256), tile_bytes, st, raw, n_out, c0, ns, target, wce, nvox, P, part);
-    else
+    if (tiled) {
+        hipLaunchKernelGGL(seg_fwd_tile_kernel<true>, dim3(nb), dim3(256), tile_bytes, st, raw, n_out, c0, ns, target, wce, nvox, P,
+                           part);
+    } else {
         hipLaunchKernelGGL(seg_fwd_kernel, dim3(nb), dim3(256), 0, st, raw, n_out, c0, ns, target, wce, nvox, P, part);
-    // blocks past the last voxel chunk still write zeros: the fold below reads all nb rows
-    hipLaunchKernelGGL(seg_class_sums_kernel, dim3(nb), dim3(256), 0, st, P, target, ns, nvox, vpb, part);
+        // blocks past the last voxel chunk still write zeros: the fold below reads all nb rows
+        hipLaunchKernelGGL(seg_class_sums_kernel, dim3(nb), dim3(256), 0, st, P, target, ns, nvox, vpb, part);
+    }
     double* sums = part + (size_t)RB * (1 + 2 * ns);             // [1 + 2 ns]
     hipLaunchKernelGGL(seg_fold_kernel, dim3(1 + 2 * ns), dim3(64), 0, st, part, nb, ns, sums);
     if (dRaw) {
