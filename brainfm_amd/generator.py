@@ -419,6 +419,19 @@ class BaseGen(torch.utils.data.Dataset):
                                             L.stream_ptr()), "permute_flip3d")
         return out
 
+    def _flip_axis1(self, t):
+        """torch.flip(t, [1]) of a (1, sx, sy, sz) target (datasets.py:676-679, 752-755) through the same mirrored gather:
+        an fp64 volume is flipped as its fp32 pairs along the last axis, which the flip along x leaves together."""
+        if not (isinstance(t, torch.Tensor) and t.dim() == 4 and t.shape[0] == 1 and t.is_cuda
+                and t.dtype in (torch.float32, torch.float64)):
+            return torch.flip(t, [1])
+        v = t[0].contiguous()
+        if v.dtype == torch.float64:
+            out = self._flip0(v.view(torch.float32)).view(torch.float64)
+        else:
+            out = self._flip0(v)
+        return out[None]
+
     def read_and_deform_image(self, task, vol, setups, deform_dict):
         """Generator/utils.py:331-345: sample, I -= min, I /= max, flip -- min / max never leave the device."""
         out = torch.empty(tuple(deform_dict["grid"][0].shape), dtype=torch.float32, device=self.device)
@@ -753,8 +766,8 @@ class BaseGen(torch.utils.data.Dataset):
             sample = self.augment_sample(case_name, img, setups, deform_dict, res, target,
                                          pathol_direction=self.get_pathology_direction(input_mode), input_mode=input_mode)
         if setups["flip"] and isinstance(target["pathology"], torch.Tensor):
-            target["pathology"] = torch.flip(target["pathology"], [1])
-            target["pathology_prob"] = torch.flip(target["pathology_prob"], [1])
+            target["pathology"] = self._flip_axis1(target["pathology"])
+            target["pathology_prob"] = self._flip_axis1(target["pathology_prob"])
         return self.datasets_num, dataset_name, input_mode, target, sample
 
 
@@ -787,8 +800,8 @@ class BrainIDGen(BaseGen):
                                              input_mode=input_mode)
             samples.append(sample)
         if setups["flip"] and isinstance(target["pathology"], torch.Tensor):
-            target["pathology"] = torch.flip(target["pathology"], [1])
-            target["pathology_prob"] = torch.flip(target["pathology_prob"], [1])
+            target["pathology"] = self._flip_axis1(target["pathology"])
+            target["pathology_prob"] = self._flip_axis1(target["pathology_prob"])
         return self.datasets_num, dataset_name, input_mode, target, samples
 
 
