@@ -51,7 +51,8 @@ class DeviceVolumes:
     host (Generator/utils.py:296-305: nib.load -> get_fdata()[box] -> torch.tensor -> device); a case is ~10 volumes of
     ~30 MB, so a few hundred cases fit in a fraction of the 288 GB and an item never touches the host copy again: the
     crop becomes a box inside the resident volume.  Least-recently-used volumes are dropped beyond `budget` bytes
-    (BFM_GEN_CACHE_GB, default 64)."""
+    (BFM_GEN_CACHE_GB, default 64).  A volume is keyed by the identity of its source object: a case array that is
+    modified in place afterwards keeps its resident copy (call `forget(vol)` or build a new dataset)."""
 
     def __init__(self, device, budget=None):
         self.device = device
@@ -72,6 +73,13 @@ class DeviceVolumes:
         if not (np.issubdtype(arr.dtype, np.floating) or np.issubdtype(arr.dtype, np.integer)):
             arr = arr.astype(np.float64)
         return arr
+
+    def forget(self, vol=None):
+        """Drop the resident copies of one source (or of all of them)."""
+        src = None if vol is None else (vol._d if isinstance(vol, ArrayVolume) else vol)
+        for key in [k for k in self.items if src is None or k[0] == id(src)]:
+            t, _ = self.items.pop(key)
+            self.bytes -= t.numel() * 4
 
     def get(self, vol, kind="f32", mean=0., scale=1.):
         """The whole volume as float32 (`kind` 'f32': what torch.tensor(get_fdata().astype(float), dtype=torch.float)
@@ -139,7 +147,8 @@ class BaseGen(torch.utils.data.Dataset):
         self.cases = cases or []
         self.volumes = DeviceVolumes(self.device)
         self._batch = None                                # pending gather jobs while _targets collects them
-        self._psum = (None, 0.0)                          # (id of target['pathology'], its sum) known to the host
+        self._psum = (None, 0.0)                          # (target['pathology'] tensor, its sum) as the host knows it; the
+                                                          # tensor is HELD, so its address cannot be handed to another one
         self.datasets_num = 1
         self.pathology_type = None
         self.hemis_mask = None
@@ -494,7 +503,7 @@ class BaseGen(torch.utils.data.Dataset):
         def zeros():
             z = {"pathology": torch.zeros(shape, device=self.device)[None],
                  "pathology_prob": torch.zeros(shape, device=self.device)[None]}
-            self._psum = (z["pathology"].data_ptr(), 0.0)
+            self._psum = (z["pathology"], 0.0)
             return z
 
         if source is None:
@@ -517,7 +526,7 @@ class BaseGen(torch.utils.data.Dataset):
         total = float(psum.item())
         if total / P.numel() <= self.shape_gen_args.pathol_tol:
             return zeros()
-        self._psum = (P.data_ptr(), total)
+        self._psum = (P, total)
         return {"pathology": P[None], "pathology_prob": Pdef[None]}
 
     def _pathology_sum(self, target):
@@ -526,7 +535,8 @@ class BaseGen(torch.utils.data.Dataset):
         P = target.get("pathology") if hasattr(target, "get") else None
         if not isinstance(P, torch.Tensor):
             return 0.0
-        if self._psum[0] == P.data_ptr():
+        held = self._psum[0]
+        if held is not None and held.data_ptr() == P.data_ptr() and held.numel() == P.numel():
             return self._psum[1]
         return float(P.sum().item())
 
@@ -693,7 +703,7 @@ class BaseGen(torch.utils.data.Dataset):
             ws = GU.workspace(self.device, lib.bfm_shape_workspace())
             L.check(lib.bfm_pathology_mask(L.ptr(P), L.ptr(Pprob), int(P.dtype == torch.float64), L.ptr(cer), cer.numel(),
                                            L.ptr(psum), L.ptr(ws), ws.numel(), L.stream_ptr()), "pathology_mask")
-            self._psum = (P.data_ptr(), float(psum.item()))
+            self._psum = (P, float(psum.item()))
             pathol_direction = self.get_pathology_direction("synth", DeviceDirection(stats))
         else:
             pathol_direction = None

@@ -338,6 +338,10 @@ def test_generator_item_is_repeatable_and_its_volumes_stay_resident():
     for v in case["distance"]:
         small.get(G.ArrayVolume(v), "f32")
     assert len(small.items) == 3 and small.bytes == 3 * int(np.prod(shp)) * 4
+    small.forget(G.ArrayVolume(case["distance"][3]))
+    assert len(small.items) == 2
+    small.forget()
+    assert len(small.items) == 0 and small.bytes == 0
 
 
 @pytest.mark.parametrize("tag,nt", [("ode64", 6), ("ode32", 4)])
