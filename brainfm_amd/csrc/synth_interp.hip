@@ -358,12 +358,27 @@ __global__ void __launch_bounds__(256) conv1d_slab(const float* __restrict__ in,
             const int64_t base = (AXIS == 0 ? (int64_t)o * nz : (int64_t)o * ny * nz) + z0;
             const int z = z0 + lane;
             __syncthreads();
-            for (int p = lo + w; p < hi; p += 4) slab[(p - lo) * 65 + lane] = z < nz ? in[base + (int64_t)p * stride + lane] : 0.f;
+            // eight rows in flight per wave before the first LDS store (one load -> wait -> store per row serialised the
+            // slab's ~12 rows per wave behind 12 memory round trips: 15 us per pass whatever the tap count)
+            for (int p = lo + w; p < hi; p += 32) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int q = p + 4 * u;
+                    v[u] = (q < hi && z < nz) ? in[base + (int64_t)q * stride + lane] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int q = p + 4 * u;
+                    if (q < hi) slab[(q - lo) * 65 + lane] = v[u];
+                }
+            }
             __syncthreads();
             if (z < nz)
                 for (int p = p0 + w; p < p1; p += 4) {
                     const int j0 = max(0, half - p), j1 = min(klen, len + half - p);
                     float acc = 0.f;
+#pragma unroll 4
                     for (int j = j0; j < j1; ++j) acc = fmaf(taps[j], slab[(p + j - half - lo) * 65 + lane], acc);
                     out[base + (int64_t)p * stride + lane] = acc;
                 }
@@ -376,9 +391,21 @@ __global__ void __launch_bounds__(256) conv1d_slab(const float* __restrict__ in,
             const int r0 = sl * C1D_ROWS, nr = min(C1D_ROWS, rows - r0);
             const int64_t base = (int64_t)r0 * nz;
             __syncthreads();
-            for (int e = threadIdx.x; e < nr * len; e += 256) {      // consecutive rows are one contiguous run
-                const int r = e / len, z = e - r * len;
-                slab[r * ld + z] = in[base + e];
+            for (int e0 = threadIdx.x; e0 < nr * len; e0 += 256 * 8) {      // consecutive rows are one contiguous run
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + 256 * u;
+                    v[u] = e < nr * len ? in[base + e] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + 256 * u;
+                    if (e < nr * len) {
+                        const int r = e / len, z = e - r * len;
+                        slab[r * ld + z] = v[u];
+                    }
+                }
             }
             __syncthreads();
             for (int e = threadIdx.x; e < nr * len; e += 256) {
@@ -386,6 +413,7 @@ __global__ void __launch_bounds__(256) conv1d_slab(const float* __restrict__ in,
                 const int j0 = max(0, half - z), j1 = min(klen, len + half - z);
                 const float* p = slab + r * ld + z - half;
                 float acc = 0.f;
+#pragma unroll 4
                 for (int j = j0; j < j1; ++j) acc = fmaf(taps[j], p[j], acc);
                 out[base + e] = acc;
             }
