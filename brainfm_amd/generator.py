@@ -66,6 +66,8 @@ class DeviceVolumes:
             arr = src
         elif hasattr(src, "dataobj"):
             arr = np.asarray(src.dataobj)
+            if arr.dtype == object or arr.ndim < 3:             # a proxy NumPy cannot read as an array: take the float copy
+                arr = src.get_fdata()
         else:
             arr = src.get_fdata()
         while arr.ndim > 3 and arr.shape[-1] == 1:

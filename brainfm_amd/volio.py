@@ -201,6 +201,11 @@ class _Sliceable:
     def __init__(self, img):
         self.img = img
 
+    def __array__(self, dtype=None, copy=None):
+        """np.asarray(img.dataobj): the whole volume in its stored type (scaled like get_fdata when the header says so)."""
+        arr = self[tuple(slice(None) for _ in self.img.shape)]
+        return arr if dtype is None else arr.astype(dtype)
+
     def __getitem__(self, idx):
         img = self.img
         if isinstance(img, _Nifti1) and not img.filename.endswith(".gz"):

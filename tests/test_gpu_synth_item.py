@@ -381,3 +381,48 @@ def test_dopri5_with_the_controller_on_the_device_equals_the_host_loop(tag, nt, 
         if mult == 6:
             assert np.isfinite(out["0"][0]).all()
             assert np.abs(out["1"][0] - out["0"][0]).max() <= (1e-10 if tag == "ode64" else 1e-5) * np.abs(out["0"][0]).max()
+
+
+def test_generator_item_from_volume_files_equals_the_in_memory_case(tmp_path):
+    """A case whose volumes are NIfTI / MGH files opened with brainfm_amd.volio.load (nibabel's interface: shape, affine,
+    dataobj, get_fdata -- what the reference's nib.load hands to Generator/utils.py:296-305) gives the item of the same
+    volumes passed as arrays, bit for bit: the resident copy is made from dataobj / get_fdata once, in the dtype the
+    reference converts to."""
+    import random
+    from brainfm_amd import generator as G, volio
+    import test_gpu_synth as SY
+    rs = np.random.RandomState(1)
+    shp = (44, 48, 40)
+    zz, yy, xx = np.meshgrid(*[np.arange(s) for s in shp], indexing="ij")
+    ell = (((zz - 22) / 18.) ** 2 + ((yy - 24) / 20.) ** 2 + ((xx - 20) / 17.) ** 2) <= 1
+    lab = ((zz // 8) * 5 + (yy // 8) * 3 + (xx // 8)) % 10
+    ids = (np.array([2, 3, 4, 41, 42, 17, 10, 11, 12, 13])[lab] * ell)
+    mem = {"name": "c", "Gen": ids.astype(np.float32), "T1": (rs.rand(*shp) * ell).astype(np.float32),
+           "segmentation": ids.astype(np.int32),
+           "distance": [(rs.rand(*shp) * 255).astype(np.float32) for _ in range(4)],
+           "registration": [(rs.randn(*shp) * 500).astype(np.float32) for _ in range(3)]}
+    aff = np.diag([1.0, 1.0, 1.0, 1.0])
+
+    def on_disk(name, arr, ext):
+        path = str(tmp_path / (name + ext))
+        volio.MRIwrite(arr, aff, path)
+        return volio.load(path)
+
+    files = {"name": "c", "Gen": on_disk("gen", mem["Gen"], ".nii.gz"), "T1": on_disk("t1", mem["T1"], ".mgz"),
+             "segmentation": on_disk("seg", mem["segmentation"], ".nii"),
+             "distance": [on_disk("d%d" % i, v, ".nii.gz") for i, v in enumerate(mem["distance"])],
+             "registration": [on_disk("r%d" % i, v, ".nii") for i, v in enumerate(mem["registration"])]}
+
+    def run(case):
+        np.random.seed(5); torch.manual_seed(5); random.seed(5)
+        ds = G.build_datasets(SY._gen_args(), DEV, cases=[case])["all"]
+        return ds[0]
+
+    _, _, _, t1, s1 = run(mem)
+    _, _, _, t2, s2 = run(files)
+    for k in t1:
+        if isinstance(t1[k], torch.Tensor):
+            assert torch.equal(t1[k], t2[k]), k
+    for a, b in zip(s1, s2):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
