@@ -154,6 +154,11 @@ SIGNATURES = {
     "bfm_loss_seg": (_I, [_P, _I, _I, _I, _P, _P, _P, _L, _F, _F, _P, _P, _P, _P, _Z, _P]),
     "bfm_head_bwd_workspace": (_Z, [_I, _I, _L]),
     "bfm_head_bwd": (_I, [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _Z, _P]),
+    "bfm_tail_raw_rows": (_I, [_P, _L, C.POINTER(TailDesc), _P, _P, _L, _P]),
+    "bfm_loss_l1_multi_rows": (_I, [_P, _L, _I, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P]),
+    "bfm_loss_grad_l1_multi_rows": (_I, [_P, _L, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _Z, _P]),
+    "bfm_loss_seg_rows": (_I, [_P, _L, _I, _I, _I, _P, _P, _P, _L, _F, _F, _P, _P, _P, _P, _Z, _P]),
+    "bfm_head_bwd_rows": (_I, [_P, _L, _P, _P, _I, _I, _L, _P, _P, _P, _P, _Z, _P]),
     "bfm_normalize_bwd": (_I, [_P, _P, _I, _L, _F, _P, _P]),
     "bfm_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
     "bfm_grad_sumsq": (_I, [_P, _L, _P, _P, _P, _Z, _P]),

@@ -44,6 +44,7 @@ struct TailParams {
     int64_t* label;
     float* raw_out;
     int n_maps;
+    int64_t raw_stride;     // > 0: raw_out as [n_out] rows of this pitch (the training losses' layout), else [nvox][n_out]
 };
 
 // exp on the hardware exp2 unit: |rel err| ~ 1e-6 for the argument ranges below (softmax <= 0, tanh via exp)
@@ -265,11 +266,18 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
         wave_lds_sync();
 
         if (p.raw_out) {                                      // TaskHead.forward only: raw logits, channels-last
-            const int n = nv * NO;
-            float* dst = p.raw_out + v0 * NO;
-            for (int i = lane; i < n; i += 64) {
-                int r = i / NO, o = i - r * NO;
-                dst[i] = slab[r * ld + o];
+            if (p.raw_stride > 0) {                           // one 256-byte row segment per output
+                if (lane < nv) {
+                    float* dst = p.raw_out + v0 + lane;
+                    for (int o = 0; o < NO; ++o) dst[(int64_t)o * p.raw_stride] = row[o];
+                }
+            } else {
+                const int n = nv * NO;
+                float* dst = p.raw_out + v0 * NO;
+                for (int i = lane; i < n; i += 64) {
+                    int r = i / NO, o = i - r * NO;
+                    dst[i] = slab[r * ld + o];
+                }
             }
             wave_lds_sync();
             continue;
@@ -390,7 +398,7 @@ __global__ void __launch_bounds__(TPBT, 2) tail_kernel(TailParams p, int ld, int
 
 static int tail_launch(const float* feat, const float* input, int64_t nvox, const bfm_tail_desc_t* desc,
                        float* feat_norm, float* const* maps_tab, float* maps_rows, int64_t row_stride, float* seg_prob,
-                       int64_t* label, float* raw_out, int skip_zero_input, bfm_stream_t stream) {
+                       int64_t* label, float* raw_out, int skip_zero_input, bfm_stream_t stream, int64_t raw_stride = 0) {
     if (!feat || !desc || nvox <= 0 || !desc->head_w || !desc->head_b || !desc->roles || !desc->out_slot)
         return BFM_E_ARG;
     const bool maps = maps_tab != nullptr || maps_rows != nullptr;
@@ -408,7 +416,7 @@ static int tail_launch(const float* feat, const float* input, int64_t nvox, cons
     for (int o = 0; o < desc->n_out; ++o) (void)o;
     if (maps && (desc->slot_high_res >= n_maps || desc->slot_fake_cortical >= n_maps)) return BFM_E_SHAPE;
     TailParams p{feat, input, nvox, *desc, feat_norm, maps_tab, maps_tab ? nullptr : maps_rows, row_stride, seg_prob, label,
-                 raw_out, n_maps};
+                 raw_out, n_maps, raw_stride};
     if (skip_zero_input) p.d.skip_zero_input = 1;
     const int ld = (desc->n_out > 0 ? desc->n_out : 1) | 1;        // odd row stride: conflict-free column access
     int64_t nb = bfm_cdiv64(bfm_cdiv64(nvox, 64), WPB);
@@ -459,4 +467,13 @@ extern "C" int bfm_tail_heads_rows(const float* feat, const float* input, int64_
     if (!maps_rows || (flags & ~1)) return BFM_E_ARG;
     return tail_launch(feat, input, nvox, desc, feat_norm, nullptr, maps_rows, row_stride, seg_prob, label, nullptr,
                        flags & 1, stream);
+}
+
+// TaskHead.forward alone with the logits as [n_out] rows of nvox values (row pitch row_stride): the layout the training
+// losses and bfm_head_bwd_rows walk (train_heads.hip).  Same arithmetic as bfm_tail_heads(..., raw_out).
+extern "C" int bfm_tail_raw_rows(const float* feat, int64_t nvox, const bfm_tail_desc_t* desc, float* feat_norm,
+                                 float* raw_rows, int64_t row_stride, bfm_stream_t stream) {
+    if (!raw_rows || row_stride < nvox) return BFM_E_ARG;
+    return tail_launch(feat, nullptr, nvox, desc, feat_norm, nullptr, nullptr, 0, nullptr, nullptr, raw_rows, 0, stream,
+                       row_stride);
 }

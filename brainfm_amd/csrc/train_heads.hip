@@ -652,6 +652,206 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g,
 
 int grid_for(int64_t n, int cap = 4096) { return (int)std::min<int64_t>(cap, std::max<int64_t>(1, bfm_cdiv64(n, 256))); }
 
+
+// ============================================================================ "rows" layout of the head outputs (round 4)
+// raw / dRaw as [n_out] rows of nvox values (row pitch rs >= nvox) instead of [nvox][n_out]: what the loss kernels walk is
+// a handful of columns per entry, which in the channels-last form costs one 4-byte element out of every 276-byte voxel row
+// (the LDS-tiled kernels above recover coalescing by staging whole rows, at 1.4-1.6 ms per pass at 128^3).  In rows every
+// access of a wave is one 256-byte segment, nothing goes through LDS and each kernel is one grid-stride loop with the SAME
+// per-voxel expressions as its channels-last twin (tests compare the two layouts bit for bit where the order allows).
+__global__ void __launch_bounds__(256) l1_multi_rows_kernel(const float* __restrict__ raw, int64_t rs, int64_t nvox,
+                                                            const L1Table tab, float* dRaw,
+                                                            double* __restrict__ part /*[nb][L1M_MAX]*/) {
+    __shared__ double red[256];
+    double acc[L1M_MAX];
+#pragma unroll
+    for (int k = 0; k < L1M_MAX; ++k) acc[k] = 0.0;
+    GRID_STRIDE(v, nvox) {
+#pragma unroll
+        for (int k = 0; k < L1M_MAX; ++k) {
+            if (k >= tab.n) continue;
+            const L1Entry& e = tab.e[k];
+            float o = raw[(int64_t)e.col * rs + v];
+            bool live = true;
+            if (e.clampv > 0.f) {
+                if (o > e.clampv) { o = e.clampv; live = false; }
+                else if (o < -e.clampv) { o = -e.clampv; live = false; }
+            }
+            const float m = e.mask ? e.mask[v] : 1.f;
+            const float w = e.weight ? e.weight[v] : 1.f;
+            const float d = o * m - e.target[v] * m;
+            acc[k] += (double)((e.l2 ? d * d : fabsf(d)) * w);
+            const float sg = e.l2 ? 2.f * d : (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+            if (live && dRaw) dRaw[(int64_t)e.col * rs + v] += e.coef * sg * w * m;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < L1M_MAX; ++k) {
+        if (k >= tab.n) continue;
+        const double sk = block_sum(acc[k], red);
+        if (threadIdx.x == 0) part[(int64_t)blockIdx.x * L1M_MAX + k] = sk;
+    }
+}
+
+__global__ void __launch_bounds__(256) grad_l1_multi_rows_kernel(const float* __restrict__ raw, int64_t rs, const GL1Table tab,
+                                                                 int D, int H, int W, float* __restrict__ dRaw,
+                                                                 double* __restrict__ part /*[nb][L1M_MAX]*/) {
+    __shared__ double red[256];
+    const int64_t nvox = (int64_t)D * H * W;
+    const int64_t s = (int64_t)H * W;
+    double acc[L1M_MAX];
+#pragma unroll
+    for (int k = 0; k < L1M_MAX; ++k) acc[k] = 0.0;
+    GRID_STRIDE(v, nvox) {
+        const int x = (int)(v % W);
+        const int64_t t2 = v / W;
+        const int y = (int)(t2 % H), z = (int)(t2 / H);
+#pragma unroll
+        for (int k = 0; k < L1M_MAX; ++k) {
+            if (k >= tab.n) continue;
+            const GL1Entry& e = tab.e[k];
+            const float* target = e.target;
+            const float* weight = e.weight;
+            const float* r0 = raw + (int64_t)e.col * rs + v;
+            const float o = r0[0], t = target[v];
+            const float w = weight ? weight[v] : 1.f;
+            float g = 0.f;
+            double a = 0.0;
+            if (x + 1 < W) {
+                const float d = (r0[1] - o) - (target[v + 1] - t);
+                a += (double)(fabsf(d) * w);
+                g -= (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * w;
+            }
+            if (y + 1 < H) {
+                const float d = (r0[W] - o) - (target[v + W] - t);
+                a += (double)(fabsf(d) * w);
+                g -= (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * w;
+            }
+            if (z + 1 < D) {
+                const float d = (r0[s] - o) - (target[v + s] - t);
+                a += (double)(fabsf(d) * w);
+                g -= (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * w;
+            }
+            if (x > 0) {
+                const float d = (o - r0[-1]) - (t - target[v - 1]);
+                g += (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * (weight ? weight[v - 1] : 1.f);
+            }
+            if (y > 0) {
+                const float d = (o - r0[-W]) - (t - target[v - W]);
+                g += (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * (weight ? weight[v - W] : 1.f);
+            }
+            if (z > 0) {
+                const float d = (o - r0[-s]) - (t - target[v - s]);
+                g += (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * (weight ? weight[v - s] : 1.f);
+            }
+            acc[k] += a;
+            if (dRaw) dRaw[(int64_t)e.col * rs + v] += e.coef * g;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < L1M_MAX; ++k) {
+        if (k >= tab.n) continue;
+        const double sk = block_sum(acc[k], red);
+        if (threadIdx.x == 0) part[(int64_t)blockIdx.x * L1M_MAX + k] = sk;
+    }
+}
+
+// softmax + CE of one voxel per thread, the logits of its ns <= LIM classes in registers; P leaves as [ns][nvox] rows
+template <int LIM>
+__global__ void __launch_bounds__(256) seg_fwd_rows_kernel(const float* __restrict__ raw, int64_t rs, int c0, int ns,
+                                                           const float* __restrict__ target, const float* __restrict__ wce,
+                                                           int64_t nvox_, float* __restrict__ P, double* __restrict__ part) {
+    __shared__ double red[256];
+    double ce = 0.0;
+    int64_t nvox = nvox_;
+    GRID_STRIDE(v, nvox_) {
+        asm volatile("" : "+s"(nvox));
+        // (opaque per iteration: hoisted out of the voxel loop, the LIM row addresses take 2 LIM scalar registers and spill)
+        asm volatile("" : "+s"(rs));
+        const float* r = raw + (int64_t)c0 * rs + v;
+        float sv[LIM];
+#pragma unroll
+        for (int c = 0; c < LIM; ++c) sv[c] = c < ns ? r[(int64_t)c * rs] : -INFINITY;
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < LIM; ++c) if (c < ns) m = fmaxf(m, sv[c]);
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < LIM; ++c) if (c < ns) sum += expf(sv[c] - m);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int c = 0; c < LIM; ++c) {
+            if (c < ns) {
+                const float pr = expf(sv[c] - m) * inv;
+                P[(int64_t)c * nvox + v] = pr;
+                ce -= (double)(logf(fmaxf(pr, 1e-5f)) * wce[c] * target[(int64_t)c * nvox + v]);
+            }
+        }
+    }
+    ce = block_sum(ce, red);
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.x * (1 + 2 * ns)] = ce;
+}
+
+// class sums of one (voxel chunk, class): both operands are rows
+__global__ void __launch_bounds__(256) seg_class_sums_rows_kernel(const float* __restrict__ P, const float* __restrict__ target,
+                                                                  int ns, int64_t nvox, int64_t vox_per_block,
+                                                                  double* __restrict__ part) {
+    __shared__ double red[256];
+    const int c = blockIdx.y;
+    const int64_t v0 = (int64_t)blockIdx.x * vox_per_block, v1 = min(nvox, v0 + vox_per_block);
+    const float* p = P + (int64_t)c * nvox;
+    const float* t = target + (int64_t)c * nvox;
+    double a = 0.0, b = 0.0;
+    for (int64_t v = v0 + threadIdx.x; v < v1; v += 256) {
+        const float pv = p[v], tc = t[v];
+        a += (double)(pv * tc);
+        b += (double)(pv + tc);
+    }
+    a = block_sum(a, red);
+    b = block_sum(b, red);
+    if (threadIdx.x == 0) {
+        part[(int64_t)blockIdx.x * (1 + 2 * ns) + 1 + c] = a;
+        part[(int64_t)blockIdx.x * (1 + 2 * ns) + 1 + ns + c] = b;
+    }
+}
+
+template <int LIM>
+__global__ void __launch_bounds__(256) seg_bwd_rows_kernel(const float* __restrict__ P, const float* __restrict__ target, int ns,
+                                                           const float* __restrict__ wce, const float* __restrict__ wdice,
+                                                           const double* __restrict__ sums, int64_t nvox_, float coef_ce,
+                                                           float coef_dice, int64_t rs, int c0, float* __restrict__ dRaw) {
+    __shared__ float ka[LIM], k1[LIM], k0[LIM];
+    for (int c = threadIdx.x; c < ns; c += 256) {
+        ka[c] = coef_ce * wce[c];
+        const double num = sums[1 + c], den = sums[1 + ns + c];
+        const double k = (double)coef_dice * (double)wdice[c];
+        k1[c] = den > 1e-5 ? (float)(-2.0 * k / den) : 0.f;
+        k0[c] = den > 1e-5 ? (float)(2.0 * k * num / (den * den)) : 0.f;
+    }
+    __syncthreads();
+    int64_t nvox = nvox_;
+    GRID_STRIDE(v, nvox_) {
+        asm volatile("" : "+s"(nvox), "+s"(rs));              // see seg_fwd_rows_kernel
+        float pv[LIM], gv[LIM];
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < LIM; ++c) {
+            if (c < ns) {
+                const float pc = P[(int64_t)c * nvox + v], tc = target[(int64_t)c * nvox + v];
+                float g = tc * k1[c] + k0[c];
+                if (pc > 1e-5f) g -= ka[c] * tc / pc;         // clamp(min=1e-5) kills the gradient below it
+                dot += g * pc;
+                pv[c] = pc;
+                gv[c] = g;
+            }
+        }
+        float* d = dRaw + (int64_t)c0 * rs + v;
+#pragma unroll
+        for (int c = 0; c < LIM; ++c)
+            if (c < ns) d[(int64_t)c * rs] += pv[c] * (gv[c] - dot);                     // softmax Jacobian
+    }
+}
+
 }  // namespace
 
 extern "C" size_t bfm_loss_workspace(int ns) { return (size_t)RB * (1 + 2 * (ns > 0 ? ns : 0)) * sizeof(double) + 4096; }
@@ -785,6 +985,7 @@ extern "C" int bfm_loss_seg(const float* raw, int n_out, int c0, int ns, const f
 constexpr int HB_TV = 64, HB_C = 64, HB_BLOCKS = 768, HB_MAXO = 96;
 __global__ void __launch_bounds__(256) head_bwd_fused_kernel(const float* __restrict__ dRaw, const float* __restrict__ Fn,
                                                              const float* __restrict__ Wt, int n_out, int64_t nvox,
+                                                             int64_t rs /* > 0: dRaw as [n_out] rows of pitch rs */,
                                                              float* __restrict__ dFn, float* __restrict__ wpart,
                                                              double* __restrict__ bpart) {
     extern __shared__ float hsm[];
@@ -808,9 +1009,16 @@ __global__ void __launch_bounds__(256) head_bwd_fused_kernel(const float* __rest
         const int64_t v0 = tb * HB_TV;
         const int nv = (int)min<int64_t>(HB_TV, nvox - v0);
         __syncthreads();
-        for (int i = t; i < HB_TV * n_out; i += 256) {            // the tile's rows are one contiguous run of dRaw
-            const int vl = i / n_out, o = i - vl * n_out;
-            sR[vl * ldr + o] = vl < nv ? dRaw[v0 * n_out + i] : 0.f;
+        if (rs > 0) {
+            for (int i = t; i < HB_TV * n_out; i += 256) {        // one 256-byte segment of a row per wave
+                const int o = i >> 6, vl = i & (HB_TV - 1);
+                sR[vl * ldr + o] = vl < nv ? dRaw[(int64_t)o * rs + v0 + vl] : 0.f;
+            }
+        } else {
+            for (int i = t; i < HB_TV * n_out; i += 256) {        // the tile's rows are one contiguous run of dRaw
+                const int vl = i / n_out, o = i - vl * n_out;
+                sR[vl * ldr + o] = vl < nv ? dRaw[v0 * n_out + i] : 0.f;
+            }
         }
         for (int i = t; i < HB_TV * (ldr - n_out); i += 256) {    // the padding columns
             const int vl = i / (ldr - n_out), o = n_out + (i - vl * (ldr - n_out));
@@ -882,14 +1090,16 @@ extern "C" size_t bfm_head_bwd_workspace(int n_out, int C, int64_t nvox) {
     return std::max(unfused, fused);
 }
 
-extern "C" int bfm_head_bwd(const float* dRaw, const float* Fn, const float* head_w, int n_out, int C, int64_t nvox,
-                            float* dW, float* db, float* dFn, void* workspace, size_t workspace_bytes,
-                            bfm_stream_t stream) {
+static int head_bwd_launch(const float* dRaw, int64_t row_stride, const float* Fn, const float* head_w, int n_out, int C,
+                           int64_t nvox, float* dW, float* db, float* dFn, void* workspace, size_t workspace_bytes,
+                           bfm_stream_t stream) {
     if (!dRaw || !Fn || !head_w || !dW || !db || !dFn || !workspace || n_out <= 0 || C <= 0 || nvox <= 0) return BFM_E_ARG;
     if (workspace_bytes < bfm_head_bwd_workspace(n_out, C, nvox)) return BFM_E_WORKSPACE;
     if ((size_t)n_out * C * sizeof(float) > 64 * 1024) return BFM_E_SHAPE;
     hipStream_t st = bfm_s(stream);
-    if (C == HB_C && n_out <= HB_MAXO && (reinterpret_cast<uintptr_t>(Fn) & 15) == 0) {
+    const bool fused = C == HB_C && n_out <= HB_MAXO && (reinterpret_cast<uintptr_t>(Fn) & 15) == 0;
+    if (row_stride > 0 && !fused) return BFM_E_SHAPE;             // the rows layout exists for the one-pass kernel only
+    if (fused) {
         const int ldr = (n_out + 2) | 1, K2 = (n_out + 1) & ~1;
         const size_t smem = ((size_t)HB_TV * ldr + (size_t)HB_TV * HB_C + (size_t)K2 * HB_C) * sizeof(float);
         const int64_t ntile = (nvox + HB_TV - 1) / HB_TV;
@@ -897,7 +1107,8 @@ extern "C" int bfm_head_bwd(const float* dRaw, const float* Fn, const float* hea
         float* wpart = static_cast<float*>(workspace);
         double* bpart = reinterpret_cast<double*>(static_cast<char*>(workspace) +
                                                   (((size_t)HB_BLOCKS * n_out * C * sizeof(float) + 255) & ~(size_t)255));
-        hipLaunchKernelGGL(head_bwd_fused_kernel, dim3(nb), dim3(256), smem, st, dRaw, Fn, head_w, n_out, nvox, dFn, wpart, bpart);
+        hipLaunchKernelGGL(head_bwd_fused_kernel, dim3(nb), dim3(256), smem, st, dRaw, Fn, head_w, n_out, nvox, row_stride, dFn,
+                           wpart, bpart);
         hipLaunchKernelGGL(fold_splits_kernel, dim3(grid_for((int64_t)n_out * C)), dim3(256), 0, st, wpart, nb,
                            (int64_t)n_out * C, dW);
         hipLaunchKernelGGL(colsum_fold_kernel, dim3(n_out), dim3(64), 0, st, bpart, nb, n_out, db);
@@ -920,6 +1131,104 @@ extern "C" int bfm_head_bwd(const float* dRaw, const float* Fn, const float* hea
     const int nb2 = (int)bfm_cdiv64(nvox, vpb);
     hipLaunchKernelGGL(colsum_kernel, dim3(nb2), dim3(256), 0, st, dRaw, n_out, nvox, vpb, cpart);
     hipLaunchKernelGGL(colsum_fold_kernel, dim3(n_out), dim3(64), 0, st, cpart, nb2, n_out, db);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_head_bwd(const float* dRaw, const float* Fn, const float* head_w, int n_out, int C, int64_t nvox,
+                            float* dW, float* db, float* dFn, void* workspace, size_t workspace_bytes,
+                            bfm_stream_t stream) {
+    return head_bwd_launch(dRaw, 0, Fn, head_w, n_out, C, nvox, dW, db, dFn, workspace, workspace_bytes, stream);
+}
+
+extern "C" int bfm_head_bwd_rows(const float* dRaw_rows, int64_t row_stride, const float* Fn, const float* head_w, int n_out,
+                                 int C, int64_t nvox, float* dW, float* db, float* dFn, void* workspace,
+                                 size_t workspace_bytes, bfm_stream_t stream) {
+    if (row_stride < nvox) return BFM_E_ARG;
+    return head_bwd_launch(dRaw_rows, row_stride, Fn, head_w, n_out, C, nvox, dW, db, dFn, workspace, workspace_bytes, stream);
+}
+
+// ---- rows layout of the head outputs: same arguments as the channels-last entries with (raw, n_out) -> (rows, pitch)
+extern "C" int bfm_loss_l1_multi_rows(const float* raw_rows, int64_t row_stride, int n_out, int64_t nvox, int n,
+                                      const int32_t* cols, const int32_t* l2, const float* clampv, const float* coef,
+                                      const float* const* targets, const float* const* weights, const float* const* masks,
+                                      float* dRaw_rows, double* loss_out, void* workspace, size_t workspace_bytes,
+                                      bfm_stream_t stream) {
+    if (!raw_rows || nvox <= 0 || row_stride < nvox || n_out <= 0 || n <= 0 || n > L1M_MAX || !cols || !l2 || !clampv ||
+        !coef || !targets || !loss_out || !workspace)
+        return BFM_E_ARG;
+    if (workspace_bytes < bfm_loss_l1_multi_workspace()) return BFM_E_WORKSPACE;
+    L1Table tab{};
+    tab.n = n;
+    for (int k = 0; k < n; ++k) {
+        if (cols[k] < 0 || cols[k] >= n_out || !targets[k]) return BFM_E_ARG;
+        tab.e[k] = L1Entry{cols[k], l2[k], clampv[k], coef[k] / (float)nvox, targets[k], weights ? weights[k] : nullptr,
+                           masks ? masks[k] : nullptr};
+    }
+    double* part = static_cast<double*>(workspace);
+    const int nb = grid_for(nvox, RB);
+    hipStream_t st = bfm_s(stream);
+    hipLaunchKernelGGL(l1_multi_rows_kernel, dim3(nb), dim3(256), 0, st, raw_rows, row_stride, nvox, tab, dRaw_rows, part);
+    hipLaunchKernelGGL(l1_multi_fold_kernel, dim3(n), dim3(64), 0, st, part, nb, n, 1.0 / (double)nvox, loss_out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_loss_grad_l1_multi_rows(const float* raw_rows, int64_t row_stride, int n_out, int n, const int32_t* cols,
+                                           const float* coef, const float* const* targets, const float* const* weights,
+                                           int D, int H, int W, float* dRaw_rows, double* loss_out, void* workspace,
+                                           size_t workspace_bytes, bfm_stream_t stream) {
+    if (!raw_rows || !cols || !coef || !targets || !loss_out || !workspace || n <= 0 || n > L1M_MAX || D <= 0 || H <= 0 ||
+        W <= 0 || n_out <= 0)
+        return BFM_E_ARG;
+    if (workspace_bytes < bfm_loss_l1_multi_workspace()) return BFM_E_WORKSPACE;
+    const int64_t nvox = (int64_t)D * H * W;
+    if (row_stride < nvox) return BFM_E_ARG;
+    GL1Table tab{};
+    tab.n = n;
+    for (int k = 0; k < n; ++k) {
+        if (cols[k] < 0 || cols[k] >= n_out || !targets[k]) return BFM_E_ARG;
+        for (int j = 0; j < k; ++j)
+            if (cols[j] == cols[k]) return BFM_E_ARG;               // two entries on one column would race on dRaw
+        tab.e[k] = GL1Entry{cols[k], coef[k] / (float)nvox, targets[k], weights ? weights[k] : nullptr};
+    }
+    double* part = static_cast<double*>(workspace);
+    const int nb = grid_for(nvox, RB);
+    hipLaunchKernelGGL(grad_l1_multi_rows_kernel, dim3(nb), dim3(256), 0, bfm_s(stream), raw_rows, row_stride, tab, D, H, W,
+                       dRaw_rows, part);
+    hipLaunchKernelGGL(l1_multi_fold_kernel, dim3(n), dim3(64), 0, bfm_s(stream), part, nb, n, 1.0 / (double)nvox, loss_out);
+    return bfm_launch_status();
+}
+
+// P = softmax probabilities as [ns] rows of nvox (scratch / output); ns <= 64
+extern "C" int bfm_loss_seg_rows(const float* raw_rows, int64_t row_stride, int n_out, int c0, int ns, const float* target,
+                                 const float* wce, const float* wdice, int64_t nvox, float coef_ce, float coef_dice,
+                                 float* P, float* dRaw_rows, double* loss_out, void* workspace, size_t workspace_bytes,
+                                 bfm_stream_t stream) {
+    if (!raw_rows || !target || !wce || !wdice || !P || !loss_out || !workspace || nvox <= 0 || row_stride < nvox ||
+        ns <= 0 || c0 < 0 || c0 + ns > n_out)
+        return BFM_E_ARG;
+    if (ns > 64) return BFM_E_SHAPE;
+    if (workspace_bytes < bfm_loss_workspace(ns)) return BFM_E_WORKSPACE;
+    double* part = static_cast<double*>(workspace);
+    const int nb = grid_for(nvox, RB);
+    hipStream_t st = bfm_s(stream);
+    const int64_t vpb = bfm_cdiv64(nvox, nb);
+    if (ns <= 32)
+        hipLaunchKernelGGL(seg_fwd_rows_kernel<32>, dim3(nb), dim3(256), 0, st, raw_rows, row_stride, c0, ns, target, wce, nvox, P, part);
+    else
+        hipLaunchKernelGGL(seg_fwd_rows_kernel<64>, dim3(nb), dim3(256), 0, st, raw_rows, row_stride, c0, ns, target, wce, nvox, P, part);
+    // blocks past the last voxel chunk still write zeros: the fold below reads all nb rows
+    hipLaunchKernelGGL(seg_class_sums_rows_kernel, dim3(nb, ns), dim3(256), 0, st, P, target, ns, nvox, vpb, part);
+    double* sums = part + (size_t)RB * (1 + 2 * ns);             // [1 + 2 ns]
+    hipLaunchKernelGGL(seg_fold_kernel, dim3(1 + 2 * ns), dim3(64), 0, st, part, nb, ns, sums);
+    if (dRaw_rows) {
+        if (ns <= 32)
+            hipLaunchKernelGGL(seg_bwd_rows_kernel<32>, dim3(grid_for(nvox, 2048)), dim3(256), 0, st, P, target, ns, wce, wdice, sums,
+                               nvox, coef_ce / (float)nvox, coef_dice, row_stride, c0, dRaw_rows);
+        else
+            hipLaunchKernelGGL(seg_bwd_rows_kernel<64>, dim3(grid_for(nvox, 2048)), dim3(256), 0, st, P, target, ns, wce, wdice, sums,
+                               nvox, coef_ce / (float)nvox, coef_dice, row_stride, c0, dRaw_rows);
+    }
+    (void)hipMemcpyAsync(loss_out, sums, (size_t)(1 + 2 * ns) * sizeof(double), hipMemcpyDeviceToDevice, st);
     return bfm_launch_status();
 }
 

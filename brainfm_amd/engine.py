@@ -1314,12 +1314,18 @@ class Tail:
         self.last_buf = maps_buf                      # [n_maps][D,H,W]: the stitcher consumes all rows in one launch
         return maps, feat_norm, seg, label
 
-    def run_raw(self, feat_cl, dims, want_feat=True):
-        """TaskHead.forward only: raw logits (D,H,W,n_out) [+ normalised features]."""
+    def run_raw(self, feat_cl, dims, want_feat=True, rows=False):
+        """TaskHead.forward only: raw logits (D,H,W,n_out) -- rows=True: (n_out, D*H*W), the training losses' layout --
+        [+ normalised features]."""
         eng = self.eng
         D, H, W = dims
-        raw = torch.empty((D, H, W, self.n_out), dtype=torch.float32, device=eng.device)
         feat_norm = torch.empty_like(feat_cl) if (want_feat and eng.unit_feat) else None
+        if rows:
+            raw = torch.empty((self.n_out, D * H * W), dtype=torch.float32, device=eng.device)
+            L.check(eng.lib.bfm_tail_raw_rows(L.ptr(feat_cl), D * H * W, C.byref(self.desc), L.ptr(feat_norm), L.ptr(raw),
+                                              D * H * W, L.stream_ptr()), "tail_raw_rows")
+            return raw, feat_norm
+        raw = torch.empty((D, H, W, self.n_out), dtype=torch.float32, device=eng.device)
         L.check(eng.lib.bfm_tail_heads(L.ptr(feat_cl), None, D * H * W, C.byref(self.desc), L.ptr(feat_norm), None,
                                        None, None, L.ptr(raw), L.stream_ptr()), "tail_heads(raw)")
         return raw, feat_norm

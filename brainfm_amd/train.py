@@ -247,8 +247,9 @@ class TrainStep:
             raise L.BfmError("target of shape %s does not match the volume %s" % (tuple(x.shape), tuple(shape_tail)))
         return x
 
-    def _sample_losses(self, raw, dims, target, sample, dRaw, vals, scale):
-        """Launch every loss of one sample; values land in `vals` (device fp64, one slot list per loss name)."""
+    def _sample_losses(self, raw, dims, target, sample, dRaw, vals, scale, rows=False):
+        """Launch every loss of one sample; values land in `vals` (device fp64, one slot list per loss name).
+        rows: raw / dRaw are (n_out, nvox) rows instead of channels-last (nvox, n_out)."""
         lib, st = self.lib, L.stream_ptr()
         D, H, W = dims
         nvox = D * H * W
@@ -266,6 +267,16 @@ class TrainStep:
             slots.setdefault(name, []).append((k, n))
             k += n
             return C.c_void_p(vals.data_ptr() + 8 * (k - n))
+
+        def seg_loss(r0, ns, tgt, c_ce, c_dice):
+            P = torch.empty(nvox * ns, dtype=torch.float32, device=self.dev)     # [nvox][ns], rows: [ns][nvox]
+            if rows:
+                L.check(lib.bfm_loss_seg_rows(L.ptr(raw), nvox, n_out, r0, ns, L.ptr(tgt), L.ptr(self.wce), L.ptr(self.wce),
+                                              nvox, c_ce, c_dice, L.ptr(P), L.ptr(dRaw), slot("seg", 1 + 2 * ns), ws, wsn, st),
+                        "loss_seg_rows")
+            else:
+                L.check(lib.bfm_loss_seg(L.ptr(raw), n_out, r0, ns, L.ptr(tgt), L.ptr(self.wce), L.ptr(self.wce), nvox,
+                                         c_ce, c_dice, L.ptr(P), L.ptr(dRaw), slot("seg", 1 + 2 * ns), ws, wsn, st), "loss_seg")
 
         for name in self.loss_names:
             coef = scale * self.loss_weights.get("loss_" + name, 0.0) / self.all_samples
@@ -321,17 +332,13 @@ class TrainStep:
                 tgt = self._t(target["segmentation"], dims).reshape(ns, D, H, W)
                 c_dice = (scale * self.loss_weights.get("loss_seg_dice", 0.0) / self.all_samples
                           if "seg_dice" in self.loss_names else 0.0)
-                P = torch.empty((nvox, ns), dtype=torch.float32, device=self.dev)
-                L.check(lib.bfm_loss_seg(L.ptr(raw), n_out, r0, ns, L.ptr(tgt), L.ptr(self.wce), L.ptr(self.wce), nvox,
-                                         coef, c_dice, L.ptr(P), L.ptr(dRaw), slot("seg", 1 + 2 * ns), ws, wsn, st), "loss_seg")
+                seg_loss(r0, ns, tgt, coef, c_dice)
             elif name == "seg_dice":
                 if "seg_ce" not in self.loss_names:
                     r0, ns = self.tail.row_of["segmentation"]
                     active.update(range(r0, r0 + ns))
                     tgt = self._t(target["segmentation"], dims).reshape(ns, D, H, W)
-                    P = torch.empty((nvox, ns), dtype=torch.float32, device=self.dev)
-                    L.check(lib.bfm_loss_seg(L.ptr(raw), n_out, r0, ns, L.ptr(tgt), L.ptr(self.wce), L.ptr(self.wce), nvox,
-                                             0.0, coef, L.ptr(P), L.ptr(dRaw), slot("seg", 1 + 2 * ns), ws, wsn, st), "loss_seg")
+                    seg_loss(r0, ns, tgt, 0.0, coef)
         # every l1 / l2 entry in batches of 32 per launch (one pass over raw each); results go to a staging row and from
         # there to their slots
         for b0 in range(0, len(dense), 32):
@@ -347,8 +354,12 @@ class TrainStep:
             keep.extend([e[2] for e in batch] + [e[3] for e in batch] + [e[4] for e in batch])
             stage = torch.empty(n, dtype=torch.float64, device=self.dev)
             wsm = self._ws_multi
-            L.check(lib.bfm_loss_l1_multi(L.ptr(raw), n_out, nvox, n, cols, l2s, clamps, coefs, tg, wt, mk, L.ptr(dRaw),
-                                          L.ptr(stage), L.ptr(wsm), wsm.numel(), st), "loss_l1_multi")
+            if rows:
+                L.check(lib.bfm_loss_l1_multi_rows(L.ptr(raw), nvox, n_out, nvox, n, cols, l2s, clamps, coefs, tg, wt, mk,
+                                                   L.ptr(dRaw), L.ptr(stage), L.ptr(wsm), wsm.numel(), st), "loss_l1_multi_rows")
+            else:
+                L.check(lib.bfm_loss_l1_multi(L.ptr(raw), n_out, nvox, n, cols, l2s, clamps, coefs, tg, wt, mk, L.ptr(dRaw),
+                                              L.ptr(stage), L.ptr(wsm), wsm.numel(), st), "loss_l1_multi")
             idx = torch.tensor([e[0] for e in batch], dtype=torch.int64, device=self.dev)
             vals.index_copy_(0, idx, stage)
         # every gradient-L1 entry in one launch (distinct columns per launch: two entries on one column go to two launches)
@@ -370,8 +381,12 @@ class TrainStep:
             keep.extend([e[2] for e in batch] + [e[3] for e in batch])
             stage = torch.empty(n, dtype=torch.float64, device=self.dev)
             wsm = self._ws_multi
-            L.check(lib.bfm_loss_grad_l1_multi(L.ptr(raw), n_out, n, cols, coefs, tg, wt, D, H, W, L.ptr(dRaw), L.ptr(stage),
-                                               L.ptr(wsm), wsm.numel(), st), "loss_grad_l1_multi")
+            if rows:
+                L.check(lib.bfm_loss_grad_l1_multi_rows(L.ptr(raw), nvox, n_out, n, cols, coefs, tg, wt, D, H, W, L.ptr(dRaw),
+                                                        L.ptr(stage), L.ptr(wsm), wsm.numel(), st), "loss_grad_l1_multi_rows")
+            else:
+                L.check(lib.bfm_loss_grad_l1_multi(L.ptr(raw), n_out, n, cols, coefs, tg, wt, D, H, W, L.ptr(dRaw), L.ptr(stage),
+                                                   L.ptr(wsm), wsm.numel(), st), "loss_grad_l1_multi")
             idx = torch.tensor([e[0] for e in batch], dtype=torch.int64, device=self.dev)
             vals.index_copy_(0, idx, stage)
         self._keep = keep
@@ -411,19 +426,27 @@ class TrainStep:
         x_cl = eng.to_cl(x)
         feats, tape = BW.backbone_forward_train(eng, x_cl, dims)
         feat_last = feats[-1][0]
-        raw, fn = tail.run_raw(feat_last, dims, want_feat=True)
+        n_out, cf = tail.n_out, tail.c_feat
+        # head outputs as rows of nvox values wherever the one-pass heads backward exists (64 features, <= 96 outputs,
+        # <= 64 classes: every shipped head set); BFM_TRAIN_ROWS=0 keeps channels-last
+        rows = (os.environ.get("BFM_TRAIN_ROWS", "1") != "0" and cf == 64 and n_out <= 96 and
+                tail.row_of.get("segmentation", (0, 0))[1] <= 64)
+        raw, fn = tail.run_raw(feat_last, dims, want_feat=True, rows=rows)
         if fn is None:
             fn = feat_last
         dRaw = torch.zeros_like(raw)
         vals = torch.zeros(4 * len(self.loss_names) + 2 * tail.n_out + 8, dtype=torch.float64, device=self.dev)
-        slots, _ = self._sample_losses(raw, dims, target, sample, dRaw, vals, scale)
-        n_out, cf = tail.n_out, tail.c_feat
+        slots, _ = self._sample_losses(raw, dims, target, sample, dRaw, vals, scale, rows=rows)
         dW = torch.empty((n_out, cf), dtype=torch.float32, device=self.dev)
         db = torch.empty(n_out, dtype=torch.float32, device=self.dev)
         dFn = torch.empty((nvox, cf), dtype=torch.float32, device=self.dev)
         wsb = torch.empty(lib.bfm_head_bwd_workspace(n_out, cf, nvox), dtype=torch.uint8, device=self.dev)
-        L.check(lib.bfm_head_bwd(L.ptr(dRaw), L.ptr(fn), L.ptr(tail.head_w), n_out, cf, nvox, L.ptr(dW), L.ptr(db),
-                                 L.ptr(dFn), L.ptr(wsb), wsb.numel(), st), "head_bwd")
+        if rows:
+            L.check(lib.bfm_head_bwd_rows(L.ptr(dRaw), nvox, L.ptr(fn), L.ptr(tail.head_w), n_out, cf, nvox, L.ptr(dW),
+                                          L.ptr(db), L.ptr(dFn), L.ptr(wsb), wsb.numel(), st), "head_bwd_rows")
+        else:
+            L.check(lib.bfm_head_bwd(L.ptr(dRaw), L.ptr(fn), L.ptr(tail.head_w), n_out, cf, nvox, L.ptr(dW), L.ptr(db),
+                                     L.ptr(dFn), L.ptr(wsb), wsb.numel(), st), "head_bwd")
         if eng.unit_feat:
             dfeat = torch.empty_like(dFn)
             L.check(lib.bfm_normalize_bwd(L.ptr(feat_last), L.ptr(dFn), cf, nvox, 1e-12, L.ptr(dfeat), st), "normalize_bwd")

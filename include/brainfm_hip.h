@@ -738,6 +738,28 @@ int bfm_loss_seg(const float* raw, int n_out, int c0, int ns, const float* targe
 size_t bfm_head_bwd_workspace(int n_out, int C, int64_t nvox);
 int bfm_head_bwd(const float* dRaw, const float* Fn, const float* head_w, int n_out, int C, int64_t nvox, float* dW,
                  float* db, float* dFn, void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+/* ---- the same five steps with the head outputs as [n_out] ROWS of nvox values (row pitch row_stride >= nvox) instead of
+ * channels-last [nvox][n_out].  criterion.py walks one channel of the outputs per loss (outputs[key][:, c], NCDHW in the
+ * reference): in rows every access is a contiguous run, the kernels need no LDS staging and the per-voxel expressions are
+ * those of the channels-last entries above.  P of bfm_loss_seg_rows is [ns][nvox]; ns <= 64.  bfm_tail_raw_rows is
+ * TaskHead.forward alone (head.py:52-59) writing that layout; bfm_head_bwd_rows needs C == 64 and n_out <= 96. */
+int bfm_tail_raw_rows(const float* feat, int64_t nvox, const bfm_tail_desc_t* desc, float* feat_norm, float* raw_rows,
+                      int64_t row_stride, bfm_stream_t stream);
+int bfm_loss_l1_multi_rows(const float* raw_rows, int64_t row_stride, int n_out, int64_t nvox, int n, const int32_t* cols,
+                           const int32_t* l2, const float* clampv, const float* coef, const float* const* targets,
+                           const float* const* weights, const float* const* masks, float* dRaw_rows, double* loss_out,
+                           void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+int bfm_loss_grad_l1_multi_rows(const float* raw_rows, int64_t row_stride, int n_out, int n, const int32_t* cols,
+                                const float* coef, const float* const* targets, const float* const* weights, int D, int H,
+                                int W, float* dRaw_rows, double* loss_out, void* workspace, size_t workspace_bytes,
+                                bfm_stream_t stream);
+int bfm_loss_seg_rows(const float* raw_rows, int64_t row_stride, int n_out, int c0, int ns, const float* target,
+                      const float* wce, const float* wdice, int64_t nvox, float coef_ce, float coef_dice, float* P,
+                      float* dRaw_rows, double* loss_out /*[1+2ns]*/, void* workspace, size_t workspace_bytes,
+                      bfm_stream_t stream);
+int bfm_head_bwd_rows(const float* dRaw_rows, int64_t row_stride, const float* Fn, const float* head_w, int n_out, int C,
+                      int64_t nvox, float* dW, float* db, float* dFn, void* workspace, size_t workspace_bytes,
+                      bfm_stream_t stream);
 int bfm_normalize_bwd(const float* feat, const float* dFn, int C, int64_t nvox, float eps, float* dfeat,
                       bfm_stream_t stream);
 /* torch.optim.AdamW step t (1-based) on one flat parameter; g is multiplied by grad_scale first (unscale * clip) */

@@ -381,3 +381,51 @@ def test_heads_backward_fused_pass_vs_float64(n_out, nvox):
         for got, ref, what in ((dFn, r64 @ w64, "dFn"), (dW, r64.t() @ f64, "dW"), (db, r64.sum(0), "db")):
             err = float((got.double() - ref).abs().max()) / max(1e-6, float(ref.abs().max()))
             assert err <= 2e-5, (cf, what, err)
+        # the rows layout of dRaw ([n_out] rows, pitch > nvox here) feeds the same tiles: same bits
+        pitch = nvox + 24
+        rows = torch.full((n_out, pitch), float("nan"), device=dev)
+        rows[:, :nvox] = dRaw.t()
+        dW2, db2, dFn2 = torch.empty_like(dW), torch.empty_like(db), torch.empty_like(dFn)
+        rc = lib.bfm_head_bwd_rows(L.ptr(rows), pitch, L.ptr(Fn), L.ptr(W), n_out, cf, nvox, L.ptr(dW2), L.ptr(db2),
+                                   L.ptr(dFn2), L.ptr(ws), ws.numel(), L.stream_ptr())
+        if cf == 64:
+            L.check(rc, "head_bwd_rows")
+            assert torch.equal(dW2, dW) and torch.equal(db2, db) and torch.equal(dFn2, dFn)
+        else:
+            assert rc == -2                            # rows exist for the one-pass kernel only
+
+
+def test_rows_layout_of_the_head_outputs_equals_channels_last():
+    """Round 4: the training step keeps the head outputs as [n_out] rows of nvox values (bfm_tail_raw_rows, bfm_loss_*_rows,
+    bfm_head_bwd_rows).  Per voxel the rows kernels evaluate the channels-last kernels' expressions: logits, probabilities
+    and d/d(raw) must be the SAME BITS (transposed), the fp64 loss sums agree to rounding of a different fold order."""
+    import ctypes as C
+    from brainfm_amd import _lib as L
+    c = load_case()
+    step, xs, target, samples = _build(c)
+    dims = tuple(xs[0].shape[-3:])
+    nvox = dims[0] * dims[1] * dims[2]
+    tail = step.tail
+    dev = _dev()
+    # (1) TaskHead.forward in both layouts
+    g = torch.Generator().manual_seed(11)
+    feat = torch.randn(dims + (tail.c_feat,), generator=g).to(dev)
+    raw_cl, fn_cl = tail.run_raw(feat, dims, want_feat=True)
+    raw_rows, fn_rows = tail.run_raw(feat, dims, want_feat=True, rows=True)
+    assert raw_rows.shape == (tail.n_out, nvox)
+    assert torch.equal(raw_rows.t().reshape(raw_cl.shape), raw_cl)
+    assert (fn_cl is None and fn_rows is None) or torch.equal(fn_cl, fn_rows)
+    # (2) every loss of a sample on random head outputs
+    raw = (torch.randn((nvox, tail.n_out), generator=g) * 1.5).to(dev)
+    outs = []
+    for rows in (False, True):
+        r = raw.t().contiguous() if rows else raw
+        dRaw = torch.zeros_like(r)
+        vals = torch.zeros(4 * len(step.loss_names) + 2 * tail.n_out + 8, dtype=torch.float64, device=dev)
+        slots, _ = step._sample_losses(r, dims, target, samples[0], dRaw, vals, 1.0, rows=rows)
+        outs.append((step._finish_losses([(slots, vals)], nvox), dRaw.t() if rows else dRaw))
+    (la, da), (lb, db) = outs
+    assert list(la) == list(lb)
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-12 * max(1.0, abs(la[k])), (k, la[k], lb[k])
+    assert torch.equal(da, db), float((da - db).abs().max())
