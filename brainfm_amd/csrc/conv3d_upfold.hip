@@ -330,25 +330,22 @@ __global__ void __launch_bounds__(256) pack_upfold_tiled(const float* __restrict
     const int nf = 2 * npl;
     const int kc = blockIdx.x % KCB, ntile = blockIdx.x / KCB;
     const float s = ldexpf(1.0f, wexp);
-    for (int i = threadIdx.x; i < 64 * KC * 27; i += 256) {
-        const int co = i / (KC * 27), r = i - co * (KC * 27);
-        pku_lds[co * PKU_ROW + r] = w[((int64_t)(ntile * 64 + co) * Cin + CA + kc * KC) * 27 + r];
-    }
+    const float* src0 = w + ((int64_t)(ntile * 64) * Cin + CA + kc * KC) * 27;
+    bfm_stage_rows<64, KC * 27, PKU_ROW, 256>(src0, (int64_t)Cin * 27, pku_lds, 1.0f,
+                                              ((reinterpret_cast<uintptr_t>(w) & 15) == 0) && (Cin & 3) == 0 && (CA & 3) == 0);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nfrag = 8 * 8 * nf;                            // (class, folded tap, fragment)
-    for (int q = wave; q < nfrag; q += 4) {
-        const int f = q % nf;
-        const int t = (q / nf) & 7;
-        const int cls = q / (nf * 8);
-        const int nb = f / npl, hl = f - nb * npl;
+    for (int q = wave; q < 8 * 8 * 2; q += 4) {              // (class, folded tap, column block): hi and lo from one sum
+        const int nb = q & 1;
+        const int t = (q >> 1) & 7;
+        const int cls = q >> 4;
         const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
         const int ta = t >> 2, tb = (t >> 1) & 1, tc = t & 1;
         const int zlo = pz == 0 ? (ta == 0 ? 0 : 1) : (ta == 0 ? 0 : 2), zhi = pz == 0 ? (ta == 0 ? 0 : 2) : (ta == 0 ? 1 : 2);
         const int ylo = py == 0 ? (tb == 0 ? 0 : 1) : (tb == 0 ? 0 : 2), yhi = py == 0 ? (tb == 0 ? 0 : 2) : (tb == 0 ? 1 : 2);
         const int xlo = px == 0 ? (tc == 0 ? 0 : 1) : (tc == 0 ? 0 : 2), xhi = px == 0 ? (tc == 0 ? 0 : 2) : (tc == 0 ? 1 : 2);
         const float* src = pku_lds + (nb * 32 + (lane & 31)) * PKU_ROW + (8 * (lane >> 5)) * 27;
-        half8 v;
+        half8 vh, vl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float* wc = src + j * 27;
@@ -358,9 +355,12 @@ __global__ void __launch_bounds__(256) pack_upfold_tiled(const float* __restrict
                     for (int kw = xlo; kw <= xhi; ++kw) sum += wc[kd * 9 + kh * 3 + kw];
             const float x = sum * s;
             const _Float16 hh = (_Float16)x;
-            v[j] = hl == 0 ? hh : (_Float16)(x - (float)hh);
+            vh[j] = hh;
+            vl[j] = (_Float16)(x - (float)hh);
         }
-        out[((((int64_t)(ntile * 8 + cls) * KCB + kc) * 8 + t) * nf + f) * 64 + lane] = __builtin_bit_cast(uint4, v);
+        uint4* dst = out + ((((int64_t)(ntile * 8 + cls) * KCB + kc) * 8 + t) * nf + nb * npl) * 64 + lane;
+        dst[0] = __builtin_bit_cast(uint4, vh);
+        if (npl == 2) dst[64] = __builtin_bit_cast(uint4, vl);
     }
 }
 

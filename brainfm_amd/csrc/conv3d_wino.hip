@@ -678,29 +678,28 @@ __global__ void __launch_bounds__(256) pack_wino_tiled(const float* __restrict__
     const int nb = blockIdx.x & 1;
     const int kc = (blockIdx.x >> 1) % KCN, ntile = (blockIdx.x >> 1) / KCN;
     const float s = ldexpf(1.0f, wexp);
-    for (int i = threadIdx.x; i < 32 * KC * 27; i += 256) {
-        const int co = i / (KC * 27), r = i - co * (KC * 27);
-        pkw_lds[co * PKW_ROW + r] = w[((int64_t)(ntile * 64 + nb * 32 + co) * Cin + kc * KC) * 27 + r];
-    }
+    const float* src0 = w + ((int64_t)(ntile * 64 + nb * 32) * Cin + kc * KC) * 27;
+    bfm_stage_rows<32, KC * 27, PKW_ROW, 256>(src0, (int64_t)Cin * 27, pkw_lds, 1.0f,
+                                              ((reinterpret_cast<uintptr_t>(w) & 15) == 0) && (Cin & 3) == 0);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nfrag = 4 * 9 * npl;                           // (ps, t, hl) of this column block
-    for (int q = wave; q < nfrag; q += 4) {
-        const int hl = q % npl;
-        const int t = (q / npl) % 9;
-        const int ps = q / (npl * 9);
-        const int f = nb * npl + hl;
+    for (int q = wave; q < 4 * 9; q += 4) {                  // (ps, t) of this column block: hi and lo from one transform
+        const int t = q % 9;
+        const int ps = q / 9;
         const float* src = pkw_lds + (lane & 31) * PKW_ROW + (8 * (lane >> 5)) * 27 + t * 3;
-        half8 v;
+        half8 vh, vl;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float g0 = src[j * 27], g1 = src[j * 27 + 1], g2 = src[j * 27 + 2];
             const float u = ps == 0 ? g0 : ps == 1 ? ((g0 + g1) + g2) * 0.5f : ps == 2 ? ((g0 - g1) + g2) * 0.5f : g2;
             const float x = u * s;
             const _Float16 hh = (_Float16)x;
-            v[j] = hl == 0 ? hh : (_Float16)(x - (float)hh);
+            vh[j] = hh;
+            vl[j] = (_Float16)(x - (float)hh);
         }
-        out[((((int64_t)(ntile * 4 + ps) * KCN + kc) * 9 + t) * nf + f) * 64 + lane] = __builtin_bit_cast(uint4, v);
+        uint4* dst = out + ((((int64_t)(ntile * 4 + ps) * KCN + kc) * 9 + t) * nf + nb * npl) * 64 + lane;
+        dst[0] = __builtin_bit_cast(uint4, vh);
+        if (npl == 2) dst[64] = __builtin_bit_cast(uint4, vl);
     }
 }
 

@@ -429,3 +429,81 @@ def test_rows_layout_of_the_head_outputs_equals_channels_last():
     for k in la:
         assert abs(la[k] - lb[k]) <= 1e-12 * max(1.0, abs(la[k])), (k, la[k], lb[k])
     assert torch.equal(da, db), float((da - db).abs().max())
+
+
+def _split_f16(x):
+    """hi = fp16(x) (round to nearest even), lo = fp16(x - hi): the two planes of every packed weight form."""
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    return hi, lo
+
+
+def test_weight_repack_kernels_against_layout_models():
+    """The kernels a training step re-runs on every layer after AdamW (round 4: LDS-tiled with 16-byte loads): max |w|, the
+    transposed + tap-mirrored (+ zero-padded) weights of the data-gradient conv, and the two matrix-core weight forms --
+    each against a numpy model of its documented layout, bit for bit."""
+    import ctypes as C
+    from brainfm_amd import _lib as L
+    lib = L.load()
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    st = L.stream_ptr()
+    # max |x|: contiguous (16-byte path), a column slice (rows with a pitch), an odd length (scalar path)
+    for shape, sl in (((64, 48, 27), None), ((64, 48, 27), 16), ((7, 5, 27), None), ((33, 3, 27), 1)):
+        w = torch.randn(shape, generator=g).to(dev)
+        t = w if sl is None else w[:, sl:]
+        out = torch.zeros(1, device=dev)
+        rows, ln, stride = (1, t.numel(), t.numel()) if t.is_contiguous() else (t.shape[0], t[0].numel(), t.stride(0))
+        L.check(lib.bfm_absmax_f32(L.ptr(t), rows, ln, stride, L.ptr(out), st), "absmax")
+        assert float(out) == float(t.abs().max()), (shape, sl)
+    # transposed, mirrored, padded
+    for cout, cin, pad in ((64, 32, 64), (96, 48, 64), (32, 16, 16), (8, 16, 64), (64, 24, 24)):
+        w = torch.randn(cout, cin, 27, generator=g).to(dev)
+        out = torch.full((pad, cout, 27), float("nan"), device=dev)
+        L.check(lib.bfm_transpose_mirror_weights(L.ptr(w), cout, cin, pad, L.ptr(out), st), "transpose_mirror")
+        ref = torch.zeros(pad, cout, 27, device=dev)
+        ref[:cin] = w.permute(1, 0, 2).flip(2)
+        assert torch.equal(out, ref), (cout, cin, pad)
+    # matrix-core forms
+    for cout, cin in ((64, 16), (128, 48)):
+        w = (torch.randn(cout, cin, 27, generator=g) * 0.1)
+        wmax = float(w.abs().max())
+        wd = w.to(dev)
+        wexp = C.c_int(0)
+        nt, kcn = cout // 64, cin // 16
+        # (a) packed[ntile][kc][tap][nb][hl][lane][8]: w[ntile*64 + nb*32 + (l&31)][kc*16 + 8*(l>>5) + j][tap]
+        buf = torch.zeros(nt * kcn * 27 * 2 * 2 * 64 * 8, dtype=torch.float16, device=dev)
+        L.check(lib.bfm_pack_conv_weights_mfma(L.ptr(wd), cin, cout, wmax, L.ptr(buf), C.byref(wexp), st), "pack_mfma")
+        x = (w.numpy() * np.float32(2.0 ** wexp.value)).astype(np.float32)
+        hi, lo = _split_f16(x)
+        ref = np.zeros((nt, kcn, 27, 2, 2, 64, 8), np.float16)
+        l = np.arange(64)
+        for n in range(nt):
+            for kc in range(kcn):
+                for nb in range(2):
+                    co = n * 64 + nb * 32 + (l & 31)
+                    for j in range(8):
+                        ci = kc * 16 + 8 * (l >> 5) + j
+                        ref[n, kc, :, nb, 0, :, j] = hi[co, ci, :].T
+                        ref[n, kc, :, nb, 1, :, j] = lo[co, ci, :].T
+        assert np.array_equal(buf.cpu().numpy().view(np.uint16), ref.reshape(-1).view(np.uint16)), ("mfma", cout, cin)
+        # (b) packed16[ntile][kc][pair 14][cb 4][hl][lane][8]: w[ntile*64 + cb*16 + (l&15)][kc*16 + 8*(kg&1) + j][2*pair + (kg>>1)]
+        nbytes = lib.bfm_pack_conv_weights_mfma16_bytes(cin, cout)
+        assert nbytes == nt * kcn * 14 * 4 * 2 * 64 * 16
+        buf = torch.zeros(nbytes // 2, dtype=torch.float16, device=dev)
+        L.check(lib.bfm_pack_conv_weights_mfma16(L.ptr(wd), cin, cout, wmax, L.ptr(buf), C.byref(wexp), st), "pack_mfma16")
+        x = (w.numpy() * np.float32(2.0 ** wexp.value)).astype(np.float32)
+        hi, lo = _split_f16(np.concatenate([x, np.zeros((cout, cin, 1), np.float32)], axis=2))      # tap 27: zeros
+        ref = np.zeros((nt, kcn, 14, 4, 2, 64, 8), np.float16)
+        kg = l >> 4
+        for n in range(nt):
+            for kc in range(kcn):
+                for pair in range(14):
+                    tap = 2 * pair + (kg >> 1)
+                    for cb in range(4):
+                        co = n * 64 + cb * 16 + (l & 15)
+                        for j in range(8):
+                            ci = kc * 16 + 8 * (kg & 1) + j
+                            ref[n, kc, pair, cb, 0, :, j] = hi[co, ci, tap]
+                            ref[n, kc, pair, cb, 1, :, j] = lo[co, ci, tap]
+        assert np.array_equal(buf.cpu().numpy().view(np.uint16), ref.reshape(-1).view(np.uint16)), ("mfma16", cout, cin)
