@@ -203,6 +203,7 @@ struct Wg3Params {
     const float* dp_bound;            // [1]  max |dP|
     const float* x_bound;             // [G]  max |GroupNorm-applied input| per group
     int G;
+    int part_cin;                     // input channels per row of `part` (Cin; CA when only the skip channels run here)
 };
 
 __device__ __forceinline__ int pow2_exp_for(float bmax) {  // e with bmax * 2^e in [2^12, 2^13)
@@ -305,7 +306,6 @@ __global__ void __launch_bounds__(WG3_THREADS) conv_wgrad_f16_kernel(const Wg3Pa
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cob = wave & 1, tg = wave >> 1;
-    const int Cin = p.CA + p.CB;
     const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 64;
     const bool fromB = ci0 >= p.CA;
 
@@ -455,7 +455,7 @@ __global__ void __launch_bounds__(WG3_THREADS) conv_wgrad_f16_kernel(const Wg3Pa
         __builtin_amdgcn_sched_barrier(0);
         wg3_mfma_phase(dPs, Xs, acc, cob, tg, l32, lh);
     }
-    float* out = p.part + (int64_t)blockIdx.x * p.Cout * Cin * 27;
+    float* out = p.part + (int64_t)blockIdx.x * p.Cout * q.part_cin * 27;
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
         if (j == 6 && tg == 3) continue;                              // group 3 has no seventh tap
@@ -463,7 +463,241 @@ __global__ void __launch_bounds__(WG3_THREADS) conv_wgrad_f16_kernel(const Wg3Pa
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = (i & 3) + 8 * (i >> 2) + 4 * lh;
-            out[((int64_t)(co0 + cob * 32 + row) * Cin + ci0 + l32) * 27 + tap] = acc[j][i] * dq;
+            out[((int64_t)(co0 + cob * 32 + row) * q.part_cin + ci0 + l32) * 27 + tap] = acc[j][i] * dq;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- weight gradient of the upsampled channels
+// Decoder first convs read cat(skip, nearest_up2(L)).  For the L channels the 27-tap correlation over the high-res grid
+//   dW[co][ci][t] = sum_v dP[v][co] * U[v + t - 1][ci],   U[v] = Ln[v >> 1]   (Ln = GroupNorm-applied L, zero outside)
+// folds, exactly as conv3d_upfold.hip folds the forward pass: an output voxel v = 2q + r (parity r in {0,1}^3) sees only
+// TWO distinct low-res positions per axis -- r = 0: q-1 (t = 0), q (t = 1, 2);  r = 1: q (t = 0, 1), q+1 (t = 2) -- so
+//   F[r][f][co][ci] = sum_q dP[2q + r][co] * Ln[q + r + f - 1][ci],      f in {0,1}^3,
+//   dW[..][t]       = sum over the 2^3 (r, f) with f = f(r, t) per axis: t=0: (0,0),(1,0); t=1: (0,1),(1,0); t=2: (0,1),(1,1)
+// 64 products per low-res voxel instead of 216 (3.4x fewer), the input tile is the low-res tensor (8x fewer voxels to
+// stage), and the padding is the same zero ring in low-res coordinates (2q+r+t-1 leaves the volume exactly when q+r+f-1
+// does, for dims = 2 x low-res dims).  Same split-fp16 scheme, LDS layouts and fragment tricks as conv_wgrad_f16_kernel:
+// a workgroup owns 32 (co) x 32 (ci) x 64 (r, f), WAVE = PARITY r (its A fragments are the dP rows of its own parity,
+// all eight waves share the low-res halo tile), eight accumulators (f) per wave, persistent over 1x4x16 low-res tiles.
+// The eighth of dP a parity owns is gathered with stride 2 along x (two 128-byte runs per voxel pair).
+constexpr int UT_Y = 4, UT_X = 16;
+constexpr int UHY = UT_Y + 2, UHR = 3 * UHY;               // 18 halo rows (z-1, z, z+1)
+constexpr int UDP_ROW = 32 * 8 + 8;                        // dwords per dP row: 32 channels x 8 x-pairs, padded
+constexpr int UDP_ROWS = 8 * UT_Y;                         // (parity, y) rows
+constexpr int UDP_PLANE = UDP_ROWS * UDP_ROW;
+constexpr int UX_PLANE = UHR * X_ROW;
+constexpr int WGU_LDS = (2 * UDP_PLANE + 2 * UX_PLANE) * 4;  // 121 KB
+constexpr int WGU_THREADS = 256;
+
+struct WgUpParams {
+    const float* dP;                  // [D][H][W][Cout], D = 2 d ...
+    const float* L;                   // [d][h][w][CB]
+    const float *scale, *shift;       // of the CB channels
+    int Cout, CB, d, h, w;
+    float* part;                      // [S][Cout][CB][64]
+    int nby, nbx, ntiles;
+    const float* dp_bound;
+    const float* x_bound;
+    int G;
+};
+
+// FOUR waves, one per SIMD with the whole register file (256 accumulator + 256 vector registers): wave w owns the two
+// parities (rz, ry) = (w >> 1, w & 1), rx = 0 and 1 -- sixteen 32x32 accumulators.  Both x parities read the same halo
+// row: x shifts 0, 1 (rx = 0) and 1, 2 (rx = 1) are three views of ONE 5-dword LDS read, so a row costs two A reads and
+// four halo reads for 48 MFMAs.  (The first version ran eight waves of 256 registers, one parity each: 19 spills and a
+// strictly serial read -> wait -> 3 MFMA schedule, 1.2x over the 27-tap kernel instead of the 2.4x the product count allows.)
+__global__ void __launch_bounds__(WGU_THREADS) conv_wgrad_up_f16_kernel(const WgUpParams p) {
+    extern __shared__ uint32_t wgu_lds[];
+    uint32_t* dPs = wgu_lds;
+    uint32_t* Xs = wgu_lds + 2 * UDP_PLANE;
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
+    const int H = 2 * p.h, W = 2 * p.w;
+
+    float xb = 0.f;
+    for (int g = 0; g < p.G; ++g) xb = fmaxf(xb, p.x_bound[g]);
+    const int ea = pow2_exp_for(p.dp_bound[0]), ex = pow2_exp_for(xb);
+    const float sa = ldexpf(1.0f, ea), sx = ldexpf(1.0f, ex), dq = ldexpf(1.0f, -(ea + ex));
+
+    floatx16 acc[16];                                      // [rx][fz][fy][fx]
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+    // Staging, one LDS row per wave instruction: lane = (channel c = lane >> 1, x half xh = lane & 1) owns the eight x of its
+    // half of a row for ONE channel -- eight (ten) 4-byte loads whose addresses differ by a wave-uniform stride (32 lanes x 4
+    // bytes contiguous per load), four x pairs converted to one 16-byte LDS store per plane.  No per-lane channel rotation
+    // (the float4-per-voxel form of conv_wgrad_f16_kernel spends half of its staging instructions on v_cndmask), no
+    // per-element masks: h % 4 == 0 and w % 16 == 0 (host-checked) leave the x ends of the halo as the only padding.
+    // Measured on the 64 + 128 -> 64 join at 128^3 (kernel 1.17 ms: MFMA phase 0.49, LDS stores 0.23, loads 0.43): the
+    // float4 form cost 0.55 (stores) + 0.32 (loads); 8-byte loads of channel pairs (62 per thread instead of 114, under
+    // the 64 a wave keeps in flight) 0.17 + 0.56 -- four 128-byte segments per load are slower than two; issuing the
+    // halo rows half way through the MFMA phase brought spills and no gain.
+    //   dP rows 8 wave + s (s = 0..7): parity (rz, ry, rx = s >> 2), y = s & 3 -- each wave stages the rows it multiplies
+    //   halo rows wave + 4 s (s = 0..4, < 18)
+    const int rz = wave >> 1, ry = wave & 1;               // this wave's parities: (rz, ry, 0) and (rz, ry, 1)
+    const int c = lane >> 1, xh = lane & 1;
+    const float scx = p.scale[ci0 + c] * sx, shx = p.shift[ci0 + c] * sx;
+    constexpr int ND = 8, NX = 5;
+    float pd[ND][8], px[NX][10];
+    unsigned xmask = 0;                                    // wave-uniform: bits 0..4 halo row s inside, 5: x0 > 0, 6: x0 + 16 < w
+    auto load_tile = [&](int tile) __attribute__((always_inline)) {
+        const int bx = tile % p.nbx;
+        const int t2 = tile / p.nbx;
+        const int by = t2 % p.nby, z0 = t2 / p.nby;
+        const int y0 = by * UT_Y, x0 = bx * UT_X;
+#pragma unroll
+        for (int s = 0; s < ND; ++s) {
+            const int rx = s >> 2, yl = s & 3;
+            const float* rp = p.dP + ((int64_t)((2 * z0 + rz) * H + 2 * (y0 + yl) + ry) * W + 2 * x0 + rx) * p.Cout + co0 +
+                              (16 * xh) * p.Cout + c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pd[s][j] = rp[(int64_t)(2 * j) * p.Cout];
+        }
+        xmask = (x0 > 0 ? 32u : 0u) | (x0 + UT_X < p.w ? 64u : 0u);
+#pragma unroll
+        for (int s = 0; s < NX; ++s) {
+            const int hrow = wave + 4 * s;
+            if (hrow < UHR) {                                          // wave-uniform
+                const int zz = z0 + hrow / UHY - 1, yy = y0 + hrow % UHY - 1;
+                if (zz >= 0 && zz < p.d && yy >= 0 && yy < p.h) xmask |= 1u << s;
+                const int zc = min(max(zz, 0), p.d - 1), yc = min(max(yy, 0), p.h - 1);
+                const float* rp = p.L + ((int64_t)(zc * p.h + yc) * p.w) * p.CB + ci0 + c;
+                const int xb_ = x0 - 1 + 8 * xh;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) px[s][j] = rp[(int64_t)(j == 0 ? max(xb_, 0) : xb_ + j) * p.CB];
+                px[s][8] = rp[(int64_t)(x0 + UT_X - 1) * p.CB];                      // hx 16, 17: kept by the xh = 0 lanes
+                px[s][9] = rp[(int64_t)min(x0 + UT_X, p.w - 1) * p.CB];
+            }
+        }
+    };
+    auto store_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < ND; ++s) {
+            uint32_t hi[4], lo[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) split_pair(pd[s][2 * k] * sa, pd[s][2 * k + 1] * sa, hi[k], lo[k]);
+            uint32_t* dst = dPs + (8 * wave + s) * UDP_ROW + c * 8 + 4 * xh;
+            *reinterpret_cast<uint4*>(dst) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+            *reinterpret_cast<uint4*>(dst + UDP_PLANE) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        }
+        const bool ok_first = xh == 1 || (xmask & 32u), ok_last = (xmask & 64u) != 0;
+#pragma unroll
+        for (int s = 0; s < NX; ++s) {
+            const int hrow = wave + 4 * s;
+            if (hrow < UHR) {
+                const bool rok = (xmask >> s) & 1u;
+                float v[10];
+#pragma unroll
+                for (int j = 0; j < 10; ++j) {
+                    const bool ok = rok && (j == 0 ? ok_first : (j == 9 ? ok_last : true));
+                    v[j] = ok ? fmaf(px[s][j], scx, shx) : 0.f;              // zero padding comes after the affine
+                }
+                uint32_t hi[5], lo[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) split_pair(v[2 * k], v[2 * k + 1], hi[k], lo[k]);
+                uint32_t* dst = Xs + hrow * X_ROW + c * X_CH + 4 * xh;
+                *reinterpret_cast<uint4*>(dst) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+                *reinterpret_cast<uint4*>(dst + UX_PLANE) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+                if (xh == 0) {
+                    dst[8] = hi[4];
+                    dst[UX_PLANE + 8] = lo[4];
+                }
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile < p.ntiles) load_tile(tile);
+    for (; tile < p.ntiles; tile += gridDim.x) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        const int nxt = tile + gridDim.x;
+        if (nxt < p.ntiles) load_tile(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 2
+        for (int yl = 0; yl < UT_Y; ++yl) {
+            const uint32_t* ap = dPs + (wave * 2 * UT_Y + yl) * UDP_ROW + l32 * 8 + 4 * lh;
+            const wg_half8 a0_hi = __builtin_bit_cast(wg_half8, *reinterpret_cast<const uint4*>(ap));
+            const wg_half8 a0_lo = __builtin_bit_cast(wg_half8, *reinterpret_cast<const uint4*>(ap + UDP_PLANE));
+            const wg_half8 a1_hi = __builtin_bit_cast(wg_half8, *reinterpret_cast<const uint4*>(ap + UT_Y * UDP_ROW));
+            const wg_half8 a1_lo = __builtin_bit_cast(wg_half8, *reinterpret_cast<const uint4*>(ap + UT_Y * UDP_ROW + UDP_PLANE));
+#pragma unroll
+            for (int fzy = 0; fzy < 4; ++fzy) {
+                const int fz = fzy >> 1, fy = fzy & 1;
+                const uint32_t* xb_ = Xs + ((rz + fz) * UHY + yl + ry + fy) * X_ROW + l32 * X_CH + 4 * lh;
+                const uint4 h = *reinterpret_cast<const uint4*>(xb_);
+                const uint32_t h4 = xb_[4];
+                const uint4 l = *reinterpret_cast<const uint4*>(xb_ + UX_PLANE);
+                const uint32_t l4 = xb_[UX_PLANE + 4];
+                wg_half8 s_hi[3], s_lo[3];                             // x shifts 0, 1, 2 of this halo row
+#pragma unroll
+                for (int k = 0; k < 3; ++k) wg3_frags(xb_, k, s_hi[k], s_lo[k], h, h4, l, l4);
+                // rx = 0: fx = 0, 1 <-> shifts 0, 1;   rx = 1: fx = 0, 1 <-> shifts 1, 2
+#pragma unroll
+                for (int fx = 0; fx < 2; ++fx) {
+                    const int j0 = fzy * 2 + fx, j1 = 8 + fzy * 2 + fx;
+                    acc[j0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0_lo, s_hi[fx], acc[j0], 0, 0, 0);
+                    acc[j1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_lo, s_hi[fx + 1], acc[j1], 0, 0, 0);
+                    acc[j0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0_hi, s_lo[fx], acc[j0], 0, 0, 0);
+                    acc[j1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_hi, s_lo[fx + 1], acc[j1], 0, 0, 0);
+                    acc[j0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0_hi, s_hi[fx], acc[j0], 0, 0, 0);
+                    acc[j1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1_hi, s_hi[fx + 1], acc[j1], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float* out = p.part + (int64_t)blockIdx.x * p.Cout * p.CB * 64;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int par = wave * 2 + (j >> 3);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * lh;
+            out[((int64_t)(co0 + row) * p.CB + ci0 + l32) * 64 + par * 8 + (j & 7)] = acc[j][i] * dq;
+        }
+    }
+}
+
+// dW[co][CA + ci][t] = sum over splits and over the eight (parity, folded tap) pairs of tap t (fixed order).
+// A block folds 16 consecutive (co, ci) pairs: 16 lanes per pair sum their float4 of the 64 folded entries over the splits
+// (4 KB contiguous per split and block), the 16 x 27 taps are then put together from LDS and leave as one contiguous run.
+__global__ void __launch_bounds__(256) wgrad_up_fold_kernel(const float* __restrict__ part, int S, int Cout, int CB, int Cin,
+                                                            int CA, float* __restrict__ dW) {
+    __shared__ float f[16][65];
+    const int64_t n = (int64_t)Cout * CB;                            // pairs; CB % 32 == 0: a block stays inside one co
+    const int t = threadIdx.x, pl = t >> 4, q = t & 15;
+    for (int64_t p0 = (int64_t)blockIdx.x * 16; p0 < n; p0 += (int64_t)gridDim.x * 16) {
+        const float4* src = reinterpret_cast<const float4*>(part + (p0 + pl) * 64) + q;
+        float4 a = src[0];
+        for (int s_ = 1; s_ < S; ++s_) {
+            const float4 v = src[(int64_t)s_ * n * 16];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        __syncthreads();
+        f[pl][4 * q] = a.x; f[pl][4 * q + 1] = a.y; f[pl][4 * q + 2] = a.z; f[pl][4 * q + 3] = a.w;
+        __syncthreads();
+        const int co = (int)(p0 / CB), ci = (int)(p0 - (int64_t)co * CB);
+        float* dst = dW + ((int64_t)co * Cin + CA + ci) * 27;
+        for (int o = t; o < 16 * 27; o += 256) {
+            const int pr = o / 27, tp = o - pr * 27;
+            const int kd = tp / 9, kh = (tp / 3) % 3, kw = tp % 3;
+            float sum = 0.f;
+#pragma unroll
+            for (int az = 0; az < 2; ++az)                            // parity along z, its folded tap for kd
+#pragma unroll
+                for (int ay = 0; ay < 2; ++ay)
+#pragma unroll
+                    for (int ax = 0; ax < 2; ++ax) {
+                        const int fz = az == 0 ? (kd >= 1) : (kd == 2), fy = ay == 0 ? (kh >= 1) : (kh == 2),
+                                  fx = ax == 0 ? (kw >= 1) : (kw == 2);
+                        sum += f[pr][(az * 4 + ay * 2 + ax) * 8 + fz * 4 + fy * 2 + fx];
+                    }
+            dst[o] = sum;
         }
     }
 }
@@ -530,6 +764,18 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ part, int S, int64
         float s = part[i];
         for (int k = 1; k < S; ++k) s += part[i + (int64_t)k * n];          // split order: deterministic
         dW[i] = s;
+    }
+}
+
+// part [S][Cout][Cp][27] (the first Cp input channels only) -> dW [Cout][Cin][27]
+__global__ void wgrad_reduce_cols_kernel(const float* __restrict__ part, int S, int Cout, int Cp, int Cin,
+                                         float* __restrict__ dW) {
+    const int64_t n = (int64_t)Cout * Cp * 27;
+    GRID_STRIDE(i, n) {
+        float s = part[i];
+        for (int k = 1; k < S; ++k) s += part[i + (int64_t)k * n];          // split order: deterministic
+        const int64_t co = i / ((int64_t)Cp * 27), r = i - co * ((int64_t)Cp * 27);
+        dW[co * (int64_t)Cin * 27 + r] = s;
     }
 }
 
@@ -876,7 +1122,12 @@ extern "C" size_t bfm_conv3x3x3_wgrad_workspace(int Cin, int Cout, int D, int H,
                  c = wgrad_plan(Cin, Cin, Cout, D, H, W, true);
     int S = a.S > b.S ? a.S : b.S;
     if (c.S > S) S = c.S;
-    return (size_t)S * Cout * Cin * 27 * sizeof(float);
+    // + the folded partials of the upsampled channels (conv_wgrad_up_f16_kernel): S_U x Cout x CB x 64 floats with
+    //   S_U x CB <= max(CB, 512 x 32 x 32 / Cout), CB < Cin
+    const size_t up = (size_t)256 * std::max<size_t>((size_t)Cout * Cin, (size_t)512 * 1024);
+    // (the skip channels alone split finer: S_A x CA <= 512 x 32 x 64 / Cout)
+    const size_t reg = std::max((size_t)S * Cout * Cin * 27 * sizeof(float), (size_t)512 * 32 * 64 * 27 * sizeof(float));
+    return reg + 256 + up;
 }
 
 extern "C" int bfm_conv3x3x3_wgrad_ex(const float* dP, int Cout, const float* A, int CA, const float* B, int CB, int D,
@@ -897,12 +1148,58 @@ extern "C" int bfm_conv3x3x3_wgrad_ex(const float* dP, int Cout, const float* A,
     hipStream_t st = bfm_s(stream);
     const int64_t n = (int64_t)Cout * Cin * 27;
     const bool f16 = passes == 3 && Cout % 64 == 0 && Cin % 32 == 0 && CA % 32 == 0;
+    // upsampled channels of an exact 2x decoder join: folded form on the low-res tensor, the skip channels alone below
+    static const bool upfold_on = []() { const char* e = getenv("BFM_WGRAD_UPFOLD"); return !(e && e[0] == '0'); }();
+    if (f16 && upfold_on && CB > 0 && CB % 32 == 0 && 2 * up->d == D && 2 * up->h == H && 2 * up->w == W &&
+        up->h % UT_Y == 0 && up->w % UT_X == 0) {
+        hipStream_t st2 = st;
+        // (1) skip channels: the tiled kernel on the first CA / 32 column blocks, compact partials
+        const WgPlan pa = wgrad_plan(CA, CA, Cout, D, H, W, true);
+        Wg3Params q{};
+        q.b = p; q.b.S = pa.S; q.nbz = pa.nbz; q.nby = pa.nby; q.nbx = pa.nbx; q.ntiles = pa.ntiles;
+        q.dp_bound = dp_bound; q.x_bound = x_bound; q.G = G; q.part_cin = CA;
+        static bool attr3a = false, attrU = false;
+        if (!attr3a) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_f16_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS) != hipSuccess)
+                return BFM_E_LAUNCH;
+            attr3a = true;
+        }
+        hipLaunchKernelGGL(conv_wgrad_f16_kernel, dim3(pa.S, CA / 32, Cout / 64), dim3(WG3_THREADS), WG3_LDS, st2, q);
+        hipLaunchKernelGGL(wgrad_reduce_cols_kernel, dim3(grid_for((int64_t)Cout * CA * 27)), dim3(256), 0, st2, p.part, pa.S,
+                           Cout, CA, Cin, dW);
+        // (2) upsampled channels
+        WgUpParams u{};
+        u.dP = dP; u.L = B; u.scale = scale + CA; u.shift = shift + CA; u.Cout = Cout; u.CB = CB;
+        u.d = up->d; u.h = up->h; u.w = up->w;
+        u.nby = bfm_cdiv(up->h, UT_Y); u.nbx = bfm_cdiv(up->w, UT_X); u.ntiles = up->d * u.nby * u.nbx;
+        u.dp_bound = dp_bound; u.x_bound = x_bound; u.G = G;
+        const int colsU = (CB / 32) * (Cout / 32);
+        int SU = 512 / colsU;
+        if (SU > u.ntiles) SU = u.ntiles;
+        if (SU < 1) SU = 1;
+        const int per = bfm_cdiv(u.ntiles, SU);
+        SU = bfm_cdiv(u.ntiles, per);
+        const size_t offA = (((size_t)pa.S * Cout * CA * 27 * sizeof(float)) + 255) & ~(size_t)255;
+        if (offA + (size_t)SU * Cout * CB * 64 * sizeof(float) > workspace_bytes) return BFM_E_WORKSPACE;
+        u.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + offA);
+        if (!attrU) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_up_f16_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, WGU_LDS) != hipSuccess)
+                return BFM_E_LAUNCH;
+            attrU = true;
+        }
+        hipLaunchKernelGGL(conv_wgrad_up_f16_kernel, dim3(SU, CB / 32, Cout / 32), dim3(WGU_THREADS), WGU_LDS, st2, u);
+        hipLaunchKernelGGL(wgrad_up_fold_kernel, dim3((unsigned)std::min<int64_t>(8192, (int64_t)Cout * CB / 16)), dim3(256), 0,
+                           st2, u.part, SU, Cout, CB, Cin, CA, dW);
+        return bfm_launch_status();
+    }
     const WgPlan pl = wgrad_plan(CA, Cin, Cout, D, H, W, f16);
     p.S = pl.S;
     if (f16) {
         Wg3Params q{};
         q.b = p; q.nbz = pl.nbz; q.nby = pl.nby; q.nbx = pl.nbx; q.ntiles = pl.ntiles;
-        q.dp_bound = dp_bound; q.x_bound = x_bound; q.G = G;
+        q.dp_bound = dp_bound; q.x_bound = x_bound; q.G = G; q.part_cin = Cin;
         static bool attr3 = false;
         if (!attr3) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_f16_kernel),

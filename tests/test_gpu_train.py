@@ -507,3 +507,46 @@ def test_weight_repack_kernels_against_layout_models():
                             ref[n, kc, pair, cb, 0, :, j] = hi[co, ci, tap]
                             ref[n, kc, pair, cb, 1, :, j] = lo[co, ci, tap]
         assert np.array_equal(buf.cpu().numpy().view(np.uint16), ref.reshape(-1).view(np.uint16)), ("mfma16", cout, cin)
+
+
+@pytest.mark.parametrize("ca,cb,cout,dims", [(32, 64, 64, (8, 16, 32)), (64, 32, 128, (6, 8, 96)), (32, 32, 64, (8, 12, 40))])
+def test_weight_gradient_of_a_decoder_join_vs_float64(ca, cb, cout, dims):
+    """bfm_conv3x3x3_wgrad_ex on cat(skip, nearest_up2(low)): for an exact 2x join whose low-res rows tile by 4 x 16 the
+    upsampled channels take the folded kernel of round 4 (64 products per low-res voxel on the low-res tensor instead of
+    27 per high-res voxel, conv_wgrad_up_f16_kernel) and the skip channels the 27-tap kernel alone; (8, 12, 40) does not
+    tile and keeps the 27-tap kernel on all channels.  Against the float64 correlation of the GroupNorm-applied,
+    zero-padded input with dP: split-fp16 products with fp32 accumulation, 2e-5 of the largest entry."""
+    import ctypes as C
+    from brainfm_amd import _lib as L
+    from brainfm_amd.engine import nearest_index_map
+    lib = L.load()
+    dev = _dev()
+    D, H, W = dims
+    lo = (D // 2, H // 2, W // 2)
+    g = torch.Generator().manual_seed(ca + cb)
+    A = torch.randn(dims + (ca,), generator=g).to(dev)
+    B = torch.randn(lo + (cb,), generator=g).to(dev)
+    dP = (torch.randn(dims + (cout,), generator=g) * 0.01).to(dev)
+    cin = ca + cb
+    scale = (torch.rand(cin, generator=g) + 0.5).to(dev)
+    shift = (torch.randn(cin, generator=g) * 0.1).to(dev)
+    maps = [nearest_index_map(lo[a], dims[a]) for a in range(3)]
+    reps = [np.bincount(maps[a], minlength=lo[a]).astype(np.int32) for a in range(3)]
+    tens = [torch.from_numpy(m).to(dev) for m in maps + reps]
+    up = L.Upsample(lo[0], lo[1], lo[2], *[t.data_ptr() for t in tens])
+    ix = [torch.from_numpy(m).long().to(dev) for m in maps]
+    X = torch.cat([A, B[ix[0]][:, ix[1]][:, :, ix[2]]], dim=-1) * scale + shift
+    bnd, xb = dP.abs().max().reshape(1), X.abs().max().reshape(1)
+    ws = torch.empty(lib.bfm_conv3x3x3_wgrad_workspace(cin, cout, D, H, W), dtype=torch.uint8, device=dev)
+    dW = torch.full((cout, cin, 27), float("nan"), dtype=torch.float32, device=dev)
+    L.check(lib.bfm_conv3x3x3_wgrad_ex(L.ptr(dP), cout, L.ptr(A), ca, L.ptr(B), cb, D, H, W, C.byref(up), L.ptr(scale),
+                                       L.ptr(shift), L.ptr(bnd), L.ptr(xb), 1, 3, L.ptr(dW), L.ptr(ws), ws.numel(),
+                                       L.stream_ptr()), "wgrad")
+    Xp = torch.nn.functional.pad(X.double().permute(3, 0, 1, 2)[None], (1, 1, 1, 1, 1, 1))[0]
+    d64 = dP.double().reshape(-1, cout)
+    ref = torch.empty((cout, cin, 27), dtype=torch.float64, device=dev)
+    for t in range(27):
+        kd, kh, kw = t // 9, (t // 3) % 3, t % 3
+        ref[:, :, t] = (Xp[:, kd:kd + D, kh:kh + H, kw:kw + W].reshape(cin, -1) @ d64).t()
+    err = float((dW.double() - ref).abs().max() / ref.abs().max())
+    assert err <= 2e-5, err
