@@ -468,6 +468,273 @@ __global__ void __launch_bounds__(WG3_THREADS) conv_wgrad_f16_kernel(const Wg3Pa
     }
 }
 
+// ----------------------------------------------------------------------------- wave-specialised weight gradient (round 4)
+// conv_wgrad_f16_kernel above stages a tile (loads -> convert -> LDS) and multiplies it in turn: measured on 64 -> 64 at
+// 128^3 the matrix core works 1.2 of the kernel's 1.9 ms (profiles/r04_wgrad_phases.txt), and the same eight waves cannot
+// overlap the two (254 registers, a 108 KB single buffer).  Here the roles are split: waves 0-3 (one per SIMD) only read
+// LDS and issue MFMAs -- a 32 (co) x 32 (ci) x 27 block, seven taps per wave -- and waves 4-11 only stage: global loads
+// run TWO tiles ahead (two register sets), convert + LDS stores one tile ahead into the other half of a double-buffered
+// tile (1 x 4 x 16 voxels: 65 KB per buffer).  One s_barrier per tile.  Skip / plain inputs only (A); nearest-upsampled
+// channels keep the kernels above.  Measured (profiles/r04_wgrad_phases.txt): the two roles do NOT simply overlap -- on
+// 64 -> 64 at 128^3 the staging waves alone take 1.23 ms, the MFMA waves alone 1.28, together 2.03 (the 8-wave kernel:
+// 2.12): under its power limit the chip pays for the staging instructions whether or not they run beside the MFMAs.  The
+// gain is on the narrower levels (twice the workgroups per layer, no idle matrix core behind a barrier): the plain layers
+// of the full-width net 7.87 -> 6.90 ms, the training iteration -2.6 ms.
+constexpr int ST_Y = 4, ST_X = 16;
+constexpr int SHY = ST_Y + 2, SHR = 3 * SHY;               // 18 halo rows
+constexpr int SDP_ROW = 32 * 8 + 8;
+constexpr int SDP_PLANE = ST_Y * SDP_ROW;
+constexpr int SX_PLANE = SHR * X_ROW;
+constexpr int WS_BUF = 2 * SDP_PLANE + 2 * SX_PLANE;       // dwords per buffer (hi + lo planes of both operands)
+constexpr int WGS_LDS = 2 * WS_BUF * 4;                    // 129.8 KB
+constexpr int WGS_THREADS = 768;                        // 4 MFMA waves + 8 staging waves
+
+struct WgWsParams {
+    const float* dP;                  // [D][H][W][Cout]
+    const float* A;                   // [D][H][W][CA]
+    const float *scale, *shift;
+    int Cout, CA, D, H, W;
+    float* part;                      // [S][Cout][part_cin][27]
+    int part_cin;
+    int nby, nbx, ntiles;
+    const float* dp_bound;
+    const float* x_bound;
+    int G;
+};
+
+__global__ void __launch_bounds__(WGS_THREADS) conv_wgrad_ws_kernel(const WgWsParams p) {
+    extern __shared__ uint32_t wgs_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
+    float xb = 0.f;
+    for (int g = 0; g < p.G; ++g) xb = fmaxf(xb, p.x_bound[g]);
+    const int ea = pow2_exp_for(p.dp_bound[0]), ex = pow2_exp_for(xb);
+    const int n_my = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;      // >= 1
+    auto barrier = [&]() __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ loaders
+        // 16 bytes per lane and load (the texture path takes a wave's load in ~16 cycles whatever its width: one 4-byte
+        // load per element, the row-per-wave form, made the four loaders the bottleneck -- 2.56 instead of 2.22 ms on
+        // 64 -> 64 at 128^3); four lanes read 64 contiguous bytes of a voxel and the channel order is rotated per lane so
+        // that the four quads land in distinct LDS banks (conv_wgrad_f16_kernel's staging; its instruction count does not
+        // matter here, the matrix core runs beside it).
+        //   dP:    quad = 4 (lw & 1) + q4, row = 2 (lw >> 1) + (sub >> 3), x pair = sub & 7        (1 item, waves lw < 4)
+        //   input: quad = 4 (lw & 1) + q4, position = 16 (lw >> 1) + sub + 64 s -> (halo row, hx pair)        (3 items)
+        // Eight staging waves: a single wave per SIMD runs this dependent convert chain at one instruction per ~14 cycles
+        // (1.5 ms on its own for 64 -> 64 at 128^3, longer than the matrix core's 1.3).
+        const int lw = wave - 4;
+        const float sa = ldexpf(1.0f, ea), sx = ldexpf(1.0f, ex);
+        const int q4 = lane & 3, sub = lane >> 2;
+        const int quad = 4 * (lw & 1) + q4, d_xp = sub & 7, d_r = 2 * ((lw >> 1) & 1) + (sub >> 3);
+        const bool has_dp = lw < 4;                            // wave-uniform: the dP tile is one item for four of the eight waves
+        const int x_pos0 = 16 * (lw >> 1) + sub;
+        const bool rot1 = q4 & 1, rot2 = q4 & 2;
+        auto rot4 = [&](const float (&v)[4], float (&u)[4]) __attribute__((always_inline)) {
+            float w_[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w_[k] = rot1 ? v[(k + 1) & 3] : v[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = rot2 ? w_[(k + 2) & 3] : w_[k];
+        };
+        float sc[4], sh[4];                                    // already rotated: sc[k] belongs to channel (k + q4) & 3
+        {
+            const float4 a = *reinterpret_cast<const float4*>(p.scale + ci0 + quad * 4);
+            const float4 b = *reinterpret_cast<const float4*>(p.shift + ci0 + quad * 4);
+            const float a4[4] = {a.x * sx, a.y * sx, a.z * sx, a.w * sx}, b4[4] = {b.x * sx, b.y * sx, b.z * sx, b.w * sx};
+            rot4(a4, sc);
+            rot4(b4, sh);
+        }
+        constexpr int NXI = 3, XSTEP = 64;
+        auto coords = [&](int k, int& z0, int& y0, int& x0) __attribute__((always_inline)) {
+            const int tile = blockIdx.x + k * gridDim.x;
+            const int bx = tile % p.nbx;
+            const int t2 = tile / p.nbx;
+            z0 = t2 / p.nby; y0 = (t2 % p.nby) * ST_Y; x0 = bx * ST_X;
+        };
+        // register set of one tile; okm: bits 0..11 input item s element e (2 s + e), 12..13 dP
+        auto load = [&](int k, float4 (&pd)[2], float4 (&px)[NXI][2], unsigned& okm) __attribute__((always_inline)) {
+            int z0, y0, x0;
+            coords(k, z0, y0, x0);
+            okm = 0;
+            if (has_dp) {
+                const int y = y0 + d_r, x = x0 + 2 * d_xp;
+                const bool rok = y < p.H;
+                const float* row = p.dP + ((int64_t)(z0 * p.H + min(y, p.H - 1)) * p.W) * p.Cout + co0 + quad * 4;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    pd[e] = *reinterpret_cast<const float4*>(row + (int64_t)min(x + e, p.W - 1) * p.Cout);
+                    okm |= (rok && x + e < p.W) ? (1u << (12 + e)) : 0u;
+                }
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < NXI; ++s_) {
+                const int pos = min(x_pos0 + XSTEP * s_, SHR * 9 - 1);        // slots past the end redo the last item (not stored)
+                const int hrow = pos / 9, hxp = pos - hrow * 9;
+                const int zz = z0 + hrow / SHY - 1, yy = y0 + hrow % SHY - 1, xx = x0 + 2 * hxp - 1;
+                const bool rok = zz >= 0 && zz < p.D && yy >= 0 && yy < p.H;
+                const int zc = min(max(zz, 0), p.D - 1), yc = min(max(yy, 0), p.H - 1);
+                const float* row = p.A + ((int64_t)(zc * p.H + yc) * p.W) * p.CA + ci0 + quad * 4;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int xe = xx + e;
+                    px[s_][e] = *reinterpret_cast<const float4*>(row + (int64_t)min(max(xe, 0), p.W - 1) * p.CA);
+                    okm |= (rok && xe >= 0 && xe < p.W) ? (1u << (2 * s_ + e)) : 0u;
+                }
+            }
+        };
+        auto convert = [&](const float4 (&pd)[2], const float4 (&px)[NXI][2], unsigned okm, uint32_t* buf)
+                           __attribute__((always_inline)) {
+            uint32_t* dPs = buf;
+            uint32_t* Xs = buf + 2 * SDP_PLANE;
+            if (has_dp) {
+                const float m0 = (okm >> 12) & 1u ? sa : 0.f, m1 = (okm >> 13) & 1u ? sa : 0.f;
+                const float v0[4] = {pd[0].x, pd[0].y, pd[0].z, pd[0].w};
+                const float v1[4] = {pd[1].x, pd[1].y, pd[1].z, pd[1].w};
+                float u0[4], u1[4];
+                rot4(v0, u0);
+                rot4(v1, u1);
+                uint32_t* dst = dPs + d_r * SDP_ROW + (quad * 4) * 8 + d_xp;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t hi, lo;
+                    split_pair(u0[k] * m0, u1[k] * m1, hi, lo);
+                    uint32_t* d_ = dst + ((k + q4) & 3) * 8;               // the channel this rotated slot belongs to
+                    d_[0] = hi;
+                    d_[SDP_PLANE] = lo;
+                }
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < NXI; ++s_) {
+                const int pos = x_pos0 + XSTEP * s_;
+                const bool live = pos < SHR * 9;
+                const int posc = min(pos, SHR * 9 - 1);
+                const int hrow = posc / 9, hxp = posc - hrow * 9;
+                const float v0[4] = {px[s_][0].x, px[s_][0].y, px[s_][0].z, px[s_][0].w};
+                const float v1[4] = {px[s_][1].x, px[s_][1].y, px[s_][1].z, px[s_][1].w};
+                float u0[4], u1[4];
+                rot4(v0, u0);
+                rot4(v1, u1);
+                const bool ok0 = (okm >> (2 * s_)) & 1u, ok1 = (okm >> (2 * s_ + 1)) & 1u;
+                uint32_t* dst = Xs + hrow * X_ROW + (quad * 4) * X_CH + hxp;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a = ok0 ? fmaf(u0[k], sc[k], sh[k]) : 0.f;       // zero padding comes after the affine
+                    const float b = ok1 ? fmaf(u1[k], sc[k], sh[k]) : 0.f;
+                    uint32_t hi, lo;
+                    split_pair(a, b, hi, lo);
+                    uint32_t* d_ = dst + ((k + q4) & 3) * X_CH;
+                    if (live) {
+                        d_[0] = hi;
+                        d_[SX_PLANE] = lo;
+                    }
+                }
+            }
+        };
+        float4 pd0[2], px0[NXI][2], pd1[2], px1[NXI][2];
+        unsigned ok0_ = 0, ok1_ = 0;
+        uint32_t* buf0 = wgs_lds;
+        uint32_t* buf1 = wgs_lds + WS_BUF;
+        load(0, pd0, px0, ok0_);
+        if (n_my > 1) load(1, pd1, px1, ok1_);
+        convert(pd0, px0, ok0_, buf0);
+        if (n_my > 2) load(2, pd0, px0, ok0_);
+        barrier();                                                     // buffer 0 holds tile 0
+        // even k: set 0 holds the loads of tile k + 2, set 1 those of tile k + 1
+        for (int k = 0; k < n_my; k += 2) {
+            if (k + 1 < n_my) convert(pd1, px1, ok1_, buf1);           // tile k + 1, beside the MFMAs of tile k (buffer 0)
+            if (k + 3 < n_my) load(k + 3, pd1, px1, ok1_);
+            barrier();
+            if (k + 1 >= n_my) break;
+            if (k + 2 < n_my) convert(pd0, px0, ok0_, buf0);           // tile k + 2, beside the MFMAs of tile k + 1 (buffer 1)
+            if (k + 4 < n_my) load(k + 4, pd0, px0, ok0_);
+            barrier();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- MFMA waves: tap group tg = wave
+    const int tg = wave;
+    const float dq = ldexpf(1.0f, -(ea + ex));
+    floatx16 acc[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    int offR[3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 2 * tg + i;
+        const int kd = row / 3, kh = row - kd * 3;
+        offR[i] = (kd * SHY + kh) * X_ROW;
+    }
+    offR[2] = (2 * SHY + 2) * X_ROW;
+    auto mfma_tile = [&](const uint32_t* buf) __attribute__((always_inline)) {
+        const uint32_t* dPs = buf;
+        const uint32_t* Xs = buf + 2 * SDP_PLANE;
+#pragma unroll 1
+        for (int yl = 0; yl < ST_Y; ++yl) {
+            const uint32_t* ap = dPs + yl * SDP_ROW + l32 * 8 + 4 * lh;
+            const wg_half8 a_hi = __builtin_bit_cast(wg_half8, *reinterpret_cast<const uint4*>(ap));
+            const wg_half8 a_lo = __builtin_bit_cast(wg_half8, *reinterpret_cast<const uint4*>(ap + SDP_PLANE));
+            const uint32_t* base = Xs + yl * X_ROW + l32 * X_CH + 4 * lh;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t* xb_ = base + offR[i];
+                const uint4 h = *reinterpret_cast<const uint4*>(xb_);
+                const uint32_t h4 = xb_[4];
+                const uint4 l = *reinterpret_cast<const uint4*>(xb_ + SX_PLANE);
+                const uint32_t l4 = xb_[SX_PLANE + 4];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    wg_half8 b_hi, b_lo;
+                    wg3_frags(xb_, kw, b_hi, b_lo, h, h4, l, l4);
+                    const int j = i * 3 + kw;
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[j], 0, 0, 0);
+                }
+            }
+            if (tg < 3) {                                              // wave-uniform
+                const uint32_t* xb_ = base + offR[2];
+                const uint4 h = *reinterpret_cast<const uint4*>(xb_);
+                const uint32_t h4 = xb_[4];
+                const uint4 l = *reinterpret_cast<const uint4*>(xb_ + SX_PLANE);
+                const uint32_t l4 = xb_[SX_PLANE + 4];
+                wg_half8 b_hi, b_lo;
+                if (tg == 0) wg3_frags(xb_, 0, b_hi, b_lo, h, h4, l, l4);
+                else if (tg == 1) wg3_frags(xb_, 1, b_hi, b_lo, h, h4, l, l4);
+                else wg3_frags(xb_, 2, b_hi, b_lo, h, h4, l, l4);
+                acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc[6], 0, 0, 0);
+                acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc[6], 0, 0, 0);
+                acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc[6], 0, 0, 0);
+            }
+        }
+    };
+    barrier();                                                         // buffer 0 holds tile 0
+#pragma unroll 1
+    for (int k = 0; k < n_my; ++k) {                                   // (one copy of the MFMA block: see wg3_mfma_phase)
+        mfma_tile(wgs_lds + (k & 1) * WS_BUF);
+        barrier();
+    }
+    float* out = p.part + (int64_t)blockIdx.x * p.Cout * p.part_cin * 27;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        if (j == 6 && tg == 3) continue;                              // group 3 has no seventh tap
+        const int tap = j < 6 ? (2 * tg + j / 3) * 3 + j % 3 : 24 + tg;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = (i & 3) + 8 * (i >> 2) + 4 * lh;
+            out[((int64_t)(co0 + row) * p.part_cin + ci0 + l32) * 27 + tap] = acc[j][i] * dq;
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------- weight gradient of the upsampled channels
 // Decoder first convs read cat(skip, nearest_up2(L)).  For the L channels the 27-tap correlation over the high-res grid
 //   dW[co][ci][t] = sum_v dP[v][co] * U[v + t - 1][ci],   U[v] = Ln[v >> 1]   (Ln = GroupNorm-applied L, zero outside)
@@ -1115,6 +1382,44 @@ WgPlan wgrad_plan(int CA, int Cin, int Cout, int D, int H, int W, bool f16 = fal
 }
 }  // namespace
 
+namespace {
+// skip / plain channels [0, CA) of a layer through conv_wgrad_ws_kernel + the fold of its partials into dW [Cout][Cin][27]
+int launch_wgrad_ws(const float* dP, int Cout, const float* A, int CA, int Cin, int D, int H, int W, const float* scale,
+                    const float* shift, const float* dp_bound, const float* x_bound, int G, float* part, float* dW,
+                    hipStream_t st) {
+    WgWsParams w{};
+    w.dP = dP; w.A = A; w.scale = scale; w.shift = shift; w.Cout = Cout; w.CA = CA; w.D = D; w.H = H; w.W = W;
+    w.part = part; w.part_cin = CA;
+    w.nby = bfm_cdiv(H, ST_Y); w.nbx = bfm_cdiv(W, ST_X); w.ntiles = D * w.nby * w.nbx;
+    w.dp_bound = dp_bound; w.x_bound = x_bound; w.G = G;
+    const int cols = (CA / 32) * (Cout / 32);
+    int S = 512 / cols;                                   // two rounds of one workgroup per CU (130 KB of LDS each)
+    if (S > w.ntiles) S = w.ntiles;
+    if (S < 1) S = 1;
+    const int per = bfm_cdiv(w.ntiles, S);
+    S = bfm_cdiv(w.ntiles, per);
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                WGS_LDS) != hipSuccess)
+            return BFM_E_LAUNCH;
+        attr = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_ws_kernel, dim3(S, CA / 32, Cout / 32), dim3(WGS_THREADS), WGS_LDS, st, w);
+    hipLaunchKernelGGL(wgrad_reduce_cols_kernel, dim3(grid_for((int64_t)Cout * CA * 27)), dim3(256), 0, st, part, S, Cout, CA,
+                       Cin, dW);
+    return BFM_OK;
+}
+size_t wgrad_ws_part_bytes(int Cout, int CA, int D, int H, int W) {
+    const int ntiles = D * bfm_cdiv(H, ST_Y) * bfm_cdiv(W, ST_X);
+    const int cols = (CA / 32) * (Cout / 32);
+    int S = cols > 0 ? 512 / cols : 1;
+    if (S > ntiles) S = ntiles;
+    if (S < 1) S = 1;
+    return (((size_t)S * Cout * CA * 27 * sizeof(float)) + 255) & ~(size_t)255;
+}
+}  // namespace
+
 extern "C" size_t bfm_conv3x3x3_wgrad_workspace(int Cin, int Cout, int D, int H, int W) {
     if (Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     // the split count does not depend on CA (only the kernel choice does): take the larger of the two plans
@@ -1150,24 +1455,38 @@ extern "C" int bfm_conv3x3x3_wgrad_ex(const float* dP, int Cout, const float* A,
     const bool f16 = passes == 3 && Cout % 64 == 0 && Cin % 32 == 0 && CA % 32 == 0;
     // upsampled channels of an exact 2x decoder join: folded form on the low-res tensor, the skip channels alone below
     static const bool upfold_on = []() { const char* e = getenv("BFM_WGRAD_UPFOLD"); return !(e && e[0] == '0'); }();
+    static const bool ws_on = []() { const char* e = getenv("BFM_WGRAD_WS"); return !(e && e[0] == '0'); }();
+    if (f16 && ws_on && CB == 0) {                         // plain layer: the wave-specialised kernel on all channels
+        if (wgrad_ws_part_bytes(Cout, CA, D, H, W) > workspace_bytes) return BFM_E_WORKSPACE;
+        const int rc = launch_wgrad_ws(dP, Cout, A, CA, Cin, D, H, W, scale, shift, dp_bound, x_bound, G, p.part, dW, st);
+        return rc != BFM_OK ? rc : bfm_launch_status();
+    }
     if (f16 && upfold_on && CB > 0 && CB % 32 == 0 && 2 * up->d == D && 2 * up->h == H && 2 * up->w == W &&
         up->h % UT_Y == 0 && up->w % UT_X == 0) {
         hipStream_t st2 = st;
-        // (1) skip channels: the tiled kernel on the first CA / 32 column blocks, compact partials
-        const WgPlan pa = wgrad_plan(CA, CA, Cout, D, H, W, true);
-        Wg3Params q{};
-        q.b = p; q.b.S = pa.S; q.nbz = pa.nbz; q.nby = pa.nby; q.nbx = pa.nbx; q.ntiles = pa.ntiles;
-        q.dp_bound = dp_bound; q.x_bound = x_bound; q.G = G; q.part_cin = CA;
+        // (1) skip channels alone, compact partials
         static bool attr3a = false, attrU = false;
-        if (!attr3a) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_f16_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS) != hipSuccess)
-                return BFM_E_LAUNCH;
-            attr3a = true;
+        size_t offA;
+        if (ws_on) {
+            const int rc = launch_wgrad_ws(dP, Cout, A, CA, Cin, D, H, W, scale, shift, dp_bound, x_bound, G, p.part, dW, st2);
+            if (rc != BFM_OK) return rc;
+            offA = wgrad_ws_part_bytes(Cout, CA, D, H, W);
+        } else {
+            const WgPlan pa = wgrad_plan(CA, CA, Cout, D, H, W, true);
+            Wg3Params q{};
+            q.b = p; q.b.S = pa.S; q.nbz = pa.nbz; q.nby = pa.nby; q.nbx = pa.nbx; q.ntiles = pa.ntiles;
+            q.dp_bound = dp_bound; q.x_bound = x_bound; q.G = G; q.part_cin = CA;
+            if (!attr3a) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_f16_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, WG3_LDS) != hipSuccess)
+                    return BFM_E_LAUNCH;
+                attr3a = true;
+            }
+            hipLaunchKernelGGL(conv_wgrad_f16_kernel, dim3(pa.S, CA / 32, Cout / 64), dim3(WG3_THREADS), WG3_LDS, st2, q);
+            hipLaunchKernelGGL(wgrad_reduce_cols_kernel, dim3(grid_for((int64_t)Cout * CA * 27)), dim3(256), 0, st2, p.part, pa.S,
+                               Cout, CA, Cin, dW);
+            offA = (((size_t)pa.S * Cout * CA * 27 * sizeof(float)) + 255) & ~(size_t)255;
         }
-        hipLaunchKernelGGL(conv_wgrad_f16_kernel, dim3(pa.S, CA / 32, Cout / 64), dim3(WG3_THREADS), WG3_LDS, st2, q);
-        hipLaunchKernelGGL(wgrad_reduce_cols_kernel, dim3(grid_for((int64_t)Cout * CA * 27)), dim3(256), 0, st2, p.part, pa.S,
-                           Cout, CA, Cin, dW);
         // (2) upsampled channels
         WgUpParams u{};
         u.dP = dP; u.L = B; u.scale = scale + CA; u.shift = shift + CA; u.Cout = Cout; u.CB = CB;
@@ -1180,7 +1499,6 @@ extern "C" int bfm_conv3x3x3_wgrad_ex(const float* dP, int Cout, const float* A,
         if (SU < 1) SU = 1;
         const int per = bfm_cdiv(u.ntiles, SU);
         SU = bfm_cdiv(u.ntiles, per);
-        const size_t offA = (((size_t)pa.S * Cout * CA * 27 * sizeof(float)) + 255) & ~(size_t)255;
         if (offA + (size_t)SU * Cout * CB * 64 * sizeof(float) > workspace_bytes) return BFM_E_WORKSPACE;
         u.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + offA);
         if (!attrU) {

@@ -2,6 +2,7 @@
 bfm_conv3x3x3_wgrad_ex timed with HIP events, against float64 on a small case first.
 
     python scripts/bench_wgrad.py [size=128] [reps=5]          BFM_WGRAD_UPFOLD=0: the 27-tap kernel on all channels
+                                                               BFM_WGRAD_WS=0: without the wave-specialised kernel
 """
 import ctypes as C
 import os
@@ -69,6 +70,33 @@ def run(lib, dev, ca, cb, cout, dims, reps, check=False):
     return ms
 
 
+def run_plain(lib, dev, cin, cout, dims, reps):
+    D, H, W = dims
+    g = torch.Generator().manual_seed(cin)
+    A = torch.randn(dims + (cin,), generator=g).to(dev)
+    dP = (torch.randn(dims + (cout,), generator=g) * 0.01).to(dev)
+    scale, shift = torch.ones(cin, device=dev), torch.zeros(cin, device=dev)
+    bnd, xb = dP.abs().max().reshape(1), A.abs().max().reshape(1)
+    ws = torch.empty(lib.bfm_conv3x3x3_wgrad_workspace(cin, cout, D, H, W), dtype=torch.uint8, device=dev)
+    dW = torch.empty((cout, cin, 27), dtype=torch.float32, device=dev)
+    st = L.stream_ptr()
+
+    def call():
+        L.check(lib.bfm_conv3x3x3_wgrad_ex(L.ptr(dP), cout, L.ptr(A), cin, None, 0, D, H, W, None, L.ptr(scale), L.ptr(shift),
+                                           L.ptr(bnd), L.ptr(xb), 1, 3, L.ptr(dW), L.ptr(ws), ws.numel(), st), "wgrad")
+    call()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print("  %4d -> %3d at %s: %.3f ms = %.0f TFLOP/s" % (cin, cout, dims, ms, 2.0 * 27 * cin * cout * D * H * W / 1e9 / ms))
+    return ms
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -83,6 +111,11 @@ def main():
     for ca, cb, cout, div in ((64, 128, 64, 1), (128, 256, 128, 2), (256, 512, 256, 4), (512, 1024, 512, 8)):
         tot += run(lib, dev, ca, cb, cout, (n // div,) * 3, reps)
     print("decoder joins together: %.2f ms" % tot)
+    tot = 0.0
+    for cin, cout, div in ((32, 64, 1), (64, 64, 1), (64, 128, 2), (128, 128, 2), (128, 256, 4), (256, 256, 4), (256, 512, 8),
+                           (512, 512, 8)):
+        tot += run_plain(lib, dev, cin, cout, (n // div,) * 3, reps)
+    print("plain layers together: %.2f ms" % tot)
 
 
 if __name__ == "__main__":
