@@ -162,6 +162,8 @@ SIGNATURES = {
     "bfm_normalize_bwd": (_I, [_P, _P, _I, _L, _F, _P, _P]),
     "bfm_adamw_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _F, _P]),
     "bfm_grad_sumsq": (_I, [_P, _L, _P, _P, _P, _Z, _P]),
+    "bfm_grad_sumsq_multi": (_I, [_P, _I, _P, _I, _L, _P, _P, _P, _Z, _P]),
+    "bfm_adamw_step_multi": (_I, [_P, _I, _P, _I, _L, _F, _F, _F, _F, _F, _P]),
     "bfm_conv3x3x3_stem": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P]),
     "bfm_conv3x3x3_mfma_workspace": (_Z, [_I, _I, _I, _I, _I, _I]),
     "bfm_conv3x3x3_mfma_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),

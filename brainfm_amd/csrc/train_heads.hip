@@ -652,6 +652,88 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ g,
 
 int grid_for(int64_t n, int cap = 4096) { return (int)std::min<int64_t>(cap, std::max<int64_t>(1, bfm_cdiv64(n, 256))); }
 
+// ---- all parameters of the step in one launch each (round 4): the per-tensor kernels above cost 252 x 3 launches per
+// iteration, most of them over a few hundred floats (GroupNorm gamma / beta).  A block owns one chunk of one tensor.
+__global__ void __launch_bounds__(256) sumsq_multi_kernel(const bfm_adam_tensor_t* __restrict__ T, const int32_t* __restrict__ chunk_tensor,
+                                                          int64_t chunk_elems, double* __restrict__ part, int* __restrict__ nonfinite) {
+    __shared__ double red[256];
+    const int t = chunk_tensor[blockIdx.x];
+    const bfm_adam_tensor_t d = T[t];
+    const int64_t i0 = (int64_t)(blockIdx.x - d.first_chunk) * chunk_elems, i1 = min(d.n, i0 + chunk_elems);
+    const float* g = d.g;
+    double acc = 0.0;
+    bool bad = false;
+    if (((reinterpret_cast<uintptr_t>(g) & 15) == 0) && ((i1 - i0) & 3) == 0) {
+        const float4* g4 = reinterpret_cast<const float4*>(g + i0);
+        for (int64_t i = threadIdx.x; i < (i1 - i0) >> 2; i += 256) {
+            const float4 x = g4[i];
+            if (!(fabsf(x.x) <= 3.402823466e+38f) || !(fabsf(x.y) <= 3.402823466e+38f) || !(fabsf(x.z) <= 3.402823466e+38f) ||
+                !(fabsf(x.w) <= 3.402823466e+38f))
+                bad = true;
+            acc += (double)x.x * (double)x.x + (double)x.y * (double)x.y + (double)x.z * (double)x.z + (double)x.w * (double)x.w;
+        }
+    } else {
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+            const float x = g[i];
+            if (!(fabsf(x) <= 3.402823466e+38f)) bad = true;
+            acc += (double)x * (double)x;
+        }
+    }
+    if (bad) atomicOr(nonfinite, 1);
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+
+__global__ void sumsq_multi_fold_kernel(const bfm_adam_tensor_t* __restrict__ T, int ntensors, int64_t chunk_elems,
+                                        const double* __restrict__ part, double* __restrict__ out) {
+    const int t = blockIdx.x, l = threadIdx.x;                    // one wave per tensor, fixed order
+    if (t >= ntensors) return;
+    const int c0 = T[t].first_chunk, nc = (int)((T[t].n + chunk_elems - 1) / chunk_elems);
+    double s_ = 0.0;
+    for (int c = l; c < nc; c += 64) s_ += part[c0 + c];
+    s_ = wave_reduce_sum(s_);
+    if (l == 0) out[t] = s_;
+}
+
+__global__ void __launch_bounds__(256) adamw_multi_kernel(const bfm_adam_tensor_t* __restrict__ T, const int32_t* __restrict__ chunk_tensor,
+                                                          int64_t chunk_elems, float lr, float b1, float b2, float eps, float wd) {
+    const int t = chunk_tensor[blockIdx.x];
+    const bfm_adam_tensor_t d = T[t];
+    const int64_t i0 = (int64_t)(blockIdx.x - d.first_chunk) * chunk_elems, i1 = min(d.n, i0 + chunk_elems);
+    const float gs = d.grad_scale, bias1 = d.bias1, bias2_sqrt = d.bias2_sqrt;
+    auto one = [&](float& pi, float gi, float& mi, float& vi) __attribute__((always_inline)) {      // adamw_kernel's expressions
+        gi = gi * gs;
+        pi = pi * (1.f - lr * wd);
+        mi = b1 * mi + (1.f - b1) * gi;
+        vi = b2 * vi + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vi) / bias2_sqrt + eps;
+        pi = pi - (lr / bias1) * (mi / denom);
+    };
+    const uintptr_t al = reinterpret_cast<uintptr_t>(d.p) | reinterpret_cast<uintptr_t>(d.g) | reinterpret_cast<uintptr_t>(d.m) |
+                         reinterpret_cast<uintptr_t>(d.v);
+    if ((al & 15) == 0 && ((i1 - i0) & 3) == 0) {
+        float4* p4 = reinterpret_cast<float4*>(d.p + i0);
+        const float4* g4 = reinterpret_cast<const float4*>(d.g + i0);
+        float4* m4 = reinterpret_cast<float4*>(d.m + i0);
+        float4* v4 = reinterpret_cast<float4*>(d.v + i0);
+        for (int64_t i = threadIdx.x; i < (i1 - i0) >> 2; i += 256) {
+            float4 pp = p4[i], mm = m4[i], vv = v4[i];
+            const float4 gg = g4[i];
+            one(pp.x, gg.x, mm.x, vv.x);
+            one(pp.y, gg.y, mm.y, vv.y);
+            one(pp.z, gg.z, mm.z, vv.z);
+            one(pp.w, gg.w, mm.w, vv.w);
+            p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        }
+    } else {
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+            float pi = d.p[i], mi = d.m[i], vi = d.v[i];
+            one(pi, d.g[i], mi, vi);
+            d.p[i] = pi; d.m[i] = mi; d.v[i] = vi;
+        }
+    }
+}
+
 
 // ============================================================================ "rows" layout of the head outputs (round 4)
 // raw / dRaw as [n_out] rows of nvox values (row pitch rs >= nvox) instead of [nvox][n_out]: what the loss kernels walk is
@@ -1263,5 +1345,30 @@ extern "C" int bfm_grad_sumsq(const float* g, int64_t n, double* out, int32_t* n
     const int nb = grid_for(n, RB);
     hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, bfm_s(stream), g, n, part, nonfinite);
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(256), 0, bfm_s(stream), part, nb, 1.0, out);
+    return bfm_launch_status();
+}
+
+// ---- multi-tensor forms: `tensors` (device, ntensors descriptors), chunk_tensor (device, tensor of every chunk of
+// chunk_elems elements, tensors in order; first_chunk in the descriptor).  workspace: nchunks doubles.
+extern "C" int bfm_grad_sumsq_multi(const bfm_adam_tensor_t* tensors, int ntensors, const int32_t* chunk_tensor, int nchunks,
+                                    int64_t chunk_elems, double* sums_out, int32_t* nonfinite, void* workspace,
+                                    size_t workspace_bytes, bfm_stream_t stream) {
+    if (!tensors || !chunk_tensor || !sums_out || !nonfinite || !workspace || ntensors <= 0 || nchunks <= 0 ||
+        chunk_elems <= 0 || (chunk_elems & 3))
+        return BFM_E_ARG;
+    if (workspace_bytes < (size_t)nchunks * sizeof(double)) return BFM_E_WORKSPACE;
+    hipStream_t st = bfm_s(stream);
+    double* part = static_cast<double*>(workspace);
+    hipLaunchKernelGGL(sumsq_multi_kernel, dim3(nchunks), dim3(256), 0, st, tensors, chunk_tensor, chunk_elems, part, nonfinite);
+    hipLaunchKernelGGL(sumsq_multi_fold_kernel, dim3(ntensors), dim3(64), 0, st, tensors, ntensors, chunk_elems, part, sums_out);
+    return bfm_launch_status();
+}
+
+extern "C" int bfm_adamw_step_multi(const bfm_adam_tensor_t* tensors, int ntensors, const int32_t* chunk_tensor, int nchunks,
+                                    int64_t chunk_elems, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                    bfm_stream_t stream) {
+    if (!tensors || !chunk_tensor || ntensors <= 0 || nchunks <= 0 || chunk_elems <= 0 || (chunk_elems & 3)) return BFM_E_ARG;
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3(nchunks), dim3(256), 0, bfm_s(stream), tensors, chunk_tensor, chunk_elems, lr, beta1,
+                       beta2, eps, weight_decay);
     return bfm_launch_status();
 }

@@ -22,6 +22,7 @@ import math
 import os
 from collections import OrderedDict
 
+import numpy as np
 import torch
 
 from . import _lib as L
@@ -96,6 +97,12 @@ def allreduce_mean_(grads, group=None):
         grads[k].copy_(flat[off:off + n].view_as(grads[k]))
         off += n
     return grads
+
+
+# bfm_adam_tensor_t (include/brainfm_hip.h): p, g, m, v, n, grad_scale, bias1, bias2_sqrt, first_chunk, reserved
+_ADAM_DESC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("grad_scale", "<f4"),
+                       ("bias1", "<f4"), ("bias2_sqrt", "<f4"), ("first_chunk", "<i4"), ("reserved", "<i8")])
+assert _ADAM_DESC.itemsize == 64
 
 
 class TrainStep:
@@ -537,10 +544,39 @@ class TrainStep:
         names = [k for k in params if k in grads]
         sums = torch.zeros(len(names), dtype=torch.float64, device=self.dev)
         flag = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        for i, k in enumerate(names):
-            g = grads[k] = grads[k].contiguous()
-            L.check(lib.bfm_grad_sumsq(L.ptr(g), g.numel(), C.c_void_p(sums.data_ptr() + 8 * i), L.ptr(flag),
-                                       L.ptr(self._ws), self._ws.numel(), st), "grad_sumsq " + k)
+        multi = os.environ.get("BFM_ADAM_MULTI", "1") != "0"
+        for k in names:
+            grads[k] = grads[k].contiguous()
+            if not params[k].is_contiguous():
+                raise L.BfmError("parameter %s is not contiguous" % k)
+            if k not in self.state:
+                self.state[k] = (torch.zeros(params[k].numel(), dtype=torch.float32, device=self.dev),
+                                 torch.zeros(params[k].numel(), dtype=torch.float32, device=self.dev))
+        if multi:
+            # every tensor's sum of squares in one launch (+ a fold): descriptors and chunk map in device memory
+            CH = 65536
+            desc = np.zeros(len(names), dtype=_ADAM_DESC)
+            first, cmap = 0, []
+            for i, k in enumerate(names):
+                n = params[k].numel()
+                m, v = self.state[k]
+                desc[i] = (params[k].data_ptr(), grads[k].data_ptr(), m.data_ptr(), v.data_ptr(), n, 0.0, 1.0, 1.0, first, 0)
+                nch = (n + CH - 1) // CH
+                cmap.extend([i] * nch)
+                first += nch
+            key = tuple(params[k].numel() for k in names)
+            if getattr(self, "_chunk_key", None) != key:
+                self._chunk_key = key
+                self._chunk_map = torch.tensor(cmap, dtype=torch.int32, device=self.dev)
+                self._chunk_ws = torch.empty(len(cmap), dtype=torch.float64, device=self.dev)
+            tdev = torch.from_numpy(desc.view(np.uint8).reshape(-1)).to(self.dev)
+            L.check(lib.bfm_grad_sumsq_multi(L.ptr(tdev), len(names), L.ptr(self._chunk_map), len(cmap), CH, L.ptr(sums),
+                                             L.ptr(flag), L.ptr(self._chunk_ws), self._chunk_ws.numel() * 8, st), "grad_sumsq_multi")
+        else:
+            for i, k in enumerate(names):
+                g = grads[k]
+                L.check(lib.bfm_grad_sumsq(L.ptr(g), g.numel(), C.c_void_p(sums.data_ptr() + 8 * i), L.ptr(flag),
+                                           L.ptr(self._ws), self._ws.numel(), st), "grad_sumsq " + k)
         inv = 1.0 / self.scaler.scale
         found_inf = bool(flag.item())
         norms = [math.sqrt(v) * inv if math.isfinite(v) else float("inf") for v in sums.cpu().tolist()]
@@ -549,7 +585,7 @@ class TrainStep:
             self.scaler.update(True)
             return False, norms
         self.t += 1
-        for k, nrm in zip(names, norms):
+        for i, (k, nrm) in enumerate(zip(names, norms)):
             p, g = params[k], grads[k]
             self.steps[k] = self.steps.get(k, 0) + 1        # torch.optim.AdamW keeps one step count per parameter
             coef = inv
@@ -557,14 +593,21 @@ class TrainStep:
                 c = self.clip / (nrm + 1e-6)
                 if c < 1:
                     coef *= c
-            if k not in self.state:
-                self.state[k] = (torch.zeros(p.numel(), dtype=torch.float32, device=self.dev),
-                                 torch.zeros(p.numel(), dtype=torch.float32, device=self.dev))
             m, v = self.state[k]
-            if not p.is_contiguous():
-                raise L.BfmError("parameter %s is not contiguous" % k)
-            L.check(lib.bfm_adamw_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, self.betas[0], self.betas[1],
-                                       self.eps, wd, self.steps[k], coef, st), "adamw " + k)
+            if multi:
+                # bias corrections in float32 as bfm_adamw_step forms them (powf, sqrtf)
+                b1 = np.float32(1.0) - np.power(np.float32(self.betas[0]), np.float32(self.steps[k]), dtype=np.float32)
+                b2 = np.sqrt(np.float32(1.0) - np.power(np.float32(self.betas[1]), np.float32(self.steps[k]), dtype=np.float32),
+                             dtype=np.float32)
+                desc[i]["grad_scale"], desc[i]["bias1"], desc[i]["bias2_sqrt"] = coef, b1, b2
+            else:
+                L.check(lib.bfm_adamw_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, self.betas[0], self.betas[1],
+                                           self.eps, wd, self.steps[k], coef, st), "adamw " + k)
+        if multi:
+            tdev = torch.from_numpy(desc.view(np.uint8).reshape(-1)).to(self.dev)
+            L.check(lib.bfm_adamw_step_multi(L.ptr(tdev), len(names), L.ptr(self._chunk_map), int(self._chunk_map.numel()), CH, lr,
+                                             self.betas[0], self.betas[1], self.eps, wd, st), "adamw_multi")
+            self._keep_desc = tdev
         self._weights_changed()
         self.scaler.update(False)
         return True, norms

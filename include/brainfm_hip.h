@@ -762,6 +762,26 @@ int bfm_head_bwd_rows(const float* dRaw_rows, int64_t row_stride, const float* F
                       bfm_stream_t stream);
 int bfm_normalize_bwd(const float* feat, const float* dFn, int C, int64_t nvox, float eps, float* dfeat,
                       bfm_stream_t stream);
+/* One descriptor per parameter tensor for the multi-tensor forms below (device memory, 64 bytes).  bias1 = 1 - beta1^t,
+ * bias2_sqrt = sqrt(1 - beta2^t) of the tensor's own step count t (torch.optim.AdamW keeps one per parameter); first_chunk =
+ * index of the tensor's first chunk in chunk_tensor. */
+typedef struct bfm_adam_tensor {
+    float* p; const float* g; float* m; float* v;
+    int64_t n;
+    float grad_scale, bias1, bias2_sqrt;
+    int32_t first_chunk;
+    int64_t reserved;
+} bfm_adam_tensor_t;
+/* utils/misc.py:1329-1338 clip_gradients' per-parameter norms and Trainer/models/__init__.py:362-366's AdamW over ALL
+ * parameters in one launch each: a block owns one chunk (chunk_elems elements, a multiple of 4) of one tensor;
+ * chunk_tensor[c] = tensor of chunk c (device).  sums_out[t] = sum of squares of tensors[t].g (fp64, fixed order);
+ * workspace >= nchunks * 8 bytes. */
+int bfm_grad_sumsq_multi(const bfm_adam_tensor_t* tensors, int ntensors, const int32_t* chunk_tensor, int nchunks,
+                         int64_t chunk_elems, double* sums_out, int32_t* nonfinite, void* workspace, size_t workspace_bytes,
+                         bfm_stream_t stream);
+int bfm_adamw_step_multi(const bfm_adam_tensor_t* tensors, int ntensors, const int32_t* chunk_tensor, int nchunks,
+                         int64_t chunk_elems, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         bfm_stream_t stream);
 /* torch.optim.AdamW step t (1-based) on one flat parameter; g is multiplied by grad_scale first (unscale * clip) */
 int bfm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, float grad_scale, bfm_stream_t stream);

@@ -550,3 +550,26 @@ def test_weight_gradient_of_a_decoder_join_vs_float64(ca, cb, cout, dims):
         ref[:, :, t] = (Xp[:, kd:kd + D, kh:kh + H, kw:kw + W].reshape(cin, -1) @ d64).t()
     err = float((dW.double() - ref).abs().max() / ref.abs().max())
     assert err <= 2e-5, err
+
+
+def test_multi_tensor_clip_norms_and_adamw_equal_the_per_tensor_kernels(monkeypatch):
+    """TrainStep.apply with all parameters in one launch each (bfm_grad_sumsq_multi, bfm_adamw_step_multi; round 4) against
+    the per-tensor kernels (BFM_ADAM_MULTI=0): same clipping norms to fp64 rounding of a different fold order, same
+    parameters after two steps to one float32 rounding of the bias corrections."""
+    c = load_case()
+    outs = []
+    for multi in ("1", "0"):
+        monkeypatch.setenv("BFM_ADAM_MULTI", multi)
+        step, xs, target, samples = _build(c)
+        norms_all = []
+        for _ in range(2):
+            _, _, grads = step.loss_and_grads(xs, target, samples)
+            ok, norms = step.apply(grads)
+            assert ok
+            norms_all.append(norms)
+        outs.append((norms_all, {k: v.clone() for k, v in step.parameters().items()}))
+    (na, pa), (nb, pb) = outs
+    assert np.allclose(na[0], nb[0], rtol=1e-12, atol=0)
+    assert np.allclose(na[1], nb[1], rtol=1e-5, atol=1e-12)
+    for k in pa:
+        assert float((pa[k] - pb[k]).abs().max()) <= 1e-6 * max(1.0, float(pb[k].abs().max())), k
