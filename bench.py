@@ -308,6 +308,63 @@ def synthesis_block(dev, items=8):
                     "where the reference computes in fp64)"}
 
 
+def training_block(dev, size=128, reps=2):
+    """SURVEY N2 on the bench line: one training iteration of the full-width net (f_maps 64, 6 levels, the demo head set,
+    16 losses) on one size^3 sample of synthetic data -- forward, losses, backward, per-parameter clip, AdamW, re-packed
+    weights -- timed with HIP events on torch's stream (scripts/bench_train.py is the stand-alone form, DDP included)."""
+    from brainfm_amd import backward as BW
+    from brainfm_amd import test_utils as TU
+    from brainfm_amd import train as TR
+    ga, ta = TU.default_inference_args(f_maps=64, num_levels=6)
+    torch.manual_seed(1)
+    s = TU.InferenceSession(ga, ta, dev, passes=3)
+    tail = s.model.head.tail(s.engine)
+    names = ["T1", "T1_grad", "T2", "T2_grad", "FLAIR", "FLAIR_grad", "CT", "CT_grad", "seg_ce", "seg_dice", "distance",
+             "bias_field_log", "registration", "registration_grad", "SR", "SR_grad"]
+    ns = tail.desc.n_seg
+    step = TR.TrainStep(s.engine, tail, names, {"loss_" + n: 1.0 for n in names}, torch.full((ns,), 1.0 / ns), 4, lr=1e-4)
+    g = torch.Generator().manual_seed(0)
+    dims = (size,) * 3
+    xs = [torch.rand((1, 1) + dims, generator=g).to(dev)]
+    lab = torch.randint(0, ns, (1,) + dims, generator=g)
+    target = {"segmentation": torch.nn.functional.one_hot(lab, ns).permute(0, 4, 1, 2, 3).float().contiguous().to(dev)}
+    for k in ("T1", "T2", "FLAIR", "CT"):
+        target[k] = torch.rand((1, 1) + dims, generator=g).to(dev)
+    target["distance"] = torch.randn((1, 4) + dims, generator=g).to(dev)
+    target["registration"] = torch.randn((1, 3) + dims, generator=g).to(dev)
+    samples = [{"bias_field_log": torch.randn((1, 1) + dims, generator=g).to(dev) * 0.3,
+                "high_res_residual": torch.randn((1, 1) + dims, generator=g).to(dev) * 0.2}]
+
+    def forward_only():
+        feats, _ = BW.backbone_forward_train(s.engine, s.engine.to_cl(xs[0]), dims)
+        tail.run_raw(feats[-1][0], dims)
+
+    forward_only()                                   # tunes the conv variants, packs the weights
+    torch.cuda.synchronize()
+    tf = tb = to = 0.0
+    total, ok = float("nan"), False
+    for r in range(reps + 1):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        e[0].record()
+        forward_only()
+        e[1].record()
+        _, total, grads = step.loss_and_grads(xs, target, samples)
+        e[2].record()
+        ok, _ = step.apply(grads)
+        e[3].record()
+        torch.cuda.synchronize()
+        if r == 0:
+            continue                                  # first pass allocates the optimiser state and the dgrad packs
+        tf += e[0].elapsed_time(e[1])
+        tb += e[1].elapsed_time(e[2])
+        to += e[2].elapsed_time(e[3])
+    tf, tb, to = tf / reps, tb / reps, to / reps
+    return {"what": "one training iteration, full-width net, one %d^3 sample, 16 losses, synthetic data" % size,
+            "iteration_ms": round(tb + to, 2), "forward_alone_ms": round(tf, 2), "forward_losses_backward_ms": round(tb, 2),
+            "clip_adamw_repack_ms": round(to, 2), "mvoxel_per_s": round(size ** 3 / (tb + to) / 1e3, 2),
+            "loss": round(float(total), 4), "stepped": bool(ok), "reps": reps, "dtype": "f32 (split-f16 x3 matrix-core products)"}
+
+
 def launch_ranks(n, argv):
     """--gpus N without a launcher: one child per device, started before this process makes any GPU call (a process
     that has initialised the GPU must not be replaced or forked into ranks).  Relays rank 0's JSON line."""
@@ -371,6 +428,7 @@ def main():
     ap.add_argument("--no-dense-check", action="store_true", help="skip the extra steps on a volume without zeros")
     ap.add_argument("--no-graphs", action="store_true", help="submit every kernel from python instead of hipGraph replay")
     ap.add_argument("--no-synthesis", action="store_true", help="skip the synthesis block (hot path B) of the line")
+    ap.add_argument("--no-training", action="store_true", help="skip the training block (SURVEY N2) of the line")
     ap.add_argument("--roofline-reps", type=int, default=3,
                     help="back-to-back launches per HIP-event bracket in the instrumented conv pass")
     args = ap.parse_args()
@@ -751,6 +809,12 @@ def main():
                 line["synthesis"] = synthesis_block(dev)
             except Exception as e:                            # noqa: BLE001 -- never lose the headline line to the extra block
                 line["synthesis"] = {"error": repr(e)}
+        line["training"] = None
+        if not args.no_training and world == 1:
+            try:
+                line["training"] = training_block(dev)
+            except Exception as e:                            # noqa: BLE001
+                line["training"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             sd = {k: v for k, v in sess.model.state_dict().items()}
             line["cpu_baseline"] = cpu_baseline(sd, full, n, ranges, not args.cpu_baseline_quick, sess)
