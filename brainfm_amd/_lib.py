@@ -218,6 +218,7 @@ SIGNATURES = {
                                 _Z, _P]),
     "bfm_minmax_normalise": (_I, [_P, _L, _P, _P]),
     "bfm_gather_onehot": (_I, [_P, _I, _I, _I, C.POINTER(_I), _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
+    "bfm_gather_onehot_rows": (_I, [_P, _I, _I, _I, C.POINTER(_I), _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
     "bfm_percentile_workspace": (_Z, []),
     "bfm_percentile_f64": (_I, [_P, _L, _L, _I, C.c_double, _P, _P, _Z, _P]),
     "bfm_shape_workspace": (_Z, []),

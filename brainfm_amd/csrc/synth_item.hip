@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256) gather_onehot(const int32_t* __restrict__
                                                      const float* __restrict__ II, const float* __restrict__ JJ,
                                                      const float* __restrict__ KK, int64_t n, int sx, int64_t syz, int flip,
                                                      const int32_t* __restrict__ lut, int nlut, int nl,
-                                                     const int32_t* __restrict__ vflip, float* __restrict__ out) {
+                                                     const int32_t* __restrict__ vflip, float* __restrict__ out, int rows) {
     __shared__ int cls[256];
     __shared__ int vf[256];
     for (int c = threadIdx.x; c < nl; c += 256) vf[c] = vflip ? vflip[c] : c;
@@ -353,6 +353,13 @@ __global__ void __launch_bounds__(256) gather_onehot(const int32_t* __restrict__
             cls[threadIdx.x] = lut[s];
         }
         __syncthreads();
+        if (rows) {                                             // [nl] rows of n voxels: what the permuted view of the reference is read as
+            if (o < n) {
+                const int mine = cls[threadIdx.x];
+                for (int c = 0; c < nl; ++c) out[(int64_t)c * n + o] = mine == vf[c] ? 1.f : 0.f;
+            }
+            continue;
+        }
         const int64_t base = blk * 256 * (int64_t)nl;
         const int cnt = (int)min((int64_t)256, n - blk * 256) * nl;
         for (int e = threadIdx.x; e < cnt; e += 256) {
@@ -783,9 +790,9 @@ extern "C" int bfm_minmax_normalise(float* x, int64_t n, const double* minmax_de
     return bfm_launch_status();
 }
 
-extern "C" int bfm_gather_onehot(const int32_t* S, int nx, int ny, int nz, const int* box6_host, const float* II,
-                                 const float* JJ, const float* KK, int sx, int sy, int sz, int flip0, const int32_t* lut,
-                                 int nlut, int n_labels, const int32_t* vflip, float* out, bfm_stream_t stream) {
+static int gather_onehot_launch(const int32_t* S, int nx, int ny, int nz, const int* box6_host, const float* II,
+                                const float* JJ, const float* KK, int sx, int sy, int sz, int flip0, const int32_t* lut,
+                                int nlut, int n_labels, const int32_t* vflip, float* out, int rows, bfm_stream_t stream) {
     Box B;
     if (!S || !II || !JJ || !KK || !lut || !out || nlut <= 0 || n_labels <= 0 || n_labels > 256 || sx <= 0 || sy <= 0 ||
         sz <= 0 || nx <= 0 || ny <= 0 || nz <= 0)
@@ -793,8 +800,24 @@ extern "C" int bfm_gather_onehot(const int32_t* S, int nx, int ny, int nz, const
     if (!make_box(box6_host, nx, ny, nz, B)) return BFM_E_SHAPE;
     const int64_t n = (int64_t)sx * sy * sz;
     hipLaunchKernelGGL(gather_onehot, dim3(grid_for(n, 256, 4096)), dim3(256), 0, bfm_s(stream), S, ny, nz, B, II, JJ, KK,
-                       n, sx, (int64_t)sy * sz, flip0 ? 1 : 0, lut, nlut, n_labels, vflip, out);
+                       n, sx, (int64_t)sy * sz, flip0 ? 1 : 0, lut, nlut, n_labels, vflip, out, rows);
     return bfm_launch_status();
+}
+
+extern "C" int bfm_gather_onehot(const int32_t* S, int nx, int ny, int nz, const int* box6_host, const float* II,
+                                 const float* JJ, const float* KK, int sx, int sy, int sz, int flip0, const int32_t* lut,
+                                 int nlut, int n_labels, const int32_t* vflip, float* out, bfm_stream_t stream) {
+    return gather_onehot_launch(S, nx, ny, nz, box6_host, II, JJ, KK, sx, sy, sz, flip0, lut, nlut, n_labels, vflip, out, 0,
+                                stream);
+}
+
+// the same with out as [n_labels][sx][sy][sz] -- the memory the reference's one_hot(...).permute([3, 0, 1, 2]) view is read
+// as by every consumer (the training criterion walks one class at a time): no strided 0.9 GB copy per 160^3 sample later
+extern "C" int bfm_gather_onehot_rows(const int32_t* S, int nx, int ny, int nz, const int* box6_host, const float* II,
+                                      const float* JJ, const float* KK, int sx, int sy, int sz, int flip0, const int32_t* lut,
+                                      int nlut, int n_labels, const int32_t* vflip, float* out, bfm_stream_t stream) {
+    return gather_onehot_launch(S, nx, ny, nz, box6_host, II, JJ, KK, sx, sy, sz, flip0, lut, nlut, n_labels, vflip, out, 1,
+                                stream);
 }
 
 namespace {

@@ -611,6 +611,11 @@ int bfm_minmax_normalise(float* x, int64_t n, const double* minmax_dev, bfm_stre
 int bfm_gather_onehot(const int32_t* S, int nx, int ny, int nz, const int* box6_host, const float* II, const float* JJ,
                       const float* KK, int sx, int sy, int sz, int flip0, const int32_t* lut, int nlut, int n_labels,
                       const int32_t* vflip /*[n_labels] or NULL*/, float* out, bfm_stream_t stream);
+/* the same, out as [n_labels][sx][sy][sz]: the element order the reference's .permute([3, 0, 1, 2]) view is read in
+ * (Generator/utils.py:423-425), so that no consumer has to make it contiguous */
+int bfm_gather_onehot_rows(const int32_t* S, int nx, int ny, int nz, const int* box6_host, const float* II, const float* JJ,
+                      const float* KK, int sx, int sy, int sz, int flip0, const int32_t* lut, int nlut, int n_labels,
+                      const int32_t* vflip /*[n_labels] or NULL*/, float* out, bfm_stream_t stream);
 
 /* np.percentile(x, q) (method 'linear', ShapeID/perlin3d.py:84-90) without leaving the device: radix select of the
  * order statistic k_lo (six passes over 11 / 9-bit digits of the order-preserving key, block histograms in LDS), the

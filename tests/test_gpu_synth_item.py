@@ -186,6 +186,12 @@ def test_gather_onehot_equals_nearest_plus_onehot_bitwise(flip):
     if flip:
         ref = torch.flip(ref, [0])[:, :, :, vflip.long()]
     assert torch.equal(out, ref)
+    # the class-major form the generator hands to the criterion: the same values in the order of the permuted view
+    rows = torch.full((nl,) + out_shape, float("nan"), device=DEV)
+    L.check(lib.bfm_gather_onehot_rows(L.ptr(St), shp[0], shp[1], shp[2], (C.c_int * 6)(*box), L.ptr(II), L.ptr(JJ), L.ptr(KK),
+                                       out_shape[0], out_shape[1], out_shape[2], int(flip), L.ptr(lut), lut.numel(), nl,
+                                       L.ptr(vflip) if flip else None, L.ptr(rows), L.stream_ptr()), "gather_onehot_rows")
+    assert torch.equal(rows, ref.permute(3, 0, 1, 2))
 
 
 def test_percentile_on_the_device_equals_numpy():
