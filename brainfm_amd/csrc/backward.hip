@@ -798,7 +798,9 @@ __global__ void __launch_bounds__(WGU_THREADS) conv_wgrad_up_f16_kernel(const Wg
     // half of a row for ONE channel -- eight (ten) 4-byte loads whose addresses differ by a wave-uniform stride (32 lanes x 4
     // bytes contiguous per load), four x pairs converted to one 16-byte LDS store per plane.  No per-lane channel rotation
     // (the float4-per-voxel form of conv_wgrad_f16_kernel spends half of its staging instructions on v_cndmask), no
-    // per-element masks: h % 4 == 0 and w % 16 == 0 (host-checked) leave the x ends of the halo as the only padding.
+    // per-element masks: every tile is a full 4 x 16 one (h >= 4, w >= 16 host-checked; the last tile of a ragged row / column is
+    // shifted back inside and the voxels it shares with its neighbour count as zero in dP), the x ends of the halo are the
+    // only padding.
     // Measured on the 64 + 128 -> 64 join at 128^3 (kernel 1.17 ms: MFMA phase 0.49, LDS stores 0.23, loads 0.43): the
     // float4 form cost 0.55 (stores) + 0.32 (loads); 8-byte loads of channel pairs (62 per thread instead of 114, under
     // the 64 a wave keeps in flight) 0.17 + 0.56 -- four 128-byte segments per load are slower than two; issuing the
@@ -810,12 +812,15 @@ __global__ void __launch_bounds__(WGU_THREADS) conv_wgrad_up_f16_kernel(const Wg
     const float scx = p.scale[ci0 + c] * sx, shx = p.shift[ci0 + c] * sx;
     constexpr int ND = 8, NX = 5;
     float pd[ND][8], px[NX][10];
-    unsigned xmask = 0;                                    // wave-uniform: bits 0..4 halo row s inside, 5: x0 > 0, 6: x0 + 16 < w
+    // wave-uniform: bits 0..4 halo row s inside, 5: x0 > 0, 6: x0 + 16 < w, 8..11 / 12..13: leading columns / rows of dP
+    // that an earlier tile already covered -- the last tile of a row (column) that does not divide by 16 (4) is shifted
+    // back inside the volume and those voxels count as zero
+    unsigned xmask = 0;
     auto load_tile = [&](int tile) __attribute__((always_inline)) {
         const int bx = tile % p.nbx;
         const int t2 = tile / p.nbx;
         const int by = t2 % p.nby, z0 = t2 / p.nby;
-        const int y0 = by * UT_Y, x0 = bx * UT_X;
+        const int y0 = min(by * UT_Y, p.h - UT_Y), x0 = min(bx * UT_X, p.w - UT_X);
 #pragma unroll
         for (int s = 0; s < ND; ++s) {
             const int rx = s >> 2, yl = s & 3;
@@ -824,7 +829,8 @@ __global__ void __launch_bounds__(WGU_THREADS) conv_wgrad_up_f16_kernel(const Wg
 #pragma unroll
             for (int j = 0; j < 8; ++j) pd[s][j] = rp[(int64_t)(2 * j) * p.Cout];
         }
-        xmask = (x0 > 0 ? 32u : 0u) | (x0 + UT_X < p.w ? 64u : 0u);
+        xmask = (x0 > 0 ? 32u : 0u) | (x0 + UT_X < p.w ? 64u : 0u) | ((unsigned)(bx * UT_X - x0) << 8) |
+                ((unsigned)(by * UT_Y - y0) << 12);
 #pragma unroll
         for (int s = 0; s < NX; ++s) {
             const int hrow = wave + 4 * s;
@@ -842,6 +848,14 @@ __global__ void __launch_bounds__(WGU_THREADS) conv_wgrad_up_f16_kernel(const Wg
         }
     };
     auto store_tile = [&]() __attribute__((always_inline)) {
+        if (xmask >> 8) {                                      // wave-uniform: a shifted tile
+            const int xskip = (int)((xmask >> 8) & 15u) - 8 * xh, yskip = (int)(xmask >> 12);
+#pragma unroll
+            for (int s = 0; s < ND; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < xskip || (s & 3) < yskip) pd[s][j] = 0.f;
+        }
 #pragma unroll
         for (int s = 0; s < ND; ++s) {
             uint32_t hi[4], lo[4];
@@ -1462,7 +1476,7 @@ extern "C" int bfm_conv3x3x3_wgrad_ex(const float* dP, int Cout, const float* A,
         return rc != BFM_OK ? rc : bfm_launch_status();
     }
     if (f16 && upfold_on && CB > 0 && CB % 32 == 0 && 2 * up->d == D && 2 * up->h == H && 2 * up->w == W &&
-        up->h % UT_Y == 0 && up->w % UT_X == 0) {
+        up->h >= UT_Y && up->w >= UT_X) {
         hipStream_t st2 = st;
         // (1) skip channels alone, compact partials
         static bool attr3a = false, attrU = false;

@@ -509,12 +509,14 @@ def test_weight_repack_kernels_against_layout_models():
         assert np.array_equal(buf.cpu().numpy().view(np.uint16), ref.reshape(-1).view(np.uint16)), ("mfma16", cout, cin)
 
 
-@pytest.mark.parametrize("ca,cb,cout,dims", [(32, 64, 64, (8, 16, 32)), (64, 32, 128, (6, 8, 96)), (32, 32, 64, (8, 12, 40))])
+@pytest.mark.parametrize("ca,cb,cout,dims", [(32, 64, 64, (8, 16, 32)), (64, 32, 128, (6, 8, 96)), (32, 32, 64, (8, 12, 40)),
+                                             (32, 64, 64, (4, 10, 36)), (32, 32, 64, (6, 14, 24))])
 def test_weight_gradient_of_a_decoder_join_vs_float64(ca, cb, cout, dims):
     """bfm_conv3x3x3_wgrad_ex on cat(skip, nearest_up2(low)): for an exact 2x join whose low-res rows tile by 4 x 16 the
     upsampled channels take the folded kernel of round 4 (64 products per low-res voxel on the low-res tensor instead of
-    27 per high-res voxel, conv_wgrad_up_f16_kernel) and the skip channels the 27-tap kernel alone; (8, 12, 40) does not
-    tile and keeps the 27-tap kernel on all channels.  Against the float64 correlation of the GroupNorm-applied,
+    27 per high-res voxel, conv_wgrad_up_f16_kernel) and the skip channels their own kernel; low-res sizes that do not
+    divide by the 4 x 16 tile -- (8, 12, 40) -> 6 x 20, (4, 10, 36) -> 5 x 18 -- shift their last tile back inside and zero the
+    shared voxels; (6, 14, 24) -> 7 x 12 is narrower than a tile and keeps the 27-tap kernel on all channels.  Against the float64 correlation of the GroupNorm-applied,
     zero-padded input with dP: split-fp16 products with fp32 accumulation, 2e-5 of the largest entry."""
     import ctypes as C
     from brainfm_amd import _lib as L
