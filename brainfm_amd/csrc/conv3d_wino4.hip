@@ -63,6 +63,11 @@ struct W4Params {
     float *rmn, *rmx;
     const int* list;                 // sparse forms: the boxes to compute, ascending
     const int* list_n;               // ... their number, on the device
+    // batch (dense form only): nMt = S * nMtS boxes, box mt belongs to sample mt / nMtS; A, out advance by sA, sO elements
+    // per sample, scale / shift by saff, bound by G; moment rows are [S * nMtS][Cout].  nMtS == 0: one sample.  A sample's
+    // workgroups do exactly what they do in a launch of that sample alone.
+    int nMtS, saff;
+    int64_t sA, sO;
 };
 
 __device__ __forceinline__ int row_perm(int l) {        // as conv_mfma: each 16-lane b128 group reads 16 consecutive positions
@@ -117,7 +122,8 @@ __device__ __forceinline__ void split_store4(const float (&t)[4], unsigned char*
 // instead of 1.  Built and measured (tests/diag/diag_wino4_uniform*.py: the pair is exact kernel by kernel, the network
 // is not); the layers that can take that shortcut stay with conv_wino (engine._needs_f23).
 template <int NPASS, int MODE>
-__device__ __forceinline__ void conv_wino4_body(const W4Params& p) {
+__device__ __forceinline__ void conv_wino4_body(const W4Params& pin) {
+    W4Params p = pin;
     constexpr bool LIST = MODE != 0;
     constexpr int NPL = (NPASS == 3) ? 2 : 1;
     constexpr int NF = 2 * NPL;
@@ -141,9 +147,19 @@ __device__ __forceinline__ void conv_wino4_body(const W4Params& p) {
     }
     const int mt = LIST ? p.list[item / p.NT] : item / p.NT;
     const int nt = item % p.NT;
-    const int tx = mt % p.nTx;
-    const int ty = (mt / p.nTx) % p.nTy;
-    const int tz = mt / (p.nTx * p.nTy);
+    int mtl = mt;                                                  // box inside its sample
+    if (!LIST && p.nMtS > 0) {
+        const int smp = mt / p.nMtS;
+        mtl = mt - smp * p.nMtS;
+        p.A += smp * p.sA;
+        p.out += smp * p.sO;
+        p.scale += smp * p.saff;
+        p.shift += smp * p.saff;
+        p.bound += smp * p.G;
+    }
+    const int tx = mtl % p.nTx;
+    const int ty = (mtl / p.nTx) % p.nTy;
+    const int tz = mtl / (p.nTx * p.nTy);
     const int z0 = tz * p.TD, y0 = ty * p.TH, x0 = tx * p.TW;
 
     float bmax = 0.f;
@@ -517,7 +533,8 @@ extern "C" int bfm_conv3x3x3_wino4_rows(int D, int H, int W, int passes) {
 
 static int w4_launch(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift, const float* bound,
                      int G, const void* wpacked, int wexp, int Cout, float slope, int passes, int flags, float* out,
-                     void* moment_rows, const float* mask_img, void* mask_ws, bfm_stream_t stream) {
+                     void* moment_rows, const float* mask_img, void* mask_ws, bfm_stream_t stream, int S = 1,
+                     int affine_stride = 0) {
     const int accumulate = flags & 1;
     if (flags & ~1) return BFM_E_ARG;                           // bit 0 = accumulate; nothing else is defined
     if (!A || CA <= 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || G <= 0 || !wpacked || !out)
@@ -541,6 +558,14 @@ static int w4_launch(const float* A, int CA, int D, int H, int W, const float* s
     const int nTz = bfm_cdiv(D, p.TD);
     p.nTy = bfm_cdiv(H, p.TH); p.nTx = bfm_cdiv(W, p.TW);
     p.nMt = nTz * p.nTy * p.nTx;
+    if (S > 1 || affine_stride > 0) {                           // batch of S same-shape samples
+        if (mask_img || S < 1 || (affine_stride != 0 && (affine_stride < CA || (affine_stride & 3)))) return BFM_E_ARG;
+        p.nMtS = p.nMt;
+        p.nMt = S * p.nMtS;
+        p.saff = affine_stride > 0 ? affine_stride : CA;
+        p.sA = (int64_t)D * H * W * CA;
+        p.sO = (int64_t)D * H * W * Cout;
+    }
     p.NT = Cout / 64;
     p.KCN = CA / KC;
     p.npos_lds = (p.TD + 2) * p.HT * p.QW;
@@ -582,6 +607,18 @@ extern "C" int bfm_conv3x3x3_wino4(const float* A, int CA, int D, int H, int W, 
                                    int passes, int flags, float* out, void* moment_rows, bfm_stream_t stream) {
     return w4_launch(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out, moment_rows,
                      nullptr, nullptr, stream);
+}
+
+// A (S,D,H,W,CA) -> out (S,D,H,W,Cout): S same-shape samples in one launch, per-sample scale / shift (rows affine_stride
+// apart, 0 = CA) and bound [S][G]; moment_rows [S * bfm_conv3x3x3_wino4_rows(...)][Cout].  Per sample the bits of
+// bfm_conv3x3x3_wino4 (the deep levels of same-shape tiles, engine.batch_conv).
+extern "C" int bfm_conv3x3x3_wino4_batch(const float* A, int CA, int S, int D, int H, int W, const float* scale,
+                                         const float* shift, const float* bound, int G, const void* wpacked, int wexp,
+                                         int Cout, float slope, int passes, int flags, float* out, void* moment_rows,
+                                         int affine_stride, bfm_stream_t stream) {
+    if (S < 1) return BFM_E_ARG;
+    return w4_launch(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out, moment_rows,
+                     nullptr, nullptr, stream, S, affine_stride > 0 ? affine_stride : CA);
 }
 
 // the tile loop's last convolution (boxes that hold input only); workspace: bfm_conv3x3x3_wino_masked_workspace() bytes

@@ -238,6 +238,12 @@ int bfm_conv3x3x3_wino4_rows(int D, int H, int W, int passes);
 int bfm_conv3x3x3_wino4(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                         const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
                         int flags, float* out, void* moment_rows /*or NULL*/, bfm_stream_t stream);
+/* S same-shape samples in one launch (A (S,D,H,W,CA) -> out (S,D,H,W,Cout)): per-sample scale / shift rows affine_stride
+ * apart (0 = CA), bound [S][G], moment_rows [S * bfm_conv3x3x3_wino4_rows()][Cout]; per sample the bits of
+ * bfm_conv3x3x3_wino4.  The deep levels of same-shape tiles (buildingblocks.py:31-60 on a batch). */
+int bfm_conv3x3x3_wino4_batch(const float* A, int CA, int S, int D, int H, int W, const float* scale, const float* shift,
+                              const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
+                              int flags, float* out, void* moment_rows, int affine_stride, bfm_stream_t stream);
 /* The masked form of the same kernel, box for box that of bfm_conv3x3x3_wino_masked (same boxes, same workspace).  There
  * is no uniform-box pair: F(4,3)'s rounding reaches 4 voxels along x where F(2,3)'s numerical support is its
  * mathematical one (conv3d_wino4.hip), so the layers that take that shortcut stay with bfm_conv3x3x3_wino_uniform. */

@@ -1485,3 +1485,46 @@ def test_winograd_f43_kernel_vs_float64_convolution(case):
         assert float((rq - (o2 * o2).sum(0)).abs().max()) <= 2e-7 * float((o2 * o2).sum(0).max())
         assert torch.equal(rows[k * 16:k * 20].view(torch.float32).view(n, cout).min(0)[0].cpu(), out.cpu().reshape(-1, cout).min(0)[0])
         assert torch.equal(rows[k * 20:k * 24].view(torch.float32).view(n, cout).max(0)[0].cpu(), out.cpu().reshape(-1, cout).max(0)[0])
+
+
+@pytest.mark.parametrize("case", [((8, 8, 16), 16, 64, 3), ((9, 11, 21), 32, 64, 2), ((5, 13, 7), 64, 128, 4)])
+def test_winograd_f43_batch_equals_one_launch_per_sample_bitwise(case):
+    """bfm_conv3x3x3_wino4_batch (round 4: the deep levels of same-shape tiles may run F(4,3)): S samples with their own
+    scale / shift / bound rows in one launch give, sample by sample, the bits of bfm_conv3x3x3_wino4 -- outputs and the
+    moment rows (a sample's workgroups do what they do alone), with the affine rows at their natural pitch and padded."""
+    from brainfm_amd import _lib as L
+    lib = L.load()
+    dev = _dev()
+    dims, cin, cout, S = case
+    g = torch.Generator().manual_seed(cin + S)
+    A = torch.randn(S, *dims, cin, generator=g).to(dev)
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) * 0.05).to(dev).contiguous()
+    wp = torch.empty(lib.bfm_pack_conv_weights_wino4_bytes(cin, cout, 3), dtype=torch.uint8, device=dev)
+    wexp = C.c_int(0)
+    L.check(lib.bfm_pack_conv_weights_wino4(L.ptr(w), cin, cout, float(w.abs().max()), 3, L.ptr(wp), C.byref(wexp),
+                                            L.stream_ptr()), "pack_wino4")
+    n = lib.bfm_conv3x3x3_wino4_rows(dims[0], dims[1], dims[2], 3)
+    k = n * cout
+    for pitch in (cin, cin + 16):
+        aff = torch.zeros(2, S, pitch, device=dev)
+        aff[0, :, :cin] = (torch.rand(S, cin, generator=g) + 0.5).to(dev)
+        aff[1, :, :cin] = (torch.randn(S, cin, generator=g) * 0.1).to(dev)
+        bound = torch.stack([torch.full((8,), float((A[s_].abs().amax((0, 1, 2)) * aff[0, s_, :cin] + aff[1, s_, :cin].abs()).max()))
+                             for s_ in range(S)]).to(dev).contiguous()
+        out = torch.full((S,) + dims + (cout,), float("nan"), device=dev)
+        rows = torch.zeros(lib.bfm_moment_rows_bytes(S * n, cout), dtype=torch.uint8, device=dev)
+        L.check(lib.bfm_conv3x3x3_wino4_batch(L.ptr(A), cin, S, dims[0], dims[1], dims[2], L.ptr(aff[0]), L.ptr(aff[1]),
+                                              L.ptr(bound), 8, L.ptr(wp), wexp.value, cout, 0.01, 3, 0, L.ptr(out),
+                                              L.ptr(rows), pitch if pitch != cin else 0, L.stream_ptr()), "conv_wino4_batch")
+        for s_ in range(S):
+            one = torch.full(dims + (cout,), float("nan"), device=dev)
+            r1 = torch.zeros(lib.bfm_moment_rows_bytes(n, cout), dtype=torch.uint8, device=dev)
+            sc, sh = aff[0, s_, :cin].contiguous(), aff[1, s_, :cin].contiguous()
+            L.check(lib.bfm_conv3x3x3_wino4(L.ptr(A[s_]), cin, dims[0], dims[1], dims[2], L.ptr(sc), L.ptr(sh),
+                                            L.ptr(bound[s_]), 8, L.ptr(wp), wexp.value, cout, 0.01, 3, 0, L.ptr(one), L.ptr(r1),
+                                            L.stream_ptr()), "conv_wino4")
+            assert torch.equal(out[s_], one), (pitch, s_)
+            K = S * k
+            for lo, hi, width in ((0, 8, 8), (8, 16, 8), (16, 20, 4), (20, 24, 4)):       # sums, squares, minima, maxima
+                got = rows[K * lo + s_ * k * width: K * lo + (s_ + 1) * k * width]
+                assert torch.equal(got, r1[k * lo: k * hi]), (pitch, s_, lo)
