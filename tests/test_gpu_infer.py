@@ -1320,8 +1320,9 @@ def test_config2_single_160_volume_all_heads():
     a float64 gap < 1e-5; a float64 oracle pass at 160^3 is too slow for the suite, so the bound here is on the fp32
     oracle's own gap, which carries that evaluation's error too.)  Fast mode (`passes=1`: plain fp16 products, the configuration's "bf16"
     class): STATED tolerance 1e-1 relative on the float outputs (2^-11 products through 22 layers; measured 6.0e-2 on this
-    all-noise volume, 1e-2 on head-shaped ones), and labels are not compared -- with random weights the 56-way softmax is
-    nearly flat."""
+    all-noise volume, 1e-2 on head-shaped ones); labels: with random weights the 56-way softmax is nearly flat, 2.8 % of the
+    voxels change their argmax, every one of them where the oracle's two best probabilities are within 1.8e-2 of each other
+    (relative) -- asserted as <= 5 % and < 5e-2."""
     from brainfm_amd import test_utils as TU
     ga, ta = TU.default_inference_args(f_maps=64, num_levels=6)
     torch.manual_seed(1)
@@ -1360,6 +1361,13 @@ def test_config2_single_160_volume_all_heads():
     print("config 2 (passes=1): worst float err %.2e" % max(errs1.values()))
     assert max(errs1.values()) <= 1e-1, errs1
     assert max(errs1.values()) > max(errs.values())                  # it IS the cheaper arithmetic
+    # labels in fast mode: compared too, with the bound the arithmetic allows -- a label may differ only
+    # where the oracle's own two best probabilities are closer than the fast mode's error on a probability
+    d1 = out1["label"].cpu() != ref["label"]
+    n1 = int(d1.sum())
+    g1 = float(gap[d1].max()) if n1 else 0.0
+    print("config 2 (passes=1): %d of %d labels differ (%.3f %%), largest oracle top-2 gap there %.2e" % (n1, lab.numel(), 100.0 * n1 / lab.numel(), g1))
+    assert n1 <= 0.05 * lab.numel() and g1 < 5e-2, (n1, g1)          # measured: 2.8 % of the voxels, all at gaps < 1.8e-2
 
 
 def test_headline_shortcuts_change_no_bit_256(monkeypatch):
