@@ -716,7 +716,8 @@ bool choose_box(int D, int H, int W, int npl, int& TD, int& TH, int& TW) {
         const int64_t plane = ((npos * 16 + 255) / 256) * 256 + 16;
         if (8 * npl * plane > 80 * 1024) continue;                 // two workgroups per CU
         int64_t cost = (int64_t)bfm_cdiv(D, o[0]) * bfm_cdiv(H, o[1]) * bfm_cdiv(W, o[2]);
-        cost = cost * 64 - o[2];
+        cost = cost * 1024 + npos;                                 // among equal box counts: the fewest halo'd positions
+                                                                   // to transform, split and store (8 x 8 x 4: 200, 4 x 4 x 16: 288)
         if (best < 0 || cost < best) { best = cost; TD = o[0]; TH = o[1]; TW = o[2]; }
     }
     return best >= 0;

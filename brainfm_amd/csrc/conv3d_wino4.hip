@@ -121,7 +121,10 @@ __device__ __forceinline__ void split_store4(const float (&t)[4], unsigned char*
 // cancel exactly -- so a box at the edge of the constant background would need a reach of 4 voxels along x per layer
 // instead of 1.  Built and measured (tests/diag/diag_wino4_uniform*.py: the pair is exact kernel by kernel, the network
 // is not); the layers that can take that shortcut stay with conv_wino (engine._needs_f23).
-template <int NPASS, int MODE>
+// ABL (diagnostics builds only, -DBFM_W4_ABLATE, tests/diag/diag_wino4_ablate.py): phases compiled out to see what the
+// launch time is made of (wrong results).  1: no weight loads in the tap loop, 2: no LDS operand reads in the tap loop,
+// 4: no staging (barriers kept), 16: no epilogue, 64: no MFMAs.
+template <int NPASS, int MODE, int ABL = 0>
 __device__ __forceinline__ void conv_wino4_body(const W4Params& pin) {
     W4Params p = pin;
     constexpr bool LIST = MODE != 0;
@@ -229,6 +232,7 @@ __device__ __forceinline__ void conv_wino4_body(const W4Params& pin) {
     const uint4* wbB = p.wp + (size_t)(nt * NPOS + posB) * S * (NF * 64) + lane;
     uint4 wq[2][2][NF];
     auto fetch = [&](int s, uint4 (&dst)[2][NF]) __attribute__((always_inline)) {
+        if constexpr ((ABL & 1) != 0) { if (s > 1) return; }
         const int sc = s < S ? s : S - 1;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
@@ -237,6 +241,16 @@ __device__ __forceinline__ void conv_wino4_body(const W4Params& pin) {
         }
     };
     fetch(0, wq[0]);
+    if constexpr ((ABL & 1) != 0) fetch(1, wq[1]);
+    half8 a_abl[3][NPL];
+    if constexpr ((ABL & 2) != 0) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int hl = 0; hl < NPL; ++hl)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a_abl[u][hl][j] = (_Float16)(0.01f * (float)((lane * 7 + u * 3 + hl * 5 + j) % 61) - 0.3f);
+    }
 
     auto do_chunk = [&](int kc, auto par_tag) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_tag)::value;      // parity of the chunk's first weight step (9 steps per chunk)
@@ -250,6 +264,7 @@ __device__ __forceinline__ void conv_wino4_body(const W4Params& pin) {
 #pragma unroll
         for (int it = 0; it < MAX_IT; ++it) {
             if (msk[it] < 0) continue;
+            if constexpr ((ABL & 4) != 0) continue;
             float4 v[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -300,8 +315,16 @@ __device__ __forceinline__ void conv_wino4_body(const W4Params& pin) {
             for (int u = 0; u < 3; ++u) {
                 half8 a[NPL];
 #pragma unroll
-                for (int hl = 0; hl < NPL; ++hl)
-                    a[hl] = *reinterpret_cast<const half8*>(lds + a_off[u] + hl * p.plane_stride + toff);
+                for (int hl = 0; hl < NPL; ++hl) {
+                    if constexpr ((ABL & 2) != 0) a[hl] = a_abl[u][hl];
+                    else a[hl] = *reinterpret_cast<const half8*>(lds + a_off[u] + hl * p.plane_stride + toff);
+                }
+                if constexpr ((ABL & 64) != 0) {
+#pragma unroll
+                    for (int hl = 0; hl < NPL; ++hl) acc[u][0][hl] += (float)a[hl][0] + (float)a[hl][7];
+                    acc[u][1][0] += __builtin_bit_cast(float, wq[cur][u < 2 ? 0 : 1][0].x) + __builtin_bit_cast(float, wq[cur][u < 2 ? 0 : 1][NF - 1].w);
+                    continue;
+                }
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
                     const half8 bhi = __builtin_bit_cast(half8, wq[cur][u < 2 ? 0 : 1][nb * NPL]);
@@ -320,6 +343,17 @@ __device__ __forceinline__ void conv_wino4_body(const W4Params& pin) {
         if (kc + 1 < p.KCN) do_chunk(kc + 1, std::integral_constant<int, 1>{});
     }
 
+    if constexpr ((ABL & 16) != 0) {
+        float sm = 0.f;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sm += acc[u][nb][i];
+        if (sm == 12345.678f) p.out[tid] = sm;
+        return;
+    }
     // ================= epilogue: output transform through LDS =================
     float* m = reinterpret_cast<float*>(lds);                      // [6 positions][64 accumulator rows][MLD]
     const int col = tid & 31, rg = tid >> 5;
@@ -445,6 +479,475 @@ __global__ void __launch_bounds__(NTHR, 2) conv_wino4(const W4Params p) { conv_w
 template <int NPASS>
 __global__ void __launch_bounds__(NTHR, 2) conv_wino4_masked(const W4Params p) { conv_wino4_body<NPASS, 1>(p); }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// conv_wino4d: the same arithmetic with the staging off the critical path (round 5).
+//
+// What the ablation of conv_wino4 showed (tests/diag/diag_wino4_ablate.py, profiles/r05_wino4_ablation.txt; 64->64 @160^3,
+// 1.75 ms): without its MFMAs the launch still takes 1.34 ms, the MFMAs alone 0.85 ms, and the staging is 0.66 ms of the
+// 1.75 although its instructions would fit in a tenth of that -- a chain of three dependent rounds of (6 global loads ->
+// affine, transform, split -> LDS stores) per 16-channel chunk with one round in flight per thread: latency, paid four
+// times per box, and two workgroups per CU hide only part of it.  Here the raw fp32 chunk of the NEXT 16 channels is
+// brought into LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no instructions waiting on it) while the nine taps
+// of the current chunk multiply, spread one or two wave instructions per tap so that each piece has two taps to land before
+// the in-order vmcnt wait of a later weight fetch reaches it; the transform then reads LDS, not memory.
+//
+// To make room for the raw chunk beside the planes at two workgroups per CU the box is 8 x 8 x 4 voxels -- ONE quad per
+// (z, y) row: 100 halo rows = 100 transformed positions per plane (the 4 x 4 x 16 box has 144: 30 % less to transform,
+// split and store per box as well), planes 38 400 B + raw 600 voxels x 64 B = 38 400 B -> 76 800 B per workgroup.
+// A 16-lane ds_read_b128 group reads two runs of eight h-neighbours at d and d + 4 (halo rows 40 positions apart: the runs
+// land in complementary halves of the 64 banks), so MFMA row block mb holds d in {2mb, 2mb+1, 2mb+4, 2mb+5}.
+// Every output voxel gets the bits of conv_wino4 (same products, same order); the moment rows are per box and therefore
+// differ in their partition, not in what they sum.
+constexpr int DB_TD = 8, DB_TH = 8, DB_HT = 10, DB_NROW = 100;
+constexpr int DB_PLANE = DB_NROW * 16;             // bytes per (position, k-half, hi | lo) plane
+constexpr int DB_RAWROW = 6 * 64;                  // one halo row of the raw chunk: 6 voxels x 16 channels fp32
+constexpr int DB_RAW = DB_NROW * DB_RAWROW;        // 38 400
+constexpr int DB_NDMA = DB_NROW / 2;               // wave instructions per chunk: two halo rows (12 voxels, 48 lanes) each
+constexpr int DB_NDMA_WAVE = (DB_NDMA + 3) / 4;    // 13 per wave (the last one on waves 0 and 1 only)
+
+// x = hi + lo in fp16 for four values: hi by truncation (v_cvt_pkrtz_f16_f32, two values per instruction; x - hi is then
+// exact in fp32), lo = fp16(x - hi) by one v_fma_mixlo/hi_f16 per value (fp32 = fp16 * -1 + fp32, rounded to nearest) in
+// place of convert-back, subtract and re-pack: 36 instead of 72 instructions per item
+template <bool LO>
+__device__ __forceinline__ void split_store4_mix(const float (&t)[4], unsigned char* dp, int plane_stride) {
+    const fp16x2_t h01 = __builtin_amdgcn_cvt_pkrtz(t[0], t[1]);
+    const fp16x2_t h23 = __builtin_amdgcn_cvt_pkrtz(t[2], t[3]);
+    uint2 hv;
+    hv.x = __builtin_bit_cast(unsigned, h01);
+    hv.y = __builtin_bit_cast(unsigned, h23);
+    *reinterpret_cast<uint2*>(dp) = hv;
+    if constexpr (LO) {
+        uint2 lv;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lv.x) : "v"(hv.x), "v"(t[0]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lv.x) : "v"(hv.x), "v"(t[1]));
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lv.y) : "v"(hv.y), "v"(t[2]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lv.y) : "v"(hv.y), "v"(t[3]));
+        *reinterpret_cast<uint2*>(dp + plane_stride) = lv;
+    }
+}
+
+// Work of a wave: position wv for the whole box (row blocks 0, 1 x cout halves 0, 1: 12 MFMAs per tap) and, of position
+// 4 + (wv >> 1), cout half wv & 1 of both row blocks (6 MFMAs per tap): 96 accumulator registers and SIX weight fragments
+// per tap (conv_wino4 splits positions 4 / 5 by row block and streams eight), which makes room for a three-deep ring:
+// weights are requested TWO taps ahead of their use.
+// ABL: diagnostics builds only (-DBFM_W4_ABLATE).  1: no weight loads in the tap loop, 2: no LDS operand reads, 4: no
+// transform stage, 8: no LDS-DMA, 16: no epilogue, 64: no MFMAs.
+template <int NPASS, int MODE, int ABL = 0>
+__device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
+    W4Params p = pin;
+    constexpr bool LIST = MODE != 0;
+    constexpr int NPL = (NPASS == 3) ? 2 : 1;
+    constexpr int NF = 2 * NPL;
+    constexpr int NWF = 3 * NPL;                                   // weight fragments per tap and wave
+    constexpr int RAW_OFF = 2 * NPOS * NPL * DB_PLANE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int posA = wv;
+    const int posB = 4 + (wv >> 1), nbB = wv & 1;
+    const int l32 = lane & 31, khalf = lane >> 5;
+    int item;
+    {
+        const int nblk = LIST ? p.list_n[0] * p.NT : p.nMt * p.NT;
+        const int bid = blockIdx.x;
+        if (LIST && bid >= nblk) return;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = LIST ? p.list[item / p.NT] : item / p.NT;
+    const int nt = item % p.NT;
+    int mtl = mt;
+    if (!LIST && p.nMtS > 0) {
+        const int smp = mt / p.nMtS;
+        mtl = mt - smp * p.nMtS;
+        p.A += smp * p.sA;
+        p.out += smp * p.sO;
+        p.scale += smp * p.saff;
+        p.shift += smp * p.saff;
+        p.bound += smp * p.G;
+    }
+    const int tx = mtl % p.nTx;
+    const int ty = (mtl / p.nTx) % p.nTy;
+    const int tz = mtl / (p.nTx * p.nTy);
+    const int z0 = tz * DB_TD, y0 = ty * DB_TH, x0 = tx * 4;
+
+    float bmax = 0.f;
+    for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, p.bound[g]);
+    int aexp = 0;
+    if (bmax > 0.f && bmax < INFINITY) {
+        int ex;
+        (void)frexpf(bmax, &ex);
+        aexp = 10 - ex;
+        aexp = aexp > 60 ? 60 : (aexp < -60 ? -60 : aexp);
+    }
+    const float a_scale = ldexpf(1.0f, aexp);
+    const float dq = ldexpf(1.0f, -(aexp + p.wexp));
+
+    // A operand offsets: MFMA row l32 of row block mb is the quad (d, h) = (2 mb + g + 4 (k >> 3), k & 7), where
+    // g * 16 + k = row_perm(l32) numbers the lanes of the two 16-lane ds_read_b128 groups
+    int a_off[4];                                                  // (posA, mb 0), (posA, mb 1), (posB, mb 0), (posB, mb 1)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int pos = u < 2 ? posA : posB, mb = u & 1;
+        const int pr = row_perm(l32);
+        const int d = mb * 2 + (pr >> 4) + 4 * ((pr & 15) >> 3), h = pr & 7;
+        a_off[u] = ((pos * 2 + khalf) * NPL) * DB_PLANE + (d * DB_HT + h) * 16;
+    }
+
+    // transform items: (halo row r = (tid >> 2) + 64 it, channel quad q4); bit i of msk: voxel x0 - 1 + i of the row exists
+    const int q4 = tid & 3;
+    int msk[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int r = (tid >> 2) + 64 * it;
+        msk[it] = -1;
+        if (r < DB_NROW) {
+            const int hz = r / DB_HT, hy = r - hz * DB_HT;
+            const int gz = z0 + hz - 1, gy = y0 + hy - 1;
+            int m = 0;
+            if (gz >= 0 && gz < p.D && gy >= 0 && gy < p.H) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    if (x0 - 1 + i >= 0 && x0 - 1 + i < p.W) m |= 1 << i;
+            }
+            msk[it] = m;
+        }
+    }
+    // the halo'd box lies inside the volume (77 % of the boxes of a 160^3 tile): no padding to apply.  Workgroup-uniform
+    const bool inner = z0 >= 1 && z0 + DB_TD < p.D && y0 >= 1 && y0 + DB_TH < p.H && x0 >= 1 && x0 + 4 < p.W;
+    const int st_plane = ((q4 >> 1) * NPL) * DB_PLANE + (q4 & 1) * 8;
+
+    // LDS-DMA: wave instruction i brings halo rows 2i and 2i + 1 (lanes 0..47: slot = lane >> 2 = 6 (row & 1) + x, 16 bytes
+    // = 4 channels each); voxels outside the volume are read from a clamped address and masked at transform time
+    const int slot = lane >> 2;
+    const int sb = slot >= 6 ? 1 : 0;
+    int gxc = x0 + (slot - 6 * sb) - 1;
+    gxc = gxc < 0 ? 0 : (gxc > p.W - 1 ? p.W - 1 : gxc);
+    const int lane_el = gxc * p.CA + (lane & 3) * 4;
+    const bool dma_lane = slot < 12;
+    // the whole raw chunk kc: 13 (12) asynchronous wave instructions.  Inline assembly on purpose: the compiler's wait
+    // insertion takes an LDS-DMA it knows about for a store that any later ds_read may alias and drains vmcnt to 0 in front
+    // of the tap loop's operand reads (seen in the ISA of the builtin form); unknown to it, the pieces are simply the oldest
+    // entries of the in-order vmcnt queue -- older than every weight fetch issued after them, so the fetches' counted waits
+    // are still sufficient for the fetches and reach the pieces three taps after their issue (see do_chunk)
+    const unsigned raw_lds = (unsigned)(__UINTPTR_TYPE__)((__attribute__((address_space(3))) unsigned char*)(lds + RAW_OFF));
+    const int zs = z0 > 0 ? z0 - 1 : 0;                        // first slice of the halo'd box inside the volume
+    const float* slab = p.A + (int64_t)zs * p.H * p.W * p.CA;  // 32-bit byte offsets from here (host: 10 slices < 4 GB)
+    auto issue_dma = [&](int kc) __attribute__((always_inline)) {
+        if constexpr ((ABL & 8) != 0) return;
+        if (dma_lane) {
+            int wvo = wv;                                      // opaque per call: the 13 row offsets are re-made on the scalar
+            asm volatile("" : "+s"(wvo));                      // unit each chunk instead of living in 13 vector registers
+#pragma unroll
+            for (int n = 0; n < DB_NDMA_WAVE; ++n) {
+                const int i = wvo + 4 * n;                     // wave-uniform
+                if (n < DB_NDMA_WAVE - 1 || i < DB_NDMA) {
+                    const int hz = i / 5, hp = i - 5 * hz;
+                    int gz = z0 + hz - 1;
+                    gz = gz < 0 ? 0 : (gz > p.D - 1 ? p.D - 1 : gz);
+                    int gy0 = y0 + 2 * hp - 1, gy1 = gy0 + 1;
+                    gy0 = gy0 < 0 ? 0 : (gy0 > p.H - 1 ? p.H - 1 : gy0);
+                    gy1 = gy1 > p.H - 1 ? p.H - 1 : gy1;
+                    const unsigned ro0 = (unsigned)((((gz - zs) * p.H + gy0) * p.W) * p.CA);
+                    const unsigned ro1 = (unsigned)((((gz - zs) * p.H + gy1) * p.W) * p.CA);
+                    const unsigned vo = ((sb ? ro1 : ro0) + (unsigned)lane_el) * 4u;       // bytes from slab + kc * KC
+                    const unsigned la = raw_lds + (unsigned)(i * (2 * DB_RAWROW));
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(slab + kc * KC), "s"(la)
+                                 : "memory");
+                }
+            }
+        }
+    };
+
+    floatx16 acc[2][2];                                            // position posA: [row block][cout half]
+    floatx16 accB[2];                                              // position posB, cout half nbB: [row block]
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[u][0][i] = 0.f; acc[u][1][i] = 0.f; accB[u][i] = 0.f; }
+    }
+
+    // this wave's weight streams: S = KCN * 9 steps (chunk-major, (kd,kh)-minor); per step the four fragments of posA
+    // ([cout half][hi | lo]) and the two of (posB, nbB); three register sets, step s in set s % 3 = tap % 3
+    const int S = p.KCN * 9;
+    const uint4* wbA = p.wp + (size_t)(nt * NPOS + posA) * S * (NF * 64) + lane;
+    const uint4* wbB = p.wp + (size_t)(nt * NPOS + posB) * S * (NF * 64) + nbB * (NPL * 64) + lane;
+    uint4 wq[3][NWF];
+    auto fetch = [&](int s, uint4 (&dst)[NWF]) __attribute__((always_inline)) {
+        if constexpr ((ABL & 1) != 0) { if (s > 2) return; }
+        const int sc = s < S ? s : S - 1;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) dst[f] = wbA[(size_t)sc * (NF * 64) + f * 64];
+#pragma unroll
+        for (int f = 0; f < NPL; ++f) dst[NF + f] = wbB[(size_t)sc * (NF * 64) + f * 64];
+    };
+    issue_dma(0);
+    fetch(0, wq[0]);
+    fetch(1, wq[1]);
+    half8 a_abl[4][NPL];
+    if constexpr ((ABL & 2) != 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int hl = 0; hl < NPL; ++hl)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a_abl[u][hl][j] = (_Float16)(0.01f * (float)((lane * 7 + u * 3 + hl * 5 + j) % 61) - 0.3f);
+    }
+
+    for (int kc = 0; kc < p.KCN; ++kc) {
+        const int c0 = kc * KC;
+        const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + c0 + q4 * 4);
+        const float4 sh4 = *reinterpret_cast<const float4*>(p.shift + c0 + q4 * 4);
+        const float sc[4] = {sc4.x * a_scale, sc4.y * a_scale, sc4.z * a_scale, sc4.w * a_scale};
+        const float sh[4] = {sh4.x * a_scale, sh4.y * a_scale, sh4.z * a_scale, sh4.w * a_scale};
+        // this wave's pieces of the raw chunk have landed (and its weight fetches: the builtin, not inline assembly, so
+        // that the compiler's own vmcnt bookkeeping starts from zero here and does not wait for them again later, which
+        // would drag the pieces issued below into that wait)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0), expcnt and lgkmcnt left alone
+        __syncthreads();                                   // ... everyone's; the previous chunk's plane readers are done
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            if (msk[it] < 0) continue;
+            if constexpr ((ABL & 4) != 0) continue;
+            const int r = (tid >> 2) + 64 * it;
+            const float4* rp = reinterpret_cast<const float4*>(
+                __builtin_assume_aligned(lds + RAW_OFF + r * DB_RAWROW + q4 * 16, 16));
+            float4 v[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) v[i] = rp[i * 4];   // six 16-byte reads in flight, one wait
+            float dd[6][4];                                // [x position][channel]: affine, zero padding after it
+            if (inner) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const float y[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dd[i][c] = fmaf(y[c], sc[c], sh[c]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const bool ok = msk[it] & (1 << i);
+                    const float y[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float a = fmaf(y[c], sc[c], sh[c]);
+                        dd[i][c] = ok ? a : 0.f;
+                    }
+                }
+            }
+            unsigned char* dst = lds + st_plane + r * 16;
+            float t[6][4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float d0 = dd[0][c], d1 = dd[1][c], d2 = dd[2][c], d3 = dd[3][c], d4 = dd[4][c], d5 = dd[5][c];
+                const float a = fmaf(-4.f, d2, d4);
+                const float b = fmaf(-4.f, d1, d3);
+                const float cc = d4 - d2;
+                const float ee = 2.f * (d3 - d1);
+                t[0][c] = fmaf(4.f, d0, fmaf(-5.f, d2, d4));
+                t[1][c] = a + b;
+                t[2][c] = a - b;
+                t[3][c] = cc + ee;
+                t[4][c] = cc - ee;
+                t[5][c] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
+            }
+#pragma unroll
+            for (int ps = 0; ps < NPOS; ++ps)
+                split_store4_mix<NPASS == 3>(t[ps], dst + (ps * 2 * NPL) * DB_PLANE, DB_PLANE);
+        }
+        __syncthreads();                                   // planes complete; the raw buffer is free again
+        // Tap 2's weights (taps 0 and 1 have theirs since the previous chunk; only two sets are live across the transform,
+        // which has no registers to spare), then the next chunk's raw rows.  vmcnt is in order: the pieces complete when
+        // tap 2 waits for its weights with the fetches of taps 1 and 2 behind them -- two taps (>= 1.2 k cycles of MFMA)
+        // to land, off every wave's critical path
+        fetch(kc * 9 + 2, wq[2]);
+        if (kc + 1 < p.KCN) issue_dma(kc + 1);
+
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int s = kc * 9 + t;
+            const int kd = t / 3, kh = t - kd * 3;
+            const int toff = (kd * DB_HT + kh) * 16;
+            constexpr int dummy = 0; (void)dummy;
+            const int cur = t % 3;
+            if (t >= 1) fetch(s + 2, wq[(t + 2) % 3]);     // into the set tap t - 1 used
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                half8 a[NPL];
+#pragma unroll
+                for (int hl = 0; hl < NPL; ++hl) {
+                    if constexpr ((ABL & 2) != 0) a[hl] = a_abl[u][hl];
+                    else a[hl] = *reinterpret_cast<const half8*>(lds + a_off[u] + hl * DB_PLANE + toff);
+                }
+                if constexpr ((ABL & 64) != 0) {
+                    float ss = 0.f;
+#pragma unroll
+                    for (int hl = 0; hl < NPL; ++hl) ss += (float)a[hl][0] + (float)a[hl][7];
+                    ss += __builtin_bit_cast(float, wq[cur][0].x) + __builtin_bit_cast(float, wq[cur][NWF - 1].w);
+                    if (u < 2) acc[u][0][0] += ss; else accB[u - 2][0] += ss;
+                    continue;
+                }
+                if (u < 2) {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const half8 bhi = __builtin_bit_cast(half8, wq[cur][nb * NPL]);
+                        if constexpr (NPASS == 3) {
+                            const half8 blo = __builtin_bit_cast(half8, wq[cur][nb * NPL + 1]);
+                            acc[u][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bhi, acc[u][nb], 0, 0, 0);
+                            acc[u][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], blo, acc[u][nb], 0, 0, 0);
+                        }
+                        acc[u][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bhi, acc[u][nb], 0, 0, 0);
+                    }
+                } else {
+                    const half8 bhi = __builtin_bit_cast(half8, wq[cur][NF]);
+                    if constexpr (NPASS == 3) {
+                        const half8 blo = __builtin_bit_cast(half8, wq[cur][NF + 1]);
+                        accB[u - 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bhi, accB[u - 2], 0, 0, 0);
+                        accB[u - 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], blo, accB[u - 2], 0, 0, 0);
+                    }
+                    accB[u - 2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bhi, accB[u - 2], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    if constexpr ((ABL & 16) != 0) {
+        float sm = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sm += acc[u][0][i] + acc[u][1][i] + accB[u][i];
+        if (sm == 12345.678f) p.out[tid] = sm;
+        return;
+    }
+    // ================= epilogue: output transform through LDS =================
+    // thread (col, rg): column col of the 32-cout block, the quads (d, h) = (it, rg), it = 0..7; quad (d, h) sits in
+    // accumulator row 32 ((d & 3) >> 1) + row_unperm(16 (d & 1) + 8 (d >> 2) + h)
+    float* m = reinterpret_cast<float*>(lds);                      // [6 positions][64 accumulator rows][MLD]
+    const int col = tid & 31, rg = tid >> 5;
+    const bool interior = z0 + DB_TD <= p.D && y0 + DB_TH <= p.H && x0 + 4 <= p.W;      // wave-uniform
+    int un[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) un[c] = row_unperm(16 * (c >> 1) + 8 * (c & 1) + rg);    // c = 2 (d & 1) + (d >> 2)
+    const unsigned off_t = (unsigned)((rg * p.W) * p.Cout + col);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        __syncthreads();                                           // A planes (or the previous round) fully consumed
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float* mw = m + (posA * 64 + u * 32 + khalf * 4) * MLD + l32;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                mw[((i >> 2) * 8 + (i & 3)) * MLD] = acc[u][nb][i];
+        }
+        if (nbB == nb) {                                           // wave-uniform: this cout half of posB is this wave's
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float* mw = m + (posB * 64 + u * 32 + khalf * 4) * MLD + l32;
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    mw[((i >> 2) * 8 + (i & 3)) * MLD] = accB[u][i];
+            }
+        }
+        __syncthreads();
+        float fs = 0.f, fq = 0.f, fmn = INFINITY, fmx = -INFINITY;
+        float* ob = p.out + nt * 64 + nb * 32 + ((int64_t)(z0 * p.H + y0) * p.W + x0) * p.Cout;
+        const float* mc = m + col;
+        if (interior) {
+            float prev[8][4];
+            if (p.accum) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const float* o = ob + (int64_t)it * p.H * p.W * p.Cout;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) prev[it][k] = o[off_t + (unsigned)(k * p.Cout)];
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                float* o = ob + (int64_t)it * p.H * p.W * p.Cout;
+                const int qr = 32 * ((it & 3) >> 1) + un[2 * (it & 1) + (it >> 2)];
+                const float* mr = mc + qr * MLD;
+                const float m0 = mr[0 * 64 * MLD], m1 = mr[1 * 64 * MLD], m2 = mr[2 * 64 * MLD];
+                const float m3 = mr[3 * 64 * MLD], m4 = mr[4 * 64 * MLD], m5 = mr[5 * 64 * MLD];
+                const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                float y[4];
+                y[0] = ((m0 + s1) + s2) * dq;
+                y[1] = fmaf(2.f, d2, d1) * dq;
+                y[2] = fmaf(4.f, s2, s1) * dq;
+                y[3] = (fmaf(8.f, d2, d1) + m5) * dq;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float r = y[k];
+                    if (p.accum) r = r + prev[it][k];
+                    r = r >= 0.f ? r : r * p.slope;
+                    o[off_t + (unsigned)(k * p.Cout)] = r;
+                    fs += r; fq = fmaf(r, r, fq); fmn = fminf(fmn, r); fmx = fmaxf(fmx, r);
+                }
+            }
+        } else if (y0 + rg < p.H) {
+#pragma unroll 2
+            for (int it = 0; it < 8; ++it) {
+                if (z0 + it >= p.D) break;
+                float* o = ob + (int64_t)it * p.H * p.W * p.Cout;
+                const int qr = 32 * ((it & 3) >> 1) + row_unperm(16 * (it & 1) + 8 * (it >> 2) + rg);
+                const float* mr = mc + qr * MLD;
+                const float m0 = mr[0 * 64 * MLD], m1 = mr[1 * 64 * MLD], m2 = mr[2 * 64 * MLD];
+                const float m3 = mr[3 * 64 * MLD], m4 = mr[4 * 64 * MLD], m5 = mr[5 * 64 * MLD];
+                const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                float y[4];
+                y[0] = ((m0 + s1) + s2) * dq;
+                y[1] = fmaf(2.f, d2, d1) * dq;
+                y[2] = fmaf(4.f, s2, s1) * dq;
+                y[3] = (fmaf(8.f, d2, d1) + m5) * dq;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (x0 + k < p.W) {
+                        float r = y[k];
+                        if (p.accum) r = r + o[off_t + (unsigned)(k * p.Cout)];
+                        r = r >= 0.f ? r : r * p.slope;
+                        o[off_t + (unsigned)(k * p.Cout)] = r;
+                        fs += r; fq = fmaf(r, r, fq); fmn = fminf(fmn, r); fmx = fmaxf(fmx, r);
+                    }
+                }
+            }
+        }
+        if (p.rsum != nullptr) {
+            double* ls = reinterpret_cast<double*>(lds + (size_t)NPOS * 64 * MLD * sizeof(float));   // [8][32]
+            double* lq = ls + NRG * 32;
+            float* lmn = reinterpret_cast<float*>(lq + NRG * 32);
+            float* lmx = lmn + NRG * 32;
+            ls[rg * 32 + col] = (double)fs; lq[rg * 32 + col] = (double)fq;
+            lmn[rg * 32 + col] = fmn; lmx[rg * 32 + col] = fmx;
+            __syncthreads();
+            if (tid < 32) {
+                double Ssum = 0.0, Q = 0.0;
+                float MN = INFINITY, MX = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < NRG; ++r) {
+                    Ssum += ls[r * 32 + tid]; Q += lq[r * 32 + tid];
+                    MN = fminf(MN, lmn[r * 32 + tid]); MX = fmaxf(MX, lmx[r * 32 + tid]);
+                }
+                const size_t o = (size_t)mt * p.Cout + nt * 64 + nb * 32 + tid;
+                p.rsum[o] = Ssum; p.rsq[o] = Q; p.rmn[o] = MN; p.rmx[o] = MX;
+            }
+        }
+    }
+}
+
+template <int NPASS>
+__global__ void __launch_bounds__(NTHR, 2) conv_wino4d(const W4Params p) { conv_wino4d_body<NPASS, 0>(p); }
+template <int NPASS>
+__global__ void __launch_bounds__(NTHR, 2) conv_wino4d_masked(const W4Params p) { conv_wino4d_body<NPASS, 1>(p); }
+#ifdef BFM_W4_ABLATE
+template <int ABL>
+__global__ void __launch_bounds__(NTHR, 2) conv_wino4d_abl(const W4Params p) { conv_wino4d_body<3, 0, ABL>(p); }
+#endif
+
 // packed[ntile64][pos 6][kc][(kd,kh) 9][nb 2][hl][lane] (uint4 = 8 halfs): lane l holds
 // B[k = 8*(l>>5)+j][n = l&31] = U_pos[co = ntile*64 + nb*32 + (l&31)][ci = kc*16 + 8*(l>>5) + j][kd][kh] * 2^wexp, U = G g along kw
 __global__ void pack_wino4(const float* __restrict__ w, int Cin, int Cout, int wexp, int npl, uint4* __restrict__ out) {
@@ -496,6 +999,20 @@ bool choose_box4(int D, int H, int W, int npl, int& TD, int& TH, int& TW) {
     return 2 * NPOS * npl * plane <= 62 * 1024;
 }
 
+// conv_wino4d (the 8 x 8 x 4 box with the LDS-DMA staging) takes every volume with at least one full box in z and y;
+// thinner ones keep conv_wino4 and conv_wino's box
+bool use_dma_kernel(int D, int H, int W) {
+#ifdef BFM_W4_ABLATE
+    if (getenv("BFM_W4_OLD")) return false;                    // diagnostics builds: time conv_wino4 beside conv_wino4d
+#endif
+    return D >= DB_TD && H >= DB_TH && W >= 4;
+}
+
+bool choose_box_any(int D, int H, int W, int npl, int& TD, int& TH, int& TW) {
+    if (use_dma_kernel(D, H, W)) { TD = DB_TD; TH = DB_TH; TW = 4; return true; }
+    return choose_box4(D, H, W, npl, TD, TH, TW);
+}
+
 }  // namespace
 
 extern "C" size_t bfm_pack_conv_weights_wino4_bytes(int Cin, int Cout, int passes) {
@@ -527,8 +1044,23 @@ extern "C" int bfm_pack_conv_weights_wino4(const float* w_oidhw, int Cin, int Co
 // rows of the output-moment table the kernel writes for this volume (its own box choice), 0 if it cannot run
 extern "C" int bfm_conv3x3x3_wino4_rows(int D, int H, int W, int passes) {
     int TD, TH, TW;
-    if (D <= 0 || H <= 0 || W <= 0 || !choose_box4(D, H, W, passes == 3 ? 2 : 1, TD, TH, TW)) return 0;
+    if (D <= 0 || H <= 0 || W <= 0 || !choose_box_any(D, H, W, passes == 3 ? 2 : 1, TD, TH, TW)) return 0;
     return bfm_cdiv(D, TD) * bfm_cdiv(H, TH) * bfm_cdiv(W, TW);
+}
+
+// the box of output voxels per workgroup for this volume (what the masked form's "boxes that hold input" are)
+extern "C" int bfm_conv3x3x3_wino4_box(int D, int H, int W, int passes, int* box) {
+    int TD, TH, TW;
+    if (!box || D <= 0 || H <= 0 || W <= 0 || !choose_box_any(D, H, W, passes == 3 ? 2 : 1, TD, TH, TW)) return BFM_E_ARG;
+    box[0] = TD; box[1] = TH; box[2] = TW;
+    return BFM_OK;
+}
+
+// bytes of the masked form's workspace: box activity (padded to 4), the count, the list
+extern "C" size_t bfm_conv3x3x3_wino4_masked_workspace(int D, int H, int W, int passes) {
+    const int n = bfm_conv3x3x3_wino4_rows(D, H, W, passes);
+    if (n <= 0) return 0;
+    return (((size_t)n + 3) & ~(size_t)3) + 4 + (size_t)n * 4;
 }
 
 static int w4_launch(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift, const float* bound,
@@ -552,7 +1084,9 @@ static int w4_launch(const float* A, int CA, int D, int H, int W, const float* s
     p.scale = scale; p.shift = shift; p.bound = bound; p.G = G;
     p.wp = static_cast<const uint4*>(wpacked);
     p.wexp = wexp; p.Cout = Cout; p.slope = slope; p.out = out; p.accum = accumulate ? 1 : 0;
-    if (!choose_box4(D, H, W, npl, p.TD, p.TH, p.TW)) return BFM_E_SHAPE;
+    if (!choose_box_any(D, H, W, npl, p.TD, p.TH, p.TW)) return BFM_E_SHAPE;
+    const bool dma = use_dma_kernel(D, H, W);
+    if (dma && (int64_t)(DB_TD + 2) * H * W * CA >= (int64_t)1 << 30) return BFM_E_SHAPE;   // 32-bit byte offsets in a slab
     p.HT = p.TH + 2; p.QW = p.TW / 4;
     p.qw_shift = ilog2i(p.QW); p.thq_shift = ilog2i(p.TH * p.QW);
     const int nTz = bfm_cdiv(D, p.TD);
@@ -570,10 +1104,22 @@ static int w4_launch(const float* A, int CA, int D, int H, int W, const float* s
     p.KCN = CA / KC;
     p.npos_lds = (p.TD + 2) * p.HT * p.QW;
     p.plane_stride = ((p.npos_lds * 16 + 255) / 256) * 256 + 16;
-    size_t smem = (size_t)2 * NPOS * npl * p.plane_stride;
+    size_t smem = dma ? (size_t)2 * NPOS * npl * DB_PLANE + DB_RAW : (size_t)2 * NPOS * npl * p.plane_stride;
     const size_t epi = (size_t)NPOS * 64 * MLD * sizeof(float) + (size_t)NRG * 32 * 24;   // output-transform scratch + moment fold
     if (smem < epi) smem = epi;
-    if (smem > 64 * 1024) return BFM_E_SHAPE;
+    if (smem > (dma ? 80u : 64u) * 1024) return BFM_E_SHAPE;
+    if (dma) {                                                  // more than 64 KB of dynamic LDS: once per process
+        static bool attr = false;
+        if (!attr) {
+            const int lim = 80 * 1024;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4d<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4d<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4d_masked<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4d_masked<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) != hipSuccess)
+                return BFM_E_LAUNCH;
+            attr = true;
+        }
+    }
     if (moment_rows) {
         if (reinterpret_cast<uintptr_t>(moment_rows) & 7) return BFM_E_ARG;
         char* rb = static_cast<char*>(moment_rows);
@@ -593,11 +1139,31 @@ static int w4_launch(const float* A, int CA, int D, int H, int W, const float* s
         if (rc != BFM_OK) return rc;
         int* cnt = reinterpret_cast<int*>(static_cast<unsigned char*>(mask_ws) + (((size_t)p.nMt + 3) & ~(size_t)3));
         p.list = cnt + 1; p.list_n = cnt;
-        if (passes == 3) hipLaunchKernelGGL(conv_wino4_masked<3>, grid, dim3(NTHR), smem, st, p);
+        if (dma) {
+            if (passes == 3) hipLaunchKernelGGL(conv_wino4d_masked<3>, grid, dim3(NTHR), smem, st, p);
+            else hipLaunchKernelGGL(conv_wino4d_masked<1>, grid, dim3(NTHR), smem, st, p);
+        } else if (passes == 3) hipLaunchKernelGGL(conv_wino4_masked<3>, grid, dim3(NTHR), smem, st, p);
         else hipLaunchKernelGGL(conv_wino4_masked<1>, grid, dim3(NTHR), smem, st, p);
         return bfm_launch_status();
     }
-    if (passes == 3) hipLaunchKernelGGL(conv_wino4<3>, grid, dim3(NTHR), smem, st, p);
+#ifdef BFM_W4_ABLATE
+    if (const char* e = getenv("BFM_W4_ABL")) {                 // diagnostics: phases compiled out, the old kernel by "old"
+        const int abl = atoi(e);
+        if (dma) {
+#define W4D_ATTR(N) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4d_abl<N>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
+            W4D_ATTR(0); W4D_ATTR(1); W4D_ATTR(2); W4D_ATTR(3); W4D_ATTR(4); W4D_ATTR(8); W4D_ATTR(12); W4D_ATTR(15); W4D_ATTR(16); W4D_ATTR(31); W4D_ATTR(64); W4D_ATTR(28);
+            switch (abl) {
+#define W4D_CASE(N) case N: hipLaunchKernelGGL(conv_wino4d_abl<N>, grid, dim3(NTHR), smem, st, p); return bfm_launch_status()
+                W4D_CASE(0); W4D_CASE(1); W4D_CASE(2); W4D_CASE(3); W4D_CASE(4); W4D_CASE(8); W4D_CASE(12); W4D_CASE(15); W4D_CASE(16); W4D_CASE(31); W4D_CASE(64); W4D_CASE(28);
+                default: return BFM_E_ARG;
+            }
+        }
+    }
+#endif
+    if (dma) {
+        if (passes == 3) hipLaunchKernelGGL(conv_wino4d<3>, grid, dim3(NTHR), smem, st, p);
+        else hipLaunchKernelGGL(conv_wino4d<1>, grid, dim3(NTHR), smem, st, p);
+    } else if (passes == 3) hipLaunchKernelGGL(conv_wino4<3>, grid, dim3(NTHR), smem, st, p);
     else hipLaunchKernelGGL(conv_wino4<1>, grid, dim3(NTHR), smem, st, p);
     return bfm_launch_status();
 }
@@ -628,7 +1194,7 @@ extern "C" int bfm_conv3x3x3_wino4_masked(const float* A, int CA, int D, int H, 
                                           size_t workspace_bytes, bfm_stream_t stream) {
     if (!mask_image || (flags & ~1)) return BFM_E_ARG;         // no moment rows (boxes are left out)
     if (!workspace || (reinterpret_cast<uintptr_t>(workspace) & 3) ||
-        workspace_bytes < bfm_conv3x3x3_wino_masked_workspace(D, H, W, passes))
+        workspace_bytes < bfm_conv3x3x3_wino4_masked_workspace(D, H, W, passes))
         return BFM_E_ARG;
     return w4_launch(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out, nullptr,
                      mask_image, workspace, stream);

@@ -510,7 +510,8 @@ class UNetEngine:
         if mask_img is not None:
             if cfg[6] not in (3, 4) or cb or rows is not None:
                 raise L.BfmError("a masked launch is a one-source Winograd kernel without moment rows")
-            nws = self.lib.bfm_conv3x3x3_wino_masked_workspace(D, H, W, self.passes)
+            nws = (self.lib.bfm_conv3x3x3_wino_masked_workspace if cfg[6] == 3
+                   else self.lib.bfm_conv3x3x3_wino4_masked_workspace)(D, H, W, self.passes)
             mws = torch.empty(nws, dtype=torch.uint8, device=self.device)       # box activity, count, list of boxes
             fn = self.lib.bfm_conv3x3x3_wino_masked if cfg[6] == 3 else self.lib.bfm_conv3x3x3_wino4_masked
             L.check(fn(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
@@ -647,7 +648,7 @@ class UNetEngine:
                 ev[1].record()
                 nv = D * H * W
                 if mask_img is not None:                    # only the boxes the kernel computes count as work
-                    nv = self.masked_voxels(mask_img, dims)
+                    nv = self.masked_voxels(mask_img, dims, cfg[6])
                 if uni_flags is not None:                   # a uniform box runs a quarter of its products
                     nv = self.uniform_voxels(uni_flags, dims)
                 lo = 0 if B is None else lo_dims[0] * lo_dims[1] * lo_dims[2]
@@ -675,12 +676,22 @@ class UNetEngine:
         self._record(ly, A, B, dims, lo_dims, scale, shift, bound, out)
         return out
 
-    def masked_voxels(self, mask_img, dims):
-        """Output voxels bfm_conv3x3x3_wino_masked computes for this image: those of the kernel's boxes that hold a
-        non-zero voxel (host-side count for the instrumented pass; synchronises)."""
+    def masked_voxels(self, mask_img, dims, ver=None):
+        """Output voxels bfm_conv3x3x3_wino_masked / _wino4_masked computes for this image: those of the kernel's boxes that
+        hold a non-zero voxel (host-side count for the instrumented pass; synchronises).  ver: the variant (3 / 4) of the
+        launch; None = what the last convolution of the network runs at these dims (the tile loop's masked layer)."""
         D, H, W = dims
+        if ver is None:
+            ly = self.dec[-1][-1] if self.dec else self.enc[0][-1]
+            key = (ly.cin, ly.cout, tuple(dims), False, False)
+            ver = _TUNE_CHOICES.get((torch.cuda.current_device(), getattr(self, "passes", None), key))
+            if ver is None:
+                ver = _tune_lookup(torch.cuda.current_device(), getattr(self, "passes", None), key)
+            if os.environ.get("BFM_CONV_VER"):
+                ver = int(os.environ["BFM_CONV_VER"])
         box = (C.c_int * 3)()
-        L.check(self.lib.bfm_conv3x3x3_wino_box(D, H, W, self.passes, box), "wino_box")
+        L.check((self.lib.bfm_conv3x3x3_wino4_box if ver == 4 else self.lib.bfm_conv3x3x3_wino_box)(D, H, W, self.passes, box),
+                "wino_box")
         td, th, tw = box[0], box[1], box[2]
         m = (mask_img.reshape(D, H, W) != 0)
         m = torch.nn.functional.pad(m, (0, -W % tw, 0, -H % th, 0, -D % td))

@@ -235,6 +235,9 @@ size_t bfm_pack_conv_weights_wino4_bytes(int Cin, int Cout, int passes);
 int bfm_pack_conv_weights_wino4(const float* w_oidhw, int Cin, int Cout, float wmax_abs_host, int passes, void* wpacked,
                                 int* wexp_host, bfm_stream_t stream);
 int bfm_conv3x3x3_wino4_rows(int D, int H, int W, int passes);
+/* the (d,h,w) box of output voxels per workgroup for this volume: 8 x 8 x 4 (conv_wino4d: raw chunks by LDS-DMA one chunk
+ * ahead, round 5) wherever the volume holds a full box in z and y, bfm_conv3x3x3_wino_box()'s otherwise */
+int bfm_conv3x3x3_wino4_box(int D, int H, int W, int passes, int* box /* [3] */);
 int bfm_conv3x3x3_wino4(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                         const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
                         int flags, float* out, void* moment_rows /*or NULL*/, bfm_stream_t stream);
@@ -244,9 +247,11 @@ int bfm_conv3x3x3_wino4(const float* A, int CA, int D, int H, int W, const float
 int bfm_conv3x3x3_wino4_batch(const float* A, int CA, int S, int D, int H, int W, const float* scale, const float* shift,
                               const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
                               int flags, float* out, void* moment_rows, int affine_stride, bfm_stream_t stream);
-/* The masked form of the same kernel, box for box that of bfm_conv3x3x3_wino_masked (same boxes, same workspace).  There
+/* The masked form of the same kernel: the boxes (bfm_conv3x3x3_wino4_box) that hold a non-zero voxel of mask_image;
+ * workspace bfm_conv3x3x3_wino4_masked_workspace(D, H, W, passes) bytes (4-byte aligned).  There
  * is no uniform-box pair: F(4,3)'s rounding reaches 4 voxels along x where F(2,3)'s numerical support is its
  * mathematical one (conv3d_wino4.hip), so the layers that take that shortcut stay with bfm_conv3x3x3_wino_uniform. */
+size_t bfm_conv3x3x3_wino4_masked_workspace(int D, int H, int W, int passes);
 int bfm_conv3x3x3_wino4_masked(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                                const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
                                int flags, float* out, const float* mask_image, void* workspace, size_t workspace_bytes,

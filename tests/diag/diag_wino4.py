@@ -41,7 +41,8 @@ def ref64(A, w, scale, shift, slope, accumulate=None):
     return torch.where(y >= 0, y, y * slope)
 
 
-for dims, cin, cout in (((8, 8, 16), 16, 64), ((9, 11, 21), 32, 64), ((12, 8, 30), 64, 128)):
+for dims, cin, cout in (((8, 8, 16), 16, 64), ((9, 11, 21), 32, 64), ((12, 8, 30), 64, 128), ((5, 9, 20), 32, 64), ((20, 20, 20), 32, 64),
+                         ((17, 24, 7), 16, 128)):
     A = torch.randn(*dims, cin, device=dev)
     w = (torch.randn(cout, cin, 3, 3, 3, device=dev) * 0.05).contiguous()
     scale = torch.rand(cin, device=dev) + 0.5

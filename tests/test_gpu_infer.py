@@ -1029,7 +1029,7 @@ def test_masked_last_convolution_computes_exactly_the_boxes_that_hold_input(dims
     part = torch.full(dims + (64,), sentinel, device=_dev())
     eng._conv_launch(ly, A, 64, None, 0, dims, None, scale, shift, bound, ly.groups, cfg, part, ws, mask_img=img)
     box = (C.c_int * 3)()
-    L.check(eng.lib.bfm_conv3x3x3_wino_box(D, H, W, eng.passes, box), "box")
+    L.check((eng.lib.bfm_conv3x3x3_wino4_box if ver == 4 else eng.lib.bfm_conv3x3x3_wino_box)(D, H, W, eng.passes, box), "box")
     td, th, tw = box[0], box[1], box[2]
     nz = (img != 0).cpu().numpy()
     active = np.zeros(dims, dtype=bool)
@@ -1042,7 +1042,7 @@ def test_masked_last_convolution_computes_exactly_the_boxes_that_hold_input(dims
     act = torch.from_numpy(active).to(_dev())
     assert torch.equal(part[act], full[act])
     assert bool((part[~act] == sentinel).all())
-    assert eng.masked_voxels(img, dims) == int(active.sum())
+    assert eng.masked_voxels(img, dims, ver) == int(active.sum())
 
 
 def test_tile_loop_mask_skip_changes_no_stitched_bit():
