@@ -113,6 +113,8 @@ SIGNATURES = {
     "bfm_conv3x3x3_wino4_rows": (_I, [_I, _I, _I, _I]),
     "bfm_conv3x3x3_wino4_box": (_I, [_I, _I, _I, _I, _P]),
     "bfm_conv3x3x3_wino4_masked_workspace": (_Z, [_I, _I, _I, _I]),
+    "bfm_conv3x3x3_wino4_uniform_scratch": (_Z, [_I]),
+    "bfm_conv3x3x3_wino4_uniform": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _P, _P, _P]),
     "bfm_conv3x3x3_wino4": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _P]),
     "bfm_conv3x3x3_wino4_batch": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _I, _P]),
     "bfm_conv3x3x3_wino4_masked": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),

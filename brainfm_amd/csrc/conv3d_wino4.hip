@@ -63,6 +63,8 @@ struct W4Params {
     float *rmn, *rmx;
     const int* list;                 // sparse forms: the boxes to compute, ascending
     const int* list_n;               // ... their number, on the device
+    const unsigned char* uni_flags;  // conv_wino4d_rest / _uniform: [nMt] 0, or 1 + the class of a box whose operands equal its class mates'
+    float* uni_acc;                  // [27][NT][2][8][NTHR] float4: the class representatives' output-transformed sums
     // batch (dense form only): nMt = S * nMtS boxes, box mt belongs to sample mt / nMtS; A, out advance by sA, sO elements
     // per sample, scale / shift by saff, bound by G; moment rows are [S * nMtS][Cout].  nMtS == 0: one sample.  A sample's
     // workgroups do exactly what they do in a launch of that sample alone.
@@ -532,10 +534,20 @@ __device__ __forceinline__ void split_store4_mix(const float (&t)[4], unsigned c
 // weights are requested TWO taps ahead of their use.
 // ABL: diagnostics builds only (-DBFM_W4_ABLATE).  1: no weight loads in the tap loop, 2: no LDS operand reads, 4: no
 // transform stage, 8: no LDS-DMA, 16: no epilogue, 64: no MFMAs.
+// MODE 0: every box.  1 (conv_wino4d_masked): the boxes of p.list (those that hold input).  2 / 3 (conv_wino4d_rest /
+// conv_wino4d_uniform, launched as a pair like conv_wino's): boxes flagged uniform by bfm_uniform_boxes -- the layer's input
+// around the box is a function of the distances to the tile's faces alone -- share the output-transformed sums of the first
+// flagged box of their class.  ONLY for layers whose output feeds no other layer that takes this shortcut (the skip halves
+// of the last two decoders' first convs): a box is a whole number of quads, so what a box's sums depend on NUMERICALLY is its
+// mathematical halo, as with F(2,3); a voxel of the OUTPUT, though, carries the rounding of its whole quad (y0 = m0 + .. + m4
+// involves d3, d4), which a consumer that assumes a reach of one voxel per layer would not see (conv_wino4 header;
+// engine._uniform_variant).
 template <int NPASS, int MODE, int ABL = 0>
 __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
     W4Params p = pin;
     constexpr bool LIST = MODE != 0;
+    constexpr bool UNI = MODE == 3;                                // stream a class's sums to its mates: no staging, no products
+    constexpr bool BY_FLAG = MODE == 2 || MODE == 3;
     constexpr int NPL = (NPASS == 3) ? 2 : 1;
     constexpr int NF = 2 * NPL;
     constexpr int NWF = 3 * NPL;                                   // weight fragments per tap and wave
@@ -573,6 +585,11 @@ __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
     const int ty = (mtl / p.nTx) % p.nTy;
     const int tz = mtl / (p.nTx * p.nTy);
     const int z0 = tz * DB_TD, y0 = ty * DB_TH, x0 = tx * 4;
+    int cls = 0;                                                   // 1 + class of a flagged box
+    if constexpr (BY_FLAG) cls = __builtin_amdgcn_readfirstlane((int)p.uni_flags[mt]);
+    const bool rep = MODE == 2 && cls != 0;                        // conv_wino4d_rest's flagged boxes: the class representatives
+    float4* const ybuf = BY_FLAG && cls ? reinterpret_cast<float4*>(p.uni_acc) + ((size_t)(cls - 1) * p.NT + nt) * (2 * 8 * NTHR) + tid
+                                        : nullptr;
 
     float bmax = 0.f;
     for (int g = 0; g < p.G; ++g) bmax = fmaxf(bmax, p.bound[g]);
@@ -586,6 +603,9 @@ __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
     const float a_scale = ldexpf(1.0f, aexp);
     const float dq = ldexpf(1.0f, -(aexp + p.wexp));
 
+    floatx16 acc[2][2];                                            // position posA: [row block][cout half]
+    floatx16 accB[2];                                              // position posB, cout half nbB: [row block]
+    if constexpr (!UNI) {
     // A operand offsets: MFMA row l32 of row block mb is the quad (d, h) = (2 mb + g + 4 (k >> 3), k & 7), where
     // g * 16 + k = row_perm(l32) numbers the lanes of the two 16-lane ds_read_b128 groups
     int a_off[4];                                                  // (posA, mb 0), (posA, mb 1), (posB, mb 0), (posB, mb 1)
@@ -662,8 +682,6 @@ __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
         }
     };
 
-    floatx16 acc[2][2];                                            // position posA: [row block][cout half]
-    floatx16 accB[2];                                              // position posB, cout half nbB: [row block]
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -815,6 +833,8 @@ __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
         }
     }
 
+    }   // !UNI
+
     if constexpr ((ABL & 16) != 0) {
         float sm = 0.f;
 #pragma unroll
@@ -836,6 +856,7 @@ __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
     const unsigned off_t = (unsigned)((rg * p.W) * p.Cout + col);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
+        if constexpr (!UNI) {
         __syncthreads();                                           // A planes (or the previous round) fully consumed
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -854,6 +875,7 @@ __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
             }
         }
         __syncthreads();
+        } else if (nb == 1 && p.rsum != nullptr) __syncthreads();  // the previous round's moment fold is done with its scratch
         float fs = 0.f, fq = 0.f, fmn = INFINITY, fmx = -INFINITY;
         float* ob = p.out + nt * 64 + nb * 32 + ((int64_t)(z0 * p.H + y0) * p.W + x0) * p.Cout;
         const float* mc = m + col;
@@ -870,16 +892,22 @@ __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 float* o = ob + (int64_t)it * p.H * p.W * p.Cout;
-                const int qr = 32 * ((it & 3) >> 1) + un[2 * (it & 1) + (it >> 2)];
-                const float* mr = mc + qr * MLD;
-                const float m0 = mr[0 * 64 * MLD], m1 = mr[1 * 64 * MLD], m2 = mr[2 * 64 * MLD];
-                const float m3 = mr[3 * 64 * MLD], m4 = mr[4 * 64 * MLD], m5 = mr[5 * 64 * MLD];
-                const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
                 float y[4];
-                y[0] = ((m0 + s1) + s2) * dq;
-                y[1] = fmaf(2.f, d2, d1) * dq;
-                y[2] = fmaf(4.f, s2, s1) * dq;
-                y[3] = (fmaf(8.f, d2, d1) + m5) * dq;
+                if constexpr (UNI) {
+                    const float4 yy = ybuf[(nb * 8 + it) * NTHR];
+                    y[0] = yy.x; y[1] = yy.y; y[2] = yy.z; y[3] = yy.w;
+                } else {
+                    const int qr = 32 * ((it & 3) >> 1) + un[2 * (it & 1) + (it >> 2)];
+                    const float* mr = mc + qr * MLD;
+                    const float m0 = mr[0 * 64 * MLD], m1 = mr[1 * 64 * MLD], m2 = mr[2 * 64 * MLD];
+                    const float m3 = mr[3 * 64 * MLD], m4 = mr[4 * 64 * MLD], m5 = mr[5 * 64 * MLD];
+                    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                    y[0] = ((m0 + s1) + s2) * dq;
+                    y[1] = fmaf(2.f, d2, d1) * dq;
+                    y[2] = fmaf(4.f, s2, s1) * dq;
+                    y[3] = (fmaf(8.f, d2, d1) + m5) * dq;
+                    if (MODE == 2 && rep) ybuf[(nb * 8 + it) * NTHR] = make_float4(y[0], y[1], y[2], y[3]);
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float r = y[k];
@@ -894,16 +922,22 @@ __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
             for (int it = 0; it < 8; ++it) {
                 if (z0 + it >= p.D) break;
                 float* o = ob + (int64_t)it * p.H * p.W * p.Cout;
-                const int qr = 32 * ((it & 3) >> 1) + row_unperm(16 * (it & 1) + 8 * (it >> 2) + rg);
-                const float* mr = mc + qr * MLD;
-                const float m0 = mr[0 * 64 * MLD], m1 = mr[1 * 64 * MLD], m2 = mr[2 * 64 * MLD];
-                const float m3 = mr[3 * 64 * MLD], m4 = mr[4 * 64 * MLD], m5 = mr[5 * 64 * MLD];
-                const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
                 float y[4];
-                y[0] = ((m0 + s1) + s2) * dq;
-                y[1] = fmaf(2.f, d2, d1) * dq;
-                y[2] = fmaf(4.f, s2, s1) * dq;
-                y[3] = (fmaf(8.f, d2, d1) + m5) * dq;
+                if constexpr (UNI) {
+                    const float4 yy = ybuf[(nb * 8 + it) * NTHR];
+                    y[0] = yy.x; y[1] = yy.y; y[2] = yy.z; y[3] = yy.w;
+                } else {
+                    const int qr = 32 * ((it & 3) >> 1) + row_unperm(16 * (it & 1) + 8 * (it >> 2) + rg);
+                    const float* mr = mc + qr * MLD;
+                    const float m0 = mr[0 * 64 * MLD], m1 = mr[1 * 64 * MLD], m2 = mr[2 * 64 * MLD];
+                    const float m3 = mr[3 * 64 * MLD], m4 = mr[4 * 64 * MLD], m5 = mr[5 * 64 * MLD];
+                    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                    y[0] = ((m0 + s1) + s2) * dq;
+                    y[1] = fmaf(2.f, d2, d1) * dq;
+                    y[2] = fmaf(4.f, s2, s1) * dq;
+                    y[3] = (fmaf(8.f, d2, d1) + m5) * dq;
+                    if (MODE == 2 && rep) ybuf[(nb * 8 + it) * NTHR] = make_float4(y[0], y[1], y[2], y[3]);
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (x0 + k < p.W) {
@@ -917,7 +951,7 @@ __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
             }
         }
         if (p.rsum != nullptr) {
-            double* ls = reinterpret_cast<double*>(lds + (size_t)NPOS * 64 * MLD * sizeof(float));   // [8][32]
+            double* ls = reinterpret_cast<double*>(lds + (UNI ? (size_t)0 : (size_t)NPOS * 64 * MLD * sizeof(float)));   // [8][32]
             double* lq = ls + NRG * 32;
             float* lmn = reinterpret_cast<float*>(lq + NRG * 32);
             float* lmx = lmn + NRG * 32;
@@ -943,6 +977,10 @@ template <int NPASS>
 __global__ void __launch_bounds__(NTHR, 2) conv_wino4d(const W4Params p) { conv_wino4d_body<NPASS, 0>(p); }
 template <int NPASS>
 __global__ void __launch_bounds__(NTHR, 2) conv_wino4d_masked(const W4Params p) { conv_wino4d_body<NPASS, 1>(p); }
+template <int NPASS>
+__global__ void __launch_bounds__(NTHR, 2) conv_wino4d_rest(const W4Params p) { conv_wino4d_body<NPASS, 2>(p); }
+template <int NPASS>
+__global__ void __launch_bounds__(NTHR, 2) conv_wino4d_uniform(const W4Params p) { conv_wino4d_body<NPASS, 3>(p); }
 #ifdef BFM_W4_ABLATE
 template <int ABL>
 __global__ void __launch_bounds__(NTHR, 2) conv_wino4d_abl(const W4Params p) { conv_wino4d_body<3, 0, ABL>(p); }
@@ -1066,7 +1104,7 @@ extern "C" size_t bfm_conv3x3x3_wino4_masked_workspace(int D, int H, int W, int 
 static int w4_launch(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift, const float* bound,
                      int G, const void* wpacked, int wexp, int Cout, float slope, int passes, int flags, float* out,
                      void* moment_rows, const float* mask_img, void* mask_ws, bfm_stream_t stream, int S = 1,
-                     int affine_stride = 0) {
+                     int affine_stride = 0, const unsigned char* uni_flags = nullptr, float* uni_acc = nullptr) {
     const int accumulate = flags & 1;
     if (flags & ~1) return BFM_E_ARG;                           // bit 0 = accumulate; nothing else is defined
     if (!A || CA <= 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || G <= 0 || !wpacked || !out)
@@ -1108,10 +1146,20 @@ static int w4_launch(const float* A, int CA, int D, int H, int W, const float* s
     const size_t epi = (size_t)NPOS * 64 * MLD * sizeof(float) + (size_t)NRG * 32 * 24;   // output-transform scratch + moment fold
     if (smem < epi) smem = epi;
     if (smem > (dma ? 80u : 64u) * 1024) return BFM_E_SHAPE;
+    if (uni_flags) {                                            // the pair: conv_wino4d only, on conv_wino's box grid
+        int bd, bh, bw;
+        if (!dma || mask_img || S > 1 || affine_stride > 0 || !uni_acc) return BFM_E_ARG;
+        if (!bfm_wino_choose_box(D, H, W, npl, bd, bh, bw) || bd != p.TD || bh != p.TH || bw != p.TW) return BFM_E_SHAPE;
+        p.uni_flags = uni_flags;
+        p.uni_acc = uni_acc;
+    }
     if (dma) {                                                  // more than 64 KB of dynamic LDS: once per process
         static bool attr = false;
         if (!attr) {
             const int lim = 80 * 1024;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4d_rest<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4d_rest<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) != hipSuccess)
+                return BFM_E_LAUNCH;
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4d<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4d<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4d_masked<3>), hipFuncAttributeMaxDynamicSharedMemorySize, lim) != hipSuccess ||
@@ -1144,6 +1192,17 @@ static int w4_launch(const float* A, int CA, int D, int H, int W, const float* s
             else hipLaunchKernelGGL(conv_wino4d_masked<1>, grid, dim3(NTHR), smem, st, p);
         } else if (passes == 3) hipLaunchKernelGGL(conv_wino4_masked<3>, grid, dim3(NTHR), smem, st, p);
         else hipLaunchKernelGGL(conv_wino4_masked<1>, grid, dim3(NTHR), smem, st, p);
+        return bfm_launch_status();
+    }
+    if (uni_flags) {                                            // disjoint boxes: the two launches may overlap
+        // flags [nMt pad 4] | first box of each class [27] | the two counts | conv_wino4d_rest's list | conv_wino4d_uniform's
+        const int* cnt = reinterpret_cast<const int*>(uni_flags + (((size_t)p.nMt + 3) & ~(size_t)3)) + 27;
+        p.list = cnt + 2; p.list_n = cnt;
+        if (passes == 3) hipLaunchKernelGGL(conv_wino4d_rest<3>, grid, dim3(NTHR), smem, st, p);
+        else hipLaunchKernelGGL(conv_wino4d_rest<1>, grid, dim3(NTHR), smem, st, p);
+        p.list = cnt + 2 + p.nMt; p.list_n = cnt + 1;
+        if (passes == 3) hipLaunchKernelGGL(conv_wino4d_uniform<3>, grid, dim3(NTHR), 6144, st, p);
+        else hipLaunchKernelGGL(conv_wino4d_uniform<1>, grid, dim3(NTHR), 6144, st, p);
         return bfm_launch_status();
     }
 #ifdef BFM_W4_ABLATE
@@ -1198,4 +1257,22 @@ extern "C" int bfm_conv3x3x3_wino4_masked(const float* A, int CA, int D, int H, 
         return BFM_E_ARG;
     return w4_launch(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out, nullptr,
                      mask_image, workspace, stream);
+}
+
+// The uniform-box pair of the same kernel (bfm_conv3x3x3_wino_uniform's counterpart: same flags from bfm_uniform_boxes,
+// same bits with the flags and without).  For layers whose output no other uniform-box layer reads (conv_wino4d_body);
+// BFM_E_SHAPE where the volume's box is not conv_wino's.  scratch: bfm_conv3x3x3_wino4_uniform_scratch(Cout) bytes.
+extern "C" size_t bfm_conv3x3x3_wino4_uniform_scratch(int Cout) {
+    if (Cout <= 0 || Cout % 64) return 0;
+    return (size_t)27 * (Cout / 64) * 2 * 8 * NTHR * sizeof(float4);
+}
+
+extern "C" int bfm_conv3x3x3_wino4_uniform(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
+                                           const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope,
+                                           int passes, int flags, float* out, void* moment_rows,
+                                           const unsigned char* uniform_flags, void* scratch, bfm_stream_t stream) {
+    if (!uniform_flags || !scratch || (reinterpret_cast<uintptr_t>(uniform_flags) & 3) || (reinterpret_cast<uintptr_t>(scratch) & 15))
+        return BFM_E_ARG;
+    return w4_launch(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out, moment_rows,
+                     nullptr, nullptr, stream, 1, 0, uniform_flags, static_cast<float*>(scratch));
 }

@@ -519,10 +519,14 @@ class UNetEngine:
                                                        cfg[7] & 1, L.ptr(out), L.ptr(mask_img), L.ptr(mws), nws, st),
                     "conv_wino(masked) " + ly.name)
             return
-        if uni_flags is not None and cfg[6] == 3 and not cb:
-            scratch = torch.empty(self.lib.bfm_conv3x3x3_wino_uniform_scratch(ly.cout), dtype=torch.uint8,
+        if uni_flags is not None and cfg[6] == 4 and not self._same_boxes(dims):
+            uni_flags = None                                # the flags are per box of conv_wino's grid: dense launch, same bits
+        if uni_flags is not None and cfg[6] in (3, 4) and not cb:
+            f4 = cfg[6] == 4
+            scratch = torch.empty((self.lib.bfm_conv3x3x3_wino4_uniform_scratch if f4
+                                   else self.lib.bfm_conv3x3x3_wino_uniform_scratch)(ly.cout), dtype=torch.uint8,
                                   device=self.device)
-            fn = self.lib.bfm_conv3x3x3_wino_uniform
+            fn = self.lib.bfm_conv3x3x3_wino4_uniform if f4 else self.lib.bfm_conv3x3x3_wino_uniform
             L.check(fn(L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound),
                                                         groups, L.ptr(ly.wpacked), ly.wexp, ly.cout, slope, self.passes,
                                                         cfg[7] & 1, L.ptr(out), L.ptr(rows[0]) if rows is not None else None,
@@ -553,22 +557,33 @@ class UNetEngine:
                 "conv_mfma " + ly.name)
 
     def _needs_f23(self, ly):
-        """The layers that can take the uniform-box shortcut (the second conv of encoders.0, both of encoders.1, the skip
-        halves of the last two decoders' first convs) stay with F(2,3): the shortcut rests on class mates multiplying the
-        same operands, F(2,3)'s numerical support is its mathematical one, F(4,3)'s rounding reaches 4 voxels along x
-        (conv3d_wino4.hip) -- and a layer must compute the same bits with the shortcut on and off, so the rule goes by
-        position in the network, never by the state of a switch."""
+        """The uniform-box layers whose OUTPUT another uniform-box layer reads (the second conv of encoders.0, both of
+        encoders.1) stay with F(2,3): the shortcut rests on class mates multiplying the same operands, with the flags grown by
+        one voxel per layer; a voxel of an F(2,3) output depends numerically on its mathematical support, a voxel of an
+        F(4,3) output on its whole quad (conv3d_wino4.hip), which a consumer's flags do not cover.  The two layers at the END
+        of those chains -- the skip halves of the last two decoders' first convs -- read F(2,3) outputs and feed no
+        uniform-box layer: a box is a whole number of quads, its sums depend on its mathematical halo only, so they may run
+        F(4,3) with the same flags (bfm_conv3x3x3_wino4_uniform, round 5).  A layer must compute the same bits with the
+        shortcut on and off, so the rule goes by position in the network, never by the state of a switch."""
         ids = self.__dict__.get("_f23_ids")
         if ids is None:
             ids = set()
             for i, j in ((0, 1), (1, 0), (1, 1)):
                 if i < len(self.enc):
                     ids.add(id(self.enc[i][j]))
-            for k in (1, 2):
-                if len(self.dec) >= k:
-                    ids.add(id(self.dec[-k][0]))
             self.__dict__["_f23_ids"] = ids
         return id(ly) in ids
+
+    def _same_boxes(self, dims):
+        """conv_wino4's box for this volume is conv_wino's (the grid bfm_uniform_boxes flags)."""
+        cache = self.__dict__.setdefault("_same_box_cache", {})
+        key = tuple(dims)
+        if key not in cache:
+            b3, b4 = (C.c_int * 3)(), (C.c_int * 3)()
+            ok = (self.lib.bfm_conv3x3x3_wino_box(dims[0], dims[1], dims[2], self.passes, b3) == 0 and
+                  self.lib.bfm_conv3x3x3_wino4_box(dims[0], dims[1], dims[2], self.passes, b4) == 0)
+            cache[key] = ok and list(b3) == list(b4)
+        return cache[key]
 
     def _f23_cfg(self, ly, cfg):
         """A tuned choice of the F(4,3) kernel (variant 4) becomes F(2,3) for the uniform-box layers and in training (the
@@ -630,7 +645,7 @@ class UNetEngine:
             reps = 1
             if mask_img is not None and not (cfg[6] in (3, 4) and B is None and self.tape is None):
                 mask_img = None
-            if uni_flags is not None and not (cfg[6] == 3 and B is None and mask_img is None):
+            if uni_flags is not None and not (cfg[6] in (3, 4) and B is None and mask_img is None):
                 uni_flags = None
             rows = self._rows_for(ly.cin, ly.cout, dims, cfg) if mask_img is None else None
             if self.prof is not None:
@@ -800,7 +815,7 @@ class UNetEngine:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         rows = self._rows_for(ca, ly.cout, dims, cfg)
-        if uni_flags is not None and cfg[6] != 3:
+        if uni_flags is not None and (cfg[6] not in (3, 4) or (cfg[6] == 4 and not self._same_boxes(dims))):
             uni_flags = None
         for _ in range(reps):
             self._conv_launch(sk, A, ca, None, 0, dims, None, scale, shift, bound, ly.groups, cfg, out, ws, rows,

@@ -252,6 +252,17 @@ int bfm_conv3x3x3_wino4_batch(const float* A, int CA, int S, int D, int H, int W
  * is no uniform-box pair: F(4,3)'s rounding reaches 4 voxels along x where F(2,3)'s numerical support is its
  * mathematical one (conv3d_wino4.hip), so the layers that take that shortcut stay with bfm_conv3x3x3_wino_uniform. */
 size_t bfm_conv3x3x3_wino4_masked_workspace(int D, int H, int W, int passes);
+/* The uniform-box pair of the F(4,3) kernel (round 5): bfm_conv3x3x3_wino_uniform's arguments and contract (flags from
+ * bfm_uniform_boxes on the same box grid, same bits with and without them), for the layers whose output no other layer
+ * that takes the shortcut reads -- the skip halves of the last two decoders' first convs (buildingblocks.py:265-276):
+ * there a box's numerical support is its mathematical halo (a box is a whole number of quads).  BFM_E_SHAPE where the
+ * volume's box differs from bfm_conv3x3x3_wino_box()'s.  scratch: bfm_conv3x3x3_wino4_uniform_scratch(Cout) bytes, 16-byte
+ * aligned. */
+size_t bfm_conv3x3x3_wino4_uniform_scratch(int Cout);
+int bfm_conv3x3x3_wino4_uniform(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
+                                const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
+                                int flags, float* out, void* moment_rows, const unsigned char* uniform_flags, void* scratch,
+                                bfm_stream_t stream);
 int bfm_conv3x3x3_wino4_masked(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                                const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
                                int flags, float* out, const float* mask_image, void* workspace, size_t workspace_bytes,

@@ -221,8 +221,25 @@ def test_tiled_ragged_odd_volume_vs_oracle():
     assert [tuple(map(tuple, r)) for r in ranges] == [tuple(map(tuple, r)) for r in ranges_ref]
     assert np.array_equal(cnt.cpu().numpy(), np.asarray(cnt_ref))
     for k, v in ref.items():
-        e = _relerr(acc[k].cpu().numpy(), np.asarray(v))
-        assert e <= (2e-2 if k == "label" else TOL_NET), (k, e)   # label: float average of ints, a flip moves it by 1/cnt
+        if k != "label":
+            e = _relerr(acc[k].cpu().numpy(), np.asarray(v))
+            assert e <= TOL_NET, (k, e)
+    # label: the float average of integer labels over the tiles that cover a voxel.  Equal to the fp32 oracle's except where
+    # a covering tile's two best classes are closer than fp32 resolves: the float64 evaluation of that tile arbitrates
+    # (round 5: one such voxel, float64 top-2 gap 2.3e-8, moved when the split's low halves went from truncation to
+    # round-to-nearest)
+    bad = np.argwhere(np.abs(acc["label"].cpu().numpy() - np.asarray(ref["label"])) > 1e-6)
+    assert len(bad) <= 3, len(bad)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    for z, y, x in bad:
+        gaps = []
+        for r in ranges_ref:
+            if all(r[a][0] <= c < r[a][1] for a, c in enumerate((z, y, x))):
+                t = full[:, :, r[0][0]:r[0][1], r[1][0]:r[1][1], r[2][0]:r[2][1]].double()
+                seg = O.forward_all(t, sd64, f_maps=16, num_levels=3)["segmentation"][0, :, z - r[0][0], y - r[1][0], x - r[2][0]]
+                top = torch.topk(seg, 2).values
+                gaps.append(float(top[0] - top[1]))
+        assert min(gaps) < 1e-5, ((int(z), int(y), int(x)), gaps)
 
 
 def test_evaluate_batch_of_two_equals_two_single_calls():
@@ -1140,7 +1157,7 @@ def test_compact_rows_index_pack_and_stitch_equal_the_dense_form_bitwise(shape, 
         assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
 
 
-@pytest.mark.parametrize("ver", [3, None])
+@pytest.mark.parametrize("ver", [3, 4, None])
 @pytest.mark.parametrize("dims", [(48, 64, 128), (50, 66, 130), (45, 70, 150)])
 def test_uniform_background_boxes_change_no_bit(dims, ver, monkeypatch):
     """Where the one-channel input is constant (the zero background of a head volume) the first layers' activations are one
@@ -1156,9 +1173,10 @@ def test_uniform_background_boxes_change_no_bit(dims, ver, monkeypatch):
     import ctypes as C
     from brainfm_amd import _lib as L
     if ver is not None:
-        monkeypatch.setenv("BFM_CONV_VER", str(ver))     # 3: every Winograd-capable layer on F(2,3); None: the tuner's choices,
-    else:                                                # with the F(4,3) kernel among them wherever the engine allows it
-        monkeypatch.setenv("BFM_CONV_TUNE", "retune")    # (the uniform-box layers never: engine._needs_f23)
+        monkeypatch.setenv("BFM_CONV_VER", str(ver))     # 3: every Winograd-capable layer on F(2,3); 4: on F(4,3) wherever the
+    else:                                                # engine allows it -- the uniform-box layers that feed another one never
+        monkeypatch.setenv("BFM_CONV_TUNE", "retune")    # (engine._needs_f23), the skip halves of the last two decoders' first
+                                                         # convs yes: bfm_conv3x3x3_wino4_uniform (round 5); None: the tuner's choices
     ga, ta = TU.default_inference_args(f_maps=64, num_levels=3)
     g = torch.Generator().manual_seed(3)
     zz, yy, xx = np.meshgrid(*[np.linspace(-1, 1, n_) for n_ in dims], indexing="ij")
@@ -1208,7 +1226,9 @@ def test_uniform_background_boxes_change_no_bit(dims, ver, monkeypatch):
                     hit = np.flatnonzero(fl == c + 1)
                     assert first[c] == (int(hit[0]) if hit.size else nb), (lvl, rad, c)
             kinds = {int(c[6]) for c in s.engine._plan_cache.values()}
-            assert ver is None or 3 in kinds                      # the Winograd variant ran: the flags were used
+            assert ver is None or ver in kinds                    # the Winograd variant ran: the flags were used
+            if ver == 4 and dims == (48, 64, 128):               # ... by the F(4,3) pair too (same box grid at both levels)
+                assert eng._same_boxes(dims) and eng._same_boxes(tuple(v >> 1 for v in dims))
     for k in outs[True]:
         if k == "feat":
             for a, b in zip(outs[True][k], outs[False][k]):
