@@ -101,7 +101,7 @@ def host_cpu_info():
     return info
 
 
-def cpu_baseline(state_dict, full, n, ranges, full_protocol=False, sess=None):
+def cpu_baseline(state_dict, full, n, ranges, full_protocol=False, sess=None, fast_sess=None):
     """The CPU oracle (oracle/unet_ref.py: a torch-CPU fp32 port of the reference's path) timed on this host, rank 0
     only, the way BASELINE.md section 4 / SURVEY 8(d) set it: threads = the physical cores of one socket, per tile
     shape of the reference tiling 1 warm-up + 3 timed runs (median), and the whole volume's time extrapolated from
@@ -139,6 +139,8 @@ def cpu_baseline(state_dict, full, n, ranges, full_protocol=False, sess=None):
                     runs.append(time.perf_counter() - t0)
                 if idx == 0 and sess is not None:
                     parity = label_parity(sess, tile, ref, sd)
+                    if fast_sess is not None:                       # the same tile through the passes=1 session
+                        parity["fast_mode"] = label_parity(fast_sess, tile, ref, sd)
             med = float(np.median(runs))
             spent += sum(runs) * (4.0 / 3.0 if small else 1.0)
             per_shape["x".join(map(str, s))] = {"tiles": cnt, "median_s": med, "runs": len(runs),
@@ -160,6 +162,17 @@ def cpu_baseline(state_dict, full, n, ranges, full_protocol=False, sess=None):
                          "(--cpu-baseline-quick)", n, total_s, spent, int(threads))}
 
 
+ELEMENTWISE_RTOL, ELEMENTWISE_ATOL_REL = 1e-3, 1e-5
+
+
+def elementwise_failures(a, b):
+    """Fraction of elements with |a - b| > 1e-3 |b| + 1e-5 max|b| (the element-wise form beside the
+    max-norm one, which never looks at a low-valued voxel's own relative error)."""
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    tol = ELEMENTWISE_RTOL * b.abs() + ELEMENTWISE_ATOL_REL * float(b.abs().max())
+    return float(((a - b).abs() > tol).double().mean())
+
+
 def label_parity(sess, tile, ref, sd):
     """The HIP path's labels on the tile the CPU baseline just evaluated, against that fp32 oracle result: number of
     differing voxels, and -- when there are any -- the relative gap of the two best class probabilities at those voxels
@@ -172,12 +185,17 @@ def label_parity(sess, tile, ref, sd):
     nd = int(differ.sum())
     res = {"tile": list(tile.shape[2:]), "n_voxels": int(lab.numel()), "label_flips_vs_fp32_oracle": nd,
            "max_fp64_gap": None, "oracle_flips_vs_fp64": None, "hip_flips_vs_fp64": None}
-    worst = 0.0
+    worst, ew = 0.0, {}
     for k, v in ref.items():
         if k in out and k not in ("feat", "label", "segmentation"):
             a, b = out[k].cpu().double(), v.double()
             worst = max(worst, float((a - b).abs().max() / max(1e-6, float(b.abs().max()))))
+            ew[k] = elementwise_failures(a, b)
     res["max_rel_err_float_maps"] = worst
+    wk = max(ew, key=ew.get) if ew else None
+    res["elementwise"] = {"rule": "|a - b| <= %g |b| + %g max|b| per element" % (ELEMENTWISE_RTOL, ELEMENTWISE_ATOL_REL),
+                          "failing_fraction_worst_map": ew.get(wk), "worst_map": wk,
+                          "failing_fraction_mean_over_maps": (sum(ew.values()) / len(ew)) if ew else None}
     if nd:
         with torch.no_grad():
             r64 = O.forward_all(tile.double(), {k: v.double() for k, v in sd.items()}, f_maps=64, num_levels=6)
@@ -187,6 +205,53 @@ def label_parity(sess, tile, ref, sd):
         res["oracle_flips_vs_fp64"] = int((ref["label"] != r64["label"]).sum())
         res["hip_flips_vs_fp64"] = int((lab != r64["label"]).sum())
     return res
+
+
+def fast_mode_block(sess, full, stride, win, reps=5):
+    """BASELINE config 2's class on the line: the opt-in passes=1 mode (one plain f16 product per
+    term instead of the three split-f16 passes; NOT the parity class) -- one 160^3 volume through forward_fused and the
+    256^3 volume through the tile loop, timed, with its measured distance from the parity-mode result of this run on the
+    160^3 volume (the distance from the fp32 oracle on the CPU baseline's 80^3 tile is added under label_parity.fast_mode)."""
+    from brainfm_amd import test_utils as TU
+    dev = sess.device
+    ga, ta = TU.default_inference_args(f_maps=64, num_levels=6)
+    fast = TU.InferenceSession(ga, ta, dev, state_dict={k: v for k, v in sess.model.state_dict().items()}, passes=1)
+    fast.atlas = sess.atlas                               # the same resident atlas volume and inverse affine
+    fast.use_graphs = sess.use_graphs
+    n = full.shape[-1]
+    c0 = max(0, (n - 160) // 2)
+    tile = full[:, :, c0:c0 + 160, c0:c0 + 160, c0:c0 + 160].contiguous()
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    ms160 = timed(lambda: fast.forward_fused(tile, want_feat=False, want_seg=False))
+    ms160_parity = timed(lambda: sess.forward_fused(tile, want_feat=False, want_seg=False))
+    a, _ = fast.forward_fused(tile, want_feat=False, want_seg=False)
+    b, _ = sess.forward_fused(tile, want_feat=False, want_seg=False)
+    worst, ew = 0.0, 0.0
+    for k, v in b.items():
+        if k in a and k not in ("feat", "label", "segmentation"):
+            worst = max(worst, float((a[k].double() - v.double()).abs().max() / max(1e-6, float(v.double().abs().max()))))
+            ew = max(ew, elementwise_failures(a[k], v))
+    flips = float((a["label"] != b["label"]).double().mean())
+    if fast.use_graphs:
+        TU.prepare_tile_graphs(full, fast, stride, win)
+    ms_vol = timed(lambda: TU.tiled_inference(full, fast, stride, win, batched=True))
+    return fast, {"what": "passes=1: plain f16 products (BASELINE config 2's 'bf16' class); opt-in, not the parity class",
+                  "volume_160_ms": ms160, "volume_160_parity_mode_ms": ms160_parity,
+                  "volume_160_mvoxel_per_s": 160 ** 3 / ms160 / 1e3,
+                  "tiled_%d_ms_per_volume" % n: ms_vol, "tiled_%d_mvoxel_per_s" % n: n ** 3 / ms_vol / 1e3,
+                  "vs_parity_mode_160": {"max_rel_err_float_maps": worst, "label_flip_fraction": flips,
+                                         "elementwise_failing_fraction_worst_map": ew},
+                  "stated_tolerance": "1e-1 max-norm on float maps (tests/test_gpu_infer.py::test_config2_single_160_volume_all_heads)"}
 
 
 def synthesis_block(dev, items=8):
@@ -429,6 +494,7 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="submit every kernel from python instead of hipGraph replay")
     ap.add_argument("--no-synthesis", action="store_true", help="skip the synthesis block (hot path B) of the line")
     ap.add_argument("--no-training", action="store_true", help="skip the training block (SURVEY N2) of the line")
+    ap.add_argument("--no-fast-mode", action="store_true", help="skip the passes=1 block (BASELINE config 2's class) of the line")
     ap.add_argument("--roofline-reps", type=int, default=3,
                     help="back-to-back launches per HIP-event bracket in the instrumented conv pass")
     args = ap.parse_args()
@@ -815,9 +881,16 @@ def main():
                 line["training"] = training_block(dev)
             except Exception as e:                            # noqa: BLE001
                 line["training"] = {"error": repr(e)}
+        line["fast_mode"] = None
+        fast_sess = None
+        if not args.no_fast_mode and world == 1 and args.passes == 3:
+            try:
+                fast_sess, line["fast_mode"] = fast_mode_block(sess, full, stride, win)
+            except Exception as e:                            # noqa: BLE001
+                line["fast_mode"] = {"error": repr(e)}
         if not args.no_cpu_baseline and world == 1:
             sd = {k: v for k, v in sess.model.state_dict().items()}
-            line["cpu_baseline"] = cpu_baseline(sd, full, n, ranges, not args.cpu_baseline_quick, sess)
+            line["cpu_baseline"] = cpu_baseline(sd, full, n, ranges, not args.cpu_baseline_quick, sess, fast_sess)
             line["label_parity"] = line["cpu_baseline"].pop("label_parity")
             try:                                              # for the N > 1 lines of the same box (rank 0 at N = 1 only)
                 os.makedirs(os.path.dirname(CPU_BASELINE_CACHE), exist_ok=True)

@@ -12,6 +12,8 @@ from oracle import unet_ref as O
 pytestmark = pytest.mark.gpu
 
 TOL_PARITY = 1e-4      # single blocks: max |a-b| / max|b| for fp32-grade paths
+EW_FRAC_PARITY = 2e-2  # element-wise rule |a-b| <= 1e-3 |b| + 1e-5 max|b|: largest failing fraction accepted per map on the
+                       # full-width net (measured values are printed by the config 1 / 2 tests and stand in DESIGN.md section 1)
 TOL_NET = 1e-3         # whole network: the north-star tolerance.  F.normalize over few channels is
                        # ill-conditioned: torch-CPU fp32 itself sits 2e-4 from an fp64 evaluation of
                        # the small golden net (tests/diag/diag_small.py), the HIP path 1.4e-4.
@@ -26,6 +28,15 @@ def _relerr(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max()) / max(1e-6, float(np.abs(b).max()))
+
+
+def _elementwise_failing_fraction(a, b, rtol=1e-3, atol_rel=1e-5):
+    """The element-wise form beside the max-norm one: fraction of elements with
+    |a - b| > rtol |b| + atol_rel max|b| -- a low-valued voxel's own relative error is looked at."""
+    a = torch.as_tensor(a).double().reshape(-1)
+    b = torch.as_tensor(b).double().reshape(-1)
+    tol = rtol * b.abs() + atol_rel * float(b.abs().max())
+    return float(((a - b).abs() > tol).double().mean())
 
 
 def _session(d=None, sd=None, f_maps=8, levels=4, left=False, passes=3, groups=8):
@@ -1324,8 +1335,11 @@ def test_config1_feature_extraction_128():
         torch.set_num_threads(prev)
     got = feat.cpu()
     err = float((got - ref).abs().max()) / float(ref.abs().max())
-    print("config 1: feat[-1] 128^3 max rel err %.2e" % err)
+    ew = _elementwise_failing_fraction(got, ref)
+    print("config 1: feat[-1] 128^3 max rel err %.2e; element-wise |a-b| <= 1e-3 |b| + 1e-5 max|b| fails on %.3e of the elements"
+          % (err, ew))
     assert err <= 1e-3, err
+    assert ew <= EW_FRAC_PARITY, ew
     nrm = got.double().pow(2).sum(1).sqrt()
     assert float((nrm - 1).abs().max()) < 1e-5                      # unit_feat: F.normalize over the 64 channels
 
@@ -1362,6 +1376,11 @@ def test_config2_single_160_volume_all_heads():
     assert len(keys) == 15 and all(k in out for k in keys)
     errs = {k: float((out[k].cpu() - ref[k]).abs().max()) / max(1e-6, float(ref[k].abs().max())) for k in keys}
     assert max(errs.values()) <= 1e-3, errs
+    ews = {k: _elementwise_failing_fraction(out[k].cpu(), ref[k]) for k in keys}
+    wk = max(ews, key=ews.get)
+    print("config 2 (parity): element-wise |a-b| <= 1e-3 |b| + 1e-5 max|b| fails on %.3e of the voxels of the worst map (%s), %.3e on "
+          "average over the 15 maps" % (ews[wk], wk, sum(ews.values()) / len(ews)))
+    assert ews[wk] <= EW_FRAC_PARITY, ews
     lab = out["label"].cpu()
     differ = lab != ref["label"]
     nd = int(differ.sum())
