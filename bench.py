@@ -257,9 +257,13 @@ def fast_mode_block(sess, full, stride, win, reps=5):
 def synthesis_block(dev, items=8):
     """Hot path B (BASELINE.json north_star: the data-synthesis kernels; SURVEY config 5's generator half) on the bench
     line: one BrainIDGen.__getitem__ counterpart -- 192^3 Voronoi label case, 4 augmented 160^3 samples, pathology on --
-    timed per item with a device synchronisation after each (median over `items`), and the streaming kernels of that
-    item timed alone at 160^3 inside replayed hipGraphs (20 launches per replay, HIP events around the replay on the
-    launch stream), each against its own algorithmic bytes and the 8 TB/s HBM peak."""
+    timed per item with a device synchronisation after each (median over `items`); the same item with a resident
+    pathology_prob volume and random_shape_prob 0, which runs warp -> Perlin velocity -> dopri5 -> binarize as ONE chain
+    (item_with_pde_ms); and the streaming kernels of the item timed alone at 160^3 inside replayed hipGraphs, TWICE
+    (VERDICT r4 #2): COLD -- every launch of a replay works on its own buffers, >= 1.2 GB per replay, far more than the
+    256 MB Infinity Cache holds, so the bytes come from HBM: frac = algorithmic bytes / time / 8 TB/s -- and HOT -- the same
+    buffers every launch (round 4's numbers), which live in the Infinity Cache: reported as a rate, with its fraction of
+    the measured on-die rate of a streaming copy of the same size (hot_copy_TB_per_s), never of the HBM peak."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import config5_lib as C5
@@ -270,29 +274,45 @@ def synthesis_block(dev, items=8):
     N = 160
     nv = N ** 3
     st_np, st_t = np.random.get_state(), torch.random.get_rng_state()
+
+    def time_items(ds, n_items):
+        for _ in range(2):
+            ds[0]
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(n_items):
+            t0 = time.perf_counter()
+            ds[0]
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return ts
+
     np.random.seed(100)
     torch.manual_seed(100)
     ga = C5.gen_args(N)
     ds = G.build_datasets(ga, str(dev), cases=[C5.voronoi_case(7)])["all"]
-    for _ in range(2):
-        ds[0]
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(items):
-        t0 = time.perf_counter()
-        ds[0]
-        torch.cuda.synchronize()
-        ts.append(time.perf_counter() - t0)
+    ts = time_items(ds, items)
     item = float(np.median(ts))
     ns = ga.generator.all_samples
+    # the chain config 5 names: file-based lesion probability -> warp -> Perlin velocity + dopri5 -> binarize, inside the item
+    np.random.seed(100)
+    torch.manual_seed(100)
+    ga_p = C5.gen_args(N, random_shape_prob=0.0)
+    ds_p = G.build_datasets(ga_p, str(dev), cases=[C5.voronoi_case(7, pathology_prob=True)])["all"]
+    ts_p = time_items(ds_p, max(4, items // 2))
+    item_pde = float(np.median(ts_p))
+    del ds_p
 
-    def timed(fn, launches=20, replays=5):
-        fn()
+    def timed(fn, sets, replays=5):
+        """us per launch of fn(j), j = 0..sets-1 once per replay, outputs kept alive inside the capture (distinct memory)."""
+        keep = [fn(j) for j in range(sets)]
+        del keep
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
+        keep = []
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            for _ in range(launches):
-                fn()
+            for j in range(sets):
+                keep.append(fn(j))
         g.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -301,34 +321,64 @@ def synthesis_block(dev, items=8):
             g.replay()
         e1.record()
         e1.synchronize()
-        return e0.elapsed_time(e1) / (launches * replays) * 1e3          # us per launch
+        us = e0.elapsed_time(e1) / (sets * replays) * 1e3
+        del keep, g
+        return us
 
-    vol = torch.rand(N, N, N, device=dev)
-    src = torch.rand(192, 192, 192, device=dev)
+    COLD_BYTES = 1.2e9
+
+    def both(make, call, touched):
+        """(hot us, cold us): `make()` -> one set of input buffers, call(set) -> output(s); touched = bytes one call moves."""
+        k = int(min(96, max(8, -(-COLD_BYTES // touched))))
+        pool = [make() for _ in range(k)]
+        hot = timed(lambda j: call(pool[0]), 20)
+        cold = timed(lambda j: call(pool[j]), k)
+        del pool
+        torch.cuda.empty_cache()
+        return hot, cold, k
+
     ax = torch.arange(N, device=dev, dtype=torch.float32)
     zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
-    si, sj, sk = (zz * 1.1 + 5 + 0.3 * torch.sin(yy / 9)).contiguous(), (yy * 1.1 + 6).contiguous(), (xx * 1.1 + 4).contiguous()
-    small = torch.rand(6, 6, 6, 3, device=dev)
-    bfs = torch.rand(5, 5, 5, device=dev)
-    kern = {}
-    kern["interp_linear (fast_3D_interp_torch, 192^3 -> 160^3)"] = (timed(lambda: GU.fast_3D_interp_torch(src, si, sj, sk)), nv * 20)
-    kern["zoom_linear (myzoom_torch 6^3x3 -> 160^3x3)"] = (timed(lambda: GU.myzoom_torch(small, N / 6.0)), nv * 12)
-    kern["zoom_linear (bias field 5^3 -> 160^3)"] = (timed(lambda: GU.myzoom_torch(bfs, N / 5.0)), nv * 4)
-    kern["conv1d_axis x3 (gaussian_blur_3d sigma 1.5)"] = (timed(lambda: GU.gaussian_blur_3d(vol, [1.5, 1.5, 1.5], dev)), nv * 24)
-    kern["ew_unary gamma"] = (timed(lambda: GU.ew_unary(L.EW_GAMMA, vol, 300.0, 1.1)), nv * 8)
-    kern["ew_binary mul_exp (bias field)"] = (timed(lambda: GU.ew_binary(L.EW_MUL_EXP, vol, vol)), nv * 12)
-    kern["reduce max (partial + fold)"] = (timed(lambda: GU.reduce_dev(1, vol)), nv * 4)
-    kern["randn_philox"] = (timed(lambda: GU.draws.randn((N, N, N), dev)), nv * 4)
+    c_i, c_j, c_k = (zz * 1.1 + 5 + 0.3 * torch.sin(yy / 9)).contiguous(), (yy * 1.1 + 6).contiguous(), (xx * 1.1 + 4).contiguous()
+    del zz, yy, xx
+    rnd = lambda *shape: torch.rand(*shape, device=dev)
     np.random.seed(0)
     grads = SH.perlin_gradients((2, 2, 2), (True, False, False))
     gdev = torch.from_numpy(np.ascontiguousarray(grads, dtype=np.float64)).to(dev)
-    noise = torch.empty((N, N, N), dtype=torch.float64, device=dev)
     lib = L.load()
-    kern["perlin3d (fp64 out)"] = (timed(lambda: L.check(lib.bfm_perlin3d(L.ptr(gdev), N, N, N, 2, 2, 2, L.ptr(noise),
-                                                                          L.stream_ptr()), "perlin3d")), nv * 8)
-    kern["percentile_f64 (radix select, 14 launches)"] = (timed(lambda: SH.percentile_dev(noise, 91.0), launches=5), nv * 8 * 7)
-    table = {k: {"us": round(us, 2), "algorithmic_MB": b / 1e6, "TB_per_s": round(b / us / 1e6, 3),
-                 "frac_of_8TBs": round(b / us / 1e6 / 8.0, 4)} for k, (us, b) in kern.items()}
+
+    def perlin(buf):
+        L.check(lib.bfm_perlin3d(L.ptr(gdev), N, N, N, 2, 2, 2, L.ptr(buf), L.stream_ptr()), "perlin3d")
+        return buf
+
+    kern = {}
+    # name -> (hot us, cold us, sets, algorithmic bytes).  The gather's coordinates are cloned per set: they are inputs too
+    kern["interp_linear (fast_3D_interp_torch, 192^3 -> 160^3)"] = both(
+        lambda: (rnd(192, 192, 192), c_i.clone(), c_j.clone(), c_k.clone()),
+        lambda b: GU.fast_3D_interp_torch(b[0], b[1], b[2], b[3]), 4 * (192 ** 3 + 4 * nv)) + (nv * 20,)
+    kern["zoom_linear (myzoom_torch 6^3x3 -> 160^3x3)"] = both(lambda: rnd(6, 6, 6, 3), lambda b: GU.myzoom_torch(b, N / 6.0),
+                                                              12 * nv) + (nv * 12,)
+    kern["zoom_linear (bias field 5^3 -> 160^3)"] = both(lambda: rnd(5, 5, 5), lambda b: GU.myzoom_torch(b, N / 5.0), 4 * nv) + (nv * 4,)
+    kern["conv1d_axis x3 (gaussian_blur_3d sigma 1.5)"] = both(lambda: rnd(N, N, N), lambda b: GU.gaussian_blur_3d(b, [1.5, 1.5, 1.5], dev),
+                                                              8 * nv) + (nv * 24,)
+    kern["ew_unary gamma"] = both(lambda: rnd(N, N, N), lambda b: GU.ew_unary(L.EW_GAMMA, b, 300.0, 1.1), 8 * nv) + (nv * 8,)
+    kern["ew_binary mul_exp (bias field)"] = both(lambda: (rnd(N, N, N), rnd(N, N, N)), lambda b: GU.ew_binary(L.EW_MUL_EXP, b[0], b[1]),
+                                                  12 * nv) + (nv * 12,)
+    kern["reduce max (partial + fold)"] = both(lambda: rnd(N, N, N), lambda b: GU.reduce_dev(1, b), 4 * nv) + (nv * 4,)
+    kern["randn_philox"] = both(lambda: None, lambda b: GU.draws.randn((N, N, N), dev), 4 * nv) + (nv * 4,)
+    kern["perlin3d (fp64 out)"] = both(lambda: torch.empty((N, N, N), dtype=torch.float64, device=dev), perlin, 8 * nv) + (nv * 8,)
+    kern["percentile_f64 (radix select, 14 launches)"] = both(
+        lambda: perlin(torch.empty((N, N, N), dtype=torch.float64, device=dev)), lambda b: SH.percentile_dev(b, 91.0), 8 * nv) + (nv * 8 * 7,)
+    # the on-die ceiling the hot numbers are read against: a plain device-to-device copy of one 160^3 fp32 volume, hot
+    cp_src, cp_dst = rnd(N, N, N), torch.empty(N, N, N, device=dev)
+    hot_copy_us = timed(lambda j: cp_dst.copy_(cp_src), 20)
+    hot_copy = 8.0 * nv / hot_copy_us / 1e6                                   # TB/s, bytes read + written
+    table = {}
+    for k, (hot, cold, sets, b) in kern.items():
+        table[k] = {"us_cold": round(cold, 2), "us_hot": round(hot, 2), "algorithmic_MB": b / 1e6, "cold_sets_per_replay": sets,
+                    "TB_per_s_cold": round(b / cold / 1e6, 3), "frac_of_8TBs_cold": round(b / cold / 1e6 / 8.0, 4),
+                    "TB_per_s_hot": round(b / hot / 1e6, 3),
+                    "frac_of_hot_copy_rate": round(min(1.0, b / hot / 1e6 / hot_copy), 4)}
     # the pathology shape augmentation alone (Generator/utils.py:542-560), longest case nt = max_nt
     t = torch.from_numpy(np.arange(10) * 0.1)
     pde = SH.AdvDiffPDE(data_spacing=[1., 1., 1.], perf_pattern="adv", V_type="vector_div_free", V_dict={}, BC="neumann",
@@ -355,22 +405,34 @@ def synthesis_block(dev, items=8):
     ode_bytes = ode_steps * (6 * (8 + 12 + 4) + 4 * 21 + 8) * nv          # per step: y (fp64) + V + k out per stage, the k_j
     np.random.set_state(st_np)
     torch.random.set_rng_state(st_t)
-    worst = min(table, key=lambda k: table[k]["frac_of_8TBs"])
+    worst = min(table, key=lambda k: table[k]["frac_of_8TBs_cold"])
     return {"workload": "BrainIDGen.__getitem__ counterpart: 192^3 Voronoi label case resident in HBM -> deformation, "
                         "8 float targets + one-hot segmentation + Perlin pathology, %d augmented %d^3 samples" % (ns, N),
             "item_ms_median": item * 1e3, "item_ms_min": min(ts) * 1e3, "items_per_s": 1.0 / item,
             "generated_voxels_per_s": ns * nv / item, "samples_per_item": ns,
             "host_syncs_per_item": 2 + ns, "round3_item_ms": 168.0,
+            "item_with_pde_ms": item_pde * 1e3,
+            "item_with_pde": "the same item with a resident pathology_prob volume and random_shape_prob 0: the lesion map is "
+                             "warped (trilinear gather), advected by a Perlin curl velocity field through dopri5 "
+                             "(augment_pathology, nt drawn in [2, 10]) and binarised inside the item -- the chain BASELINE "
+                             "config 5 names; median of %d items" % len(ts_p),
             "kernels_160": table, "lowest_frac_kernel": worst,
+            "hot_copy_TB_per_s": round(hot_copy, 3),
             "augment_pathology_160": {"ms_median": ode_ms, "steps": ode_steps, "nt": int(shp_args.max_nt),
                                       "algorithmic_GB": ode_bytes / 1e9,
                                       "TB_per_s": ode_bytes / ode_ms / 1e9, "frac_of_8TBs": ode_bytes / ode_ms / 1e9 / 8.0,
+                                      "working_set_MB": 220,
                                       "note": "dopri5 over the upwind advection PDE, step controller on the device; per "
                                               "step and voxel: 6 stages x (fp64 state 8 B + 3 velocities 12 B + k out 4 B) "
-                                              "+ the 21 reads of earlier k_j (4 B) + y1 out 8 B"},
-            "note": "kernel times: 20 launches captured in a hipGraph, replayed 5x inside one HIP event pair on the launch "
-                    "stream; algorithmic bytes per SURVEY 8(d) (coordinates + one touch of the source + output; fp64 "
-                    "where the reference computes in fp64)"}
+                                              "+ the 21 reads of earlier k_j (4 B) + y1 out 8 B; its ~220 MB working set "
+                                              "sits at the edge of the 256 MB Infinity Cache, so the fraction is an upper "
+                                              "bound on an HBM fraction (measured HBM bytes: profiles/r05_synth_hbm_traffic.json)"},
+            "note": "kernel times: hipGraph replays between two HIP events on the launch stream.  cold = each launch of a replay "
+                    "on its own input and output buffers (cold_sets_per_replay sets, >= 1.2 GB touched per replay: HBM); hot = 20 "
+                    "launches on one set (Infinity-Cache resident; hot_copy_TB_per_s = a device-to-device copy measured the same "
+                    "way, the on-die rate the hot numbers are read against); algorithmic bytes per SURVEY 8(d) (coordinates + "
+                    "one touch of the source + output; fp64 where the reference computes in fp64); measured HBM bytes per "
+                    "kernel: profiles/r05_synth_hbm_traffic.json"}
 
 
 def training_block(dev, size=128, reps=2):

@@ -16,7 +16,7 @@ LOSS_NAMES = ["T1", "T1_grad", "seg_ce", "seg_dice", "distance", "bias_field_log
               "SR_grad"]
 
 
-def voronoi_case(seed, n=192, nseeds=40):
+def voronoi_case(seed, n=192, nseeds=40, pathology_prob=False):
     rs = np.random.RandomState(seed)
     ax = np.arange(n, dtype=np.float32)
     zz, yy, xx = np.meshgrid(ax, ax, ax, indexing="ij")
@@ -32,18 +32,29 @@ def voronoi_case(seed, n=192, nseeds=40):
         lab[m] = i
     ids = np.array([2, 3, 4, 41, 42, 17, 10, 11, 12, 13, 7, 8, 16, 18, 26, 28])[lab % 16] * ell
     shp = (n, n, n)
-    return {"name": "voronoi%d" % seed, "Gen": ids.astype(np.float32), "T1": rs.rand(*shp).astype(np.float32) * ell,
+    case = {"name": "voronoi%d" % seed, "Gen": ids.astype(np.float32), "T1": rs.rand(*shp).astype(np.float32) * ell,
             "segmentation": ids.astype(np.int32),
             "distance": [rs.rand(*shp).astype(np.float32) * 255 for _ in range(4)],
             "registration": [rs.randn(*shp).astype(np.float32) * 500 for _ in range(3)]}
+    if pathology_prob:
+        # a resident lesion-probability volume (what a dataset's pathology_prob file holds): three smooth blobs inside the
+        # head.  With random_shape_prob < 1 the item then takes the file-based branch of read_and_deform_pathology, i.e.
+        # trilinear warp -> Perlin velocity field -> dopri5 advection (augment_pathology) -> binarize: the chain BASELINE
+        # config 5 names (Generator/utils.py:428-459, 542-560)
+        pp = np.zeros(shp, dtype=np.float32)
+        for cz, cy, cx, r in ((0.40, 0.45, 0.55, 0.09), (0.58, 0.52, 0.40, 0.07), (0.50, 0.60, 0.62, 0.05)):
+            d2 = (zz - cz * n) ** 2 + (yy - cy * n) ** 2 + (xx - cx * n) ** 2
+            pp = np.maximum(pp, np.exp(-d2 / (2.0 * (r * n) ** 2)).astype(np.float32))
+        case["pathology_prob"] = pp * ell
+    return case
 
 
-def gen_args(size):
+def gen_args(size, random_shape_prob=1.0):
     g = Namespace(size=[size] * 3, photo_prob=0.2, max_rotation=15, max_shear=0.2, max_scaling=0.2, nonlin_scale_min=0.03,
                   nonlin_scale_max=0.06, nonlin_std_max=4, bf_scale_min=0.02, bf_scale_max=0.04, bf_std_min=0.1,
                   bf_std_max=0.6, gamma_std=0.1, noise_std_min=0.05, noise_std_max=1., random_shift=False,
                   nonlinear_transform=True, left_hemis_only=False, low_res_only=False, ct_prob=0, flip_prob=0.,
-                  pathology_prob=1.0, random_shape_prob=1.0, augment_pathology=True, bspline_zooming=False,
+                  pathology_prob=1.0, random_shape_prob=random_shape_prob, augment_pathology=True, bspline_zooming=False,
                   mild_samples=2, all_samples=4)
     shp = Namespace(perlin_res=[2, 2, 2], integ_method="dopri5", bc="neumann", V_multiplier=500, dt=0.1, max_nt=10,
                     pathol_thres=0.2, pathol_tol=1e-5, mask_percentile_min=85., mask_percentile_max=99.)

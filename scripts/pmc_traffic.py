@@ -21,8 +21,10 @@ def last_step(path, counter):
 
 def family(name):
     """bench.py's kernel names (CONV_KERNELS); longest match first."""
-    if "conv_wino4_masked" in name:            # bench.py counts a masked launch as conv_wino_masked whichever variant ran
-        return "conv_wino_masked"
+    if "conv_wino4_masked" in name or "conv_wino4d_masked" in name:   # bench.py counts a masked launch as conv_wino_masked
+        return "conv_wino_masked"                                      # whichever variant ran
+    if "conv_wino4d_uniform" in name:          # ... and a uniform-box pair as conv_wino_uniform (F(2,3) or F(4,3))
+        return "conv_wino_uniform"
     for k in ("conv_upfold", "conv_wino_masked", "conv_wino_uniform", "conv_wino4", "conv_wino", "conv_mfma16", "conv_mfma_ws", "conv_mfma",
               "conv_stem", "tail_kernel"):
         if k in name:
@@ -39,7 +41,7 @@ for rows, key, mult in ((fetch, "fetch_bytes", 2.0), (write, "write_bytes", 1.0)
     for r in rows:
         # conv_wino_rest + conv_wino_uniform are the two halves of ONE bfm_conv3x3x3_wino_uniform launch (disjoint boxes):
         # bench.py counts the pair once, as conv_wino_uniform
-        rest = "conv_wino_rest" in r["Kernel_Name"]
+        rest = "conv_wino_rest" in r["Kernel_Name"] or "conv_wino4d_rest" in r["Kernel_Name"]
         fam = "conv_wino_uniform" if rest else family(r["Kernel_Name"])
         if fam is None:
             continue
