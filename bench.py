@@ -435,6 +435,111 @@ def synthesis_block(dev, items=8):
                     "kernel: profiles/r05_synth_hbm_traffic.json"}
 
 
+def config4_block(sess, dev, rank, world, use_dist, stride, win, n=512, steps=2):
+    """BASELINE config 4: a 512^3 volume (the bench volume's construction, scaled), the reference tiling's 216 tiles sharded
+    over the ranks, compact rows gathered to rank 0 and stitched there; timed like `value` (K volumes back to back between
+    barrier + synchronize brackets, max over ranks).  Collective: every rank calls it."""
+    import torch.distributed as dist
+    from brainfm_amd import test_utils as TU
+    full = make_volume(n, dev) if rank == 0 else None
+    if world > 1:
+        full = TU.broadcast_volume(full, dev, shape=(n, n, n))
+    xs = {}
+
+    def step():
+        if use_dist:
+            xs.clear()
+            return TU.tiled_inference_distributed(full if rank == 0 else None, sess, stride, win, shape=(n, n, n), stats=xs,
+                                                  broadcast=True)
+        return TU.tiled_inference(full, sess, stride, win, batched=True)
+
+    if sess.use_graphs:
+        TU.prepare_tile_graphs(full, sess, stride, win, world=world, rank=rank)
+    step()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        acc = step()[0]
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t.item()) / steps * 1e3
+    exposed = None
+    if use_dist and rank == 0 and "ev_own_done" in xs:
+        exposed = max(0.0, xs["ev_own_done"].elapsed_time(xs["ev_gathers_done"]))
+    nt = len(TU.tiling_ranges((n, n, n), stride, win))
+    del acc, full
+    torch.cuda.empty_cache()
+    return {"workload": "%d^3 volume, reference tiling -> %d tiles over %d rank(s), 17 stitched keys" % (n, nt, world),
+            "ms_per_volume": ms, "value": n ** 3 / ms * 1e3, "unit": "voxels/s", "steps": steps, "scaling": "strong",
+            "exchange": None if not use_dist else {"bytes_sent_per_peer": xs.get("bytes_sent_per_peer"), "rounds": xs.get("rounds"),
+                                                  "broadcast_bytes": xs.get("broadcast_bytes"), "exchange_exposed_ms": exposed}}
+
+
+def config5_block(dev, rank, world, use_dist, size=160, items=2):
+    """BASELINE config 5: per rank one generator item (192^3 Voronoi label case -> 4 augmented 160^3 samples, pathology on)
+    feeding ONE training iteration of the full-width net, gradients averaged by one flat all-reduce (DDP, weak scaling,
+    batch = N items).  Collective: every rank calls it (scripts/bench_config5.py is the stand-alone form)."""
+    import numpy as np
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import config5_lib as C5
+    st_np, st_t = np.random.get_state(), torch.random.get_rng_state()
+    ds, step, ga = C5.build(dev, size, rank)
+
+    def one():
+        t0 = time.perf_counter()
+        _, _, _, target, samples = ds[0]
+        tg, sm = C5.collate(target, samples)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        _, total, ok = step.step([s["input"] for s in sm], tg, sm)
+        torch.cuda.synchronize()
+        return t1 - t0, time.perf_counter() - t1, total, ok
+
+    one()                                                       # warm-up: conv variants, optimiser state, packed weights
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_all = time.perf_counter()
+    tg = tt = ar = 0.0
+    for _ in range(items):
+        a, b, total, ok = one()
+        tg += a
+        tt += b
+        ev = step.__dict__.get("allreduce_events") or []
+        if len(ev) == 3:
+            ar += ev[0].elapsed_time(ev[1])
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t = torch.tensor([time.perf_counter() - t_all], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t_all = float(t.item())
+    ns = ga.generator.all_samples
+    ev = step.__dict__.get("allreduce_events") or []
+    out = {"workload": "per rank: 192^3 label case -> generator (pathology on) -> %d augmented %d^3 samples -> one training "
+                       "iteration of the 64 x 6 net (10 losses), flat gradient all-reduce over %d rank(s)" % (ns, size, world),
+           "items_per_s_per_gpu": items / t_all, "items_per_s": world * items / t_all,
+           "generated_and_trained_mvoxel_per_s": world * items * ns * size ** 3 / t_all / 1e6,
+           "generator_ms_per_item": tg / items * 1e3, "iteration_ms_per_item": tt / items * 1e3,
+           "allreduce_ms_per_iteration": (ar / items) if world > 1 and len(ev) == 3 else None,
+           "allreduce_bytes": ev[2] if len(ev) == 3 else None,
+           "allreduce_note": "one flat all-reduce after the backward pass, not overlapped: what it takes is what it exposes",
+           "last_loss": float(total), "stepped": bool(ok), "scaling": "weak", "items_timed": items}
+    del ds, step
+    np.random.set_state(st_np)
+    torch.random.set_rng_state(st_t)
+    torch.cuda.empty_cache()
+    return out
+
+
 def training_block(dev, size=128, reps=2):
     """SURVEY N2 on the bench line: one training iteration of the full-width net (f_maps 64, 6 levels, the demo head set,
     16 losses) on one size^3 sample of synthetic data -- forward, losses, backward, per-parameter clip, AdamW, re-packed
@@ -557,6 +662,8 @@ def main():
     ap.add_argument("--no-synthesis", action="store_true", help="skip the synthesis block (hot path B) of the line")
     ap.add_argument("--no-training", action="store_true", help="skip the training block (SURVEY N2) of the line")
     ap.add_argument("--no-fast-mode", action="store_true", help="skip the passes=1 block (BASELINE config 2's class) of the line")
+    ap.add_argument("--no-config4", action="store_true", help="skip the 512^3 block (BASELINE config 4) of the line")
+    ap.add_argument("--no-config5", action="store_true", help="skip the generator + training-iteration block (BASELINE config 5)")
     ap.add_argument("--roofline-reps", type=int, default=3,
                     help="back-to-back launches per HIP-event bracket in the instrumented conv pass")
     args = ap.parse_args()
@@ -788,6 +895,16 @@ def main():
                   "algorithmic_bytes_per_step": sum(e[2] for e in per.values())}
         return kernels, groups, family, mine
 
+    # BASELINE configs 4 and 5 on the same line, every rank taking part: a 512^3 volume through the same
+    # tile flow (216 tiles sharded over the ranks, compact rows gathered to rank 0), and the generator feeding one training
+    # iteration per rank with the flat gradient all-reduce.  Both are deterministic in what they launch and collective in
+    # the same places on every rank; neither is `value`.
+    config4 = config5 = None
+    if not args.no_config4 and n == 256:
+        config4 = config4_block(sess, dev, rank, world, use_dist, stride, win)
+    if not args.no_config5:
+        config5 = config5_block(dev, rank, world, use_dist)
+
     kernels, groups, family, mine = {}, {}, {}, {}
     dense_family = None
     if args.roofline_reps > 0:                      # 0: skip (used for rocprofv3 runs that should hold the timed steps only)
@@ -943,6 +1060,8 @@ def main():
                 line["training"] = training_block(dev)
             except Exception as e:                            # noqa: BLE001
                 line["training"] = {"error": repr(e)}
+        line["config4"] = config4
+        line["config5"] = config5
         line["fast_mode"] = None
         fast_sess = None
         if not args.no_fast_mode and world == 1 and args.passes == 3:

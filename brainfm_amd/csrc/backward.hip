@@ -1397,6 +1397,14 @@ WgPlan wgrad_plan(int CA, int Cin, int Cout, int D, int H, int W, bool f16 = fal
 }  // namespace
 
 namespace {
+// conv_wgrad_ws_kernel needs 130 KB of dynamic LDS and 768 threads: asked for once per process; where the device refuses
+// (a 64 KB-LDS part), the callers keep the 8-wave conv_wgrad_f16_kernel plan instead of failing the step
+bool wgrad_ws_available() {
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_ws_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, WGS_LDS) == hipSuccess;
+    return ok;
+}
+
 // skip / plain channels [0, CA) of a layer through conv_wgrad_ws_kernel + the fold of its partials into dW [Cout][Cin][27]
 int launch_wgrad_ws(const float* dP, int Cout, const float* A, int CA, int Cin, int D, int H, int W, const float* scale,
                     const float* shift, const float* dp_bound, const float* x_bound, int G, float* part, float* dW,
@@ -1412,13 +1420,6 @@ int launch_wgrad_ws(const float* dP, int Cout, const float* A, int CA, int Cin, 
     if (S < 1) S = 1;
     const int per = bfm_cdiv(w.ntiles, S);
     S = bfm_cdiv(w.ntiles, per);
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                WGS_LDS) != hipSuccess)
-            return BFM_E_LAUNCH;
-        attr = true;
-    }
     hipLaunchKernelGGL(conv_wgrad_ws_kernel, dim3(S, CA / 32, Cout / 32), dim3(WGS_THREADS), WGS_LDS, st, w);
     hipLaunchKernelGGL(wgrad_reduce_cols_kernel, dim3(grid_for((int64_t)Cout * CA * 27)), dim3(256), 0, st, part, S, Cout, CA,
                        Cin, dW);
@@ -1469,7 +1470,7 @@ extern "C" int bfm_conv3x3x3_wgrad_ex(const float* dP, int Cout, const float* A,
     const bool f16 = passes == 3 && Cout % 64 == 0 && Cin % 32 == 0 && CA % 32 == 0;
     // upsampled channels of an exact 2x decoder join: folded form on the low-res tensor, the skip channels alone below
     static const bool upfold_on = []() { const char* e = getenv("BFM_WGRAD_UPFOLD"); return !(e && e[0] == '0'); }();
-    static const bool ws_on = []() { const char* e = getenv("BFM_WGRAD_WS"); return !(e && e[0] == '0'); }();
+    static const bool ws_on = []() { const char* e = getenv("BFM_WGRAD_WS"); return !(e && e[0] == '0'); }() && wgrad_ws_available();
     if (f16 && ws_on && CB == 0) {                         // plain layer: the wave-specialised kernel on all channels
         if (wgrad_ws_part_bytes(Cout, CA, D, H, W) > workspace_bytes) return BFM_E_WORKSPACE;
         const int rc = launch_wgrad_ws(dP, Cout, A, CA, Cin, D, H, W, scale, shift, dp_bound, x_bound, G, p.part, dW, st);

@@ -337,11 +337,11 @@ __global__ void __launch_bounds__(TPB) rows_group_finalize(RowsSrc sa, RowsSrc s
     __syncthreads();
     if (t == 0) {
         // release: the workgroup's partials (written through and acknowledged above) are ordered before the ticket in the
-        // memory model too, not only by the vmcnt wait; the counter is taken modulo KS so that a ticket left non-zero by
-        // an aborted launch cannot mark the wrong arriver as the last one for ever (it costs that one launch at most,
-        // and the host entry point zeroes the tickets when a launch fails)
+        // memory model too, not only by the vmcnt wait.  The counter must be 0 when a launch starts: every completed launch
+        // leaves it there (the last arriver resets it), and the host entry point zeroes the tickets when a launch fails --
+        // the kernel itself cannot heal a stale count (round 4's modulo did not: ADVICE r4), so that memset is the guard
         const int got = __hip_atomic_fetch_add(tickets + g, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (got % KS) == KS - 1;
+        is_last = got == KS - 1;
         if (is_last) __hip_atomic_store(tickets + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all KS have arrived
     }
     __syncthreads();

@@ -1179,11 +1179,26 @@ static int head_bwd_launch(const float* dRaw, int64_t row_stride, const float* F
     if (workspace_bytes < bfm_head_bwd_workspace(n_out, C, nvox)) return BFM_E_WORKSPACE;
     if ((size_t)n_out * C * sizeof(float) > 64 * 1024) return BFM_E_SHAPE;
     hipStream_t st = bfm_s(stream);
-    const bool fused = C == HB_C && n_out <= HB_MAXO && (reinterpret_cast<uintptr_t>(Fn) & 15) == 0;
+    bool fused = C == HB_C && n_out <= HB_MAXO && (reinterpret_cast<uintptr_t>(Fn) & 15) == 0;
+    const int ldr = (n_out + 2) | 1, K2 = (n_out + 1) & ~1;
+    const size_t smem = ((size_t)HB_TV * ldr + (size_t)HB_TV * HB_C + (size_t)K2 * HB_C) * sizeof(float);
+    if (fused && smem > 64 * 1024) {
+        // more than 64 KB of dynamic LDS (n_out 95, 96): allowed on this part once the attribute is set; where the device
+        // has less, the three-pass kernels below take over -- except in the rows layout, which only this
+        // kernel reads
+        static int big_ok = -1;                                   // -1 unknown, 0 refused, 1 set
+        if (big_ok < 0) {
+            int dev = 0, lim = 0;
+            big_ok = hipGetDevice(&dev) == hipSuccess &&
+                     hipDeviceGetAttribute(&lim, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess &&
+                     (size_t)lim >= ((size_t)HB_TV * (HB_MAXO + 3) + (size_t)HB_TV * HB_C + (size_t)HB_MAXO * HB_C) * sizeof(float) &&
+                     hipFuncSetAttribute(reinterpret_cast<const void*>(&head_bwd_fused_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lim) == hipSuccess;
+        }
+        if (!big_ok) fused = false;
+    }
     if (row_stride > 0 && !fused) return BFM_E_SHAPE;             // the rows layout exists for the one-pass kernel only
     if (fused) {
-        const int ldr = (n_out + 2) | 1, K2 = (n_out + 1) & ~1;
-        const size_t smem = ((size_t)HB_TV * ldr + (size_t)HB_TV * HB_C + (size_t)K2 * HB_C) * sizeof(float);
         const int64_t ntile = (nvox + HB_TV - 1) / HB_TV;
         const int nb = (int)std::min<int64_t>(HB_BLOCKS, ntile);
         float* wpart = static_cast<float*>(workspace);

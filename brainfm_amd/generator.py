@@ -51,14 +51,34 @@ class DeviceVolumes:
     host (Generator/utils.py:296-305: nib.load -> get_fdata()[box] -> torch.tensor -> device); a case is ~10 volumes of
     ~30 MB, so a few hundred cases fit in a fraction of the 288 GB and an item never touches the host copy again: the
     crop becomes a box inside the resident volume.  Least-recently-used volumes are dropped beyond `budget` bytes
-    (BFM_GEN_CACHE_GB, default 64).  A volume is keyed by the identity of its source object: a case array that is
-    modified in place afterwards keeps its resident copy (call `forget(vol)` or build a new dataset)."""
+    (BFM_GEN_CACHE_GB, default 64).  A volume is keyed by the identity of its source object AND a cheap content stamp
+    (shape, dtype, data address and the sum of ~256 strided samples, taken at every request: a few microseconds): an array
+    re-filled in place -- re-used buffers, on-the-fly pre-processing -- gets a fresh resident copy instead of silently
+    serving the old one (`forget(vol)` / `invalidate()` drop copies explicitly).  mean 0 / scale 1 'prep' copies
+    of a volume without NaNs are the 'f32' copy itself."""
 
     def __init__(self, device, budget=None):
         self.device = device
         self.budget = int(float(os.environ.get("BFM_GEN_CACHE_GB", "64")) * 2 ** 30) if budget is None else budget
-        self.items = OrderedDict()                        # (id(source), kind) -> (tensor, source kept alive)
+        self.items = OrderedDict()                        # (id(source), kind, ...) -> (tensor, source kept alive, stamp)
         self.bytes = 0
+
+    @staticmethod
+    def _stamp(src):
+        """What changes when an in-memory source is re-filled: sampled content, not only identity (file-backed sources:
+        their array proxy's identity and shape)."""
+        arr = src if isinstance(src, np.ndarray) else getattr(src, "_d", None)
+        if not isinstance(arr, np.ndarray) or arr.size == 0:
+            return (getattr(src, "shape", None),)
+        tot = 0.0
+        if arr.flags.c_contiguous and arr.dtype.kind in "fiub":
+            flat = arr.reshape(-1)
+            tot = float(np.nansum(flat[::max(1, flat.size // 256)].astype(np.float64)))
+        return (arr.shape, arr.dtype.str, arr.ctypes.data, tot)
+
+    def invalidate(self):
+        """Drop every resident copy (the sources changed in a way the sampled stamp may not see)."""
+        self.forget(None)
 
     @staticmethod
     def _host_array(src):
@@ -80,8 +100,9 @@ class DeviceVolumes:
         """Drop the resident copies of one source (or of all of them)."""
         src = None if vol is None else (vol._d if isinstance(vol, ArrayVolume) else vol)
         for key in [k for k in self.items if src is None or k[0] == id(src)]:
-            t, _ = self.items.pop(key)
-            self.bytes -= t.numel() * 4
+            t = self.items.pop(key)[0]
+            if not any(v[0] is t for v in self.items.values()):      # an aliased 'prep' / 'f32' pair is counted once
+                self.bytes -= t.numel() * 4
 
     def get(self, vol, kind="f32", mean=0., scale=1.):
         """The whole volume as float32 (`kind` 'f32': what torch.tensor(get_fdata().astype(float), dtype=torch.float)
@@ -90,10 +111,18 @@ class DeviceVolumes:
         to the resident volume once gives every later crop the values the reference computes per item)."""
         src = vol._d if isinstance(vol, ArrayVolume) else vol
         key = (id(src), kind, float(mean), float(scale))
+        stamp = self._stamp(src)
         hit = self.items.get(key)
         if hit is not None:
-            self.items.move_to_end(key)
-            return hit[0]
+            if hit[2] == stamp:
+                self.items.move_to_end(key)
+                return hit[0]
+            self.forget(src)                                        # re-filled in place since it was uploaded
+        if kind == "prep" and mean == 0. and scale == 1.:           # identity transform: share the 'f32' copy when it has
+            base = self.get(vol, "f32")                             # no NaN to scrub (one resident copy instead of two)
+            if bool(torch.isfinite(base).all().item()):             # nan_to_num would change nothing
+                self.items[key] = (base, src, stamp)
+                return base
         arr = self._host_array(src)
         if kind in ("f32", "prep"):
             host = np.ascontiguousarray(arr, dtype=np.float32)
@@ -108,9 +137,10 @@ class DeviceVolumes:
                     t = GU.ew_unary(L.EW_SUB_DIV, t, float(mean), float(scale))
         nbytes = t.numel() * 4
         while self.items and self.bytes + nbytes > self.budget:
-            _, (old, _) = self.items.popitem(last=False)
-            self.bytes -= old.numel() * 4
-        self.items[key] = (t, src)
+            old = self.items.popitem(last=False)[1][0]
+            if not any(v[0] is old for v in self.items.values()):
+                self.bytes -= old.numel() * 4
+        self.items[key] = (t, src, stamp)
         self.bytes += nbytes
         return t
 

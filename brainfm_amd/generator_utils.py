@@ -41,10 +41,35 @@ class DeviceDraws:
     across devices is not a goal).  Tests replace ``generator_utils.draws`` with ReplayDraws to feed the reference's own
     recorded draws through the chain (tests/golden/make_golden_gen.py)."""
 
+    _last_state = None
+    _same_state_calls = 0
+
+    def _key(self):
+        """63-bit Philox key of the next field: a hash of torch's default CPU generator STATE plus the number of fields
+        drawn since that state last changed.  Nothing is drawn from the host stream (round 4 took a randint per field,
+        which shifted every later torch.rand / np-independent host draw relative to the reference's order: ADVICE r4);
+        torch.manual_seed(s) restarts the fields with the host stream, and two runs from the same seed draw the same
+        fields.  (One corner cannot be seen from the state: re-seeding to the state the generator is already in -- the same
+        seed again with no host draw since -- continues the count; reseed() restarts it explicitly.)  Device generators
+        (torch.cuda.manual_seed) play no part."""
+        import hashlib
+        st = torch.random.get_rng_state()
+        h = int.from_bytes(hashlib.blake2b(st.numpy().tobytes(), digest_size=8).digest(), "little")
+        if h == DeviceDraws._last_state:
+            DeviceDraws._same_state_calls += 1
+        else:
+            DeviceDraws._last_state, DeviceDraws._same_state_calls = h, 0
+        return (h + DeviceDraws._same_state_calls * 0x9E3779B97F4A7C15) & (2 ** 63 - 1)
+
+    @staticmethod
+    def reseed():
+        """Restart the count of fields drawn at the current host-generator state (see _key)."""
+        DeviceDraws._last_state, DeviceDraws._same_state_calls = None, 0
+
     def randn(self, shape, device):
-        """N(0,1) field from bfm_randn_philox.  Each call takes its 63-bit Philox key from torch's default CPU generator,
-        so torch.manual_seed makes a run repeatable and re-seeding restarts the stream, as with torch.randn."""
-        key = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        """N(0,1) field from bfm_randn_philox (Philox4x32-10 + Box-Muller on 24-bit uniforms: |x| <= 5.9 sigma), keyed by
+        _key(): repeatable under torch.manual_seed, no host draw consumed."""
+        key = self._key()
         out = torch.empty(list(shape), dtype=torch.float, device=device)
         if out.numel():
             L.check(L.load().bfm_randn_philox(L.ptr(out), out.numel(), C.c_uint64(key), C.c_uint64(0), 1.0,

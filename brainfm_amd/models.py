@@ -602,12 +602,20 @@ def _restricted_pickle_module():
                ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
                ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer")}
 
+    # the tensor re-builders by name (torch's own weights_only allow-list, torch/_weights_only_unpickler.py), not "anything
+    # that starts with _rebuild_" (ADVICE r4): a re-builder missing here turns its tensor into an InertObject, which
+    # read_checkpoint_file then reports instead of letting it surface later as a confusing missing-key error
+    rebuilders = {"_rebuild_tensor", "_rebuild_tensor_v2", "_rebuild_parameter", "_rebuild_parameter_with_state",
+                  "_rebuild_qtensor", "_rebuild_sparse_tensor", "_rebuild_nested_tensor", "_rebuild_wrapper_subclass",
+                  "_rebuild_device_tensor_from_numpy", "_rebuild_meta_tensor_no_storage"}
+
     class Unpickler(pickle.Unpickler):
         def find_class(self, module, name):
             if module == "builtins":
                 return getattr(builtins, name) if name in safe_builtins else InertObject
             ok = (module, name) in allowed \
-                or (module == "torch._utils" and name.startswith("_rebuild_")) \
+                or (module == "torch._utils" and name in rebuilders and hasattr(torch._utils, name)) \
+                or (module, name) == ("torch._tensor", "_rebuild_from_type_v2") \
                 or (module in ("torch", "torch.storage") and name.endswith("Storage")) \
                 or (module == "torch" and isinstance(getattr(torch, name, None), torch.dtype))
             if ok:
@@ -638,7 +646,39 @@ def read_checkpoint_file(path):
         with torch.serialization.safe_globals([argparse.Namespace]):
             return torch.load(path, map_location="cpu", weights_only=True)
     except pickle.UnpicklingError:
-        return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_restricted_pickle_module())
+        import warnings
+        warnings.warn("%s holds more than tensors and plain containers: read with the restricted unpickler (classes this package "
+                      "does not know become inert dicts, none of the file's code runs; BFM_TRUST_CHECKPOINT=1 for a full unpickle)"
+                      % (path,), stacklevel=2)
+        ckp = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_restricted_pickle_module())
+        _refuse_inert_tensors(ckp, path)
+        return ckp
+
+
+def _refuse_inert_tensors(ckp, path):
+    """After a restricted read: an InertObject where a tensor belongs (under 'model', or in the optimiser's per-parameter
+    state) means a tensor re-builder the allow-list lacks -- say so here rather than as a missing key or a shape error later."""
+    def bad(obj, where, depth=0):
+        if isinstance(obj, InertObject):
+            raise BfmCheckpointError("%s: %s was pickled through a class the restricted unpickler does not rebuild; load with "
+                                     "BFM_TRUST_CHECKPOINT=1 if you trust the file" % (path, where))
+        if depth < 4 and isinstance(obj, dict):
+            for k, v in obj.items():
+                bad(v, "%s[%r]" % (where, k), depth + 1)
+        elif depth < 4 and isinstance(obj, (list, tuple)):
+            for i, v in enumerate(obj):
+                bad(v, "%s[%d]" % (where, i), depth + 1)
+    if isinstance(ckp, dict) and not isinstance(ckp, InertObject):
+        for key in ("model", "state_dict"):
+            if key in ckp:
+                bad(ckp[key], key)
+        opt = ckp.get("optimizer")
+        if isinstance(opt, dict) and not isinstance(opt, InertObject) and "state" in opt:
+            bad(opt["state"], "optimizer['state']")
+
+
+class BfmCheckpointError(RuntimeError):
+    pass
 
 
 def load_state_dict_by_suffix(model, loaded):

@@ -81,15 +81,24 @@ def multistep_scheduler(base_value, lr_drops, epochs, niter_per_ep, warmup_epoch
     return np.concatenate((warm, sched))
 
 
-def allreduce_mean_(grads, group=None):
+def allreduce_mean_(grads, group=None, events=None):
     """DDP's gradient averaging (scripts/train.py:153-158) as ONE flat all-reduce over all parameters: xGMI rings are
-    per-link bound, so a single ~100 MB bucket beats many small ones.  In place; no-op without a process group."""
+    per-link bound, so a single ~100 MB bucket beats many small ones.  In place; no-op without a process group.
+    events: a list that receives (start, end) device events around the collective (it is not overlapped with anything: what
+    it takes is what it exposes; bench.py's config 5 block reports it)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return grads
     keys = list(grads.keys())
     flat = torch.cat([grads[k].reshape(-1) for k in keys])
+    if events is not None and flat.is_cuda:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if events is not None and flat.is_cuda:
+        e1.record()
+        del events[:]
+        events.extend([e0, e1, flat.numel() * flat.element_size()])
     flat /= dist.get_world_size(group)
     off = 0
     for k in keys:
@@ -638,7 +647,7 @@ class TrainStep:
             touched = {task for j, task in enumerate(tasks) if t[2 * nk + j] > 0}     # find_unused_parameters=True
         if not math.isfinite(total):
             return loss_dict, total, False                     # engine.py:129-136: non-finite loss -> skip the iteration
-        allreduce_mean_(grads, group)
+        allreduce_mean_(grads, group, self.__dict__.setdefault("allreduce_events", []))
         for task in self.tail.row_of:                          # heads nobody's loss reached: no gradient, no step
             if task not in touched:
                 grads.pop("head.final_conv_%s.weight" % task, None)

@@ -2,7 +2,7 @@
 # usage (GPU box): bash scripts/bench_quick.sh [out.json] [extra bench args...]
 cd ${GRAFT_REPO_ROOT:-.}
 out=${1:-gpurun_out/bench_quick.json}; shift || true
-timeout -k 10 900 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $out 2> ${out%.json}.err || { tail -5 ${out%.json}.err; exit 1; }
+timeout -k 10 900 python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-fast-mode --no-config4 --no-config5 "$@" > $out 2> ${out%.json}.err || { tail -5 ${out%.json}.err; exit 1; }
 python3 - <<PY
 import json
 d = json.loads(open("$out").read().strip().splitlines()[-1])

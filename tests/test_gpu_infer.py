@@ -1454,7 +1454,7 @@ def test_bench_line_fields_two_ranks_dry_run():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, BFM_BENCH_SHARE_GPU="1", BFM_BENCH_BACKEND="gloo")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--size", "200", "--no-dense-check", "--no-cpu-baseline"], capture_output=True, text=True,
+                        "--size", "200", "--no-dense-check", "--no-cpu-baseline", "--no-config5"], capture_output=True, text=True,
                        timeout=900, env=env, cwd=root)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
     assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-800:], r.stderr[-3000:])
@@ -1469,6 +1469,29 @@ def test_bench_line_fields_two_ranks_dry_run():
     assert set(rf["per_kernel"]) >= {"conv_wino", "conv_upfold"} and len(rf["conv_family"]["kernel_ms_per_rank"]) == 2
     assert rf["conv_family"]["kernel_ms_per_step"] == max(rf["conv_family"]["kernel_ms_per_rank"])
     assert "reference_equivalent_frac" not in rf["conv_family"]
+
+
+def test_bench_configs_4_and_5_two_ranks_dry_run():
+    """The config 4 (512^3 volume, 216 tiles over the ranks) and config 5 (generator -> one DDP training iteration per rank,
+    flat gradient all-reduce) blocks of `python bench.py --gpus 2`, as a dry run on this one GPU (gloo ranks sharing cuda:0;
+    timings meaningless): both are collective calls every rank makes, the line carries their fields."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BFM_BENCH_SHARE_GPU="1", BFM_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-dense-check", "--no-cpu-baseline", "--roofline-reps", "0"], capture_output=True, text=True,
+                       timeout=1500, env=env, cwd=root)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-800:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    c4, c5 = d["config4"], d["config5"]
+    assert d["n_gpus"] == 2 and c4["ms_per_volume"] > 0 and c4["value"] > 0 and "216 tiles over 2 rank(s)" in c4["workload"]
+    assert c4["exchange"]["broadcast_bytes"] == 4 * 512 ** 3 and c4["exchange"]["bytes_sent_per_peer"] > 0
+    assert c5["items_per_s"] > 0 and c5["scaling"] == "weak" and c5["stepped"] and np.isfinite(c5["last_loss"])
+    assert c5["allreduce_ms_per_iteration"] is not None and c5["allreduce_bytes"] > 4 * 2.6e8      # 264 M fp32 gradients
 
 
 def test_crop3d_is_the_tile_window():

@@ -48,9 +48,19 @@ def test_randn_philox_is_a_repeatable_standard_normal_stream():
     d = GU.DeviceDraws()
     torch.manual_seed(5)
     x1, x2 = N(d.randn((4, 5, 6), DEV)), N(d.randn((4, 5, 6), DEV))
+    torch.rand(2)                                                        # the host stream moves on, as inside an item
+    x3 = N(d.randn((4, 5, 6), DEV))
     torch.manual_seed(5)
-    y1 = N(d.randn((4, 5, 6), DEV))
-    assert np.array_equal(x1, y1) and not np.array_equal(x1, x2)
+    y1, y2 = N(d.randn((4, 5, 6), DEV)), N(d.randn((4, 5, 6), DEV))
+    assert np.array_equal(x1, y1) and np.array_equal(x2, y2) and not np.array_equal(x1, x2) and not np.array_equal(x1, x3)
+    d.reseed()                                                           # same state, count restarted by hand
+    assert np.array_equal(N(d.randn((4, 5, 6), DEV)), x1)
+    # ... and consume nothing from the host stream: the host draws that follow are those of a run without fields
+    torch.manual_seed(9)
+    h0 = torch.rand(3)
+    torch.manual_seed(9)
+    d.randn((2, 2, 2), DEV)
+    assert torch.equal(torch.rand(3), h0)
 
 
 @pytest.mark.parametrize("photo", [False, True])
@@ -337,7 +347,9 @@ def test_generator_item_is_repeatable_and_its_volumes_stay_resident():
         for k in a:
             assert torch.equal(a[k], b[k]), k
     n_resident, nbytes = len(ds1.volumes.items), ds1.volumes.bytes
-    assert n_resident == 10 and nbytes == 10 * int(np.prod(shp)) * 4      # Gen, T1, seg, 4 distance, 3 registration
+    n_tensors = len({v[0].data_ptr() for v in ds1.volumes.items.values()})
+    # Gen, T1, seg, 4 distance, 3 registration: ten resident tensors (an identity 'prep' request aliases the 'f32' copy)
+    assert n_tensors == 10 and nbytes == 10 * int(np.prod(shp)) * 4, (n_resident, n_tensors, nbytes)
     ds1[0]
     assert len(ds1.volumes.items) == n_resident and ds1.volumes.bytes == nbytes
     small = G.DeviceVolumes(torch.device(DEV), budget=3 * int(np.prod(shp)) * 4)
@@ -347,6 +359,17 @@ def test_generator_item_is_repeatable_and_its_volumes_stay_resident():
     small.forget(G.ArrayVolume(case["distance"][3]))
     assert len(small.items) == 2
     small.forget()
+    assert len(small.items) == 0 and small.bytes == 0
+    # an array re-filled in place is re-uploaded (content stamp), not served stale; an identity 'prep' copy of a
+    # finite volume is the 'f32' copy itself
+    src = rs.rand(*shp).astype(np.float32)
+    vol = G.ArrayVolume(src)
+    a = small.get(vol, "f32").clone()
+    assert small.get(vol, "prep") is small.get(vol, "f32") and small.bytes == int(np.prod(shp)) * 4
+    src[...] = rs.rand(*shp).astype(np.float32)
+    b = small.get(vol, "f32")
+    assert not torch.equal(a, b) and np.array_equal(b.cpu().numpy(), src)
+    small.invalidate()
     assert len(small.items) == 0 and small.bytes == 0
 
 

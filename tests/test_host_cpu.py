@@ -526,3 +526,19 @@ torch.save({"model": {"module.backbone.w": w, "head.b": torch.ones(2)}, "optimiz
     plain = str(tmp_path / "plain.pth")
     torch.save({"model": {"w": torch.zeros(2)}}, plain)
     assert torch.equal(M.read_checkpoint_file(plain)["model"]["w"], torch.zeros(2))
+    # a weight pickled through a class the restricted reader does not rebuild must be REPORTED, not handed on as
+    # an empty dict that fails later as a missing key; and the restricted path says that it was taken
+    odd = str(tmp_path / "odd.pth")
+    writer2 = '''
+import sys, types, torch
+m = types.ModuleType("theirs"); sys.modules["theirs"] = m
+class Wrapped:
+    def __init__(self, t): self.t = t
+Wrapped.__module__ = "theirs"; m.Wrapped = Wrapped
+torch.save({"model": {"w": Wrapped(torch.ones(3))}, "epoch": 1}, %r)
+''' % odd
+    subprocess.check_call([sys.executable, "-c", writer2])
+    import pytest
+    with pytest.warns(UserWarning, match="restricted unpickler"):
+        with pytest.raises(M.BfmCheckpointError, match="model\\['w'\\]"):
+            M.read_checkpoint_file(odd)
