@@ -21,8 +21,8 @@ def sections_of(path, counter):
 
 
 def short(name):
-    n = name.split("(")[0].replace("void ", "").strip()
-    return n[:60]
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0].strip()[:60] or name[:60]
 
 
 fetch = sections_of(sys.argv[1], "FETCH_SIZE")
