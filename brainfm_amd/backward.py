@@ -160,8 +160,9 @@ def backward_single_conv(eng, t, dY, need_input_grad=True):
 
         def _launch(c):
             eng._conv_launch(dg, dP, ly.cout, None, 0, t.dims, None, ones, zeros, bnd, 1, c, dXn, ws2, None, slope=1.0)
-        # F(4,3) is an inference choice: _autotune hands back a narrowed COPY (variant 3) when the table says 4
-        cfg = eng._autotune(dg, key, _launch, vers=(0, 1, 2) if key[3] else (0, 1, 2, 3))
+        # F(4,3) where the table says so (round 5; BFM_TRAIN_F43=0: _autotune hands back a narrowed COPY, variant 3)
+        from brainfm_amd.engine import TRAIN_F43
+        cfg = eng._autotune(dg, key, _launch, vers=(0, 1, 2) if key[3] else ((0, 1, 2, 3, 4) if TRAIN_F43 else (0, 1, 2, 3)))
         _launch(cfg)
         if dg.cout != ly.cin:
             dXn = dXn[..., :ly.cin].contiguous()

@@ -36,9 +36,12 @@ __device__ __forceinline__ uint32_t ld_tex(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// C == 1: the two z-neighbours of every corner pair come with ONE 8-byte load (sc1 through a buffer descriptor, whose
-// range check covers the read one past a clamped upper corner); same values, same arithmetic, half the L2 requests
+// C == 1.  MODE 2 ships: eight 4-byte agent-scope loads, the only form that never returned a wrong texel beside a kernel that
+// uses LDS-DMA (profiles/r05_atlas_hazard_bisect.txt: round 4's paired 8-byte loads -- MODE 0 through a buffer descriptor with
+// aux = sc1, MODE 1 sc0 sc1, MODE 3 a global 8-byte load at system scope -- all did beside conv_wino4d, although they bypass the
+// L1).  The other modes exist in -DBFM_DIAG builds only (BFM_INTERP_MODE = 10 / 1 / 3).
 typedef int v2i_t __attribute__((ext_vector_type(2)));
+template <int MODE>
 __global__ void interp_linear1(const float* __restrict__ X, int nx, int ny, int nz, uint32_t vol_bytes,
                                const float* __restrict__ II, const float* __restrict__ JJ,
                                const float* __restrict__ KK, int64_t n, float defv, float* __restrict__ out) {
@@ -56,9 +59,23 @@ __global__ void interp_linear1(const float* __restrict__ X, int nx, int ny, int 
         const int64_t sx = (int64_t)ny * nz, sy = nz;
         const bool zp = cz != fz;
         auto pair = [&](int a, int b, float& lo, float& hi) {
-            const v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(R, (uint32_t)((a * sx + b * sy + fz) << 2), 0, 16);
-            lo = __int_as_float(v.x);
-            hi = zp ? __int_as_float(v.y) : lo;
+            if constexpr (MODE == 0 || MODE == 1) {
+                const v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(R, (uint32_t)((a * sx + b * sy + fz) << 2), 0, MODE == 0 ? 16 : 17);
+                lo = __int_as_float(v.x);
+                hi = zp ? __int_as_float(v.y) : lo;
+            } else if constexpr (MODE == 2) {
+                const float* q = X + (a * sx + b * sy + fz);
+                lo = ld_tex(q);
+                hi = zp ? ld_tex(q + 1) : lo;
+            } else {
+                // one 8-byte global load at system scope (a volatile access: global_load_dwordx2 sc0 sc1), the pair moved one
+                // back where the upper corner is clamped so that nothing past the row is read
+                const float* q = X + (a * sx + b * sy + (zp ? fz : max(fz - 1, 0)));
+                typedef v2i_t __attribute__((aligned(4))) v2i_a4;
+                const v2i_t v = *(const volatile __attribute__((address_space(1))) v2i_a4*)q;
+                lo = zp ? __int_as_float(v.x) : (fz >= 1 ? __int_as_float(v.y) : __int_as_float(v.x));
+                hi = zp ? __int_as_float(v.y) : lo;
+            }
         };
         float t000, t001, t100, t101, t010, t011, t110, t111;
         pair(fx, fy, t000, t001); pair(cx, fy, t100, t101); pair(fx, cy, t010, t011); pair(cx, cy, t110, t111);
@@ -125,6 +142,9 @@ __device__ __forceinline__ float ld_l2(const float* p) {
 // scope, served past the non-coherent caches); 1 = ordinary global_load_dword, the form that misbehaved; 2 = ordinary loads
 // behind an agent-scope acquire at the start of the kernel (buffer_inv sc1: this CU's L1 invalidated); 3 = agent-scope
 // loads (sc1: past the L1, served by the XCD's L2)
+// round 5 bisection (diagnostics only): 4 = ordinary texel loads with the mask predicate dropped (every voxel sampled, the
+// mask applied to the result: no divergent, exec-masked gather); 5 = ordinary texel loads, the four coalesced ROW loads at
+// agent scope; 7 = ordinary loads everywhere with the row loads drained (s_waitcnt vmcnt(0)) before the first texel load
 template <bool NZ, int LOADS = 0>
 __global__ void deformed_atlas(const float* __restrict__ mask, const float* __restrict__ rx,
                                const float* __restrict__ ry, const float* __restrict__ rz, const float* X, int nx,
@@ -132,8 +152,17 @@ __global__ void deformed_atlas(const float* __restrict__ mask, const float* __re
     if (LOADS == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     GRID_STRIDE(i, n) {
         float r = 0.f;
-        if (NZ ? (mask[i] != 0.f) : (mask[i] > 0.f)) {
-            const float xx = 100.f * rx[i], yy = 100.f * ry[i], zz = 100.f * rz[i];
+        const float mk = LOADS == 5 ? __hip_atomic_load(mask + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mask[i];
+        const bool keep = NZ ? (mk != 0.f) : (mk > 0.f);
+        if (keep || LOADS == 4) {
+            float r0 = rx[i], r1 = ry[i], r2 = rz[i];
+            if (LOADS == 5) {
+                r0 = __hip_atomic_load(rx + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                r1 = __hip_atomic_load(ry + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                r2 = __hip_atomic_load(rz + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (LOADS == 7) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0), "+v"(r1), "+v"(r2));
+            const float xx = 100.f * r0, yy = 100.f * r1, zz = 100.f * r2;
             const float x = ((A.a[0] * xx + A.a[1] * yy) + A.a[2] * zz) + A.a[3];
             const float y = ((A.a[4] * xx + A.a[5] * yy) + A.a[6] * zz) + A.a[7];
             const float z = ((A.a[8] * xx + A.a[9] * yy) + A.a[10] * zz) + A.a[11];
@@ -147,7 +176,7 @@ __global__ void deformed_atlas(const float* __restrict__ mask, const float* __re
                 const float wfx = 1.f - wcx, wfy = 1.f - wcy, wfz = 1.f - wcz;
                 auto at = [&](int a, int b, int c) {
                     const float* q = X + (((int64_t)a * ny + b) * nz + c);
-                    if (LOADS == 1 || LOADS == 2) return *q;
+                    if (LOADS == 1 || LOADS == 2 || LOADS == 4 || LOADS == 5 || LOADS == 7) return *q;
                     if (LOADS == 3) return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     return ld_l2(q);
                 };
@@ -160,7 +189,7 @@ __global__ void deformed_atlas(const float* __restrict__ mask, const float* __re
                 r = c0 * wfz + c1 * wcz;
             }
         }
-        out[i] = r;
+        out[i] = (LOADS == 4 && !keep) ? 0.f : r;
     }
 }
 
@@ -503,7 +532,7 @@ __global__ void grid_pull3d(const float* __restrict__ inp, int Bi, int C, int nx
         const int b = (int)(i / nout);
         const int64_t v = i - (int64_t)b * nout;
         const float* g = grid + ((int64_t)(Bg == 1 ? 0 : b) * nout + v) * 3;
-        const float gx = g[0], gy = g[1], gz = g[2];
+        const float gx = ld_tex(g), gy = ld_tex(g + 1), gz = ld_tex(g + 2);   // 4-byte agent-scope loads
         float mask = 1.f;
         if (extrap == 0 || extrap == 2) {
             const float thr = extrap == 2 ? 0.5f + 5e-2f : 5e-2f;
@@ -556,7 +585,7 @@ __global__ void grid_push3d(const float* __restrict__ inp, int Bi, int C, const 
         const int b = (int)(i / nin);
         const int64_t v = i - (int64_t)b * nin;
         const float* g = grid + ((int64_t)(Bg == 1 ? 0 : b) * nin + v) * 3;
-        const float gx = g[0], gy = g[1], gz = g[2];
+        const float gx = ld_tex(g), gy = ld_tex(g + 1), gz = ld_tex(g + 2);   // 4-byte agent-scope loads
         float mask = 1.f;
         if (extrap == 0 || extrap == 2) {
             const float thr = extrap == 2 ? 0.5f + 5e-2f : 5e-2f;
@@ -602,7 +631,7 @@ __global__ void grid_grad3d(const float* __restrict__ inp, int Bi, int C, int nx
         const int b = (int)(i / nout);
         const int64_t v = i - (int64_t)b * nout;
         const float* g = grid + ((int64_t)(Bg == 1 ? 0 : b) * nout + v) * 3;
-        const float gx = g[0], gy = g[1], gz = g[2];
+        const float gx = ld_tex(g), gy = ld_tex(g + 1), gz = ld_tex(g + 2);   // 4-byte agent-scope loads
         float mask = 1.f;
         if (extrap == 0 || extrap == 2) {
             const float thr = extrap == 2 ? 0.5f + 5e-2f : 5e-2f;
@@ -761,9 +790,16 @@ extern "C" int bfm_interp3d_linear(const float* X, int nx, int ny, int nz, int C
                                    const float* KK, int64_t n, float default_value, float* out, bfm_stream_t stream) {
     if (!X || !II || !JJ || !KK || !out || nx <= 0 || ny <= 0 || nz <= 0 || C <= 0 || n <= 0) return BFM_E_ARG;
     const int64_t vbytes = (int64_t)nx * ny * nz * 4;
-    if (C == 1 && vbytes < ((int64_t)1 << 32))
-        hipLaunchKernelGGL(interp_linear1, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), X, nx, ny, nz, (uint32_t)vbytes,
-                           II, JJ, KK, n, default_value, out);
+    if (C == 1 && vbytes < ((int64_t)1 << 32)) {
+        int mode = 0;
+#ifdef BFM_DIAG
+        if (const char* e = getenv("BFM_INTERP_MODE")) mode = atoi(e);          // diagnostics: the candidate load forms
+#endif
+#define BFM_IL1(M) hipLaunchKernelGGL(interp_linear1<M>, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), X, nx, ny, nz, (uint32_t)vbytes, \
+                                      II, JJ, KK, n, default_value, out)
+        if (mode == 1) BFM_IL1(1); else if (mode == 10) BFM_IL1(0); else if (mode == 3) BFM_IL1(3); else BFM_IL1(2);
+#undef BFM_IL1
+    }
     else
         hipLaunchKernelGGL(interp_linear, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), X, nx, ny, nz, C, II, JJ, KK, n,
                            default_value, out);
@@ -805,9 +841,13 @@ extern "C" int bfm_deformed_atlas_tile(const float* tile_in, const float* regx, 
     // library has no switch: a stray environment variable cannot select them.
     static int loads = -1;
     if (loads < 0) { const char* e = getenv("BFM_ATLAS_PLAIN_LOADS"); loads = e ? atoi(e) : 0; }
+    if (const char* e = getenv("BFM_ATLAS_PLAIN_LOADS_NOW")) loads = atoi(e);      // re-read per launch (one-process sweeps)
     if (loads == 1) BFM_ATLAS_LAUNCH(1);
     else if (loads == 2) BFM_ATLAS_LAUNCH(2);
     else if (loads == 3) BFM_ATLAS_LAUNCH(3);
+    else if (loads == 4) BFM_ATLAS_LAUNCH(4);
+    else if (loads == 5) BFM_ATLAS_LAUNCH(5);
+    else if (loads == 7) BFM_ATLAS_LAUNCH(7);
     else BFM_ATLAS_LAUNCH(0);
 #else
     BFM_ATLAS_LAUNCH(0);

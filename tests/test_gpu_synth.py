@@ -465,14 +465,21 @@ def test_gathers_inside_captured_graphs_on_two_lanes_keep_their_goldens():
     ly.name, ly.cin, ly.cout, ly.groups = "corunner", cin, cout, 8
     ly.w_raw = (torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05).contiguous()
     ly.packs, ly.kind, ly.wpacked, ly.wexp, ly.skip = {}, None, None, 0, None
-    ccfg = (C.c_int * 8)()
-    L.check(eng.lib.bfm_conv3x3x3_mfma_plan(cin, cout, cd[0], cd[1], cd[2], ccfg), "plan")
-    ccfg[6] = 0                                                     # conv_mfma: weights through an LDS-DMA ring
+    ccfgs = []
+    for ver in (0, 4):          # conv_mfma: weights through an LDS-DMA ring; conv_wino4d: raw activation chunks by LDS-DMA --
+        c = (C.c_int * 8)()     # the strongest trigger of the hazard found so far (profiles/r05_atlas_hazard_bisect.txt)
+        L.check(eng.lib.bfm_conv3x3x3_mfma_plan(cin, cout, cd[0], cd[1], cd[2], c), "plan")
+        c[6] = ver
+        ccfgs.append(c)
+    state = {"it": 0}
 
     def conv_beside():
+        ccfg = ccfgs[state["it"] % 2]
+        state["it"] += 1
         for _ in range(6):
             eng._conv_launch(ly, cA, cin, None, 0, cd, None, csc, csh, cbd, 8, ccfg, cout_t, cws)
 
+    conv_beside()
     conv_beside()
     torch.cuda.synchronize()
     lanes = []
@@ -514,8 +521,9 @@ def test_streaming_kernels_with_l1_reuse_beside_an_lds_dma_corunner_keep_their_b
     """DESIGN.md section 3.3 / VERDICT r3 #6: besides the gathers, three kernels of the tile flow read with ordinary
     vector loads that re-use L1 lines between neighbouring lanes -- the stem's halo gather (bfm_conv3x3x3_stem_ex),
     maxpool2 (bfm_maxpool2_ex) and the uniform-box flags (bfm_uniform_boxes_level).  Each runs on two streams at once
-    beside the LDS-DMA co-runner the atlas gather went wrong beside (conv_mfma, variant 0), 40 rounds; every output must
-    equal the kernel's own serial result bit for bit."""
+    beside the LDS-DMA co-runners the atlas gather went wrong beside (conv_mfma and -- the strongest trigger -- conv_wino4d,
+    alternating), 40 rounds; every output must equal the kernel's own serial result bit for bit.  Round 5 added a victim of
+    the tile flow whose ordinary loads re-use L1 lines: the F(2,3) Winograd convolution."""
     import ctypes as C
     from brainfm_amd import _lib as L, test_utils as TU
     from brainfm_amd.engine import _Layer
@@ -532,13 +540,33 @@ def test_streaming_kernels_with_l1_reuse_beside_an_lds_dma_corunner_keep_their_b
     ly.name, ly.cin, ly.cout, ly.groups = "corunner", cin, cout, 8
     ly.w_raw = (torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05).contiguous()
     ly.packs, ly.kind, ly.wpacked, ly.wexp, ly.skip = {}, None, None, 0, None
-    ccfg = (C.c_int * 8)()
-    L.check(lib.bfm_conv3x3x3_mfma_plan(cin, cout, cd[0], cd[1], cd[2], ccfg), "plan")
-    ccfg[6] = 0
+    ccfgs = []
+    for ver in (0, 4):          # conv_mfma (LDS-DMA weight ring) and conv_wino4d (LDS-DMA raw chunks: the strongest trigger of
+        c = (C.c_int * 8)()     # the atlas hazard found so far, profiles/r05_atlas_hazard_bisect.txt), alternating
+        L.check(lib.bfm_conv3x3x3_mfma_plan(cin, cout, cd[0], cd[1], cd[2], c), "plan")
+        c[6] = ver
+        ccfgs.append(c)
+    state = {"it": 0}
 
     def conv_beside():
+        ccfg = ccfgs[state["it"] % 2]
+        state["it"] += 1
         for _ in range(6):
             eng._conv_launch(ly, cA, cin, None, 0, cd, None, csc, csh, cbd, 8, ccfg, cout_t, cws)
+
+    # a victim with ordinary loads that DO re-use L1 lines: the F(2,3) Winograd convolution (neighbouring boxes share halo
+    # rows, the two workgroups of a CU share weight fragments) -- in the two-lane tile flow it runs beside conv_wino4d
+    vly = _Layer()
+    vly.name, vly.cin, vly.cout, vly.groups = "victim", 64, 64, 8
+    vly.w_raw = (torch.randn(64, 64, 3, 3, 3, generator=torch.Generator().manual_seed(8)) * 0.05).to(DEV).contiguous()
+    vly.packs, vly.kind, vly.wpacked, vly.wexp, vly.skip = {}, None, None, 0, None
+    vd = (32, 40, 48)
+    vA = torch.randn(*vd, 64, generator=torch.Generator().manual_seed(9)).to(DEV)
+    vsc, vsh, vbd = torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV) * 0.1, torch.full((8,), 6.0, device=DEV)
+    vcfg = (C.c_int * 8)()
+    L.check(lib.bfm_conv3x3x3_mfma_plan(64, 64, vd[0], vd[1], vd[2], vcfg), "plan")
+    vcfg[6] = 3
+    vws = [torch.empty(1 << 24, dtype=torch.uint8, device=DEV) for _ in range(3)]
 
     g = torch.Generator().manual_seed(3)
     dims = (96, 80, 112)
@@ -568,14 +596,18 @@ def test_streaming_kernels_with_l1_reuse_beside_an_lds_dma_corunner_keep_their_b
             L.check(lib.bfm_uniform_boxes_level(L.ptr(x_cl), dims[0], dims[1], dims[2], level, 3, eng.passes, L.ptr(fl),
                                                 L.stream_ptr()), "uniform_boxes")
             store["flags%d" % level] = fl
+        vout = torch.empty(*vd, 64, device=DEV)
+        eng._conv_launch(vly, vA, 64, None, 0, vd, None, vsc, vsh, vbd, 8, vcfg, vout, vws[store.get("_slot", 2)])
+        store["conv_wino"] = vout
 
     want = {}
     run_all(want)
     conv_beside()
+    conv_beside()
     torch.cuda.synchronize()
     assert int((want["flags0"] != 0).sum()) > 0                       # the zero slabs give flagged boxes
     for it in range(40):
-        got = [{}, {}]
+        got = [{"_slot": 0}, {"_slot": 1}]
         with torch.cuda.stream(side):
             conv_beside()
         for lane in range(2):
@@ -584,4 +616,5 @@ def test_streaming_kernels_with_l1_reuse_beside_an_lds_dma_corunner_keep_their_b
         torch.cuda.synchronize()
         for lane in range(2):
             for k, v in want.items():
-                assert torch.equal(got[lane][k], v), (it, lane, k)
+                if k != "_slot":
+                    assert torch.equal(got[lane][k], v), (it, lane, k)
