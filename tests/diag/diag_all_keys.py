@@ -1,5 +1,7 @@
 """Stress: the batched / graph / two-lane flow against the eager tile-by-tile flow, every stitched key, many volumes.
-   python tests/diag/diag_all_keys.py [size=256] [reps=40]"""
+   python tests/diag/diag_all_keys.py [size=256] [reps=40] [pipelined=0]
+   pipelined = K: K volumes are submitted back to back WITHOUT a synchronisation in between (the stitch of one volume then
+   runs beside the first tiles of the next, as in bench.py's timed region) and compared afterwards."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -21,6 +23,21 @@ for v in vols:
     refs.append({k: t.clone() for k, t in e.items()})
 TU.prepare_tile_graphs(vols[0], s, [80] * 3, [160] * 3)
 bad_total = 0
+pipe = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+if pipe:
+    for r0 in range(0, reps, pipe):
+        outs = []
+        for rep in range(r0, min(reps, r0 + pipe)):
+            outs.append((rep, TU.tiled_inference(vols[rep % 2], s, [80] * 3, [160] * 3, graphs=True)[0]))
+        torch.cuda.synchronize()
+        for rep, g in outs:
+            bad = {k: int((refs[rep % 2][k] != g[k]).sum()) for k in g}
+            if sum(bad.values()):
+                print("rep", rep, {k: b for k, b in bad.items() if b}, flush=True)
+            bad_total += sum(bad.values())
+        del outs
+    print("volumes %d x %d^3 in pipelines of %d, %d keys each: differing voxels in total %d" % (reps, n, pipe, len(refs[0]), bad_total))
+    sys.exit(0)
 for rep in range(reps):
     v = vols[rep % 2]
     g, _, _ = TU.tiled_inference(v, s, [80] * 3, [160] * 3, graphs=True)
