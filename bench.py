@@ -481,7 +481,7 @@ def config4_block(sess, dev, rank, world, use_dist, stride, win, n=512, steps=2)
                                                   "broadcast_bytes": xs.get("broadcast_bytes"), "exchange_exposed_ms": exposed}}
 
 
-def config5_block(dev, rank, world, use_dist, size=160, items=2):
+def config5_block(dev, rank, world, use_dist, size=160, items=3):
     """BASELINE config 5: per rank one generator item (192^3 Voronoi label case -> 4 augmented 160^3 samples, pathology on)
     feeding ONE training iteration of the full-width net, gradients averaged by one flat all-reduce (DDP, weak scaling,
     batch = N items).  Collective: every rank calls it (scripts/bench_config5.py is the stand-alone form)."""
@@ -506,22 +506,26 @@ def config5_block(dev, rank, world, use_dist, size=160, items=2):
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    t_all = time.perf_counter()
     tg = tt = ar = 0.0
+    per_item = []
     for _ in range(items):
+        if use_dist:
+            dist.barrier()                                      # an item = one DDP step: the ranks start it together
+        t_it = time.perf_counter()
         a, b, total, ok = one()
+        per_item.append(time.perf_counter() - t_it)
         tg += a
         tt += b
         ev = step.__dict__.get("allreduce_events") or []
         if len(ev) == 3:
             ar += ev[0].elapsed_time(ev[1])
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t = torch.tensor([time.perf_counter() - t_all], device=dev, dtype=torch.float64)
+    # median item (the step is submitted from Python: a host hiccup in one item must not halve the reported rate), the
+    # slowest rank's
+    t = torch.tensor([float(np.median(per_item))], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    t_all = float(t.item())
+    t_med = float(t.item())
+    t_all = t_med * items
     ns = ga.generator.all_samples
     ev = step.__dict__.get("allreduce_events") or []
     out = {"workload": "per rank: 192^3 label case -> generator (pathology on) -> %d augmented %d^3 samples -> one training "
@@ -532,6 +536,7 @@ def config5_block(dev, rank, world, use_dist, size=160, items=2):
            "allreduce_ms_per_iteration": (ar / items) if world > 1 and len(ev) == 3 else None,
            "allreduce_bytes": ev[2] if len(ev) == 3 else None,
            "allreduce_note": "one flat all-reduce after the backward pass, not overlapped: what it takes is what it exposes",
+           "item_s_each_rank0": [round(v, 4) for v in per_item], "rate_from": "median item time, max over ranks",
            "last_loss": float(total), "stepped": bool(ok), "scaling": "weak", "items_timed": items}
     del ds, step
     np.random.set_state(st_np)
