@@ -42,6 +42,7 @@ struct UpParams {
     int BHW, BVOX;                   // BH * BW, BD * BH * BW (<= 128; rows past it are padding)
     int nTy, nTx, nMt, NT, KCB;
     int nvox_lds, plane_stride;
+    int rowoff_lds;                  // byte offset of the epilogue's row table (128 ints) in LDS
     int kc_per_split;                // K chunks per blockIdx.y slab (a multiple of 3: the weight ring's phase period)
     float* slab;                     // split-K: [sample][gridDim.y][2d][2h][2w][Cout] partial sums, summed by upfold_reduce
     int64_t slab_stride;
@@ -66,8 +67,11 @@ __device__ __forceinline__ void box_coords(const UpParams& p, int q, int& bd, in
     bw = rem - bh * p.BW;
 }
 
-template <int NPASS>
-__global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
+// ABL (diagnostics builds only, -DBFM_UP_ABLATE, tests/diag/diag_upfold_ablate.py): phases compiled out to see what the
+// launch time is made of.  1: no weight loads in the tap loop, 2: no LDS operand reads, 4: no staging at all, 8: staging
+// without its global loads, 16: no epilogue, 64: no MFMAs.  Ablated launches compute wrong results.
+template <int NPASS, int ABL = 0>
+__device__ __forceinline__ void conv_upfold_body(const UpParams& p) {
     constexpr int NPL = (NPASS == 3) ? 2 : 1;
     constexpr int NF = 2 * NPL;                       // weight fragments per tap: 2 column blocks x (hi[, lo])
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -118,6 +122,16 @@ __global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
         a_off[mb] = (khalf * NPL) * p.plane_stride + (((bd + pz) * p.HT + (bh + py)) * p.WT + (bw + px)) * 16;
     }
 
+    // the epilogue's row table: element offset of row q's full-res voxel (class (0,0,0)) from the box's, -1 for rows that
+    // are padding or outside the tensor; published by the chunk loop's first barrier
+    int* const rowoff = reinterpret_cast<int*>(lds + p.rowoff_lds);
+    if (tid < 128) {
+        int bd, bh, bw;
+        box_coords(p, tid < p.BVOX ? tid : 0, bd, bh, bw);
+        const bool ok = tid < p.BVOX && z0 + bd < p.d && y0 + bh < p.h && x0 + bw < p.w;
+        rowoff[tid] = ok ? (((2 * bd) * (2 * p.h) + 2 * bh) * (2 * p.w) + 2 * bw) * p.Cout : -1;
+    }
+
     // staging bookkeeping: element e = tid + it*NTHR -> (halo voxel, channel quad)
     constexpr int MAX_IT = 4;
     const int n_el = p.nvox_lds * 4;
@@ -153,7 +167,18 @@ __global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
     const int S = p.KCB * 8;
     const uint4* wbase = p.wp + (size_t)(nt * 8 + cls) * S * (NF * 64) + lane;
     uint4 wq[3][NF];
+    const int kc0_ = blockIdx.y * p.kc_per_split * 8;
+    half8 a_abl[4][NPL];
+    if constexpr ((ABL & 2) != 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int hl = 0; hl < NPL; ++hl)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a_abl[u][hl][j] = (_Float16)(0.01f * (float)((lane * 7 + u * 3 + hl * 5 + j) % 61) - 0.3f);
+    }
     auto fetch = [&](int s, uint4 (&dst)[NF]) __attribute__((always_inline)) {
+        if constexpr ((ABL & 1) != 0) { if (s > kc0_ + 1) return; }
         const int sc = s < S ? s : S - 1;
 #pragma unroll
         for (int f = 0; f < NF; ++f) dst[f] = wbase[(size_t)sc * (NF * 64) + f * 64];
@@ -176,10 +201,13 @@ __global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
         __syncthreads();                                 // previous chunk's readers are done
 #pragma unroll
         for (int u0 = 0; u0 < MAX_IT; u0 += 2) {
+            if constexpr ((ABL & 4) != 0) continue;
             float4 v[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr ((ABL & 8) != 0) v[u] = make_float4(0.1f * lane, 0.2f, 0.3f * kc, 0.4f);
+                else
                 if (off[u0 + u] >= 0) v[u] = *reinterpret_cast<const float4*>(src + off[u0 + u]);
             }
 #pragma unroll
@@ -220,8 +248,18 @@ __global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
             for (int mb = 0; mb < 4; ++mb) {
                 half8 a[NPL];
 #pragma unroll
-                for (int hl = 0; hl < NPL; ++hl)
-                    a[hl] = *reinterpret_cast<const half8*>(lds + a_off[mb] + hl * p.plane_stride + toff);
+                for (int hl = 0; hl < NPL; ++hl) {
+                    if constexpr ((ABL & 2) != 0) a[hl] = a_abl[mb][hl];
+                    else a[hl] = *reinterpret_cast<const half8*>(lds + a_off[mb] + hl * p.plane_stride + toff);
+                }
+                if constexpr ((ABL & 64) != 0) {
+                    float ss = 0.f;
+#pragma unroll
+                    for (int hl = 0; hl < NPL; ++hl) ss += (float)a[hl][0] + (float)a[hl][7];
+                    ss += __builtin_bit_cast(float, bw[0].x) + __builtin_bit_cast(float, bw[NF - 1].w);
+                    acc[mb][0][0] += ss;
+                    continue;
+                }
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
                     const half8 bhi = __builtin_bit_cast(half8, bw[nb * NPL]);
@@ -241,26 +279,51 @@ __global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) {
         if (kc + 2 < kc1) do_chunk(kc + 2, std::integral_constant<int, 1>{});
     }
 
-    // epilogue: class (pz,py,px) of low-res voxel (zl,yl,xl) is full-res voxel (2zl+pz, 2yl+py, 2xl+px)
+    if constexpr ((ABL & 16) != 0) {
+        float sm = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sm += acc[mb][0][i] + acc[mb][1][i];
+        if (sm == 12345.678f) p.out[tid] = sm;
+        return;
+    }
+    // epilogue: class (pz,py,px) of low-res voxel (zl,yl,xl) is full-res voxel (2zl+pz, 2yl+py, 2xl+px).  The element offset
+    // of a row's full-res voxel relative to the box's comes from the table written at the top (round 5: the divisions of
+    // box_coords per stored row were 4 900 instructions per wave, a sixth of the launch); lanes of one k-half read the same
+    // four consecutive entries (row_perm keeps aligned groups of four together): a broadcast ds_read_b128
     const int H2 = 2 * p.h, W2 = 2 * p.w;
     float* const obase = p.slab ? p.slab + ((int64_t)smp * gridDim.y + blockIdx.y) * p.slab_stride : p.out + smp * p.sO;
+    float* const ob = obase + (((int64_t)(2 * z0 + pz) * H2 + (2 * y0 + py)) * W2 + (2 * x0 + px)) * p.Cout + nt * 64;   // wave-uniform
+    auto store_rows = [&](auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
+        for (int mb = 0; mb < 4; ++mb) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rr = (i >> 2) * 8 + khalf * 4 + (i & 3);
-            int bd, bh, bw;
-            const int q = mb * 32 + row_perm(rr);
-            box_coords(p, q, bd, bh, bw);
-            const int zl = z0 + bd, yl = y0 + bh, xl = x0 + bw;
-            if (q >= p.BVOX || zl >= p.d || yl >= p.h || xl >= p.w) continue;
-            float* orow = obase + (((int64_t)(2 * zl + pz) * H2 + (2 * yl + py)) * W2 + (2 * xl + px)) * p.Cout +
-                          nt * 64 + l32;
+            for (int ig = 0; ig < 4; ++ig) {
+                const int4 r4 = *reinterpret_cast<const int4*>(rowoff + mb * 32 + row_perm(ig * 8 + khalf * 4));
+                const int rel[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) orow[nb * 32] = acc[mb][nb][i] * dq;
+                for (int j = 0; j < 4; ++j) {
+                    if (!FULL && rel[j] < 0) continue;        // padding row, or outside the tensor
+                    const unsigned o = (unsigned)rel[j] + (unsigned)l32;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) ob[o + nb * 32] = acc[mb][nb][ig * 4 + j] * dq;
+                }
+            }
         }
-    }
+    };
+    // a box with all 128 rows inside the tensor (wave-uniform) stores without a test per row
+    if (p.BVOX == 128 && z0 + p.BD <= p.d && y0 + p.BH <= p.h && x0 + p.BW <= p.w) store_rows(std::true_type{});
+    else store_rows(std::false_type{});
 }
+
+template <int NPASS>
+__global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) { conv_upfold_body<NPASS, 0>(p); }
+#ifdef BFM_UP_ABLATE
+template <int ABL>
+__global__ void __launch_bounds__(NTHR, 1) conv_upfold_abl(const UpParams p) { conv_upfold_body<3, ABL>(p); }
+#endif
 
 // split-K: out = sum of the slabs in slab order (deterministic)
 __global__ void upfold_reduce(const float4* __restrict__ slab, int nsplit, int64_t n4, float4* __restrict__ out) {
@@ -506,7 +569,9 @@ static int upfold_launch(const float* B, int CB, int S, int d, int h, int w, con
     if (p.nvox_lds * 4 > 4 * NTHR) return BFM_E_SHAPE;
     p.plane_stride = ((p.nvox_lds * 16 + 255) / 256) * 256 + 16;          // +16: planes start on different banks
     const int npl = passes == 3 ? 2 : 1;
-    const size_t smem = (size_t)2 * npl * p.plane_stride + 64;
+    p.rowoff_lds = ((2 * npl * p.plane_stride + 64 + 15) / 16) * 16;
+    const size_t smem = (size_t)p.rowoff_lds + 128 * sizeof(int);
+    if ((int64_t)(2 * p.BD) * (2 * h) * (2 * w) * Cout > 0x7fffffffLL) return BFM_E_SHAPE;   // 32-bit row offsets inside a box
     if ((int64_t)p.nMt * p.NT > 0x7fffffff) return BFM_E_SHAPE;
     int nsplit = 1, per = p.KCB;
     const int64_t nout = (int64_t)8 * d * h * w * Cout;
@@ -525,6 +590,19 @@ static int upfold_launch(const float* B, int CB, int S, int d, int h, int w, con
     p.slab = nsplit > 1 ? static_cast<float*>(workspace) : nullptr;
     p.slab_stride = nout;
     dim3 grid((unsigned)(p.nMt * p.NT), (unsigned)nsplit, (unsigned)S);
+#ifdef BFM_UP_ABLATE
+    if (const char* e = getenv("BFM_UP_ABL")) {
+        const int a = atoi(e);
+        hipStream_t st = bfm_s(stream);
+#define UPA(n) case n: hipLaunchKernelGGL(conv_upfold_abl<n>, grid, dim3(NTHR), smem, st, p); break;
+        switch (a) {
+            UPA(0) UPA(1) UPA(2) UPA(4) UPA(8) UPA(16) UPA(64) UPA(3) UPA(5) UPA(7) UPA(23) UPA(68) UPA(71) UPA(87) UPA(80) UPA(20) UPA(12)
+            default: return BFM_E_ARG;
+        }
+#undef UPA
+        return bfm_launch_status();
+    }
+#endif
     if (passes == 3) hipLaunchKernelGGL(conv_upfold<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
     else hipLaunchKernelGGL(conv_upfold<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
     if (nsplit > 1) {
