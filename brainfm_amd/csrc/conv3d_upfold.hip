@@ -49,6 +49,7 @@ struct UpParams {
     // batch: blockIdx.z = sample; B, out advance by sB, sO elements per sample, scale / shift by saff (CB when the tables are the B half alone), bound by G.  A
     // sample's workgroups do exactly what they do in a launch of that sample alone.
     int64_t sB, sO;
+    int dbg_sleep;                   // diagnostics builds: odd CUs' first workgroups start this many kilocycles late
 };
 
 __device__ __forceinline__ int row_perm(int l) {        // same lane -> row order as conv_mfma (conflict-free b128)
@@ -80,6 +81,10 @@ __device__ __forceinline__ void conv_upfold_body(const UpParams& p) {
     const int cls = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = output parity class (pz,py,px)
     const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
     const int l32 = lane & 31, khalf = lane >> 5;
+#ifdef BFM_UP_ABLATE
+    if (p.dbg_sleep > 0 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1))   // de-phase neighbouring CUs (experiment)
+        for (int i = 0; i < p.dbg_sleep; ++i) __builtin_amdgcn_s_sleep(16);
+#endif
 
     int bid = blockIdx.x;
     {
@@ -265,10 +270,10 @@ __device__ __forceinline__ void conv_upfold_body(const UpParams& p) {
                     const half8 bhi = __builtin_bit_cast(half8, bw[nb * NPL]);
                     if constexpr (NPASS == 3) {
                         const half8 blo = __builtin_bit_cast(half8, bw[nb * NPL + 1]);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bhi, acc[mb][nb], 0, 0, 0);
-                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], blo, acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi, a[1], acc[mb][nb], 0, 0, 0);
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(blo, a[0], acc[mb][nb], 0, 0, 0);
                     }
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bhi, acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bhi, a[0], acc[mb][nb], 0, 0, 0);
                 }
             }
         }
@@ -288,34 +293,30 @@ __device__ __forceinline__ void conv_upfold_body(const UpParams& p) {
         if (sm == 12345.678f) p.out[tid] = sm;
         return;
     }
-    // epilogue: class (pz,py,px) of low-res voxel (zl,yl,xl) is full-res voxel (2zl+pz, 2yl+py, 2xl+px).  The element offset
-    // of a row's full-res voxel relative to the box's comes from the table written at the top (round 5: the divisions of
-    // box_coords per stored row were 4 900 instructions per wave, a sixth of the launch); lanes of one k-half read the same
-    // four consecutive entries (row_perm keeps aligned groups of four together): a broadcast ds_read_b128
+    // epilogue: class (pz,py,px) of low-res voxel (zl,yl,xl) is full-res voxel (2zl+pz, 2yl+py, 2xl+px).  The products run
+    // with the operands swapped (weights as the MFMA's row operand, voxels as its column operand: the two register layouts
+    // are the same, so this costs nothing), which leaves lane l with VOXEL mb*32 + row_perm(l32) and registers
+    // i -> cout 8 (i >> 2) + 4 khalf + (i & 3): four consecutive couts per register quad, one 16-byte store each.  Round 5
+    // measured what the dword stores of the other orientation cost: 128 store instructions per thread were 0.12 of a 1.33 ms
+    // launch, and the same stores into an L2-resident window cost the same -- the instructions, not the bytes.  The element
+    // offset of a row's voxel relative to the box's comes from the table written at the top (the divisions of box_coords per
+    // stored row were 4 900 instructions per wave before that, a sixth of the launch).
     const int H2 = 2 * p.h, W2 = 2 * p.w;
     float* const obase = p.slab ? p.slab + ((int64_t)smp * gridDim.y + blockIdx.y) * p.slab_stride : p.out + smp * p.sO;
-    float* const ob = obase + (((int64_t)(2 * z0 + pz) * H2 + (2 * y0 + py)) * W2 + (2 * x0 + px)) * p.Cout + nt * 64;   // wave-uniform
-    auto store_rows = [&](auto full_tag) __attribute__((always_inline)) {
-        constexpr bool FULL = decltype(full_tag)::value;
+    float* const ob = obase + (((int64_t)(2 * z0 + pz) * H2 + (2 * y0 + py)) * W2 + (2 * x0 + px)) * p.Cout + nt * 64 + khalf * 4;
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
+    for (int mb = 0; mb < 4; ++mb) {
+        const int rel = rowoff[mb * 32 + row_perm(l32)];
+        if (rel < 0) continue;                                // padding row, or outside the tensor
+        float* const o = ob + (unsigned)rel;
 #pragma unroll
-            for (int ig = 0; ig < 4; ++ig) {
-                const int4 r4 = *reinterpret_cast<const int4*>(rowoff + mb * 32 + row_perm(ig * 8 + khalf * 4));
-                const int rel[4] = {r4.x, r4.y, r4.z, r4.w};
+        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (!FULL && rel[j] < 0) continue;        // padding row, or outside the tensor
-                    const unsigned o = (unsigned)rel[j] + (unsigned)l32;
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) ob[o + nb * 32] = acc[mb][nb][ig * 4 + j] * dq;
-                }
-            }
-        }
-    };
-    // a box with all 128 rows inside the tensor (wave-uniform) stores without a test per row
-    if (p.BVOX == 128 && z0 + p.BD <= p.d && y0 + p.BH <= p.h && x0 + p.BW <= p.w) store_rows(std::true_type{});
-    else store_rows(std::false_type{});
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(o + nb * 32 + g * 8) =
+                    make_float4(acc[mb][nb][4 * g] * dq, acc[mb][nb][4 * g + 1] * dq, acc[mb][nb][4 * g + 2] * dq,
+                                acc[mb][nb][4 * g + 3] * dq);
+    }
 }
 
 template <int NPASS>
@@ -591,6 +592,7 @@ static int upfold_launch(const float* B, int CB, int S, int d, int h, int w, con
     p.slab_stride = nout;
     dim3 grid((unsigned)(p.nMt * p.NT), (unsigned)nsplit, (unsigned)S);
 #ifdef BFM_UP_ABLATE
+    if (const char* e = getenv("BFM_UP_SLEEP")) p.dbg_sleep = atoi(e);
     if (const char* e = getenv("BFM_UP_ABL")) {
         const int a = atoi(e);
         hipStream_t st = bfm_s(stream);

@@ -70,6 +70,7 @@ struct W4Params {
     // workgroups do exactly what they do in a launch of that sample alone.
     int nMtS, saff;
     int64_t sA, sO;
+    int dbg_sleep;                   // diagnostics builds: the first round's odd wave slots start this many kilocycles late
 };
 
 __device__ __forceinline__ int row_perm(int l) {        // as conv_mfma: each 16-lane b128 group reads 16 consecutive positions
@@ -560,6 +561,14 @@ __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
     const int posA = wv;
     const int posB = 4 + (wv >> 1), nbB = wv & 1;
     const int l32 = lane & 31, khalf = lane >> 5;
+#ifdef BFM_W4_ABLATE
+    if (p.dbg_sleep > 0 && blockIdx.x < 512) {                     // de-phase the two workgroups of a CU (experiment)
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if (hwid & 1)
+            for (int i = 0; i < p.dbg_sleep; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     int item;
     {
         const int nblk = LIST ? p.list_n[0] * p.NT : p.nMt * p.NT;
@@ -856,7 +865,7 @@ __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
     const unsigned off_t = (unsigned)((rg * p.W) * p.Cout + col);
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        if constexpr (!UNI) {
+        if constexpr (!UNI && (ABL & 256) == 0) {
         __syncthreads();                                           // A planes (or the previous round) fully consumed
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -878,6 +887,7 @@ __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
         } else if (nb == 1 && p.rsum != nullptr) __syncthreads();  // the previous round's moment fold is done with its scratch
         float fs = 0.f, fq = 0.f, fmn = INFINITY, fmx = -INFINITY;
         float* ob = p.out + nt * 64 + nb * 32 + ((int64_t)(z0 * p.H + y0) * p.W + x0) * p.Cout;
+        if constexpr ((ABL & 512) != 0) ob = p.out + nt * 64 + nb * 32 + (mt & 127) * 16384;    // the same stores into 8 MB
         const float* mc = m + col;
         if (interior) {
             float prev[8][4];
@@ -892,6 +902,7 @@ __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 float* o = ob + (int64_t)it * p.H * p.W * p.Cout;
+                if constexpr ((ABL & 512) != 0) o = ob + it * 2048 - (int)off_t + (rg * 256 + col);
                 float y[4];
                 if constexpr (UNI) {
                     const float4 yy = ybuf[(nb * 8 + it) * NTHR];
@@ -899,8 +910,14 @@ __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
                 } else {
                     const int qr = 32 * ((it & 3) >> 1) + un[2 * (it & 1) + (it >> 2)];
                     const float* mr = mc + qr * MLD;
-                    const float m0 = mr[0 * 64 * MLD], m1 = mr[1 * 64 * MLD], m2 = mr[2 * 64 * MLD];
-                    const float m3 = mr[3 * 64 * MLD], m4 = mr[4 * 64 * MLD], m5 = mr[5 * 64 * MLD];
+                    float m0, m1, m2, m3, m4, m5;
+                    if constexpr ((ABL & 256) != 0) {
+                        m0 = acc[0][nb][it]; m1 = acc[1][nb][it]; m2 = accB[0][it]; m3 = accB[1][it];
+                        m4 = acc[0][nb][it + 8]; m5 = acc[1][nb][it + 8];
+                    } else {
+                        m0 = mr[0 * 64 * MLD]; m1 = mr[1 * 64 * MLD]; m2 = mr[2 * 64 * MLD];
+                        m3 = mr[3 * 64 * MLD]; m4 = mr[4 * 64 * MLD]; m5 = mr[5 * 64 * MLD];
+                    }
                     const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
                     y[0] = ((m0 + s1) + s2) * dq;
                     y[1] = fmaf(2.f, d2, d1) * dq;
@@ -913,10 +930,11 @@ __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
                     float r = y[k];
                     if (p.accum) r = r + prev[it][k];
                     r = r >= 0.f ? r : r * p.slope;
-                    o[off_t + (unsigned)(k * p.Cout)] = r;
+                    if constexpr ((ABL & 128) == 0) o[off_t + (unsigned)(k * p.Cout)] = r;
                     fs += r; fq = fmaf(r, r, fq); fmn = fminf(fmn, r); fmx = fmaxf(fmx, r);
                 }
             }
+            if constexpr ((ABL & 128) != 0) { if (fs == 12345.678f) p.out[tid] = fs + fq + fmn + fmx; }
         } else if (y0 + rg < p.H) {
 #pragma unroll 2
             for (int it = 0; it < 8; ++it) {
@@ -1206,14 +1224,15 @@ static int w4_launch(const float* A, int CA, int D, int H, int W, const float* s
         return bfm_launch_status();
     }
 #ifdef BFM_W4_ABLATE
+    if (const char* e = getenv("BFM_W4_SLEEP")) p.dbg_sleep = atoi(e);
     if (const char* e = getenv("BFM_W4_ABL")) {                 // diagnostics: phases compiled out, the old kernel by "old"
         const int abl = atoi(e);
         if (dma) {
 #define W4D_ATTR(N) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4d_abl<N>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
-            W4D_ATTR(0); W4D_ATTR(1); W4D_ATTR(2); W4D_ATTR(3); W4D_ATTR(4); W4D_ATTR(8); W4D_ATTR(12); W4D_ATTR(15); W4D_ATTR(16); W4D_ATTR(31); W4D_ATTR(64); W4D_ATTR(28);
+            W4D_ATTR(0); W4D_ATTR(1); W4D_ATTR(2); W4D_ATTR(3); W4D_ATTR(4); W4D_ATTR(8); W4D_ATTR(12); W4D_ATTR(15); W4D_ATTR(16); W4D_ATTR(31); W4D_ATTR(64); W4D_ATTR(28); W4D_ATTR(128); W4D_ATTR(256); W4D_ATTR(384); W4D_ATTR(512);
             switch (abl) {
 #define W4D_CASE(N) case N: hipLaunchKernelGGL(conv_wino4d_abl<N>, grid, dim3(NTHR), smem, st, p); return bfm_launch_status()
-                W4D_CASE(0); W4D_CASE(1); W4D_CASE(2); W4D_CASE(3); W4D_CASE(4); W4D_CASE(8); W4D_CASE(12); W4D_CASE(15); W4D_CASE(16); W4D_CASE(31); W4D_CASE(64); W4D_CASE(28);
+                W4D_CASE(0); W4D_CASE(1); W4D_CASE(2); W4D_CASE(3); W4D_CASE(4); W4D_CASE(8); W4D_CASE(12); W4D_CASE(15); W4D_CASE(16); W4D_CASE(31); W4D_CASE(64); W4D_CASE(28); W4D_CASE(128); W4D_CASE(256); W4D_CASE(384); W4D_CASE(512);
                 default: return BFM_E_ARG;
             }
         }

@@ -59,5 +59,10 @@ for a in abls:
     os.environ["BFM_UP_ABL"] = str(a)
     what = " + ".join(v for k, v in NAMES.items() if a & k) or "everything kept (ablation build's copy)"
     print("ABL %3d: %.3f ms   %s" % (a, timed(), what), flush=True)
+os.environ["BFM_UP_ABL"] = "0"
+for sl in (0, 2, 5, 10, 20, 40, 60):
+    os.environ["BFM_UP_SLEEP"] = str(sl)
+    print("first-round stagger of %2d kilocycles: %.3f ms" % (sl, timed()), flush=True)
+os.environ.pop("BFM_UP_SLEEP", None)
 os.environ.pop("BFM_UP_ABL", None)
 print("shipped kernel again: %.3f ms" % timed(), flush=True)
