@@ -106,6 +106,8 @@ SIGNATURES = {
     "bfm_conv3x3x3_stem_ex": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _F, _P, _P, _P]),
     "bfm_gn_stats_rows_workspace": (_Z, [_I, _I, _I, _I]),
     "bfm_gn_stats_rows": (_I, [_P, _I, _I, _P, _I, _I, C.c_double, _L, _P, _P, _I, _F, _P, _P, _P, _P, _Z, _P, _P]),
+    "bfm_gn_stats_rows_sliced": (_I, [_P, _I, _I, _I, _I, _P, _I, _I, _I, _I, C.c_double, _L, _P, _P, _I, _F, _P, _P, _P, _P, _Z,
+                                      _P, _P]),
     "bfm_gn_stats_rows_train": (_I, [_P, _I, _I, _P, _I, _I, C.c_double, _L, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P, _Z, _P, _P]),
     "bfm_crop3d": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
     "bfm_pack_conv_weights_wino4_bytes": (_Z, [_I, _I, _I]),
@@ -138,6 +140,8 @@ SIGNATURES = {
     "bfm_conv3x3x3_wino_masked": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
     "bfm_maxpool2_rows": (_I, [_I, _I, _I, _I]),
     "bfm_maxpool2_ex": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "bfm_maxpool2_batch_rows": (_I, [_I, _I, _I, _I]),
+    "bfm_maxpool2_batch": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P]),
     "bfm_grid_push3d_linear": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, C.POINTER(_I), _I, _P, _P]),
     "bfm_grid_grad3d_linear": (_I, [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, C.POINTER(_I), _I, _P, _P]),
     "bfm_gn_stats_train": (_I, [_P, _I, _P, _I, _I, _I, _I, _UP, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P, _Z, _P]),

@@ -1152,6 +1152,74 @@ __global__ void splitk_reduce(const float* __restrict__ ws, int splitk, int64_t 
     }
 }
 
+// The same, emitting the output's moment rows (what the conv epilogues write when there is no split): workgroup
+// (rb, cz, s) sums rows [rb * vpb, (rb + 1) * vpb) of sample s on its CGB column quads; thread (vl, cgl) takes every NV-th
+// voxel, the NV partials of a column fold in lane order (fp32 per thread over <= vpb / NV values, fp64 across threads, as
+// the epilogues do).  Row (s * nrows + rb) of the tables.  Deterministic: fixed order, no atomics.
+__global__ void __launch_bounds__(256) splitk_reduce_rows(const float* __restrict__ ws, int splitk, int64_t stride4,
+                                                          int nvox, int Cout, int vpb, int nrows, float slope, int accum,
+                                                          float* __restrict__ out, double* __restrict__ rsum,
+                                                          double* __restrict__ rsq, float* __restrict__ rmn,
+                                                          float* __restrict__ rmx) {
+    __shared__ float4 lsh[4][256];
+    const int CG = Cout >> 2;
+    const int CGB = CG < 64 ? CG : 64;
+    const int NV = 256 / CGB;
+    const int tid = threadIdx.x;
+    const int cgl = tid % CGB, vl = tid / CGB;
+    const int c4 = blockIdx.y * CGB + cgl;
+    const int smp = blockIdx.z, rb = blockIdx.x;
+    const int v0 = rb * vpb, v1 = min(nvox, v0 + vpb);
+    const float4* w4 = reinterpret_cast<const float4*>(ws);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    float4 fs = make_float4(0.f, 0.f, 0.f, 0.f), fq = fs;
+    float4 mn = make_float4(INFINITY, INFINITY, INFINITY, INFINITY), mx = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int v = v0 + vl; v < v1; v += NV) {
+        const int64_t i = ((int64_t)smp * nvox + v) * CG + c4;
+        float4 a = w4[i];
+        for (int k = 1; k < splitk; ++k) {
+            const float4 t = w4[i + k * stride4];
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        if (accum) {
+            const float4 t = o4[i];
+            a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+        }
+        a.x = a.x >= 0.f ? a.x : a.x * slope; a.y = a.y >= 0.f ? a.y : a.y * slope;
+        a.z = a.z >= 0.f ? a.z : a.z * slope; a.w = a.w >= 0.f ? a.w : a.w * slope;
+        o4[i] = a;
+        fs.x += a.x; fs.y += a.y; fs.z += a.z; fs.w += a.w;
+        fq.x = fmaf(a.x, a.x, fq.x); fq.y = fmaf(a.y, a.y, fq.y); fq.z = fmaf(a.z, a.z, fq.z); fq.w = fmaf(a.w, a.w, fq.w);
+        mn.x = fminf(mn.x, a.x); mn.y = fminf(mn.y, a.y); mn.z = fminf(mn.z, a.z); mn.w = fminf(mn.w, a.w);
+        mx.x = fmaxf(mx.x, a.x); mx.y = fmaxf(mx.y, a.y); mx.z = fmaxf(mx.z, a.z); mx.w = fmaxf(mx.w, a.w);
+    }
+    lsh[0][tid] = fs; lsh[1][tid] = fq; lsh[2][tid] = mn; lsh[3][tid] = mx;
+    __syncthreads();
+    if (vl == 0) {
+        double S[4] = {0.0, 0.0, 0.0, 0.0}, Q[4] = {0.0, 0.0, 0.0, 0.0};
+        float MN[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, MX[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int j = 0; j < NV; ++j) {
+            const float4 a = lsh[0][j * CGB + cgl], b = lsh[1][j * CGB + cgl], c = lsh[2][j * CGB + cgl], d = lsh[3][j * CGB + cgl];
+            S[0] += (double)a.x; S[1] += (double)a.y; S[2] += (double)a.z; S[3] += (double)a.w;
+            Q[0] += (double)b.x; Q[1] += (double)b.y; Q[2] += (double)b.z; Q[3] += (double)b.w;
+            MN[0] = fminf(MN[0], c.x); MN[1] = fminf(MN[1], c.y); MN[2] = fminf(MN[2], c.z); MN[3] = fminf(MN[3], c.w);
+            MX[0] = fmaxf(MX[0], d.x); MX[1] = fmaxf(MX[1], d.y); MX[2] = fmaxf(MX[2], d.z); MX[3] = fmaxf(MX[3], d.w);
+        }
+        const size_t o = ((size_t)smp * nrows + rb) * Cout + (size_t)c4 * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { rsum[o + k] = S[k]; rsq[o + k] = Q[k]; rmn[o + k] = MN[k]; rmx[o + k] = MX[k]; }
+    }
+}
+
+// rows of voxels one workgroup of splitk_reduce_rows folds into one moment row (a multiple of its voxel lanes; at most 128
+// rows per sample, so that the batched finalize reads the table directly), and the row count
+static int splitk_rows_vpb(int64_t nvox, int Cout) {
+    const int CG = Cout / 4, CGB = CG < 64 ? CG : 64, NV = 256 / CGB;
+    int64_t vpb = std::max<int64_t>((int64_t)NV * 4, bfm_cdiv64(nvox, 128));
+    vpb = bfm_cdiv64(vpb, NV) * NV;
+    return (int)std::min<int64_t>(vpb, 0x7fffffff);
+}
+
 // packed[ntile64][kc][tap][nb][hl][lane] (uint4 = 8 halfs): lane l holds
 // B[k = 8*(l>>5)+j][n = l&31] = w[co = ntile*64 + nb*32 + (l&31)][ci = kc*16 + 8*(l>>5) + j][tap] * 2^wexp
 // The same packing with the 64 (co) x 16 (ci) x 27 block of one (N tile, K chunk) staged through LDS: its 64 rows of
@@ -1396,11 +1464,16 @@ extern "C" size_t bfm_conv3x3x3_mfma_workspace(int Cin, int Cout, int D, int H, 
 // rows of the output-moment table a launch with this plan writes (0: this plan cannot emit them)
 extern "C" int bfm_conv3x3x3_mfma_rows(int Cin, int Cout, int D, int H, int W, const int* cfg) {
     if (!cfg || Cin <= 0 || Cout <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    if (cfg[6] == 1 || cfg[6] >= 3) return 0;                   // the persistent / Winograd variants do not emit rows
+    if (cfg[6] >= 3 || cfg[6] < 0) return 0;                    // the Winograd variants have their own row counts
     int splitk = cfg[5] < 1 ? 1 : cfg[5];
     const int KCN = Cin / KC;
     if (splitk > KCN) splitk = KCN;
-    if (splitk > 1 && bfm_cdiv(KCN, bfm_cdiv(KCN, splitk)) > 1) return 0;
+    if (splitk > 1 && bfm_cdiv(KCN, bfm_cdiv(KCN, splitk)) > 1) {  // split-K: the slab reduction writes the rows (round 5)
+        if (Cout % 64) return 0;
+        const int64_t nvox = (int64_t)D * H * W;
+        return (int)bfm_cdiv64(nvox, splitk_rows_vpb(nvox, Cout));
+    }
+    if (cfg[6] == 1) return 0;                                  // the persistent variant does not emit rows
     if (cfg[2] < 1 || cfg[3] < 1 || cfg[4] < 1) return 0;
     return bfm_cdiv(D, cfg[2]) * bfm_cdiv(H, cfg[3]) * bfm_cdiv(W, cfg[4]);
 }
@@ -1527,8 +1600,10 @@ static int conv_mfma_launch(const float* A, int CA, const float* B, int CB, int 
     } else {
         p.out = out;
     }
-    if (moment_rows) {
-        if (p.splitk != 1 || hp.ver == 1) return BFM_E_SHAPE;  // see bfm_conv3x3x3_mfma_rows
+    if (moment_rows && p.splitk > 1) {
+        if (reinterpret_cast<uintptr_t>(moment_rows) & 7) return BFM_E_ARG;      // written by splitk_reduce_rows below
+    } else if (moment_rows) {
+        if (hp.ver == 1) return BFM_E_SHAPE;                   // see bfm_conv3x3x3_mfma_rows
         if (reinterpret_cast<uintptr_t>(moment_rows) & 7) return BFM_E_ARG;
         char* rb = static_cast<char*>(moment_rows);
         const size_t n = (size_t)p.nMt * Cout;
@@ -1558,7 +1633,19 @@ static int conv_mfma_launch(const float* A, int CA, const float* B, int CB, int 
     }
     int rc = bfm_launch_status();
     if (rc != BFM_OK) return rc;
-    if (p.splitk > 1) {
+    if (p.splitk > 1 && moment_rows) {
+        if (nvox > 0x7fffffffLL || S > 65535) return BFM_E_SHAPE;
+        const int vpb = splitk_rows_vpb(nvox, Cout);
+        const int nrows = (int)bfm_cdiv64(nvox, vpb);
+        const int CG = Cout / 4, CGB = CG < 64 ? CG : 64;
+        char* rb = static_cast<char*>(moment_rows);
+        const size_t n = (size_t)S * nrows * Cout;
+        hipLaunchKernelGGL(splitk_reduce_rows, dim3(nrows, CG / CGB, S), dim3(256), 0, st,
+                           static_cast<const float*>(workspace), p.splitk, p.split_stride / 4, (int)nvox, Cout, vpb, nrows,
+                           slope, p.accum, out, reinterpret_cast<double*>(rb), reinterpret_cast<double*>(rb + n * 8),
+                           reinterpret_cast<float*>(rb + n * 16), reinterpret_cast<float*>(rb + n * 20));
+        rc = bfm_launch_status();
+    } else if (p.splitk > 1) {
         int64_t n4 = (int64_t)S * nvox * Cout / 4;
         int nb = (int)std::min<int64_t>(2048, bfm_cdiv64(n4, 256));
         hipLaunchKernelGGL(splitk_reduce, dim3(nb), dim3(256), 0, st, static_cast<const float*>(workspace), p.splitk,

@@ -584,11 +584,12 @@ struct RowsView {
     const float *mn, *mx;
 };
 
-RowsView rows_view(const void* rows, int nrows, int C) {
+// rows: a table of `total` rows (four planes of total * C entries); the view starts at its row `first`
+RowsView rows_view(const void* rows, int total, int C, int first = 0) {
     const char* b = static_cast<const char*>(rows);
-    const size_t n = (size_t)nrows * C;
-    return RowsView{reinterpret_cast<const double*>(b), reinterpret_cast<const double*>(b + n * 8),
-                    reinterpret_cast<const float*>(b + n * 16), reinterpret_cast<const float*>(b + n * 20)};
+    const size_t n = (size_t)total * C, o = (size_t)first * C;
+    return RowsView{reinterpret_cast<const double*>(b) + o, reinterpret_cast<const double*>(b + n * 8) + o,
+                    reinterpret_cast<const float*>(b + n * 16) + o, reinterpret_cast<const float*>(b + n * 20) + o};
 }
 
 size_t rows_ws_bytes(int nrows, int C) {            // reduced table (only when nrows > RR_MAX)
@@ -597,8 +598,8 @@ size_t rows_ws_bytes(int nrows, int C) {            // reduced table (only when 
 }
 
 // returns the table gn_finalize should read; launches rows_reduce into ws when the row count is large
-PartTab rows_source(const void* rows, int nrows, int C, double wgt, char* ws, hipStream_t st) {
-    RowsView v = rows_view(rows, nrows, C);
+PartTab rows_source(const void* rows, int nrows, int C, double wgt, char* ws, hipStream_t st, int total = 0, int first = 0) {
+    RowsView v = rows_view(rows, total > 0 ? total : nrows, C, first);
     if (nrows <= RR_MAX) return PartTab{v.sum, v.sq, v.mn, v.mx, nrows, C, wgt};
     const int rpb = bfm_cdiv(nrows, RR_MAX);
     const int nb = bfm_cdiv(nrows, rpb);
@@ -623,11 +624,40 @@ extern "C" size_t bfm_gn_stats_rows_workspace(int nrowsA, int CA, int nrowsB, in
     return rows_ws_bytes(nrowsA, CA) + (CB > 0 ? rows_ws_bytes(nrowsB, CB) : 0) + 256;
 }
 
+static int gn_rows_sliced(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB,
+                          double weightB, int64_t nvox, const float* gamma, const float* beta, int G,
+                          float eps, float* scale, float* shift, float* bound, float* mean_out,
+                          float* rstd_out, void* workspace, size_t workspace_bytes, void* ticket,
+                          bfm_stream_t stream, int totalA, int firstA, int totalB, int firstB);
+
 extern "C" int bfm_gn_stats_rows_train(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB,
                                        double weightB, int64_t nvox, const float* gamma, const float* beta, int G,
                                        float eps, float* scale, float* shift, float* bound, float* mean_out,
                                        float* rstd_out, void* workspace, size_t workspace_bytes, void* ticket,
                                        bfm_stream_t stream) {
+    return gn_rows_sliced(rowsA, nrowsA, CA, rowsB, nrowsB, CB, weightB, nvox, gamma, beta, G, eps, scale, shift, bound,
+                          mean_out, rstd_out, workspace, workspace_bytes, ticket, stream, nrowsA, 0, nrowsB, 0);
+}
+
+// The same with each table given as rows [first, first + nrows) of a larger one of `total` rows: one sample's rows of a
+// batched producer (bfm_conv3x3x3_mfma_batch writes [S * nrows][C] planes), read where they lie.
+extern "C" int bfm_gn_stats_rows_sliced(const void* rowsA, int totalA, int firstA, int nrowsA, int CA, const void* rowsB,
+                                        int totalB, int firstB, int nrowsB, int CB, double weightB, int64_t nvox,
+                                        const float* gamma, const float* beta, int G, float eps, float* scale,
+                                        float* shift, float* bound, void* workspace, size_t workspace_bytes, void* ticket,
+                                        bfm_stream_t stream) {
+    if (firstA < 0 || nrowsA <= 0 || firstA + nrowsA > totalA) return BFM_E_ARG;
+    if (CB > 0 && (firstB < 0 || nrowsB <= 0 || firstB + nrowsB > totalB)) return BFM_E_ARG;
+    return gn_rows_sliced(rowsA, nrowsA, CA, rowsB, nrowsB, CB, weightB, nvox, gamma, beta, G, eps, scale, shift, bound,
+                          nullptr, nullptr, workspace, workspace_bytes, ticket, stream, totalA, firstA, CB > 0 ? totalB : 0,
+                          CB > 0 ? firstB : 0);
+}
+
+static int gn_rows_sliced(const void* rowsA, int nrowsA, int CA, const void* rowsB, int nrowsB, int CB,
+                          double weightB, int64_t nvox, const float* gamma, const float* beta, int G,
+                          float eps, float* scale, float* shift, float* bound, float* mean_out,
+                          float* rstd_out, void* workspace, size_t workspace_bytes, void* ticket,
+                          bfm_stream_t stream, int totalA, int firstA, int totalB, int firstB) {
     if (!rowsA || nrowsA <= 0 || CA <= 0 || nvox <= 0 || !gamma || !beta || !scale || !shift || !bound) return BFM_E_ARG;
     if (CB < 0 || (CB > 0 && (!rowsB || nrowsB <= 0 || !(weightB > 0.0)))) return BFM_E_ARG;
     if ((reinterpret_cast<uintptr_t>(rowsA) & 7) || (CB > 0 && (reinterpret_cast<uintptr_t>(rowsB) & 7))) return BFM_E_ARG;
@@ -646,11 +676,11 @@ extern "C" int bfm_gn_stats_rows_train(const void* rowsA, int nrowsA, int CA, co
     // partials fit the workspace the two-launch form would have used
     if (ticket && needA + needB > 0 && G <= BFM_GN_TICKETS && (size_t)KS * Ctot * 24 <= needA + needB &&
         (size_t)cpg * 24 + (size_t)TPB * 24 <= 64 * 1024) {
-        RowsView va = rows_view(rowsA, nrowsA, CA);
+        RowsView va = rows_view(rowsA, totalA, CA, firstA);
         RowsSrc sa{va.sum, va.sq, va.mn, va.mx, nrowsA, CA, 1.0};
         RowsSrc sb{nullptr, nullptr, nullptr, nullptr, 0, 0, 1.0};
         if (CB > 0) {
-            RowsView vb = rows_view(rowsB, nrowsB, CB);
+            RowsView vb = rows_view(rowsB, totalB, CB, firstB);
             sb = RowsSrc{vb.sum, vb.sq, vb.mn, vb.mx, nrowsB, CB, weightB};
         }
         const size_t n = (size_t)KS * Ctot;
@@ -662,9 +692,9 @@ extern "C" int bfm_gn_stats_rows_train(const void* rowsA, int nrowsA, int CA, co
         if (rc != BFM_OK) (void)hipMemsetAsync(ticket, 0, (size_t)G * sizeof(int), st);    // never leave a partial count behind
         return rc;
     }
-    PartTab ta = rows_source(rowsA, nrowsA, CA, 1.0, ws, st);
+    PartTab ta = rows_source(rowsA, nrowsA, CA, 1.0, ws, st, totalA, firstA);
     PartTab tb{nullptr, nullptr, nullptr, nullptr, 0, 0, 1.0};
-    if (CB > 0) tb = rows_source(rowsB, nrowsB, CB, weightB, ws + needA, st);
+    if (CB > 0) tb = rows_source(rowsB, nrowsB, CB, weightB, ws + needA, st, totalB, firstB);
     hipLaunchKernelGGL(gn_finalize, dim3(G), dim3(TPB), fin_smem, st, ta, tb, G, (double)nvox, eps, gamma, beta, scale,
                        shift, bound, mean_out, rstd_out);
     return bfm_launch_status();

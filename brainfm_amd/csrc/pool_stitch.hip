@@ -12,6 +12,10 @@ template <int VEC>
 __global__ void maxpool2_kernel(const float* __restrict__ in, int C, int D, int H, int W, int d, int h, int w,
                                 float* __restrict__ out, double* __restrict__ rsum, double* __restrict__ rsq,
                                 float* __restrict__ rmn, float* __restrict__ rmx) {
+    // batch (bfm_maxpool2_batch): blockIdx.y = sample; a sample's blocks do exactly what they do in a launch of it alone
+    in += (int64_t)blockIdx.y * D * H * W * C;
+    out += (int64_t)blockIdx.y * d * h * w * C;
+    const size_t row0 = (size_t)blockIdx.y * gridDim.x;
     const int CV = C / VEC;
     float fs[VEC], fq[VEC], fmn[VEC], fmx[VEC];
 #pragma unroll
@@ -83,7 +87,7 @@ __global__ void maxpool2_kernel(const float* __restrict__ in, int C, int D, int 
                 S += ls[tt * VEC + k]; Q += lq[tt * VEC + k];
                 MN = fminf(MN, lmn[tt * VEC + k]); MX = fmaxf(MX, lmx[tt * VEC + k]);
             }
-            const size_t o = (size_t)blockIdx.x * C + c;
+            const size_t o = (row0 + blockIdx.x) * C + c;
             rsum[o] = S; rsq[o] = Q; rmn[o] = MN; rmx[o] = MX;
         }
     }
@@ -534,6 +538,39 @@ extern "C" int bfm_maxpool2_ex(const float* in, int C, int D, int H, int W, floa
                                rsum, rsq, rmn, rmx);
     else hipLaunchKernelGGL(maxpool2_kernel<1>, dim3(nb), dim3(256), 0, bfm_s(stream), in, C, D, H, W, d, h, w, out, rsum,
                             rsq, rmn, rmx);
+    return bfm_launch_status();
+}
+
+// S same-shape samples (S,D,H,W,C) -> (S,D/2,H/2,W/2,C) in one launch (the batched levels, engine.deep_region); moment rows
+// [S * bfm_maxpool2_batch_rows()][C], at most 128 per sample so that bfm_gn_stats_rows_batch reads them directly.  A sample's
+// output and rows do not depend on S.
+extern "C" int bfm_maxpool2_batch_rows(int C, int D, int H, int W) {
+    const int n = bfm_maxpool2_rows(C, D, H, W);
+    return n > 128 ? 128 : n;
+}
+
+extern "C" int bfm_maxpool2_batch(const float* in, int C, int S, int D, int H, int W, float* out, void* moment_rows,
+                                  bfm_stream_t stream) {
+    if (!in || !out || C <= 0 || S < 1 || S > 65535 || D < 2 || H < 2 || W < 2) return BFM_E_ARG;
+    if ((C % 4) || ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15)) return BFM_E_SHAPE;
+    const int d = D / 2, h = H / 2, w = W / 2;
+    const int nb = std::min(128, grid_for((int64_t)d * h * w * (C / 4)));
+    double *rsum = nullptr, *rsq = nullptr;
+    float *rmn = nullptr, *rmx = nullptr;
+    size_t smem = 0;
+    if (moment_rows) {
+        if (bfm_maxpool2_batch_rows(C, D, H, W) != nb) return BFM_E_SHAPE;
+        if (reinterpret_cast<uintptr_t>(moment_rows) & 7) return BFM_E_ARG;
+        char* rb = static_cast<char*>(moment_rows);
+        const size_t k = (size_t)S * nb * C;
+        rsum = reinterpret_cast<double*>(rb);
+        rsq = reinterpret_cast<double*>(rb + k * 8);
+        rmn = reinterpret_cast<float*>(rb + k * 16);
+        rmx = reinterpret_cast<float*>(rb + k * 20);
+        smem = (size_t)256 * 4 * 24;
+    }
+    hipLaunchKernelGGL(maxpool2_kernel<4>, dim3(nb, S), dim3(256), smem, bfm_s(stream), in, C, D, H, W, d, h, w, out, rsum,
+                       rsq, rmn, rmx);
     return bfm_launch_status();
 }
 

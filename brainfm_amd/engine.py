@@ -472,6 +472,8 @@ class UNetEngine:
         st = L.stream_ptr()
         ra = getattr(A, "_bfm_rows", None) if self.fuse_stats else None
         rb = getattr(B, "_bfm_rows", None) if (self.fuse_stats and B is not None) else None
+        if self.tape is not None and ((ra is not None and len(ra) > 2) or (rb is not None and len(rb) > 2)):
+            ra = rb = None                                   # (slices of a batch's rows: the inference flow only)
         exact2 = B is None or tuple(dims) == tuple(2 * v for v in lo_dims)
         mean = rstd = None
         if self.tape is not None:
@@ -481,6 +483,18 @@ class UNetEngine:
         if ra is not None and (B is None or (rb is not None and exact2)):
             need = self.lib.bfm_gn_stats_rows_workspace(ra[1], ca, rb[1] if rb is not None else 0, cb)
             ws = self._workspace(max(need, ws_min))
+            if (len(ra) > 2 or (rb is not None and len(rb) > 2)) and self.tape is None:
+                # a source that is one sample of a batched producer: its rows are a slice (total, first) of the batch's
+                ta, fa = (ra[2], ra[3]) if len(ra) > 2 else (ra[1], 0)
+                tb, fb = ((rb[2], rb[3]) if len(rb) > 2 else (rb[1], 0)) if rb is not None else (0, 0)
+                L.check(self.lib.bfm_gn_stats_rows_sliced(L.ptr(ra[0]), ta, fa, ra[1], ca,
+                                                          L.ptr(rb[0]) if rb is not None else None, tb, fb,
+                                                          rb[1] if rb is not None else 0, cb, 8.0, D * H * W, L.ptr(ly.gamma),
+                                                          L.ptr(ly.beta), ly.groups, self.eps, L.ptr(scale), L.ptr(shift),
+                                                          L.ptr(bound), L.ptr(ws), ws.numel(),
+                                                          L.ptr(self._gn_ticket()) if self.gn_one_launch else None, st),
+                        "gn_stats_rows(slice) " + ly.name)
+                return ws
             L.check(self.lib.bfm_gn_stats_rows_train(L.ptr(ra[0]), ra[1], ca, L.ptr(rb[0]) if rb is not None else None,
                                                      rb[1] if rb is not None else 0, cb, 8.0, D * H * W, L.ptr(ly.gamma),
                                                      L.ptr(ly.beta), ly.groups, self.eps, L.ptr(scale), L.ptr(shift),
@@ -854,6 +868,25 @@ class UNetEngine:
             self.tape.append(dict(pool_in=X, pool_dims=tuple(dims)))
         return out, (D // 2, H // 2, W // 2)
 
+    def maxpool_batch(self, X, dims):
+        """MaxPool3d(2) of a batch (S,D,H,W,C) in one launch; per sample the bits of bfm_maxpool2."""
+        S, (D, H, W), c = X.shape[0], dims, X.shape[-1]
+        out = torch.empty((S, D // 2, H // 2, W // 2, c), dtype=torch.float32, device=self.device)
+        if c % 4 or self.tape is not None:
+            for s_ in range(S):
+                self.maxpool(X[s_], dims, out=out[s_])
+            return out
+        rows = None
+        if self.fuse_stats:
+            n = self.lib.bfm_maxpool2_batch_rows(c, D, H, W)
+            if n > 0:
+                rows = (torch.empty(self.lib.bfm_moment_rows_bytes(S * n, c), dtype=torch.uint8, device=self.device), n)
+        L.check(self.lib.bfm_maxpool2_batch(L.ptr(X), c, S, D, H, W, L.ptr(out), L.ptr(rows[0]) if rows is not None else None,
+                                            L.stream_ptr()), "maxpool2_batch")
+        if rows is not None:
+            out._bfm_rows = rows
+        return out
+
     # ------------------------------------------------------------------ backbone
     # ------------------------------------------------------------------ the deep levels, batched over samples
     # Levels >= deep_from (20^3 voxels and fewer on a 160^3 tile) are bound by their weights: 253 M of the 264 M
@@ -1104,11 +1137,9 @@ class UNetEngine:
             if min(d) < 2:
                 raise L.BfmError("volume too small for %d pooling levels" % (len(self.enc) - 1))
             d2 = tuple(v // 2 for v in d)
-            P = torch.empty((S,) + d2 + (x.shape[-1],), dtype=torch.float32, device=self.device)
-            for s_ in range(S):
-                self.maxpool(x[s_], d, out=P[s_])
-            d = d2                                           # (statistics of pooled batches are always recomputed from the
-            x = self.batch_conv(l1, P, d)                    # tensor: the per-sample pooling rows are separate tables)
+            P = self.maxpool_batch(x, d)                     # one launch for the batch; its rows feed the next GroupNorm
+            d = d2
+            x = self.batch_conv(l1, P, d)
             x = self.batch_conv(l2, x, d)
             skips.insert(0, (x, d))
         feats = [(x, d)]
@@ -1203,7 +1234,11 @@ class UNetEngine:
         for s_, skips in enumerate(tops):
             feats = [(f[s_], fd) for f, fd in deep_feats]
             mask_img = xs[s_] if (mask_last and self.mask_skip and xs[s_].shape[-1] == 1) else None
-            feats += self.decoder_top(skips, out[s_], d, mask_img=mask_img, df=df, image=xs[s_])
+            o_s = out[s_]
+            rws = getattr(out, "_bfm_rows", None)
+            if rws is not None:                               # this sample's rows of the region's last layer
+                o_s._bfm_rows = (rws[0], rws[1], len(tops) * rws[1], s_ * rws[1])
+            feats += self.decoder_top(skips, o_s, d, mask_img=mask_img, df=df, image=xs[s_])
             res.append(feats)
         return res
 

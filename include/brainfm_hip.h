@@ -201,6 +201,12 @@ int bfm_gn_stats_rows_batch(const void* rowsA, int nrowsA_per_sample, int CA, co
 int bfm_maxpool2_rows(int C, int D, int H, int W);
 int bfm_maxpool2_ex(const float* in, int C, int D, int H, int W, float* out, void* moment_rows /*or NULL*/,
                     bfm_stream_t stream);
+/* nn.MaxPool3d(2) (buildingblocks.py:185-186) of S same-shape samples in one launch (the batched levels); moment rows
+ * [S * bfm_maxpool2_batch_rows()][C] (at most 128 per sample: bfm_gn_stats_rows_batch reads them directly).  A sample's
+ * output and rows do not depend on S.  C % 4 == 0. */
+int bfm_maxpool2_batch_rows(int C, int D, int H, int W);
+int bfm_maxpool2_batch(const float* in, int C, int S, int D, int H, int W, float* out, void* moment_rows /*or NULL*/,
+                       bfm_stream_t stream);
 int bfm_conv3x3x3_stem_rows(int D, int H, int W);
 int bfm_conv3x3x3_stem_ex(const float* A, int D, int H, int W, const float* scale, const float* shift,
                           const float* bound, const float* wpacked_direct, int Cout, float slope, float* out,
@@ -225,6 +231,14 @@ int bfm_gn_stats_rows_train(const void* rowsA, int nrowsA, int CA, const void* r
                             int64_t nvox, const float* gamma, const float* beta, int G, float eps, float* scale,
                             float* shift, float* bound, float* mean_out, float* rstd_out, void* workspace,
                             size_t workspace_bytes, void* ticket, bfm_stream_t stream);
+
+/* the same with each table given as rows [first, first + nrows) of a larger table of `total` rows: one sample's rows of a
+ * batched producer ([S * nrows][C] planes, bfm_conv3x3x3_mfma_batch), read where they lie -- the first decoder above the
+ * batched levels (buildingblocks.py:265-276: its upsampled source is one sample of the batch's output) */
+int bfm_gn_stats_rows_sliced(const void* rowsA, int totalA, int firstA, int nrowsA, int CA, const void* rowsB, int totalB,
+                             int firstB, int nrowsB, int CB, double weightB, int64_t nvox, const float* gamma,
+                             const float* beta, int G, float eps, float* scale, float* shift, float* bound,
+                             void* workspace, size_t workspace_bytes, void* ticket, bfm_stream_t stream);
 
 /* Winograd F(4,3) along x (conv3d_wino4.hip): the same SingleConv body (buildingblocks.py:31-60) with 13.5 tap-rows
  * per output voxel instead of F(2,3)'s 18 -- dense boxes, one source, no split-K; rounding ~2x F(2,3)'s per layer
