@@ -136,6 +136,10 @@ SIGNATURES = {
     "bfm_uniform_boxes_bytes": (_Z, [_I, _I, _I, _I]),
     "bfm_conv3x3x3_wino_uniform_scratch": (_Z, [_I]),
     "bfm_conv3x3x3_wino_uniform": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _P, _P, _P]),
+    "bfm_conv3x3x3_wino_pool_ok": (_I, [_I, _I, _I, _I]),
+    "bfm_conv3x3x3_wino_pool": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _P, _P, _P]),
+    "bfm_conv3x3x3_wino_uniform_pool": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P,
+                                             _P]),
     "bfm_conv3x3x3_wino_masked_workspace": (_Z, [_I, _I, _I, _I]),
     "bfm_conv3x3x3_wino_masked": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _I, _I, _F, _I, _I, _P, _P, _P, _Z, _P]),
     "bfm_maxpool2_rows": (_I, [_I, _I, _I, _I]),

@@ -54,6 +54,11 @@ struct WinoParams {
     float* uni_acc;                  // [27][NT][2][16][NTHR][2]: those boxes' output-transformed sums, for their class mates
     const int* list;                 // sparse forms: the boxes to compute, ascending
     const int* list_n;               // ... their number, on the device
+    // fused MaxPool3d(2) (the POOL kernels: box 8 x 8 x 4, every box inside the tensor): the pooled output (D/2,H/2,W/2,Cout)
+    // and its own moment rows [nMt][Cout]
+    float* pool_out;
+    double *prsum, *prsq;
+    float *prmn, *prmx;
 };
 
 __device__ __forceinline__ int row_perm(int l) {        // as conv_mfma: each 16-lane b128 group reads 16 consecutive positions
@@ -114,7 +119,15 @@ __device__ __forceinline__ void split_store4(const float (&t)[4], unsigned char*
 // the bits its own main loop and transform would have produced -- in the same thread order, and runs the rest of the
 // epilogue (accumulate mode, activation, store, moment rows) on them: no staging, no weights, no matrix products, no LDS.  Two kernels rather than a branch: a second loop body in one kernel made the
 // allocator spill 54 registers and the layer 25 % slower.
-template <int NPASS, int MODE>
+// POOL = 1 (encoder layers whose output nn.MaxPool3d(2) reads next, buildingblocks.py:185-186; box 8 x 8 x 4 with every box
+// inside the tensor, checked by the host): the epilogue also writes the pooled tensor and its moment rows -- the 2 x 2 x 2
+// windows are whole inside a box, so the separate pooling launch and its read of the full-resolution output go away.  A
+// thread's 16 pairs are (j, h) = (row0 & 1, (row0 >> 1) + 4 (it & 1)), d = it >> 1: the x pair of a window is the Winograd
+// pair, its d pair is in the thread, its h pair in the thread 64 further (row0 ^ 2), met through LDS.  max in the order
+// bfm_maxpool2 takes it (dz, dy, dx), NaN kept the same way.
+__device__ __forceinline__ float pool_max(float m, float q) { return (q != q) ? q : fmaxf(m, q); }
+
+template <int NPASS, int MODE, int POOL = 0>
 __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
     constexpr bool UNI = MODE == 3;                      // this kernel computes the flagged boxes (one row block each)
     constexpr bool BY_FLAG = MODE == 2 || MODE == 3;
@@ -358,7 +371,8 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
     // is then uniform base + one 32-bit lane offset.  The general path spent ~1600 of the epilogue's 3200 vector
     // instructions per box on q -> (d,h,j) -> address chains, 480 of them quarter-rate 32/64-bit multiplies -- more
     // vector work than the four K-chunks of a 64-channel layer's main loop.
-    const bool interior = z0 + p.TD <= p.D && y0 + p.TH <= p.H && x0 + p.TW <= p.W;      // wave-uniform
+    // (the POOL kernels are launched on tensors their box tiles exactly: no other path is compiled for them)
+    const bool interior = POOL == 1 || (z0 + p.TD <= p.D && y0 + p.TH <= p.H && x0 + p.TW <= p.W);      // wave-uniform
     const int th_shift = p.thp_shift - p.pw_shift;
     unsigned off_t = 0;
     int un0 = 0, un3 = 0;
@@ -374,6 +388,9 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
     for (int nb = 0; nb < 2; ++nb) {
         __syncthreads();                                           // A planes (or the previous round) fully consumed
         float fs = 0.f, fq = 0.f, fmn = INFINITY, fmx = -INFINITY;   // this thread's column, its 16 pairs (<= 32 values)
+        float pm[8];                                               // POOL: this thread's row of its 8 windows (hb, dp)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pm[k] = -INFINITY;
         if (interior) {
             float* ob = p.out + nt * 64 + nb * 32;
             float prev0[16], prev1[16];
@@ -424,6 +441,9 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
                 o[off_t + (unsigned)p.Cout] = y1v;
                 fs += y0v; fq = fmaf(y0v, y0v, fq); fmn = fminf(fmn, y0v); fmx = fmaxf(fmx, y0v);
                 fs += y1v; fq = fmaf(y1v, y1v, fq); fmn = fminf(fmn, y1v); fmx = fmaxf(fmx, y1v);
+                if constexpr (POOL == 1) {                          // window (hb, dp) = (it & 1, it >> 2): dz-major, then dx
+                    pm[(it & 1) * 4 + (it >> 2)] = pool_max(pool_max(pm[(it & 1) * 4 + (it >> 2)], y0v), y1v);
+                }
             }
         } else {
         // accumulate mode: what `out` holds is fetched now, so that its latency hides under the LDS exchange
@@ -506,11 +526,66 @@ __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {
                 p.rsum[o] = S; p.rsq[o] = Q; p.rmn[o] = MN; p.rmx[o] = MX;
             }
         }
+        if constexpr (POOL == 1) {
+            if (interior) {                                            // (the host launches these kernels on such tensors only)
+            // window (hb, dp) of the pair of threads (row0, row0 ^ 2) = rows h, h ^ 1: each thread has the maximum over its
+            // row's two d slices and x pair (pm, in bfm_maxpool2's order dz, dx); the even-h thread finishes the windows of
+            // hb = 0, the odd-h one those of hb = 1 (dy = 0 first)
+            const int POOL_OFF = UNI ? 6144 : 0;                       // m is consumed (barrier below); UNI: behind its row fold
+            float* xs = reinterpret_cast<float*>(lds + POOL_OFF);      // [8 (hb, dp)][NTHR]
+            __syncthreads();                                           // every thread is done with m
+#pragma unroll
+            for (int k = 0; k < 8; ++k) xs[k * NTHR + tid] = pm[k];
+            __syncthreads();
+            const int hb = (row0 >> 1) & 1;
+            const int te = tid & ~64, to = tid | 64;                   // the pair's even-h / odd-h thread (row0 bit 1 = tid bit 6)
+            float ps = 0.f, pq = 0.f, pmn = INFINITY, pmx = -INFINITY;
+            const int H2 = p.H >> 1, W2 = p.W >> 1;
+            float* pb = p.pool_out + nt * 64 + nb * 32 + col +
+                        (((int64_t)(z0 >> 1) * H2 + (y0 >> 1) + (row0 >> 2) + 2 * hb) * W2 + (x0 >> 1) + (row0 & 1)) * p.Cout;
+            const unsigned zstep = (unsigned)(H2 * W2 * p.Cout);       // one pooled slice (fits: the tensor has < 2^31 elements)
+            const float* xe = xs + hb * 4 * NTHR + te;
+            const float* xo = xs + hb * 4 * NTHR + to;
+#pragma unroll
+            for (int dp = 0; dp < 4; ++dp) {
+                const float mv = pool_max(pool_max(-INFINITY, xe[dp * NTHR]), xo[dp * NTHR]);
+                pb[dp * zstep] = mv;
+                ps += mv; pq = fmaf(mv, mv, pq); pmn = fminf(pmn, mv); pmx = fmaxf(pmx, mv);
+            }
+            if (p.prsum != nullptr) {
+                double* ls2 = reinterpret_cast<double*>(lds + POOL_OFF + 8 * NTHR * sizeof(float));        // behind xs
+                double* lq2 = ls2 + 256;
+                float* lmn2 = reinterpret_cast<float*>(lq2 + 256);
+                float* lmx2 = lmn2 + 256;
+                ls2[row0 * 32 + col] = (double)ps; lq2[row0 * 32 + col] = (double)pq;
+                lmn2[row0 * 32 + col] = pmn; lmx2[row0 * 32 + col] = pmx;
+                __syncthreads();
+                if (tid < 32) {
+                    double S = 0.0, Q = 0.0;
+                    float MN = INFINITY, MX = -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        S += ls2[r * 32 + tid]; Q += lq2[r * 32 + tid];
+                        MN = fminf(MN, lmn2[r * 32 + tid]); MX = fmaxf(MX, lmx2[r * 32 + tid]);
+                    }
+                    const size_t o = (size_t)mt * p.Cout + nt * 64 + nb * 32 + tid;
+                    p.prsum[o] = S; p.prsq[o] = Q; p.prmn[o] = MN; p.prmx[o] = MX;
+                }
+            }
+            }
+        }
     }
 }
 
 template <int NPASS>
 __global__ void __launch_bounds__(NTHR, 2) conv_wino(const WinoParams p) { conv_wino_body<NPASS, 0>(p); }
+// the dense form and the uniform-box pair with the pooling fused (POOL above)
+template <int NPASS>
+__global__ void __launch_bounds__(NTHR, 2) conv_wino_pool(const WinoParams p) { conv_wino_body<NPASS, 0, 1>(p); }
+template <int NPASS>
+__global__ void __launch_bounds__(NTHR, 2) conv_wino_rest_pool(const WinoParams p) { conv_wino_body<NPASS, 2, 1>(p); }
+template <int NPASS>
+__global__ void __launch_bounds__(NTHR, 2) conv_wino_uniform_pool(const WinoParams p) { conv_wino_body<NPASS, 3, 1>(p); }
 
 // the same kernel for the tile loop's last convolution: boxes whose image voxels (p.mask_img) are all zero return at once
 template <int NPASS>
@@ -808,7 +883,44 @@ extern "C" int bfm_conv3x3x3_wino(const float* A, int CA, int D, int H, int W, c
 static int wino_launch(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                        const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes, int flags,
                        float* out, void* moment_rows, const float* mask_img, bfm_stream_t stream,
-                       const unsigned char* uni_flags = nullptr, float* uni_acc = nullptr, void* mask_ws = nullptr);
+                       const unsigned char* uni_flags = nullptr, float* uni_acc = nullptr, void* mask_ws = nullptr,
+                       float* pool_out = nullptr, void* pool_rows = nullptr);
+
+static bool pool_ok_box(int TD, int TH, int TW, int D, int H, int W) {
+    return TD == 8 && TH == 8 && TW == 4 && D % 8 == 0 && H % 8 == 0 && W % 4 == 0;
+}
+
+// 1 when bfm_conv3x3x3_wino_pool / _wino_uniform_pool take a (D,H,W) tensor: the kernel's box there is 8 x 8 x 4 and tiles the
+// tensor exactly (a 2 x 2 x 2 pooling window is then whole inside one box); 0: pool with bfm_maxpool2 afterwards
+extern "C" int bfm_conv3x3x3_wino_pool_ok(int D, int H, int W, int passes) {
+    int TD, TH, TW;
+    if (D <= 0 || H <= 0 || W <= 0 || !choose_box(D, H, W, passes == 3 ? 2 : 1, TD, TH, TW)) return 0;
+    return pool_ok_box(TD, TH, TW, D, H, W) ? 1 : 0;
+}
+
+// bfm_conv3x3x3_wino_ex that also writes nn.MaxPool3d(2) of its output (buildingblocks.py:185-186: what the next encoder
+// level reads) into pooled (D/2,H/2,W/2,Cout) and that tensor's moment rows [bfm_conv3x3x3_wino_rows()][Cout] into
+// pooled_rows (or NULL): out and moment_rows as bfm_conv3x3x3_wino_ex writes them, pooled the bits of bfm_maxpool2(out)
+extern "C" int bfm_conv3x3x3_wino_pool(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
+                                       const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope,
+                                       int passes, int flags, float* out, void* moment_rows, float* pooled,
+                                       void* pooled_rows, bfm_stream_t stream) {
+    if (!pooled) return BFM_E_ARG;
+    return wino_launch(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out, moment_rows,
+                       nullptr, stream, nullptr, nullptr, nullptr, pooled, pooled_rows);
+}
+
+// the same for the uniform-box pair (bfm_conv3x3x3_wino_uniform)
+extern "C" int bfm_conv3x3x3_wino_uniform_pool(const float* A, int CA, int D, int H, int W, const float* scale,
+                                               const float* shift, const float* bound, int G, const void* wpacked,
+                                               int wexp, int Cout, float slope, int passes, int flags, float* out,
+                                               void* moment_rows, const unsigned char* uniform_flags, void* scratch,
+                                               float* pooled, void* pooled_rows, bfm_stream_t stream) {
+    if (!uniform_flags || !scratch || !pooled || (flags & ~1)) return BFM_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(uniform_flags) & 3) || (reinterpret_cast<uintptr_t>(scratch) & 15)) return BFM_E_ARG;
+    return wino_launch(A, CA, D, H, W, scale, shift, bound, G, wpacked, wexp, Cout, slope, passes, flags, out, moment_rows,
+                       nullptr, stream, uniform_flags, static_cast<float*>(scratch), nullptr, pooled, pooled_rows);
+}
 
 extern "C" size_t bfm_uniform_boxes_bytes(int D, int H, int W, int passes) {
     int TD, TH, TW;
@@ -887,7 +999,7 @@ extern "C" int bfm_conv3x3x3_wino_masked(const float* A, int CA, int D, int H, i
 static int wino_launch(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
                        const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes, int flags,
                        float* out, void* moment_rows, const float* mask_img, bfm_stream_t stream,
-                       const unsigned char* uni_flags, float* uni_acc, void* mask_ws) {
+                       const unsigned char* uni_flags, float* uni_acc, void* mask_ws, float* pool_out, void* pool_rows) {
     const int accumulate = flags & 1;
     if (flags & ~1) return BFM_E_ARG;                           // bit 0 = accumulate; nothing else is defined
     if (!A || CA <= 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !bound || G <= 0 || !wpacked || !out)
@@ -931,10 +1043,28 @@ static int wino_launch(const float* A, int CA, int D, int H, int W, const float*
         p.rmn = reinterpret_cast<float*>(rb + n * 16);
         p.rmx = reinterpret_cast<float*>(rb + n * 20);
     }
+    if (pool_out) {                                            // the POOL kernels: box 8 x 8 x 4, every box inside the tensor
+        if (mask_img || !pool_ok_box(p.TD, p.TH, p.TW, D, H, W)) return BFM_E_SHAPE;
+        if (reinterpret_cast<uintptr_t>(pool_out) & 15) return BFM_E_ARG;
+        p.pool_out = pool_out;
+        if (pool_rows) {
+            if (reinterpret_cast<uintptr_t>(pool_rows) & 7) return BFM_E_ARG;
+            char* rb = static_cast<char*>(pool_rows);
+            const size_t n = (size_t)p.nMt * Cout;
+            p.prsum = reinterpret_cast<double*>(rb);
+            p.prsq = reinterpret_cast<double*>(rb + n * 8);
+            p.prmn = reinterpret_cast<float*>(rb + n * 16);
+            p.prmx = reinterpret_cast<float*>(rb + n * 20);
+        }
+    } else if (pool_rows) return BFM_E_ARG;
     if ((int64_t)p.nMt * p.NT > 0x7fffffff) return BFM_E_SHAPE;
     if (smem > 80 * 1024) return BFM_E_SHAPE;
     static bool attr_done = false;
     if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pool<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_pool<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_rest_pool<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_rest_pool<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             80 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -965,6 +1095,21 @@ static int wino_launch(const float* A, int CA, int D, int H, int W, const float*
         p.list = cnt + 1; p.list_n = cnt;
         if (passes == 3) hipLaunchKernelGGL(conv_wino_masked<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
         else hipLaunchKernelGGL(conv_wino_masked<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+        return bfm_launch_status();
+    }
+    if (uni_flags && pool_out) {
+        const int* cnt = p.uni_first + 27;
+        p.list = cnt + 2; p.list_n = cnt;
+        if (passes == 3) hipLaunchKernelGGL(conv_wino_rest_pool<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+        else hipLaunchKernelGGL(conv_wino_rest_pool<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+        p.list = cnt + 2 + p.nMt; p.list_n = cnt + 1;
+        if (passes == 3) hipLaunchKernelGGL(conv_wino_uniform_pool<3>, grid, dim3(NTHR), 20480, bfm_s(stream), p);
+        else hipLaunchKernelGGL(conv_wino_uniform_pool<1>, grid, dim3(NTHR), 20480, bfm_s(stream), p);
+        return bfm_launch_status();
+    }
+    if (pool_out) {
+        if (passes == 3) hipLaunchKernelGGL(conv_wino_pool<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+        else hipLaunchKernelGGL(conv_wino_pool<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
         return bfm_launch_status();
     }
     if (uni_flags) {                                           // disjoint boxes: the two launches may overlap

@@ -170,6 +170,8 @@ class UNetEngine:
         self.upfold_min = int(os.environ.get("BFM_UPFOLD_MIN", "250"))    # fewest low-res voxels worth it (split-K below ~4000)
         # GroupNorm moments from rows the producing conv wrote in its epilogue instead of a pass over the activation
         self.fuse_stats = os.environ.get("BFM_FUSE_STATS", "1") != "0"
+        # MaxPool3d(2) in the epilogue of the F(2,3) layers that feed it (round 5; 0: the separate launch, same bits)
+        self.fuse_pool = os.environ.get("BFM_FUSE_POOL", "1") != "0"
         self.prof_reps = 1
         self.prof = None            # bench.py: list collecting (start_event, end_event, flops, bytes) per MFMA conv launch
         sd = self._normalise_keys(state_dict)
@@ -517,7 +519,7 @@ class UNetEngine:
                                   scale=scale, shift=shift, bound=bound, mean=mean, rstd=rstd, out=out))
 
     def _conv_launch(self, ly, A, ca, B, cb, dims, upp, scale, shift, bound, groups, cfg, out, ws, rows=None, slope=None,
-                     mask_img=None, uni_flags=None):
+                     mask_img=None, uni_flags=None, pool=None):
         """One launch of the planned variant of GN-apply + conv + LeakyReLU (cfg[6]: 0/1/2 conv_mfma family,
         3 Winograd; cfg[7] bit 0: accumulate onto `out`).  mask_img (variant 3 only): the tile's input image; boxes of
         output voxels where it is all zero are left uncomputed (bfm_conv3x3x3_wino_masked).  uni_flags (variant 3, one
@@ -537,6 +539,25 @@ class UNetEngine:
                                                        groups, L.ptr(ly.wpacked), ly.wexp, ly.cout, slope, self.passes,
                                                        cfg[7] & 1, L.ptr(out), L.ptr(mask_img), L.ptr(mws), nws, st),
                     "conv_wino(masked) " + ly.name)
+            return
+        if pool is not None:
+            # (pooled tensor, its moment rows): the F(2,3) kernel writes MaxPool3d(2) of its output too (single_conv(pool=True))
+            if cfg[6] != 3 or cb or mask_img is not None:
+                raise L.BfmError("the fused pooling is the one-source F(2,3) kernel's")
+            pooled, prow = pool
+            if uni_flags is not None:
+                scratch = torch.empty(self.lib.bfm_conv3x3x3_wino_uniform_scratch(ly.cout), dtype=torch.uint8,
+                                      device=self.device)
+                L.check(self.lib.bfm_conv3x3x3_wino_uniform_pool(
+                    L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound), groups, L.ptr(ly.wpacked), ly.wexp,
+                    ly.cout, slope, self.passes, cfg[7] & 1, L.ptr(out), L.ptr(rows[0]) if rows is not None else None,
+                    L.ptr(uni_flags), L.ptr(scratch), L.ptr(pooled), L.ptr(prow[0]) if prow is not None else None, st),
+                        "conv_wino(uniform, pool) " + ly.name)
+            else:
+                L.check(self.lib.bfm_conv3x3x3_wino_pool(
+                    L.ptr(A), ca, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound), groups, L.ptr(ly.wpacked), ly.wexp,
+                    ly.cout, slope, self.passes, cfg[7] & 1, L.ptr(out), L.ptr(rows[0]) if rows is not None else None,
+                    L.ptr(pooled), L.ptr(prow[0]) if prow is not None else None, st), "conv_wino(pool) " + ly.name)
             return
         if uni_flags is not None and cfg[6] == 4 and not self._same_boxes(dims):
             uni_flags = None                                # the flags are per box of conv_wino's grid: dense launch, same bits
@@ -629,7 +650,7 @@ class UNetEngine:
         return (buf, n)
 
     # ------------------------------------------------------------------ one SingleConv
-    def single_conv(self, ly, A, dims, B=None, lo_dims=None, mask_img=None, uni_flags=None):
+    def single_conv(self, ly, A, dims, B=None, lo_dims=None, mask_img=None, uni_flags=None, pool=False):
         """GroupNorm -> Conv3d(3,p=1) -> LeakyReLU on cat((A, nearest_up(B))).
         A: (D,H,W,CA) fp32, B: (d,h,w,CB) fp32 or None.  Returns (D,H,W,Cout).
         mask_img: (D,H,W) image; the caller promises to look at the output only where it is non-zero (the tile loop's
@@ -668,6 +689,17 @@ class UNetEngine:
             if uni_flags is not None and not (cfg[6] in (3, 4) and B is None and mask_img is None):
                 uni_flags = None
             rows = self._rows_for(ly.cin, ly.cout, dims, cfg) if mask_img is None else None
+            # pool: the caller pools this output next (an encoder level's second conv): where the F(2,3) kernel's box allows
+            # it writes MaxPool3d(2) of the output and that tensor's moment rows in its epilogue; maxpool() then returns them
+            pl = None
+            if (pool and cfg[6] == 3 and B is None and mask_img is None and self.tape is None and self.fuse_pool
+                    and min(dims) >= 2 and self.lib.bfm_conv3x3x3_wino_pool_ok(D, H, W, self.passes)):
+                pooled = torch.empty((D // 2, H // 2, W // 2, ly.cout), dtype=torch.float32, device=self.device)
+                prow = None
+                if self.fuse_stats:
+                    n = self.lib.bfm_conv3x3x3_wino_rows(D, H, W, self.passes)
+                    prow = (torch.empty(self.lib.bfm_moment_rows_bytes(n, ly.cout), dtype=torch.uint8, device=self.device), n)
+                pl = (pooled, prow)
             if self.prof is not None:
                 # instrumented pass (bench.py): the launch is issued prof_reps times back to back inside one HIP
                 # event pair (the result is idempotent), so the bracket holds kernel time, not host submission gaps
@@ -676,9 +708,13 @@ class UNetEngine:
                 ev[0].record()
             for _ in range(reps):
                 self._conv_launch(ly, A, ca, B, cb, dims, upp, scale, shift, bound, ly.groups, cfg, out, ws, rows,
-                                  mask_img=mask_img, uni_flags=uni_flags)
+                                  mask_img=mask_img, uni_flags=uni_flags, pool=pl)
             if rows is not None:
                 out._bfm_rows = rows
+            if pl is not None:
+                if pl[1] is not None:
+                    pl[0]._bfm_rows = pl[1]
+                out._bfm_pooled = (pl[0], (D // 2, H // 2, W // 2))
             if ev is not None:
                 ev[1].record()
                 nv = D * H * W
@@ -853,6 +889,9 @@ class UNetEngine:
     def maxpool(self, X, dims, out=None):
         D, H, W = dims
         c = X.shape[-1]
+        fused = getattr(X, "_bfm_pooled", None)
+        if fused is not None and out is None and self.tape is None:
+            return fused                                     # written by the producing conv's epilogue (single_conv(pool=True))
         if out is None:
             out = torch.empty((D // 2, H // 2, W // 2, c), dtype=torch.float32, device=self.device)
         rows = None
@@ -1174,7 +1213,7 @@ class UNetEngine:
             uf1 = self.uniform_flags(x_cl, dims, UR[("enc", i, 0)], i) if ("enc", i, 0) in UR else None
             x = self.single_conv(l1, x, d, uni_flags=uf1)
             uf2 = self.uniform_flags(x_cl, dims, UR[("enc", i, 1)], i) if ("enc", i, 1) in UR else None
-            x = self.single_conv(l2, x, d, uni_flags=uf2)
+            x = self.single_conv(l2, x, d, uni_flags=uf2, pool=i + 1 < len(self.enc))
             skips.insert(0, (x, d))
         skips = skips[1:]
         feats = [(x, d)]
@@ -1191,7 +1230,8 @@ class UNetEngine:
         """Encoder levels < df (default deep_from) of one sample: ([(skip, dims)] shallowest first, top = last of them)."""
         skips = []
         x, d = x_cl, tuple(dims)
-        for i, (l1, l2) in enumerate(self.enc[:self.deep_from if df is None else df]):
+        nlev = self.deep_from if df is None else df
+        for i, (l1, l2) in enumerate(self.enc[:nlev]):
             if i > 0:
                 if min(d) < 2:
                     raise L.BfmError("volume %s too small for %d pooling levels" % (dims, len(self.enc) - 1))
@@ -1200,7 +1240,7 @@ class UNetEngine:
             uf1 = self.uniform_flags(x_cl, dims, UR[("enc", i, 0)], i) if ("enc", i, 0) in UR else None
             x = self.single_conv(l1, x, d, uni_flags=uf1)
             uf2 = self.uniform_flags(x_cl, dims, UR[("enc", i, 1)], i) if ("enc", i, 1) in UR else None
-            x = self.single_conv(l2, x, d, uni_flags=uf2)
+            x = self.single_conv(l2, x, d, uni_flags=uf2, pool=i + 1 < nlev)     # (the region pools the last level itself)
             skips.append((x, d))
         return skips
 

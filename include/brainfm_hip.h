@@ -152,6 +152,23 @@ int bfm_conv3x3x3_wino_uniform(const float* A, int CA, int D, int H, int W, cons
                                const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
                                int flags, float* out, void* moment_rows, const unsigned char* uniform_flags, void* scratch,
                                bfm_stream_t stream);
+/* SingleConv followed by nn.MaxPool3d(2) (Encoder.forward, buildingblocks.py:185-186, 211-214: the pooling of the next
+ * encoder level reads this layer's output) in one pass: out and moment_rows as bfm_conv3x3x3_wino_ex / _wino_uniform write
+ * them (the skip connection keeps the full-resolution tensor), pooled (D/2,H/2,W/2,Cout) = the bits of bfm_maxpool2(out), and
+ * pooled_rows (or NULL) = that tensor's moment rows, [bfm_conv3x3x3_wino_rows()][Cout].  The 2 x 2 x 2 windows must be whole
+ * inside one box of the kernel: bfm_conv3x3x3_wino_pool_ok() says whether a (D,H,W) tensor qualifies (its box is 8 x 8 x 4
+ * and tiles it exactly -- the 80- and 160-voxel tiles of the reference tiling at levels 0 and 1 do); BFM_E_SHAPE otherwise,
+ * nothing launched: pool with bfm_maxpool2_ex then. */
+int bfm_conv3x3x3_wino_pool_ok(int D, int H, int W, int passes);
+int bfm_conv3x3x3_wino_pool(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
+                            const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope, int passes,
+                            int flags, float* out, void* moment_rows, float* pooled, void* pooled_rows /*or NULL*/,
+                            bfm_stream_t stream);
+int bfm_conv3x3x3_wino_uniform_pool(const float* A, int CA, int D, int H, int W, const float* scale, const float* shift,
+                                    const float* bound, int G, const void* wpacked, int wexp, int Cout, float slope,
+                                    int passes, int flags, float* out, void* moment_rows,
+                                    const unsigned char* uniform_flags, void* scratch, float* pooled,
+                                    void* pooled_rows /*or NULL*/, bfm_stream_t stream);
 int bfm_conv3x3x3_wino_box(int D, int H, int W, int passes, int* box /* [3]: the (d,h,w) box of output voxels per workgroup */);
 /* workspace: bfm_conv3x3x3_wino_masked_workspace(D, H, W, passes) bytes (4-byte aligned) for the per-box activity, the
  * number of boxes that hold input and their list, built on the device ahead of the persistent launch that walks it. */

@@ -1598,3 +1598,120 @@ def test_winograd_f43_batch_equals_one_launch_per_sample_bitwise(case):
             for lo, hi, width in ((0, 8, 8), (8, 16, 8), (16, 20, 4), (20, 24, 4)):       # sums, squares, minima, maxima
                 got = rows[K * lo + s_ * k * width: K * lo + (s_ + 1) * k * width]
                 assert torch.equal(got, r1[k * lo: k * hi]), (pitch, s_, lo)
+
+
+def _rows_totals(buf, nrows, c):
+    """Column totals of a moment-row table (sum, sum of squares in float64; min, max)."""
+    raw = buf.cpu().numpy()
+    n = nrows * c
+    s = raw[:n * 8].view(np.float64).reshape(nrows, c).sum(0)
+    q = raw[n * 8:n * 16].view(np.float64).reshape(nrows, c).sum(0)
+    mn = raw[n * 16:n * 20].view(np.float32).reshape(nrows, c).min(0)
+    mx = raw[n * 20:n * 24].view(np.float32).reshape(nrows, c).max(0)
+    return s, q, mn, mx
+
+
+@pytest.mark.parametrize("uniform", [False, True])
+@pytest.mark.parametrize("dims,cin,cout", [((16, 24, 32), 32, 64), ((40, 40, 80), 64, 128)])
+def test_pooling_in_the_winograd_epilogue_changes_no_bit(dims, cin, cout, uniform):
+    """Round 5: the F(2,3) layers that nn.MaxPool3d(2) reads next (Encoder.forward, buildingblocks.py:185-186, 211-214) write the
+    pooled tensor and its moment rows in their epilogue (bfm_conv3x3x3_wino_pool / _wino_uniform_pool).  `out` and its rows
+    are the unfused call's bits, `pooled` those of bfm_maxpool2(out), and the pooled rows add up to the pooled tensor's
+    moments (float64; min / max exact).  Shapes the box does not tile are refused, nothing written."""
+    from brainfm_amd import _lib as L
+    lib = L.load()
+    dev = _dev()
+    D, H, W = dims
+    assert lib.bfm_conv3x3x3_wino_pool_ok(D, H, W, 3) == 1
+    assert lib.bfm_conv3x3x3_wino_pool_ok(D + 2, H, W, 3) == 0 and lib.bfm_conv3x3x3_wino_pool_ok(D, H, W + 2, 3) == 0
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn((D, H, W, cin), generator=g).to(dev)
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=g) * 0.05).to(dev).contiguous()
+    scale = (torch.rand(cin, generator=g) + 0.5).to(dev)
+    shift = (torch.randn(cin, generator=g) * 0.1).to(dev)
+    bound = torch.full((8,), 6.0, device=dev)
+    wp = torch.empty(lib.bfm_pack_conv_weights_wino_bytes(cin, cout, 3), dtype=torch.uint8, device=dev)
+    wexp = C.c_int(0)
+    L.check(lib.bfm_pack_conv_weights_wino(L.ptr(w), cin, cout, float(w.abs().max()), 3, L.ptr(wp), C.byref(wexp), L.stream_ptr()),
+            "pack")
+    nrows = lib.bfm_conv3x3x3_wino_rows(D, H, W, 3)
+    st = L.stream_ptr()
+    flags = scratch = None
+    if uniform:
+        img = torch.zeros((D, H, W), device=dev)
+        img[: D // 2, : H // 2, : W // 3] = torch.rand((D // 2, H // 2, W // 3), generator=g).to(dev) + 0.1
+        flags = torch.empty(lib.bfm_uniform_boxes_bytes(D, H, W, 3), dtype=torch.uint8, device=dev)
+        L.check(lib.bfm_uniform_boxes_level(L.ptr(img), D, H, W, 0, 2, 3, L.ptr(flags), st), "flags")
+        assert int((flags[:nrows] != 0).sum()) > 0
+        scratch = torch.empty(lib.bfm_conv3x3x3_wino_uniform_scratch(cout), dtype=torch.uint8, device=dev)
+
+    def run(pool):
+        out = torch.full((D, H, W, cout), float("nan"), device=dev)
+        rows = torch.zeros(lib.bfm_moment_rows_bytes(nrows, cout), dtype=torch.uint8, device=dev)
+        pooled = torch.full((D // 2, H // 2, W // 2, cout), float("nan"), device=dev) if pool else None
+        prow = torch.zeros(lib.bfm_moment_rows_bytes(nrows, cout), dtype=torch.uint8, device=dev) if pool else None
+        common = (L.ptr(A), cin, D, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound), 8, L.ptr(wp), wexp.value, cout, 0.01, 3, 0,
+                  L.ptr(out), L.ptr(rows))
+        if uniform and pool:
+            rc = lib.bfm_conv3x3x3_wino_uniform_pool(*common, L.ptr(flags), L.ptr(scratch), L.ptr(pooled), L.ptr(prow), st)
+        elif uniform:
+            rc = lib.bfm_conv3x3x3_wino_uniform(*common, L.ptr(flags), L.ptr(scratch), st)
+        elif pool:
+            rc = lib.bfm_conv3x3x3_wino_pool(*common, L.ptr(pooled), L.ptr(prow), st)
+        else:
+            rc = lib.bfm_conv3x3x3_wino_ex(*common, st)
+        L.check(rc, "conv")
+        torch.cuda.synchronize()
+        return out, rows, pooled, prow
+
+    out0, rows0, _, _ = run(False)
+    out1, rows1, pooled, prow = run(True)
+    assert not bool(torch.isnan(out0).any())
+    assert torch.equal(out0, out1) and torch.equal(rows0, rows1)
+    want = torch.empty_like(pooled)
+    L.check(lib.bfm_maxpool2(L.ptr(out0), cout, D, H, W, L.ptr(want), st), "maxpool2")
+    torch.cuda.synchronize()
+    assert torch.equal(pooled, want)
+    s, q, mn, mx = _rows_totals(prow, nrows, cout)
+    ref = want.double().reshape(-1, cout)
+    assert np.allclose(s, ref.sum(0).cpu().numpy(), rtol=1e-6, atol=1e-3)       # (fp32 partial sums of 4 values per thread)
+    assert np.allclose(q, (ref * ref).sum(0).cpu().numpy(), rtol=1e-6, atol=1e-3)
+    assert np.array_equal(mn, want.reshape(-1, cout).min(0).values.cpu().numpy())
+    assert np.array_equal(mx, want.reshape(-1, cout).max(0).values.cpu().numpy())
+    # a tensor the 8 x 8 x 4 box does not tile: refused
+    bad = torch.empty((D + 2, H, W, cin), device=dev)
+    o2 = torch.empty((D + 2, H, W, cout), device=dev)
+    p2 = torch.empty(((D + 2) // 2, H // 2, W // 2, cout), device=dev)
+    rc = lib.bfm_conv3x3x3_wino_pool(L.ptr(bad), cin, D + 2, H, W, L.ptr(scale), L.ptr(shift), L.ptr(bound), 8, L.ptr(wp), wexp.value,
+                                     cout, 0.01, 3, 0, L.ptr(o2), None, L.ptr(p2), None, st)
+    assert rc == -2                                                    # BFM_E_SHAPE
+
+
+def test_fused_pooling_flow_equals_separate_pooling(monkeypatch):
+    """The whole network with the pooling of levels 0 and 1 in the producing layers' epilogues (engine.fuse_pool) against the
+    separate bfm_maxpool2 launches.  The pooled tensors are bit-identical (the test above); the next GroupNorm's moment rows
+    are partitioned by box instead of by pooling block (fp32 partial sums of 4 values per thread instead of a grid-stride
+    run's), so its scale / shift move in their last bits: the outputs agree to 1e-5 of their maximum (measured 1.1e-6 on the
+    deepest feature map)."""
+    from brainfm_amd import test_utils as TU
+    monkeypatch.setenv("BFM_CONV_VER", "3")
+    ga, ta = TU.default_inference_args(f_maps=64, num_levels=3)
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand((1, 1, 48, 64, 128), generator=g) + 0.05).to(_dev())
+    outs = {}
+    for fuse in (True, False):
+        torch.manual_seed(4)
+        s = TU.InferenceSession(ga, ta, _dev(), passes=3)
+        s.engine.fuse_pool = fuse
+        out, _ = s.forward_fused(x)
+        outs[fuse] = out
+        if fuse:
+            assert s.engine.lib.bfm_conv3x3x3_wino_pool_ok(48, 64, 128, 3) == 1
+    for k in outs[True]:
+        if k == "feat":
+            for a, b in zip(outs[True][k], outs[False][k]):
+                assert _relerr(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5
+        else:
+            a, b = outs[True][k], outs[False][k]
+            if a.dtype.is_floating_point:
+                assert _relerr(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5, k
