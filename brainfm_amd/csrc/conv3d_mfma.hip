@@ -72,6 +72,7 @@ struct ConvParams {
     // consumer's GroupNorm reduces these instead of re-reading the activation (gn_stats.hip: bfm_gn_stats_rows).
     double *rsum, *rsq;
     float *rmn, *rmx;
+    int abl;                         // diagnostics builds (-DBFM_MFMA_ABLATE): 32 = no K loop, 16 = no epilogue
 };
 
 
@@ -138,6 +139,27 @@ __device__ __forceinline__ void box_coords(const ConvParams& p, int q, int& d, i
         h = rem / p.TW;
         w = rem - h * p.TW;
     }
+}
+
+// The element offset of every row's output voxel relative to the box's first voxel (-1: a padding row or a voxel outside the
+// tensor), one entry per row in LDS at offset 0, written by one thread per row.  Round 5: the accumulate-mode preload and the
+// epilogue worked the row -> (d,h,w) -> address chain out per STORED ROW AND THREAD (32 rows x two integer divisions each);
+// on the split-K layers of the deep levels, whose workgroups run four K chunks, that epilogue was 10-20 % of the launch
+// (tests/diag/diag_mfma_overheads.py).  The caller puts a barrier before (LDS free) and after (table visible).
+template <int ROWS, int NTHR>
+__device__ __forceinline__ const int* build_row_table(const ConvParams& p, unsigned char* lds, int tid, int z0, int y0, int x0,
+                                                      int boxN) {
+    int* tab = reinterpret_cast<int*>(lds);
+    for (int q = tid; q < ROWS; q += NTHR) {
+        int rel = -1;
+        if (q < boxN) {
+            int d, h, w;
+            box_coords(p, q, d, h, w);
+            if (z0 + d < p.D && y0 + h < p.H && x0 + w < p.W) rel = ((d * p.H + h) * p.W + w) * p.Cout;
+        }
+        tab[q] = rel;
+    }
+    return tab;
 }
 
 template <int WM, int WN, int NPASS, int NSLOT>
@@ -265,25 +287,31 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(const ConvParams p)
         // accumulate mode: start from what `out` holds (the up-folded half), in the accumulator's scaled domain; the
         // loads are issued here so that their latency hides under the K loop instead of the epilogue
         const float inv_dq = ldexpf(1.0f, aexp + p.wexp);
+        const int* rowtab = build_row_table<WM * 64, NTHR>(p, lds, tid, z0, y0, x0, boxN);    // LDS is not in use yet
+        __syncthreads();
+        const float* ib = pout + (((int64_t)z0 * p.H + y0) * p.W + x0) * p.Cout + ntw * 64 + l32;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rr = (i >> 2) * 8 + khalf * 4 + (i & 3);
-                const int q = wm * 64 + mb * 32 + row_perm(rr);
-                if (q >= boxN) continue;
-                int d, h, w;
-                box_coords(p, q, d, h, w);
-                const int gz = z0 + d, gy = y0 + h, gx = x0 + w;
-                if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
-                const float* orow = pout + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + ntw * 64 + l32;
+            for (int ig = 0; ig < 4; ++ig) {
+                const int4 r4 = *reinterpret_cast<const int4*>(rowtab + wm * 64 + mb * 32 + row_perm(ig * 8 + khalf * 4));
+                const int rel[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) acc[mb][nb][i] = orow[nb * 32] * inv_dq;
+                for (int j = 0; j < 4; ++j) {
+                    if (rel[j] < 0) continue;
+                    const float* orow = ib + (unsigned)rel[j];
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) acc[mb][nb][ig * 4 + j] = orow[nb * 32] * inv_dq;
+                }
             }
         }
+        // (the first chunk's barrier comes before anything is staged over the table)
     }
     const int kc_begin = split * p.kc_per_split;
-    const int kc_end = min(p.KCN, kc_begin + p.kc_per_split);
+    int kc_end = min(p.KCN, kc_begin + p.kc_per_split);
+#ifdef BFM_MFMA_ABLATE
+    if (p.abl & 32) kc_end = kc_begin;
+#endif
 
     // ---- weight stream: row R = (chunk, kd, kh); fragment f of a row -> LDS slot (R % NSLOT)
     const int b_base = 2 * NPL * p.plane_stride;
@@ -413,32 +441,47 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma(const ConvParams p)
 #endif
 
     // ================= epilogue =================
+#ifdef BFM_MFMA_ABLATE
+    if (p.abl & 16) {
+        float sm = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sm += acc[mb][0][i] + acc[mb][1][i];
+        if (sm == 12345.678f) pout[tid] = sm;
+        return;
+    }
+#endif
     const bool final_out = p.splitk == 1;
     const bool want_rows = final_out && p.rsum != nullptr;
     float* obase = pout + (final_out ? 0 : (int64_t)split * p.split_stride);
     // per-lane partial moments of <= 32 stored values per column in fp32 (then fp64 across lanes, waves and tiles)
     float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};
     float mmn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mmx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    __syncthreads();                                           // every wave is done with the planes and the ring
+    const int* rowtab = build_row_table<WM * 64, NTHR>(p, lds, tid, z0, y0, x0, boxN);
+    __syncthreads();
+    float* const ob = obase + (((int64_t)z0 * p.H + y0) * p.W + x0) * p.Cout + ntw * 64 + l32;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int rr = (i >> 2) * 8 + khalf * 4 + (i & 3);
-            const int q = wm * 64 + mb * 32 + row_perm(rr);
-            if (q >= boxN) continue;
-            int d, h, w;
-            box_coords(p, q, d, h, w);
-            const int gz = z0 + d, gy = y0 + h, gx = x0 + w;
-            if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
-            float* orow = obase + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + ntw * 64 + l32;
+        for (int ig = 0; ig < 4; ++ig) {
+            // rows (ig, khalf, j = 0..3) are four consecutive entries (row_perm keeps aligned groups of four together)
+            const int4 r4 = *reinterpret_cast<const int4*>(rowtab + wm * 64 + mb * 32 + row_perm(ig * 8 + khalf * 4));
+            const int rel[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                float r = acc[mb][nb][i] * dq;
-                if (final_out) r = r >= 0.f ? r : r * p.slope;     // accumulate mode preloaded `out` into acc
-                orow[nb * 32] = r;
-                if (want_rows) {
-                    fs[nb] += r; fq[nb] = fmaf(r, r, fq[nb]);
-                    mmn[nb] = fminf(mmn[nb], r); mmx[nb] = fmaxf(mmx[nb], r);
+            for (int j = 0; j < 4; ++j) {
+                if (rel[j] < 0) continue;
+                float* orow = ob + (unsigned)rel[j];
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    float r = acc[mb][nb][ig * 4 + j] * dq;
+                    if (final_out) r = r >= 0.f ? r : r * p.slope;     // accumulate mode preloaded `out` into acc
+                    orow[nb * 32] = r;
+                    if (want_rows) {
+                        fs[nb] += r; fq[nb] = fmaf(r, r, fq[nb]);
+                        mmn[nb] = fminf(mmn[nb], r); mmx[nb] = fmaxf(mmx[nb], r);
+                    }
                 }
             }
         }
@@ -579,24 +622,27 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma16(const ConvParams 
     const int ntw = nt * WN + wn;
     if (p.accum && p.splitk == 1) {                      // accumulate mode: see conv_mfma
         const float inv_dq = ldexpf(1.0f, aexp + p.wexp);
+        const int* rowtab = build_row_table<WM * 64, NTHR>(p, lds, tid, z0, y0, x0, boxN);    // LDS is not in use yet
+        __syncthreads();
+        const float* ib = pout + (((int64_t)z0 * p.H + y0) * p.W + x0) * p.Cout + ntw * 64 + l16;
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) {
+            const int4 r4 = *reinterpret_cast<const int4*>(rowtab + wm * 64 + rb * 16 + kg * 4);
+            const int rel[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int q = wm * 64 + rb * 16 + kg * 4 + i;
-                if (q >= boxN) continue;
-                int d, h, w;
-                box_coords(p, q, d, h, w);
-                const int gz = z0 + d, gy = y0 + h, gx = x0 + w;
-                if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
-                const float* orow = pout + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + ntw * 64 + l16;
+                if (rel[i] < 0) continue;
+                const float* orow = ib + (unsigned)rel[i];
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) acc[rb][cb][i] = orow[cb * 16] * inv_dq;
             }
         }
     }
     const int kc_begin = split * p.kc_per_split;
-    const int kc_end = min(p.KCN, kc_begin + p.kc_per_split);
+    int kc_end = min(p.KCN, kc_begin + p.kc_per_split);
+#ifdef BFM_MFMA_ABLATE
+    if (p.abl & 32) kc_end = kc_begin;
+#endif
     const int b_base = 2 * NPL * p.plane_stride;
     const int total_slots = (kc_end - kc_begin) * NSL;
     auto issue_slot = [&](int S) __attribute__((always_inline)) {
@@ -704,22 +750,35 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_mfma16(const ConvParams 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+#ifdef BFM_MFMA_ABLATE
+    if (p.abl & 16) {
+        float sm = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) sm += acc[rb][cb][0] + acc[rb][cb][1] + acc[rb][cb][2] + acc[rb][cb][3];
+        if (sm == 12345.678f) pout[tid] = sm;
+        return;
+    }
+#endif
     const bool final_out = p.splitk == 1;
     const bool want_rows = final_out && p.rsum != nullptr;
     float* obase = pout + (final_out ? 0 : (int64_t)split * p.split_stride);
     float fs[4] = {0.f, 0.f, 0.f, 0.f}, fq[4] = {0.f, 0.f, 0.f, 0.f};      // <= 16 values per column per lane in fp32
     float mmn[4] = {INFINITY, INFINITY, INFINITY, INFINITY}, mmx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    __syncthreads();                                           // every wave is done with the planes and the ring
+    const int* rowtab = build_row_table<WM * 64, NTHR>(p, lds, tid, z0, y0, x0, boxN);
+    __syncthreads();
+    float* const ob = obase + (((int64_t)z0 * p.H + y0) * p.W + x0) * p.Cout + ntw * 64 + l16;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
+        // C/D: row = (lane>>4)*4 + reg, col = lane&15: this lane's four rows of the block are consecutive table entries
+        const int4 r4 = *reinterpret_cast<const int4*>(rowtab + wm * 64 + rb * 16 + kg * 4);
+        const int rel[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int q = wm * 64 + rb * 16 + kg * 4 + i;          // C/D: row = (lane>>4)*4 + reg, col = lane&15
-            if (q >= boxN) continue;
-            int d, h, w;
-            box_coords(p, q, d, h, w);
-            const int gz = z0 + d, gy = y0 + h, gx = x0 + w;
-            if (gz >= p.D || gy >= p.H || gx >= p.W) continue;
-            float* orow = obase + (((int64_t)gz * p.H + gy) * p.W + gx) * p.Cout + ntw * 64 + l16;
+            if (rel[i] < 0) continue;
+            float* orow = ob + (unsigned)rel[i];
 #pragma unroll
             for (int cb = 0; cb < 4; ++cb) {
                 float r = acc[rb][cb][i] * dq;
@@ -1612,6 +1671,10 @@ static int conv_mfma_launch(const float* A, int CA, const float* B, int CB, int 
         p.rmn = reinterpret_cast<float*>(rb + n * 16);
         p.rmx = reinterpret_cast<float*>(rb + n * 20);
     }
+#ifdef BFM_MFMA_ABLATE
+    if (const char* e = getenv("BFM_MFMA_ABL")) p.abl = atoi(e);
+#endif
+    if ((int64_t)hp.TD * H * W * Cout > 0x7fffffffLL) return BFM_E_SHAPE;     // 32-bit row offsets inside a box (build_row_table)
     if ((int64_t)p.nMt * p.NT > 0x7fffffff) return BFM_E_SHAPE;
     if (nvox * CA > 0x7fffffffLL || (CB > 0 && (int64_t)up->d * up->h * up->w * CB > 0x7fffffffLL))
         return BFM_E_SHAPE;                                   // the staging path keeps 32-bit element offsets
