@@ -1715,3 +1715,101 @@ def test_fused_pooling_flow_equals_separate_pooling(monkeypatch):
             a, b = outs[True][k], outs[False][k]
             if a.dtype.is_floating_point:
                 assert _relerr(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5, k
+
+
+def test_batched_pooling_equals_per_sample_pooling_bitwise():
+    """bfm_maxpool2_batch (round 5: one launch per batch on the batched levels): every sample's pooled tensor is
+    bfm_maxpool2's, bit for bit, for even and odd extents, and a sample's moment rows do not depend on the batch it is in;
+    the rows add up to the pooled tensor's moments."""
+    from brainfm_amd import _lib as L
+    lib = L.load()
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    for (D, H, W), c in (((10, 10, 20), 512), ((5, 5, 5), 1024), ((20, 20, 20), 256)):
+        S = 4
+        x = torch.randn((S, D, H, W, c), generator=g).to(dev)
+        n = lib.bfm_maxpool2_batch_rows(c, D, H, W)
+        assert 0 < n <= 128
+        out = torch.full((S, D // 2, H // 2, W // 2, c), float("nan"), device=dev)
+        rows = torch.zeros(lib.bfm_moment_rows_bytes(S * n, c), dtype=torch.uint8, device=dev)
+        L.check(lib.bfm_maxpool2_batch(L.ptr(x), c, S, D, H, W, L.ptr(out), L.ptr(rows), L.stream_ptr()), "pool batch")
+        one = torch.empty_like(out[0])
+        rows1 = torch.zeros(lib.bfm_moment_rows_bytes(n, c), dtype=torch.uint8, device=dev)
+        for s_ in range(S):
+            L.check(lib.bfm_maxpool2(L.ptr(x[s_]), c, D, H, W, L.ptr(one), L.stream_ptr()), "pool")
+            torch.cuda.synchronize()
+            assert torch.equal(out[s_], one), (D, H, W, s_)
+            # the same sample alone in a batch of one: the same rows
+            o1 = torch.empty_like(one)
+            L.check(lib.bfm_maxpool2_batch(L.ptr(x[s_]), c, 1, D, H, W, L.ptr(o1), L.ptr(rows1), L.stream_ptr()), "pool batch 1")
+            torch.cuda.synchronize()
+            raw, raw1 = rows.cpu().numpy(), rows1.cpu().numpy()
+            tot = S * n * c
+            for plane, width in ((0, 8), (tot * 8, 8), (tot * 16, 4), (tot * 20, 4)):
+                a = raw[plane + s_ * n * c * width: plane + (s_ + 1) * n * c * width]
+                b = raw1[plane // S: plane // S + n * c * width]
+                assert np.array_equal(a, b), (D, H, W, s_, plane)
+            sm, sq, mn, mx = _rows_totals(rows1, n, c)
+            ref = one.double().reshape(-1, c)
+            assert np.allclose(sm, ref.sum(0).cpu().numpy(), rtol=1e-6, atol=1e-3)
+            assert np.array_equal(mx, one.reshape(-1, c).max(0).values.cpu().numpy())
+
+
+def test_splitk_rows_and_sliced_rows_give_the_statistics_of_the_tensor():
+    """Round 5: a split-K convolution's slab reduction writes the output's moment rows (bfm_conv3x3x3_mfma_rows > 0 for such
+    plans), and bfm_gn_stats_rows_sliced reads ONE sample's rows out of a batched producer's table.  The output is the bits
+    of the launch without rows; GroupNorm scale / shift / bound from the sliced rows equal those bfm_gn_stats computes from
+    the sample's tensor to 1e-5 (fp32 outputs of float64 sums taken in a different order)."""
+    from brainfm_amd import _lib as L
+    lib = L.load()
+    dev = _dev()
+    g = torch.Generator().manual_seed(22)
+    cin, cout, (D, H, W), S = 512, 256, (10, 10, 10), 3
+    A = torch.randn((S, D, H, W, cin), generator=g).to(dev)
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=g) * 0.03).to(dev).contiguous()
+    scale = (torch.rand((S, cin), generator=g) + 0.5).to(dev)
+    shift = (torch.randn((S, cin), generator=g) * 0.1).to(dev)
+    bound = torch.full((S, 8), 6.0, device=dev)
+    cfg = (C.c_int * 8)()
+    L.check(lib.bfm_conv3x3x3_mfma_plan(cin, cout, D, H, W, cfg), "plan")
+    cfg[6] = 0
+    assert cfg[5] > 1, "the planner splits K on this shape"
+    n = lib.bfm_conv3x3x3_mfma_rows(cin, cout, D, H, W, cfg)
+    assert 0 < n <= 128
+    wp = torch.empty(lib.bfm_pack_conv_weights_mfma_bytes(cin, cout), dtype=torch.uint8, device=dev)
+    wexp = C.c_int(0)
+    L.check(lib.bfm_pack_conv_weights_mfma(L.ptr(w), cin, cout, float(w.abs().max()), L.ptr(wp), C.byref(wexp), L.stream_ptr()), "pack")
+    ws = torch.empty(lib.bfm_conv3x3x3_mfma_batch_workspace(cin, cout, S, D, H, W, cfg[5]), dtype=torch.uint8, device=dev)
+    st = L.stream_ptr()
+
+    def run(rows):
+        out = torch.full((S, D, H, W, cout), float("nan"), device=dev)
+        L.check(lib.bfm_conv3x3x3_mfma_batch(L.ptr(A), cin, None, 0, S, D, H, W, None, L.ptr(scale), L.ptr(shift), L.ptr(bound), 8,
+                                             L.ptr(wp), wexp.value, cout, 0.01, 3, cfg, L.ptr(out), L.ptr(ws), ws.numel(),
+                                             L.ptr(rows) if rows is not None else None, 0, st), "conv")
+        torch.cuda.synchronize()
+        return out
+
+    rows = torch.zeros(lib.bfm_moment_rows_bytes(S * n, cout), dtype=torch.uint8, device=dev)
+    o0, o1 = run(None), run(rows)
+    assert torch.equal(o0, o1) and not bool(torch.isnan(o0).any())
+    gamma = (torch.rand(cout, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    for s_ in range(S):
+        got = [torch.empty(cout, device=dev), torch.empty(cout, device=dev), torch.empty(8, device=dev)]
+        need = lib.bfm_gn_stats_rows_workspace(n, cout, 0, 0)
+        wsr = torch.empty(max(need, 256), dtype=torch.uint8, device=dev)
+        L.check(lib.bfm_gn_stats_rows_sliced(L.ptr(rows), S * n, s_ * n, n, cout, None, 0, 0, 0, 0, 1.0, D * H * W, L.ptr(gamma),
+                                             L.ptr(beta), 8, 1e-5, L.ptr(got[0]), L.ptr(got[1]), L.ptr(got[2]), L.ptr(wsr), wsr.numel(),
+                                             None, st), "rows sliced")
+        want = [torch.empty(cout, device=dev), torch.empty(cout, device=dev), torch.empty(8, device=dev)]
+        wsb = torch.empty(max(lib.bfm_gn_stats_workspace(cout, 0, D, H, W, None), 256), dtype=torch.uint8, device=dev)
+        L.check(lib.bfm_gn_stats(L.ptr(o0[s_]), cout, None, 0, D, H, W, None, L.ptr(gamma), L.ptr(beta), 8, 1e-5, L.ptr(want[0]),
+                                 L.ptr(want[1]), L.ptr(want[2]), L.ptr(wsb), wsb.numel(), st), "gn_stats")
+        torch.cuda.synchronize()
+        for a, b in zip(got, want):
+            assert _relerr(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5, s_
+    # a slice outside the table is refused
+    rc = lib.bfm_gn_stats_rows_sliced(L.ptr(rows), S * n, S * n - n + 1, n, cout, None, 0, 0, 0, 0, 1.0, D * H * W, L.ptr(gamma),
+                                      L.ptr(beta), 8, 1e-5, L.ptr(got[0]), L.ptr(got[1]), L.ptr(got[2]), L.ptr(wsr), wsr.numel(), None, st)
+    assert rc == -1                                                    # BFM_E_ARG
