@@ -114,6 +114,22 @@ def _dgrad_layer(eng, ly):
     return dg
 
 
+def _identity_affine(eng, c):
+    """(ones, zeros) of c floats on the engine's device: the identity GroupNorm affine of the data-gradient convolutions."""
+    cache = eng.__dict__.setdefault("_identity_affine", {})
+    if c not in cache:
+        cache[c] = (torch.ones(c, dtype=torch.float32, device=eng.device), torch.zeros(c, dtype=torch.float32, device=eng.device))
+    return cache[c]
+
+
+def _add(a, b):
+    """a + b of two same-shape fp32 gradients through bfm_ew_binary (no torch operator in the step)."""
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or a.shape != b.shape:
+        return a + b
+    from .generator_utils import ew_binary
+    return ew_binary(L.EW_ADD, a, b)
+
+
 def backward_single_conv(eng, t, dY, need_input_grad=True):
     """Returns (dA, dB, grads) for one taped SingleConv; dB is the gradient of the LOW-RES tensor (or None)."""
     ly = t.ly
@@ -147,8 +163,7 @@ def backward_single_conv(eng, t, dY, need_input_grad=True):
     if dg is None:
         dg = ly.packs["dgrad_layer"] = _dgrad_layer(eng, ly)
     ly.touch("dgrad_layer")
-    ones = torch.ones(ly.cout, dtype=torch.float32, device=dev)
-    zeros = torch.zeros(ly.cout, dtype=torch.float32, device=dev)
+    ones, zeros = _identity_affine(eng, ly.cout)                 # cached per width: no fill launches per layer and iteration
     dXn = torch.empty((D, H, W, dg.cout), dtype=torch.float32, device=dev)
     if ly.cout % 16 == 0 and dg.cout % 64 == 0:
         # the data gradient is a plain single-source conv of dP with the transposed weights: it goes through the
@@ -260,12 +275,12 @@ def backbone_backward(eng, tape, dfeats):
         dskip[nlev - 2 - j] = dsk
         g = dlow
         if dfeats[j] is not None:
-            g = g + dfeats[j]
+            g = _add(g, dfeats[j])
     # g is now the gradient w.r.t. the deepest encoder output
     for i in range(nlev - 1, -1, -1):
         t1, t2 = tape["enc"][i]
         if dskip[i] is not None:
-            g = g + dskip[i] if g is not None else dskip[i]
+            g = _add(g, dskip[i]) if g is not None else dskip[i]
         dy, _, gr = backward_single_conv(eng, t2, g)
         grads.update(gr)
         dx, _, gr = backward_single_conv(eng, t1, dy, need_input_grad=i > 0)
