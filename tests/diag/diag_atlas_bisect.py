@@ -13,6 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import torch
 from brainfm_amd import _lib as L
+if os.environ.get("BFM_DIAG_LIB"):                 # a variant build (scripts/build_variant.py)
+    L.LIB_PATH = os.path.join(ROOT, os.environ["BFM_DIAG_LIB"])
 from brainfm_amd import test_utils as TU
 from brainfm_amd.engine import _Layer
 

@@ -442,12 +442,11 @@ def test_gathers_inside_captured_graphs_on_two_lanes_keep_their_goldens():
     concurrently on two streams 100 times with a third stream beside them running a convolution that fills its LDS by
     LDS-DMA (global_load_lds: round 3 found that THIS is what the atlas gather's ordinary loads went wrong beside,
     tests/diag/diag_atlas_repro.py), and every replay must give the reference's golden bits (interp: exact; grid_pull:
-    1e-6).  The co-runner alternates conv_mfma and conv_wino4d, the strongest trigger found.  grid_pull is held to its goldens
-    in the conv_mfma rounds only: beside conv_wino4d it is a KNOWN OPEN failure (about 100 wrong elements per 400 eager
-    two-stream rounds, once in 5 suite runs inside these graphs; every load form tried -- agent / system scope, read twice
-    and compared, one load in flight -- failed on some box: profiles/r05_atlas_hazard_bisect.txt items 6-7), which is why no
-    shipped flow runs it beside a convolution (the generator and the training step share a stream).  fast_3D_interp_torch
-    (the generator's gather) has not returned a wrong element in any of those runs and is checked in every round."""
+    1e-6).  The co-runner alternates conv_mfma and conv_wino4d.  Rounds 3-5 held grid_pull to its goldens in the conv_mfma
+    rounds only, because beside conv_wino4d it returned about 100 wrong elements per 400 eager rounds; round 6 found the
+    cause (profiles/r06_hazard_root_cause.txt: not a load at all -- the low half of a packed-FP32 multiply, v_pk_mul_f32 with
+    bank-conflicting sources, lost in lanes 48..63 beside the MFMA tap loop) and the library is built without packed-FP32
+    instructions since (brainfm_amd/build.py), so EVERY round asserts both gathers again."""
     import ctypes as C
     from brainfm_amd import _lib as L, test_utils as TU
     from brainfm_amd.engine import _Layer
@@ -518,9 +517,88 @@ def test_gathers_inside_captured_graphs_on_two_lanes_keep_their_goldens():
         torch.cuda.synchronize()
         for lane, (_, outs) in enumerate(lanes):
             assert np.array_equal(N(outs["interp"]), d["lin1"]), (it, lane)
-            if it % 2 == 0:                                           # conv_beside() ran conv_mfma this round (ccfgs[0])
-                _close(N(outs["pull_zero"]), d2["out_zero_0"], 1e-6)
-                _close(N(outs["pull_dct2"]), d2["out_dct2_1"], 1e-6)
+            _close(N(outs["pull_zero"]), d2["out_zero_0"], 1e-6)
+            _close(N(outs["pull_dct2"]), d2["out_dct2_1"], 1e-6)
+
+
+def _cu_masked_stream(bits):
+    """A stream confined to the CUs whose mask bits are given (hipExtStreamCreateWithCUMask of the HIP runtime torch has
+    loaded; bit i -> XCD i % 8, shader engine (i // 8) % 4, CU (i // 32) of it)."""
+    import ctypes as C
+    hip = None
+    for line in open("/proc/self/maps"):
+        if "libamdhip64" in line:
+            hip = C.CDLL(line.split()[-1])
+            break
+    assert hip is not None
+    words = (C.c_uint32 * 8)()
+    for i in bits:
+        words[i // 32] |= 1 << (i % 32)
+    st = C.c_void_p()
+    assert hip.hipExtStreamCreateWithCUMask(C.byref(st), 8, words) == 0
+    return torch.cuda.ExternalStream(st.value)
+
+
+def test_grid_pull_beside_conv_wino4d_on_the_same_compute_units():
+    """The high-rate form of the hazard round 6 closed (profiles/r06_hazard_root_cause.txt): interpol.grid_pull on the golden
+    grid repeated 16 times (15 workgroups) on two streams, six launches of conv_wino4d (128 -> 128 on 40^3) on a third, all
+    three streams confined to the SAME half of the compute units so that victim and MFMA waves share SIMDs.  With the library
+    built WITH packed-FP32 instructions 40 % of the rounds return wrong elements (83-166 of 250-400 rounds on three boxes,
+    always the trilinear sum minus corner 010 or 100 in lanes 48..63); built without them -- what ships -- none: 300 rounds,
+    every element within 1e-6 of the reference's golden values, fast_3D_interp_torch exact."""
+    import ctypes as C
+    from brainfm_amd import _lib as L, test_utils as TU
+    from brainfm_amd.engine import _Layer
+    from brainfm_amd.generator_utils import fast_3D_interp_torch
+    from brainfm_amd.interpol import grid_pull
+    d = load_npz("synth_interp.npz")
+    d2 = load_npz("synth_grid_pull.npz")
+    X = T(d["X1"])
+    vol = T(d2["vol"])
+    grid = T(np.concatenate([d2["grid"]] * 16, axis=1))
+    want = np.concatenate([d2["out_zero_0"]] * 16, axis=2)
+    half = [i for i in range(256) if (i // 8) % 2 == 0]
+    streams = [_cu_masked_stream(half), _cu_masked_stream(half)]
+    side = _cu_masked_stream(half)
+    ga, ta = TU.default_inference_args(f_maps=64, num_levels=6)
+    eng = TU.InferenceSession(ga, ta, torch.device(DEV)).engine
+    cin = cout = 128
+    cd = (40, 40, 40)
+    cA = torch.randn(*cd, cin, device=DEV)
+    csc, csh, cbd = torch.rand(cin, device=DEV) + 0.5, torch.randn(cin, device=DEV) * 0.1, torch.full((8,), 6.0, device=DEV)
+    cout_t, cws = torch.empty(*cd, cout, device=DEV), torch.empty(1 << 26, dtype=torch.uint8, device=DEV)
+    ly = _Layer()
+    ly.name, ly.cin, ly.cout, ly.groups = "corunner", cin, cout, 8
+    ly.w_raw = (torch.randn(cout, cin, 3, 3, 3, device=DEV) * 0.05).contiguous()
+    ly.packs, ly.kind, ly.wpacked, ly.wexp, ly.skip = {}, None, None, 0, None
+    ccfg = (C.c_int * 8)()
+    L.check(eng.lib.bfm_conv3x3x3_mfma_plan(cin, cout, cd[0], cd[1], cd[2], ccfg), "plan")
+    ccfg[6] = 4                                                        # conv_wino4d
+
+    def conv_beside():
+        for _ in range(6):
+            eng._conv_launch(ly, cA, cin, None, 0, cd, None, csc, csh, cbd, 8, ccfg, cout_t, cws)
+
+    conv_beside()
+    torch.cuda.synchronize()
+    lanes = []
+    for lane in range(2):
+        lanes.append((T(d["II"]), T(d["JJ"]), T(d["KK"]), grid.clone()))
+    wrong_rounds = 0
+    for it in range(300):
+        outs = []
+        with torch.cuda.stream(side):
+            conv_beside()
+        for lane, (ii, jj, kk, gcopy) in enumerate(lanes):
+            with torch.cuda.stream(streams[lane]):
+                a = fast_3D_interp_torch(X, ii, jj, kk, "linear")
+                b = grid_pull(vol, gcopy, interpolation="linear", bound="zero", extrapolate=False, prefilter=False)
+                outs.append((a, b))
+        torch.cuda.synchronize()
+        for a, b in outs:
+            assert np.array_equal(N(a), d["lin1"]), it
+            wrong_rounds += int(np.abs(N(b) - want).max() > 1e-6 * np.abs(want).max())
+    assert wrong_rounds == 0, wrong_rounds
 
 
 def test_streaming_kernels_with_l1_reuse_beside_an_lds_dma_corunner_keep_their_bits():

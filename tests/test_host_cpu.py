@@ -544,6 +544,53 @@ torch.save({"model": {"w": Wrapped(torch.ones(3))}, "epoch": 1}, %r)
             M.read_checkpoint_file(odd)
 
 
+def _device_code_objects(lib_path):
+    """The gfx950 code objects inside a HIP shared library: the .hip_fatbin section is a sequence of clang offload bundles
+    (magic, entry count, then (offset, size, triple) records), one per translation unit."""
+    import struct
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.check_call([llvm + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, lib_path])
+        d = open(fat, "rb").read()
+        magic = b"__CLANG_OFFLOAD_BUNDLE__"
+        for m in re.finditer(magic, d):
+            p = m.start()
+            n = struct.unpack_from("<Q", d, p + 24)[0]
+            off = p + 32
+            for _ in range(n):
+                o, sz, tl = struct.unpack_from("<QQQ", d, off)
+                off += 24
+                triple = d[off:off + tl].decode()
+                off += tl
+                if "gfx950" in triple:
+                    co = os.path.join(tmp, "co.o")
+                    open(co, "wb").write(d[p + o:p + o + sz])
+                    yield subprocess.run([llvm + "/llvm-objdump", "-d", co], capture_output=True, text=True, check=True).stdout
+
+
+def test_no_packed_fp32_instruction_in_the_code_objects():
+    """profiles/r06_hazard_root_cause.txt: the low half of a packed-FP32 multiply (v_pk_mul_f32 with bank-conflicting sources)
+    is lost in lanes 48..63 when conv_wino4 / conv_wino4d's MFMA tap loop shares the compute unit -- the cause of every
+    "gather beside a convolution" wrong result of rounds 2-5.  The library is therefore built without that instruction
+    class (brainfm_amd/build.py: NO_PACKED_FP32).  This checks what was BUILT, not the flags: the disassembly of every gfx950
+    code object in libbrainfm_hip.so holds no v_pk_*_f32 (v_pk_mul / add / fma / mov _f32)."""
+    from brainfm_amd import _lib as L
+    if not os.path.exists(L.LIB_PATH):
+        from brainfm_amd import build
+        build.build(verbose=False)
+    nobj = nkern = 0
+    for dis in _device_code_objects(L.LIB_PATH):
+        nobj += 1
+        nkern += len(re.findall(r"^[0-9a-f]+ <\S+>:", dis, re.M))
+        found = re.findall(r"\bv_pk_\w+_f32\b.*", dis)
+        assert not found, found[:3]
+        assert "v_mfma_" in dis or "s_endpgm" in dis              # it IS a disassembly
+    assert nobj >= 15 and nkern >= 200, (nobj, nkern)
+
+
 def test_gather_kernels_load_their_texels_past_the_l1():
     """an ordinary (L1-cached) load of a gather that runs beside a kernel using LDS-DMA can come back as 0
     (profiles/r05_atlas_hazard_bisect.txt); agent-scope loads never did.  Source-level guard: in the files that hold the
