@@ -1215,6 +1215,11 @@ __global__ void splitk_reduce(const float* __restrict__ ws, int splitk, int64_t 
 // (rb, cz, s) sums rows [rb * vpb, (rb + 1) * vpb) of sample s on its CGB column quads; thread (vl, cgl) takes every NV-th
 // voxel, the NV partials of a column fold in lane order (fp32 per thread over <= vpb / NV values, fp64 across threads, as
 // the epilogues do).  Row (s * nrows + rb) of the tables.  Deterministic: fixed order, no atomics.
+// column quads per workgroup of splitk_reduce_rows: the largest of 64 / 32 / 16 that divides Cout / 4 (a multiple of 16, as
+// Cout % 64 == 0), so that the grid's y extent covers every quad exactly and 256 / CGB voxel lanes is a whole number for
+// every such Cout (192, 320, 384 ... included: ADVICE r5); unchanged for the widths 64 * 2^k
+__host__ __device__ inline int splitk_cgb(int CG) { return (CG & 63) == 0 ? 64 : ((CG & 31) == 0 ? 32 : 16); }
+
 __global__ void __launch_bounds__(256) splitk_reduce_rows(const float* __restrict__ ws, int splitk, int64_t stride4,
                                                           int nvox, int Cout, int vpb, int nrows, float slope, int accum,
                                                           float* __restrict__ out, double* __restrict__ rsum,
@@ -1222,7 +1227,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_rows(const float* __restric
                                                           float* __restrict__ rmx) {
     __shared__ float4 lsh[4][256];
     const int CG = Cout >> 2;
-    const int CGB = CG < 64 ? CG : 64;
+    const int CGB = splitk_cgb(CG);
     const int NV = 256 / CGB;
     const int tid = threadIdx.x;
     const int cgl = tid % CGB, vl = tid / CGB;
@@ -1273,7 +1278,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_rows(const float* __restric
 // rows of voxels one workgroup of splitk_reduce_rows folds into one moment row (a multiple of its voxel lanes; at most 128
 // rows per sample, so that the batched finalize reads the table directly), and the row count
 static int splitk_rows_vpb(int64_t nvox, int Cout) {
-    const int CG = Cout / 4, CGB = CG < 64 ? CG : 64, NV = 256 / CGB;
+    const int CG = Cout / 4, CGB = splitk_cgb(CG), NV = 256 / CGB;
     int64_t vpb = std::max<int64_t>((int64_t)NV * 4, bfm_cdiv64(nvox, 128));
     vpb = bfm_cdiv64(vpb, NV) * NV;
     return (int)std::min<int64_t>(vpb, 0x7fffffff);
@@ -1700,7 +1705,7 @@ static int conv_mfma_launch(const float* A, int CA, const float* B, int CB, int 
         if (nvox > 0x7fffffffLL || S > 65535) return BFM_E_SHAPE;
         const int vpb = splitk_rows_vpb(nvox, Cout);
         const int nrows = (int)bfm_cdiv64(nvox, vpb);
-        const int CG = Cout / 4, CGB = CG < 64 ? CG : 64;
+        const int CG = Cout / 4, CGB = splitk_cgb(CG);
         char* rb = static_cast<char*>(moment_rows);
         const size_t n = (size_t)S * nrows * Cout;
         hipLaunchKernelGGL(splitk_reduce_rows, dim3(nrows, CG / CGB, S), dim3(256), 0, st,

@@ -125,7 +125,8 @@ __device__ __forceinline__ void split_store4(const float (&t)[4], unsigned char*
 // thread's 16 pairs are (j, h) = (row0 & 1, (row0 >> 1) + 4 (it & 1)), d = it >> 1: the x pair of a window is the Winograd
 // pair, its d pair is in the thread, its h pair in the thread 64 further (row0 ^ 2), met through LDS.  max in the order
 // bfm_maxpool2 takes it (dz, dy, dx), NaN kept the same way.
-__device__ __forceinline__ float pool_max(float m, float q) { return (q != q) ? q : fmaxf(m, q); }
+// NaN-sticky like torch's max: a NaN seen at any corner of the window stays (fmaxf alone would drop it on the next corner)
+__device__ __forceinline__ float pool_max(float m, float q) { return (m != m) ? m : ((q != q) ? q : fmaxf(m, q)); }
 
 template <int NPASS, int MODE, int POOL = 0>
 __device__ __forceinline__ void conv_wino_body(const WinoParams& p) {

@@ -685,7 +685,9 @@ __device__ __forceinline__ void conv_wino4d_body(const W4Params& pin) {
                     const unsigned vo = ((sb ? ro1 : ro0) + (unsigned)lane_el) * 4u;       // bytes from slab + kc * KC
                     const unsigned la = raw_lds + (unsigned)(i * (2 * DB_RAWROW));
                     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(slab + kc * KC), "s"(la)
-                                 : "memory");
+                                 : "memory");      // M0 is written here; it cannot be named as a clobber (a reserved register:
+                    // clang warns "may lead to undefined behaviour").  Nothing else in these kernels uses M0 (no movrel, no
+                    // builtin LDS-DMA, no sendmsg): tests/test_host_cpu.py::test_m0_is_written_only_for_the_lds_dma_of_conv_wino4d
                 }
             }
         }

@@ -3,6 +3,8 @@
 
 namespace {
 
+__device__ __forceinline__ float nan_max(float m, float q) { return (m != m) ? m : ((q != q) ? q : fmaxf(m, q)); }
+
 // nn.MaxPool3d(kernel_size=2): window 2, stride 2, floor, no padding
 // (Trainer/models/unet3d/buildingblocks.py:185-186).  Channels-last, float4 per lane.
 // Optional output-moment rows (see conv3d_mfma.hip / gn_stats.hip): one row per block, so that the GroupNorm of the
@@ -41,14 +43,14 @@ __global__ void maxpool2_kernel(const float* __restrict__ in, int C, int D, int 
                                      (int64_t)cv * VEC;
                     if constexpr (VEC == 4) {
                         float4 q = *reinterpret_cast<const float4*>(p);
-                        // torch's max propagates NaN; fmaxf does not -- keep NaN visible
-                        m[0] = (q.x != q.x) ? q.x : fmaxf(m[0], q.x);
-                        m[1] = (q.y != q.y) ? q.y : fmaxf(m[1], q.y);
-                        m[2] = (q.z != q.z) ? q.z : fmaxf(m[2], q.z);
-                        m[3] = (q.w != q.w) ? q.w : fmaxf(m[3], q.w);
+                        // torch's max propagates NaN from ANY corner; fmaxf does not -- sticky in both operands
+                        m[0] = nan_max(m[0], q.x);
+                        m[1] = nan_max(m[1], q.y);
+                        m[2] = nan_max(m[2], q.z);
+                        m[3] = nan_max(m[3], q.w);
                     } else {
                         float q = *p;
-                        m[0] = (q != q) ? q : fmaxf(m[0], q);
+                        m[0] = nan_max(m[0], q);
                     }
                 }
         float* o = out + v * C + (int64_t)cv * VEC;

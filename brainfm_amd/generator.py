@@ -54,7 +54,11 @@ class DeviceVolumes:
     (BFM_GEN_CACHE_GB, default 64).  A volume is keyed by the identity of its source object AND a cheap content stamp
     (shape, dtype, data address and the sum of ~256 strided samples, taken at every request: a few microseconds): an array
     re-filled in place -- re-used buffers, on-the-fly pre-processing -- gets a fresh resident copy instead of silently
-    serving the old one (`forget(vol)` / `invalidate()` drop copies explicitly).  mean 0 / scale 1 'prep' copies
+    serving the old one.  The stamp is a BEST-EFFORT guard, not a hash: it samples ~256 elements of C-contiguous
+    arrays only, so an in-place edit that leaves the sampled voxels alone (a lesion mask touched locally, a label volume
+    whose sampled voxels stay background) is NOT seen -- after editing a source array in place call `forget(vol)` (one
+    volume) or `invalidate()` (all) before the next item (a full crc32 of a 160^3 volume costs 5-15 ms per
+    request against 4 ms for the whole item, which is why it is not the default).  mean 0 / scale 1 'prep' copies
     of a volume without NaNs are the 'f32' copy itself."""
 
     def __init__(self, device, budget=None):

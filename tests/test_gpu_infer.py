@@ -1813,3 +1813,80 @@ def test_splitk_rows_and_sliced_rows_give_the_statistics_of_the_tensor():
     rc = lib.bfm_gn_stats_rows_sliced(L.ptr(rows), S * n, S * n - n + 1, n, cout, None, 0, 0, 0, 0, 1.0, D * H * W, L.ptr(gamma),
                                       L.ptr(beta), 8, 1e-5, L.ptr(got[0]), L.ptr(got[1]), L.ptr(got[2]), L.ptr(wsr), wsr.numel(), None, st)
     assert rc == -1                                                    # BFM_E_ARG
+
+
+@pytest.mark.parametrize("cout", [192, 320])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_splitk_rows_for_widths_that_are_not_64_times_a_power_of_two(cout, accumulate):
+    """splitk_reduce_rows launched Cout / 4 / 64 workgroups in y by integer division and had no column guard, so
+    for Cout = 320 the quads past the last full block of 64 were never reduced, and for Cout = 192 (48 quads, 256 / 48 voxel
+    lanes) sixteen threads re-did the first lane's voxels -- a double add in accumulate mode.  The block of column quads is
+    now the largest of 64 / 32 / 16 that divides Cout / 4.  Checked against the same launch WITHOUT moment rows (the plain
+    slab reduction, which always handled these widths): equal bits, no NaN left, and the rows give the tensor's statistics."""
+    from brainfm_amd import _lib as L
+    lib = L.load()
+    dev = _dev()
+    g = torch.Generator().manual_seed(23 + cout + accumulate)
+    cin, (D, H, W), S = 512, (6, 5, 7), 2
+    A = torch.randn((S, D, H, W, cin), generator=g).to(dev)
+    w = (torch.randn((cout, cin, 3, 3, 3), generator=g) * 0.03).to(dev).contiguous()
+    scale = (torch.rand((S, cin), generator=g) + 0.5).to(dev)
+    shift = (torch.randn((S, cin), generator=g) * 0.1).to(dev)
+    bound = torch.full((S, 8), 6.0, device=dev)
+    prior = torch.randn((S, D, H, W, cout), generator=g).to(dev)
+    cfg = (C.c_int * 8)()
+    L.check(lib.bfm_conv3x3x3_mfma_plan(cin, cout, D, H, W, cfg), "plan")
+    cfg[6] = 0
+    if cfg[5] < 2:
+        cfg[5] = 4
+    cfg[7] = accumulate
+    n = lib.bfm_conv3x3x3_mfma_rows(cin, cout, D, H, W, cfg)
+    assert 0 < n <= 128
+    wp = torch.empty(lib.bfm_pack_conv_weights_mfma_bytes(cin, cout), dtype=torch.uint8, device=dev)
+    wexp = C.c_int(0)
+    L.check(lib.bfm_pack_conv_weights_mfma(L.ptr(w), cin, cout, float(w.abs().max()), L.ptr(wp), C.byref(wexp), L.stream_ptr()), "pack")
+    ws = torch.empty(lib.bfm_conv3x3x3_mfma_batch_workspace(cin, cout, S, D, H, W, cfg[5]), dtype=torch.uint8, device=dev)
+    st = L.stream_ptr()
+
+    def run(rows):
+        out = prior.clone() if accumulate else torch.full((S, D, H, W, cout), float("nan"), device=dev)
+        L.check(lib.bfm_conv3x3x3_mfma_batch(L.ptr(A), cin, None, 0, S, D, H, W, None, L.ptr(scale), L.ptr(shift), L.ptr(bound), 8,
+                                             L.ptr(wp), wexp.value, cout, 0.01, 3, cfg, L.ptr(out), L.ptr(ws), ws.numel(),
+                                             L.ptr(rows) if rows is not None else None, 0, st), "conv")
+        torch.cuda.synchronize()
+        return out
+
+    rows = torch.zeros(lib.bfm_moment_rows_bytes(S * n, cout), dtype=torch.uint8, device=dev)
+    o0, o1 = run(None), run(rows)
+    assert not bool(torch.isnan(o1).any())
+    assert torch.equal(o0, o1)
+    nb = S * n * cout
+    rsum = rows[:nb * 8].view(torch.float64).view(S, n, cout).sum(1)
+    rmx = rows[nb * 20:nb * 24].view(torch.float32).view(S, n, cout).amax(1)
+    t = o1.view(S, -1, cout).double()
+    assert _relerr(rsum.cpu().numpy(), t.sum(1).cpu().numpy()) <= 1e-6
+    assert torch.equal(rmx, o1.view(S, -1, cout).amax(1))
+
+
+def test_maxpool_keeps_a_nan_from_any_corner_of_the_window():
+    """`q != q ? q : fmaxf(m, q)` keeps a NaN only when it is the LAST corner visited; nn.MaxPool3d propagates a
+    NaN from any corner (buildingblocks.py:185-186), so a diverging activation must stay visible after pooling.  One NaN
+    in each of the eight corners of a window in turn, C = 4 (the float4 path) and C = 3 (the scalar path), against
+    torch.nn.functional.max_pool3d on the host: same NaN positions, same finite values."""
+    from brainfm_amd import _lib as L
+    lib = L.load()
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    for c in (4, 3):
+        for corner in range(8):
+            x = torch.randn((c, 4, 6, 4), generator=g)
+            dz, dy, dx = corner >> 2, (corner >> 1) & 1, corner & 1
+            x[:, 2 + dz, 2 + dy, 0 + dx] = float("nan")
+            want = torch.nn.functional.max_pool3d(x[None], 2)[0]
+            x_cl = x.permute(1, 2, 3, 0).contiguous().to(dev)
+            out = torch.empty((2, 3, 2, c), device=dev)
+            L.check(lib.bfm_maxpool2(L.ptr(x_cl), c, 4, 6, 4, L.ptr(out), L.stream_ptr()), "maxpool2")
+            got = out.permute(3, 0, 1, 2).cpu()
+            assert torch.equal(torch.isnan(got), torch.isnan(want)), (c, corner)
+            assert bool(torch.isnan(got[:, 1, 1, 0]).all())
+            assert torch.equal(torch.nan_to_num(got), torch.nan_to_num(want)), (c, corner)

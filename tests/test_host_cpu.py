@@ -591,6 +591,33 @@ def test_no_packed_fp32_instruction_in_the_code_objects():
     assert nobj >= 15 and nkern >= 200, (nobj, nkern)
 
 
+def test_m0_is_written_only_for_the_lds_dma_of_conv_wino4d():
+    """conv_wino4d's inline assembly writes M0 for global_load_lds_dwordx4 without being able to declare it (M0 is
+    reserved; naming it as a clobber is a warning, not a constraint).  That is safe only while nothing else in those kernels
+    holds a value in M0.  Checked on the built code: in every conv_wino4d* kernel each instruction that mentions m0 is an
+    `s_mov_b32 m0, sN` whose next instructions are `s_nop 0` and the DMA, every DMA has that pair in front of it, and no
+    other reader of M0 (movrel, readlane by m0, sendmsg, ds_gws, interp) occurs."""
+    from brainfm_amd import _lib as L
+    if not os.path.exists(L.LIB_PATH):
+        from brainfm_amd import build
+        build.build(verbose=False)
+    nk = ndma = 0
+    for dis in _device_code_objects(L.LIB_PATH):
+        for m in re.finditer(r"^[0-9a-f]+ <(\S*conv_wino4d\S*)>:\n(.*?)(?=^\n|\Z)", dis, re.M | re.S):
+            body = [l.split("//")[0].strip() for l in m.group(2).splitlines() if l.strip()]
+            if not any("global_load_lds" in l for l in body):
+                continue
+            nk += 1
+            for i, l in enumerate(body):
+                if "global_load_lds" in l:
+                    ndma += 1
+                    assert body[i - 1].startswith("s_nop 0") and re.match(r"s_mov_b32 m0, s\d+", body[i - 2]), (m.group(1), body[i - 3:i + 1])
+                elif re.search(r"\bm0\b", l):
+                    assert re.match(r"s_mov_b32 m0, s\d+", l) and "global_load_lds" in body[i + 2], (m.group(1), l)
+                assert not re.match(r"(s_movrel|v_movrel|s_sendmsg|ds_gws|v_interp)", l), (m.group(1), l)
+    assert nk >= 4 and ndma >= 4 * 13, (nk, ndma)
+
+
 def test_gather_kernels_load_their_texels_past_the_l1():
     """an ordinary (L1-cached) load of a gather that runs beside a kernel using LDS-DMA can come back as 0
     (profiles/r05_atlas_hazard_bisect.txt); agent-scope loads never did.  Source-level guard: in the files that hold the
