@@ -647,6 +647,16 @@ def kernel_of(p):
     return "conv_upfold" if tag.endswith("up") else _VER_NAME.get(cfg[6], "conv_mfma")
 
 
+def issue_factor(p, passes):
+    """fp16 MFMA FLOPs a conv launch ISSUES per algorithmic FLOP (2*27*Cin*Cout per voxel): the split passes times what the
+    kernel's algebra saves -- Winograd F(2,3) along x 18/27 tap-rows, F(4,3) 13.5/27, the up-folded form 8 taps of 27
+    (profiles/r06_conv_wino4d_pmc.txt, r06_conv_upfold_pmc.txt: SQ_INSTS_MFMA x 32 768 agrees)."""
+    tag, cfg = p[5][0], p[5][4]
+    if tag.endswith("up"):
+        return passes * 8.0 / 27.0
+    return passes * {3: 18.0 / 27.0, 4: 13.5 / 27.0}.get(cfg[6], 1.0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -838,13 +848,14 @@ def main():
         sess.use_graphs = g
         prof = eng.prof
         eng.prof = None
-        per = {k: [0.0, 0.0, 0.0, 0.0] for k in CONV_KERNELS}       # ms, flops, bytes, launches
+        per = {k: [0.0, 0.0, 0.0, 0.0, 0.0] for k in CONV_KERNELS}  # ms, flops, bytes, launches, issued fp16 MFMA flops
         for p in prof:
             e = per[kernel_of(p)]
             e[0] += p[0].elapsed_time(p[1]) / p[4]
             e[1] += p[2]
             e[2] += p[3]
             e[3] += 1
+            e[4] += p[2] * issue_factor(p, args.passes)
         if table and rank == 0:
             tab = {}
             for p in prof:
@@ -876,12 +887,13 @@ def main():
         k_ms = max(rank_ms)                                      # conv kernel time of the slowest rank
         k_fl = sum(e[1] for e in per.values())
         kernels = {}
-        for k, (ms, fl, by, cnt) in per.items():
+        for k, (ms, fl, by, cnt, iss) in per.items():
             if cnt <= 0:
                 continue
             ach = fl / (ms * 1e-3) / 1e12 / max(world, 1)       # per GPU: the ranks' FLOPs over the slowest rank's time
             kernels[k] = {"launches_per_step": int(cnt), "ms_per_step": ms, "avg_launch_us": ms * 1e3 * max(world, 1) / cnt,
-                          "achieved": ach, "frac": ach / peak, "algorithmic_bytes_per_launch": by / cnt}
+                          "achieved": ach, "frac": ach / peak, "algorithmic_bytes_per_launch": by / cnt,
+                          "mfma_issue_frac": iss / (ms * 1e-3) / 1e12 / max(world, 1) / peak}
         groups = {}
         for gname, members in KERNEL_GROUPS.items():
             ms = sum(per[m][0] for m in members)
@@ -890,11 +902,15 @@ def main():
             if cnt <= 0:
                 continue
             ach = fl / (ms * 1e-3) / 1e12 / max(world, 1)
+            iss = sum(per[m][4] for m in members)
             groups[gname] = {"kernels": [m for m in members if per[m][3] > 0], "launches_per_step": int(cnt),
                              "ms_per_step": ms, "achieved": ach, "frac": ach / peak,
+                             "mfma_issue_frac": iss / (ms * 1e-3) / 1e12 / max(world, 1) / peak,
                              "share_of_conv_time": ms / sum(per[m][0] for m in CONV_KERNELS)}
         fam_ach = k_fl / (k_ms * 1e-3) / 1e12 / max(world, 1) if k_ms > 0 else 0.0
+        k_iss = sum(e[4] for e in per.values())
         family = {"achieved": fam_ach, "frac": fam_ach / peak, "kernel_ms_per_step": k_ms,
+                  "mfma_issue_frac": (k_iss / (k_ms * 1e-3) / 1e12 / max(world, 1) / peak) if k_ms > 0 else 0.0,
                   "kernel_ms_per_rank": rank_ms if world > 1 else None,
                   "launches_per_step": int(sum(e[3] for e in per.values())),
                   "algorithmic_bytes_per_step": sum(e[2] for e in per.values())}
@@ -1036,6 +1052,11 @@ def main():
                        "tiles_in_flight_per_gpu": sess.lanes if sess.use_graphs else 1},
             "roofline": {"bound": "mfma", "kernel": dominant, "kernel_members": dk.get("kernels"),
                          "achieved": dk.get("achieved"), "peak": peak, "unit": "TFLOP/s", "frac": dk.get("frac"),
+                         "mfma_issue_frac": dk.get("mfma_issue_frac"),
+                         "mfma_issue_note": "issued fp16 MFMA FLOPs / peak: the algorithmic FLOPs times the split passes times the "
+                                            "kernel's reduction (F(2,3) 18/27, F(4,3) 13.5/27, up-fold 8/27, direct 1); what the "
+                                            "matrix pipe sustains on random operands fed from LDS + L2 is 0.56 of the nameplate "
+                                            "(1 410 TFLOP/s, profiles/r02_mfma_sustained_micro.txt)",
                          "traffic": dk.get("traffic_per_launch"), "traffic_source": traffic_note,
                          "avg_launch_us": dk.get("avg_launch_us"),
                          "algorithmic_bytes_per_launch": dk.get("algorithmic_bytes_per_launch"),

@@ -71,14 +71,27 @@ __device__ __forceinline__ void box_coords(const UpParams& p, int q, int& bd, in
 // ABL (diagnostics builds only, -DBFM_UP_ABLATE, tests/diag/diag_upfold_ablate.py): phases compiled out to see what the
 // launch time is made of.  1: no weight loads in the tap loop, 2: no LDS operand reads, 4: no staging at all, 8: staging
 // without its global loads, 16: no epilogue, 64: no MFMAs.  Ablated launches compute wrong results.
-template <int NPASS, int ABL = 0>
+// NW (round 6): waves per workgroup.  8 = one workgroup holds all eight parity classes of a box (512 threads, one workgroup
+// per CU: its staging and epilogue phases leave the matrix pipe idle -- 60 % busy, profiles/r06_conv_upfold_pmc.txt).
+// 4 = a workgroup holds the classes of ONE z parity (256 threads, two workgroups per CU): the two halves of a box stage the
+// same halo'd box independently and drift apart, so one half's staging / epilogue runs under the other's products.  A wave
+// does exactly what it does in the 8-wave form (same products, same order, same stores): the bits do not change.
+template <int NPASS, int ABL = 0, int NW = 8>
 __device__ __forceinline__ void conv_upfold_body(const UpParams& p) {
+    constexpr int NTHRV = NW * 64;
     constexpr int NPL = (NPASS == 3) ? 2 : 1;
     constexpr int NF = 2 * NPL;                       // weight fragments per tap: 2 column blocks x (hi[, lo])
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int cls = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = output parity class (pz,py,px)
+    int xcd_ = blockIdx.x & 7, idx_ = blockIdx.x >> 3, half_ = 0;
+    if constexpr (NW == 4) {                                       // id -> (xcd, half, idx): both halves of a box on one XCD
+        half_ = idx_ & 1;
+        idx_ >>= 1;
+        const int nblk = p.nMt * p.NT;
+        if (idx_ >= (nblk >> 3) + (xcd_ < (nblk & 7) ? 1 : 0)) return;     // the grid is padded to whole octets
+    }
+    const int cls = __builtin_amdgcn_readfirstlane(tid >> 6) + half_ * 4;  // wave = output parity class (pz,py,px)
     const int pz = cls >> 2, py = (cls >> 1) & 1, px = cls & 1;
     const int l32 = lane & 31, khalf = lane >> 5;
 #ifdef BFM_UP_ABLATE
@@ -86,11 +99,11 @@ __device__ __forceinline__ void conv_upfold_body(const UpParams& p) {
         for (int i = 0; i < p.dbg_sleep; ++i) __builtin_amdgcn_s_sleep(16);
 #endif
 
-    int bid = blockIdx.x;
+    int bid;
     {
         const int nblk = p.nMt * p.NT;
         const int q = nblk >> 3, r = nblk & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
+        const int xcd = xcd_, idx = idx_;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int mt = bid / p.NT, nt = bid - mt * p.NT;
@@ -138,13 +151,13 @@ __device__ __forceinline__ void conv_upfold_body(const UpParams& p) {
     }
 
     // staging bookkeeping: element e = tid + it*NTHR -> (halo voxel, channel quad)
-    constexpr int MAX_IT = 4;
+    constexpr int MAX_IT = 2048 / NTHRV;
     const int n_el = p.nvox_lds * 4;
     const int q4 = tid & 3;
     int off[MAX_IT];
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
-        const int e = tid + it * NTHR;
+        const int e = tid + it * NTHRV;
         off[it] = -2;
         if (e < n_el) {
             const int vox = e >> 2;
@@ -217,7 +230,7 @@ __device__ __forceinline__ void conv_upfold_body(const UpParams& p) {
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int e = tid + (u0 + u) * NTHR;
+                const int e = tid + (u0 + u) * NTHRV;
                 if (off[u0 + u] != -2) {
                     const bool ok = off[u0 + u] >= 0;
                     float y[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
@@ -321,6 +334,8 @@ __device__ __forceinline__ void conv_upfold_body(const UpParams& p) {
 
 template <int NPASS>
 __global__ void __launch_bounds__(NTHR, 1) conv_upfold(const UpParams p) { conv_upfold_body<NPASS, 0>(p); }
+template <int NPASS>
+__global__ void __launch_bounds__(NTHR / 2, 2) conv_upfold_h(const UpParams p) { conv_upfold_body<NPASS, 0, 4>(p); }
 #ifdef BFM_UP_ABLATE
 template <int ABL>
 __global__ void __launch_bounds__(NTHR, 1) conv_upfold_abl(const UpParams p) { conv_upfold_body<3, ABL>(p); }
@@ -605,7 +620,20 @@ static int upfold_launch(const float* B, int CB, int S, int d, int h, int w, con
         return bfm_launch_status();
     }
 #endif
-    if (passes == 3) hipLaunchKernelGGL(conv_upfold<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
+    // Two half-box workgroups per CU (see conv_upfold_body) where the launch has fewer full workgroups than CUs: 7-12 % faster
+    // there (20^3 256 -> 128: 0.136 -> 0.126 ms, 10^3 1024 -> 512: 0.277 -> 0.246, 5^3 2048 -> 1024: 0.175 -> 0.159), 2 % slower
+    // on launches that fill the chip (the matrix pipe is power-limited, not phase-limited: profiles/r06_conv_upfold_pmc.txt).
+    // Same bits either way; BFM_UPFOLD_WAVES = 4 | 8 forces one form (diagnostics).
+    static const int waves_env = [] { const char* e = getenv("BFM_UPFOLD_WAVES"); return e ? atoi(e) : 0; }();
+    const int waves = waves_env ? waves_env : ((int64_t)p.nMt * p.NT * nsplit * S < 256 ? 4 : 8);
+    if (waves == 4) {
+        const int64_t nblk = (int64_t)p.nMt * p.NT;
+        const int64_t gx = 16 * bfm_cdiv64(nblk, 8);
+        if (gx > 0x7fffffff) return BFM_E_SHAPE;
+        dim3 gridh((unsigned)gx, (unsigned)nsplit, (unsigned)S);
+        if (passes == 3) hipLaunchKernelGGL(conv_upfold_h<3>, gridh, dim3(NTHR / 2), smem, bfm_s(stream), p);
+        else hipLaunchKernelGGL(conv_upfold_h<1>, gridh, dim3(NTHR / 2), smem, bfm_s(stream), p);
+    } else if (passes == 3) hipLaunchKernelGGL(conv_upfold<3>, grid, dim3(NTHR), smem, bfm_s(stream), p);
     else hipLaunchKernelGGL(conv_upfold<1>, grid, dim3(NTHR), smem, bfm_s(stream), p);
     if (nsplit > 1) {
         const int64_t n4 = nout / 4;
