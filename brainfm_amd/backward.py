@@ -149,10 +149,14 @@ def backward_single_conv(eng, t, dY, need_input_grad=True):
     # ---- weight gradient (split-fp16 matrix-core kernel on the wide layers, exact fp32 one elsewhere / on request)
     wsb = lib.bfm_conv3x3x3_wgrad_workspace(ly.cin, ly.cout, D, H, W)
     ws = torch.empty(max(wsb, 256), dtype=torch.uint8, device=dev)
-    dW = torch.empty((ly.cout, ly.cin, 3, 3, 3), dtype=torch.float32, device=dev)
+    sink = getattr(eng, "grad_sink", None)                       # train.GradStore: gradients land in their flat slot
+    dW = (sink.out(ly.name + ".conv.weight", (ly.cout, ly.cin, 3, 3, 3)) if sink is not None else
+          torch.empty((ly.cout, ly.cin, 3, 3, 3), dtype=torch.float32, device=dev))
     L.check(lib.bfm_conv3x3x3_wgrad_ex(L.ptr(dP), ly.cout, L.ptr(t.A), ca, L.ptr(t.B), cb, D, H, W, upp, L.ptr(t.scale),
                                        L.ptr(t.shift), L.ptr(bnd), L.ptr(t.bound), ly.groups, WGRAD_PASSES, L.ptr(dW),
                                        L.ptr(ws), ws.numel(), st), "conv_wgrad " + ly.name)
+    if sink is not None:
+        sink.done(ly.name + ".conv.weight")
     grads = OrderedDict()
     grads[ly.name + ".conv.weight"] = dW
     if not need_input_grad and ly.cin < 8:
@@ -188,13 +192,16 @@ def backward_single_conv(eng, t, dY, need_input_grad=True):
     # ---- GroupNorm backward
     dA = torch.empty((D, H, W, ca), dtype=torch.float32, device=dev)
     dB = torch.empty(tuple(t.lo_dims) + (cb,), dtype=torch.float32, device=dev) if cb else None
-    dgamma = torch.empty(ly.cin, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(ly.cin, dtype=torch.float32, device=dev)
+    dgamma = sink.out(ly.name + ".groupnorm.weight", (ly.cin,)) if sink is not None else torch.empty(ly.cin, dtype=torch.float32, device=dev)
+    dbeta = sink.out(ly.name + ".groupnorm.bias", (ly.cin,)) if sink is not None else torch.empty(ly.cin, dtype=torch.float32, device=dev)
     starts = _start_tables(eng, t.lo_dims, t.dims) if cb else [None, None, None]
     wsg = torch.empty(lib.bfm_gn_bwd_workspace(ly.cin, D, H, W), dtype=torch.uint8, device=dev)
     L.check(lib.bfm_gn_bwd(L.ptr(dXn), L.ptr(t.A), ca, L.ptr(t.B), cb, D, H, W, upp, L.ptr(starts[0]), L.ptr(starts[1]),
                            L.ptr(starts[2]), L.ptr(t.mean), L.ptr(t.rstd), L.ptr(ly.gamma), ly.groups, L.ptr(dA),
                            L.ptr(dB), L.ptr(dgamma), L.ptr(dbeta), L.ptr(wsg), wsg.numel(), st), "gn_bwd " + ly.name)
+    if sink is not None:
+        sink.done(ly.name + ".groupnorm.weight")
+        sink.done(ly.name + ".groupnorm.bias")
     grads[ly.name + ".groupnorm.weight"] = dgamma
     grads[ly.name + ".groupnorm.bias"] = dbeta
     return dA, dB, grads

@@ -136,6 +136,7 @@ class UNetEngine:
     pack_count = 0              # packed weight forms created so far (train.py: lazily created ones order the sample lanes)
     _ws_lanes = None
     tape = None                 # training (backward.py): list that single_conv / maxpool append their records to
+    grad_sink = None            # training (train.GradStore through train._Sink): where the backward kernels put gradients
     prof_reps = 1
     use_upfold = False
     upfold_min = 250

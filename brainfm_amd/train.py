@@ -108,6 +108,137 @@ def allreduce_mean_(grads, group=None, events=None):
     return grads
 
 
+class _Sink:
+    """What the backward pass sees of a GradStore (engine.grad_sink): `out` hands a kernel its slot, `done` adds the
+    earlier samples' sum for that slot and counts its bucket down."""
+
+    def __init__(self, store, partial, row_of):
+        self.store, self.partial, self.row_of = store, partial, row_of
+
+    def out(self, name, shape):
+        return self.store.out(name, shape)
+
+    def done(self, name):
+        if self.partial is not None:
+            v = self.store.views[name]
+            if name in ("head.weight_all", "head.bias_all"):
+                kind = "weight" if name == "head.weight_all" else "bias"
+                for task, (r0, n) in self.row_of.items():
+                    v[r0:r0 + n].add_(self.partial["head.final_conv_%s.%s" % (task, kind)])
+            else:
+                v.add_(self.partial[name])
+        self.store.done(name)
+
+
+class GradStore:
+    """All parameter gradients of one iteration in ONE persistent flat fp32 buffer, laid out in the order the backward pass
+    completes them (heads, decoders last to first, encoders last to first), cut into a few buckets of about equal bytes.
+    The weight-gradient kernels write straight into their slot (`out`), `done` counts a bucket down, and a bucket whose last
+    tensor is complete is all-reduced on a communication stream while the backward pass goes on -- DDP's bucketed overlap
+    (scripts/train.py:153-158) without DDP's copies: no torch.cat of 252 tensors in front of the collective and no 252
+    copy_ launches behind it.  The optimiser reads the slots in place; the mean's 1 / world is folded into
+    its gradient scale.  xGMI rings are per-link bound, so buckets are large (default 6 of ~180 MB for the 264 M-parameter
+    net; BFM_GRAD_BUCKETS).  Every rank issues the same collectives in the same order whatever its loss turns out to be; an
+    iteration that is skipped afterwards only wastes them."""
+
+    def __init__(self, named_shapes, device, n_buckets=None):
+        self.device = device
+        nb = int(os.environ.get("BFM_GRAD_BUCKETS", "6")) if n_buckets is None else int(n_buckets)
+        self.names = [n for n, _ in named_shapes]
+        sizes = [int(np.prod(s)) for _, s in named_shapes]
+        offs = np.concatenate([[0], np.cumsum([(n + 3) // 4 * 4 for n in sizes])])      # 16-byte aligned slots
+        self.total = int(offs[-1])
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.views = OrderedDict()
+        for (name, shape), o, n in zip(named_shapes, offs[:-1], sizes):
+            self.views[name] = self.flat[int(o):int(o) + n].view(tuple(shape))
+        # bucket b = tensors [first[b], first[b + 1]): cut where the running byte count passes b / nb of the total
+        nb = max(1, min(nb, len(self.names)))
+        self.first = [0]
+        for i in range(1, len(self.names)):
+            if len(self.first) < nb and offs[i] >= self.total * len(self.first) / nb:
+                self.first.append(i)
+        self.first.append(len(self.names))
+        self.range = [(int(offs[self.first[b]]), int(offs[self.first[b + 1]])) for b in range(len(self.first) - 1)]
+        self.bucket_of = {}
+        for b in range(len(self.first) - 1):
+            for i in range(self.first[b], self.first[b + 1]):
+                self.bucket_of[self.names[i]] = b
+        self.comm = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        self.group = None
+        self.works = []
+        self.pending = []
+        self.launched = []
+        self.events = None
+        self.active = False
+
+    def begin(self, group=None):
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.pending = [self.first[b + 1] - self.first[b] for b in range(len(self.range))]
+        self.launched = [False] * len(self.range)
+        self.works = []
+        self.events = None
+        self.active = True
+
+    def out(self, name, shape):
+        v = self.views[name]
+        if tuple(v.shape) != tuple(shape):
+            raise L.BfmError("gradient slot %s has shape %s, the kernel writes %s" % (name, tuple(v.shape), tuple(shape)))
+        return v
+
+    def done(self, name):
+        """The kernel that completes `name` has been enqueued on the current stream."""
+        b = self.bucket_of[name]
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        if self.launched[b]:
+            return
+        self.launched[b] = True
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        lo, hi = self.range[b]
+        seg = self.flat[lo:hi]
+        if self.comm is None:
+            self.works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        ev = torch.cuda.Event()
+        ev.record()                                                   # the bucket's last producer, on the compute stream
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(ev)
+            self.works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Backward is over: launch what is left (a slot nobody wrote is all-reduced as the zeros it holds), then make the
+        compute stream wait for the collectives.  events = (backward end, collectives end, bytes): the time between the two
+        is what the all-reduce EXPOSES (bench.py: config5.allreduce_exposed_ms)."""
+        for b in range(len(self.range)):
+            if not self.launched[b]:
+                self._launch(b)
+        self.active = False
+        if self.world <= 1:
+            return
+        if self.comm is None:
+            for w in self.works:
+                w.wait()
+            return
+        main = torch.cuda.current_stream(self.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(main)
+        with torch.cuda.stream(self.comm):
+            for w in self.works:
+                w.wait()
+            e1.record(self.comm)
+        main.wait_event(e1)
+        self.events = (e0, e1, self.total * 4)
+        self.works = []
+
+
 # bfm_adam_tensor_t (include/brainfm_hip.h): p, g, m, v, n, grad_scale, bias1, bias2_sqrt, first_chunk, reserved
 _ADAM_DESC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("grad_scale", "<f4"),
                        ("bias1", "<f4"), ("bias2_sqrt", "<f4"), ("first_chunk", "<i4"), ("reserved", "<i8")])
@@ -176,6 +307,19 @@ class TrainStep:
             p["head.final_conv_%s.weight" % task] = self.tail.head_w[r0:r0 + n]
             p["head.final_conv_%s.bias" % task] = self.tail.head_b[r0:r0 + n]
         return p
+
+    def grad_store(self):
+        """The persistent gradient buffer (GradStore), slots in the order the backward pass completes them."""
+        st = self.__dict__.get("_grad_store")
+        if st is None:
+            named = [("head.weight_all", (self.tail.n_out, self.tail.c_feat)), ("head.bias_all", (self.tail.n_out,))]
+            for pair in list(reversed(self.eng.dec)) + list(reversed(self.eng.enc)):
+                for ly in reversed(pair):
+                    named.append((ly.name + ".conv.weight", tuple(ly.w_raw.shape)))
+                    named.append((ly.name + ".groupnorm.weight", tuple(ly.gamma.shape)))
+                    named.append((ly.name + ".groupnorm.bias", tuple(ly.beta.shape)))
+            st = self._grad_store = GradStore(named, self.dev)
+        return st
 
     def _weights_changed(self):
         """Right after the optimiser: every packed form a layer holds (forward variants, skip half, up-folded, transposed
@@ -453,8 +597,9 @@ class TrainStep:
         dRaw = torch.zeros_like(raw)
         vals = torch.zeros(4 * len(self.loss_names) + 2 * tail.n_out + 8, dtype=torch.float64, device=self.dev)
         slots, _ = self._sample_losses(raw, dims, target, sample, dRaw, vals, scale, rows=rows)
-        dW = torch.empty((n_out, cf), dtype=torch.float32, device=self.dev)
-        db = torch.empty(n_out, dtype=torch.float32, device=self.dev)
+        sink = getattr(eng, "grad_sink", None)
+        dW = sink.out("head.weight_all", (n_out, cf)) if sink is not None else torch.empty((n_out, cf), dtype=torch.float32, device=self.dev)
+        db = sink.out("head.bias_all", (n_out,)) if sink is not None else torch.empty(n_out, dtype=torch.float32, device=self.dev)
         dFn = torch.empty((nvox, cf), dtype=torch.float32, device=self.dev)
         wsb = torch.empty(lib.bfm_head_bwd_workspace(n_out, cf, nvox), dtype=torch.uint8, device=self.dev)
         if rows:
@@ -463,6 +608,9 @@ class TrainStep:
         else:
             L.check(lib.bfm_head_bwd(L.ptr(dRaw), L.ptr(fn), L.ptr(tail.head_w), n_out, cf, nvox, L.ptr(dW), L.ptr(db),
                                      L.ptr(dFn), L.ptr(wsb), wsb.numel(), st), "head_bwd")
+        if sink is not None:
+            sink.done("head.weight_all")
+            sink.done("head.bias_all")
         if eng.unit_feat:
             dfeat = torch.empty_like(dFn)
             L.check(lib.bfm_normalize_bwd(L.ptr(feat_last), L.ptr(dFn), cf, nvox, 1e-12, L.ptr(dfeat), st), "normalize_bwd")
@@ -495,8 +643,23 @@ class TrainStep:
         lanes = self.sample_lanes if (n > 1 and self.t >= 1) else 1
         nvox = None
         results = []
-        if lanes <= 1:
-            for x, sample in zip(xs, samples):
+        # Where the gradients of the iteration are collected.  With more than one rank -- or with one sample lane -- the LAST
+        # sample's kernels write straight into the persistent GradStore and start its buckets' all-reduces as each bucket
+        # completes, i.e. under that sample's own backward pass; the earlier samples' sum (in sample order; a + b == b + a
+        # bit for bit) is added slot by slot in front of each `done`.  That is DDP with gradient accumulation: no_sync for
+        # all samples but the last.  The last sample then runs on the caller's stream after the lanes have joined.  One
+        # rank with two lanes keeps every sample on the lanes (nothing to all-reduce).
+        import torch.distributed as dist
+        group = getattr(self, "_group", None)
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        # only inside step(): a bare loss_and_grads() call must neither start collectives nor hand out views of a buffer the
+        # next call overwrites
+        use_store = (self.__dict__.pop("_store_next", False) and os.environ.get("BFM_GRAD_STORE", "1") != "0" and
+                     (lanes <= 1 or world > 1))
+        n_head = n - 1 if use_store else n                 # samples that go the ordinary way
+        store = None
+        if lanes <= 1 or n_head <= 1:
+            for x, sample in zip(xs[:n_head], samples[:n_head]):
                 results.append(self._one_sample(x, target, sample, scale) + (None,))
         else:
             main = torch.cuda.current_stream(self.dev)
@@ -505,7 +668,7 @@ class TrainStep:
             start = torch.cuda.Event()
             start.record(main)
             seen = eng.pack_count
-            for i, (x, sample) in enumerate(zip(xs, samples)):
+            for i, (x, sample) in enumerate(zip(xs[:n_head], samples[:n_head])):
                 k = i % lanes
                 st = self._lane_streams[k]
                 st.wait_event(start)
@@ -527,25 +690,42 @@ class TrainStep:
                 vals.record_stream(main)
                 for t_ in g.values():
                     t_.record_stream(main)
+        if use_store:
+            store = self.grad_store()
+            store.begin(group)
+            part = None
+            for r in results:
+                part = r[0] if part is None else OrderedDict((k_, part[k_] + v_) for k_, v_ in r[0].items())
+            eng.grad_sink = _Sink(store, part, self.tail.row_of)
+            try:
+                results.append(self._one_sample(xs[-1], target, samples[-1], scale) + (None,))
+            finally:
+                eng.grad_sink = None
         grads = None
         per_sample = []
+        self._store_live = store
         for x, (g, slots, vals, _) in zip(xs, results):
             nvox = x.shape[-3] * x.shape[-2] * x.shape[-1]
             per_sample.append((slots, vals))
+            if store is not None:
+                continue                                   # the last sample's slots already hold the sum
             if grads is None:
                 grads = g
             else:
                 for k_, v_ in g.items():
                     grads[k_] = grads[k_] + v_
+        if store is not None:
+            grads = results[-1][0]
         loss_dict = self._finish_losses(per_sample, nvox)
         total = sum(v * self.loss_weights.get(k, 0.0) for k, v in loss_dict.items() if k in self.loss_weights)
         return loss_dict, total, grads
 
     # ------------------------------------------------------------------ optimiser
     @L.on_device(lambda self, *a, **k: self.dev)
-    def apply(self, grads, lr=None, weight_decay=None):
+    def apply(self, grads, lr=None, weight_decay=None, grad_div=1.0):
         """unscale -> per-parameter clip (utils/misc.py:1329-1338) -> AdamW -> scaler.update.  Returns
-        (stepped, norms): stepped is False when a non-finite gradient made the scaler skip the step."""
+        (stepped, norms): stepped is False when a non-finite gradient made the scaler skip the step.
+        grad_div: the gradients hold a SUM over that many ranks (GradStore); the mean's division is folded into the unscale."""
         lib, st = self.lib, L.stream_ptr()
         lr = self.lr if lr is None else float(lr)
         wd = self.wd if weight_decay is None else float(weight_decay)
@@ -586,7 +766,7 @@ class TrainStep:
                 g = grads[k]
                 L.check(lib.bfm_grad_sumsq(L.ptr(g), g.numel(), C.c_void_p(sums.data_ptr() + 8 * i), L.ptr(flag),
                                            L.ptr(self._ws), self._ws.numel(), st), "grad_sumsq " + k)
-        inv = 1.0 / self.scaler.scale
+        inv = 1.0 / (self.scaler.scale * grad_div)
         found_inf = bool(flag.item())
         norms = [math.sqrt(v) * inv if math.isfinite(v) else float("inf") for v in sums.cpu().tolist()]
         found_inf = found_inf or any(not math.isfinite(v) for v in norms)
@@ -627,9 +807,15 @@ class TrainStep:
         the loss dictionary is averaged over the ranks first (utils.reduce_dict, engine.py:124-130) and the skip decision
         is taken on that reduced value, so every rank skips -- or enters the gradient all-reduce -- together."""
         import torch.distributed as dist
+        self._group = group
+        self._store_next = True
         loss_dict, total, grads = self.loss_and_grads(xs, target, samples)
+        store = self.__dict__.pop("_store_live", None)
         touched = set(self._touched_heads)
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if store is not None:
+            store.finish()                                     # every rank, whatever its loss: the collectives are in flight
+            self.allreduce_events = list(store.events) if store.events else []
         if multi:
             world = dist.get_world_size(group)
             tasks = list(self.tail.row_of.keys())
@@ -647,10 +833,14 @@ class TrainStep:
             touched = {task for j, task in enumerate(tasks) if t[2 * nk + j] > 0}     # find_unused_parameters=True
         if not math.isfinite(total):
             return loss_dict, total, False                     # engine.py:129-136: non-finite loss -> skip the iteration
-        allreduce_mean_(grads, group, self.__dict__.setdefault("allreduce_events", []))
+        grad_div = 1.0
+        if store is not None:
+            grad_div = float(store.world)                      # the buckets hold the SUM over the ranks; the mean's 1 / world
+        else:                                                  # goes into the optimiser's gradient scale
+            allreduce_mean_(grads, group, self.__dict__.setdefault("allreduce_events", []))
         for task in self.tail.row_of:                          # heads nobody's loss reached: no gradient, no step
             if task not in touched:
                 grads.pop("head.final_conv_%s.weight" % task, None)
                 grads.pop("head.final_conv_%s.bias" % task, None)
-        stepped, _ = self.apply(grads, lr, weight_decay)
+        stepped, _ = self.apply(grads, lr, weight_decay, grad_div=grad_div)
         return loss_dict, total, stepped
