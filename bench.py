@@ -176,7 +176,7 @@ def elementwise_failures(a, b):
 def label_parity(sess, tile, ref, sd):
     """The HIP path's labels on the tile the CPU baseline just evaluated, against that fp32 oracle result: number of
     differing voxels, and -- when there are any -- the relative gap of the two best class probabilities at those voxels
-    in a float64 evaluation of the same network (a difference there is a tie fp32 cannot resolve)."""
+    in a float64 evaluation of the same network (a difference there is a tie fp32 cannot resolve, HISTORY.md section 1)."""
     from oracle import unet_ref as O
     dev = sess.device
     out, _ = sess.forward_fused(tile.to(dev), want_feat=False, want_seg=False)

@@ -1,6 +1,6 @@
 // 3x3x3 convolution with a Winograd F(2,3) transform along x: 1.5x fewer matrix-core FLOPs for the same result.
 //
-// The conv_mfma family is bound by what the matrix pipe sustains under its power limit, so the only
+// The conv_mfma family is bound by what the matrix pipe sustains under its power limit (HISTORY.md section 3.1), so the only
 // way up is to issue fewer MFMAs.  Along x, two neighbouring outputs (x0, x0+1) of a 3-tap correlation need 4
 // products instead of 6:
 //      d = in[x0-1 .. x0+2]            V = (d0-d2, d1+d2, d2-d1, d1-d3)

@@ -25,7 +25,7 @@ inline int grid_for(int64_t n, int tpb = 256, int cap = 8192) {
 
 // Texel loads of the gathers (data-dependent addresses, lines re-used from the L1 by neighbouring lanes and waves) go past
 // the per-CU vector L1: agent scope = global_load_dword sc1, served by the XCD's L2.  Round 3 cornered what round 2 had
-// only worked around (tests/diag/diag_atlas_repro.py, profiles/r03_atlas_gather_hazard.txt): with
+// only worked around (HISTORY.md section 3.3, tests/diag/diag_atlas_repro.py, profiles/r03_atlas_gather_hazard.txt): with
 // ordinary loads such a gather gets wrong texels -- whole 16-lane groups -- whenever a kernel that fills its LDS by LDS-DMA
 // (global_load_lds, every conv kernel here) runs beside it on another stream; an L1 invalidate at kernel start does not
 // help, L1-bypassing loads (agent or system scope) do.  The value type is float or a 4-byte bit pattern.
@@ -532,7 +532,7 @@ __global__ void grid_pull3d(const float* __restrict__ inp, int Bi, int C, int nx
         const int b = (int)(i / nout);
         const int64_t v = i - (int64_t)b * nout;
         const float* g = grid + ((int64_t)(Bg == 1 ? 0 : b) * nout + v) * 3;
-        const float gx = ld_tex(g), gy = ld_tex(g + 1), gz = ld_tex(g + 2);   // 4-byte agent-scope loads
+        const float gx = ld_tex(g), gy = ld_tex(g + 1), gz = ld_tex(g + 2);   // 4-byte agent-scope loads (HISTORY.md section 3.3, round 5)
         float mask = 1.f;
         if (extrap == 0 || extrap == 2) {
             const float thr = extrap == 2 ? 0.5f + 5e-2f : 5e-2f;
@@ -585,7 +585,7 @@ __global__ void grid_push3d(const float* __restrict__ inp, int Bi, int C, const 
         const int b = (int)(i / nin);
         const int64_t v = i - (int64_t)b * nin;
         const float* g = grid + ((int64_t)(Bg == 1 ? 0 : b) * nin + v) * 3;
-        const float gx = ld_tex(g), gy = ld_tex(g + 1), gz = ld_tex(g + 2);   // 4-byte agent-scope loads
+        const float gx = ld_tex(g), gy = ld_tex(g + 1), gz = ld_tex(g + 2);   // 4-byte agent-scope loads (HISTORY.md section 3.3, round 5)
         float mask = 1.f;
         if (extrap == 0 || extrap == 2) {
             const float thr = extrap == 2 ? 0.5f + 5e-2f : 5e-2f;
@@ -631,7 +631,7 @@ __global__ void grid_grad3d(const float* __restrict__ inp, int Bi, int C, int nx
         const int b = (int)(i / nout);
         const int64_t v = i - (int64_t)b * nout;
         const float* g = grid + ((int64_t)(Bg == 1 ? 0 : b) * nout + v) * 3;
-        const float gx = ld_tex(g), gy = ld_tex(g + 1), gz = ld_tex(g + 2);   // 4-byte agent-scope loads
+        const float gx = ld_tex(g), gy = ld_tex(g + 1), gz = ld_tex(g + 2);   // 4-byte agent-scope loads (HISTORY.md section 3.3, round 5)
         float mask = 1.f;
         if (extrap == 0 || extrap == 2) {
             const float thr = extrap == 2 ? 0.5f + 5e-2f : 5e-2f;

@@ -24,7 +24,7 @@ inline int grid_for(int64_t n, int tpb = 256, int cap = 8192) {
 #define GRID_STRIDE(i, n) \
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (int64_t)gridDim.x * blockDim.x)
 
-__device__ __forceinline__ float ld_tex(const float* p) {          // past the per-CU L1
+__device__ __forceinline__ float ld_tex(const float* p) {          // past the per-CU L1 (HISTORY.md section 3.3)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ int32_t ld_tex(const int32_t* p) {

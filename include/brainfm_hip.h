@@ -502,7 +502,7 @@ int bfm_deformed_atlas(const float* mask, const float* regx, const float* regy, 
                        int nx, int ny, int nz, const float* A_host, int64_t n, float* out, bfm_stream_t stream);
 /* The same inside the tile loop -- scripts/demo_test.py:88-89,102-104: the mask operand is the tile's input image and
  * M = (tile_in != 0), i.e. the 0/1 mask the script builds before it calls get_deformed_atlas.  Both entry points read
- * the atlas with L1-bypassing (sc1) loads: see DESIGN.md section 3.3. */
+ * the atlas with L1-bypassing (sc1) loads: see HISTORY.md section 3.3. */
 int bfm_deformed_atlas_tile(const float* tile_in, const float* regx, const float* regy, const float* regz,
                             const float* atlas, int nx, int ny, int nz, const float* A_host, int64_t n, float* out,
                             bfm_stream_t stream);

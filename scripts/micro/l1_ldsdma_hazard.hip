@@ -1,4 +1,4 @@
-// Library-independent reproducer attempt for the hazard of DESIGN.md section 3.3: does a gather whose
+// Library-independent reproducer attempt for the hazard of HISTORY.md section 3.3: does a gather whose
 // ordinary vector loads re-use lines from the per-CU L1 return wrong texels while ANOTHER kernel on another stream fills
 // its LDS with global_load_lds_dwordx4 (LDS-DMA)?  Two kernels, no library:
 //   gather<SC1>  : every thread samples 8 neighbouring texels of a 256^3 float volume whose content is a known function

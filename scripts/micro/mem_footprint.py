@@ -1,4 +1,4 @@
-"""Device memory of the tile flow after two volumes at 256^3 and 512^3."""
+"""Device memory of the tile flow after two volumes at 256^3 and 512^3 (HISTORY.md section 2)."""
 import os
 import sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench

@@ -1,5 +1,5 @@
 """Accuracy of a 3-tap correlation along x over K = 64 x 9 fp32-accumulated terms with split-fp16 three-pass products:
-direct, Winograd F(2,3) (what conv3d_wino.hip does) and F(4,3), against float64.
+direct, Winograd F(2,3) (what conv3d_wino.hip does) and F(4,3) (HISTORY.md section 7, item 1a), against float64.
   python scripts/micro/wino_f43_accuracy.py   ->   direct 3.9e-07, F(2,3) 8.3e-07, F(4,3) 7.3e-06 (max, relative to max|y|)"""
 import numpy as np
 rng=np.random.default_rng(0)

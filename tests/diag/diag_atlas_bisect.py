@@ -1,4 +1,4 @@
-"""Round 5 bisection of the atlas-gather hazard (-DBFM_DIAG build): which loads of deformed_atlas have to be
+"""Round 5 bisection of the atlas-gather hazard (HISTORY.md section 3.3; -DBFM_DIAG build): which loads of deformed_atlas have to be
 ordinary for wrong texels to appear beside conv_mfma / conv_mfma16, and what the wrong values are.
     python tests/diag/diag_atlas_bisect.py [iterations=100]
 One atlas stream (eager) + the co-runner on a side stream, constant atlas (any value other than 100 / 0 is a wrong load)

@@ -1,4 +1,4 @@
-"""Stand-alone reproducer attempt for the atlas-gather hazard of DESIGN.md section 3.3 (round 3, time-boxed).
+"""Stand-alone reproducer attempt for the atlas-gather hazard of HISTORY.md section 3.3 (round 3, time-boxed).
 
     BFM_ATLAS_PLAIN_LOADS=1 python tests/diag/diag_atlas_repro.py     # texels by plain global loads (the form that failed)
     python tests/diag/diag_atlas_repro.py                              # texels by sc0 sc1 loads (what ships)

@@ -1,4 +1,4 @@
-"""Round 6: the gather-beside-conv_wino4d hazard -- aggressor-side and placement experiments.
+"""Round 6: the gather-beside-conv_wino4d hazard (HISTORY.md section 3.3) -- aggressor-side and placement experiments.
 
     python tests/diag/diag_hazard_r6.py <co-runner variant 0|2|3|4> <eager|graph> [rounds]
     BFM_DIAG_LIB=brainfm_amd/libbrainfm_hip_fullexec.so   a diagnostics build of the library (scripts/build_variant.py)

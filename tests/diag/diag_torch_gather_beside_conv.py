@@ -1,4 +1,4 @@
-"""DESIGN.md section 3.3, one more cut (round 4): is it OUR gather, or anything with L1-cached data-dependent loads, that
+"""HISTORY.md section 3.3, one more cut (round 4): is it OUR gather, or anything with L1-cached data-dependent loads, that
 reads wrong values while the library's conv_mfma (weights into LDS by LDS-DMA) runs on another stream?  The gather here
 is torch's own index kernel (torch.take: ordinary global loads, no code of this library), on two streams, beside six
 conv_mfma launches on a third; every result is compared with a serial run.  The library-independent pair of kernels

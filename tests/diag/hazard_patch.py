@@ -1,4 +1,4 @@
-"""Round 6: assembly-level bisection of the grid_pull3d-beside-conv_wino4d hazard.
+"""Round 6: assembly-level bisection of the grid_pull3d-beside-conv_wino4d hazard (HISTORY.md section 3.3).
 
 Compiles brainfm_amd/csrc/synth_interp.hip to gfx950 assembly exactly as the library build does, then writes variants of the
 code object in which ONLY grid_pull3d is edited (s_nop's behind one instruction class at a time) into

@@ -1,4 +1,8 @@
-"""Pin brainfm_amd.volio to the one real volume file the reference's hot path reads:
+"""PARITY UNPINNED (nibabel absent): this fixture does NOT come from the reference's reader (utils/misc.py:194-222 MRIread /
+MRIwrite = nibabel), which cannot be imported in this image.  It is the closest available substitute and is labelled as such
+in DESIGN.md section 9 and README.md: row N3 stays "partial" until a nibabel-made fixture exists.
+
+Pin brainfm_amd.volio to the one real volume file the reference's hot path reads:
 files/gca.mgz (utils/test_utils.py:38-43 -> MNI, aff2).  nibabel is absent from this image, so the expected values are
 produced HERE by an independent parse of the FreeSurfer MGH format definition (gzip + struct, nothing from volio):
 

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 TOL_PARITY = 1e-4      # single blocks: max |a-b| / max|b| for fp32-grade paths
 EW_FRAC_PARITY = 2e-2  # element-wise rule |a-b| <= 1e-3 |b| + 1e-5 max|b|: largest failing fraction accepted per map on the
-                       # full-width net (measured values are printed by the config 1 / 2 tests and stand in DESIGN.md section 1)
+                       # full-width net (measured values are printed by the config 1 / 2 tests and stand in HISTORY.md section 1)
 TOL_NET = 1e-3         # whole network: the north-star tolerance.  F.normalize over few channels is
                        # ill-conditioned: torch-CPU fp32 itself sits 2e-4 from an fp64 evaluation of
                        # the small golden net (tests/diag/diag_small.py), the HIP path 1.4e-4.

@@ -437,7 +437,7 @@ def test_generator_getitem_vs_reference_golden(tag):
 def test_gathers_inside_captured_graphs_on_two_lanes_keep_their_goldens():
     """The gathers of the library that read texels with plain loads -- fast_3D_interp_torch (bfm_interp3d_linear) and
     interpol.grid_pull (bfm_grid_pull3d_linear) -- had only ever run on one stream outside any graph, while the atlas
-    gather misbehaved exactly inside two concurrently replaying graphs.  Each is captured in a
+    gather misbehaved exactly inside two concurrently replaying graphs (HISTORY.md section 3.3).  Each is captured in a
     hipGraph per lane (own coordinate and output buffers, one shared source volume), the two graphs are replayed
     concurrently on two streams 100 times with a third stream beside them running a convolution that fills its LDS by
     LDS-DMA (global_load_lds: round 3 found that THIS is what the atlas gather's ordinary loads went wrong beside,
@@ -602,7 +602,7 @@ def test_grid_pull_beside_conv_wino4d_on_the_same_compute_units():
 
 
 def test_streaming_kernels_with_l1_reuse_beside_an_lds_dma_corunner_keep_their_bits():
-    """DESIGN.md section 3.3 / VERDICT r3 #6: besides the gathers, three kernels of the tile flow read with ordinary
+    """HISTORY.md section 3.3 / VERDICT r3 #6: besides the gathers, three kernels of the tile flow read with ordinary
     vector loads that re-use L1 lines between neighbouring lanes -- the stem's halo gather (bfm_conv3x3x3_stem_ex),
     maxpool2 (bfm_maxpool2_ex) and the uniform-box flags (bfm_uniform_boxes_level).  Each runs on two streams at once
     beside the LDS-DMA co-runners the atlas gather went wrong beside (conv_mfma and -- the strongest trigger -- conv_wino4d,

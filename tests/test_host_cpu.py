@@ -754,7 +754,7 @@ def test_m0_is_written_only_for_the_lds_dma_of_conv_wino4d():
 
 
 def test_gather_kernels_load_their_texels_past_the_l1():
-    """an ordinary (L1-cached) load of a gather that runs beside a kernel using LDS-DMA can come back as 0
+    """HISTORY.md section 3.3: an ordinary (L1-cached) load of a gather that runs beside a kernel using LDS-DMA can come back as 0
     (profiles/r05_atlas_hazard_bisect.txt); agent-scope loads never did.  Source-level guard: in the files that hold the
     kernels with data-dependent addresses, every read of the gathered volume goes through ld_tex / ld_l2 (agent / system
     scope atomics) or a raw buffer load with the sc1 aux bit -- never a plain dereference of the source pointer."""
