@@ -36,10 +36,10 @@ __device__ __forceinline__ uint32_t ld_tex(const uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// C == 1.  MODE 2 ships: eight 4-byte agent-scope loads, the only form that never returned a wrong texel beside a kernel that
-// uses LDS-DMA (profiles/r05_atlas_hazard_bisect.txt: round 4's paired 8-byte loads -- MODE 0 through a buffer descriptor with
-// aux = sc1, MODE 1 sc0 sc1, MODE 3 a global 8-byte load at system scope -- all did beside conv_wino4d, although they bypass the
-// L1).  The other modes exist in -DBFM_DIAG builds only (BFM_INTERP_MODE = 10 / 1 / 3).
+// C == 1.  MODE 0 ships: the two z-neighbours of a corner in ONE 8-byte load through a buffer descriptor (aux 16 = sc1), four
+// loads per sample instead of eight (20 against 25 us at 160^3).  MODE 1: the same with sc0 sc1; MODE 2: eight 4-byte
+// agent-scope loads (what round 5 shipped); MODE 3: an 8-byte global load at system scope.  Modes other than 0 are reachable
+// in -DBFM_DIAG builds only (BFM_INTERP_MODE).
 typedef int v2i_t __attribute__((ext_vector_type(2)));
 template <int MODE>
 __global__ void interp_linear1(const float* __restrict__ X, int nx, int ny, int nz, uint32_t vol_bytes,
@@ -797,7 +797,10 @@ extern "C" int bfm_interp3d_linear(const float* X, int nx, int ny, int nz, int C
 #endif
 #define BFM_IL1(M) hipLaunchKernelGGL(interp_linear1<M>, dim3(grid_for(n)), dim3(256), 0, bfm_s(stream), X, nx, ny, nz, (uint32_t)vbytes, \
                                       II, JJ, KK, n, default_value, out)
-        if (mode == 1) BFM_IL1(1); else if (mode == 10) BFM_IL1(0); else if (mode == 3) BFM_IL1(3); else BFM_IL1(2);
+        // MODE 0 ships again (round 6): one 8-byte load per z pair through a buffer descriptor.  Round 5 shipped MODE 2 (4-byte
+        // loads) because the paired forms "failed beside conv_wino4d"; what failed was a packed-FP32 multiply of the corner
+        // weights (profiles/r06_hazard_root_cause.txt), and the library holds no such instruction any more.
+        if (mode == 1) BFM_IL1(1); else if (mode == 2) BFM_IL1(2); else if (mode == 3) BFM_IL1(3); else BFM_IL1(0);
 #undef BFM_IL1
     }
     else

@@ -31,11 +31,20 @@ __device__ __forceinline__ int32_t ld_tex(const int32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Round 5: back to two 4-byte agent-scope loads.  The 8-byte forms (buffer or global, sc1 or sc0 sc1) returned zeros for some
-// lanes beside conv_wino4d's LDS-DMA traffic (profiles/r05_atlas_hazard_bisect.txt); 4-byte global sc1 loads never have.
-__device__ __forceinline__ void ld_tex2(const float* base, int64_t elem, bool second_distinct, float& a, float& b) {
-    a = ld_tex(base + elem);
-    b = second_distinct ? ld_tex(base + elem + 1) : a;
+// The two z-neighbours of a trilinear sample sit side by side in memory: ONE 8-byte load (aux 16 = sc1, agent scope) through
+// a buffer descriptor whose range check makes the one-past-the-end read of a clamped upper corner harmless (it returns 0 and
+// the value is not used).  Halves the L2 requests of the gathers (round 4: interp_linear 37 -> 20 us at 160^3).  Round 5 had
+// gone back to two 4-byte loads because the 8-byte forms "returned zeros beside conv_wino4d"; round 6 found that the zeros were
+// corner WEIGHTS lost by a packed-FP32 multiply, not texels (profiles/r06_hazard_root_cause.txt), and the library is built
+// without packed-FP32 instructions since -- so the fast form is back.
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tex_rsrc(const float* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void ld_tex2(__amdgpu_buffer_rsrc_t r, int64_t elem, bool second_distinct, float& a, float& b) {
+    const v2i_t v = __builtin_amdgcn_raw_buffer_load_b64(r, (uint32_t)(elem << 2), 0, 16);
+    a = __int_as_float(v.x);
+    b = second_distinct ? __int_as_float(v.y) : a;
 }
 
 __device__ __forceinline__ float nan_to_num(float x) {
@@ -263,8 +272,9 @@ __global__ void gather_targets(GJobs J, int ny, int nz, Box B, uint32_t vol_byte
                 const float* X = jb.src;
                 float t000, t001, t100, t101, t010, t011, t110, t111;
                 if (paired) {
-                    ld_tex2(X, o000, zpair, t000, t001); ld_tex2(X, o100, zpair, t100, t101);
-                    ld_tex2(X, o010, zpair, t010, t011); ld_tex2(X, o110, zpair, t110, t111);
+                    const __amdgpu_buffer_rsrc_t R = tex_rsrc(X, vol_bytes);
+                    ld_tex2(R, o000, zpair, t000, t001); ld_tex2(R, o100, zpair, t100, t101);
+                    ld_tex2(R, o010, zpair, t010, t011); ld_tex2(R, o110, zpair, t110, t111);
                 } else {
                     t000 = ld_tex(X + o000); t001 = ld_tex(X + o001); t100 = ld_tex(X + o100); t101 = ld_tex(X + o101);
                     t010 = ld_tex(X + o010); t011 = ld_tex(X + o011); t110 = ld_tex(X + o110); t111 = ld_tex(X + o111);
@@ -610,9 +620,10 @@ __global__ void interp_linear_axes(const float* __restrict__ X, int nx, int ny, 
         const int64_t sx = (int64_t)ny * nz, sy = nz;
         float t000, t001, t100, t101, t010, t011, t110, t111;
         if (vol_bytes) {
+            const __amdgpu_buffer_rsrc_t R = tex_rsrc(X, vol_bytes);
             const bool zp = cz != fz;
-            ld_tex2(X, fx * sx + fy * sy + fz, zp, t000, t001); ld_tex2(X, cx * sx + fy * sy + fz, zp, t100, t101);
-            ld_tex2(X, fx * sx + cy * sy + fz, zp, t010, t011); ld_tex2(X, cx * sx + cy * sy + fz, zp, t110, t111);
+            ld_tex2(R, fx * sx + fy * sy + fz, zp, t000, t001); ld_tex2(R, cx * sx + fy * sy + fz, zp, t100, t101);
+            ld_tex2(R, fx * sx + cy * sy + fz, zp, t010, t011); ld_tex2(R, cx * sx + cy * sy + fz, zp, t110, t111);
         } else {
             auto at = [&](int a, int b, int c) { return ld_tex(X + a * sx + b * sy + c); };
             t000 = at(fx, fy, fz); t001 = at(fx, fy, cz); t100 = at(cx, fy, fz); t101 = at(cx, fy, cz);

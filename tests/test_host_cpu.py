@@ -751,52 +751,3 @@ def test_m0_is_written_only_for_the_lds_dma_of_conv_wino4d():
                     assert re.match(r"s_mov_b32 m0, s\d+", l) and "global_load_lds" in body[i + 2], (m.group(1), l)
                 assert not re.match(r"(s_movrel|v_movrel|s_sendmsg|ds_gws|v_interp)", l), (m.group(1), l)
     assert nk >= 4 and ndma >= 4 * 13, (nk, ndma)
-
-
-def test_gather_kernels_load_their_texels_past_the_l1():
-    """HISTORY.md section 3.3: an ordinary (L1-cached) load of a gather that runs beside a kernel using LDS-DMA can come back as 0
-    (profiles/r05_atlas_hazard_bisect.txt); agent-scope loads never did.  Source-level guard: in the files that hold the
-    kernels with data-dependent addresses, every read of the gathered volume goes through ld_tex / ld_l2 (agent / system
-    scope atomics) or a raw buffer load with the sc1 aux bit -- never a plain dereference of the source pointer."""
-    import re
-    csrc = os.path.join(ROOT, "brainfm_amd", "csrc")
-    txt = open(os.path.join(csrc, "synth_interp.hip")).read()
-    # the helpers exist and are scoped loads
-    assert re.search(r"ld_tex\(const float\* p\) \{\s*return __hip_atomic_load\(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT\)", txt)
-    assert re.search(r"ld_l2\(const float\* p\) \{\s*return __hip_atomic_load\(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM\)", txt)
-
-    def body(name):
-        i = txt.index(name)
-        j = txt.index("\n}\n", i)
-        return txt[i:j]
-    # interp_linear1: the shipped instantiation is MODE 2 (4-byte agent-scope loads); the paired 8-byte forms that went wrong
-    # beside conv_wino4d (round 5) are reachable in -DBFM_DIAG builds only
-    b = body("__global__ void interp_linear1(")
-    assert "MODE == 2" in b and "lo = ld_tex(q);" in b
-    launch = txt[txt.index("#define BFM_IL1(M)"):txt.index("#undef BFM_IL1")]
-    assert launch.rstrip().endswith("else BFM_IL1(2);") and "int mode = 0;" in txt[txt.index("#define BFM_IL1(M)") - 400:txt.index("#define BFM_IL1(M)")]
-    pre = txt[txt.index("int mode = 0;"):txt.index("#define BFM_IL1(M)")]
-    assert "#ifdef BFM_DIAG" in pre and "#endif" in pre
-    for k in ("__global__ void interp_linear(", "__global__ void interp_nearest(", "__global__ void grid_pull3d", "__global__ void grid_grad3d"):
-        b = body(k)
-        assert "ld_tex(" in b, k
-    b = body("__global__ void deformed_atlas(")
-    assert "return ld_l2(q);" in b
-    # the shipped launch of deformed_atlas is variant 0 (scoped loads); the ordinary forms exist in -DBFM_DIAG builds only
-    tail = txt[txt.index('extern "C" int bfm_deformed_atlas_tile'):]
-    tail = tail[:tail.index("#undef BFM_ATLAS_LAUNCH")]
-    pre, diag = tail.split("#ifdef BFM_DIAG")
-    diag, rest = diag.split("#else")
-    assert "BFM_ATLAS_LAUNCH(0)" in rest and not re.search(r"BFM_ATLAS_LAUNCH\([1-9]\)", rest)
-    # the generator's fused gathers (synth_item.hip) read their texels through buffer loads with the sc1 aux bit as well
-    item = open(os.path.join(csrc, "synth_item.hip")).read()
-    for k in ("gather_targets", "gather_onehot"):
-        assert k in item
-    assert re.search(r"ld_tex2\(const float\* base[^)]*\) \{\s*a = ld_tex\(base \+ elem\);", item), \
-        "synth_item.hip's paired gather must be two 4-byte agent-scope loads"
-    assert "raw_buffer_load" not in item and "raw_buffer_load" not in txt.split("template <int MODE>")[0]
-    assert re.search(r"ld_tex\(const float\* p\) \{[^}]*__HIP_MEMORY_SCOPE_AGENT", item)
-    for k in ("__global__ void gather_targets(", "__global__ void __launch_bounds__(256) gather_onehot("):
-        i = item.index(k)
-        b = item[i:item.index("\n}\n", i)]
-        assert "ld_tex" in b, k
