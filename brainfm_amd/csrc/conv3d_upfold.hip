@@ -620,12 +620,14 @@ static int upfold_launch(const float* B, int CB, int S, int d, int h, int w, con
         return bfm_launch_status();
     }
 #endif
-    // Two half-box workgroups per CU (see conv_upfold_body) where the launch has fewer full workgroups than CUs: 7-12 % faster
-    // there (20^3 256 -> 128: 0.136 -> 0.126 ms, 10^3 1024 -> 512: 0.277 -> 0.246, 5^3 2048 -> 1024: 0.175 -> 0.159), 2 % slower
-    // on launches that fill the chip (the matrix pipe is power-limited, not phase-limited: profiles/r06_conv_upfold_pmc.txt).
-    // Same bits either way; BFM_UPFOLD_WAVES = 4 | 8 forces one form (diagnostics).
+    // Two half-box workgroups per CU (see conv_upfold_body) where full workgroups would leave half the CUs idle (<= 128 of
+    // them) or where K is split (short workgroups: staging and epilogue are a large share of each): 7-12 % faster there
+    // (20^3 256 -> 128, 126 workgroups: 0.136 -> 0.126 ms; 10^3 1024 -> 512, split 6: 0.277 -> 0.246; 5^3 2048 -> 1024, split
+    // 22: 0.175 -> 0.159).  Slower where the chip is full and K is long -- 2 % at >= 500 workgroups, 5 % at 250 (in the flow:
+    // decoders.3.1up on the 160 x 80 x 80 tiles 158 -> 167 us): the matrix pipe is power-limited, not phase-limited
+    // (profiles/r06_conv_upfold_pmc.txt).  Same bits either way; BFM_UPFOLD_WAVES = 4 | 8 forces one form (diagnostics).
     static const int waves_env = [] { const char* e = getenv("BFM_UPFOLD_WAVES"); return e ? atoi(e) : 0; }();
-    const int waves = waves_env ? waves_env : ((int64_t)p.nMt * p.NT * nsplit * S < 256 ? 4 : 8);
+    const int waves = waves_env ? waves_env : ((nsplit > 1 || (int64_t)p.nMt * p.NT * S <= 128) ? 4 : 8);
     if (waves == 4) {
         const int64_t nblk = (int64_t)p.nMt * p.NT;
         const int64_t gx = 16 * bfm_cdiv64(nblk, 8);
