@@ -283,6 +283,8 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise BfmError("HIP extension missing: %s (run `python -m brainfm_amd.build`); "
                            "there is no CPU fallback in the product path" % LIB_PATH)
+        import torch  # noqa: F401 -- first: torch ships its own libamdhip64; the extension must bind to THAT runtime (the one
+        #                          whose streams and pointers it is handed), not to a second copy from /opt/rocm
         lib = C.CDLL(LIB_PATH)
         _bind(lib, SIGNATURES)
         _lib = lib
