@@ -31,7 +31,7 @@ from . import models as M
 
 IMAGE_KEYS = ("T1", "T2", "FLAIR", "CT")
 SUPPORTED = set(IMAGE_KEYS) | {k + "_grad" for k in IMAGE_KEYS} | {
-    "SR", "SR_grad", "distance", "registration", "registration_grad", "bias_field_log", "seg_ce", "seg_dice"}
+    "SR", "SR_grad", "distance", "surface", "registration", "registration_grad", "bias_field_log", "seg_ce", "seg_dice"}
 
 
 class LossScaler:
@@ -459,8 +459,10 @@ class TrainStep:
                 else:
                     slot(name)
                     dense.append((k - 1, co, tgt, wt, None, 0.0, 0, coef))
-            elif name in ("distance", "registration", "registration_grad"):
-                head = "registration" if name.startswith("registration") else "distance"
+            elif name in ("distance", "surface", "registration", "registration_grad"):
+                # criterion.py:175-185: loss_image / loss_image_grad of the whole multi-channel map (surface: 8 channels,
+                # Trainer/models/__init__.py:103-106; its head has no processor, so no clamp)
+                head = "registration" if name.startswith("registration") else name
                 if head not in target or head not in self.tail.row_of:
                     continue
                 nch = self.tail.row_of[head][1]

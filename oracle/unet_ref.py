@@ -130,6 +130,8 @@ def default_out_channels(left_hemis_only=False, uncertainty=False, tasks=None):
         oc["distance"] = 2 if left_hemis_only else 4
     if "registration" in tasks:
         oc["registration"] = 3
+    if "surface" in tasks:                        # Trainer/models/__init__.py:103-106
+        oc["surface"] = 8
     if "super_resolution" in tasks:
         oc["high_res_residual"] = r
     if "pathology" in tasks:

@@ -575,3 +575,49 @@ def test_multi_tensor_clip_norms_and_adamw_equal_the_per_tensor_kernels(monkeypa
     assert np.allclose(na[1], nb[1], rtol=1e-5, atol=1e-12)
     for k in pa:
         assert float((pa[k] - pb[k]).abs().max()) <= 1e-6 * max(1.0, float(pb[k].abs().max())), k
+
+
+def test_surface_loss_matches_oracle():
+    """criterion.py:175-176 `loss_surface` (round 6: one of the losses outside brain_id.yaml that used to raise): the L1 of
+    the 8-channel surface head (Trainer/models/__init__.py:103-106, 235-237) against its target, value and d/d(raw) against
+    float64 autograd of the restated criterion, next to the clamped distance loss in the same launch."""
+    from brainfm_amd import test_utils as TU
+    from brainfm_amd import train as TR
+    from oracle import unet_ref as O
+    tasks = dict(T1=True, T2=False, FLAIR=False, CT=False, segmentation=False, distance=True, bias_field=False,
+                 registration=False, super_resolution=False, surface=True, pathology=False, contrastive=False)
+    gi, ti = TU.default_inference_args(f_maps=8, num_levels=2, tasks=tasks, size=(16, 16, 16))
+    oc = O.default_out_channels(tasks=[k for k, v in tasks.items() if v])
+    assert oc.get("surface") == 8
+    sd = O.random_state_dict(1, 8, 2, out_channels=oc, seed=3)
+    s = TU.InferenceSession(gi, ti, _dev(), state_dict=sd, passes=3)
+    tail = s.model.head.tail(s.engine)
+    names = ["T1", "distance", "surface"]
+    weights = {"loss_T1": 1.0, "loss_distance": 0.7, "loss_surface": 1.3}
+    step = TR.TrainStep(s.engine, tail, names, weights, torch.ones(1), all_samples=1, max_surf_distance=3.0)
+    dims = (16, 16, 16)
+    nvox = 16 ** 3
+    g = torch.Generator().manual_seed(8)
+    target = {"T1": torch.rand((1, 1) + dims, generator=g), "distance": torch.randn((1, oc["distance"]) + dims, generator=g) * 2,
+              "surface": torch.randn((1, 8) + dims, generator=g)}
+    raw = torch.randn((nvox, tail.n_out), generator=g) * 1.5
+    raw_d = raw.to(_dev())
+    dRaw = torch.zeros_like(raw_d)
+    vals = torch.zeros(4 * len(names) + 2 * tail.n_out + 8, dtype=torch.float64, device=_dev())
+    slots, _ = step._sample_losses(raw_d, dims, target, {}, dRaw, vals, 1.0)
+    got = step._finish_losses([(slots, vals)], nvox)
+    r64 = raw.double().requires_grad_(True)
+    out = {task: r64[:, r0:r0 + n].t().reshape((1, n) + dims) for task, (r0, n) in tail.row_of.items()}
+    out = T.processors(out, 3.0)
+    ld = T.multi_criterion([out], {k: v.double() for k, v in target.items()}, [{}], names, torch.ones(1).double(), 1)
+    tot = sum(ld[k] * weights[k] for k in ld)
+    tot.backward()
+    assert set(got) == set(ld)
+    for k, v in ld.items():
+        v = float(v.detach())
+        assert abs(got[k] - v) <= 2e-6 * max(abs(v), 1e-3), (k, got[k], v)
+    ref = r64.grad.numpy()
+    err = np.abs(dRaw.cpu().numpy().astype(np.float64) - ref)
+    assert (err > 1e-5 * np.abs(ref).max()).mean() < 1e-4
+    r0, n = tail.row_of["surface"]
+    assert n == 8 and float(np.abs(ref[:, r0:r0 + n]).max()) > 0
