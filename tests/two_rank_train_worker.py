@@ -67,6 +67,28 @@ def worker(rank, world, port, q):
     # ... and the next finite iteration runs again on both
     ld3, tot3, ok3 = step.step([xs[rank]], target, [samples[rank]])
     good = good and bool(ok3)
+    step_state_before4 = {k: (m.clone(), v.clone()) for k, (m, v) in step.state.items()}
+    steps_before4, t_before4 = dict(step.steps), step.t
+    # gradient accumulation over two samples per rank (each rank sees both, in opposite order): the first sample goes the
+    # ordinary way, the LAST one writes into the GradStore, adds the first one's gradients slot by slot and starts the
+    # buckets' all-reduces under its own backward pass; mean over the ranks of (g_a + g_b) == g_0 + g_1, i.e. what ONE process
+    # computes for both samples
+    before4 = {k: v.clone() for k, v in step.parameters().items()}
+    order = [rank, 1 - rank]
+    ld4, tot4, ok4 = step.step([xs[i] for i in order], target, [samples[i] for i in order])
+    good = good and bool(ok4)
+    if rank == 0:
+        ref2, xs3, target3, samples3 = build(c, dev)
+        for k, v in ref2.parameters().items():
+            v.copy_(before4[k])
+        ref2._weights_changed()
+        ref2.state = {k: (m.clone(), v.clone()) for k, (m, v) in step_state_before4.items()} if step_state_before4 else {}
+        ref2.steps, ref2.t = dict(steps_before4), t_before4
+        _, _, gr = ref2.loss_and_grads([xs3[0], xs3[1]], target3, [samples3[0], samples3[1]])
+        ref2.apply(gr)
+        worst = max(float((v - step.parameters()[k]).abs().max()) for k, v in ref2.parameters().items())
+        print("two samples per rank: max |param difference| %.3e (lr %.1e)" % (worst, c["lr"]), flush=True)
+        good = good and worst <= 2e-2 * c["lr"]
     after = {k: v.clone() for k, v in step.parameters().items()}
     flags = [None] * world
     dist.all_gather_object(flags, bool(good))
