@@ -165,6 +165,8 @@ SIGNATURES = {
     "bfm_loss_grad_l1_multi": (_I, [_P, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _Z, _P]),
     "bfm_loss_grad_l1": (_I, [_P, _I, _I, _P, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P]),
     "bfm_loss_seg": (_I, [_P, _I, _I, _I, _P, _P, _P, _L, _F, _F, _P, _P, _P, _P, _Z, _P]),
+    "bfm_loss_pathol_workspace": (_Z, []),
+    "bfm_loss_pathol": (_I, [_P, _L, _L, _P, _L, _F, _F, _P, _P, _P, _P, _Z, _P]),
     "bfm_head_bwd_workspace": (_Z, [_I, _I, _L]),
     "bfm_head_bwd": (_I, [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _Z, _P]),
     "bfm_tail_raw_rows": (_I, [_P, _L, C.POINTER(TailDesc), _P, _P, _L, _P]),

@@ -934,6 +934,71 @@ __global__ void __launch_bounds__(256) seg_bwd_rows_kernel(const float* __restri
     }
 }
 
+// ----------------------------------------------------------------------------- pathology head (round 6)
+// criterion.py:193-212 loss_pathol_ce / loss_pathol_dice on p = sigmoid(raw) (PatholProcessor, joiner.py:79-87), one channel:
+//   ce = mean_v( -log(max(p, 1e-5)) * t ),   dice = 1 - 2 sum(p t) / max(sum(p + t), 1e-5)
+// The head output of voxel v is raw[col_off + v * vstride] (channels-last: col_off = column, vstride = n_out; rows: col_off =
+// column * row stride, vstride = 1).  part: [3][RB] block partials (fp64) of { -log(max(p,1e-5)) t, p t, p + t }.
+__global__ void __launch_bounds__(256) pathol_fwd_kernel(const float* __restrict__ raw, int64_t col_off, int64_t vstride,
+                                                         const float* __restrict__ target, int64_t nvox,
+                                                         double* __restrict__ part) {
+    __shared__ double red[256];
+    double a = 0.0, b = 0.0, c = 0.0;
+    GRID_STRIDE(v, nvox) {
+        const float x = raw[col_off + v * vstride];
+        const float p = 1.0f / (1.0f + expf(-x));
+        const float t = target[v];
+        a += (double)(-logf(fmaxf(p, 1e-5f)) * t);
+        b += (double)(p * t);
+        c += (double)(p + t);
+    }
+    a = block_sum(a, red);
+    b = block_sum(b, red);
+    c = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = a;
+        part[RB + blockIdx.x] = b;
+        part[2 * RB + blockIdx.x] = c;
+    }
+}
+
+// sums[0..2] = the three totals; loss_out[0] = ce, loss_out[1] = dice
+__global__ void pathol_fold_kernel(const double* __restrict__ part, int nb, double inv_nvox, double* __restrict__ sums,
+                                   double* __restrict__ loss_ce, double* __restrict__ loss_dice) {
+    __shared__ double red[256];
+    double t[3];
+    for (int k = 0; k < 3; ++k) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < nb; i += 256) s += part[k * RB + i];
+        t[k] = block_sum(s, red);
+    }
+    if (threadIdx.x == 0) {
+        sums[0] = t[0]; sums[1] = t[1]; sums[2] = t[2];
+        if (loss_ce) loss_ce[0] = t[0] * inv_nvox;
+        if (loss_dice) loss_dice[0] = 1.0 - 2.0 * t[1] / fmax(t[2], 1e-5);
+    }
+}
+
+__global__ void __launch_bounds__(256) pathol_bwd_kernel(const float* __restrict__ raw, int64_t col_off, int64_t vstride,
+                                                         const float* __restrict__ target, int64_t nvox,
+                                                         const double* __restrict__ sums, float coef_ce, float coef_dice,
+                                                         float* __restrict__ dRaw) {
+    const double num = sums[1], den = sums[2];
+    const bool clamped = den < 1e-5;                       // torch.clamp(min=1e-5): no gradient through the denominator then
+    const double dc = clamped ? 1e-5 : den;
+    const float g_t = (float)(-2.0 / dc);                  // d dice / d p = -2 t / dc + 2 num / dc^2 (the latter only unclamped)
+    const float g_1 = clamped ? 0.f : (float)(2.0 * num / (dc * dc));
+    GRID_STRIDE(v, nvox) {
+        const int64_t o = col_off + v * vstride;
+        const float x = raw[o];
+        const float p = 1.0f / (1.0f + expf(-x));
+        const float t = target[v];
+        float g = coef_dice * (g_t * t + g_1);
+        if (p > 1e-5f) g += coef_ce * (-t / p);            // clamp(p, min=1e-5): zero gradient where it clamps
+        dRaw[o] += g * p * (1.0f - p);
+    }
+}
+
 }  // namespace
 
 extern "C" size_t bfm_loss_workspace(int ns) { return (size_t)RB * (1 + 2 * (ns > 0 ? ns : 0)) * sizeof(double) + 4096; }
@@ -1385,5 +1450,27 @@ extern "C" int bfm_adamw_step_multi(const bfm_adam_tensor_t* tensors, int ntenso
     if (!tensors || !chunk_tensor || ntensors <= 0 || nchunks <= 0 || chunk_elems <= 0 || (chunk_elems & 3)) return BFM_E_ARG;
     hipLaunchKernelGGL(adamw_multi_kernel, dim3(nchunks), dim3(256), 0, bfm_s(stream), tensors, chunk_tensor, chunk_elems, lr, beta1,
                        beta2, eps, weight_decay);
+    return bfm_launch_status();
+}
+
+
+extern "C" size_t bfm_loss_pathol_workspace(void) { return (size_t)(3 * RB + 8) * sizeof(double); }
+
+extern "C" int bfm_loss_pathol(const float* raw, int64_t col_offset, int64_t voxel_stride, const float* target, int64_t nvox,
+                               float coef_ce, float coef_dice, float* dRaw, double* loss_ce, double* loss_dice,
+                               void* workspace, size_t workspace_bytes, bfm_stream_t stream) {
+    if (!raw || !target || !workspace || nvox <= 0 || col_offset < 0 || voxel_stride <= 0 || (!loss_ce && !loss_dice))
+        return BFM_E_ARG;
+    if (workspace_bytes < bfm_loss_pathol_workspace()) return BFM_E_WORKSPACE;
+    if (reinterpret_cast<uintptr_t>(workspace) & 7) return BFM_E_ARG;
+    double* part = static_cast<double*>(workspace);
+    double* sums = part + 3 * RB;
+    const int nb = grid_for(nvox, RB);
+    hipStream_t st = bfm_s(stream);
+    hipLaunchKernelGGL(pathol_fwd_kernel, dim3(nb), dim3(256), 0, st, raw, col_offset, voxel_stride, target, nvox, part);
+    hipLaunchKernelGGL(pathol_fold_kernel, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)nvox, sums, loss_ce, loss_dice);
+    if (dRaw)
+        hipLaunchKernelGGL(pathol_bwd_kernel, dim3(grid_for(nvox)), dim3(256), 0, st, raw, col_offset, voxel_stride, target, nvox,
+                           sums, loss_ce ? coef_ce / (float)nvox : 0.f, loss_dice ? coef_dice : 0.f, dRaw);
     return bfm_launch_status();
 }

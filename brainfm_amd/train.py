@@ -31,7 +31,8 @@ from . import models as M
 
 IMAGE_KEYS = ("T1", "T2", "FLAIR", "CT")
 SUPPORTED = set(IMAGE_KEYS) | {k + "_grad" for k in IMAGE_KEYS} | {
-    "SR", "SR_grad", "distance", "surface", "registration", "registration_grad", "bias_field_log", "seg_ce", "seg_dice"}
+    "SR", "SR_grad", "distance", "surface", "registration", "registration_grad", "bias_field_log", "seg_ce", "seg_dice",
+    "pathol_ce", "pathol_dice"}
 
 
 class LossScaler:
@@ -421,6 +422,7 @@ class TrainStep:
         grads_l1 = []                                     # (slot index, col, target, weight, coef): the gradient-L1 entries, one launch
         keep = []                                         # tensors the deferred launch reads
         active = set()                                    # head rows some loss of this sample differentiates
+        pathol_done = False
 
         def slot(name, n=1):
             nonlocal k
@@ -479,6 +481,28 @@ class TrainStep:
                         clampv = self.max_dist if head == "distance" else 0.0
                         slot(name)
                         dense.append((k - 1, co, tgt[j], None, None, clampv, 0, coef / nch))
+            elif name in ("pathol_ce", "pathol_dice"):
+                # criterion.py:193-212 on sigmoid(raw) (PatholProcessor): both names of a sample in ONE bfm_loss_pathol call,
+                # issued when the first of them comes up
+                if pathol_done:
+                    continue
+                pathol_done = True
+                if "pathology" not in target or "pathology" not in self.tail.row_of:
+                    continue                                          # shape mismatch / no head -> 0, as the reference
+                tgt = self._t(target["pathology"], dims).reshape(-1)
+                if tgt.numel() != nvox:
+                    continue
+                co = self._col("pathology")
+                active.add(co)
+                cf = {n_: scale * self.loss_weights.get("loss_" + n_, 0.0) / self.all_samples
+                      for n_ in ("pathol_ce", "pathol_dice") if n_ in self.loss_names}
+                p_ce = slot("pathol_ce") if "pathol_ce" in cf else None
+                p_di = slot("pathol_dice") if "pathol_dice" in cf else None
+                wsp = torch.empty(lib.bfm_loss_pathol_workspace(), dtype=torch.uint8, device=self.dev)
+                keep.extend([tgt, wsp])
+                L.check(lib.bfm_loss_pathol(L.ptr(raw), co * raw.stride(0) if rows else co, 1 if rows else n_out, L.ptr(tgt),
+                                            nvox, cf.get("pathol_ce", 0.0), cf.get("pathol_dice", 0.0), L.ptr(dRaw), p_ce, p_di,
+                                            L.ptr(wsp), wsp.numel(), st), "loss_pathol")
             elif name == "bias_field_log":
                 if "bias_field_log" not in sample or "bias_field_log" not in self.tail.row_of:
                     continue

@@ -792,6 +792,15 @@ int bfm_loss_grad_l1_multi(const float* raw, int n_out, int n, const int32_t* co
 int bfm_loss_seg(const float* raw, int n_out, int c0, int ns, const float* target, const float* wce, const float* wdice,
                  int64_t nvox, float coef_ce, float coef_dice, float* P, float* dRaw, double* loss_out /*[1+2ns]*/,
                  void* workspace, size_t workspace_bytes, bfm_stream_t stream);
+/* Trainer/models/criterion.py:193-212 loss_pathol_ce / loss_pathol_dice on p = sigmoid(raw) (PatholProcessor,
+ * Trainer/models/joiner.py:79-87), the one-channel pathology head: ce = mean_v(-log(max(p, 1e-5)) t), dice = 1 - 2 sum(p t) /
+ * max(sum(p + t), 1e-5).  The head output of voxel v is raw[col_offset + v * voxel_stride] (channels-last: column, n_out;
+ * rows: column * row_stride, 1); dRaw (same addressing, may be NULL) += coef_ce d ce + coef_dice d dice; loss_ce / loss_dice
+ * (device fp64; either may be NULL: that loss and its gradient are left out).  Fixed-order fp64 reductions. */
+size_t bfm_loss_pathol_workspace(void);
+int bfm_loss_pathol(const float* raw, int64_t col_offset, int64_t voxel_stride, const float* target, int64_t nvox,
+                    float coef_ce, float coef_dice, float* dRaw, double* loss_ce, double* loss_dice, void* workspace,
+                    size_t workspace_bytes, bfm_stream_t stream);
 /* dW [n_out][C], db [n_out], dFn [nvox][C] from dRaw [nvox][n_out] and the normalised features Fn [nvox][C] */
 size_t bfm_head_bwd_workspace(int n_out, int C, int64_t nvox);
 int bfm_head_bwd(const float* dRaw, const float* Fn, const float* head_w, int n_out, int C, int64_t nvox, float* dW,

@@ -43,6 +43,8 @@ def processors(out, max_surf_distance=3.0):
         out["segmentation"] = torch.softmax(out["segmentation"], dim=1)
     if "distance" in out:
         out["distance"] = torch.clamp(out["distance"], -max_surf_distance, max_surf_distance)
+    if "pathology" in out:                                        # PatholProcessor, Trainer/models/joiner.py:79-87
+        out["pathology"] = torch.sigmoid(out["pathology"])
     return out
 
 
@@ -68,6 +70,12 @@ def sample_losses(out, target, sample, loss_names, weights_ce, bias_l2=True):
             m = 1.0 - target["segmentation"][:, 0]
             a, b = out["bias_field_log"] * m, sample["bias_field_log"] * m
             v = torch.mean((a - b) ** 2) if bias_l2 else torch.mean((a - b).abs())
+        elif name == "pathol_ce":                                 # criterion.py:193-201
+            p, t = out["pathology"], target["pathology"]
+            v = torch.mean(-torch.sum(torch.log(torch.clamp(p, min=1e-5)) * t, dim=1))
+        elif name == "pathol_dice":                               # criterion.py:203-212
+            p, t = out["pathology"], target["pathology"]
+            v = torch.sum(1.0 - 2.0 * (p * t).sum(dim=[2, 3, 4]) / torch.clamp((p + t).sum(dim=[2, 3, 4]), min=1e-5))
         elif name == "seg_ce":
             p, t = out["segmentation"], target["segmentation"]
             v = torch.mean(-torch.sum(torch.log(torch.clamp(p, min=1e-5)) * wce * t, dim=1))

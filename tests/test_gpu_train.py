@@ -621,3 +621,55 @@ def test_surface_loss_matches_oracle():
     assert (err > 1e-5 * np.abs(ref).max()).mean() < 1e-4
     r0, n = tail.row_of["surface"]
     assert n == 8 and float(np.abs(ref[:, r0:r0 + n]).max()) > 0
+
+
+@pytest.mark.parametrize("rows", [False, True])
+def test_pathology_losses_match_oracle(rows):
+    """criterion.py:193-212 `loss_pathol_ce` / `loss_pathol_dice` on the sigmoid of the one-channel pathology head
+    (PatholProcessor, joiner.py:79-87; round 6: bfm_loss_pathol): values and d/d(raw) against float64 autograd of the
+    restated criterion, for the channels-last and the rows layout of the head outputs, with a target that is mostly zero
+    (a lesion) so that the Dice denominator is small but not clamped."""
+    from brainfm_amd import test_utils as TU
+    from brainfm_amd import train as TR
+    from oracle import unet_ref as O
+    tasks = dict(T1=True, T2=False, FLAIR=False, CT=False, segmentation=False, distance=False, bias_field=False,
+                 registration=False, super_resolution=False, surface=False, pathology=True, contrastive=False)
+    gi, ti = TU.default_inference_args(f_maps=8, num_levels=2, tasks=tasks, size=(16, 16, 16))
+    oc = O.default_out_channels(tasks=[k for k, v in tasks.items() if v])
+    sd = O.random_state_dict(1, 8, 2, out_channels=oc, seed=4)
+    s = TU.InferenceSession(gi, ti, _dev(), state_dict=sd, passes=3)
+    tail = s.model.head.tail(s.engine)
+    names = ["T1", "pathol_ce", "pathol_dice"]
+    weights = {"loss_T1": 1.0, "loss_pathol_ce": 0.8, "loss_pathol_dice": 1.7}
+    step = TR.TrainStep(s.engine, tail, names, weights, torch.ones(1), all_samples=2)
+    dims = (16, 16, 16)
+    nvox = 16 ** 3
+    g = torch.Generator().manual_seed(9)
+    lesion = (torch.rand((1, 1) + dims, generator=g) > 0.9).float()
+    target = {"T1": torch.rand((1, 1) + dims, generator=g), "pathology": lesion}
+    raw = torch.randn((nvox, tail.n_out), generator=g) * 2.0
+    raw[:7, tail.row_of["pathology"][0]] = -20.0                       # p < 1e-5: the clamp of the cross entropy
+    lesion.reshape(-1)[:7] = 1.0
+    raw_d = (raw.t().contiguous() if rows else raw).to(_dev())
+    dRaw = torch.zeros_like(raw_d)
+    vals = torch.zeros(4 * len(names) + 2 * tail.n_out + 8, dtype=torch.float64, device=_dev())
+    slots, _ = step._sample_losses(raw_d, dims, target, {}, dRaw, vals, 1.0, rows=rows)
+    got = step._finish_losses([(slots, vals)], nvox)
+    r64 = raw.double().requires_grad_(True)
+    out = {task: r64[:, r0:r0 + n].t().reshape((1, n) + dims) for task, (r0, n) in tail.row_of.items()}
+    out = T.processors(out, 3.0)
+    ld = T.multi_criterion([out], {k: v.double() for k, v in target.items()}, [{}], names, torch.ones(1).double(), 2)
+    tot = sum(ld[k] * weights[k] for k in ld)
+    tot.backward()
+    assert list(got) == ["loss_" + n for n in names]
+    for k, v in ld.items():
+        v = float(v.detach())
+        assert abs(got[k] - v) <= 5e-6 * max(abs(v), 1e-3), (k, got[k], v)
+    ref = r64.grad.numpy()
+    have = dRaw.cpu().numpy().astype(np.float64)
+    if rows:
+        have = have.T
+    err = np.abs(have - ref)
+    assert (err > 2e-5 * np.abs(ref).max()).mean() < 1e-4, (err.max(), np.abs(ref).max())
+    c = tail.row_of["pathology"][0]
+    assert np.abs(ref[:, c]).max() > 0 and np.abs(have[:7, c]).max() < 1e-6 * np.abs(ref[:, c]).max() + 1e-12
