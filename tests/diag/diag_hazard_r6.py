@@ -104,6 +104,31 @@ def conv_beside():
 conv_beside(); torch.cuda.synchronize()
 ref_conv = cout_t.clone()
 
+# BFM_DIAG_AGGR=<mode>: replace the library's convolution by the stand-alone aggressor of tests/diag/hazard_aggressor.hip
+# (mode bits: 1 global loads into VGPRs, 2 LDS operand reads, 4 MFMAs; 7 = the whole tap loop)
+aggr_mode = int(os.environ.get("BFM_DIAG_AGGR", "0"))
+if aggr_mode:
+    hipA = hip_runtime()
+    modA = C.c_void_p(); fnA = C.c_void_p()
+    dataA = open(os.path.join(ROOT, "tests", "diag", "hazard_variants", "aggr.hsaco"), "rb").read()
+    bufA = C.create_string_buffer(dataA, len(dataA))
+    assert hipA.hipModuleLoadData(C.byref(modA), bufA) == 0
+    assert hipA.hipModuleGetFunction(C.byref(fnA), modA, b"hazard_aggressor") == 0
+    assert hipA.hipFuncSetAttribute(fnA, 8, 80 * 1024) in (0, 1) or True      # hipFuncAttributeMaxDynamicSharedMemorySize
+    nfragA = 64 * 1024
+    wA = torch.full((nfragA * 1024 // 4,), 1.0009765625, dtype=torch.float32, device=DEV)
+    sinkA = torch.zeros(1, device=DEV)
+    stepsA = int(os.environ.get("BFM_DIAG_AGGR_STEPS", "400"))
+
+    def conv_beside():
+        vals = [C.c_void_p(wA.data_ptr()), C.c_int(nfragA), C.c_int(stepsA), C.c_int(aggr_mode), C.c_void_p(sinkA.data_ptr())]
+        params = (C.c_void_p * len(vals))(*[C.cast(C.pointer(v), C.c_void_p) for v in vals])
+        for _ in range(6):
+            rc = hipA.hipModuleLaunchKernel(fnA, 1024, 1, 1, 256, 1, 1, 76800, C.c_void_p(torch.cuda.current_stream().cuda_stream), params, None)
+            assert rc == 0, rc
+    conv_beside(); torch.cuda.synchronize()
+    ref_conv = cout_t.clone()
+
 # corner terms of the golden pull (bound zero, extrapolate no): want[i] = sum_c term[i, c]
 volh, gridh = d2["vol"], d2["grid"]
 Bn, Cn, nx, ny, nz = volh.shape

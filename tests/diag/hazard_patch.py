@@ -22,7 +22,12 @@ NOP = "\ts_nop 7\n\ts_nop 7\n"
 
 def device_asm(extra=()):
     s = os.path.join(OUT, "synth_interp.s")
-    cmd = [B.HIPCC] + [f for f in B.FLAGS if f != "-Wall"] + list(extra) + ["-S", "--cuda-device-only",
+    # the variants bisect the FAILING build: the library's flags of rounds 1-5, i.e. WITH packed-FP32 instructions ("nopk" adds
+    # the switch back)
+    flags = list(B.FLAGS)
+    i = flags.index(B.NO_PACKED_FP32[0])
+    del flags[i:i + len(B.NO_PACKED_FP32)]
+    cmd = [B.HIPCC] + [f for f in flags if f != "-Wall"] + list(extra) + ["-S", "--cuda-device-only",
            os.path.join(B.CSRC, "synth_interp.hip"), "-o", s]
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
     return open(s).read()
@@ -95,6 +100,11 @@ def main():
             ins.append("\tv_lshl_add_u64 v[76:77], v[76:77], 0, v[78:79]")
     dump = "\n".join(lines[:st + 1] + ins + lines[st + 1:])
     variants["dump"] = dump
+    # "aggr": the stand-alone aggressor (tests/diag/hazard_aggressor.hip) as a code object of its own
+    src = os.path.join(ROOT, "tests", "diag", "hazard_aggressor.hip")
+    subprocess.check_call([B.HIPCC, "-O3", "--offload-arch=gfx950", "--cuda-device-only", "-c", src, "-o", os.path.join(OUT, "aggr.hsaco")],
+                          stderr=subprocess.DEVNULL)
+    print("aggr: hazard_aggressor code object")
     # "nopk": the same source compiled with the packed-FP32 instructions switched off (no v_pk_*_f32 anywhere)
     nopk = device_asm(["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"])
     assert not re.search(r"v_pk_\w+_f32", nopk)
