@@ -17,7 +17,7 @@
 //              bit for bit with a quiet run of the same kernel.
 //
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o scripts/micro/pk_f32_mfma_hazard scripts/micro/pk_f32_mfma_hazard.hip
-//   ./scripts/micro/pk_f32_mfma_hazard [rounds]                # packed build: wrong rounds > 0 beside every aggressor with MFMAs
+//   ./scripts/micro/pk_f32_mfma_hazard [rounds [mask|nomask [fix [lines]]]]   # packed build: wrong rounds > 0 beside every aggressor with MFMAs
 //   hipcc ... -Xclang -target-feature -Xclang -packed-fp32-ops ...   # the same source without packed FP32: 0 wrong rounds
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -86,9 +86,11 @@ __device__ __forceinline__ int bound_sign(int i, int n, int b) {
     }
 }
 
+template <int FIX>
 __global__ void grid_pull3d(const float* __restrict__ inp, int Bi, int C, int nx, int ny, int nz,
                             const float* __restrict__ grid, int Bg, int64_t nout, int bx, int by, int bz, int extrap,
                             int B, float* __restrict__ out) {
+    if (FIX) { bx = by = bz = 0; extrap = 0; }            // variant: the 2 000 instructions of the bound switch compile away
     const int64_t n = (int64_t)B * nout;
     GRID_STRIDE(i, n) {
         const int b = (int)(i / nout);
@@ -223,8 +225,10 @@ int main(int argc, char** argv) {
     hipStream_t s[3];
     for (int i = 0; i < 3; ++i) CK((hipError_t)make_stream(&s[i], masked));
     const int nb = (int)((Bn * nout + 255) / 256);
+    const int fix = argc > 3 ? atoi(argv[3]) : 0;
     auto pull = [&](hipStream_t st, float* g, float* o) {
-        hipLaunchKernelGGL(grid_pull3d, dim3(nb), dim3(256), 0, st, vol, Bn, Cn, nx, ny, nz, g, Bn, nout, 0, 0, 0, 0, Bn, o);
+        if (fix) hipLaunchKernelGGL(grid_pull3d<1>, dim3(nb), dim3(256), 0, st, vol, Bn, Cn, nx, ny, nz, g, Bn, nout, 0, 0, 0, 0, Bn, o);
+        else hipLaunchKernelGGL(grid_pull3d<0>, dim3(nb), dim3(256), 0, st, vol, Bn, Cn, nx, ny, nz, g, Bn, nout, 0, 0, 0, 0, Bn, o);
     };
     pull(s[0], grid[0], ref);                                      // the quiet run: the reference bits
     CK(hipDeviceSynchronize());
@@ -234,9 +238,11 @@ int main(int argc, char** argv) {
            "# %s; %d rounds per line; a wrong round = at least one output element differs from the quiet run\n",
            nb, masked ? "all three streams on the same half of the CUs" : "no CU masks", rounds);
     const int modes[6] = {-1, 7, 4, 5, 6, 3};
+    const int nmodes = argc > 4 ? atoi(argv[4]) : 6;              // 3: none, the full tap loop, the MFMA chain alone
     const char* mname[8] = {"", "", "", "loads + LDS reads, NO MFMA", "MFMA chain only", "MFMA + global loads -> VGPR", "MFMA + LDS operand reads",
                             "MFMA + global loads + LDS reads"};
-    for (int mi = 0; mi < 6; ++mi) {
+    printf("# victim variant: %s\n", fix ? "bounds fixed at compile time (zero bound, no extrapolation)" : "as in the library (run-time bounds)");
+    for (int mi = 0; mi < nmodes; ++mi) {
         const int mode = modes[mi];
         long wrong_rounds = 0, wrong_el = 0, lanes_hi = 0, lanes_lo = 0;
         for (int r = 0; r < rounds; ++r) {
