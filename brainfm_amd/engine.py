@@ -937,6 +937,10 @@ class UNetEngine:
     deep_from = int(os.environ.get("BFM_DEEP_FROM", "3"))
     deep_batch = os.environ.get("BFM_DEEP_BATCH", "1") != "0"
     DEEP_VERS = (0, 2)                                     # conv_mfma, conv_mfma16: the variants that take a batch
+    # round 6: single-source layers of the batched levels may also run conv_wino4d on the batch (bfm_conv3x3x3_wino4_batch:
+    # per sample the bits of bfm_conv3x3x3_wino4) where the committed tune table says so -- the level-2 layers of the
+    # 160 x 80 x 80-class tiles were 250-workgroup launches at half the kernel's rate, four of them per shape
+    DEEP_VERS_1SRC = (0, 2, 4)
     deep_upfold = os.environ.get("BFM_DEEP_UPFOLD", "1") != "0"          # fold exact 2x upsamples inside the region too
     deep_upfold_min = int(os.environ.get("BFM_DEEP_UPFOLD_MIN", "100"))  # fewest low-res voxels per sample worth it
     # The tile loop multiplies every output of a tile by (tile input != 0) (scripts/demo_test.py:88-100): the last
@@ -949,9 +953,10 @@ class UNetEngine:
     uniform_skip = os.environ.get("BFM_UNIFORM_SKIP", "1") != "0"
 
     # A small tile's level deep_from - 1 is small too (80^3: 20^3 voxels of 256 channels -- launches of 60-100 us that
-    # fill a fifth of the chip): the region starts one level higher for tiles whose level there has at most this many
-    # voxels.  A function of the tile shape alone, like everything that decides which kernels a tile runs.
-    deep_vox = int(os.environ.get("BFM_DEEP_VOX", "8000"))
+    # fill a fifth of the chip; round 6: the 160 x 80 x 80 class too, 40 x 20 x 20 = 16 000 voxels, 250 workgroups per
+    # launch): the region starts one level higher for tiles whose level there has at most this many voxels.  A function
+    # of the tile shape alone, like everything that decides which kernels a tile runs.
+    deep_vox = int(os.environ.get("BFM_DEEP_VOX", "16000"))
 
     def _region_ok(self, df):
         cache = self.__dict__.setdefault("_deep_ok", {})
@@ -1020,10 +1025,11 @@ class UNetEngine:
                 and lo_dims[0] * lo_dims[1] * lo_dims[2] >= self.deep_upfold_min):
             return self._batch_conv_upfold(ly, A, dims, B, lo_dims, scale, shift, bound)
         key = (ly.cin, ly.cout, tuple(dims), B is not None, False, 1)       # trailing 1: a layer of the batched levels
+        vers = self.DEEP_VERS if B is not None else self.DEEP_VERS_1SRC
         if key not in self._plan_cache:
             cfg = (C.c_int * 8)()
             L.check(self.lib.bfm_conv3x3x3_mfma_plan(ly.cin, ly.cout, D, H, W, cfg), "mfma_plan")
-            if cfg[6] not in self.DEEP_VERS:
+            if cfg[6] not in vers:
                 cfg[6] = 0
             self._plan_cache[key] = cfg
         cfg = self._plan_cache[key]
@@ -1032,6 +1038,12 @@ class UNetEngine:
 
         def _launch(c, rows=None, A_=A, B_=B, S_=S, out_=out, sc=scale, sh=shift, bd=bound):
             self._pack(ly, True, c[6])
+            if c[6] == 4:
+                L.check(self.lib.bfm_conv3x3x3_wino4_batch(L.ptr(A_), ca, S_, D, H, W, L.ptr(sc), L.ptr(sh), L.ptr(bd), ly.groups,
+                                                           L.ptr(ly.wpacked), ly.wexp, ly.cout, self.slope, self.passes, 0,
+                                                           L.ptr(out_), L.ptr(rows[0]) if rows is not None else None, 0, st),
+                        "conv_wino4_batch " + ly.name)
+                return
             wsb = self.lib.bfm_conv3x3x3_mfma_batch_workspace(ly.cin, ly.cout, S_, D, H, W, c[5])
             ws = self._workspace(wsb)
             L.check(self.lib.bfm_conv3x3x3_mfma_batch(L.ptr(A_), ca, L.ptr(B_) if cb else None, cb, S_, D, H, W,
@@ -1043,11 +1055,12 @@ class UNetEngine:
         if key not in self._tuned:
             # timed on ONE sample (the choice must not depend on the batch size: a tile's bits may not either)
             cfg = self._autotune(ly, key, lambda c: _launch(c, None, A[0:1], B[0:1] if B is not None else None, 1, out[0:1],
-                                                            scale[0:1], shift[0:1], bound[0:1]), vers=self.DEEP_VERS)
+                                                            scale[0:1], shift[0:1], bound[0:1]), vers=vers)
         self._pack(ly, True, cfg[6])
         rows = None
         if self.fuse_stats:
-            n = self.lib.bfm_conv3x3x3_mfma_rows(ly.cin, ly.cout, D, H, W, cfg)
+            n = (self.lib.bfm_conv3x3x3_wino4_rows(D, H, W, self.passes) if cfg[6] == 4 else
+                 self.lib.bfm_conv3x3x3_mfma_rows(ly.cin, ly.cout, D, H, W, cfg))
             if n > 0:
                 rows = (torch.empty(self.lib.bfm_moment_rows_bytes(S * n, ly.cout), dtype=torch.uint8, device=self.device), n)
         ev = None
@@ -1093,7 +1106,7 @@ class UNetEngine:
         if key not in self._plan_cache:
             cfg = (C.c_int * 8)()
             L.check(self.lib.bfm_conv3x3x3_mfma_plan(ca, ly.cout, D, H, W, cfg), "mfma_plan")
-            if cfg[6] not in self.DEEP_VERS:
+            if cfg[6] not in self.DEEP_VERS_1SRC:
                 cfg[6] = 0
             cfg[7] = 1
             self._plan_cache[key] = cfg
@@ -1101,6 +1114,12 @@ class UNetEngine:
 
         def _launch_skip(c, rows=None, A_=A, S_=S, out_=out, sc=sc_a, sh=sh_a, bd=bound):
             self._pack(sk, True, c[6])
+            if c[6] == 4:                                      # conv_wino4d on the batch, accumulating onto the up-folded half
+                L.check(self.lib.bfm_conv3x3x3_wino4_batch(L.ptr(A_), ca, S_, D, H, W, L.ptr(sc), L.ptr(sh), L.ptr(bd), ly.groups,
+                                                           L.ptr(sk.wpacked), sk.wexp, ly.cout, self.slope, self.passes, 1,
+                                                           L.ptr(out_), L.ptr(rows[0]) if rows is not None else None, aff, st),
+                        "conv_wino4_batch " + sk.name)
+                return
             ws = self._workspace(self.lib.bfm_conv3x3x3_mfma_batch_workspace(ca, ly.cout, S_, D, H, W, c[5]))
             L.check(self.lib.bfm_conv3x3x3_mfma_batch(L.ptr(A_), ca, None, 0, S_, D, H, W, None, L.ptr(sc), L.ptr(sh),
                                                       L.ptr(bd), ly.groups, L.ptr(sk.wpacked), sk.wexp, ly.cout,
@@ -1109,7 +1128,7 @@ class UNetEngine:
                     "conv_mfma_batch " + sk.name)
         if key not in self._tuned:                              # on one sample; trials accumulate onto garbage
             cfg = self._autotune(sk, key, lambda c: _launch_skip(c, None, A[0:1], 1, out[0:1], sc_a[0:1], sh_a[0:1],
-                                                                 bound[0:1]), vers=self.DEEP_VERS)
+                                                                 bound[0:1]), vers=self.DEEP_VERS_1SRC)
         self._pack(sk, True, cfg[6])
         nv = D * H * W
         lo = lo_dims[0] * lo_dims[1] * lo_dims[2]
@@ -1134,7 +1153,8 @@ class UNetEngine:
             ev[0].record()
         rows = None
         if self.fuse_stats:
-            n = self.lib.bfm_conv3x3x3_mfma_rows(ca, ly.cout, D, H, W, cfg)
+            n = (self.lib.bfm_conv3x3x3_wino4_rows(D, H, W, self.passes) if cfg[6] == 4 else
+                 self.lib.bfm_conv3x3x3_mfma_rows(ca, ly.cout, D, H, W, cfg))
             if n > 0:
                 rows = (torch.empty(self.lib.bfm_moment_rows_bytes(S * n, ly.cout), dtype=torch.uint8, device=self.device), n)
         for _ in range(reps):
