@@ -454,6 +454,58 @@ def _gradstore_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _gradstore_worker8(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from brainfm_amd import train as TR
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    # the slot list of a 3-level, 8-wide net as TrainStep.grad_store() lays it out: heads, decoders last to first, encoders
+    named = [("head.weight_all", (12, 8)), ("head.bias_all", (12,))]
+    for name, cin, cout in (("dec1.2", 8, 8), ("dec1.1", 24, 8), ("dec0.2", 16, 16), ("dec0.1", 48, 16), ("enc2.2", 16, 32), ("enc2.1", 16, 16),
+                            ("enc1.2", 8, 16), ("enc1.1", 8, 8), ("enc0.2", 4, 8), ("enc0.1", 1, 4)):
+        named += [(name + ".conv.weight", (cout, cin, 3, 3, 3)), (name + ".groupnorm.weight", (cin,)), (name + ".groupnorm.bias", (cin,))]
+    st = TR.GradStore(named, "cpu", n_buckets=6)
+    st.begin()
+    g = torch.Generator().manual_seed(7 + rank)
+    sink = TR._Sink(st, None, {})
+    order = []
+    for n, shp in named:
+        sink.out(n, shp).copy_(torch.randn(*shp, generator=g))
+        sink.done(n)
+        order.append(sum(st.launched))
+    st.finish()
+    if rank == 0:
+        q.put(({n: v.clone().numpy() for n, v in st.views.items()}, [n for n, _ in named], [list(s_) for _, s_ in named],
+               len(st.range), order, st.world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_store_eight_ranks_six_buckets():
+    """The training side of SCALE's N = 8: eight gloo ranks, the slot list of a whole (small) backbone in
+    backward order, six buckets going out one after the other while later slots are still being written; every slot ends up
+    holding the sum of the eight ranks' gradients."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gradstore_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res, names, shapes, nb, order, world = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert world == 8 and nb == 6 and order == sorted(order) and order[-1] == 6 and order[0] == 0
+    exp = {}
+    for rank in range(8):
+        g = torch.Generator().manual_seed(7 + rank)
+        for n, shp in zip(names, shapes):
+            exp[n] = exp.get(n, 0) + torch.randn(*shp, generator=g)
+    for n in names:
+        assert np.allclose(res[n], exp[n].numpy(), atol=2e-6), n
+
+
 def test_grad_store_buckets_sum_over_two_ranks_in_place():
     """VERDICT r5 #2 / #5b: train.GradStore -- one persistent flat buffer, slots in backward order, a few buckets, each
     all-reduced as soon as its last slot is complete (async, while later slots are still being written), no concatenation and
