@@ -28,7 +28,7 @@ import torch  # noqa: E402
 
 CONV_KERNELS = ["conv_wino", "conv_wino4", "conv_wino_masked", "conv_wino_uniform", "conv_upfold", "conv_mfma", "conv_mfma_ws", "conv_mfma16"]
 _VER_NAME = {0: "conv_mfma", 1: "conv_mfma_ws", 2: "conv_mfma16", 3: "conv_wino", 4: "conv_wino4"}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_conv_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_conv_hbm_traffic.json")
 # One body, several launch forms: the Winograd kernel in full, over the boxes the tile mask keeps, and as the rest / uniform
 # pair.  The roofline's top level reports the GROUP with the largest share of the conv time (round 2 picked by kernel
 # name, which put conv_upfold on top while half the time ran in the four names of the Winograd body).
