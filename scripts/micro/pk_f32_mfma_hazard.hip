@@ -91,6 +91,9 @@ __global__ void grid_pull3d(const float* __restrict__ inp, int Bi, int C, int nx
                             const float* __restrict__ grid, int Bg, int64_t nout, int bx, int by, int bz, int extrap,
                             int B, float* __restrict__ out) {
     if (FIX) { bx = by = bz = 0; extrap = 0; }            // variant: the 2 000 instructions of the bound switch compile away
+#ifdef VICTIM_VGPRS_128
+    asm volatile("v_mov_b32 v127, 0" ::: "v127");          // mapping experiment: the victim wave is allocated 128 registers
+#endif
     const int64_t n = (int64_t)B * nout;
     GRID_STRIDE(i, n) {
         const int b = (int)(i / nout);
@@ -141,7 +144,13 @@ __global__ void grid_pull3d(const float* __restrict__ inp, int Bi, int C, int nx
 // ------------------------------------------------------------------ the aggressor
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
-constexpr int BALLAST = 6;
+#ifndef BALLAST_N
+#define BALLAST_N 6
+#endif
+#ifndef LDS_BYTES
+#define LDS_BYTES 76800
+#endif
+constexpr int BALLAST = BALLAST_N;        // -DBALLAST_N=0: ~120 VGPRs instead of ~215 (mapping experiments, profiles/r06_hazard_root_cause.txt item 13)
 
 __global__ void __launch_bounds__(256, 2) aggressor(const uint4* __restrict__ w, int nfrag, int steps, int mode,
                                                     float* __restrict__ sink) {
@@ -249,7 +258,7 @@ int main(int argc, char** argv) {
             for (int l = 0; l < 2; ++l) CK(hipMemsetAsync(out[l], 0xff, Bn * Cn * nout * 4, 0));
             CK(hipDeviceSynchronize());
             if (mode >= 0)
-                for (int k = 0; k < 6; ++k) hipLaunchKernelGGL(aggressor, dim3(1024), dim3(256), 76800, s[2], w, nfrag, 400, mode, sink);
+                for (int k = 0; k < 6; ++k) hipLaunchKernelGGL(aggressor, dim3(1024), dim3(256), LDS_BYTES, s[2], w, nfrag, 400, mode, sink);
             for (int l = 0; l < 2; ++l) pull(s[l], grid[l], out[l]);
             CK(hipDeviceSynchronize());
             bool bad = false;
